@@ -1,0 +1,95 @@
+"""Programmatic builders for the model/data configs this path is measured on.
+
+The MODEL section produced by ``gdmae_ssl_model_cfg()`` equals the ``MODEL`` section of the
+reference's ``tools/cfgs/{waymo,kitti,once}_models/gd_mae_ssl.yaml`` (lines 46-175; the three
+files share it) - asserted by ``tests/golden/make_golden.py`` in the build container.  The named
+configs A/B/E are the BASELINE.json workloads as made concrete in SURVEY.md §8(d).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from pcdet.config import AttrDict
+
+
+def _drop_info():
+    lv = {'0': {'max_tokens': 16, 'drop_range': [0, 16]},
+          '1': {'max_tokens': 32, 'drop_range': [16, 32]},
+          '2': {'max_tokens': 64, 'drop_range': [32, 100000]}}
+    return {'train': lv, 'test': {k: dict(v) for k, v in lv.items()}}
+
+
+def _sst_block(name, stride, d_model, ff, num_blocks=2, nhead=8):
+    return {
+        'NAME': name,
+        'PREPROCESS': {'WINDOW_SHAPE': [8, 8, 1], 'DROP_INFO': _drop_info(), 'SHUFFLE_VOXELS': False,
+                       'POS_TEMPERATURE': 1000, 'NORMALIZE_POS': False},
+        'ENCODER': {'NUM_BLOCKS': num_blocks, 'STRIDE': stride, 'D_MODEL': d_model, 'NHEAD': nhead,
+                    'DIM_FEEDFORWARD': ff, 'DROPOUT': 0.0, 'ACTIVATION': 'gelu',
+                    'LAYER_CFG': {'cosine': True, 'tau_min': 0.01}},
+    }
+
+
+def gdmae_ssl_model_cfg(mask_ratio=0.85, d_models=(128, 256, 256), ffs=(256, 512, 512), num_blocks=2,
+                        vfe_mlps=(64, 128), eval_metric='waymo_custom'):
+    strides = [1, 2, 2][:len(d_models)]
+    names = ['sst_block_x1', 'sst_block_x2', 'sst_block_x4'][:len(d_models)]
+    blocks = [_sst_block(n, s, d, f, num_blocks) for n, s, d, f in zip(names, strides, d_models, ffs)]
+    srcs = ['x_conv1', 'x_conv2', 'x_conv3'][:len(d_models)]
+    fuse = {src: {'UPSAMPLE_STRIDE': int(np.prod(strides[:i + 1])), 'NUM_FILTER': d_models[i], 'NUM_UPSAMPLE_FILTER': 128}
+            for i, src in enumerate(srcs)}
+    return AttrDict({
+        'NAME': 'GDMAE',
+        'VFE': {'NAME': 'DynVFE', 'TYPE': 'mean', 'WITH_DISTANCE': False, 'USE_ABSLOTE_XYZ': True,
+                'USE_CLUSTER_XYZ': True, 'MLPS': [list(vfe_mlps)]},
+        'BACKBONE_3D': {'NAME': 'SPTBackboneMAE', 'SST_BLOCK_LIST': blocks,
+                        'MASK_CONFIG': {'RATIO': mask_ratio, 'NUM_PRD_POINTS': 16, 'NUM_GT_POINTS': 64},
+                        'FEATURES_SOURCE': srcs, 'FUSE_LAYER': fuse},
+        'POST_PROCESSING': {'RECALL_THRESH_LIST': [0.3, 0.5, 0.7], 'EVAL_METRIC': eval_metric},
+    })
+
+
+def optimization_cfg(batch_size_per_gpu=8, num_epochs=30):
+    """OPTIMIZATION section of the ssl yamls (gd_mae_ssl.yaml:183-203)."""
+    return AttrDict({'BATCH_SIZE_PER_GPU': batch_size_per_gpu, 'NUM_EPOCHS': num_epochs, 'OPTIMIZER': 'adam_onecycle',
+                     'LR': 0.003, 'WEIGHT_DECAY': 0.01, 'MOMENTUM': 0.9, 'MOMS': [0.95, 0.85], 'PCT_START': 0.4,
+                     'DIV_FACTOR': 10, 'DECAY_STEP_LIST': [35, 45], 'LR_DECAY': 0.1, 'LR_CLIP': 0.0000001,
+                     'LR_WARMUP': False, 'WARMUP_EPOCH': 1, 'GRAD_NORM_CLIP': 10})
+
+
+class SyntheticDatasetInfo:
+    """The attributes ``Detector3DTemplate.build_networks`` reads from the dataset object
+    (detector3d_template.py:45-53; dataset.py:27-41; data_processor.py:166-171)."""
+
+    def __init__(self, point_cloud_range, voxel_size, num_point_features, class_names):
+        self.class_names = list(class_names)
+        self.point_cloud_range = np.array(point_cloud_range, dtype=np.float32)
+        self.voxel_size = list(voxel_size)
+        grid = (self.point_cloud_range[3:6] - self.point_cloud_range[0:3]) / np.array(voxel_size)
+        self.grid_size = np.round(grid).astype(np.int64)
+        self.point_feature_encoder = AttrDict({'num_point_features': num_point_features})
+
+
+WAYMO = dict(point_cloud_range=[-74.88, -74.88, -2, 74.88, 74.88, 4.0], voxel_size=[0.32, 0.32, 6.0],
+             num_point_features=5, class_names=['Vehicle', 'Pedestrian', 'Cyclist'])
+KITTI = dict(point_cloud_range=[0, -39.68, -3, 69.12, 39.68, 1], voxel_size=[0.32, 0.32, 4],
+             num_point_features=4, class_names=['Car', 'Pedestrian', 'Cyclist'])
+ONCE = dict(point_cloud_range=[-74.88, -74.88, -5.0, 74.88, 74.88, 3.0], voxel_size=[0.32, 0.32, 8.0],
+            num_point_features=4, class_names=['Car', 'Bus', 'Truck', 'Pedestrian', 'Cyclist'])
+
+
+def named_config(name: str, mask_ratio=None):
+    """BASELINE.json configs: 'A' CPU plumbing, 'B' Waymo-shape, 'E' ONCE-shape stress.
+    Returns (model_cfg, dataset_info, synth kwargs)."""
+    if name == 'A':
+        m = gdmae_ssl_model_cfg(0.5 if mask_ratio is None else mask_ratio, d_models=(128,), ffs=(256,), num_blocks=1,
+                                eval_metric='kitti')
+        return m, SyntheticDatasetInfo(**KITTI), dict(beams=32, azimuths=600, extra=800, features=4)
+    if name == 'B':
+        m = gdmae_ssl_model_cfg(0.75 if mask_ratio is None else mask_ratio)
+        return m, SyntheticDatasetInfo(**WAYMO), dict(beams=64, azimuths=2650, extra=10400, features=5)
+    if name == 'E':
+        m = gdmae_ssl_model_cfg(0.75 if mask_ratio is None else mask_ratio, d_models=(256, 256, 256), ffs=(512, 512, 512),
+                                num_blocks=1, vfe_mlps=(64, 256), eval_metric='once')
+        return m, SyntheticDatasetInfo(**ONCE), dict(beams=40, azimuths=1400, extra=4000, features=4)
+    raise KeyError(name)

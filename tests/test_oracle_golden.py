@@ -1,0 +1,59 @@
+"""CPU: the oracle restatement vs the golden vectors captured from the unmodified reference
+(tests/golden/make_golden.py).  Integer outputs bit-exact; floats to fp32 round-off."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import assert_sampled_close, load_case
+from oracle import gdmae_oracle as orc
+
+
+@pytest.mark.parametrize("name", ["kitti_b2", "kitti_b2_m75", "waymo_b1"])
+def test_oracle_forward_backward_matches_reference_golden(name):
+    z, ds, cfg, shapes = load_case(name)
+    sd = orc.seeded_state_dict(shapes, seed=int(z["seed"]), requires_grad=True)
+    pts = torch.from_numpy(z["points"])
+    o = orc.forward(pts, int(z["batch_size"]), cfg, sd, ds.point_cloud_range, ds.voxel_size, ds.grid_size,
+                    noise=torch.from_numpy(z["noise"]))
+    assert o["points"].shape[0] == int(z["keep_count"])
+    assert np.array_equal(o["voxel_coords"].numpy(), z["voxel_coords"])
+    assert np.array_equal(o["point_inverse_indices"].numpy(), z["inverse"])
+    assert np.array_equal(o["voxel_mae_mask"].numpy().astype(np.uint8), z["mask"])
+    assert np.array_equal(o["gt_group_inds"].numpy(), z["gt_group_inds"])
+    for i, tr in enumerate(o["stage_trace"]):
+        assert np.array_equal(tr["coords"][:, [0, 2, 3]].numpy(), z[f"st{i}_indices"])
+        for s in range(2):
+            p = tr["parts"][s]
+            assert np.array_equal(p["win_id"].numpy(), z[f"st{i}_win_id{s}"])
+            assert np.array_equal(p["level"].numpy(), z[f"st{i}_level{s}"])
+            assert np.array_equal(p["slot"].numpy(), z[f"st{i}_slot{s}"])
+        assert_sampled_close(tr["features"], z[f"st{i}_features_s"], z[f"st{i}_features_c"], 2e-4, f"stage{i}")
+    for nm in ("pillar_features", "spatial_features", "pred_points", "gt_points"):
+        assert_sampled_close(o[nm], z[nm + "_s"], z[nm + "_c"], 2e-4, nm)
+    assert abs(float(o["loss"]) - float(z["loss"])) / float(z["loss"]) < 1e-5
+    o["loss"].backward()
+    names = sorted(shapes)
+    gn = np.array([float(sd[k].grad.double().norm()) for k in names])
+    rel = np.abs(gn - z["grad_norm"]) / (z["grad_norm"] + 1e-12)
+    tol = np.array([5e-2 if k.endswith("tau") else 1e-2 for k in names])
+    assert (rel <= tol).all(), [(names[i], rel[i]) for i in np.flatnonzero(rel > tol)]
+
+
+def test_mask_tie_break_is_stable_ascending_index():
+    noise = torch.tensor([0.5, 0.2, 0.2, 0.9, 0.2, 0.1])
+    m = orc.random_masking(6, 0.5, noise)          # keep 3 smallest: 0.1, then ties 0.2 by index -> idx 1, 2
+    assert m.tolist() == [1, 0, 0, 1, 1, 0]
+    assert int(6 * (1 - 0.85)) == 0 and int(20 * (1 - 0.85)) == 3   # python-double len_keep (0.15000000000000002)
+
+
+def test_empty_and_single_point_inputs():
+    cfgrid = [10, 10, 1]
+    keep, coords = orc.point_coords(torch.zeros(0, 5), [0, 0, 0, 10, 10, 1], [1, 1, 1], cfgrid)
+    vc, inv, rank, cnt = orc.unique_pillars(coords, cfgrid)
+    assert vc.shape == (0, 4) and inv.numel() == 0
+    pts = torch.tensor([[0, 3.5, 2.5, 0.5, 1.0], [0, 3.6, 2.4, 0.1, 1.0], [0, -0.5, 2.4, 0.1, 1.0]])
+    keep, coords = orc.point_coords(pts, [0, 0, 0, 10, 10, 1], [1, 1, 1], cfgrid)
+    # x = -0.5 truncates toward zero to index 0 and is KEPT (common_utils.py:74 uses .to(int64), not floor)
+    assert keep.tolist() == [True, True, True]
+    vc, inv, rank, cnt = orc.unique_pillars(coords, cfgrid)
+    assert vc.tolist() == [[0, 0, 2, 0], [0, 0, 2, 3]] and inv.tolist() == [1, 1, 0] and rank.tolist() == [0, 1, 0]
