@@ -1,0 +1,409 @@
+// Windowed cosine multi-head attention (forward + backward) over variable-length token groups, reading
+// the window CSR directly - the padded (nW, T, d) tensors, key-padding masks and the flat2window /
+// window2flat copies of the reference are never materialised.
+//
+// Replaces:
+//   flat2window_v2 / window2flat_v2        reference pcdet/models/model_utils/sst_utils.py:107-180
+//   WindowAttention.forward                pcdet/models/model_utils/sst_basic_block.py:22-54
+//   _scaled_cosine_attention               pcdet/models/model_utils/cosine_msa.py:114-176
+//     q^ = q/max(|q|,1e-12), k^ likewise (F.normalize), A = q^ k^T / clamp(tau, tau_min),
+//     -inf on padded keys, softmax, P V.  (in/out projections stay token-wise GEMMs outside.)
+//
+// MI355X mapping.  A window holds n <= 64 tokens (8x8 BEV cells) and a head is 16 or 32 wide, so one
+// (window, head) problem is at most 64x64x32 - far too small to amortise MFMA fragment shuffles, and
+// the kernel is bound by fetching each token's q/k/v rows once from HBM/L2 (< 1 GFLOP per
+// frame).  The layout is therefore "one lane = one query row": a 64-lane wavefront covers the T=64
+// occupancy level exactly, and packs 2 (T=32) or 4 (T=16) heads of a window for the sparser levels so
+// no lane idles on padding rows that the reference computes and discards.  K^ and V of the wave's
+// heads are staged once in LDS (rows padded to DH+4 floats: conflict-free 16-byte stores, broadcast
+// reads), scores/softmax/PV are lane-local register loops - no cross-lane reduction anywhere.  The
+// backward runs two lane-local phases (lane = query for dQ, then lane = key for dK/dV) re-using the
+// same two LDS tiles, so there are no atomics and gradients are deterministic; d(tau) is reduced
+// per wave and summed in a fixed order by a second tiny kernel.
+#include "common.h"
+
+#define ATT_EPS 1e-12f
+
+template <int DH>
+__device__ inline void load_row(const float* __restrict__ p, float (&r)[DH]) {
+#pragma unroll
+  for (int c = 0; c < DH; c += 4) {
+    float4 v = *reinterpret_cast<const float4*>(p + c);
+    r[c] = v.x;
+    r[c + 1] = v.y;
+    r[c + 2] = v.z;
+    r[c + 3] = v.w;
+  }
+}
+template <int DH>
+__device__ inline void store_row(float* __restrict__ p, const float (&r)[DH]) {
+#pragma unroll
+  for (int c = 0; c < DH; c += 4) *reinterpret_cast<float4*>(p + c) = make_float4(r[c], r[c + 1], r[c + 2], r[c + 3]);
+}
+template <int DH>
+__device__ inline float dot_lds(const float (&a)[DH], const float* __restrict__ l) {
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < DH; c += 4) {
+    float4 v = *reinterpret_cast<const float4*>(l + c);
+    s = fmaf(a[c], v.x, s);
+    s = fmaf(a[c + 1], v.y, s);
+    s = fmaf(a[c + 2], v.z, s);
+    s = fmaf(a[c + 3], v.w, s);
+  }
+  return s;
+}
+template <int DH>
+__device__ inline float normalize(float (&r)[DH], float& inv_norm) {
+  float ss = 0.f;
+#pragma unroll
+  for (int c = 0; c < DH; ++c) ss = fmaf(r[c], r[c], ss);
+  float n = sqrtf(ss);
+  inv_norm = 1.f / fmaxf(n, ATT_EPS);
+#pragma unroll
+  for (int c = 0; c < DH; ++c) r[c] *= inv_norm;
+  return n;
+}
+
+struct AttnArgs {
+  const float* qk;   // (Ms, 2d): q in [0,d), k in [d,2d)
+  const float* v;    // (Ms, d)
+  float* out;        // (Ms, d)
+  const int* csr_tok;
+  const int* win_start;
+  const int* win_len;
+  int n_win;
+  int d;             // model dim = H * DH
+  int H;
+  const float* tau;
+  float tau_min;
+};
+
+template <int T, int DH>
+__global__ __launch_bounds__(256) void k_win_attn_fwd(AttnArgs A) {
+  constexpr int G = GD_WAVE / T;          // heads per wavefront
+  constexpr int LD = DH + 4;              // padded LDS row
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = threadIdx.x & (GD_WAVE - 1);
+  const int wib = threadIdx.x / GD_WAVE;
+  float* sK = smem + wib * (2 * GD_WAVE * LD);
+  float* sV = sK + GD_WAVE * LD;
+  const int groups = A.H / G;
+  const long long item = (long long)blockIdx.x * 4 + wib;
+  if (item >= (long long)A.n_win * groups) return;
+  const int w = (int)(item / groups);
+  const int hg = (int)(item % groups);
+  const int sub = lane / T, r = lane % T;
+  const int h = hg * G + sub;
+  const int n = A.win_len[w];
+  const int start = A.win_start[w];
+  const bool act = r < n;
+  const int t = act ? A.csr_tok[start + r] : 0;
+  const float inv_tau = 1.f / fmaxf(*A.tau, A.tau_min);
+
+  float q[DH], tmp[DH];
+  float dummy;
+  if (act) {
+    load_row<DH>(A.qk + (long long)t * 2 * A.d + h * DH, q);
+    normalize<DH>(q, dummy);
+    load_row<DH>(A.qk + (long long)t * 2 * A.d + A.d + h * DH, tmp);
+    normalize<DH>(tmp, dummy);
+    store_row<DH>(sK + lane * LD, tmp);
+    load_row<DH>(A.v + (long long)t * A.d + h * DH, tmp);
+    store_row<DH>(sV + lane * LD, tmp);
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (!act) return;
+  const float* kb = sK + sub * T * LD;
+  const float* vb = sV + sub * T * LD;
+  float s[T];
+  float m = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < T; ++j) {
+    float a = -INFINITY;
+    if (j < n) a = dot_lds<DH>(q, kb + j * LD) * inv_tau;
+    s[j] = a;
+    m = fmaxf(m, a);
+  }
+  float l = 0.f;
+#pragma unroll
+  for (int j = 0; j < T; ++j) {
+    float p = (j < n) ? expf(s[j] - m) : 0.f;
+    s[j] = p;
+    l += p;
+  }
+  float o[DH];
+#pragma unroll
+  for (int c = 0; c < DH; ++c) o[c] = 0.f;
+#pragma unroll
+  for (int j = 0; j < T; ++j) {
+    if (j < n) {
+      const float p = s[j];
+#pragma unroll
+      for (int c = 0; c < DH; c += 4) {
+        float4 vv = *reinterpret_cast<const float4*>(vb + j * LD + c);
+        o[c] = fmaf(p, vv.x, o[c]);
+        o[c + 1] = fmaf(p, vv.y, o[c + 1]);
+        o[c + 2] = fmaf(p, vv.z, o[c + 2]);
+        o[c + 3] = fmaf(p, vv.w, o[c + 3]);
+      }
+    }
+  }
+  const float il = 1.f / l;
+#pragma unroll
+  for (int c = 0; c < DH; ++c) o[c] *= il;
+  store_row<DH>(A.out + (long long)t * A.d + h * DH, o);
+}
+
+struct AttnBwdArgs {
+  const float* qk;
+  const float* v;
+  const float* dout;  // (Ms, d)
+  float* dqk;         // (Ms, 2d)
+  float* dv;          // (Ms, d)
+  float* dtau_part;   // one partial per wavefront item
+  const int* csr_tok;
+  const int* win_start;
+  const int* win_len;
+  int n_win;
+  int d;
+  int H;
+  const float* tau;
+  float tau_min;
+};
+
+template <int T, int DH>
+__global__ __launch_bounds__(256) void k_win_attn_bwd(AttnBwdArgs A) {
+  constexpr int G = GD_WAVE / T;
+  constexpr int LD = DH + 4;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = threadIdx.x & (GD_WAVE - 1);
+  const int wib = threadIdx.x / GD_WAVE;
+  float* s0 = smem + wib * (2 * GD_WAVE * LD + 2 * GD_WAVE);
+  float* s1 = s0 + GD_WAVE * LD;
+  float* sLse = s1 + GD_WAVE * LD;
+  float* sD = sLse + GD_WAVE;
+  const int groups = A.H / G;
+  const long long item = (long long)blockIdx.x * 4 + wib;
+  if (item >= (long long)A.n_win * groups) return;
+  const int w = (int)(item / groups);
+  const int hg = (int)(item % groups);
+  const int sub = lane / T, r = lane % T;
+  const int h = hg * G + sub;
+  const int n = A.win_len[w];
+  const int start = A.win_start[w];
+  const bool act = r < n;
+  const int t = act ? A.csr_tok[start + r] : 0;
+  const float tau_c = fmaxf(*A.tau, A.tau_min);
+  const float inv_tau = 1.f / tau_c;
+
+  float q[DH], dO[DH];
+  float qin = 0.f, kin = 0.f;  // 1 / max(|q|, eps)
+  if (act) {
+    float tmp[DH];
+    load_row<DH>(A.qk + (long long)t * 2 * A.d + A.d + h * DH, tmp);
+    normalize<DH>(tmp, kin);
+    store_row<DH>(s0 + lane * LD, tmp);  // K^
+    load_row<DH>(A.v + (long long)t * A.d + h * DH, tmp);
+    store_row<DH>(s1 + lane * LD, tmp);  // V
+    load_row<DH>(A.qk + (long long)t * 2 * A.d + h * DH, q);
+    normalize<DH>(q, qin);
+    load_row<DH>(A.dout + (long long)t * A.d + h * DH, dO);
+  }
+  __builtin_amdgcn_wave_barrier();
+  float dtau = 0.f;
+  const float* b0 = s0 + sub * T * LD;
+  const float* b1 = s1 + sub * T * LD;
+  // ---- phase A: lane = query row i
+  if (act) {
+    float s[T];
+    float m = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < T; ++j) {
+      float a = -INFINITY;
+      if (j < n) a = dot_lds<DH>(q, b0 + j * LD) * inv_tau;
+      s[j] = a;
+      m = fmaxf(m, a);
+    }
+    // s[j] <- e_j = exp(a_ij - m); l = sum e_j; D = sum p_j (dO_i . V_j)
+    float l = 0.f, D = 0.f;
+#pragma unroll
+    for (int j = 0; j < T; ++j) {
+      if (j < n) {
+        const float e = expf(s[j] - m);
+        l += e;
+        D = fmaf(e, dot_lds<DH>(dO, b1 + j * LD), D);
+        s[j] = e;
+      }
+    }
+    const float il = 1.f / l;
+    D *= il;
+    float dq[DH];
+#pragma unroll
+    for (int c = 0; c < DH; ++c) dq[c] = 0.f;
+#pragma unroll
+    for (int j = 0; j < T; ++j) {
+      if (j < n) {
+        const float p = s[j] * il;
+        const float dS = p * (dot_lds<DH>(dO, b1 + j * LD) - D);
+        const float a = (s[j] > 0.f) ? logf(s[j]) + m : 0.f;  // a_ij recovered from e_j (p = 0 contributes 0)
+        dtau = fmaf(-dS, a * inv_tau, dtau);       // d a_ij / d tau_c = -a_ij / tau_c
+        const float g = dS * inv_tau;
+#pragma unroll
+        for (int c = 0; c < DH; c += 4) {
+          float4 kk = *reinterpret_cast<const float4*>(b0 + j * LD + c);
+          dq[c] = fmaf(g, kk.x, dq[c]);
+          dq[c + 1] = fmaf(g, kk.y, dq[c + 1]);
+          dq[c + 2] = fmaf(g, kk.z, dq[c + 2]);
+          dq[c + 3] = fmaf(g, kk.w, dq[c + 3]);
+        }
+      }
+    }
+    // through q^ = q / max(|q|, eps):  dq = (dq^ - q^ (q^ . dq^)) / max(|q|, eps)
+    float pr = 0.f;
+#pragma unroll
+    for (int c = 0; c < DH; ++c) pr = fmaf(q[c], dq[c], pr);
+#pragma unroll
+    for (int c = 0; c < DH; ++c) dq[c] = (dq[c] - q[c] * pr) * qin;
+    store_row<DH>(A.dqk + (long long)t * 2 * A.d + h * DH, dq);
+    sLse[lane] = m + logf(l);
+    sD[lane] = D;
+  }
+  __builtin_amdgcn_wave_barrier();
+  // ---- phase B: lane = key row j; tiles now hold Q^ and dO
+  float k[DH], vv[DH];
+  if (act) {
+    load_row<DH>(s0 + lane * LD, k);
+    load_row<DH>(s1 + lane * LD, vv);
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (act) {
+    store_row<DH>(s0 + lane * LD, q);
+    store_row<DH>(s1 + lane * LD, dO);
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (act) {
+    float dk[DH], dvv[DH];
+#pragma unroll
+    for (int c = 0; c < DH; ++c) {
+      dk[c] = 0.f;
+      dvv[c] = 0.f;
+    }
+    const float* lse = sLse + sub * T;
+    const float* Dr = sD + sub * T;
+    for (int i = 0; i < n; ++i) {
+      const float a = dot_lds<DH>(k, b0 + i * LD) * inv_tau;
+      const float p = expf(a - lse[i]);
+      const float g = dot_lds<DH>(vv, b1 + i * LD);
+      const float dS = p * (g - Dr[i]) * inv_tau;
+#pragma unroll
+      for (int c = 0; c < DH; c += 4) {
+        float4 qq = *reinterpret_cast<const float4*>(b0 + i * LD + c);
+        float4 dd = *reinterpret_cast<const float4*>(b1 + i * LD + c);
+        dk[c] = fmaf(dS, qq.x, dk[c]);
+        dk[c + 1] = fmaf(dS, qq.y, dk[c + 1]);
+        dk[c + 2] = fmaf(dS, qq.z, dk[c + 2]);
+        dk[c + 3] = fmaf(dS, qq.w, dk[c + 3]);
+        dvv[c] = fmaf(p, dd.x, dvv[c]);
+        dvv[c + 1] = fmaf(p, dd.y, dvv[c + 1]);
+        dvv[c + 2] = fmaf(p, dd.z, dvv[c + 2]);
+        dvv[c + 3] = fmaf(p, dd.w, dvv[c + 3]);
+      }
+    }
+    float pr = 0.f;
+#pragma unroll
+    for (int c = 0; c < DH; ++c) pr = fmaf(k[c], dk[c], pr);
+#pragma unroll
+    for (int c = 0; c < DH; ++c) dk[c] = (dk[c] - k[c] * pr) * kin;
+    store_row<DH>(A.dqk + (long long)t * 2 * A.d + A.d + h * DH, dk);
+    store_row<DH>(A.dv + (long long)t * A.d + h * DH, dvv);
+  }
+  dtau = gd_wave_sum(dtau);
+  if (lane == 0) A.dtau_part[item] = dtau;
+}
+
+// deterministic sum of `n` partials into out[0] (single workgroup, fixed association order)
+__global__ __launch_bounds__(1024) void k_sum_partials(const float* __restrict__ part, long long n, float scale,
+                                                       float* __restrict__ out, int accumulate) {
+  __shared__ float sh[1024 / GD_WAVE];
+  float acc = 0.f;
+  for (long long i = threadIdx.x; i < n; i += 1024) acc += part[i];
+  acc = gd_wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x / 64] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int i = 0; i < 1024 / GD_WAVE; ++i) s += sh[i];
+    s *= scale;
+    out[0] = accumulate ? out[0] + s : s;
+  }
+}
+
+extern "C" int gdmae_sum_partials(const float* part, long long n, float scale, float* out, int accumulate, void* stream) {
+  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, (hipStream_t)stream, part, n, scale, out, accumulate);
+  GD_LAUNCH_CHECK();
+  return 0;
+}
+
+template <int T, int DH>
+static int launch_fwd(const AttnArgs& A, hipStream_t st) {
+  constexpr int G = GD_WAVE / T;
+  const long long items = (long long)A.n_win * (A.H / G);
+  const size_t lds = 4 * (2 * GD_WAVE * (DH + 4)) * sizeof(float);
+  hipLaunchKernelGGL((k_win_attn_fwd<T, DH>), dim3(gd_div_up(items, 4)), dim3(256), lds, st, A);
+  GD_LAUNCH_CHECK();
+  return 0;
+}
+template <int T, int DH>
+static int launch_bwd(const AttnBwdArgs& A, hipStream_t st) {
+  constexpr int G = GD_WAVE / T;
+  const long long items = (long long)A.n_win * (A.H / G);
+  const size_t lds = 4 * (2 * GD_WAVE * (DH + 4) + 2 * GD_WAVE) * sizeof(float);
+  hipLaunchKernelGGL((k_win_attn_bwd<T, DH>), dim3(gd_div_up(items, 4)), dim3(256), lds, st, A);
+  GD_LAUNCH_CHECK();
+  return 0;
+}
+
+// One occupancy level: windows [0, n_win) of (win_start, win_len); T = padded tokens of the level.
+extern "C" int gdmae_window_attention_fwd(const float* qk, const float* v, float* out, const int* csr_tok,
+                                          const int* win_start, const int* win_len, int n_win, int T, int d, int H,
+                                          const float* tau, float tau_min, void* stream) {
+  if (n_win <= 0) return 0;
+  GD_REQUIRE(d % H == 0, "d % H");
+  const int DH = d / H;
+  GD_REQUIRE(DH == 16 || DH == 32, "head dim must be 16 or 32");
+  GD_REQUIRE(T == 16 || T == 32 || T == 64, "T must be 16/32/64");
+  GD_REQUIRE(H % (GD_WAVE / T) == 0, "heads must pack evenly into a wavefront");
+  AttnArgs A{qk, v, out, csr_tok, win_start, win_len, n_win, d, H, tau, tau_min};
+  hipStream_t st = (hipStream_t)stream;
+  if (DH == 16) {
+    if (T == 16) return launch_fwd<16, 16>(A, st);
+    if (T == 32) return launch_fwd<32, 16>(A, st);
+    return launch_fwd<64, 16>(A, st);
+  }
+  if (T == 16) return launch_fwd<16, 32>(A, st);
+  if (T == 32) return launch_fwd<32, 32>(A, st);
+  return launch_fwd<64, 32>(A, st);
+}
+
+// dtau_part must hold n_win * H / (64 / T) floats.
+extern "C" int gdmae_window_attention_bwd(const float* qk, const float* v, const float* dout, float* dqk, float* dv,
+                                          float* dtau_part, const int* csr_tok, const int* win_start, const int* win_len,
+                                          int n_win, int T, int d, int H, const float* tau, float tau_min, void* stream) {
+  if (n_win <= 0) return 0;
+  GD_REQUIRE(d % H == 0, "d % H");
+  const int DH = d / H;
+  GD_REQUIRE(DH == 16 || DH == 32, "head dim must be 16 or 32");
+  GD_REQUIRE(T == 16 || T == 32 || T == 64, "T must be 16/32/64");
+  GD_REQUIRE(H % (GD_WAVE / T) == 0, "heads must pack evenly into a wavefront");
+  AttnBwdArgs A{qk, v, dout, dqk, dv, dtau_part, csr_tok, win_start, win_len, n_win, d, H, tau, tau_min};
+  hipStream_t st = (hipStream_t)stream;
+  if (DH == 16) {
+    if (T == 16) return launch_bwd<16, 16>(A, st);
+    if (T == 32) return launch_bwd<32, 16>(A, st);
+    return launch_bwd<64, 16>(A, st);
+  }
+  if (T == 16) return launch_bwd<16, 32>(A, st);
+  if (T == 32) return launch_bwd<32, 32>(A, st);
+  return launch_bwd<64, 32>(A, st);
+}

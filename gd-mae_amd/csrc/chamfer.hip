@@ -1,0 +1,153 @@
+// Reconstruction targets and the masked Chamfer loss (forward + gradient w.r.t. the prediction).
+//
+// Replaces:
+//   group_inner_inds_kernel + repeat_group_idx_kernel   reference pcdet/ops/sst_ops/src/sst_ops_gpu.cu:22-39
+//     (atomic arrival order there; here the first min(cnt,K) points by ascending index, then cyclic pad)
+//   points[group_inds] gather, get_voxel_centers, gt - centre
+//                                                        pcdet/ops/sst_ops/sst_ops_utils.py:15-27,
+//                                                        pcdet/utils/common_utils.py:130-145,
+//                                                        pcdet/models/backbones_3d/spt_backbone_mae.py:64-69
+//   pytorch3d.loss.chamfer_distance(pred, gt, weights=mask)   spt_backbone_mae.py:88 (knn_points K=1 x2)
+//
+// MI355X mapping: NUM_GT_POINTS = 64 = one wavefront: lane j owns ground-truth point j of a pillar, the
+// 16 predicted points are broadcast from LDS, the 16x64 distance tile lives in registers; row minima are
+// wave reductions, column minima are lane-local.  Pillars with weight 0 (visible pillars) are skipped.
+// The scalar loss is assembled from per-pillar partials in a fixed order (deterministic).
+#include "common.h"
+
+struct GtParams {
+  float lo[3], vs[3];
+  int ncols;
+  int K;
+};
+
+__global__ __launch_bounds__(256) void k_group_gt(const float* __restrict__ pts, const int* __restrict__ pt_off,
+                                                  const int* __restrict__ csr, const long long* __restrict__ voxel_coords,
+                                                  int M, GtParams P, float* __restrict__ gt, int* __restrict__ gidx) {
+  const int lane = threadIdx.x & (GD_WAVE - 1);
+  const int wib = threadIdx.x / GD_WAVE;
+  for (int p = blockIdx.x * 4 + wib; p < M; p += gridDim.x * 4) {
+    const int off = pt_off[p];
+    const int cnt = pt_off[p + 1] - off;
+    const long long* vc = voxel_coords + 4ll * p;  // b, z, y, x
+    // centre = (idx + 0.5) * vs + lo per axis, reference op order
+    const float cx = __fadd_rn(__fmul_rn(__fadd_rn((float)vc[3], 0.5f), P.vs[0]), P.lo[0]);
+    const float cy = __fadd_rn(__fmul_rn(__fadd_rn((float)vc[2], 0.5f), P.vs[1]), P.lo[1]);
+    const float cz = __fadd_rn(__fmul_rn(__fadd_rn((float)vc[1], 0.5f), P.vs[2]), P.lo[2]);
+    for (int k = lane; k < P.K; k += GD_WAVE) {
+      const int src = k < cnt ? k : k % cnt;
+      const int pid = csr[off + src];
+      const float* r = pts + (long long)pid * P.ncols;
+      float* o = gt + ((long long)p * P.K + k) * 3;
+      o[0] = __fsub_rn(r[1], cx);
+      o[1] = __fsub_rn(r[2], cy);
+      o[2] = __fsub_rn(r[3], cz);
+      if (gidx) gidx[(long long)p * P.K + k] = pid;
+    }
+  }
+}
+
+extern "C" int gdmae_group_gt_points(const float* points, int n_cols, const int* pillar_pt_off, const int* pillar_pts,
+                                     const long long* voxel_coords, int M, int K, const float* lo, const float* vs,
+                                     float* gt_points, int* gt_index, void* stream) {
+  if (M <= 0) return 0;
+  GtParams P;
+  for (int i = 0; i < 3; ++i) {
+    P.lo[i] = lo[i];
+    P.vs[i] = vs[i];
+  }
+  P.ncols = n_cols;
+  P.K = K;
+  int grid = gd_div_up(M, 4);
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(k_group_gt, dim3(grid), dim3(256), 0, (hipStream_t)stream, points, pillar_pt_off, pillar_pts,
+                     voxel_coords, M, P, gt_points, gt_index);
+  GD_LAUNCH_CHECK();
+  return 0;
+}
+
+// term[m] = w_m * ( (1/P1) sum_i min_j |x_i - y_j|^2 + (1/P2) sum_j min_i |x_i - y_j|^2 )
+// dpred[m,i,:] = d term[m] / d x_i
+template <int P1MAX>
+__global__ __launch_bounds__(256) void k_chamfer(const float* __restrict__ pred, const float* __restrict__ gt,
+                                                 const float* __restrict__ w, int M, int P1, int P2,
+                                                 float* __restrict__ term, float* __restrict__ dpred) {
+  __shared__ float sx[4][P1MAX * 3];
+  const int lane = threadIdx.x & (GD_WAVE - 1);
+  const int wib = threadIdx.x / GD_WAVE;
+  for (int m = blockIdx.x * 4 + wib; m < M; m += gridDim.x * 4) {
+    const float wm = w[m];
+    float* dp = dpred + (long long)m * P1 * 3;
+    if (wm == 0.f) {
+      for (int e = lane; e < P1 * 3; e += GD_WAVE) dp[e] = 0.f;
+      if (lane == 0) term[m] = 0.f;
+      continue;
+    }
+    for (int e = lane; e < P1 * 3; e += GD_WAVE) sx[wib][e] = pred[(long long)m * P1 * 3 + e];
+    __builtin_amdgcn_wave_barrier();
+    const bool has = lane < P2;
+    float y0 = 0.f, y1 = 0.f, y2 = 0.f;
+    if (has) {
+      const float* g = gt + ((long long)m * P2 + lane) * 3;
+      y0 = g[0];
+      y1 = g[1];
+      y2 = g[2];
+    }
+    float best = INFINITY;
+    int besti = 0;
+    float sumx = 0.f;
+    const float cx = wm / (float)P1, cy = wm / (float)P2;
+    for (int i = 0; i < P1; ++i) {
+      const float x0 = sx[wib][3 * i], x1 = sx[wib][3 * i + 1], x2 = sx[wib][3 * i + 2];
+      const float d0 = x0 - y0, d1 = x1 - y1, d2 = x2 - y2;
+      const float d = has ? (d0 * d0 + d1 * d1 + d2 * d2) : INFINITY;
+      if (d < best) {
+        best = d;
+        besti = i;
+      }
+      const float dmin = gd_wave_min(d);
+      const unsigned long long bal = __ballot(d == dmin);
+      const int jstar = __ffsll((long long)bal) - 1;
+      sumx += dmin;
+      // gradient through min_j for row i: 2 (x_i - y_j*) * w / P1
+      const float g0 = 2.f * cx * __shfl(d0, jstar, GD_WAVE);
+      const float g1 = 2.f * cx * __shfl(d1, jstar, GD_WAVE);
+      const float g2 = 2.f * cx * __shfl(d2, jstar, GD_WAVE);
+      if (lane == 0) {
+        dp[3 * i] = g0;
+        dp[3 * i + 1] = g1;
+        dp[3 * i + 2] = g2;
+      }
+    }
+    const float sumy = gd_wave_sum(has ? best : 0.f);
+    if (lane == 0) term[m] = cx * sumx + cy * sumy;
+    // gradient through min_i for column j: lanes whose nearest prediction is i add 2 (x_i - y_j) * w / P2
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    for (int i = 0; i < P1; ++i) {
+      const bool mine = has && besti == i;
+      const float x0 = sx[wib][3 * i], x1 = sx[wib][3 * i + 1], x2 = sx[wib][3 * i + 2];
+      const float a0 = gd_wave_sum(mine ? 2.f * cy * (x0 - y0) : 0.f);
+      const float a1 = gd_wave_sum(mine ? 2.f * cy * (x1 - y1) : 0.f);
+      const float a2 = gd_wave_sum(mine ? 2.f * cy * (x2 - y2) : 0.f);
+      if (lane == 0) {
+        dp[3 * i] += a0;
+        dp[3 * i + 1] += a1;
+        dp[3 * i + 2] += a2;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+extern "C" int gdmae_chamfer(const float* pred, const float* gt, const float* weights, int M, int P1, int P2, float* term,
+                             float* dpred, void* stream) {
+  if (M <= 0) return 0;
+  GD_REQUIRE(P2 >= 1 && P2 <= GD_WAVE, "NUM_GT_POINTS must be <= 64 (one lane per ground-truth point)");
+  GD_REQUIRE(P1 >= 1 && P1 <= 64, "NUM_PRD_POINTS must be <= 64");
+  int grid = gd_div_up(M, 4);
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL((k_chamfer<64>), dim3(grid), dim3(256), 0, (hipStream_t)stream, pred, gt, weights, M, P1, P2, term,
+                     dpred);
+  GD_LAUNCH_CHECK();
+  return 0;
+}

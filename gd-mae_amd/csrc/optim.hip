@@ -1,0 +1,79 @@
+// Fused global-norm clip + decoupled weight decay + Adam over ONE flat fp32 parameter buffer.
+//
+// Replaces the per-parameter python loops of the reference optimizer step:
+//   clip_grad_norm_(model.parameters(), 10)                      reference tools/train_utils/train_utils.py:52
+//   OptimWrapper.step: p.mul_(1 - wd*lr) for every param, then Adam.step()
+//                                                                tools/train_utils/optimization/fastai_optim.py:135-152
+// (~190 tensors x several kernels each in the reference; two launches here).  The same flat gradient
+// buffer is what the data-parallel all-reduce operates on, so no gather/scatter of gradients is needed.
+#include "common.h"
+
+__global__ __launch_bounds__(256) void k_sq_partials(const float* __restrict__ g, long long n, float* __restrict__ part) {
+  __shared__ float sh[4];
+  float acc = 0.f;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    acc = fmaf(g[i], g[i], acc);
+  acc = gd_wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x / 64] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+struct AdamArgs {
+  float lr, beta1, beta2, eps, wd, max_norm;
+  float bc1, bc2_sqrt;  // 1 - beta1^t, sqrt(1 - beta2^t)
+};
+
+__global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                              float* __restrict__ v, long long n, AdamArgs A,
+                                              const float* __restrict__ sq_norm) {
+  float coef = 1.f;
+  if (A.max_norm > 0.f) {
+    const float total = sqrtf(*sq_norm);
+    coef = fminf(A.max_norm / (total + 1e-6f), 1.f);
+  }
+  const float decay = 1.f - A.wd * A.lr;
+  const float step = A.lr / A.bc1;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float gi = g[i] * coef;
+    float pi = p[i] * decay;
+    const float mi = A.beta1 * m[i] + (1.f - A.beta1) * gi;
+    const float vi = A.beta2 * v[i] + (1.f - A.beta2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / A.bc2_sqrt + A.eps;
+    p[i] = pi - step * (mi / denom);
+  }
+}
+
+// sq_norm_out[0] receives |g|^2 (after the caller's all-reduce of g); partials needs >= 1024 floats.
+extern "C" int gdmae_grad_sq_norm(const float* grad, long long n, float* partials, float* sq_norm_out, void* stream);
+extern "C" int gdmae_sum_partials(const float* part, long long n, float scale, float* out, int accumulate, void* stream);
+
+extern "C" int gdmae_grad_sq_norm(const float* grad, long long n, float* partials, float* sq_norm_out, void* stream) {
+  const int nb = 1024;
+  hipLaunchKernelGGL(k_sq_partials, dim3(nb), dim3(256), 0, (hipStream_t)stream, grad, n, partials);
+  GD_LAUNCH_CHECK();
+  return gdmae_sum_partials(partials, nb, 1.f, sq_norm_out, 0, stream);
+}
+
+extern "C" int gdmae_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr,
+                               float beta1, float beta2, float eps, float weight_decay, int step, float max_norm,
+                               const float* sq_norm, void* stream) {
+  GD_REQUIRE(step >= 1, "step counts from 1");
+  AdamArgs A;
+  A.lr = lr;
+  A.beta1 = beta1;
+  A.beta2 = beta2;
+  A.eps = eps;
+  A.wd = weight_decay;
+  A.max_norm = max_norm;
+  A.bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+  A.bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+  int grid = gd_div_up(n, 256);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(k_adam, dim3(grid), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, A,
+                     sq_norm);
+  GD_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,298 @@
+// Dynamic pillar voxelization for gfx950: range filter -> pillar key -> direct-address pillar table
+// -> canonical CSR of points per pillar -> per-pillar mean.
+//
+// Replaces, for the GD-MAE hot path (SURVEY.md §8 rows a1-a3 and the rank part of a17):
+//   get_in_range_mask + coord build        reference pcdet/utils/common_utils.py:66-76,
+//                                           pcdet/models/backbones_3d/vfe/dyn_vfe.py:62-67
+//   coords.unique(dim=0, return_inverse)   dyn_vfe.py:68      (ATen sort-based unique)
+//   torch_scatter.scatter(reduce='mean')   dyn_vfe.py:81
+//   ingroup rank of a point in its pillar  pcdet/ops/sst_ops/src/sst_ops_gpu.cu:22-28 (atomic
+//                                           arrival order there; canonical ascending index here)
+//
+// MI355X design: the pillar key space is the dense BEV grid (B*Z*Y*X cells, 1.75 M for a batch of
+// 8 Waymo frames = 7 MB of int32), so "unique" is a direct-address table in HBM/L2 instead of a
+// multi-pass sort of 4 x int64 rows: one atomic histogram pass, one packed (flag|count) scan over
+// the cells - which yields the pillars already in lexicographic (b,z,y,x) order, i.e. exactly the
+// order torch.unique(dim=0) returns - and one fill pass.  Determinism: the fill pass places points
+// in arrival order inside a pillar's CSR segment, then one wavefront per pillar ranks the segment
+// by point index (<= 64 points: one point per lane, rank by counting through v_readlane), so every
+// downstream consumer sees ascending-index order regardless of atomic timing.  No host sync: all
+// counts stay on the device (counts[]), launches use bounded grid-stride loops.
+#include "common.h"
+
+struct VoxParams {
+  float lo[3];
+  float vs[3];
+  int gx, gy, gz;
+  int B;
+  int ncols;  // 1 + F
+};
+
+// IEEE-exact (p - lo) / vs, truncation toward zero; -ffp-contract must not touch these.
+__device__ inline bool vox_coord(float p, float lo, float vs, int g, int& c) {
+  float q = __fdiv_rn(__fsub_rn(p, lo), vs);
+  // trunc(q) in [0, g-1]  <=>  -1 < q < g   (NaN/inf fail both; q in (-1,0) truncates to 0 and is KEPT,
+  // matching `.to(torch.int64)` in common_utils.py:74)
+  bool ok = (q > -1.0f) && (q < (float)g);
+  c = ok ? (int)q : 0;
+  return ok;
+}
+
+__global__ __launch_bounds__(256) void k_point_keys(const float* __restrict__ pts, long long n0, VoxParams P,
+                                                    int* __restrict__ key, int* __restrict__ cell_cnt) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n0;
+       i += (long long)gridDim.x * blockDim.x) {
+    const float* r = pts + i * P.ncols;
+    float bf = r[0];
+    int cx, cy, cz;
+    bool ok = vox_coord(r[1], P.lo[0], P.vs[0], P.gx, cx);
+    ok &= vox_coord(r[2], P.lo[1], P.vs[1], P.gy, cy);
+    ok &= vox_coord(r[3], P.lo[2], P.vs[2], P.gz, cz);
+    ok &= (bf > -1.0f) && (bf < (float)P.B);
+    int k = -1;
+    if (ok) {
+      int b = (int)bf;
+      k = ((b * P.gz + cz) * P.gy + cy) * P.gx + cx;
+      atomicAdd(&cell_cnt[k], 1);
+    }
+    key[i] = k;
+  }
+}
+
+struct KeepLoad {
+  const int* key;
+  __device__ int operator()(long long i) const { return key[i] >= 0 ? 1 : 0; }
+};
+struct KeepStore {
+  int* pos;
+  __device__ void operator()(long long i, int ex, int) const { pos[i] = ex; }
+};
+
+struct CellLoad {
+  const int* cell_cnt;
+  __device__ unsigned long long operator()(long long c) const {
+    int n = cell_cnt[c];
+    return n > 0 ? ((1ull << 32) | (unsigned long long)(unsigned)n) : 0ull;
+  }
+};
+struct CellStore {
+  VoxParams P;
+  int* cell2pillar;
+  int* pt_off;
+  int* pillar_cell;
+  long long* voxel_coords;
+  int* sample_off;
+  __device__ void operator()(long long c, unsigned long long ex, unsigned long long v) const {
+    const int p = (int)(ex >> 32);
+    const int cps = P.gz * P.gy * P.gx;
+    if (c % cps == 0) sample_off[c / cps] = p;
+    if (v) {
+      cell2pillar[c] = p;
+      pt_off[p] = (int)(unsigned)ex;
+      pillar_cell[p] = (int)c;
+      int x = (int)(c % P.gx);
+      long long t = c / P.gx;
+      int y = (int)(t % P.gy);
+      t /= P.gy;
+      int z = (int)(t % P.gz);
+      int b = (int)(t / P.gz);
+      long long* o = voxel_coords + 4ll * p;
+      o[0] = b;
+      o[1] = z;
+      o[2] = y;
+      o[3] = x;
+    } else {
+      cell2pillar[c] = -1;
+    }
+  }
+};
+
+// counts: [0]=N kept points, [1]=M pillars
+__global__ void k_vox_finalize(const unsigned long long* total, const int* n_keep, int B, int* pt_off, int* sample_off,
+                               int* counts) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    int M = (int)(*total >> 32);
+    int N = (int)(unsigned)(*total);
+    pt_off[M] = N;
+    sample_off[B] = M;
+    counts[0] = *n_keep;
+    counts[1] = M;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_point_fill(const float* __restrict__ pts, long long n0, VoxParams P,
+                                                    const int* __restrict__ key, const int* __restrict__ pos,
+                                                    const int* __restrict__ cell2pillar, const int* __restrict__ pt_off,
+                                                    int* __restrict__ cell_cnt, float* __restrict__ pts_out,
+                                                    long long* __restrict__ point_coords, long long* __restrict__ inverse,
+                                                    int* __restrict__ inverse32, int* __restrict__ csr_raw) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n0;
+       i += (long long)gridDim.x * blockDim.x) {
+    int k = key[i];
+    if (k < 0) continue;
+    int dst = pos[i];
+    int p = cell2pillar[k];
+    int slot = atomicSub(&cell_cnt[k], 1) - 1;  // leaves the table zeroed for the next call
+    csr_raw[pt_off[p] + slot] = dst;
+    inverse[dst] = p;
+    inverse32[dst] = p;
+    const float* r = pts + i * P.ncols;
+    float* w = pts_out + (long long)dst * P.ncols;
+    for (int c = 0; c < P.ncols; ++c) w[c] = r[c];
+    int x = k % P.gx;
+    int t = k / P.gx;
+    int y = t % P.gy;
+    t /= P.gy;
+    int z = t % P.gz;
+    int b = t / P.gz;
+    long long* o = point_coords + 4ll * dst;
+    o[0] = b;
+    o[1] = z;
+    o[2] = y;
+    o[3] = x;
+  }
+}
+
+// One wavefront per pillar: sort the pillar's point ids ascending (canonical order), write the rank
+// of every point, then lanes 0..F-1 each accumulate one feature channel SEQUENTIALLY in that order
+// (bit-identical to a sequential CPU index_add_) and divide by the count.
+__global__ __launch_bounds__(256) void k_pillar_sort_mean(const int* __restrict__ counts, const int* __restrict__ pt_off,
+                                                          const int* __restrict__ csr_raw, int* __restrict__ csr,
+                                                          int* __restrict__ rank, const float* __restrict__ pts_out,
+                                                          int ncols, float* __restrict__ mean) {
+  __shared__ int s_sorted[4][GD_WAVE];
+  const int lane = threadIdx.x & (GD_WAVE - 1);
+  const int wib = threadIdx.x / GD_WAVE;
+  const int M = counts[1];
+  const int F = ncols - 1;
+  for (int p = blockIdx.x * 4 + wib; p < M; p += gridDim.x * 4) {
+    const int off = pt_off[p];
+    const int cnt = pt_off[p + 1] - off;
+    if (cnt <= GD_WAVE) {
+      int v = lane < cnt ? csr_raw[off + lane] : 0x7fffffff;
+      int r = 0;
+      for (int j = 0; j < cnt; ++j) r += (__shfl(v, j, GD_WAVE) < v) ? 1 : 0;
+      if (lane < cnt) {
+        csr[off + r] = v;
+        rank[v] = r;
+        s_sorted[wib][r] = v;
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (lane < F) {
+        float acc = 0.f;
+        for (int j = 0; j < cnt; ++j) acc = __fadd_rn(acc, pts_out[(long long)s_sorted[wib][j] * ncols + 1 + lane]);
+        mean[(long long)p * F + lane] = __fdiv_rn(acc, (float)cnt);
+      }
+      __builtin_amdgcn_wave_barrier();
+    } else {
+      // large pillar: rank by counting against the whole segment (uniform, cached reads)
+      for (int base = 0; base < cnt; base += GD_WAVE * 4) {
+        int own[4], rk[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          int e = base + q * GD_WAVE + lane;
+          own[q] = e < cnt ? csr_raw[off + e] : 0x7fffffff;
+          rk[q] = 0;
+        }
+        for (int j = 0; j < cnt; ++j) {
+          int u = csr_raw[off + j];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) rk[q] += (u < own[q]) ? 1 : 0;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          int e = base + q * GD_WAVE + lane;
+          if (e < cnt) {
+            csr[off + rk[q]] = own[q];
+            rank[own[q]] = rk[q];
+          }
+        }
+      }
+      // make this wave's csr[] stores visible to its own later loads (same CU: workgroup scope)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      if (lane < F) {
+        float acc = 0.f;
+        for (int j = 0; j < cnt; ++j) {
+          int pid = __builtin_nontemporal_load(&csr[off + j]);
+          acc = __fadd_rn(acc, pts_out[(long long)pid * ncols + 1 + lane]);
+        }
+        mean[(long long)p * F + lane] = __fdiv_rn(acc, (float)cnt);
+      }
+    }
+  }
+}
+
+extern "C" size_t gdmae_voxelize_workspace_bytes(long long n_points, int batch_size, int gx, int gy, int gz) {
+  long long cells = (long long)batch_size * gx * gy * gz;
+  size_t b = 0;
+  b += gd_align(sizeof(int) * cells);                               // cell_cnt (must be zero on entry)
+  b += gd_align(sizeof(int) * cells);                               // cell2pillar
+  b += gd_align(sizeof(int) * n_points) * 3;                        // key, pos, csr_raw
+  b += gd_align(sizeof(unsigned long long) * gd_scan_ws_elems(cells > n_points ? cells : n_points));
+  b += gd_align(sizeof(unsigned long long) * 2) + gd_align(sizeof(int) * 2);
+  return b + 4096;
+}
+
+// See include/gdmae_hip.h for the contract.
+extern "C" int gdmae_voxelize(const float* points, long long n_points, int n_cols, const float* lo, const float* vs,
+                              const int* grid_xyz, int batch_size, float* points_out, long long* point_coords,
+                              long long* inverse, int* inverse32, long long* voxel_coords, int* pillar_cell,
+                              int* pillar_pt_off, int* pillar_pts, int* point_rank, int* sample_pillar_off,
+                              float* pillar_mean, int* cell2pillar_out, int* counts, void* workspace,
+                              size_t workspace_bytes, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  GD_REQUIRE(n_cols >= 4 && n_cols <= 65, "n_cols must be 1+F with 3 <= F <= 64");
+  VoxParams P;
+  for (int i = 0; i < 3; ++i) {
+    P.lo[i] = lo[i];
+    P.vs[i] = vs[i];
+  }
+  P.gx = grid_xyz[0];
+  P.gy = grid_xyz[1];
+  P.gz = grid_xyz[2];
+  P.B = batch_size;
+  P.ncols = n_cols;
+  const long long cells = (long long)batch_size * P.gx * P.gy * P.gz;
+  GD_REQUIRE(cells > 0 && cells < (1ll << 31), "B*Z*Y*X must fit int32");
+  GD_REQUIRE(n_points < (1ll << 31), "too many points");
+  GD_REQUIRE(workspace_bytes >= gdmae_voxelize_workspace_bytes(n_points, batch_size, P.gx, P.gy, P.gz),
+             "voxelize workspace too small");
+  GdArena A(workspace, workspace_bytes);
+  int* cell_cnt = A.take<int>(cells);
+  int* cell2pillar = cell2pillar_out ? cell2pillar_out : A.take<int>(cells);
+  int* key = A.take<int>(n_points);
+  int* pos = A.take<int>(n_points);
+  int* csr_raw = A.take<int>(n_points);
+  unsigned long long* scan_ws = A.take<unsigned long long>(gd_scan_ws_elems(cells > n_points ? cells : n_points));
+  unsigned long long* total = A.take<unsigned long long>(2);
+  int* n_keep = A.take<int>(2);
+
+  GD_CHECK(hipMemsetAsync(cell_cnt, 0, sizeof(int) * cells, st));
+  const int grid_pts = n_points > 0 ? (gd_div_up(n_points, 256) < 4096 ? gd_div_up(n_points, 256) : 4096) : 1;
+  if (n_points > 0) {
+    hipLaunchKernelGGL(k_point_keys, dim3(grid_pts), dim3(256), 0, st, points, n_points, P, key, cell_cnt);
+    GD_LAUNCH_CHECK();
+  }
+  {
+    int rc = gd_device_scan<int>(n_points, KeepLoad{key}, KeepStore{pos}, n_keep, (int*)scan_ws, st);
+    if (rc) return rc;
+  }
+  {
+    CellStore cs{P, cell2pillar, pillar_pt_off, pillar_cell, voxel_coords, sample_pillar_off};
+    int rc = gd_device_scan<unsigned long long>(cells, CellLoad{cell_cnt}, cs, total, scan_ws, st);
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(k_vox_finalize, dim3(1), dim3(64), 0, st, total, n_keep, batch_size, pillar_pt_off,
+                     sample_pillar_off, counts);
+  GD_LAUNCH_CHECK();
+  if (n_points > 0) {
+    hipLaunchKernelGGL(k_point_fill, dim3(grid_pts), dim3(256), 0, st, points, n_points, P, key, pos, cell2pillar,
+                       pillar_pt_off, cell_cnt, points_out, point_coords, inverse, inverse32, csr_raw);
+    GD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_pillar_sort_mean, dim3(2048), dim3(256), 0, st, counts, pillar_pt_off, csr_raw, pillar_pts,
+                       point_rank, points_out, n_cols, pillar_mean);
+    GD_LAUNCH_CHECK();
+  }
+  return 0;
+}

@@ -1,0 +1,60 @@
+"""Build libgdmae_hip.so for gfx950 with hipcc (in-tree; the .so travels to the GPU box with the snapshot).
+
+    python -m gdmae_hip.build            # from gd-mae_amd/
+
+`-ffp-contract=off` keeps the bit-exact integer/voxel arithmetic free of FMA contraction (explicit fmaf
+is still used in the floating-point kernels); fp32 division/sqrt stay correctly rounded (HIP default).
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.abspath(os.path.join(HERE, "..", "csrc"))
+LIB = os.path.join(CSRC, "libgdmae_hip.so")
+SOURCES = ["capi.hip", "voxelize.hip", "mask.hip", "partition.hip", "segment.hip", "attention.hip", "chamfer.hip",
+           "optim.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+         "-Wno-unused-result"]
+
+
+def _newer(src, dst):
+    return not os.path.exists(dst) or os.path.getmtime(src) > os.path.getmtime(dst)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objs = []
+    deps = [os.path.join(CSRC, "common.h")]
+    procs = []
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(CSRC, s.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or _newer(src, obj) or any(_newer(d, obj) for d in deps):
+            cmd = [hipcc, *FLAGS, "-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    failed = False
+    for s, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            failed = True
+            sys.stderr.write(f"--- {s} failed ---\n{out.decode()}\n")
+        elif verbose and out.strip():
+            print(out.decode())
+    if failed:
+        raise RuntimeError("hipcc failed")
+    if force or procs or not os.path.exists(LIB):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

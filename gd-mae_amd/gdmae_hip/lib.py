@@ -1,0 +1,93 @@
+"""ctypes binding of libgdmae_hip.so (the C ABI declared in include/gdmae_hip.h).
+
+The product path has NO fallback: if the HIP library is missing or an entry point fails, a
+``GdmaeHipError`` is raised.  Nothing here imports ``oracle/``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.abspath(os.path.join(_HERE, "..", "csrc", "libgdmae_hip.so"))
+
+
+class GdmaeHipError(RuntimeError):
+    pass
+
+
+_P, _I, _L, _F, _D, _Z = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_double, C.c_size_t
+
+# name -> (restype, argtypes); must list every symbol of include/gdmae_hip.h
+SIGNATURES = {
+    "gdmae_abi_version": (_I, []),
+    "gdmae_target_arch": (C.c_char_p, []),
+    "gdmae_last_error": (C.c_char_p, []),
+    "gdmae_voxelize_workspace_bytes": (_Z, [_L, _I, _I, _I, _I]),
+    "gdmae_voxelize": (_I, [_P, _L, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    "gdmae_decorate_points": (_I, [_P, _P, _P, _P, _L, _I, _P, _P, _P, _P]),
+    "gdmae_segment_max": (_I, [_P, _P, _P, _I, _I, _P, _P, _P]),
+    "gdmae_segment_max_bwd": (_I, [_P, _P, _P, _L, _I, _P, _P]),
+    "gdmae_random_mask": (_I, [_P, _P, _I, _D, _P, _P, _P]),
+    "gdmae_visible_tokens": (_I, [_P, _P, _P, _L, _L, _P, _P, _P, _P, _P, _P]),
+    "gdmae_downsample_tokens": (_I, [_P, _P, _L, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "gdmae_rulebook": (_I, [_P, _P, _L, _I, _I, _I, _I, _I, _P, _I, _P, _P]),
+    "gdmae_window_workspace_bytes": (_Z, [_I, _I, _I, _I, _I]),
+    "gdmae_window_partition": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    "gdmae_gather_rows": (_I, [_P, _P, _L, _I, _P, _P]),
+    "gdmae_scatter_rows": (_I, [_P, _P, _L, _I, _P, _P]),
+    "gdmae_window_attention_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _F, _P]),
+    "gdmae_window_attention_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _F, _P]),
+    "gdmae_sum_partials": (_I, [_P, _L, _F, _P, _I, _P]),
+    "gdmae_group_gt_points": (_I, [_P, _I, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
+    "gdmae_chamfer": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P]),
+    "gdmae_grad_sq_norm": (_I, [_P, _L, _P, _P, _P]),
+    "gdmae_adam_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _P, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library and bind every declared symbol (works without a GPU)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GdmaeHipError(f"{LIB_PATH} not found - build it with `python -m gdmae_hip.build` "
+                            "(__graft_entry__.build()); there is no CPU fallback for the product path")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def ptr(t):
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "HIP entry points need contiguous device tensors"
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise GdmaeHipError(f"{name} failed ({rc}): {lib.gdmae_last_error().decode()}")
+
+
+def host_f32(vals):
+    return (C.c_float * len(vals))(*[float(v) for v in vals])
+
+
+def host_i32(vals):
+    return (C.c_int * len(vals))(*[int(v) for v in vals])

@@ -1,0 +1,218 @@
+"""torch.autograd wrappers around the HIP entry points (the feature side of the hot path).
+
+Token-wise GEMMs, the dense decoder convolutions and the norm layers are issued through PyTorch-ROCm
+(hipBLASLt / MIOpen); everything that is gather/scatter/segment/attention/loss shaped runs in
+libgdmae_hip.so.  There is no fallback path: without the library these ops raise.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import lib as L
+
+I32 = torch.int32
+
+
+def _f32c(t):
+    assert t.dtype == torch.float32
+    return t.contiguous()
+
+
+# ------------------------------------------------------------------------------------------------
+# row gather / scatter
+# ------------------------------------------------------------------------------------------------
+def gather_rows_raw(src: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    """out[s] = src[idx[s]] or 0 for idx < 0; idx any shape (int32), result idx.shape + (C,)."""
+    src = src.contiguous()
+    C = src.shape[-1]
+    rb = C * src.element_size()
+    out = torch.empty(tuple(idx.shape) + (C,), dtype=src.dtype, device=src.device)
+    L.call("gdmae_gather_rows", L.ptr(src), L.ptr(idx.contiguous()), idx.numel(), rb, L.ptr(out), L.stream())
+    return out
+
+
+def scatter_rows_raw(src: torch.Tensor, idx: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
+    src = src.contiguous()
+    rb = src.shape[-1] * src.element_size()
+    L.call("gdmae_scatter_rows", L.ptr(src), L.ptr(idx.contiguous()), idx.numel(), rb, L.ptr(dst), L.stream())
+    return dst
+
+
+class ScatterToDense(torch.autograd.Function):
+    """feat (n, C) -> zero-filled (R, C) with feat rows at idx (unique).  SparseConvTensor.dense()."""
+
+    @staticmethod
+    def forward(ctx, feat, idx, n_rows):
+        ctx.save_for_backward(idx)
+        dst = torch.zeros(n_rows, feat.shape[1], dtype=feat.dtype, device=feat.device)
+        return scatter_rows_raw(feat, idx, dst)
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        return gather_rows_raw(g, idx), None, None
+
+
+class GatherUnique(torch.autograd.Function):
+    """dense (R, C) -> rows at idx (unique, >= 0).  Gather of decoder features at the pillar sites."""
+
+    @staticmethod
+    def forward(ctx, dense, idx):
+        ctx.save_for_backward(idx)
+        ctx.n_rows = dense.shape[0]
+        return gather_rows_raw(dense, idx)
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        dst = torch.zeros(ctx.n_rows, g.shape[1], dtype=g.dtype, device=g.device)
+        return scatter_rows_raw(g, idx, dst), None
+
+
+# ------------------------------------------------------------------------------------------------
+# 2-D sparse convolution = rulebook gather (HIP) + one GEMM (hipBLASLt)
+# ------------------------------------------------------------------------------------------------
+class SparseConv3x3(torch.autograd.Function):
+    """out[o] = sum_k W[:, ky, kx, :] . x[nbr[o, k]];  W in spconv-2.x layout (Cout, 3, 3, Cin).
+
+    nbr (n_out, 9) maps output sites to input rows; nbr_t (n_in, 9) maps input rows to output rows
+    (same tap index), used to express the input gradient as a gather as well (no atomics).
+    """
+
+    @staticmethod
+    def forward(ctx, x, weight, nbr, nbr_t):
+        cout, _, _, cin = weight.shape
+        cols = gather_rows_raw(x, nbr).view(nbr.shape[0], 9 * cin)
+        wmat = weight.reshape(cout, 9 * cin)
+        ctx.save_for_backward(cols, weight, nbr_t)
+        return cols @ wmat.t().to(cols.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        cols, weight, nbr_t = ctx.saved_tensors
+        cout, _, _, cin = weight.shape
+        g = g.contiguous()
+        dw = (g.t() @ cols).view(cout, 3, 3, cin).to(weight.dtype)
+        gcols = gather_rows_raw(g, nbr_t).view(nbr_t.shape[0], 9 * cout)
+        wt = weight.permute(1, 2, 0, 3).reshape(9 * cout, cin).to(g.dtype)
+        return gcols @ wt, dw, None, None
+
+
+# ------------------------------------------------------------------------------------------------
+# segmented max over the pillar CSR
+# ------------------------------------------------------------------------------------------------
+class SegmentMax(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, pt_off, pillar_pts, inverse32):
+        x = _f32c(x)
+        M = pt_off.numel() - 1
+        C = x.shape[1]
+        out = torch.empty(M, C, dtype=torch.float32, device=x.device)
+        arg = torch.empty(M, C, dtype=I32, device=x.device)
+        L.call("gdmae_segment_max", L.ptr(x), L.ptr(pt_off), L.ptr(pillar_pts), M, C, L.ptr(out), L.ptr(arg), L.stream())
+        ctx.save_for_backward(arg, inverse32)
+        ctx.shape = x.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        arg, inv = ctx.saved_tensors
+        N, C = ctx.shape
+        dx = torch.empty(N, C, dtype=torch.float32, device=g.device)
+        L.call("gdmae_segment_max_bwd", L.ptr(_f32c(g)), L.ptr(arg), L.ptr(inv), N, C, L.ptr(dx), L.stream())
+        return dx, None, None, None
+
+
+def decorate_points(vox) -> torch.Tensor:
+    """(N, 6+F) decorated point features of DynVFE (no gradient: raw geometry)."""
+    F = vox.n_cols - 1
+    out = torch.empty(vox.N, F + 6, dtype=torch.float32, device=vox.points.device)
+    L.call("gdmae_decorate_points", L.ptr(vox.points), L.ptr(vox.point_coords), L.ptr(vox.inverse32),
+           L.ptr(vox.pillar_mean), vox.N, vox.n_cols, L.host_f32(vox.lo), L.host_f32(vox.vs), L.ptr(out), L.stream())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# windowed cosine attention
+# ------------------------------------------------------------------------------------------------
+class WindowCosineAttention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qk, v, tau, wplan, nhead, tau_min):
+        qk, v = _f32c(qk), _f32c(v)
+        n, d = v.shape
+        out = torch.empty(n, d, dtype=torch.float32, device=v.device)
+        tau_flat = tau.detach().reshape(1).contiguous()
+        base = 0
+        for lvl, nw in enumerate(wplan.n_win):
+            if nw > 0:
+                L.call("gdmae_window_attention_fwd", L.ptr(qk), L.ptr(v), L.ptr(out), L.ptr(wplan.csr_tok),
+                       L.ptr(wplan.win_start[base:]), L.ptr(wplan.win_len[base:]), nw, wplan.max_tokens[lvl], d, nhead,
+                       L.ptr(tau_flat), float(tau_min), L.stream())
+            base += nw
+        ctx.save_for_backward(qk, v, tau_flat)
+        ctx.wplan, ctx.nhead, ctx.tau_min, ctx.tau_shape = wplan, nhead, tau_min, tau.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        qk, v, tau_flat = ctx.saved_tensors
+        wplan, H = ctx.wplan, ctx.nhead
+        n, d = v.shape
+        g = _f32c(g)
+        dqk = torch.empty_like(qk)
+        dv = torch.empty_like(v)
+        n_items = [nw * H // (64 // T) for nw, T in zip(wplan.n_win, wplan.max_tokens)]
+        part = torch.empty(max(sum(n_items), 1), dtype=torch.float32, device=v.device)
+        base, pbase = 0, 0
+        for lvl, nw in enumerate(wplan.n_win):
+            if nw > 0:
+                L.call("gdmae_window_attention_bwd", L.ptr(qk), L.ptr(v), L.ptr(g), L.ptr(dqk), L.ptr(dv),
+                       L.ptr(part[pbase:]), L.ptr(wplan.csr_tok), L.ptr(wplan.win_start[base:]),
+                       L.ptr(wplan.win_len[base:]), nw, wplan.max_tokens[lvl], d, H, L.ptr(tau_flat), float(ctx.tau_min),
+                       L.stream())
+            base += nw
+            pbase += n_items[lvl]
+        dtau = torch.zeros(1, dtype=torch.float32, device=v.device)
+        if pbase > 0:
+            L.call("gdmae_sum_partials", L.ptr(part), pbase, 1.0, L.ptr(dtau), 0, L.stream())
+        # d clamp(tau, min)/d tau = 1 where tau >= min (torch.clamp backward)
+        dtau = torch.where(tau_flat >= ctx.tau_min, dtau, torch.zeros_like(dtau)).view(ctx.tau_shape)
+        return dqk, dv, dtau, None, None, None
+
+
+# ------------------------------------------------------------------------------------------------
+# targets + Chamfer
+# ------------------------------------------------------------------------------------------------
+def group_gt_points(vox, K: int, want_index: bool = False):
+    """(M, K, 3) ground-truth points relative to the pillar centre (+ optional (M, K) point ids)."""
+    dev = vox.points.device
+    gt = torch.empty(vox.M, K, 3, dtype=torch.float32, device=dev)
+    gi = torch.empty(vox.M, K, dtype=I32, device=dev) if want_index else None
+    L.call("gdmae_group_gt_points", L.ptr(vox.points), vox.n_cols, L.ptr(vox.pt_off), L.ptr(vox.pillar_pts),
+           L.ptr(vox.voxel_coords), vox.M, K, L.host_f32(vox.lo), L.host_f32(vox.vs), L.ptr(gt), L.ptr(gi), L.stream())
+    return (gt, gi) if want_index else gt
+
+
+class ChamferLoss(torch.autograd.Function):
+    """pytorch3d-style weighted Chamfer distance; gradient w.r.t. pred only (gt carries none)."""
+
+    @staticmethod
+    def forward(ctx, pred, gt, weights):
+        pred, gt, weights = _f32c(pred), _f32c(gt), _f32c(weights)
+        M, P1, _ = pred.shape
+        P2 = gt.shape[1]
+        term = torch.empty(max(M, 1), dtype=torch.float32, device=pred.device)
+        dpred = torch.empty_like(pred)
+        L.call("gdmae_chamfer", L.ptr(pred), L.ptr(gt), L.ptr(weights), M, P1, P2, L.ptr(term), L.ptr(dpred), L.stream())
+        sums = torch.zeros(2, dtype=torch.float32, device=pred.device)
+        if M > 0:
+            L.call("gdmae_sum_partials", L.ptr(term), M, 1.0, L.ptr(sums[0:1]), 0, L.stream())
+            L.call("gdmae_sum_partials", L.ptr(weights), M, 1.0, L.ptr(sums[1:2]), 0, L.stream())
+        inv = torch.where(sums[1] > 0, 1.0 / sums[1].clamp(min=1e-30), torch.zeros_like(sums[1]))
+        ctx.save_for_backward(dpred, inv)
+        return sums[0] * inv
+
+    @staticmethod
+    def backward(ctx, g):
+        dpred, inv = ctx.saved_tensors
+        return dpred * (g * inv), None, None

@@ -1,0 +1,248 @@
+"""Geometry plan: every index structure of a pre-training step, built on the GPU by the HIP library.
+
+``voxelize`` covers SURVEY §8 rows a1-a3 (+ the canonical in-pillar order used by a17);
+``encoder_plan`` covers a5 (masking), the index side of a6 (token sets + sparse-conv rulebooks) and
+a7-a10 (shifted-window partition) for all stages and both shifts.  Each of the two functions enqueues
+all of its kernels back-to-back and performs exactly ONE device->host copy of a few int32 counts at
+the end (the reference performs dozens of ``.item()`` / ``unique`` / boolean-index syncs on this path:
+SURVEY §3.2).  Nothing here falls back to PyTorch/CPU arithmetic: sizes and pointers only.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import torch
+
+from . import lib as L
+
+I32 = torch.int32
+
+
+def _empty(n, dtype, dev):
+    return torch.empty(int(n), dtype=dtype, device=dev)
+
+
+@dataclass
+class VoxelPlan:
+    batch_size: int
+    grid: tuple            # (X, Y, Z)
+    lo: tuple
+    vs: tuple
+    n_cols: int
+    N: int
+    M: int
+    points: torch.Tensor          # (N, 1+F) kept points, original order
+    point_coords: torch.Tensor    # (N, 4) int64 [b, z, y, x]
+    inverse: torch.Tensor         # (N,) int64
+    inverse32: torch.Tensor       # (N,) int32
+    voxel_coords: torch.Tensor    # (M, 4) int64
+    pillar_cell: torch.Tensor     # (M,) int32
+    pt_off: torch.Tensor          # (M+1,) int32
+    pillar_pts: torch.Tensor      # (N,) int32
+    point_rank: torch.Tensor      # (N,) int32
+    sample_off: torch.Tensor      # (B+1,) int32
+    pillar_mean: torch.Tensor     # (M, F)
+    cell2pillar: torch.Tensor     # (B*Z*Y*X,) int32
+    counts: torch.Tensor          # device int32[2]
+
+
+def voxelize(points: torch.Tensor, point_cloud_range, voxel_size, grid_size, batch_size: int) -> VoxelPlan:
+    """points (N0, 1+F) fp32 on the GPU -> VoxelPlan (one host sync for N, M)."""
+    assert points.is_cuda and points.dtype == torch.float32 and points.dim() == 2
+    points = points.contiguous()
+    dev = points.device
+    n0, ncols = points.shape
+    gx, gy, gz = (int(g) for g in grid_size)
+    cells = batch_size * gx * gy * gz
+    lo = tuple(float(v) for v in point_cloud_range[:3])
+    vs = tuple(float(v) for v in voxel_size)
+    F = ncols - 1
+    cap = max(n0, 1)
+    pts_out = _empty(cap * ncols, torch.float32, dev)
+    pcoords = _empty(cap * 4, torch.int64, dev)
+    inverse = _empty(cap, torch.int64, dev)
+    inverse32 = _empty(cap, I32, dev)
+    vcoords = _empty(cap * 4, torch.int64, dev)
+    pillar_cell = _empty(cap, I32, dev)
+    pt_off = _empty(cap + 1, I32, dev)
+    pillar_pts = _empty(cap, I32, dev)
+    prank = _empty(cap, I32, dev)
+    sample_off = _empty(batch_size + 1, I32, dev)
+    mean = _empty(cap * F, torch.float32, dev)
+    cell2pillar = _empty(cells, I32, dev)
+    counts = _empty(2, I32, dev)
+    wsb = L.load().gdmae_voxelize_workspace_bytes(n0, batch_size, gx, gy, gz)
+    ws = _empty(wsb, torch.uint8, dev)
+    L.call("gdmae_voxelize", L.ptr(points), n0, ncols, L.host_f32(lo), L.host_f32(vs), L.host_i32((gx, gy, gz)),
+           batch_size, L.ptr(pts_out), L.ptr(pcoords), L.ptr(inverse), L.ptr(inverse32), L.ptr(vcoords),
+           L.ptr(pillar_cell), L.ptr(pt_off), L.ptr(pillar_pts), L.ptr(prank), L.ptr(sample_off), L.ptr(mean),
+           L.ptr(cell2pillar), L.ptr(counts), L.ptr(ws), wsb, L.stream())
+    N, M = (int(v) for v in counts.tolist())      # the one host sync of this phase
+    return VoxelPlan(batch_size, (gx, gy, gz), lo, vs, ncols, N, M,
+                     pts_out[:N * ncols].view(N, ncols), pcoords[:N * 4].view(N, 4), inverse[:N], inverse32[:N],
+                     vcoords[:M * 4].view(M, 4), pillar_cell[:M], pt_off[:M + 1], pillar_pts[:N], prank[:N],
+                     sample_off, mean[:M * F].view(M, F), cell2pillar, counts)
+
+
+@dataclass
+class WindowPlan:
+    """One shift of one stage (tokens grouped into windows, windows grouped into occupancy levels)."""
+    tok_win: torch.Tensor
+    tok_level: torch.Tensor
+    tok_slot: torch.Tensor
+    tok_pos: torch.Tensor
+    csr_tok: torch.Tensor
+    win_start: torch.Tensor
+    win_len: torch.Tensor
+    n_win: List[int] = field(default_factory=list)    # per level
+    n_tok: List[int] = field(default_factory=list)    # per level
+    max_tokens: List[int] = field(default_factory=list)
+
+
+@dataclass
+class StagePlan:
+    B: int
+    Y: int
+    X: int
+    n_tok: int
+    tok_cell: torch.Tensor            # (n_tok,) int32 linear key (b*Y+y)*X+x, ascending
+    map: torch.Tensor                 # (B*Y*X,) int32 cell -> token / -1
+    nbr_subm: torch.Tensor            # (n_tok, 9) int32
+    nbr_down: Optional[torch.Tensor]  # (n_tok, 9) ids into the previous stage (strided conv forward)
+    nbr_down_t: Optional[torch.Tensor]  # (n_prev, 9) ids into THIS stage (strided conv backward)
+    windows: List[WindowPlan] = field(default_factory=list)
+
+    def indices_byx(self) -> torch.Tensor:
+        c = self.tok_cell.long()
+        x = c % self.X
+        r = c // self.X
+        return torch.stack([r // self.Y, r % self.Y, x], dim=-1).int()
+
+
+@dataclass
+class EncoderPlan:
+    mask: Optional[torch.Tensor]       # (M,) fp32 0 visible / 1 masked (None when nothing is masked)
+    tok_pillar: torch.Tensor           # (M1,) pillar id of each stage-1 token
+    stages: List[StagePlan]
+
+
+def _drop_arrays(drop_info):
+    d = {int(k): v for k, v in drop_info.items()}
+    keys = sorted(d)
+    assert keys == list(range(len(keys))) and len(keys) <= 3
+    lo = [int(d[k]["drop_range"][0]) for k in keys]
+    hi = [int(d[k]["drop_range"][1]) for k in keys]
+    T = [int(d[k]["max_tokens"]) for k in keys]
+    return lo, hi, T
+
+
+def encoder_plan(vox: VoxelPlan, strides, window_shapes, drop_infos, keep_frac: Optional[float] = None,
+                 noise: Optional[torch.Tensor] = None) -> EncoderPlan:
+    """Masking + token sets + rulebooks + window partitions for all stages; ONE host sync at the end.
+
+    strides: per stage conv_down stride (1 or 2); window_shapes: per stage [wx, wy, wz];
+    drop_infos: per stage DROP_INFO['train'] dict; keep_frac = 1 - MASK RATIO (python double) or None
+    for no masking (fine-tune backbone); noise: (M,) fp32 masking noise (drawn if None).
+    """
+    dev = vox.points.device
+    gx, gy, gz = vox.grid
+    assert gz == 1, "the SST backbone works on single-layer pillar grids (spt_backbone_mae.py:94)"
+    B, M = vox.batch_size, vox.M
+    lib = L.load()
+    st = L.stream()
+    scan_ws = _empty(8 * (max(B * gx * gy, M) // 4096 + 4), torch.int64, dev)
+    pending = []   # (device counts tensor) read back together at the end
+
+    # ---- a5 masking
+    if keep_frac is not None:
+        if noise is None:
+            noise = torch.rand(max(M, 1), device=dev, dtype=torch.float32)[:M]
+        assert noise.shape == (M,) and noise.dtype == torch.float32
+        mask = _empty(max(M, 1), torch.float32, dev)[:M]
+        len_keep = _empty(B, I32, dev)
+        L.call("gdmae_random_mask", L.ptr(noise.contiguous()), L.ptr(vox.sample_off), B, float(keep_frac), L.ptr(mask),
+               L.ptr(len_keep), st)
+    else:
+        mask = torch.zeros(max(M, 1), dtype=torch.float32, device=dev)[:M]
+
+    # ---- stage-1 tokens = visible pillars
+    cap = max(M, 1)
+    Y, X = gy, gx
+    tok_pillar = _empty(cap, I32, dev)
+    tok_cell = _empty(cap, I32, dev)
+    smap = _empty(B * Y * X, I32, dev)
+    n_tok = _empty(1, I32, dev)
+    L.call("gdmae_visible_tokens", L.ptr(mask), L.ptr(vox.pillar_cell), L.ptr(vox.counts), M, B * Y * X,
+           L.ptr(tok_pillar), L.ptr(tok_cell), L.ptr(smap), L.ptr(n_tok), L.ptr(scan_ws), st)
+
+    raw = []   # per stage dict of capacity-sized tensors
+    prev = None
+    for si, stride in enumerate(strides):
+        if stride > 1:
+            assert stride == 2, "only the k3 s2 p1 strided sparse conv of the shipped configs is implemented"
+            Yi, Xi = Y, X
+            Y, X = (Yi - 1) // 2 + 1, (Xi - 1) // 2 + 1
+            cap_in = cap
+            cap = min(4 * cap_in, B * Y * X)
+            tok_cell_n = _empty(cap, I32, dev)
+            smap_n = _empty(B * Y * X, I32, dev)
+            n_tok_n = _empty(1, I32, dev)
+            flag = _empty(B * Y * X, I32, dev)
+            L.call("gdmae_downsample_tokens", L.ptr(n_tok), L.ptr(tok_cell), cap_in, B, Yi, Xi, L.ptr(tok_cell_n),
+                   L.ptr(smap_n), L.ptr(n_tok_n), L.ptr(flag), L.ptr(scan_ws), st)
+            nbr_down = _empty(cap * 9, I32, dev)
+            L.call("gdmae_rulebook", L.ptr(n_tok_n), L.ptr(tok_cell_n), cap, B, Y, X, Yi, Xi, L.ptr(smap), 1,
+                   L.ptr(nbr_down), st)
+            nbr_down_t = _empty(cap_in * 9, I32, dev)
+            L.call("gdmae_rulebook", L.ptr(n_tok), L.ptr(tok_cell), cap_in, B, Yi, Xi, Y, X, L.ptr(smap_n), 2,
+                   L.ptr(nbr_down_t), st)
+            tok_cell, smap, n_tok = tok_cell_n, smap_n, n_tok_n
+        else:
+            nbr_down = nbr_down_t = None
+        nbr_subm = _empty(cap * 9, I32, dev)
+        L.call("gdmae_rulebook", L.ptr(n_tok), L.ptr(tok_cell), cap, B, Y, X, Y, X, L.ptr(smap), 0, L.ptr(nbr_subm), st)
+        wx, wy, wz = (int(v) for v in window_shapes[si])
+        assert wz == 1
+        dlo, dhi, dT = _drop_arrays(drop_infos[si])
+        assert wx * wy <= max(dT), "token drop would not be the identity: unsupported (SURVEY header item 5)"
+        wsb = lib.gdmae_window_workspace_bytes(B, Y, X, wx, wy)
+        wins = []
+        for shifted in (0, 1):
+            nwin_cap = B * ((X + wx - 1) // wx + 1) * ((Y + wy - 1) // wy + 1)
+            w = dict(tok_win=_empty(cap, I32, dev), tok_level=_empty(cap, I32, dev), tok_slot=_empty(cap, I32, dev),
+                     tok_pos=_empty(cap, I32, dev), csr_tok=_empty(cap, I32, dev),
+                     win_start=_empty(min(nwin_cap, cap), I32, dev), win_len=_empty(min(nwin_cap, cap), I32, dev),
+                     counts=_empty(8, I32, dev), T=dT)
+            ws = _empty(wsb, torch.uint8, dev)
+            L.call("gdmae_window_partition", L.ptr(smap), B, Y, X, wx, wy, shifted, len(dT), L.host_i32(dlo),
+                   L.host_i32(dhi), L.host_i32(dT), L.ptr(w["tok_win"]), L.ptr(w["tok_level"]), L.ptr(w["tok_slot"]),
+                   L.ptr(w["tok_pos"]), L.ptr(w["csr_tok"]), L.ptr(w["win_start"]), L.ptr(w["win_len"]),
+                   L.ptr(w["counts"]), L.ptr(ws), wsb, st)
+            w["_ws"] = ws
+            wins.append(w)
+        raw.append(dict(B=B, Y=Y, X=X, cap=cap, tok_cell=tok_cell, map=smap, n_tok=n_tok, nbr_subm=nbr_subm,
+                        nbr_down=nbr_down, nbr_down_t=nbr_down_t, wins=wins, prev=prev))
+        prev = raw[-1]
+
+    # ---- the one host sync of this phase: all counts in one copy
+    allc = torch.cat([r["n_tok"] for r in raw] + [w["counts"] for r in raw for w in r["wins"]]).tolist()
+    ns = len(raw)
+    stages = []
+    for si, r in enumerate(raw):
+        n = int(allc[si])
+        wps = []
+        for k, w in enumerate(r["wins"]):
+            c = allc[ns + 8 * (2 * si + k): ns + 8 * (2 * si + k) + 8]
+            assert c[7] == n, (c, n)
+            nw = int(c[6])
+            wps.append(WindowPlan(w["tok_win"][:n], w["tok_level"][:n], w["tok_slot"][:n], w["tok_pos"][:n],
+                                  w["csr_tok"][:n], w["win_start"][:nw], w["win_len"][:nw],
+                                  [int(v) for v in c[0:3]], [int(v) for v in c[3:6]], list(w["T"])))
+        n_prev = int(allc[si - 1]) if r["nbr_down"] is not None else 0
+        stages.append(StagePlan(r["B"], r["Y"], r["X"], n, r["tok_cell"][:n], r["map"],
+                                r["nbr_subm"][:n * 9].view(n, 9),
+                                None if r["nbr_down"] is None else r["nbr_down"][:n * 9].view(n, 9),
+                                None if r["nbr_down_t"] is None else r["nbr_down_t"][:n_prev * 9].view(n_prev, 9),
+                                wps))
+    return EncoderPlan(mask if keep_frac is not None else None, tok_pillar[:stages[0].n_tok], stages)

@@ -1,0 +1,74 @@
+"""MAE pre-training backbone: masking -> SRA encoder on visible pillars -> generative decoder ->
+reconstruction targets + Chamfer loss.  Interface and parameter names follow the reference
+``SPTBackboneMAE`` (pcdet/models/backbones_3d/spt_backbone_mae.py:11-153); all index work, the sparse
+convolutions' gathers, the attention, the target grouping and the loss run in libgdmae_hip.so.
+"""
+import torch
+import torch.nn as nn
+
+from .spt_backbone import SSTBlockV1, build_decoder, run_decoder, stage_plan_args
+from ...utils.spconv_utils import SparseConvTensor
+from gdmae_hip import ops, plan as gplan
+
+
+class SPTBackboneMAE(nn.Module):
+    def __init__(self, model_cfg, input_channels, grid_size, voxel_size, point_cloud_range, **kwargs):
+        super().__init__()
+        self.model_cfg, self.grid_size, self.voxel_size, self.point_cloud_range = model_cfg, grid_size, voxel_size, point_cloud_range
+        self.sparse_shape = grid_size[[1, 0]]
+        self.mask_cfg = model_cfg.get('MASK_CONFIG', None)
+        self.mask_ratio = self.mask_cfg.RATIO if self.mask_cfg is not None else 0.0
+        c = input_channels
+        self.sst_blocks = nn.ModuleList()
+        for b in model_cfg.SST_BLOCK_LIST:
+            self.sst_blocks.append(SSTBlockV1(b, c, b.NAME))
+            c = b.ENCODER.D_MODEL
+        self.decoder_deblocks, self.decoder_conv_out, c = build_decoder(model_cfg)
+        self.decoder_pred = nn.Linear(c, self.mask_cfg.NUM_PRD_POINTS * 3, bias=True)
+        self.forward_ret_dict = {}
+        self.num_point_features = c
+
+    def get_loss(self, tb_dict=None):
+        tb_dict = {} if tb_dict is None else tb_dict
+        r = self.forward_ret_dict
+        return ops.ChamferLoss.apply(r['pred_points'], r['gt_points'], r['mask']), tb_dict
+
+    def forward(self, batch_dict):
+        """Inputs: DynVFE's ``voxel_features`` + the voxel plan.  Optional ``mae_noise`` (M,) injects the
+        masking noise (one value per pillar, samples concatenated) for bit-exact mask parity tests."""
+        vox = batch_dict['_gdmae_vox']
+        all_feat, all_coords = batch_dict['voxel_features'], batch_dict['voxel_coords']
+        ep = gplan.encoder_plan(vox, *stage_plan_args(self.model_cfg.SST_BLOCK_LIST),
+                                keep_frac=1 - self.mask_ratio, noise=batch_dict.get('mae_noise', None))
+        batch_dict['voxel_mae_mask'] = ep.mask
+        batch_dict['_gdmae_plan'] = ep
+        x = SparseConvTensor(ops.GatherUnique.apply(all_feat, ep.tok_pillar), ep, 0)
+        hidden = []
+        for blk in self.sst_blocks:
+            x = blk(x)
+            hidden.append(x)
+        feats, strides = {}, {}
+        Y0 = int(self.sparse_shape[0])
+        for i, h in enumerate(hidden):
+            feats[f'x_conv{i + 1}'] = h
+            strides[f'x_conv{i + 1}'] = Y0 // h.spatial_shape[0]
+        sf = run_decoder(self.model_cfg, self.decoder_deblocks, self.decoder_conv_out, hidden)   # (B, C, Y, X)
+        B, C, Y, X = sf.shape
+        assert B == batch_dict['batch_size'] and Y == self.grid_size[1] and X == self.grid_size[0]
+        src0 = self.model_cfg.FEATURES_SOURCE[0]
+        batch_dict.update({'encoded_spconv_tensor': hidden[-1], 'encoded_spconv_tensor_stride': Y0 // hidden[-1].spatial_shape[0],
+                           'multi_scale_3d_features': feats, 'multi_scale_3d_strides': strides, 'spatial_features': sf,
+                           'spatial_features_stride': strides[src0] // self.model_cfg.FUSE_LAYER[src0].UPSAMPLE_STRIDE})
+        # features of ALL pillars (masked and visible) gathered from the channels-last map
+        rows = sf.permute(0, 2, 3, 1).reshape(B * Y * X, C)
+        pyramid = ops.GatherUnique.apply(rows, vox.pillar_cell)
+        batch_dict.update({'voxel_features': pyramid, 'voxel_coords': all_coords,
+                           'voxel_shuffle_inds': torch.arange(all_coords.shape[0], device=all_coords.device)})
+        self.forward_ret_dict = self.target_assigner(batch_dict)
+        return batch_dict
+
+    def target_assigner(self, batch_dict):
+        vox = batch_dict['_gdmae_vox']
+        gt = ops.group_gt_points(vox, self.mask_cfg.NUM_GT_POINTS)         # (M, K, 3), centre-relative
+        pred = self.decoder_pred(batch_dict['voxel_features']).view(vox.M, -1, 3)
+        return {'pred_points': pred, 'gt_points': gt, 'mask': batch_dict['voxel_mae_mask']}

@@ -1,0 +1,44 @@
+"""Dynamic pillar VFE on the HIP voxelizer (interface of the reference ``DynVFE``,
+pcdet/models/backbones_3d/vfe/dyn_vfe.py:11-124; parameters ``dvfe_mlps.0.{0,1,3,4}``).
+
+forward: one ``gdmae_voxelize`` call (range filter, pillar table, canonical point CSR, per-pillar mean),
+one decoration kernel, the two Linear/BN/ReLU layers as token GEMMs, and a segmented max over the CSR.
+"""
+from functools import partial
+
+import torch
+import torch.nn as nn
+
+from .vfe_template import VFETemplate
+from ...model_utils.network_utils import make_fc_layers
+from gdmae_hip import ops, plan as gplan
+
+
+class DynVFE(VFETemplate):
+    def __init__(self, model_cfg, num_point_features, voxel_size, point_cloud_range, grid_size, **kwargs):
+        super().__init__(model_cfg=model_cfg)
+        self.sample_type = model_cfg.get('TYPE', 'mean')
+        mlps = model_cfg.get('MLPS', None)
+        if self.sample_type != 'mean' or mlps is None or len(mlps) != 1 or model_cfg.get('AGGREGATION_MLPS', None):
+            raise NotImplementedError("hot path: TYPE mean, one MLPS entry, no aggregation MLP (gd_mae_ssl.yaml:49-55)")
+        if model_cfg.WITH_DISTANCE or not model_cfg.USE_ABSLOTE_XYZ or not model_cfg.USE_CLUSTER_XYZ:
+            raise NotImplementedError("hot path: USE_ABSLOTE_XYZ and USE_CLUSTER_XYZ on, WITH_DISTANCE off")
+        self.with_distance, self.use_absolute_xyz, self.use_cluster_xyz = False, True, True
+        norm_fn = partial(nn.BatchNorm1d, eps=1e-3, momentum=0.01)
+        self.dvfe_mlps = nn.ModuleList([make_fc_layers(mlps[0], num_point_features + 6, norm_fn=norm_fn)])
+        self.aggregation_mlp = None
+        self.num_point_features = mlps[0][-1]
+        self.voxel_size, self.point_cloud_range, self.grid_size = voxel_size, point_cloud_range, grid_size
+
+    def get_output_feature_dim(self):
+        return self.num_point_features
+
+    def forward(self, batch_dict, **kwargs):
+        vox = gplan.voxelize(batch_dict['points'], self.point_cloud_range, self.voxel_size, self.grid_size,
+                             int(batch_dict['batch_size']))
+        x = self.dvfe_mlps[0](ops.decorate_points(vox))
+        x = ops.SegmentMax.apply(x.float(), vox.pt_off, vox.pillar_pts, vox.inverse32)
+        batch_dict.update({'points': vox.points, 'point_coords': vox.point_coords,
+                           'point_inverse_indices': vox.inverse, 'voxel_coords': vox.voxel_coords,
+                           'pillar_features': x, 'voxel_features': x, '_gdmae_vox': vox})
+        return batch_dict

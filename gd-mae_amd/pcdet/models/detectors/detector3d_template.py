@@ -1,0 +1,106 @@
+"""Model-builder subset of the reference ``Detector3DTemplate``
+(pcdet/models/detectors/detector3d_template.py:14-100, 361-442): the ``module_topology`` walk with the
+same keyword calls into the name->class registries, ``global_step``, and checkpoint loading by
+key+shape.  Builders for modules outside the GD-MAE pre-training path return ``None`` unless their yaml
+section is present, in which case they raise (nothing is silently skipped)."""
+import os
+
+import torch
+import torch.nn as nn
+
+from .. import backbones_3d
+from ..backbones_3d import vfe
+
+
+class Detector3DTemplate(nn.Module):
+    def __init__(self, model_cfg, num_class, dataset, logger):
+        super().__init__()
+        self.model_cfg, self.num_class, self.dataset, self.logger = model_cfg, num_class, dataset, logger
+        self.class_names = dataset.class_names
+        self.register_buffer('global_step', torch.LongTensor(1).zero_())
+        self.module_topology = ['img_backbone', 'vfe', 'backbone_3d', 'map_to_bev_module', 'pfe', 'backbone_2d',
+                                'dense_head', 'point_head', 'roi_head']
+        self._cfg_key = {'img_backbone': 'IMG_BACKBONE', 'vfe': 'VFE', 'backbone_3d': 'BACKBONE_3D',
+                         'map_to_bev_module': 'MAP_TO_BEV', 'pfe': 'PFE', 'backbone_2d': 'BACKBONE_2D',
+                         'dense_head': 'DENSE_HEAD', 'point_head': 'POINT_HEAD', 'roi_head': 'ROI_HEAD'}
+
+    @property
+    def mode(self):
+        return 'TRAIN' if self.training else 'TEST'
+
+    def update_global_step(self):
+        self.global_step += 1
+
+    def build_networks(self):
+        info = {'module_list': [], 'num_rawpoint_features': self.dataset.point_feature_encoder.num_point_features,
+                'num_point_features': self.dataset.point_feature_encoder.num_point_features,
+                'grid_size': self.dataset.grid_size, 'point_cloud_range': self.dataset.point_cloud_range,
+                'voxel_size': self.dataset.voxel_size}
+        for name in self.module_topology:
+            builder = getattr(self, 'build_%s' % name, None)
+            if builder is None:
+                if self.model_cfg.get(self._cfg_key[name], None) is not None:
+                    raise NotImplementedError(f"{self._cfg_key[name]} is outside the GD-MAE pre-training hot path")
+                module = None
+            else:
+                module, info = builder(model_info_dict=info)
+            self.add_module(name, module)
+        return info['module_list']
+
+    def build_vfe(self, model_info_dict):
+        if self.model_cfg.get('VFE', None) is None:
+            return None, model_info_dict
+        m = vfe.__all__[self.model_cfg.VFE.NAME](
+            model_cfg=self.model_cfg.VFE, num_point_features=model_info_dict['num_rawpoint_features'],
+            point_cloud_range=model_info_dict['point_cloud_range'], voxel_size=model_info_dict['voxel_size'],
+            grid_size=model_info_dict['grid_size'])
+        model_info_dict['num_point_features'] = m.get_output_feature_dim()
+        model_info_dict['module_list'].append(m)
+        return m, model_info_dict
+
+    def build_backbone_3d(self, model_info_dict):
+        if self.model_cfg.get('BACKBONE_3D', None) is None:
+            return None, model_info_dict
+        m = backbones_3d.__all__[self.model_cfg.BACKBONE_3D.NAME](
+            model_cfg=self.model_cfg.BACKBONE_3D, input_channels=model_info_dict['num_point_features'],
+            grid_size=model_info_dict['grid_size'], voxel_size=model_info_dict['voxel_size'],
+            point_cloud_range=model_info_dict['point_cloud_range'])
+        model_info_dict['module_list'].append(m)
+        model_info_dict['num_point_features'] = m.num_point_features
+        model_info_dict['backbone_channels'] = getattr(m, 'backbone_channels', None)
+        return m, model_info_dict
+
+    def forward(self, **kwargs):
+        raise NotImplementedError
+
+    # ---- checkpoints (reference-compatible dict: model_state / optimizer_state / epoch / it / version)
+    def _load_state_dict(self, model_state_disk, *, strict=True):
+        state_dict = self.state_dict()
+        update = {k: v for k, v in model_state_disk.items() if k in state_dict and state_dict[k].shape == v.shape}
+        if strict:
+            self.load_state_dict(model_state_disk)
+        else:
+            state_dict.update(update)
+            self.load_state_dict(state_dict)
+        return state_dict, update
+
+    def load_params_from_file(self, filename, logger, to_cpu=False):
+        if not os.path.isfile(filename):
+            raise FileNotFoundError(filename)
+        ckpt = torch.load(filename, map_location=torch.device('cpu') if to_cpu else None)
+        disk = ckpt['model_state']
+        logger.info('==> Loading parameters from checkpoint %s (version %s)' % (filename, ckpt.get('version', None)))
+        state_dict, update = self._load_state_dict(disk, strict=False)
+        for k in state_dict:
+            if k not in update:
+                logger.info('Not updated weight %s: %s' % (k, str(state_dict[k].shape)))
+        logger.info('==> Done (loaded %d/%d)' % (len(update), len(state_dict)))
+
+    def load_params_with_optimizer(self, filename, to_cpu=False, optimizer=None, logger=None):
+        if not os.path.isfile(filename):
+            raise FileNotFoundError(filename)
+        ckpt = torch.load(filename, map_location=torch.device('cpu') if to_cpu else None)
+        self._load_state_dict(ckpt['model_state'], strict=True)
+        if optimizer is not None and ckpt.get('optimizer_state', None) is not None:
+            optimizer.load_state_dict(ckpt['optimizer_state'])
+        return ckpt.get('it', 0.0), ckpt.get('epoch', -1)

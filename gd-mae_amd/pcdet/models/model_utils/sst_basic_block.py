@@ -1,0 +1,57 @@
+"""Encoder layer stack with the reference's module tree (pcdet/models/model_utils/sst_basic_block.py):
+``BasicShiftBlockV2.encoder_list[k]`` = post-norm ``EncoderLayer`` with ``win_attn.self_attn``,
+``linear1/linear2``, ``norm1/norm2``; layer 0 uses the un-shifted window partition, layer 1 the
+shifted one (:100-114)."""
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .cosine_msa import CosineMultiheadAttention
+
+
+class WindowAttention(nn.Module):
+    def __init__(self, d_model, nhead, dropout, batch_first=False, layer_cfg=None):
+        super().__init__()
+        layer_cfg = layer_cfg or {}
+        if not layer_cfg.get('cosine', False):
+            raise NotImplementedError("GD-MAE uses LAYER_CFG.cosine = True")
+        self.nhead = nhead
+        self.self_attn = CosineMultiheadAttention(d_model, nhead, dropout=dropout, tau_min=layer_cfg.get('tau_min', 0.01),
+                                                  non_shared_tau=layer_cfg.get('non_shared_tau', False))
+
+    def forward(self, feat_2d, pos, wplan):
+        return self.self_attn(feat_2d, pos, wplan)
+
+
+class EncoderLayer(nn.Module):
+    def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1, activation="relu", batch_first=False,
+                 mlp_dropout=0, layer_cfg=None):
+        super().__init__()
+        if mlp_dropout != 0:
+            raise NotImplementedError
+        self.win_attn = WindowAttention(d_model, nhead, dropout, layer_cfg=layer_cfg)
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+        if activation not in ("gelu", "relu"):
+            raise RuntimeError(f"activation should be relu/gelu, not {activation}.")
+        self.activation = F.gelu if activation == "gelu" else F.relu
+
+    def forward(self, src, pos, wplan):
+        src = self.norm1(src + self.win_attn(src, pos, wplan))
+        return self.norm2(src + self.linear2(self.activation(self.linear1(src))))
+
+
+class BasicShiftBlockV2(nn.Module):
+    def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1, activation="relu", batch_first=False,
+                 layer_cfg=None):
+        super().__init__()
+        self.encoder_list = nn.ModuleList([
+            EncoderLayer(d_model, nhead, dim_feedforward, dropout, activation, batch_first, layer_cfg=layer_cfg)
+            for _ in range(2)])
+
+    def forward(self, src, pos_list, wplan_list):
+        for i, layer in enumerate(self.encoder_list):
+            k = i % len(wplan_list)
+            src = layer(src, pos_list[k], wplan_list[k])
+        return src

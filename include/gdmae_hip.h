@@ -1,0 +1,164 @@
+/* gdmae_hip.h - C ABI of libgdmae_hip.so: the MI355X (gfx950) native implementation of the GD-MAE
+ * pre-training hot path.  Plain pointers and sizes only; no torch types.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless the parameter is documented "host";
+ *  - `stream` is a hipStream_t (pass torch.cuda.current_stream().cuda_stream); every launch goes to it,
+ *    nothing synchronises with the host, nothing allocates: all scratch is caller provided;
+ *  - return value 0 = ok, non-zero = failure (hipError_t value or -1 for a violated precondition);
+ *    gdmae_last_error() returns a thread-local description.  The library never calls exit()
+ *    (the reference's wrappers do: pcdet/ops/sst_ops/src/sst_ops.cpp:7-19);
+ *  - element counts that are data dependent (pillars, tokens, windows) are produced ON THE DEVICE in
+ *    small int32 `counts` arrays; the host reads them once per step after the whole geometry plan has
+ *    been enqueued (one D2H copy instead of the reference's dozens of .item() syncs);
+ *  - "canonical order" = ascending original index; it replaces the atomic arrival order
+ *    of the reference kernels (pcdet/ops/sst_ops/src/sst_ops_gpu.cu:14-28) and makes results deterministic.
+ *
+ * The reference's FFI for this path is the pybind11 module pcdet.ops.sst_ops.sst_ops_cuda
+ * (pcdet/ops/sst_ops/src/sst_ops_api.cpp:6-9: ingroup_inds_wrapper, group_inner_inds_wrapper) plus three
+ * un-vendored GPU libraries reached from Python (spconv, torch_scatter, pytorch3d).  Each entry point
+ * below names the reference interface it replaces.  INTEGRATION.md shows the binding a maintainer adds.
+ */
+#ifndef GDMAE_HIP_H
+#define GDMAE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- housekeeping --------------------------------------------------------------------------- */
+int gdmae_abi_version(void);
+const char* gdmae_target_arch(void); /* "gfx950" */
+const char* gdmae_last_error(void);
+
+/* ---- a1-a3, a17(rank): dynamic pillar voxelisation ------------------------------------------ *
+ * Replaces: common_utils.get_in_range_mask (pcdet/utils/common_utils.py:66-76), the coord build and
+ * coords.unique(dim=0, return_inverse=True) of DynVFE.forward (pcdet/models/backbones_3d/vfe/dyn_vfe.py:62-68),
+ * torch_scatter.scatter(reduce='mean') (dyn_vfe.py:81) and the in-pillar rank that
+ * group_inner_inds_kernel derives from atomics (sst_ops_gpu.cu:22-28).
+ *
+ * points        (n_points, n_cols) fp32 rows [batch_idx, x, y, z, f...]; n_cols = 1 + F.
+ * lo, vs        HOST float[3]: point_cloud_range[:3], voxel_size.      grid_xyz  HOST int[3] = (X, Y, Z).
+ * Outputs (capacity in elements; N = kept points, M = pillars, both <= n_points):
+ *   points_out (n_points*n_cols)  kept rows in original order          point_coords (n_points*4) int64 [b,z,y,x]
+ *   inverse (n_points) int64, inverse32 (n_points) int32  pillar id of each kept point
+ *   voxel_coords (n_points*4) int64 [b,z,y,x], lexicographically ascending (= torch.unique(dim=0) order)
+ *   pillar_cell (n_points) int32  linear cell key ((b*Z+z)*Y+y)*X+x of each pillar
+ *   pillar_pt_off (n_points+1) int32 CSR offsets; pillar_pts (n_points) int32 kept-point ids grouped by
+ *   pillar, ascending inside a pillar; point_rank (n_points) int32 rank of each kept point in its pillar
+ *   sample_pillar_off (batch_size+1) int32 first pillar of every sample
+ *   pillar_mean (n_points*F) fp32 per-pillar mean of [x,y,z,f...] accumulated in canonical order
+ *   cell2pillar (B*Z*Y*X) int32 dense map cell -> pillar id or -1 (may be NULL: kept in the workspace)
+ *   counts int32[2] = {N, M}
+ * workspace: gdmae_voxelize_workspace_bytes(...) bytes. */
+size_t gdmae_voxelize_workspace_bytes(long long n_points, int batch_size, int gx, int gy, int gz);
+int gdmae_voxelize(const float* points, long long n_points, int n_cols, const float* lo, const float* vs,
+                   const int* grid_xyz, int batch_size, float* points_out, long long* point_coords,
+                   long long* inverse, int* inverse32, long long* voxel_coords, int* pillar_cell,
+                   int* pillar_pt_off, int* pillar_pts, int* point_rank, int* sample_pillar_off,
+                   float* pillar_mean, int* cell2pillar, int* counts, void* workspace, size_t workspace_bytes,
+                   void* stream);
+
+/* ---- a4: point decoration, segmented max ---------------------------------------------------- *
+ * gdmae_decorate_points replaces dyn_vfe.py:85-105 ([xyz - centre, xyz+feat, xyz - mean], 6+F channels).
+ * gdmae_segment_max[_bwd] replaces torch_scatter.scatter_max (dyn_vfe.py:109): out (M,C), arg (M,C) =
+ * kept-point id of the maximum (lowest id on ties); backward routes dout to the arg-max row only. */
+int gdmae_decorate_points(const float* points, const long long* point_coords, const int* inverse32,
+                          const float* pillar_mean, long long N, int n_cols, const float* lo, const float* vs,
+                          float* out, void* stream);
+int gdmae_segment_max(const float* x, const int* pillar_pt_off, const int* pillar_pts, int M, int C, float* out,
+                      int* arg, void* stream);
+int gdmae_segment_max_bwd(const float* dout, const int* arg, const int* inverse32, long long N, int C, float* dx,
+                          void* stream);
+
+/* ---- a5: MAE random masking ------------------------------------------------------------------ *
+ * Replaces common_utils.random_masking (common_utils.py:49-63) and the per-sample loop with a host sync
+ * per sample (pcdet/models/backbones_3d/spt_backbone_mae.py:96-100).  noise: one fp32 per pillar;
+ * keep_frac = (1 - RATIO) evaluated by the caller in fp64; len_keep = (int)(L * keep_frac) per sample.
+ * mask_out (M) fp32: 0 = visible (the len_keep smallest noise values, ties -> lower index), 1 = masked. */
+int gdmae_random_mask(const float* noise, const int* sample_pillar_off, int batch_size, double keep_frac,
+                      float* mask_out, int* len_keep_out, void* stream);
+
+/* ---- a6 (index side): token sets and sparse-conv rulebooks ----------------------------------- *
+ * Replace spconv's hash-table rulebook construction for SubMConv2d(k3) / SparseConv2d(k3,s2,p1)
+ * (call sites pcdet/utils/spconv_utils.py:41-43; spt_backbone.py:206,217) and the boolean-mask
+ * compaction features[mask == 0] (spt_backbone_mae.py:102-107).
+ * A token set = ascending linear cell keys tok_cell[] ((b*Y+y)*X+x) + dense map cell -> token (-1 empty).
+ * gdmae_visible_tokens: stage-1 tokens = pillars with mask == 0.   vox_counts = counts of gdmae_voxelize.
+ * gdmae_downsample_tokens: output active set of a k3 s2 p1 sparse conv (site o active iff an active
+ *   input 2*o-1+k exists), ordered by linear key at the output resolution (Yo = (Yi-1)/2+1).
+ * gdmae_rulebook: nbr[t*9+k] = token feeding t through tap k=ky*3+kx or -1;
+ *   mode 0 submanifold, 1 strided forward (map = input map), 2 strided transposed (map = output map). */
+int gdmae_visible_tokens(const float* mask, const int* pillar_cell, const int* vox_counts, long long m_cap,
+                         long long n_cells, int* tok_pillar, int* tok_cell, int* map, int* n_tok, void* scan_ws,
+                         void* stream);
+int gdmae_downsample_tokens(const int* n_in, const int* tok_cell_in, long long cap_in, int B, int Yi, int Xi,
+                            int* tok_cell_out, int* map_out, int* n_out, int* flag_ws, void* scan_ws, void* stream);
+int gdmae_rulebook(const int* n_tok, const int* tok_cell, long long cap, int B, int Yt, int Xt, int Ym, int Xm,
+                   const int* map, int mode, int* nbr, void* stream);
+
+/* ---- a7-a10: shifted-window partition --------------------------------------------------------- *
+ * Replaces get_window_coors (pcdet/models/model_utils/sst_utils.py:6-47), get_inner_win_inds ->
+ * ingroup_inds_kernel (sst_ops_gpu.cu:14-20), drop_single_shift (spt_backbone.py:32-51),
+ * make_continuous_inds / get_flat2win_inds (sst_utils.py:50-104).
+ * Per token (capacity = tokens): tok_win = batch_win_inds, tok_level = drop level, tok_slot = flat2window
+ * index inside the level (dense_window * max_tokens + canonical rank), tok_pos = in-window cell y*wx+x.
+ * Window lists ordered by (level, dense index): win_start/win_len into csr_tok (tokens of a window,
+ * canonical order).  counts int32[8]: [0..2] windows per level, [3..5] tokens per level, [6],[7] totals. */
+size_t gdmae_window_workspace_bytes(int B, int Y, int X, int wx, int wy);
+int gdmae_window_partition(const int* map, int B, int Y, int X, int wx, int wy, int shifted, int nlev,
+                           const int* drop_lo, const int* drop_hi, const int* max_tokens, int* tok_win,
+                           int* tok_level, int* tok_slot, int* tok_pos, int* csr_tok, int* win_start, int* win_len,
+                           int* counts, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- a6/a16 data movement: row gather / scatter ----------------------------------------------- *
+ * gdmae_gather_rows: out[s,:] = idx[s] >= 0 ? src[idx[s],:] : 0  (rulebook im2col with n_slots = tokens*9,
+ *   gather of decoder features at pillar sites: spt_backbone_mae.py:141-143).
+ * gdmae_scatter_rows: dst[idx[r],:] = src[r,:] (SparseConvTensor.dense(): spt_backbone_mae.py:128).
+ * row_bytes must be a multiple of 16; dtype agnostic. */
+int gdmae_gather_rows(const void* src, const int* idx, long long n_slots, int row_bytes, void* out, void* stream);
+int gdmae_scatter_rows(const void* src, const int* idx, long long n_rows, int row_bytes, void* dst, void* stream);
+
+/* ---- a11, a13: windowed cosine attention ------------------------------------------------------ *
+ * Replaces flat2window_v2/window2flat_v2 (sst_utils.py:107-180), WindowAttention.forward
+ * (pcdet/models/model_utils/sst_basic_block.py:22-54) and _scaled_cosine_attention
+ * (pcdet/models/model_utils/cosine_msa.py:114-176) for ONE occupancy level (T = 16/32/64 padded tokens).
+ * qk (Ms, 2d): projected queries [0,d) and keys [d,2d); v (Ms, d); out (Ms, d) written at token rows.
+ * Backward: dqk (Ms,2d), dv (Ms,d), dtau_part: n_win*H/(64/T) partials of d loss / d clamp(tau). */
+int gdmae_window_attention_fwd(const float* qk, const float* v, float* out, const int* csr_tok, const int* win_start,
+                               const int* win_len, int n_win, int T, int d, int H, const float* tau, float tau_min,
+                               void* stream);
+int gdmae_window_attention_bwd(const float* qk, const float* v, const float* dout, float* dqk, float* dv,
+                               float* dtau_part, const int* csr_tok, const int* win_start, const int* win_len,
+                               int n_win, int T, int d, int H, const float* tau, float tau_min, void* stream);
+int gdmae_sum_partials(const float* part, long long n, float scale, float* out, int accumulate, void* stream);
+
+/* ---- a17-a19: reconstruction targets and Chamfer loss ----------------------------------------- *
+ * gdmae_group_gt_points replaces sst_ops_cuda.group_inner_inds_wrapper (sst_ops_api.cpp:8;
+ * sst_ops_gpu.cu:22-39) + points[group_inds] + get_voxel_centers (common_utils.py:130-145):
+ *   gt_points (M,K,3) = xyz of the first min(cnt,K) points of the pillar (canonical order, cyclic pad)
+ *   minus the pillar centre; gt_index (M,K) int32 optional.
+ * gdmae_chamfer replaces pytorch3d.loss.chamfer_distance(pred, gt, weights) (spt_backbone_mae.py:88):
+ *   term[m] = w_m ((1/P1) sum_i min_j |x_i-y_j|^2 + (1/P2) sum_j min_i |x_i-y_j|^2), dpred = d term / d pred.
+ *   loss = sum(term) / sum(w). */
+int gdmae_group_gt_points(const float* points, int n_cols, const int* pillar_pt_off, const int* pillar_pts,
+                          const long long* voxel_coords, int M, int K, const float* lo, const float* vs,
+                          float* gt_points, int* gt_index, void* stream);
+int gdmae_chamfer(const float* pred, const float* gt, const float* weights, int M, int P1, int P2, float* term,
+                  float* dpred, void* stream);
+
+/* ---- a21: fused optimizer step over one flat buffer ------------------------------------------- *
+ * Replaces clip_grad_norm_ (tools/train_utils/train_utils.py:52) and OptimWrapper.step
+ * (tools/train_utils/optimization/fastai_optim.py:135-152: p *= 1 - wd*lr, then torch Adam). */
+int gdmae_grad_sq_norm(const float* grad, long long n, float* partials /* >= 1024 */, float* sq_norm_out, void* stream);
+int gdmae_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr,
+                    float beta1, float beta2, float eps, float weight_decay, int step, float max_norm,
+                    const float* sq_norm, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GDMAE_HIP_H */
