@@ -1,0 +1,204 @@
+#!/usr/bin/env python
+"""GD-MAE pre-training throughput on MI355X: frames/s of the full training step (forward, backward,
+gradient all-reduce, global-norm clip, fused Adam) on synthetic Waymo-shape clouds.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One process per GPU; frames are sharded across ranks (weak scaling: --batch-per-gpu frames each), the only
+collective is one all-reduce of the flat 32 MB gradient buffer per step (RCCL over xGMI).  Rank 0 prints
+ONE JSON line.  Inputs are resident in HBM when the timed region starts (the PCIe-inclusive rate is
+reported separately under "h2d_inclusive").
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import logging
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+for p in (REPO, os.path.join(REPO, "gd-mae_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+MFMA_BF16_PEAK_TF = 2500.0  # dense bf16
+MFMA_F32_PEAK_TF = 157.3
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch-per-gpu", type=int, default=8, help="frames per GPU per step (gd_mae_ssl.yaml:184)")
+    ap.add_argument("--config", default="B", choices=["A", "B", "E"])
+    ap.add_argument("--mask-ratio", type=float, default=0.75)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--pool", type=int, default=3, help="distinct pre-generated batches cycled through")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def algorithmic_bytes_per_frame(N, M, Ms, ds, G, a):
+    """BYTES_FWD of SURVEY.md §8(d) (S1..S5); BYTES_TRAIN = 3 x BYTES_FWD."""
+    F = 5
+    s1 = N * (1 + F) * 4 + N * 4 + M * (16 + 4 * F)
+    s2 = 3 * (N * (1 + F) * 4 + N * 4) + M * 128 * a
+    s3 = sum(4 * 10 * m * d * a for m, d in zip(Ms, ds))
+    cin = [128] + list(ds[:-1])
+    s3 += sum((mi * ci + mo * co) * a for mi, ci, mo, co in zip([Ms[0]] + list(Ms[:-1]), cin, Ms, ds))   # conv_down
+    s3 += sum(2 * m * d * a for m, d in zip(Ms, ds))                                                       # conv_out
+    s4 = 2208 * G * a
+    s5 = M * (128 + 48) * a + N * 12 + 2 * M * 64 * 12
+    return s1 + s2 + s3 + s4 + s5
+
+
+def measure_cpu_baseline(config: str, mask_ratio: float):
+    """The CPU oracle (oracle/gdmae_oracle.py + oracle/optim_oracle.py: the reference algorithm restated in
+    PyTorch fp32, validated against the imported reference modules) timed on this box's host cores on ONE
+    frame of the same workload: forward + backward + optimizer step."""
+    from gdmae_hip import configs, synth
+    from oracle import gdmae_oracle as orc
+    from oracle import optim_oracle as oo
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg, ds, skw = configs.named_config(config, mask_ratio=mask_ratio)
+    F = ds.point_feature_encoder.num_point_features
+    pts = torch.from_numpy(synth.synth_batch(424242, 1, ds.point_cloud_range, **skw))
+    sd = orc.seeded_state_dict(orc.param_shapes(cfg, F), seed=1, requires_grad=True)
+    names = sorted(sd)
+    opt = oo.AdamOneCycle([sd[k] for k in names])
+    t0 = time.perf_counter()
+    o = orc.forward(pts, 1, cfg, sd, ds.point_cloud_range, ds.voxel_size, ds.grid_size, noise_seed=0)
+    o["loss"].backward()
+    opt.step(*oo.one_cycle(0, 100, 0.003, [0.95, 0.85], 10, 0.4))
+    dt = time.perf_counter() - t0
+    return {"value": round(1.0 / dt, 4), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"1 frame of config {config} ({pts.shape[0]} pts), full train step fwd+bwd+Adam in fp32, {dt:.1f} s, "
+                      f"torch.set_num_threads({cores})"}
+
+
+def measure_roofline(net, opt, step, dev_batches, args, use_bf16):
+    return None
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)   # nccl == RCCL on ROCm
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+
+    from gdmae_hip import configs, optim, synth
+    from pcdet.models import build_network
+
+    cfg, ds, skw = configs.named_config(args.config, mask_ratio=args.mask_ratio)
+    torch.manual_seed(1234)                       # identical initial weights on every rank
+    net = build_network(cfg, len(ds.class_names), ds, logging.getLogger("bench")).to(dev).train()
+    net.sync_loss_scalar = False                  # keep the loss on the device: no per-step host sync
+    total_steps = args.warmup + args.steps + 1
+    opt = optim.FlatAdamOneCycle(net, configs.optimization_cfg(args.batch_per_gpu), total_steps=total_steps)
+    n_params = opt.n
+
+    # synthetic frames: frame f of rank r uses seed 1000 * r + f; pool of distinct batches, resident in HBM
+    B = args.batch_per_gpu
+    host_batches = [synth.synth_batch(100000 * rank + 97 * k, B, ds.point_cloud_range, **skw) for k in range(args.pool)]
+    pinned = [torch.from_numpy(b).pin_memory() for b in host_batches]
+    dev_batches = [p.to(dev, non_blocking=True) for p in pinned]
+    torch.cuda.synchronize()
+    use_bf16 = args.dtype == "bf16"
+
+    def step(i, pts):
+        opt.zero_grad()
+        bd = {"points": pts, "batch_size": B}
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=use_bf16):
+            ret, tb, _ = net(bd)
+        ret["loss"].backward()
+        opt.all_reduce_grads()
+        opt.step(i)
+        return ret["loss"], bd
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        loss, bd = step(i, dev_batches[i % args.pool])
+    sync_all()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss, bd = step(args.warmup + i, dev_batches[i % args.pool])
+    sync_all()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    frames = B * world * args.steps
+    fps = frames / dt
+    final_loss = float(loss.detach())
+    assert np.isfinite(final_loss), "training diverged"
+
+    out = {"metric": "MAE pre-train frames/sec (Waymo-shape, 180k pts, 75% mask)", "value": round(fps, 2),
+           "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+           "config": {"workload": f"config {args.config}: synthetic Waymo-shape clouds ~180k pts x5 feat, 0.32 m pillars (468x468), "
+                                  f"GD-MAE SRA encoder 128/256/256 x12 layers + generative decoder, mask {args.mask_ratio}, "
+                                  f"full train step (fwd+bwd+grad all-reduce+clip+Adam)" if args.config == "B" else f"config {args.config}",
+                      "frames_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
+                      "params": n_params, "mask_ratio": args.mask_ratio, "loss_last": round(final_loss, 5)}}
+
+    if rank == 0:
+        # ---- sizes of the last batch (for the algorithmic byte model)
+        vox, ep = bd["_gdmae_vox"], bd["_gdmae_plan"]
+        N, M = vox.N / B, vox.M / B
+        Ms = [s.n_tok / B for s in ep.stages]
+        dsz = [int(b.ENCODER.D_MODEL) for b in cfg.BACKBONE_3D.SST_BLOCK_LIST]
+        G = int(ds.grid_size[0]) * int(ds.grid_size[1])
+        a = 2 if use_bf16 else 4
+        bytes_train = 3 * algorithmic_bytes_per_frame(N, M, Ms, dsz, G, a)
+        out["config"].update({"points_per_frame": int(N), "pillars_per_frame": int(M), "tokens_per_frame": [int(m) for m in Ms]})
+        out["step_bytes_model"] = {"bytes_train_per_frame": int(bytes_train), "achieved_GBs": round(bytes_train * fps / world / 1e9, 1),
+                                   "frac_of_8TBs": round(bytes_train * fps / world / 1e9 / HBM_PEAK_GBS, 4),
+                                   "note": "SURVEY §8d whole-step algorithmic bytes x frames/s per GPU"}
+        if not args.no_roofline:
+            out["roofline"] = measure_roofline(net, opt, step, dev_batches, args, use_bf16)
+        # ---- PCIe-inclusive variant (host buffers handed over every step); never the headline value
+        sync_all_local = torch.cuda.synchronize
+        sync_all_local()
+        if world == 1:
+            t1 = time.perf_counter()
+            k = max(3, args.steps // 4)
+            for i in range(k):
+                step(args.warmup + args.steps, pinned[i % args.pool].to(dev, non_blocking=True))
+            sync_all_local()
+            out["h2d_inclusive"] = {"value": round(B * k / (time.perf_counter() - t1), 2), "unit": "frames/s"}
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = measure_cpu_baseline(args.config, args.mask_ratio)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
