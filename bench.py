@@ -88,8 +88,25 @@ def measure_cpu_baseline(config: str, mask_ratio: float):
                       f"torch.set_num_threads({cores})"}
 
 
-def measure_roofline(net, opt, step, dev_batches, args, use_bf16):
-    return None
+def measure_roofline(step, dev_batches, args, n_steps=4):
+    """HIP-event timing of the dominant kernel over `n_steps` extra steps (after the timed region).
+
+    Dominant kernel of the step (profiles/r01_*_kernel_stats*.csv): k_win_attn_bwd, the windowed cosine
+    attention backward - HBM bound: per token it must read the q, k, v and dOut rows and write the dq, dk, dv
+    rows (7 x d fp32) exactly once; algorithmic bytes per launch = tokens_of_level * (28 d + 4) + 8 * windows
+    (DESIGN.md 'Kernels').  achieved = sum(bytes) / sum(duration) over all its launches."""
+    from gdmae_hip import timing
+    with timing.collect() as T:
+        for i in range(n_steps):
+            step(args.warmup + args.steps, dev_batches[i % args.pool])
+        summ = T.summary()
+    k = summ["k_win_attn_bwd"]
+    gbs = k["total_bytes"] / (k["total_ms"] * 1e-3) / 1e9
+    return {"kernel": "k_win_attn_bwd", "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "launches_per_step": k["launches"] / n_steps,
+            "avg_launch_us": round(k["avg_us"], 2), "algorithmic_bytes_per_launch": int(k["bytes_per_launch"]),
+            "also": {n: {"avg_us": round(v["avg_us"], 2), "GBs": round(v["total_bytes"] / (v["total_ms"] * 1e-3) / 1e9, 1)}
+                     for n, v in summ.items() if n != "k_win_attn_bwd"}}
 
 
 def main():
@@ -181,7 +198,7 @@ def main():
                                    "frac_of_8TBs": round(bytes_train * fps / world / 1e9 / HBM_PEAK_GBS, 4),
                                    "note": "SURVEY §8d whole-step algorithmic bytes x frames/s per GPU"}
         if not args.no_roofline:
-            out["roofline"] = measure_roofline(net, opt, step, dev_batches, args, use_bf16)
+            out["roofline"] = measure_roofline(step, dev_batches, args)
         # ---- PCIe-inclusive variant (host buffers handed over every step); never the headline value
         sync_all_local = torch.cuda.synchronize
         sync_all_local()

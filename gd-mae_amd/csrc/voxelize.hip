@@ -296,3 +296,134 @@ extern "C" int gdmae_voxelize(const float* points, long long n_points, int n_col
   }
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Drop-in equivalents of the reference's own native op API for this path (pybind module
+// pcdet.ops.sst_ops.sst_ops_cuda, pcdet/ops/sst_ops/src/sst_ops_api.cpp:6-9), for arbitrary group ids:
+//   ingroup_inds_wrapper(group_inds, out_inds)        -> gdmae_ingroup_inds
+//   group_inner_inds_wrapper(inverse_inds, group_inds) -> gdmae_group_inner_inds
+// Same outputs as sst_ops_gpu.cu:14-39 evaluated sequentially (canonical ascending-index order instead
+// of atomic arrival order), the counter scratch is caller provided, launches go to the caller's stream,
+// and failures are returned instead of exit(-1).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_group_count(const long long* __restrict__ gid, long long n, long long n_groups,
+                                                     int* __restrict__ cnt, int* __restrict__ bad) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    long long g = gid[i];
+    if (g < 0 || g >= n_groups) {
+      *bad = 1;
+      continue;
+    }
+    atomicAdd(&cnt[g], 1);
+  }
+}
+struct CntLoad {
+  const int* cnt;
+  __device__ int operator()(long long g) const { return cnt[g]; }
+};
+struct OffStore {
+  int* off;
+  __device__ void operator()(long long g, int ex, int) const { off[g] = ex; }
+};
+__global__ void k_group_finalize(const int* total, long long n_groups, int* off, int* counts) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    off[n_groups] = *total;
+    counts[0] = *total;
+    counts[1] = (int)n_groups;
+  }
+}
+__global__ __launch_bounds__(256) void k_group_fill(const long long* __restrict__ gid, long long n, long long n_groups,
+                                                    const int* __restrict__ off, int* __restrict__ cnt,
+                                                    int* __restrict__ csr_raw) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    long long g = gid[i];
+    if (g < 0 || g >= n_groups) continue;
+    int slot = atomicSub(&cnt[g], 1) - 1;
+    csr_raw[off[g] + slot] = (int)i;
+  }
+}
+__global__ __launch_bounds__(256) void k_rank_to_i64(const int* __restrict__ rank, long long n, long long* __restrict__ out) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    out[i] = rank[i];
+}
+__global__ __launch_bounds__(256) void k_group_inner(const int* __restrict__ off, const int* __restrict__ csr, long long M,
+                                                     int K, long long* __restrict__ group_inds) {
+  const long long total = M * K;
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const long long g = e / K;
+    const int k = (int)(e % K);
+    const int o = off[g], cnt = off[g + 1] - o;
+    group_inds[e] = cnt == 0 ? -1 : (long long)csr[o + (k < cnt ? k : k % cnt)];
+  }
+}
+
+extern "C" size_t gdmae_group_workspace_bytes(long long n, long long n_groups) {
+  return gd_align(sizeof(int) * (n_groups + 1)) * 2 + gd_align(sizeof(int) * n) * 3 +
+         gd_align(sizeof(int) * (gd_scan_ws_elems(n_groups) + 8)) + 4096;
+}
+
+static int gd_group_csr(const long long* gid, long long n, long long n_groups, GdArena& A, int** off_out, int** csr_out,
+                        int** rank_out, hipStream_t st) {
+  GD_REQUIRE(n < (1ll << 31) && n_groups < (1ll << 31) && n_groups > 0, "sizes must fit int32");
+  int* cnt = A.take<int>(n_groups + 1);
+  int* off = A.take<int>(n_groups + 1);
+  int* csr_raw = A.take<int>(n);
+  int* csr = A.take<int>(n);
+  int* rank = A.take<int>(n);
+  int* scan_ws = A.take<int>(gd_scan_ws_elems(n_groups) + 8);
+  int* total = scan_ws + gd_scan_ws_elems(n_groups);
+  int* counts = total + 2;
+  int* bad = total + 4;
+  GD_REQUIRE(A.ok(), "group workspace too small");
+  GD_CHECK(hipMemsetAsync(cnt, 0, sizeof(int) * (n_groups + 1), st));
+  GD_CHECK(hipMemsetAsync(bad, 0, sizeof(int), st));
+  int grid = gd_div_up(n > 0 ? n : 1, 256);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(k_group_count, dim3(grid), dim3(256), 0, st, gid, n, n_groups, cnt, bad);
+  GD_LAUNCH_CHECK();
+  int rc = gd_device_scan<int>(n_groups, CntLoad{cnt}, OffStore{off}, total, scan_ws, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_group_finalize, dim3(1), dim3(64), 0, st, total, n_groups, off, counts);
+  GD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_group_fill, dim3(grid), dim3(256), 0, st, gid, n, n_groups, off, cnt, csr_raw);
+  GD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_pillar_sort_mean, dim3(2048), dim3(256), 0, st, counts, off, csr_raw, csr, rank,
+                     (const float*)nullptr, 1, (float*)nullptr);
+  GD_LAUNCH_CHECK();
+  *off_out = off;
+  *csr_out = csr;
+  *rank_out = rank;
+  return 0;
+}
+
+extern "C" int gdmae_ingroup_inds(const long long* group_inds, long long n, long long n_groups, long long* out_inds,
+                                  void* workspace, size_t workspace_bytes, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (n <= 0) return 0;
+  GD_REQUIRE(workspace_bytes >= gdmae_group_workspace_bytes(n, n_groups), "group workspace too small");
+  GdArena A(workspace, workspace_bytes);
+  int *off, *csr, *rank;
+  int rc = gd_group_csr(group_inds, n, n_groups, A, &off, &csr, &rank, st);
+  if (rc) return rc;
+  int grid = gd_div_up(n, 256);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(k_rank_to_i64, dim3(grid), dim3(256), 0, st, rank, n, out_inds);
+  GD_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gdmae_group_inner_inds(const long long* inverse_inds, long long n, long long M, int K,
+                                      long long* group_inds, void* workspace, size_t workspace_bytes, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  GD_REQUIRE(M > 0 && K > 0, "M, K");
+  GD_REQUIRE(workspace_bytes >= gdmae_group_workspace_bytes(n, M), "group workspace too small");
+  GdArena A(workspace, workspace_bytes);
+  int *off, *csr, *rank;
+  int rc = gd_group_csr(inverse_inds, n, M, A, &off, &csr, &rank, st);
+  if (rc) return rc;
+  int grid = gd_div_up(M * K, 256);
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(k_group_inner, dim3(grid), dim3(256), 0, st, off, csr, M, K, group_inds);
+  GD_LAUNCH_CHECK();
+  return 0;
+}

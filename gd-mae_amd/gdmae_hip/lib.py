@@ -43,6 +43,9 @@ SIGNATURES = {
     "gdmae_sum_partials": (_I, [_P, _L, _F, _P, _I, _P]),
     "gdmae_group_gt_points": (_I, [_P, _I, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
     "gdmae_chamfer": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P]),
+    "gdmae_group_workspace_bytes": (_Z, [_L, _L]),
+    "gdmae_ingroup_inds": (_I, [_P, _L, _L, _P, _P, _Z, _P]),
+    "gdmae_group_inner_inds": (_I, [_P, _L, _L, _I, _P, _P, _Z, _P]),
     "gdmae_grad_sq_norm": (_I, [_P, _L, _P, _P, _P]),
     "gdmae_adam_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _P, _P]),
 }

@@ -9,6 +9,7 @@ from __future__ import annotations
 import torch
 
 from . import lib as L
+from . import timing
 
 I32 = torch.int32
 
@@ -82,16 +83,16 @@ class SparseConv3x3(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, nbr, nbr_t):
         cout, _, _, cin = weight.shape
-        cols = gather_rows_raw(x, nbr).view(nbr.shape[0], 9 * cin)
-        wmat = weight.reshape(cout, 9 * cin)
+        cdt = torch.bfloat16 if torch.is_autocast_enabled() else x.dtype      # bf16 throughput mode under autocast
+        cols = gather_rows_raw(x.to(cdt), nbr).view(nbr.shape[0], 9 * cin)
         ctx.save_for_backward(cols, weight, nbr_t)
-        return cols @ wmat.t().to(cols.dtype)
+        return cols @ weight.reshape(cout, 9 * cin).t().to(cdt)
 
     @staticmethod
     def backward(ctx, g):
         cols, weight, nbr_t = ctx.saved_tensors
         cout, _, _, cin = weight.shape
-        g = g.contiguous()
+        g = g.contiguous().to(cols.dtype)
         dw = (g.t() @ cols).view(cout, 3, 3, cin).to(weight.dtype)
         gcols = gather_rows_raw(g, nbr_t).view(nbr_t.shape[0], 9 * cout)
         wt = weight.permute(1, 2, 0, 3).reshape(9 * cout, cin).to(g.dtype)
@@ -145,9 +146,11 @@ class WindowCosineAttention(torch.autograd.Function):
         base = 0
         for lvl, nw in enumerate(wplan.n_win):
             if nw > 0:
-                L.call("gdmae_window_attention_fwd", L.ptr(qk), L.ptr(v), L.ptr(out), L.ptr(wplan.csr_tok),
-                       L.ptr(wplan.win_start[base:]), L.ptr(wplan.win_len[base:]), nw, wplan.max_tokens[lvl], d, nhead,
-                       L.ptr(tau_flat), float(tau_min), L.stream())
+                # algorithmic bytes: q,k,v rows read + out row written per token, + CSR (4 B/token + 8 B/window)
+                with timing.kernel("k_win_attn_fwd", wplan.n_tok[lvl] * (16 * d + 4) + 8 * nw):
+                    L.call("gdmae_window_attention_fwd", L.ptr(qk), L.ptr(v), L.ptr(out), L.ptr(wplan.csr_tok),
+                           L.ptr(wplan.win_start[base:]), L.ptr(wplan.win_len[base:]), nw, wplan.max_tokens[lvl], d, nhead,
+                           L.ptr(tau_flat), float(tau_min), L.stream())
             base += nw
         ctx.save_for_backward(qk, v, tau_flat)
         ctx.wplan, ctx.nhead, ctx.tau_min, ctx.tau_shape = wplan, nhead, tau_min, tau.shape
@@ -166,10 +169,12 @@ class WindowCosineAttention(torch.autograd.Function):
         base, pbase = 0, 0
         for lvl, nw in enumerate(wplan.n_win):
             if nw > 0:
-                L.call("gdmae_window_attention_bwd", L.ptr(qk), L.ptr(v), L.ptr(g), L.ptr(dqk), L.ptr(dv),
-                       L.ptr(part[pbase:]), L.ptr(wplan.csr_tok), L.ptr(wplan.win_start[base:]),
-                       L.ptr(wplan.win_len[base:]), nw, wplan.max_tokens[lvl], d, H, L.ptr(tau_flat), float(ctx.tau_min),
-                       L.stream())
+                # algorithmic bytes: q,k,v,dout rows read + dq,dk,dv rows written per token (7 d floats), + CSR
+                with timing.kernel("k_win_attn_bwd", wplan.n_tok[lvl] * (28 * d + 4) + 8 * nw):
+                    L.call("gdmae_window_attention_bwd", L.ptr(qk), L.ptr(v), L.ptr(g), L.ptr(dqk), L.ptr(dv),
+                           L.ptr(part[pbase:]), L.ptr(wplan.csr_tok), L.ptr(wplan.win_start[base:]),
+                           L.ptr(wplan.win_len[base:]), nw, wplan.max_tokens[lvl], d, H, L.ptr(tau_flat),
+                           float(ctx.tau_min), L.stream())
             base += nw
             pbase += n_items[lvl]
         dtau = torch.zeros(1, dtype=torch.float32, device=v.device)

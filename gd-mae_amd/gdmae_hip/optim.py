@@ -41,7 +41,7 @@ class FlatAdamOneCycle:
 
     def __init__(self, model: torch.nn.Module, optim_cfg, total_steps: int, process_group=None):
         params = [p for p in model.parameters() if p.requires_grad]
-        assert params and all(p.dtype == torch.float32 and p.is_cuda for p in params)
+        assert params and all(p.dtype == torch.float32 for p in params)
         dev = params[0].device
         n = sum(p.numel() for p in params)
         self.n = n

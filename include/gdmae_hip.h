@@ -150,6 +150,22 @@ int gdmae_group_gt_points(const float* points, int n_cols, const int* pillar_pt_
 int gdmae_chamfer(const float* pred, const float* gt, const float* weights, int M, int P1, int P2, float* term,
                   float* dpred, void* stream);
 
+/* ---- the reference's own native op API for this path, for arbitrary group ids ------------------- *
+ * Drop-in equivalents of pybind module pcdet.ops.sst_ops.sst_ops_cuda (pcdet/ops/sst_ops/src/sst_ops_api.cpp:6-9):
+ *   int ingroup_inds_wrapper(at::Tensor group_inds, at::Tensor out_inds)          (sst_ops.cpp:21-33)
+ *   int group_inner_inds_wrapper(at::Tensor inverse_inds, at::Tensor group_inds)  (sst_ops.cpp:35-48)
+ * gdmae_ingroup_inds: out_inds[i] = number of EARLIER elements with the same group id (ids in [0,n_groups)).
+ * gdmae_group_inner_inds: group_inds (M,K) int64 = first min(cnt,K) member indices of every group in
+ *   ascending order, slot k >= cnt filled with slot k % cnt, empty groups -1.
+ * Differences from the reference wrappers: canonical order instead of atomic arrival order; the caller
+ * supplies n_groups (no max().item() sync) and the workspace (no cudaMalloc/cudaFree per call); launches
+ * go to `stream` (not the legacy default stream); errors are returned (no exit(-1)). */
+size_t gdmae_group_workspace_bytes(long long n, long long n_groups);
+int gdmae_ingroup_inds(const long long* group_inds, long long n, long long n_groups, long long* out_inds,
+                       void* workspace, size_t workspace_bytes, void* stream);
+int gdmae_group_inner_inds(const long long* inverse_inds, long long n, long long M, int K, long long* group_inds,
+                           void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- a21: fused optimizer step over one flat buffer ------------------------------------------- *
  * Replaces clip_grad_norm_ (tools/train_utils/train_utils.py:52) and OptimWrapper.step
  * (tools/train_utils/optimization/fastai_optim.py:135-152: p *= 1 - wd*lr, then torch Adam). */

@@ -317,3 +317,32 @@ def test_full_model_forward_backward_vs_reference_golden(name):
     scale = np.abs(z["grad_head"]).max(axis=1, keepdims=True) + 1e-8
     bad = np.abs(gh - z["grad_head"]) / scale
     assert (bad.max(axis=1) <= tol * 5).all(), [(names[i], bad[i].max()) for i in np.flatnonzero(bad.max(axis=1) > tol * 5)]
+
+
+def test_sst_ops_dropin_api_matches_sequential_kernels():
+    """pcdet.ops.sst_ops.sst_ops_utils (the reference's own op API) vs a sequential evaluation of its kernels."""
+    from pcdet.ops.sst_ops import sst_ops_utils
+    rng = np.random.default_rng(9)
+    g = np.concatenate([rng.integers(0, 500, 6000), np.full(300, 77), rng.integers(900, 1000, 50)])
+    g = g[rng.permutation(len(g))]
+    seen, rank = {}, np.empty(len(g), np.int64)
+    for i, v in enumerate(g):
+        rank[i] = seen.get(v, 0)
+        seen[v] = rank[i] + 1
+    out = sst_ops_utils.get_inner_win_inds(torch.from_numpy(g).to(dev()))
+    assert np.array_equal(out.cpu().numpy(), rank)
+    K = 64
+    pts = torch.randn(len(g), 3)
+    grouped = sst_ops_utils.group_inner_inds(pts.to(dev()), torch.from_numpy(g).to(dev()), K)
+    M = int(g.max()) + 1
+    exp = -np.ones((M, K), np.int64)
+    for i, v in enumerate(g):
+        if rank[i] < K:
+            exp[v, rank[i]] = i
+    for m in range(M):
+        c = seen.get(m, 0)
+        if 0 < c < K:
+            exp[m, c:] = exp[m, np.arange(c, K) % c]
+    assert grouped.shape == (M, K, 3)
+    ref = pts[torch.from_numpy(exp)]           # -1 indexes the last row, exactly like the reference's points[group_inds]
+    assert torch.equal(grouped.cpu(), ref)
