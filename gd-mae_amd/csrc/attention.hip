@@ -83,11 +83,13 @@ template <int T, int DH>
 __global__ __launch_bounds__(256) void k_win_attn_fwd(AttnArgs A) {
   constexpr int G = GD_WAVE / T;          // heads per wavefront
   constexpr int LD = DH + 4;              // padded LDS row
+  constexpr int GS = T * LD + 16;         // head-tile stride: +16 floats so packed heads start on different banks
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = threadIdx.x & (GD_WAVE - 1);
   const int wib = threadIdx.x / GD_WAVE;
-  float* sK = smem + wib * (2 * GD_WAVE * LD);
-  float* sV = sK + GD_WAVE * LD;
+  constexpr int TILE = G * GS;
+  float* sK = smem + wib * (2 * TILE);
+  float* sV = sK + TILE;
   const int groups = A.H / G;
   const long long item = (long long)blockIdx.x * 4 + wib;
   if (item >= (long long)A.n_win * groups) return;
@@ -108,14 +110,14 @@ __global__ __launch_bounds__(256) void k_win_attn_fwd(AttnArgs A) {
     normalize<DH>(q, dummy);
     load_row<DH>(A.qk + (long long)t * 2 * A.d + A.d + h * DH, tmp);
     normalize<DH>(tmp, dummy);
-    store_row<DH>(sK + lane * LD, tmp);
+    store_row<DH>(sK + sub * GS + r * LD, tmp);
     load_row<DH>(A.v + (long long)t * A.d + h * DH, tmp);
-    store_row<DH>(sV + lane * LD, tmp);
+    store_row<DH>(sV + sub * GS + r * LD, tmp);
   }
   __builtin_amdgcn_wave_barrier();
   if (!act) return;
-  const float* kb = sK + sub * T * LD;
-  const float* vb = sV + sub * T * LD;
+  const float* kb = sK + sub * GS;
+  const float* vb = sV + sub * GS;
   float s[T];
   float m = -INFINITY;
 #pragma unroll
@@ -176,12 +178,14 @@ template <int T, int DH>
 __global__ __launch_bounds__(256) void k_win_attn_bwd(AttnBwdArgs A) {
   constexpr int G = GD_WAVE / T;
   constexpr int LD = DH + 4;
+  constexpr int GS = T * LD + 16;
+  constexpr int TILE = G * GS;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = threadIdx.x & (GD_WAVE - 1);
   const int wib = threadIdx.x / GD_WAVE;
-  float* s0 = smem + wib * (2 * GD_WAVE * LD + 2 * GD_WAVE);
-  float* s1 = s0 + GD_WAVE * LD;
-  float* sLse = s1 + GD_WAVE * LD;
+  float* s0 = smem + wib * (2 * TILE + 2 * GD_WAVE);
+  float* s1 = s0 + TILE;
+  float* sLse = s1 + TILE;
   float* sD = sLse + GD_WAVE;
   const int groups = A.H / G;
   const long long item = (long long)blockIdx.x * 4 + wib;
@@ -203,17 +207,17 @@ __global__ __launch_bounds__(256) void k_win_attn_bwd(AttnBwdArgs A) {
     float tmp[DH];
     load_row<DH>(A.qk + (long long)t * 2 * A.d + A.d + h * DH, tmp);
     normalize<DH>(tmp, kin);
-    store_row<DH>(s0 + lane * LD, tmp);  // K^
+    store_row<DH>(s0 + sub * GS + r * LD, tmp);  // K^
     load_row<DH>(A.v + (long long)t * A.d + h * DH, tmp);
-    store_row<DH>(s1 + lane * LD, tmp);  // V
+    store_row<DH>(s1 + sub * GS + r * LD, tmp);  // V
     load_row<DH>(A.qk + (long long)t * 2 * A.d + h * DH, q);
     normalize<DH>(q, qin);
     load_row<DH>(A.dout + (long long)t * A.d + h * DH, dO);
   }
   __builtin_amdgcn_wave_barrier();
   float dtau = 0.f;
-  const float* b0 = s0 + sub * T * LD;
-  const float* b1 = s1 + sub * T * LD;
+  const float* b0 = s0 + sub * GS;
+  const float* b1 = s1 + sub * GS;
   // ---- phase A: lane = query row i
   if (act) {
     float s[T];
@@ -273,13 +277,13 @@ __global__ __launch_bounds__(256) void k_win_attn_bwd(AttnBwdArgs A) {
   // ---- phase B: lane = key row j; tiles now hold Q^ and dO
   float k[DH], vv[DH];
   if (act) {
-    load_row<DH>(s0 + lane * LD, k);
-    load_row<DH>(s1 + lane * LD, vv);
+    load_row<DH>(s0 + sub * GS + r * LD, k);
+    load_row<DH>(s1 + sub * GS + r * LD, vv);
   }
   __builtin_amdgcn_wave_barrier();
   if (act) {
-    store_row<DH>(s0 + lane * LD, q);
-    store_row<DH>(s1 + lane * LD, dO);
+    store_row<DH>(s0 + sub * GS + r * LD, q);
+    store_row<DH>(s1 + sub * GS + r * LD, dO);
   }
   __builtin_amdgcn_wave_barrier();
   if (act) {
@@ -349,7 +353,7 @@ template <int T, int DH>
 static int launch_fwd(const AttnArgs& A, hipStream_t st) {
   constexpr int G = GD_WAVE / T;
   const long long items = (long long)A.n_win * (A.H / G);
-  const size_t lds = 4 * (2 * GD_WAVE * (DH + 4)) * sizeof(float);
+  const size_t lds = 4 * (2 * G * (T * (DH + 4) + 16)) * sizeof(float);
   hipLaunchKernelGGL((k_win_attn_fwd<T, DH>), dim3(gd_div_up(items, 4)), dim3(256), lds, st, A);
   GD_LAUNCH_CHECK();
   return 0;
@@ -358,7 +362,7 @@ template <int T, int DH>
 static int launch_bwd(const AttnBwdArgs& A, hipStream_t st) {
   constexpr int G = GD_WAVE / T;
   const long long items = (long long)A.n_win * (A.H / G);
-  const size_t lds = 4 * (2 * GD_WAVE * (DH + 4) + 2 * GD_WAVE) * sizeof(float);
+  const size_t lds = 4 * (2 * G * (T * (DH + 4) + 16) + 2 * GD_WAVE) * sizeof(float);
   hipLaunchKernelGGL((k_win_attn_bwd<T, DH>), dim3(gd_div_up(items, 4)), dim3(256), lds, st, A);
   GD_LAUNCH_CHECK();
   return 0;

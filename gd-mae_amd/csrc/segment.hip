@@ -13,28 +13,32 @@
 #include "common.h"
 
 // out[r, k, :] = idx[r*K + k] >= 0 ? src[idx[r*K+k], :] : 0        (row_vec = row bytes / 16)
+// (the table side - src of a gather, dst of a scatter - may be a column slice of wider rows:
+//  table row j starts at vector j * tab_stride + tab_off)
 __global__ __launch_bounds__(256) void k_gather_rows(const uint4* __restrict__ src, const int* __restrict__ idx,
-                                                     long long n_slots, int row_vec, uint4* __restrict__ out) {
+                                                     long long n_slots, int row_vec, int tab_stride, int tab_off,
+                                                     uint4* __restrict__ out) {
   const long long total = n_slots * row_vec;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const long long s = i / row_vec;
     const int v = (int)(i % row_vec);
     const int j = idx[s];
     uint4 val = make_uint4(0, 0, 0, 0);
-    if (j >= 0) val = src[(long long)j * row_vec + v];
+    if (j >= 0) val = src[(long long)j * tab_stride + tab_off + v];
     out[i] = val;
   }
 }
 
 // dst[idx[r], :] = src[r, :]   (idx unique; rows with idx < 0 are skipped)
 __global__ __launch_bounds__(256) void k_scatter_rows(const uint4* __restrict__ src, const int* __restrict__ idx,
-                                                      long long n_rows, int row_vec, uint4* __restrict__ dst) {
+                                                      long long n_rows, int row_vec, int tab_stride, int tab_off,
+                                                      uint4* __restrict__ dst) {
   const long long total = n_rows * row_vec;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const long long s = i / row_vec;
     const int v = (int)(i % row_vec);
     const int j = idx[s];
-    if (j >= 0) dst[(long long)j * row_vec + v] = src[i];
+    if (j >= 0) dst[(long long)j * tab_stride + tab_off + v] = src[i];
   }
 }
 
@@ -49,7 +53,32 @@ extern "C" int gdmae_gather_rows(const void* src, const int* idx, long long n_sl
   if (n_slots <= 0) return 0;
   const int rv = row_bytes / 16;
   hipLaunchKernelGGL(k_gather_rows, dim3(gd_grid_for(n_slots * rv)), dim3(256), 0, (hipStream_t)stream,
-                     (const uint4*)src, idx, n_slots, rv, (uint4*)out);
+                     (const uint4*)src, idx, n_slots, rv, rv, 0, (uint4*)out);
+  GD_LAUNCH_CHECK();
+  return 0;
+}
+
+// column-slice variants: the table's rows are table_row_bytes wide and the slice starts at table_col_bytes
+extern "C" int gdmae_gather_rows_strided(const void* src, const int* idx, long long n_slots, int row_bytes,
+                                         int table_row_bytes, int table_col_bytes, void* out, void* stream) {
+  GD_REQUIRE(row_bytes % 16 == 0 && table_row_bytes % 16 == 0 && table_col_bytes % 16 == 0, "16-byte granularity");
+  GD_REQUIRE(table_col_bytes + row_bytes <= table_row_bytes, "slice exceeds the table row");
+  if (n_slots <= 0) return 0;
+  const int rv = row_bytes / 16;
+  hipLaunchKernelGGL(k_gather_rows, dim3(gd_grid_for(n_slots * rv)), dim3(256), 0, (hipStream_t)stream,
+                     (const uint4*)src, idx, n_slots, rv, table_row_bytes / 16, table_col_bytes / 16, (uint4*)out);
+  GD_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gdmae_scatter_rows_strided(const void* src, const int* idx, long long n_rows, int row_bytes,
+                                          int table_row_bytes, int table_col_bytes, void* dst, void* stream) {
+  GD_REQUIRE(row_bytes % 16 == 0 && table_row_bytes % 16 == 0 && table_col_bytes % 16 == 0, "16-byte granularity");
+  GD_REQUIRE(table_col_bytes + row_bytes <= table_row_bytes, "slice exceeds the table row");
+  if (n_rows <= 0) return 0;
+  const int rv = row_bytes / 16;
+  hipLaunchKernelGGL(k_scatter_rows, dim3(gd_grid_for(n_rows * rv)), dim3(256), 0, (hipStream_t)stream,
+                     (const uint4*)src, idx, n_rows, rv, table_row_bytes / 16, table_col_bytes / 16, (uint4*)dst);
   GD_LAUNCH_CHECK();
   return 0;
 }
@@ -60,7 +89,7 @@ extern "C" int gdmae_scatter_rows(const void* src, const int* idx, long long n_r
   if (n_rows <= 0) return 0;
   const int rv = row_bytes / 16;
   hipLaunchKernelGGL(k_scatter_rows, dim3(gd_grid_for(n_rows * rv)), dim3(256), 0, (hipStream_t)stream,
-                     (const uint4*)src, idx, n_rows, rv, (uint4*)dst);
+                     (const uint4*)src, idx, n_rows, rv, rv, 0, (uint4*)dst);
   GD_LAUNCH_CHECK();
   return 0;
 }
@@ -69,27 +98,52 @@ extern "C" int gdmae_scatter_rows(const void* src, const int* idx, long long n_r
 // segmented max over the pillar CSR: out[p, c] = max_{i in pillar p} x[i, c], arg[p, c] = that i
 // (lowest i on ties).  One wavefront per pillar, lanes on channels (float2 per lane for C = 128).
 // ------------------------------------------------------------------------------------------
+// LPP = lanes per point = C / 4 (each lane owns 4 consecutive channels as one 16-byte load); the 64 / LPP lane
+// groups of the wavefront walk interleaved points of the pillar (several independent row loads in flight),
+// then the groups are combined with xor-shuffles (ties -> lowest point id, i.e. canonical order).
+template <int LPP>
 __global__ __launch_bounds__(256) void k_segment_max(const float* __restrict__ x, const int* __restrict__ pt_off,
-                                                     const int* __restrict__ csr, int M, int C, float* __restrict__ out,
+                                                     const int* __restrict__ csr, int M, float* __restrict__ out,
                                                      int* __restrict__ arg) {
+  constexpr int C = LPP * 4;
+  constexpr int G = GD_WAVE / LPP;  // points in flight per step
   const int lane = threadIdx.x & (GD_WAVE - 1);
   const int wib = threadIdx.x / GD_WAVE;
+  const int grp = lane / LPP, cl = lane % LPP;
   for (int p = blockIdx.x * 4 + wib; p < M; p += gridDim.x * 4) {
     const int off = pt_off[p];
     const int cnt = pt_off[p + 1] - off;
-    for (int c = lane; c < C; c += GD_WAVE) {
-      float best = -INFINITY;
-      int bi = -1;
-      for (int j = 0; j < cnt; ++j) {
-        const int i = csr[off + j];
-        const float v = x[(long long)i * C + c];
-        if (v > best || bi < 0) {
-          best = v;
-          bi = i;
+    float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    int bi[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
+#pragma unroll 4
+    for (int j = grp; j < cnt; j += G) {
+      const int i = csr[off + j];
+      const float4 v = *reinterpret_cast<const float4*>(x + (long long)i * C + cl * 4);
+      const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (vv[e] > best[e] || bi[e] == 0x7fffffff) {   // first point always taken (also NaN / -inf rows)
+          best[e] = vv[e];
+          bi[e] = i;
         }
       }
-      out[(long long)p * C + c] = best;
-      arg[(long long)p * C + c] = bi;
+    }
+#pragma unroll
+    for (int d = LPP; d < GD_WAVE; d <<= 1) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float ob = __shfl_xor(best[e], d, GD_WAVE);
+        const int oi = __shfl_xor(bi[e], d, GD_WAVE);
+        const bool take = (oi != 0x7fffffff) && (bi[e] == 0x7fffffff || ob > best[e] || (ob == best[e] && oi < bi[e]));
+        if (take) {
+          best[e] = ob;
+          bi[e] = oi;
+        }
+      }
+    }
+    if (grp == 0) {
+      *reinterpret_cast<float4*>(out + (long long)p * C + cl * 4) = make_float4(best[0], best[1], best[2], best[3]);
+      *reinterpret_cast<int4*>(arg + (long long)p * C + cl * 4) = make_int4(bi[0], bi[1], bi[2], bi[3]);
     }
   }
 }
@@ -110,8 +164,16 @@ __global__ __launch_bounds__(256) void k_segment_max_bwd(const float* __restrict
 extern "C" int gdmae_segment_max(const float* x, const int* pt_off, const int* csr, int M, int C, float* out, int* arg,
                                  void* stream) {
   if (M <= 0) return 0;
-  hipLaunchKernelGGL(k_segment_max, dim3(gd_grid_for(M, 4, 8192)), dim3(256), 0, (hipStream_t)stream, x, pt_off, csr, M, C,
-                     out, arg);
+  const dim3 grid(gd_grid_for(M, 4, 16384)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  switch (C) {
+    case 16: hipLaunchKernelGGL((k_segment_max<4>), grid, block, 0, st, x, pt_off, csr, M, out, arg); break;
+    case 32: hipLaunchKernelGGL((k_segment_max<8>), grid, block, 0, st, x, pt_off, csr, M, out, arg); break;
+    case 64: hipLaunchKernelGGL((k_segment_max<16>), grid, block, 0, st, x, pt_off, csr, M, out, arg); break;
+    case 128: hipLaunchKernelGGL((k_segment_max<32>), grid, block, 0, st, x, pt_off, csr, M, out, arg); break;
+    case 256: hipLaunchKernelGGL((k_segment_max<64>), grid, block, 0, st, x, pt_off, csr, M, out, arg); break;
+    default: GD_REQUIRE(false, "segment_max supports C in {16, 32, 64, 128, 256}");
+  }
   GD_LAUNCH_CHECK();
   return 0;
 }
@@ -166,6 +228,100 @@ extern "C" int gdmae_decorate_points(const float* points, const long long* point
   P.ncols = n_cols;
   hipLaunchKernelGGL(k_decorate, dim3(gd_grid_for(N)), dim3(256), 0, (hipStream_t)stream, points, point_coords, inverse32,
                      pillar_mean, N, P, out);
+  GD_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// per-column sum and sum of squares of a row-major (R, C) matrix (fp32 or bf16), fp64 result.
+// Used for BatchNorm statistics of dense channels-last maps (reference nn.BatchNorm2d in
+// spt_backbone_mae.py:40,47) and for column sums of dense gradients.  Each workgroup reduces a
+// contiguous chunk of rows with 16-byte loads (fp32 partials), a second kernel combines the
+// per-workgroup partials in fp64 in a fixed order (deterministic).
+// ------------------------------------------------------------------------------------------
+__device__ inline void unpack8(const uint4& u, float (&f)[8]) {
+  const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    f[2 * k] = __uint_as_float(w[k] << 16);
+    f[2 * k + 1] = __uint_as_float(w[k] & 0xFFFF0000u);
+  }
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(256) void k_colstats_partial(const uint4* __restrict__ x, long long R, int C,
+                                                          float* __restrict__ part /* (grid, 2, C) */) {
+  constexpr int EPV = BF16 ? 8 : 4;  // elements per 16-byte vector
+  const int vec_per_row = C / EPV;
+  const int rows_per_iter = 256 / vec_per_row;       // threads beyond rows_per_iter * vec_per_row idle
+  const int vr = threadIdx.x / vec_per_row;          // row within the iteration
+  const int vc = threadIdx.x % vec_per_row;          // vector column
+  const bool live = vr < rows_per_iter;
+  const long long chunk = (R + gridDim.x - 1) / gridDim.x;
+  const long long r0 = blockIdx.x * chunk;
+  const long long r1 = r0 + chunk < R ? r0 + chunk : R;
+  float s[EPV], q[EPV];
+#pragma unroll
+  for (int e = 0; e < EPV; ++e) s[e] = q[e] = 0.f;
+  for (long long r = r0 + vr; live && r < r1; r += rows_per_iter) {
+    const uint4 u = x[r * vec_per_row + vc];
+    float f[8];
+    if (BF16) {
+      unpack8(u, f);
+    } else {
+      f[0] = __uint_as_float(u.x);
+      f[1] = __uint_as_float(u.y);
+      f[2] = __uint_as_float(u.z);
+      f[3] = __uint_as_float(u.w);
+    }
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) {
+      s[e] += f[e];
+      q[e] = fmaf(f[e], f[e], q[e]);
+    }
+  }
+  extern __shared__ float sh[];  // (rows_per_iter, 2, C)
+  if (live) {
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) {
+      sh[(vr * 2 + 0) * C + vc * EPV + e] = s[e];
+      sh[(vr * 2 + 1) * C + vc * EPV + e] = q[e];
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < 2 * C; c += 256) {
+    float acc = 0.f;
+    for (int rr = 0; rr < rows_per_iter; ++rr) acc += sh[rr * 2 * C + c];
+    part[(long long)blockIdx.x * 2 * C + c] = acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_colstats_final(const float* __restrict__ part, int nblk, int C2,
+                                                        double* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C2) return;
+  double acc = 0.0;
+  for (int b = 0; b < nblk; ++b) acc += (double)part[(long long)b * C2 + c];
+  out[c] = acc;
+}
+
+extern "C" size_t gdmae_colstats_workspace_bytes(int C) { return (size_t)1024 * 2 * C * sizeof(float); }
+
+// out: double[2*C] = {sum[0..C), sumsq[0..C)};  is_bf16: 0 = fp32 rows, 1 = bf16 rows
+extern "C" int gdmae_colstats(const void* x, long long R, int C, int is_bf16, double* out, void* workspace, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const int epv = is_bf16 ? 8 : 4;
+  GD_REQUIRE(C % epv == 0 && (C / epv) <= 256, "C must be a multiple of 8 (bf16) / 4 (fp32) and <= 2048 / 1024");
+  int nblk = (int)(R / 64 > 1024 ? 1024 : (R / 64 > 0 ? R / 64 : 1));
+  const int rows_per_iter = 256 / (C / epv);
+  const size_t lds = (size_t)rows_per_iter * 2 * C * sizeof(float);
+  GD_REQUIRE(lds <= 64 * 1024, "colstats LDS");
+  if (is_bf16)
+    hipLaunchKernelGGL((k_colstats_partial<true>), dim3(nblk), dim3(256), lds, st, (const uint4*)x, R, C, (float*)workspace);
+  else
+    hipLaunchKernelGGL((k_colstats_partial<false>), dim3(nblk), dim3(256), lds, st, (const uint4*)x, R, C, (float*)workspace);
+  GD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_colstats_final, dim3(gd_div_up(2 * C, 256)), dim3(256), 0, st, (const float*)workspace, nblk, 2 * C, out);
   GD_LAUNCH_CHECK();
   return 0;
 }

@@ -1,0 +1,203 @@
+"""Sparse-aware generative decoder: the same arithmetic as the reference's dense decoder
+(pcdet/models/backbones_3d/spt_backbone_mae.py:120-143: densify -> ConvTranspose2d(k = s) + BN2d + ReLU per
+source stage -> cat -> Conv2d 3x3 + BN2d + ReLU -> gather at all pillar sites), restructured around what
+is actually dense.
+
+Exact identities used (no approximation):
+* ConvTranspose2d with kernel = stride maps each input site to its own s x s output block, so on a map
+  that is zero outside the active set it is one token GEMM  P = X @ W.view(Cin, s*s*Cout)  and zeros
+  elsewhere.
+* BatchNorm2d statistics over ALL B*Y*X sites of such a map follow from the token values alone
+  (sum and sum of squares over tokens, divided by the dense count); after BN + ReLU every empty site
+  holds the same per-channel constant relu(beta - gamma*mean/sigma).
+* The concatenated 384-channel map is therefore "constant background + token rows": it is written once
+  (fill + three row scatters into column slices) instead of 3 dense deconvs, 3 dense BN passes, 3 ReLUs
+  and a cat copy.
+* The 3x3 convolution is the one genuinely dense contraction (MIOpen implicit GEMM, bf16 in throughput
+  mode).  Its BatchNorm needs dense statistics (one read pass, gdmae_colstats) but its output is only
+  consumed at the M pillar sites, so BN + ReLU are applied to the gathered rows only; in the backward
+  the dense gradient of the conv output is an affine function of the conv output plus M sparse rows.
+
+Autograd: the token-side algebra is ordinary differentiable torch code on token-sized tensors; only
+the two dense boundaries are custom Functions (BuildDenseCat, DenseBNReLUGather).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+from . import lib as L
+from . import ops
+
+BN_EPS, BN_MOM = 1e-3, 0.01
+
+
+def colstats(x2d: torch.Tensor):
+    """(sum, sumsq) per column of a contiguous (R, C) fp32/bf16 device matrix, as float64 (C,) tensors."""
+    R, C = x2d.shape
+    assert x2d.is_contiguous() and x2d.dtype in (torch.float32, torch.bfloat16)
+    out = torch.empty(2 * C, dtype=torch.float64, device=x2d.device)
+    ws = torch.empty(L.load().gdmae_colstats_workspace_bytes(C), dtype=torch.uint8, device=x2d.device)
+    L.call("gdmae_colstats", L.ptr(x2d), R, C, int(x2d.dtype == torch.bfloat16), L.ptr(out), L.ptr(ws), L.stream())
+    return out[:C], out[C:]
+
+
+def _gather_slice(table2d, idx, col0, ncol):
+    es = table2d.element_size()
+    out = torch.empty(idx.numel(), ncol, dtype=table2d.dtype, device=table2d.device)
+    L.call("gdmae_gather_rows_strided", L.ptr(table2d), L.ptr(idx), idx.numel(), ncol * es, table2d.shape[1] * es,
+           col0 * es, L.ptr(out), L.stream())
+    return out
+
+
+def _scatter_slice(src2d, idx, table2d, col0):
+    es = table2d.element_size()
+    src2d = src2d.contiguous()
+    assert src2d.dtype == table2d.dtype
+    L.call("gdmae_scatter_rows_strided", L.ptr(src2d), L.ptr(idx), idx.numel(), src2d.shape[1] * es,
+           table2d.shape[1] * es, col0 * es, L.ptr(table2d), L.stream())
+
+
+class BuildDenseCat(torch.autograd.Function):
+    """Z (R, sum C_i) = per-channel background everywhere, token rows written into column slices.
+
+    forward(R, dtype, idx_0, vals_0, bg_0, idx_1, vals_1, bg_1, ...):  vals_i (n_i, C_i) rows for the
+    unique sites idx_i (int32), bg_i (C_i,) the value of every other site."""
+
+    @staticmethod
+    def forward(ctx, R, dtype, *args):
+        k = len(args) // 3
+        idxs, vals, bgs = args[0::3], args[1::3], args[2::3]
+        widths = [int(v.shape[1]) for v in vals]
+        Z = torch.cat([b.detach() for b in bgs]).to(dtype).expand(R, sum(widths)).contiguous()
+        col = 0
+        for i in range(k):
+            _scatter_slice(vals[i].detach().to(dtype), idxs[i], Z, col)
+            col += widths[i]
+        ctx.save_for_backward(*idxs)
+        ctx.widths = widths
+        ctx.in_dtypes = [(v.dtype, b.dtype) for v, b in zip(vals, bgs)]
+        return Z
+
+    @staticmethod
+    def backward(ctx, dZ):
+        idxs = ctx.saved_tensors
+        dZ = dZ.contiguous()
+        tot, _ = colstats(dZ)                      # column sums over ALL sites (fp64)
+        grads = [None, None]
+        col = 0
+        for i, w in enumerate(ctx.widths):
+            g = _gather_slice(dZ, idxs[i], col, w)             # gradient rows of the token sites
+            vd, bd = ctx.in_dtypes[i]
+            dbg = (tot[col:col + w] - g.sum(0, dtype=torch.float64)).to(bd)   # every other site shares bg
+            grads += [None, g.to(vd), dbg]
+            col += w
+        return tuple(grads)
+
+
+class DenseBNReLUGather(torch.autograd.Function):
+    """relu(BatchNorm2d_train(Y))[sites]: batch statistics over all R rows of the channels-last map Y (R, C),
+    affine + ReLU applied only to the gathered rows.  Returns (out (M, C) fp32, mean, biased var)."""
+
+    @staticmethod
+    def forward(ctx, Y, gamma, beta, sites, eps):
+        R, C = Y.shape
+        s1, s2 = colstats(Y)
+        mean64 = s1 / R
+        var64 = (s2 / R - mean64 * mean64).clamp_(min=0)
+        mean, var = mean64.float(), var64.float()
+        inv = torch.rsqrt(var + eps)
+        rows = ops.gather_rows_raw(Y, sites).float()
+        yhat = (rows - mean) * inv
+        out = torch.relu(yhat * gamma + beta)
+        ctx.save_for_backward(Y, sites, yhat, out > 0, inv, mean, gamma)
+        ctx.mark_non_differentiable(mean, var)
+        return out, mean, var
+
+    @staticmethod
+    def backward(ctx, dout, _dm, _dv):
+        Y, sites, yhat, mask, inv, mean, gamma = ctx.saved_tensors
+        R = Y.shape[0]
+        g = dout * mask
+        dgamma = (g * yhat).sum(0)
+        dbeta = g.sum(0)
+        dyh = g * gamma
+        m1 = dyh.sum(0, dtype=torch.float64) / R
+        m2 = (dyh * yhat).sum(0, dtype=torch.float64) / R
+        inv64, mean64 = inv.double(), mean.double()
+        # dy = inv * (dyhat - m1 - yhat * m2),  yhat = (y - mean) * inv   ->   dense part = k0 + k1 * y
+        k1 = (-(inv64 * inv64) * m2)
+        k0 = (-inv64 * m1 - k1 * mean64)
+        dY = torch.addcmul(k0.to(Y.dtype), Y, k1.to(Y.dtype))
+        rows = ops.gather_rows_raw(dY, sites).float() + dyh * inv
+        ops.scatter_rows_raw(rows.to(Y.dtype), sites, dY)
+        return dY, dgamma, dbeta, None, None
+
+
+def _update_running(bn, mean, var_biased, n):
+    """nn.BatchNorm running statistics (momentum 0.01, unbiased variance) for checkpoint parity."""
+    if bn.running_mean is None:
+        return
+    with torch.no_grad():
+        bn.running_mean.mul_(1 - bn.momentum).add_(mean.to(bn.running_mean.dtype), alpha=bn.momentum)
+        bn.running_var.mul_(1 - bn.momentum).add_(var_biased.to(bn.running_var.dtype) * (n / max(n - 1, 1)), alpha=bn.momentum)
+        bn.num_batches_tracked += 1
+
+
+def upsampled_sites(stage_plan, s: int, Y: int, X: int) -> torch.Tensor:
+    """(n_tok * s*s,) int32 full-resolution cell of every (token, dy, dx) of a stride-s stage."""
+    c = stage_plan.tok_cell
+    if s == 1:
+        return c
+    x = c % stage_plan.X
+    r = torch.div(c, stage_plan.X, rounding_mode='floor')
+    y = r % stage_plan.Y
+    b = torch.div(r, stage_plan.Y, rounding_mode='floor')
+    d = torch.arange(s, device=c.device, dtype=c.dtype)
+    yy = (y * s).view(-1, 1, 1) + d.view(1, s, 1)
+    xx = (x * s).view(-1, 1, 1) + d.view(1, 1, s)
+    return ((b.view(-1, 1, 1) * Y + yy) * X + xx).reshape(-1).contiguous()
+
+
+def sparse_decoder(model_cfg, deblocks, conv_out, hidden, pillar_cell, B, Y, X, want_dense=False):
+    """hidden: list of SparseConvTensor per stage.  Returns (features at the pillar sites (M, C) fp32,
+    dense spatial_features (B, C, Y, X) or None)."""
+    R = B * Y * X
+    args = []
+    cdt = torch.bfloat16 if torch.is_autocast_enabled() else torch.float32
+    for i, src in enumerate(model_cfg.FEATURES_SOURCE):
+        h = hidden[int(src[-1]) - 1]
+        sp = h.stage_plan
+        deconv, bn = deblocks[i][0], deblocks[i][1]
+        s = int(deconv.stride[0])
+        assert deconv.kernel_size == (s, s) and sp.Y * s == Y and sp.X * s == X and deconv.bias is None
+        cin, cout = deconv.weight.shape[0], deconv.weight.shape[1]
+        wmat = deconv.weight.permute(0, 2, 3, 1).reshape(cin, s * s * cout)      # columns ordered (dy, dx, c)
+        P = (h.features.to(cdt) @ wmat.to(cdt)).view(-1, cout).float()          # (n_tok * s*s, cout)
+        s1 = P.sum(0, dtype=torch.float64)
+        s2 = (P.double() ** 2).sum(0)
+        mean64 = s1 / R
+        var64 = (s2 / R - mean64 * mean64).clamp(min=0)
+        mean, var = mean64.float(), var64.float()
+        a = bn.weight * torch.rsqrt(var + bn.eps)
+        b = bn.bias - a * mean
+        if bn.training:
+            _update_running(bn, mean.detach(), var.detach(), R)
+        args += [upsampled_sites(sp, s, Y, X), torch.relu(P * a + b), torch.relu(b)]
+    Z = BuildDenseCat.apply(R, cdt, *args)                                       # (R, 384) channels-last
+    conv, bn2 = conv_out[0], conv_out[1]
+    zin = Z.view(B, Y, X, -1).permute(0, 3, 1, 2)                                # NCHW view of NHWC memory
+    y2 = F.conv2d(zin, conv.weight.to(cdt) if cdt != conv.weight.dtype else conv.weight, None, 1, 1)
+    y2 = y2.permute(0, 2, 3, 1)
+    if not y2.is_contiguous():
+        y2 = y2.contiguous()
+    y2 = y2.view(R, -1)
+    out, mean2, var2 = DenseBNReLUGather.apply(y2, bn2.weight, bn2.bias, pillar_cell, bn2.eps)
+    if bn2.training:
+        _update_running(bn2, mean2, var2, R)
+    dense = None
+    if want_dense:
+        with torch.no_grad():
+            a2 = bn2.weight * torch.rsqrt(var2 + bn2.eps)
+            dense = torch.relu(y2.float() * a2 + (bn2.bias - a2 * mean2)).view(B, Y, X, -1).permute(0, 3, 1, 2)
+    return out, dense

@@ -38,6 +38,10 @@ SIGNATURES = {
     "gdmae_window_partition": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
     "gdmae_gather_rows": (_I, [_P, _P, _L, _I, _P, _P]),
     "gdmae_scatter_rows": (_I, [_P, _P, _L, _I, _P, _P]),
+    "gdmae_gather_rows_strided": (_I, [_P, _P, _L, _I, _I, _I, _P, _P]),
+    "gdmae_scatter_rows_strided": (_I, [_P, _P, _L, _I, _I, _I, _P, _P]),
+    "gdmae_colstats_workspace_bytes": (_Z, [_I]),
+    "gdmae_colstats": (_I, [_P, _L, _I, _I, _P, _P, _P]),
     "gdmae_window_attention_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _F, _P]),
     "gdmae_window_attention_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _F, _P]),
     "gdmae_sum_partials": (_I, [_P, _L, _F, _P, _I, _P]),

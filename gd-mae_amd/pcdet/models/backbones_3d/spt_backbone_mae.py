@@ -8,10 +8,16 @@ import torch.nn as nn
 
 from .spt_backbone import SSTBlockV1, build_decoder, run_decoder, stage_plan_args
 from ...utils.spconv_utils import SparseConvTensor
-from gdmae_hip import ops, plan as gplan
+from gdmae_hip import decoder as gdec, ops, plan as gplan
 
 
 class SPTBackboneMAE(nn.Module):
+    # 'sparse': exact sparse-aware decoder (gdmae_hip/decoder.py); 'dense': the reference's dataflow through
+    # the torch modules (kept for A/B tests).  dense_spatial_features: materialise batch_dict['spatial_features']
+    # (B, C, Y, X) as the reference does; the pre-training step itself only needs the rows at the pillar sites.
+    decoder_impl = 'sparse'
+    dense_spatial_features = True
+
     def __init__(self, model_cfg, input_channels, grid_size, voxel_size, point_cloud_range, **kwargs):
         super().__init__()
         self.model_cfg, self.grid_size, self.voxel_size, self.point_cloud_range = model_cfg, grid_size, voxel_size, point_cloud_range
@@ -52,16 +58,19 @@ class SPTBackboneMAE(nn.Module):
         for i, h in enumerate(hidden):
             feats[f'x_conv{i + 1}'] = h
             strides[f'x_conv{i + 1}'] = Y0 // h.spatial_shape[0]
-        sf = run_decoder(self.model_cfg, self.decoder_deblocks, self.decoder_conv_out, hidden)   # (B, C, Y, X)
-        B, C, Y, X = sf.shape
-        assert B == batch_dict['batch_size'] and Y == self.grid_size[1] and X == self.grid_size[0]
+        B, X, Y = int(batch_dict['batch_size']), int(self.grid_size[0]), int(self.grid_size[1])
+        if self.decoder_impl == 'sparse':
+            pyramid, sf = gdec.sparse_decoder(self.model_cfg, self.decoder_deblocks, self.decoder_conv_out, hidden,
+                                              vox.pillar_cell, B, Y, X, want_dense=self.dense_spatial_features)
+        else:
+            sf = run_decoder(self.model_cfg, self.decoder_deblocks, self.decoder_conv_out, hidden)   # (B, C, Y, X)
+            assert sf.shape[0] == B and sf.shape[2] == Y and sf.shape[3] == X
+            # features of ALL pillars (masked and visible) gathered from the channels-last map
+            pyramid = ops.GatherUnique.apply(sf.permute(0, 2, 3, 1).reshape(B * Y * X, sf.shape[1]), vox.pillar_cell)
         src0 = self.model_cfg.FEATURES_SOURCE[0]
         batch_dict.update({'encoded_spconv_tensor': hidden[-1], 'encoded_spconv_tensor_stride': Y0 // hidden[-1].spatial_shape[0],
                            'multi_scale_3d_features': feats, 'multi_scale_3d_strides': strides, 'spatial_features': sf,
                            'spatial_features_stride': strides[src0] // self.model_cfg.FUSE_LAYER[src0].UPSAMPLE_STRIDE})
-        # features of ALL pillars (masked and visible) gathered from the channels-last map
-        rows = sf.permute(0, 2, 3, 1).reshape(B * Y * X, C)
-        pyramid = ops.GatherUnique.apply(rows, vox.pillar_cell)
         batch_dict.update({'voxel_features': pyramid, 'voxel_coords': all_coords,
                            'voxel_shuffle_inds': torch.arange(all_coords.shape[0], device=all_coords.device)})
         self.forward_ret_dict = self.target_assigner(batch_dict)

@@ -122,6 +122,19 @@ int gdmae_window_partition(const int* map, int B, int Y, int X, int wx, int wy, 
 int gdmae_gather_rows(const void* src, const int* idx, long long n_slots, int row_bytes, void* out, void* stream);
 int gdmae_scatter_rows(const void* src, const int* idx, long long n_rows, int row_bytes, void* dst, void* stream);
 
+/* Column-slice variants (the table - src of the gather / dst of the scatter - has rows of table_row_bytes and
+ * the moved slice starts at table_col_bytes): write / read one 128-channel source of the decoder's 384-channel
+ * concatenated map in place, instead of torch.cat (spt_backbone_mae.py:132). */
+int gdmae_gather_rows_strided(const void* src, const int* idx, long long n_slots, int row_bytes, int table_row_bytes,
+                              int table_col_bytes, void* out, void* stream);
+int gdmae_scatter_rows_strided(const void* src, const int* idx, long long n_rows, int row_bytes, int table_row_bytes,
+                               int table_col_bytes, void* dst, void* stream);
+/* gdmae_colstats: out double[2*C] = per-column {sum, sum of squares} of a row-major (R, C) fp32 (is_bf16 = 0)
+ * or bf16 (1) matrix; deterministic.  BatchNorm2d batch statistics of channels-last dense maps
+ * (nn.BatchNorm2d in spt_backbone_mae.py:40,47) and column sums of dense gradients. */
+size_t gdmae_colstats_workspace_bytes(int C);
+int gdmae_colstats(const void* x, long long R, int C, int is_bf16, double* out, void* workspace, void* stream);
+
 /* ---- a11, a13: windowed cosine attention ------------------------------------------------------ *
  * Replaces flat2window_v2/window2flat_v2 (sst_utils.py:107-180), WindowAttention.forward
  * (pcdet/models/model_utils/sst_basic_block.py:22-54) and _scaled_cosine_attention

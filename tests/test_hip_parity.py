@@ -278,14 +278,17 @@ def test_chamfer_matches_oracle():
     assert float(z) == 0.0
 
 
+@pytest.mark.parametrize("decoder_impl", ["sparse", "dense"])
 @pytest.mark.parametrize("name", CASES)
-def test_full_model_forward_backward_vs_reference_golden(name):
-    """Whole pre-training forward/backward through the pcdet-compatible modules, fp32 mode."""
+def test_full_model_forward_backward_vs_reference_golden(name, decoder_impl):
+    """Whole pre-training forward/backward through the pcdet-compatible modules, fp32 mode, with the
+    sparse-aware decoder (product default) and with the reference's dense dataflow."""
     import logging
     from pcdet.models import build_network
     z, ds, cfg, shapes = load_case(name)
     torch.manual_seed(0)
     net = build_network(cfg, len(ds.class_names), ds, logging.getLogger("t")).to(dev())
+    net.backbone_3d.decoder_impl = decoder_impl
     sd = orc.seeded_state_dict(shapes, seed=int(z["seed"]))
     missing, unexpected = net.load_state_dict(sd, strict=False)
     assert not unexpected and all(("running_" in m or "num_batches" in m or m == "global_step") for m in missing)
@@ -346,3 +349,58 @@ def test_sst_ops_dropin_api_matches_sequential_kernels():
     assert grouped.shape == (M, K, 3)
     ref = pts[torch.from_numpy(exp)]           # -1 indexes the last row, exactly like the reference's points[group_inds]
     assert torch.equal(grouped.cpu(), ref)
+
+
+def test_colstats_and_strided_rows():
+    from gdmae_hip import decoder as gdec
+    g = torch.Generator().manual_seed(4)
+    for dtype, C, R in [(torch.float32, 128, 5003), (torch.bfloat16, 128, 70001), (torch.bfloat16, 384, 9000),
+                        (torch.float32, 384, 777), (torch.float32, 64, 1)]:
+        x = (torch.randn(R, C, generator=g) * 3 + 1).to(dtype)
+        s1, s2 = gdec.colstats(x.to(dev()))
+        xd = x.double()
+        assert torch.allclose(s1.cpu(), xd.sum(0), rtol=1e-6, atol=1e-6 * R)
+        assert torch.allclose(s2.cpu(), (xd * xd).sum(0), rtol=1e-6, atol=1e-6 * R)
+    table = torch.randn(1000, 384, generator=g).to(torch.bfloat16)
+    idx = torch.randperm(1000, generator=g)[:300].int()
+    sl = gdec._gather_slice(table.to(dev()), idx.to(dev()), 128, 128)
+    assert torch.equal(sl.cpu(), table[idx.long(), 128:256])
+    dst = table.clone().to(dev())
+    src = torch.randn(300, 128, generator=g).to(torch.bfloat16)
+    gdec._scatter_slice(src.to(dev()), idx.to(dev()), dst, 256)
+    exp = table.clone()
+    exp[idx.long(), 256:384] = src
+    assert torch.equal(dst.cpu(), exp)
+
+
+def test_sparse_decoder_equals_dense_decoder_and_updates_running_stats():
+    """A/B on the same weights: the exact sparse-aware decoder vs the dense torch dataflow (loss, pillar features,
+    every decoder / encoder gradient, BN running statistics)."""
+    import copy
+    import logging
+    from pcdet.models import build_network
+    z, ds, cfg, shapes = load_case("kitti_b2_m75")
+    res = {}
+    for impl in ("sparse", "dense"):
+        torch.manual_seed(0)
+        net = build_network(cfg, 3, ds, logging.getLogger("t")).to(dev())
+        net.load_state_dict(orc.seeded_state_dict(shapes, seed=5), strict=False)
+        net.backbone_3d.decoder_impl = impl
+        net.train()
+        bd = {"points": torch.from_numpy(z["points"]).to(dev()), "batch_size": int(z["batch_size"]),
+              "mae_noise": torch.from_numpy(z["noise"]).to(dev())}
+        ret, _, _ = net(bd)
+        ret["loss"].backward()
+        res[impl] = (float(ret["loss"].detach()), bd["voxel_features"].detach().cpu(), bd["spatial_features"].detach().cpu(),
+                     {k: p.grad.detach().cpu() for k, p in net.named_parameters()},
+                     {k: v.detach().cpu().clone() for k, v in net.state_dict().items() if "running" in k or "num_batches" in k})
+    ls, vs, sfs, gs, rs = res["sparse"]
+    ld, vd, sfd, gd, rd = res["dense"]
+    assert abs(ls - ld) <= 2e-6 * abs(ld)
+    assert (vs - vd).abs().max() <= 2e-5 * vd.abs().max()
+    assert (sfs - sfd).abs().max() <= 2e-5 * sfd.abs().max()
+    for k in gs:
+        tol = 5e-2 if k.endswith("tau") else 2e-3
+        assert (gs[k] - gd[k]).norm() <= tol * gd[k].norm() + 1e-7, (k, float((gs[k] - gd[k]).norm() / gd[k].norm()))
+    for k in rs:
+        assert torch.allclose(rs[k].float(), rd[k].float(), rtol=1e-4, atol=1e-6), k
