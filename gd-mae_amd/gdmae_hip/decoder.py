@@ -173,7 +173,7 @@ def sparse_decoder(model_cfg, deblocks, conv_out, hidden, pillar_cell, B, Y, X, 
         assert deconv.kernel_size == (s, s) and sp.Y * s == Y and sp.X * s == X and deconv.bias is None
         cin, cout = deconv.weight.shape[0], deconv.weight.shape[1]
         wmat = deconv.weight.permute(0, 2, 3, 1).reshape(cin, s * s * cout)      # columns ordered (dy, dx, c)
-        P = (h.features.to(cdt) @ wmat.to(cdt)).view(-1, cout).float()          # (n_tok * s*s, cout)
+        P = ops.linear(h.features, wmat.t()).view(-1, cout).float()             # (n_tok * s*s, cout)
         s1 = P.sum(0, dtype=torch.float64)
         s2 = (P.double() ** 2).sum(0)
         mean64 = s1 / R

@@ -71,6 +71,68 @@ class GatherUnique(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------------------------------------
+# token-wise linear layers: split-K weight gradients
+# ------------------------------------------------------------------------------------------------
+_BMM_OUT_DTYPE_OK = None
+
+
+def splitk_tn(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """a (K, m), b (K, n) -> a^T @ b (m, n) in fp32, with the long K (= tokens / points / sites) dimension
+    split over a batched GEMM.  Weight gradients of this model are (<=512 x <=2304) outputs with K = 20 k ... 1.4 M:
+    as one GEMM they fill 16-72 output tiles, i.e. a few CUs of 256 (measured 130-1950 us each on MI355X);
+    as S batched partial products + one small reduction every CU is busy."""
+    global _BMM_OUT_DTYPE_OK
+    K, m = a.shape
+    n = b.shape[1]
+    tiles = max(1, (m + 127) // 128) * max(1, (n + 127) // 128)
+    S = max(1, min(K // 256, (1024 + tiles - 1) // tiles, 256))
+    if S <= 1:
+        return (a.t() @ b).float()
+    kc = K // S
+    K0 = kc * S
+    a3 = a[:K0].view(S, kc, m).transpose(1, 2)
+    b3 = b[:K0].view(S, kc, n)
+    out = None
+    if a.dtype != torch.float32 and _BMM_OUT_DTYPE_OK is not False:
+        try:
+            out = torch.bmm(a3, b3, out_dtype=torch.float32).sum(0)
+            _BMM_OUT_DTYPE_OK = True
+        except (TypeError, RuntimeError):
+            _BMM_OUT_DTYPE_OK = False
+    if out is None:
+        out = torch.bmm(a3, b3).sum(0, dtype=torch.float32)
+    if K0 < K:
+        out = out + (a[K0:].t() @ b[K0:]).float()
+    return out
+
+
+class LinearSplitK(torch.autograd.Function):
+    """y = x W^T + b with bf16 compute under autocast (fp32 otherwise) and a split-K weight gradient."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        cdt = torch.bfloat16 if torch.is_autocast_enabled() else x.dtype
+        xc = x.to(cdt)
+        y = torch.nn.functional.linear(xc, weight.to(cdt), None if bias is None else bias.to(cdt))
+        ctx.save_for_backward(xc, weight)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        xc, weight = ctx.saved_tensors
+        g = g.contiguous().to(xc.dtype)
+        dx = g @ weight.to(g.dtype)
+        dw = splitk_tn(g, xc).to(weight.dtype)
+        db = g.sum(0, dtype=torch.float32) if ctx.has_bias else None
+        return dx, dw, db
+
+
+def linear(x, weight, bias=None):
+    return LinearSplitK.apply(x, weight, bias)
+
+
+# ------------------------------------------------------------------------------------------------
 # 2-D sparse convolution = rulebook gather (HIP) + one GEMM (hipBLASLt)
 # ------------------------------------------------------------------------------------------------
 class SparseConv3x3(torch.autograd.Function):
@@ -93,7 +155,7 @@ class SparseConv3x3(torch.autograd.Function):
         cols, weight, nbr_t = ctx.saved_tensors
         cout, _, _, cin = weight.shape
         g = g.contiguous().to(cols.dtype)
-        dw = (g.t() @ cols).view(cout, 3, 3, cin).to(weight.dtype)
+        dw = splitk_tn(g, cols).view(cout, 3, 3, cin).to(weight.dtype)
         gcols = gather_rows_raw(g, nbr_t).view(nbr_t.shape[0], 9 * cout)
         wt = weight.permute(1, 2, 0, 3).reshape(9 * cout, cin).to(g.dtype)
         return gcols @ wt, dw, None, None

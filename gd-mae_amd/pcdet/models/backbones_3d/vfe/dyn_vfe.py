@@ -36,7 +36,9 @@ class DynVFE(VFETemplate):
     def forward(self, batch_dict, **kwargs):
         vox = gplan.voxelize(batch_dict['points'], self.point_cloud_range, self.voxel_size, self.grid_size,
                              int(batch_dict['batch_size']))
-        x = self.dvfe_mlps[0](ops.decorate_points(vox))
+        x = ops.decorate_points(vox)
+        for m in self.dvfe_mlps[0]:                      # Linear(no bias) -> BN1d -> ReLU, twice
+            x = ops.linear(x, m.weight, m.bias) if isinstance(m, nn.Linear) else m(x)
         x = ops.SegmentMax.apply(x.float(), vox.pt_off, vox.pillar_pts, vox.inverse32)
         batch_dict.update({'points': vox.points, 'point_coords': vox.point_coords,
                            'point_inverse_indices': vox.inverse, 'voxel_coords': vox.voxel_coords,

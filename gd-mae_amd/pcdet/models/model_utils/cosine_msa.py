@@ -30,7 +30,7 @@ class CosineMultiheadAttention(nn.Module):
         """x (n, d) tokens, pos (n, d) positional embedding of the tokens, wplan: gdmae_hip.plan.WindowPlan.
         q = k = x + pos, v = x with separate q/k/v slices of the packed projection (cosine_msa.py:56-62)."""
         d = self.embed_dim
-        qk = F.linear(x + pos, self.in_proj_weight[:2 * d], self.in_proj_bias[:2 * d])
-        v = F.linear(x, self.in_proj_weight[2 * d:], self.in_proj_bias[2 * d:])
+        qk = ops.linear(x + pos, self.in_proj_weight[:2 * d], self.in_proj_bias[:2 * d])
+        v = ops.linear(x, self.in_proj_weight[2 * d:], self.in_proj_bias[2 * d:])
         o = ops.WindowCosineAttention.apply(qk.float(), v.float(), self.tau, wplan, self.num_heads, self.tau_min)
-        return self.out_proj(o.to(x.dtype))
+        return ops.linear(o, self.out_proj.weight, self.out_proj.bias)

@@ -6,6 +6,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .cosine_msa import CosineMultiheadAttention
+from gdmae_hip import ops
 
 
 class WindowAttention(nn.Module):
@@ -39,7 +40,8 @@ class EncoderLayer(nn.Module):
 
     def forward(self, src, pos, wplan):
         src = self.norm1(src + self.win_attn(src, pos, wplan))
-        return self.norm2(src + self.linear2(self.activation(self.linear1(src))))
+        h = self.activation(ops.linear(src, self.linear1.weight, self.linear1.bias))
+        return self.norm2(src + ops.linear(h, self.linear2.weight, self.linear2.bias))
 
 
 class BasicShiftBlockV2(nn.Module):
