@@ -24,6 +24,58 @@
 
 #define ATT_EPS 1e-12f
 
+// ---- global-memory row IO: fp32 or bf16 (token GEMM outputs under bf16 autocast), fp32 in registers ----
+__device__ inline float bf2f(unsigned v) { return __uint_as_float(v << 16); }
+__device__ inline unsigned f2bf(float f) {   // round-to-nearest-even
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7F800000u) == 0x7F800000u) return u >> 16;
+  return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+struct IoF32 {
+  typedef float T;
+  template <int DH>
+  static __device__ inline void load(const T* __restrict__ p, float (&r)[DH]) {
+#pragma unroll
+    for (int c = 0; c < DH; c += 4) {
+      float4 v = *reinterpret_cast<const float4*>(p + c);
+      r[c] = v.x; r[c + 1] = v.y; r[c + 2] = v.z; r[c + 3] = v.w;
+    }
+  }
+  template <int DH>
+  static __device__ inline void store(T* __restrict__ p, const float (&r)[DH]) {
+#pragma unroll
+    for (int c = 0; c < DH; c += 4) *reinterpret_cast<float4*>(p + c) = make_float4(r[c], r[c + 1], r[c + 2], r[c + 3]);
+  }
+};
+struct IoBF16 {
+  typedef unsigned short T;
+  template <int DH>
+  static __device__ inline void load(const T* __restrict__ p, float (&r)[DH]) {
+#pragma unroll
+    for (int c = 0; c < DH; c += 8) {
+      uint4 v = *reinterpret_cast<const uint4*>(p + c);
+      const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        r[c + 2 * k] = bf2f(w[k] & 0xFFFFu);
+        r[c + 2 * k + 1] = __uint_as_float(w[k] & 0xFFFF0000u);
+      }
+    }
+  }
+  template <int DH>
+  static __device__ inline void store(T* __restrict__ p, const float (&r)[DH]) {
+#pragma unroll
+    for (int c = 0; c < DH; c += 8) {
+      uint4 v;
+      v.x = f2bf(r[c]) | (f2bf(r[c + 1]) << 16);
+      v.y = f2bf(r[c + 2]) | (f2bf(r[c + 3]) << 16);
+      v.z = f2bf(r[c + 4]) | (f2bf(r[c + 5]) << 16);
+      v.w = f2bf(r[c + 6]) | (f2bf(r[c + 7]) << 16);
+      *reinterpret_cast<uint4*>(p + c) = v;
+    }
+  }
+};
+
 template <int DH>
 __device__ inline void load_row(const float* __restrict__ p, float (&r)[DH]) {
 #pragma unroll
@@ -66,9 +118,9 @@ __device__ inline float normalize(float (&r)[DH], float& inv_norm) {
 }
 
 struct AttnArgs {
-  const float* qk;   // (Ms, 2d): q in [0,d), k in [d,2d)
-  const float* v;    // (Ms, d)
-  float* out;        // (Ms, d)
+  const void* qk;    // (Ms, 2d): q in [0,d), k in [d,2d)   fp32 or bf16 (IO)
+  const void* v;     // (Ms, d)
+  void* out;         // (Ms, d)
   const int* csr_tok;
   const int* win_start;
   const int* win_len;
@@ -79,8 +131,12 @@ struct AttnArgs {
   float tau_min;
 };
 
-template <int T, int DH>
+template <int T, int DH, typename IO>
 __global__ __launch_bounds__(256) void k_win_attn_fwd(AttnArgs A) {
+  typedef typename IO::T io_t;
+  const io_t* gqk = (const io_t*)A.qk;
+  const io_t* gv = (const io_t*)A.v;
+  io_t* gout = (io_t*)A.out;
   constexpr int G = GD_WAVE / T;          // heads per wavefront
   constexpr int LD = DH + 4;              // padded LDS row
   constexpr int GS = T * LD + 16;         // head-tile stride: +16 floats so packed heads start on different banks
@@ -106,12 +162,12 @@ __global__ __launch_bounds__(256) void k_win_attn_fwd(AttnArgs A) {
   float q[DH], tmp[DH];
   float dummy;
   if (act) {
-    load_row<DH>(A.qk + (long long)t * 2 * A.d + h * DH, q);
+    IO::template load<DH>(gqk + (long long)t * 2 * A.d + h * DH, q);
     normalize<DH>(q, dummy);
-    load_row<DH>(A.qk + (long long)t * 2 * A.d + A.d + h * DH, tmp);
+    IO::template load<DH>(gqk + (long long)t * 2 * A.d + A.d + h * DH, tmp);
     normalize<DH>(tmp, dummy);
     store_row<DH>(sK + sub * GS + r * LD, tmp);
-    load_row<DH>(A.v + (long long)t * A.d + h * DH, tmp);
+    IO::template load<DH>(gv + (long long)t * A.d + h * DH, tmp);
     store_row<DH>(sV + sub * GS + r * LD, tmp);
   }
   __builtin_amdgcn_wave_barrier();
@@ -154,15 +210,15 @@ __global__ __launch_bounds__(256) void k_win_attn_fwd(AttnArgs A) {
   const float il = 1.f / l;
 #pragma unroll
   for (int c = 0; c < DH; ++c) o[c] *= il;
-  store_row<DH>(A.out + (long long)t * A.d + h * DH, o);
+  IO::template store<DH>(gout + (long long)t * A.d + h * DH, o);
 }
 
 struct AttnBwdArgs {
-  const float* qk;
-  const float* v;
-  const float* dout;  // (Ms, d)
-  float* dqk;         // (Ms, 2d)
-  float* dv;          // (Ms, d)
+  const void* qk;     // fp32 or bf16 (IO), like the forward
+  const void* v;
+  const void* dout;   // (Ms, d)
+  void* dqk;          // (Ms, 2d)
+  void* dv;           // (Ms, d)
   float* dtau_part;   // one partial per wavefront item
   const int* csr_tok;
   const int* win_start;
@@ -174,8 +230,14 @@ struct AttnBwdArgs {
   float tau_min;
 };
 
-template <int T, int DH>
+template <int T, int DH, typename IO>
 __global__ __launch_bounds__(256) void k_win_attn_bwd(AttnBwdArgs A) {
+  typedef typename IO::T io_t;
+  const io_t* gqk = (const io_t*)A.qk;
+  const io_t* gv = (const io_t*)A.v;
+  const io_t* gdo = (const io_t*)A.dout;
+  io_t* gdqk = (io_t*)A.dqk;
+  io_t* gdv = (io_t*)A.dv;
   constexpr int G = GD_WAVE / T;
   constexpr int LD = DH + 4;
   constexpr int GS = T * LD + 16;
@@ -205,14 +267,14 @@ __global__ __launch_bounds__(256) void k_win_attn_bwd(AttnBwdArgs A) {
   float qin = 0.f, kin = 0.f;  // 1 / max(|q|, eps)
   if (act) {
     float tmp[DH];
-    load_row<DH>(A.qk + (long long)t * 2 * A.d + A.d + h * DH, tmp);
+    IO::template load<DH>(gqk + (long long)t * 2 * A.d + A.d + h * DH, tmp);
     normalize<DH>(tmp, kin);
     store_row<DH>(s0 + sub * GS + r * LD, tmp);  // K^
-    load_row<DH>(A.v + (long long)t * A.d + h * DH, tmp);
+    IO::template load<DH>(gv + (long long)t * A.d + h * DH, tmp);
     store_row<DH>(s1 + sub * GS + r * LD, tmp);  // V
-    load_row<DH>(A.qk + (long long)t * 2 * A.d + h * DH, q);
+    IO::template load<DH>(gqk + (long long)t * 2 * A.d + h * DH, q);
     normalize<DH>(q, qin);
-    load_row<DH>(A.dout + (long long)t * A.d + h * DH, dO);
+    IO::template load<DH>(gdo + (long long)t * A.d + h * DH, dO);
   }
   __builtin_amdgcn_wave_barrier();
   float dtau = 0.f;
@@ -269,7 +331,7 @@ __global__ __launch_bounds__(256) void k_win_attn_bwd(AttnBwdArgs A) {
     for (int c = 0; c < DH; ++c) pr = fmaf(q[c], dq[c], pr);
 #pragma unroll
     for (int c = 0; c < DH; ++c) dq[c] = (dq[c] - q[c] * pr) * qin;
-    store_row<DH>(A.dqk + (long long)t * 2 * A.d + h * DH, dq);
+    IO::template store<DH>(gdqk + (long long)t * 2 * A.d + h * DH, dq);
     sLse[lane] = m + logf(l);
     sD[lane] = D;
   }
@@ -319,8 +381,8 @@ __global__ __launch_bounds__(256) void k_win_attn_bwd(AttnBwdArgs A) {
     for (int c = 0; c < DH; ++c) pr = fmaf(k[c], dk[c], pr);
 #pragma unroll
     for (int c = 0; c < DH; ++c) dk[c] = (dk[c] - k[c] * pr) * kin;
-    store_row<DH>(A.dqk + (long long)t * 2 * A.d + A.d + h * DH, dk);
-    store_row<DH>(A.dv + (long long)t * A.d + h * DH, dvv);
+    IO::template store<DH>(gdqk + (long long)t * 2 * A.d + A.d + h * DH, dk);
+    IO::template store<DH>(gdv + (long long)t * A.d + h * DH, dvv);
   }
   dtau = gd_wave_sum(dtau);
   if (lane == 0) A.dtau_part[item] = dtau;
@@ -349,27 +411,51 @@ extern "C" int gdmae_sum_partials(const float* part, long long n, float scale, f
   return 0;
 }
 
-template <int T, int DH>
+template <int T, int DH, typename IO>
 static int launch_fwd(const AttnArgs& A, hipStream_t st) {
   constexpr int G = GD_WAVE / T;
   const long long items = (long long)A.n_win * (A.H / G);
   const size_t lds = 4 * (2 * G * (T * (DH + 4) + 16)) * sizeof(float);
-  hipLaunchKernelGGL((k_win_attn_fwd<T, DH>), dim3(gd_div_up(items, 4)), dim3(256), lds, st, A);
+  hipLaunchKernelGGL((k_win_attn_fwd<T, DH, IO>), dim3(gd_div_up(items, 4)), dim3(256), lds, st, A);
   GD_LAUNCH_CHECK();
   return 0;
 }
-template <int T, int DH>
+template <int T, int DH, typename IO>
 static int launch_bwd(const AttnBwdArgs& A, hipStream_t st) {
   constexpr int G = GD_WAVE / T;
   const long long items = (long long)A.n_win * (A.H / G);
   const size_t lds = 4 * (2 * G * (T * (DH + 4) + 16) + 2 * GD_WAVE) * sizeof(float);
-  hipLaunchKernelGGL((k_win_attn_bwd<T, DH>), dim3(gd_div_up(items, 4)), dim3(256), lds, st, A);
+  hipLaunchKernelGGL((k_win_attn_bwd<T, DH, IO>), dim3(gd_div_up(items, 4)), dim3(256), lds, st, A);
   GD_LAUNCH_CHECK();
   return 0;
 }
 
+template <typename IO>
+static int dispatch_fwd(const AttnArgs& A, int T, int DH, hipStream_t st) {
+  if (DH == 16) {
+    if (T == 16) return launch_fwd<16, 16, IO>(A, st);
+    if (T == 32) return launch_fwd<32, 16, IO>(A, st);
+    return launch_fwd<64, 16, IO>(A, st);
+  }
+  if (T == 16) return launch_fwd<16, 32, IO>(A, st);
+  if (T == 32) return launch_fwd<32, 32, IO>(A, st);
+  return launch_fwd<64, 32, IO>(A, st);
+}
+template <typename IO>
+static int dispatch_bwd(const AttnBwdArgs& A, int T, int DH, hipStream_t st) {
+  if (DH == 16) {
+    if (T == 16) return launch_bwd<16, 16, IO>(A, st);
+    if (T == 32) return launch_bwd<32, 16, IO>(A, st);
+    return launch_bwd<64, 16, IO>(A, st);
+  }
+  if (T == 16) return launch_bwd<16, 32, IO>(A, st);
+  if (T == 32) return launch_bwd<32, 32, IO>(A, st);
+  return launch_bwd<64, 32, IO>(A, st);
+}
+
 // One occupancy level: windows [0, n_win) of (win_start, win_len); T = padded tokens of the level.
-extern "C" int gdmae_window_attention_fwd(const float* qk, const float* v, float* out, const int* csr_tok,
+// io_bf16 = 0: qk / v / out are fp32; 1: bf16 (arithmetic is fp32 in registers either way).
+extern "C" int gdmae_window_attention_fwd(const void* qk, const void* v, void* out, int io_bf16, const int* csr_tok,
                                           const int* win_start, const int* win_len, int n_win, int T, int d, int H,
                                           const float* tau, float tau_min, void* stream) {
   if (n_win <= 0) return 0;
@@ -380,18 +466,11 @@ extern "C" int gdmae_window_attention_fwd(const float* qk, const float* v, float
   GD_REQUIRE(H % (GD_WAVE / T) == 0, "heads must pack evenly into a wavefront");
   AttnArgs A{qk, v, out, csr_tok, win_start, win_len, n_win, d, H, tau, tau_min};
   hipStream_t st = (hipStream_t)stream;
-  if (DH == 16) {
-    if (T == 16) return launch_fwd<16, 16>(A, st);
-    if (T == 32) return launch_fwd<32, 16>(A, st);
-    return launch_fwd<64, 16>(A, st);
-  }
-  if (T == 16) return launch_fwd<16, 32>(A, st);
-  if (T == 32) return launch_fwd<32, 32>(A, st);
-  return launch_fwd<64, 32>(A, st);
+  return io_bf16 ? dispatch_fwd<IoBF16>(A, T, DH, st) : dispatch_fwd<IoF32>(A, T, DH, st);
 }
 
 // dtau_part must hold n_win * H / (64 / T) floats.
-extern "C" int gdmae_window_attention_bwd(const float* qk, const float* v, const float* dout, float* dqk, float* dv,
+extern "C" int gdmae_window_attention_bwd(const void* qk, const void* v, const void* dout, void* dqk, void* dv, int io_bf16,
                                           float* dtau_part, const int* csr_tok, const int* win_start, const int* win_len,
                                           int n_win, int T, int d, int H, const float* tau, float tau_min, void* stream) {
   if (n_win <= 0) return 0;
@@ -402,12 +481,5 @@ extern "C" int gdmae_window_attention_bwd(const float* qk, const float* v, const
   GD_REQUIRE(H % (GD_WAVE / T) == 0, "heads must pack evenly into a wavefront");
   AttnBwdArgs A{qk, v, dout, dqk, dv, dtau_part, csr_tok, win_start, win_len, n_win, d, H, tau, tau_min};
   hipStream_t st = (hipStream_t)stream;
-  if (DH == 16) {
-    if (T == 16) return launch_bwd<16, 16>(A, st);
-    if (T == 32) return launch_bwd<32, 16>(A, st);
-    return launch_bwd<64, 16>(A, st);
-  }
-  if (T == 16) return launch_bwd<16, 32>(A, st);
-  if (T == 32) return launch_bwd<32, 32>(A, st);
-  return launch_bwd<64, 32>(A, st);
+  return io_bf16 ? dispatch_bwd<IoBF16>(A, T, DH, st) : dispatch_bwd<IoF32>(A, T, DH, st);
 }

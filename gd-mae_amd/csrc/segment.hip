@@ -298,11 +298,19 @@ __global__ __launch_bounds__(256) void k_colstats_partial(const uint4* __restric
 
 __global__ __launch_bounds__(256) void k_colstats_final(const float* __restrict__ part, int nblk, int C2,
                                                         double* __restrict__ out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C2) return;
+  __shared__ double sh[16][17];
+  const int cl = threadIdx.x & 15, ps = threadIdx.x >> 4;   // 16 columns x 16 partial slices per workgroup
+  const int c = blockIdx.x * 16 + cl;
   double acc = 0.0;
-  for (int b = 0; b < nblk; ++b) acc += (double)part[(long long)b * C2 + c];
-  out[c] = acc;
+  if (c < C2)
+    for (int b = ps; b < nblk; b += 16) acc += (double)part[(long long)b * C2 + c];
+  sh[ps][cl] = acc;
+  __syncthreads();
+  if (ps == 0 && c < C2) {
+    double s = 0.0;
+    for (int k = 0; k < 16; ++k) s += sh[k][cl];
+    out[c] = s;
+  }
 }
 
 extern "C" size_t gdmae_colstats_workspace_bytes(int C) { return (size_t)1024 * 2 * C * sizeof(float); }
@@ -321,7 +329,7 @@ extern "C" int gdmae_colstats(const void* x, long long R, int C, int is_bf16, do
   else
     hipLaunchKernelGGL((k_colstats_partial<false>), dim3(nblk), dim3(256), lds, st, (const uint4*)x, R, C, (float*)workspace);
   GD_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_colstats_final, dim3(gd_div_up(2 * C, 256)), dim3(256), 0, st, (const float*)workspace, nblk, 2 * C, out);
+  hipLaunchKernelGGL(k_colstats_final, dim3(gd_div_up(2 * C, 16)), dim3(256), 0, st, (const float*)workspace, nblk, 2 * C, out);
   GD_LAUNCH_CHECK();
   return 0;
 }

@@ -196,26 +196,66 @@ def decorate_points(vox) -> torch.Tensor:
 
 
 # ------------------------------------------------------------------------------------------------
+# fused residual add + LayerNorm
+# ------------------------------------------------------------------------------------------------
+class AddLayerNorm(torch.autograd.Function):
+    """LayerNorm(a + b) * gamma + beta, one HBM pass (a fp32, b fp32 or bf16)."""
+
+    @staticmethod
+    def forward(ctx, a, b, gamma, beta, eps):
+        a = _f32c(a)
+        b = b.contiguous()
+        assert b.dtype in (torch.float32, torch.bfloat16) and a.shape == b.shape
+        n, d = a.shape
+        y = torch.empty_like(a)
+        stats = torch.empty(n, 2, dtype=torch.float32, device=a.device)
+        L.call("gdmae_add_layernorm_fwd", L.ptr(a), L.ptr(b), int(b.dtype == torch.bfloat16), L.ptr(gamma.detach().contiguous()),
+               L.ptr(beta.detach().contiguous()), n, d, float(eps), L.ptr(y), L.ptr(stats), L.stream())
+        ctx.save_for_backward(a, b, gamma, stats)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b, gamma, stats = ctx.saved_tensors
+        n, d = a.shape
+        dx = torch.empty_like(a)
+        dgb = torch.empty(2 * d, dtype=torch.float32, device=a.device)
+        ws = torch.empty(L.load().gdmae_add_layernorm_workspace_bytes(d), dtype=torch.uint8, device=a.device)
+        L.call("gdmae_add_layernorm_bwd", L.ptr(a), L.ptr(b), int(b.dtype == torch.bfloat16), L.ptr(gamma.detach().contiguous()),
+               L.ptr(stats), L.ptr(_f32c(g)), n, d, L.ptr(dx), L.ptr(dgb), L.ptr(ws), L.stream())
+        return dx, dx.to(b.dtype), dgb[:d], dgb[d:], None
+
+
+def add_layer_norm(a, b, norm: torch.nn.LayerNorm):
+    return AddLayerNorm.apply(a, b, norm.weight, norm.bias, norm.eps)
+
+
+# ------------------------------------------------------------------------------------------------
 # windowed cosine attention
 # ------------------------------------------------------------------------------------------------
 class WindowCosineAttention(torch.autograd.Function):
+    """qk (n, 2d), v (n, d) fp32 or bf16 (both the same) -> out (n, d) in that dtype; fp32 arithmetic inside."""
+
     @staticmethod
     def forward(ctx, qk, v, tau, wplan, nhead, tau_min):
-        qk, v = _f32c(qk), _f32c(v)
+        assert qk.dtype == v.dtype and qk.dtype in (torch.float32, torch.bfloat16)
+        qk, v = qk.contiguous(), v.contiguous()
+        bf = int(qk.dtype == torch.bfloat16)
+        es = qk.element_size()
         n, d = v.shape
-        out = torch.empty(n, d, dtype=torch.float32, device=v.device)
-        tau_flat = tau.detach().reshape(1).contiguous()
+        out = torch.empty(n, d, dtype=v.dtype, device=v.device)
+        tau_flat = tau.detach().reshape(1).float().contiguous()
         base = 0
         for lvl, nw in enumerate(wplan.n_win):
             if nw > 0:
                 # algorithmic bytes: q,k,v rows read + out row written per token, + CSR (4 B/token + 8 B/window)
-                with timing.kernel("k_win_attn_fwd", wplan.n_tok[lvl] * (16 * d + 4) + 8 * nw):
-                    L.call("gdmae_window_attention_fwd", L.ptr(qk), L.ptr(v), L.ptr(out), L.ptr(wplan.csr_tok),
+                with timing.kernel("k_win_attn_fwd", wplan.n_tok[lvl] * (4 * d * es + 4) + 8 * nw):
+                    L.call("gdmae_window_attention_fwd", L.ptr(qk), L.ptr(v), L.ptr(out), bf, L.ptr(wplan.csr_tok),
                            L.ptr(wplan.win_start[base:]), L.ptr(wplan.win_len[base:]), nw, wplan.max_tokens[lvl], d, nhead,
                            L.ptr(tau_flat), float(tau_min), L.stream())
             base += nw
         ctx.save_for_backward(qk, v, tau_flat)
-        ctx.wplan, ctx.nhead, ctx.tau_min, ctx.tau_shape = wplan, nhead, tau_min, tau.shape
+        ctx.wplan, ctx.nhead, ctx.tau_min, ctx.tau_shape, ctx.tau_dtype = wplan, nhead, tau_min, tau.shape, tau.dtype
         return out
 
     @staticmethod
@@ -223,7 +263,9 @@ class WindowCosineAttention(torch.autograd.Function):
         qk, v, tau_flat = ctx.saved_tensors
         wplan, H = ctx.wplan, ctx.nhead
         n, d = v.shape
-        g = _f32c(g)
+        g = g.contiguous().to(v.dtype)
+        bf = int(v.dtype == torch.bfloat16)
+        es = v.element_size()
         dqk = torch.empty_like(qk)
         dv = torch.empty_like(v)
         n_items = [nw * H // (64 // T) for nw, T in zip(wplan.n_win, wplan.max_tokens)]
@@ -231,9 +273,9 @@ class WindowCosineAttention(torch.autograd.Function):
         base, pbase = 0, 0
         for lvl, nw in enumerate(wplan.n_win):
             if nw > 0:
-                # algorithmic bytes: q,k,v,dout rows read + dq,dk,dv rows written per token (7 d floats), + CSR
-                with timing.kernel("k_win_attn_bwd", wplan.n_tok[lvl] * (28 * d + 4) + 8 * nw):
-                    L.call("gdmae_window_attention_bwd", L.ptr(qk), L.ptr(v), L.ptr(g), L.ptr(dqk), L.ptr(dv),
+                # algorithmic bytes: q,k,v,dout rows read + dq,dk,dv rows written per token (7 d elements), + CSR
+                with timing.kernel("k_win_attn_bwd", wplan.n_tok[lvl] * (7 * d * es + 4) + 8 * nw):
+                    L.call("gdmae_window_attention_bwd", L.ptr(qk), L.ptr(v), L.ptr(g), L.ptr(dqk), L.ptr(dv), bf,
                            L.ptr(part[pbase:]), L.ptr(wplan.csr_tok), L.ptr(wplan.win_start[base:]),
                            L.ptr(wplan.win_len[base:]), nw, wplan.max_tokens[lvl], d, H, L.ptr(tau_flat),
                            float(ctx.tau_min), L.stream())
@@ -243,7 +285,7 @@ class WindowCosineAttention(torch.autograd.Function):
         if pbase > 0:
             L.call("gdmae_sum_partials", L.ptr(part), pbase, 1.0, L.ptr(dtau), 0, L.stream())
         # d clamp(tau, min)/d tau = 1 where tau >= min (torch.clamp backward)
-        dtau = torch.where(tau_flat >= ctx.tau_min, dtau, torch.zeros_like(dtau)).view(ctx.tau_shape)
+        dtau = torch.where(tau_flat >= ctx.tau_min, dtau, torch.zeros_like(dtau)).view(ctx.tau_shape).to(ctx.tau_dtype)
         return dqk, dv, dtau, None, None, None
 
 

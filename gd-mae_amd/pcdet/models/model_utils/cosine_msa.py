@@ -32,5 +32,5 @@ class CosineMultiheadAttention(nn.Module):
         d = self.embed_dim
         qk = ops.linear(x + pos, self.in_proj_weight[:2 * d], self.in_proj_bias[:2 * d])
         v = ops.linear(x, self.in_proj_weight[2 * d:], self.in_proj_bias[2 * d:])
-        o = ops.WindowCosineAttention.apply(qk.float(), v.float(), self.tau, wplan, self.num_heads, self.tau_min)
+        o = ops.WindowCosineAttention.apply(qk, v, self.tau, wplan, self.num_heads, self.tau_min)
         return ops.linear(o, self.out_proj.weight, self.out_proj.bias)

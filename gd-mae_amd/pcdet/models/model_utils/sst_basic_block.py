@@ -39,9 +39,9 @@ class EncoderLayer(nn.Module):
         self.activation = F.gelu if activation == "gelu" else F.relu
 
     def forward(self, src, pos, wplan):
-        src = self.norm1(src + self.win_attn(src, pos, wplan))
+        src = ops.add_layer_norm(src, self.win_attn(src, pos, wplan), self.norm1)
         h = self.activation(ops.linear(src, self.linear1.weight, self.linear1.bias))
-        return self.norm2(src + ops.linear(h, self.linear2.weight, self.linear2.bias))
+        return ops.add_layer_norm(src, ops.linear(h, self.linear2.weight, self.linear2.bias), self.norm2)
 
 
 class BasicShiftBlockV2(nn.Module):

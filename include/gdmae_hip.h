@@ -139,15 +139,28 @@ int gdmae_colstats(const void* x, long long R, int C, int is_bf16, double* out, 
  * Replaces flat2window_v2/window2flat_v2 (sst_utils.py:107-180), WindowAttention.forward
  * (pcdet/models/model_utils/sst_basic_block.py:22-54) and _scaled_cosine_attention
  * (pcdet/models/model_utils/cosine_msa.py:114-176) for ONE occupancy level (T = 16/32/64 padded tokens).
- * qk (Ms, 2d): projected queries [0,d) and keys [d,2d); v (Ms, d); out (Ms, d) written at token rows.
+ * qk (Ms, 2d): projected queries [0,d) and keys [d,2d); v (Ms, d); out (Ms, d) written at token rows;
+ * io_bf16 selects fp32 (0) or bf16 (1) rows in HBM - arithmetic is fp32 in registers either way.
  * Backward: dqk (Ms,2d), dv (Ms,d), dtau_part: n_win*H/(64/T) partials of d loss / d clamp(tau). */
-int gdmae_window_attention_fwd(const float* qk, const float* v, float* out, const int* csr_tok, const int* win_start,
-                               const int* win_len, int n_win, int T, int d, int H, const float* tau, float tau_min,
-                               void* stream);
-int gdmae_window_attention_bwd(const float* qk, const float* v, const float* dout, float* dqk, float* dv,
+int gdmae_window_attention_fwd(const void* qk, const void* v, void* out, int io_bf16, const int* csr_tok,
+                               const int* win_start, const int* win_len, int n_win, int T, int d, int H,
+                               const float* tau, float tau_min, void* stream);
+int gdmae_window_attention_bwd(const void* qk, const void* v, const void* dout, void* dqk, void* dv, int io_bf16,
                                float* dtau_part, const int* csr_tok, const int* win_start, const int* win_len,
                                int n_win, int T, int d, int H, const float* tau, float tau_min, void* stream);
 int gdmae_sum_partials(const float* part, long long n, float scale, float* out, int accumulate, void* stream);
+
+/* ---- a14: fused residual add + LayerNorm ------------------------------------------------------- *
+ * Replaces `src = src + src2; src = self.normN(src)` of EncoderLayer.forward
+ * (pcdet/models/model_utils/sst_basic_block.py:77-84; nn.LayerNorm(d), eps 1e-5): y = LN(a + b) * gamma + beta,
+ * a fp32 (n,d), b fp32 or bf16 (n,d), d in {64,128,256}; stats (n,2) = per-row mean, rstd (saved for backward).
+ * Backward: dx (n,d) = gradient w.r.t. (a + b) (goes to both), dgamma_dbeta (2d) = {dgamma, dbeta}. */
+size_t gdmae_add_layernorm_workspace_bytes(int d);
+int gdmae_add_layernorm_fwd(const float* a, const void* b, int b_is_bf16, const float* gamma, const float* beta,
+                            long long n, int d, float eps, float* y, float* stats, void* stream);
+int gdmae_add_layernorm_bwd(const float* a, const void* b, int b_is_bf16, const float* gamma, const float* stats,
+                            const float* dy, long long n, int d, float* dx, float* dgamma_dbeta, void* workspace,
+                            void* stream);
 
 /* ---- a17-a19: reconstruction targets and Chamfer loss ----------------------------------------- *
  * gdmae_group_gt_points replaces sst_ops_cuda.group_inner_inds_wrapper (sst_ops_api.cpp:8;

@@ -404,3 +404,32 @@ def test_sparse_decoder_equals_dense_decoder_and_updates_running_stats():
         assert (gs[k] - gd[k]).norm() <= tol * gd[k].norm() + 1e-7, (k, float((gs[k] - gd[k]).norm() / gd[k].norm()))
     for k in rs:
         assert torch.allclose(rs[k].float(), rd[k].float(), rtol=1e-4, atol=1e-6), k
+
+
+@pytest.mark.parametrize("d", [128, 256])
+@pytest.mark.parametrize("bdt", [torch.float32, torch.bfloat16])
+def test_fused_add_layernorm_matches_torch(d, bdt):
+    from gdmae_hip import ops
+    g = torch.Generator().manual_seed(8)
+    n = 3001
+    a = torch.randn(n, d, generator=g) * 2
+    b = (torch.randn(n, d, generator=g)).to(bdt)
+    ln = torch.nn.LayerNorm(d)
+    with torch.no_grad():
+        ln.weight.copy_(torch.rand(d, generator=g) + 0.5)
+        ln.bias.copy_(torch.randn(d, generator=g) * 0.1)
+    ar, br = a.clone().requires_grad_(True), b.float().clone().requires_grad_(True)
+    ref = ln(ar + br)
+    go = torch.randn(n, d, generator=g)
+    (ref * go).sum().backward()
+    lng = torch.nn.LayerNorm(d).to(dev())
+    lng.load_state_dict(ln.state_dict())
+    ag, bg = a.to(dev()).requires_grad_(True), b.to(dev()).requires_grad_(True)
+    out = ops.add_layer_norm(ag, bg, lng)
+    (out * go.to(dev())).sum().backward()
+    assert (out.cpu() - ref.detach()).abs().max() < 2e-5
+    assert (ag.grad.cpu() - ar.grad).abs().max() < 5e-5 * ar.grad.abs().max() + 1e-6
+    tol = 1e-2 if bdt == torch.bfloat16 else 5e-5
+    assert (bg.grad.float().cpu() - br.grad).abs().max() < tol * br.grad.abs().max() + 1e-6
+    assert (lng.weight.grad.cpu() - ln.weight.grad).abs().max() < 1e-4 * ln.weight.grad.abs().max()
+    assert (lng.bias.grad.cpu() - ln.bias.grad).abs().max() < 1e-4 * ln.bias.grad.abs().max()
