@@ -203,7 +203,8 @@ class AddLayerNorm(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, a, b, gamma, beta, eps):
-        a = _f32c(a)
+        ctx.a_dtype = a.dtype
+        a = a.float().contiguous()        # bf16 only for the first layer after a sparse conv under autocast
         b = b.contiguous()
         assert b.dtype in (torch.float32, torch.bfloat16) and a.shape == b.shape
         n, d = a.shape
@@ -223,7 +224,7 @@ class AddLayerNorm(torch.autograd.Function):
         ws = torch.empty(L.load().gdmae_add_layernorm_workspace_bytes(d), dtype=torch.uint8, device=a.device)
         L.call("gdmae_add_layernorm_bwd", L.ptr(a), L.ptr(b), int(b.dtype == torch.bfloat16), L.ptr(gamma.detach().contiguous()),
                L.ptr(stats), L.ptr(_f32c(g)), n, d, L.ptr(dx), L.ptr(dgb), L.ptr(ws), L.stream())
-        return dx, dx.to(b.dtype), dgb[:d], dgb[d:], None
+        return dx.to(ctx.a_dtype), dx.to(b.dtype), dgb[:d], dgb[d:], None
 
 
 def add_layer_norm(a, b, norm: torch.nn.LayerNorm):
