@@ -389,8 +389,10 @@ __global__ __launch_bounds__(256) void k_win_attn_bwd(AttnBwdArgs A) {
 }
 
 // deterministic sum of `n` partials into out[0] (single workgroup, fixed association order)
+// gate (optional): out is zeroed unless gate[0] >= gate_min (gradient of clamp(tau, min) w.r.t. tau)
 __global__ __launch_bounds__(1024) void k_sum_partials(const float* __restrict__ part, long long n, float scale,
-                                                       float* __restrict__ out, int accumulate) {
+                                                       float* __restrict__ out, int accumulate,
+                                                       const float* __restrict__ gate, float gate_min) {
   __shared__ float sh[1024 / GD_WAVE];
   float acc = 0.f;
   for (long long i = threadIdx.x; i < n; i += 1024) acc += part[i];
@@ -401,12 +403,22 @@ __global__ __launch_bounds__(1024) void k_sum_partials(const float* __restrict__
     float s = 0.f;
     for (int i = 0; i < 1024 / GD_WAVE; ++i) s += sh[i];
     s *= scale;
+    if (gate && !(gate[0] >= gate_min)) s = 0.f;
     out[0] = accumulate ? out[0] + s : s;
   }
 }
 
 extern "C" int gdmae_sum_partials(const float* part, long long n, float scale, float* out, int accumulate, void* stream) {
-  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, (hipStream_t)stream, part, n, scale, out, accumulate);
+  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, (hipStream_t)stream, part, n, scale, out, accumulate,
+                     (const float*)nullptr, 0.f);
+  GD_LAUNCH_CHECK();
+  return 0;
+}
+
+// out[0] = (gate[0] >= gate_min) ? scale * sum(part) : 0    (d loss / d tau through clamp(tau, tau_min))
+extern "C" int gdmae_sum_partials_gated(const float* part, long long n, float scale, float* out, const float* gate,
+                                        float gate_min, void* stream) {
+  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, (hipStream_t)stream, part, n, scale, out, 0, gate, gate_min);
   GD_LAUNCH_CHECK();
   return 0;
 }

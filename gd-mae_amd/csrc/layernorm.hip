@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void k_reduce_partials_f32(const float* __rest
 
 static inline int ln_grid(long long n) {
   long long g = (n + 3) / 4;
-  if (g > 2048) g = 2048;
+  if (g > 256) g = 256;     // few partial blocks: the dgamma/dbeta reduction stays a handful of iterations
   if (g < 1) g = 1;
   return (int)g;
 }

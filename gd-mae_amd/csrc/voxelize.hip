@@ -176,7 +176,8 @@ __global__ __launch_bounds__(256) void k_pillar_sort_mean(const int* __restrict_
       for (int cb = 0; cb < cnt; cb += GD_WAVE) {
         const int u = cb + lane < cnt ? csr_raw[off + cb + lane] : 0x7fffffff;
         const int lim = cnt - cb < GD_WAVE ? cnt - cb : GD_WAVE;
-        for (int j = 0; j < lim; ++j) rk += (__shfl(u, j, GD_WAVE) < own) ? 1 : 0;
+#pragma unroll 8
+        for (int j = 0; j < lim; ++j) rk += (__builtin_amdgcn_readlane(u, j) < own) ? 1 : 0;   // j is wave-uniform
       }
       if (base + lane < cnt) {
         csr[off + rk] = own;
@@ -185,7 +186,8 @@ __global__ __launch_bounds__(256) void k_pillar_sort_mean(const int* __restrict_
       if (cnt <= GD_WAVE) {
         // in-register inverse permutation: lane r fetches the id whose rank is r
         int src = 0;
-        for (int j = 0; j < cnt; ++j) src = (__shfl(rk, j, GD_WAVE) == lane) ? j : src;
+#pragma unroll 8
+        for (int j = 0; j < cnt; ++j) src = (__builtin_amdgcn_readlane(rk, j) == lane) ? j : src;
         first_sorted = __shfl(own, src, GD_WAVE);
       }
     }
@@ -207,7 +209,8 @@ __global__ __launch_bounds__(256) void k_pillar_sort_mean(const int* __restrict_
         const int lim = cnt - cb < GD_WAVE ? cnt - cb : GD_WAVE;
         for (int j = 0; j < lim; ++j) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) acc[e] = __fadd_rn(acc[e], __shfl(v[e], j, GD_WAVE));
+          for (int e = 0; e < 8; ++e)
+            acc[e] = __fadd_rn(acc[e], __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[e]), j)));
         }
       }
       if (lane < 8 && c0 + lane < F) {

@@ -106,6 +106,33 @@ def splitk_tn(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def shadow(t: torch.Tensor, dtype) -> torch.Tensor:
+    """`t` in `dtype` for GEMM use.  Parameters registered with a flat optimizer (gdmae_hip.optim) carry a bf16
+    shadow that is refreshed once per optimizer step by ONE cast of the whole flat buffer, instead of one tiny cast
+    kernel per weight per use; anything else is cast on the fly."""
+    if t.dtype == dtype:
+        return t
+    base = t._base if t._base is not None else t
+    sh = getattr(base, "_gd_shadow", None)
+    if sh is not None and dtype == torch.bfloat16 and sh[1] == base._version:
+        s16 = sh[0]
+        if t is base:
+            return s16
+        return s16.as_strided(t.shape, t.stride(), s16.storage_offset() + t.storage_offset() - base.storage_offset())
+    return t.to(dtype)
+
+
+def colsum_f32(x2d: torch.Tensor) -> torch.Tensor:
+    """Column sums (fp32) of a contiguous (R, C) fp32/bf16 matrix via gdmae_colstats (deterministic, fp64 combine)."""
+    R, C = x2d.shape
+    if R == 0 or (C % (8 if x2d.dtype == torch.bfloat16 else 4)) or C > 1024:
+        return x2d.sum(0, dtype=torch.float32)
+    out = torch.empty(2 * C, dtype=torch.float64, device=x2d.device)
+    ws = torch.empty(L.load().gdmae_colstats_workspace_bytes(C), dtype=torch.uint8, device=x2d.device)
+    L.call("gdmae_colstats", L.ptr(x2d), R, C, int(x2d.dtype == torch.bfloat16), L.ptr(out), L.ptr(ws), L.stream())
+    return out[:C].float()
+
+
 class LinearSplitK(torch.autograd.Function):
     """y = x W^T + b with bf16 compute under autocast (fp32 otherwise) and a split-K weight gradient."""
 
@@ -113,18 +140,20 @@ class LinearSplitK(torch.autograd.Function):
     def forward(ctx, x, weight, bias):
         cdt = torch.bfloat16 if torch.is_autocast_enabled() else x.dtype
         xc = x.to(cdt)
-        y = torch.nn.functional.linear(xc, weight.to(cdt), None if bias is None else bias.to(cdt))
-        ctx.save_for_backward(xc, weight)
+        wc = shadow(weight, cdt)
+        y = torch.nn.functional.linear(xc, wc, None if bias is None else shadow(bias, cdt))
+        ctx.save_for_backward(xc, wc)
         ctx.has_bias = bias is not None
+        ctx.w_dtype = weight.dtype
         return y
 
     @staticmethod
     def backward(ctx, g):
-        xc, weight = ctx.saved_tensors
+        xc, wc = ctx.saved_tensors
         g = g.contiguous().to(xc.dtype)
-        dx = g @ weight.to(g.dtype)
-        dw = splitk_tn(g, xc).to(weight.dtype)
-        db = g.sum(0, dtype=torch.float32) if ctx.has_bias else None
+        dx = g @ wc
+        dw = splitk_tn(g, xc).to(ctx.w_dtype)
+        db = colsum_f32(g) if ctx.has_bias else None
         return dx, dw, db
 
 
@@ -282,12 +311,11 @@ class WindowCosineAttention(torch.autograd.Function):
                            float(ctx.tau_min), L.stream())
             base += nw
             pbase += n_items[lvl]
-        dtau = torch.zeros(1, dtype=torch.float32, device=v.device)
-        if pbase > 0:
-            L.call("gdmae_sum_partials", L.ptr(part), pbase, 1.0, L.ptr(dtau), 0, L.stream())
-        # d clamp(tau, min)/d tau = 1 where tau >= min (torch.clamp backward)
-        dtau = torch.where(tau_flat >= ctx.tau_min, dtau, torch.zeros_like(dtau)).view(ctx.tau_shape).to(ctx.tau_dtype)
-        return dqk, dv, dtau, None, None, None
+        dtau = torch.empty(1, dtype=torch.float32, device=v.device)
+        # d clamp(tau, min)/d tau = 1 where tau >= min (torch.clamp backward), folded into the partial sum
+        L.call("gdmae_sum_partials_gated", L.ptr(part), pbase, 1.0, L.ptr(dtau), L.ptr(tau_flat), float(ctx.tau_min),
+               L.stream())
+        return dqk, dv, dtau.view(ctx.tau_shape).to(ctx.tau_dtype), None, None, None
 
 
 # ------------------------------------------------------------------------------------------------

@@ -57,12 +57,23 @@ class FlatAdamOneCycle:
             p.grad = self.flat_grad[off:off + k].view_as(p.data)     # autograd accumulates in place
             off += k
         self.params = params
+        self.flat_param_bf16 = torch.empty(n, dtype=torch.bfloat16, device=dev)
+        self._refresh_shadows()
         self.cfg = optim_cfg
         self.total_steps = max(int(total_steps), 1)
         self.t = 0
         self.pg = process_group
         self._part = torch.empty(1024, dtype=torch.float32, device=dev)
         self._sq = torch.zeros(1, dtype=torch.float32, device=dev)
+
+    def _refresh_shadows(self):
+        """One cast of the flat buffer -> bf16 views per parameter (consumed by gdmae_hip.ops.shadow)."""
+        self.flat_param_bf16.copy_(self.flat_param)
+        off = 0
+        for p in self.params:
+            k = p.numel()
+            p._gd_shadow = (self.flat_param_bf16[off:off + k].view(p.shape), p._version)
+            off += k
 
     def zero_grad(self):
         self.flat_grad.zero_()
@@ -86,6 +97,7 @@ class FlatAdamOneCycle:
         L.call("gdmae_adam_step", L.ptr(self.flat_param), L.ptr(self.flat_grad), L.ptr(self.exp_avg),
                L.ptr(self.exp_avg_sq), self.n, float(lr), float(beta1), 0.99, 1e-8, float(c.WEIGHT_DECAY), self.t,
                float(c.GRAD_NORM_CLIP), L.ptr(self._sq), st)
+        self._refresh_shadows()
         return lr, beta1
 
     def state_dict(self):

@@ -149,6 +149,8 @@ int gdmae_window_attention_bwd(const void* qk, const void* v, const void* dout, 
                                float* dtau_part, const int* csr_tok, const int* win_start, const int* win_len,
                                int n_win, int T, int d, int H, const float* tau, float tau_min, void* stream);
 int gdmae_sum_partials(const float* part, long long n, float scale, float* out, int accumulate, void* stream);
+int gdmae_sum_partials_gated(const float* part, long long n, float scale, float* out, const float* gate, float gate_min,
+                             void* stream); /* out = gate[0] >= gate_min ? scale*sum : 0 (clamp(tau) gradient) */
 
 /* ---- a14: fused residual add + LayerNorm ------------------------------------------------------- *
  * Replaces `src = src + src2; src = self.normN(src)` of EncoderLayer.forward
