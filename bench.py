@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--pool", type=int, default=3, help="distinct pre-generated batches cycled through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--miopen-find", type=int, default=0, help="1: torch.backends.cudnn.benchmark (MIOpen find mode)")
     return ap.parse_args()
 
 
@@ -129,6 +130,7 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
     torch.cuda.set_device(local)
+    torch.backends.cudnn.benchmark = bool(args.miopen_find)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -82,8 +82,20 @@ struct CellStore {
   int* pillar_cell;
   long long* voxel_coords;
   int* sample_off;
+  int* big;  // [0] = #items, [1] = #big pillars, then items (pillar, chunk) pairs from big + 2, pillars after big_cap items
+  int big_cap;
   __device__ void operator()(long long c, unsigned long long ex, unsigned long long v) const {
     const int p = (int)(ex >> 32);
+    const int cnt = (int)(unsigned)v;
+    if (cnt > GD_WAVE) {   // pillars with more than one wavefront of points: ranked by (pillar, 64-point chunk) work items
+      const int nch = (cnt + GD_WAVE - 1) / GD_WAVE;
+      const int base = atomicAdd(&big[0], nch);
+      for (int k = 0; k < nch; ++k) {
+        big[2 + 2 * (base + k)] = p;
+        big[2 + 2 * (base + k) + 1] = k;
+      }
+      big[2 + 2 * big_cap + atomicAdd(&big[1], 1)] = p;
+    }
     const int cps = P.gz * P.gy * P.gx;
     if (c % cps == 0) sample_off[c / cps] = p;
     if (v) {
@@ -153,11 +165,39 @@ __global__ __launch_bounds__(256) void k_point_fill(const float* __restrict__ pt
   }
 }
 
-// One wavefront per pillar: rank the pillar's point ids (canonical ascending order) by counting - candidates are
-// loaded 64 at a time, one per lane, and broadcast with v_readlane - then accumulate the per-pillar feature sums
-// SEQUENTIALLY in that order (bit-identical to a sequential CPU index_add_): 64 points are loaded at once (one
-// row per lane), the adds walk them through v_readlane, so there is no dependent global load in the add chain
-// and a 1000-point pillar costs ~10 us instead of ~1 ms.
+// Sequential (canonical-order) feature sums of one pillar by one wavefront: 64 points are loaded at once (one row
+// per lane) and the adds walk them through v_readlane, so the add chain has no dependent global load and the
+// result is bit-identical to a sequential CPU index_add_.  `sorted_lane` = id held by this lane for cnt <= 64,
+// otherwise ids are re-read from the sorted CSR.
+__device__ inline void pillar_mean(const float* __restrict__ pts_out, int ncols, int F, const int* __restrict__ csr, int off,
+                                   int cnt, int sorted_lane, int lane, float* __restrict__ mean_row) {
+  for (int c0 = 0; c0 < F; c0 += 8) {
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int cb = 0; cb < cnt; cb += GD_WAVE) {
+      int pid = 0;
+      if (cb + lane < cnt) pid = cnt <= GD_WAVE ? sorted_lane : __builtin_nontemporal_load(&csr[off + cb + lane]);
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (cb + lane < cnt && c0 + e < F) ? pts_out[(long long)pid * ncols + 1 + c0 + e] : 0.f;
+      const int lim = cnt - cb < GD_WAVE ? cnt - cb : GD_WAVE;
+      for (int j = 0; j < lim; ++j) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          acc[e] = __fadd_rn(acc[e], __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[e]), j)));
+      }
+    }
+    if (lane < 8 && c0 + lane < F) {
+      float mine = acc[0];
+#pragma unroll
+      for (int e = 1; e < 8; ++e) mine = (lane == e) ? acc[e] : mine;
+      mean_row[c0 + lane] = __fdiv_rn(mine, (float)cnt);
+    }
+  }
+}
+
+// One wavefront per pillar with <= 64 points (98.5 % of them): one point id per lane, rank by counting through
+// v_readlane (canonical ascending order), in-register inverse permutation, sequential mean.  Larger pillars are
+// left to k_big_rank / k_big_mean.
 __global__ __launch_bounds__(256) void k_pillar_sort_mean(const int* __restrict__ counts, const int* __restrict__ pt_off,
                                                           const int* __restrict__ csr_raw, int* __restrict__ csr,
                                                           int* __restrict__ rank, const float* __restrict__ pts_out,
@@ -167,59 +207,64 @@ __global__ __launch_bounds__(256) void k_pillar_sort_mean(const int* __restrict_
   const int M = counts[1];
   const int F = ncols - 1;
   for (int p = blockIdx.x * 4 + wib; p < M; p += gridDim.x * 4) {
-    const int off = pt_off[p];
-    const int cnt = pt_off[p + 1] - off;
-    int first_sorted = 0;   // lane r holds the r-th smallest id when cnt <= 64
-    for (int base = 0; base < cnt; base += GD_WAVE) {
-      const int own = base + lane < cnt ? csr_raw[off + base + lane] : 0x7fffffff;
-      int rk = 0;
-      for (int cb = 0; cb < cnt; cb += GD_WAVE) {
-        const int u = cb + lane < cnt ? csr_raw[off + cb + lane] : 0x7fffffff;
-        const int lim = cnt - cb < GD_WAVE ? cnt - cb : GD_WAVE;
-#pragma unroll 8
-        for (int j = 0; j < lim; ++j) rk += (__builtin_amdgcn_readlane(u, j) < own) ? 1 : 0;   // j is wave-uniform
-      }
-      if (base + lane < cnt) {
-        csr[off + rk] = own;
-        rank[own] = rk;
-      }
-      if (cnt <= GD_WAVE) {
-        // in-register inverse permutation: lane r fetches the id whose rank is r
-        int src = 0;
-#pragma unroll 8
-        for (int j = 0; j < cnt; ++j) src = (__builtin_amdgcn_readlane(rk, j) == lane) ? j : src;
-        first_sorted = __shfl(own, src, GD_WAVE);
-      }
+    const int off = __builtin_amdgcn_readfirstlane(pt_off[p]);
+    const int cnt = __builtin_amdgcn_readfirstlane(pt_off[p + 1]) - off;   // wave-uniform -> scalar loop control
+    if (cnt > GD_WAVE) continue;
+    const int own = lane < cnt ? csr_raw[off + lane] : 0x7fffffff;
+    int rk = 0;
+    for (int j = 0; j < cnt; ++j) rk += (__builtin_amdgcn_readlane(own, j) < own) ? 1 : 0;
+    if (lane < cnt) {
+      csr[off + rk] = own;
+      rank[own] = rk;
     }
     if (F <= 0) continue;
-    if (cnt > GD_WAVE) {
-      // make this wave's csr[] stores visible to its own loads below (same CU: workgroup scope)
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    int src = 0;   // lane r fetches the id whose rank is r
+    for (int j = 0; j < cnt; ++j) src = (__builtin_amdgcn_readlane(rk, j) == lane) ? j : src;
+    const int sorted_lane = __shfl(own, src, GD_WAVE);
+    pillar_mean(pts_out, ncols, F, csr, off, cnt, sorted_lane, lane, mean + (long long)p * F);
+  }
+}
+
+// Pillars with > 64 points: one wavefront per (pillar, 64-point chunk) work item ranks its 64 ids against the whole
+// pillar (candidates loaded 64 at a time and broadcast by v_readlane), so a 1000-point wall pillar is 16 independent
+// ~1000-step items instead of one 16000-step serial tail.
+__global__ __launch_bounds__(256) void k_big_rank(const int* __restrict__ big, const int* __restrict__ pt_off,
+                                                  const int* __restrict__ csr_raw, int* __restrict__ csr,
+                                                  int* __restrict__ rank) {
+  const int lane = threadIdx.x & (GD_WAVE - 1);
+  const int wib = threadIdx.x / GD_WAVE;
+  const int n_items = big[0];
+  for (int it = blockIdx.x * 4 + wib; it < n_items; it += gridDim.x * 4) {
+    const int p = __builtin_amdgcn_readfirstlane(big[2 + 2 * it]);
+    const int base = __builtin_amdgcn_readfirstlane(big[2 + 2 * it + 1]) * GD_WAVE;
+    const int off = __builtin_amdgcn_readfirstlane(pt_off[p]);
+    const int cnt = __builtin_amdgcn_readfirstlane(pt_off[p + 1]) - off;
+    const int own = base + lane < cnt ? csr_raw[off + base + lane] : 0x7fffffff;
+    int rk = 0;
+    for (int cb = 0; cb < cnt; cb += GD_WAVE) {
+      const int u = cb + lane < cnt ? csr_raw[off + cb + lane] : 0x7fffffff;
+      const int lim = cnt - cb < GD_WAVE ? cnt - cb : GD_WAVE;
+      for (int j = 0; j < lim; ++j) rk += (__builtin_amdgcn_readlane(u, j) < own) ? 1 : 0;
     }
-    for (int c0 = 0; c0 < F; c0 += 8) {
-      float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      for (int cb = 0; cb < cnt; cb += GD_WAVE) {
-        int pid = 0;
-        if (cb + lane < cnt) pid = cnt <= GD_WAVE ? first_sorted : __builtin_nontemporal_load(&csr[off + cb + lane]);
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-          v[e] = (cb + lane < cnt && c0 + e < F) ? pts_out[(long long)pid * ncols + 1 + c0 + e] : 0.f;
-        const int lim = cnt - cb < GD_WAVE ? cnt - cb : GD_WAVE;
-        for (int j = 0; j < lim; ++j) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e)
-            acc[e] = __fadd_rn(acc[e], __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[e]), j)));
-        }
-      }
-      if (lane < 8 && c0 + lane < F) {
-        float mine = acc[0];
-#pragma unroll
-        for (int e = 1; e < 8; ++e) mine = (lane == e) ? acc[e] : mine;
-        mean[(long long)p * F + c0 + lane] = __fdiv_rn(mine, (float)cnt);
-      }
+    if (base + lane < cnt) {
+      csr[off + rk] = own;
+      rank[own] = rk;
     }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_big_mean(const int* __restrict__ big, int big_cap, const int* __restrict__ pt_off,
+                                                  const int* __restrict__ csr, const float* __restrict__ pts_out, int ncols,
+                                                  float* __restrict__ mean) {
+  const int lane = threadIdx.x & (GD_WAVE - 1);
+  const int wib = threadIdx.x / GD_WAVE;
+  const int n_big = big[1];
+  const int F = ncols - 1;
+  for (int b = blockIdx.x * 4 + wib; b < n_big; b += gridDim.x * 4) {
+    const int p = __builtin_amdgcn_readfirstlane(big[2 + 2 * big_cap + b]);
+    const int off = __builtin_amdgcn_readfirstlane(pt_off[p]);
+    const int cnt = __builtin_amdgcn_readfirstlane(pt_off[p + 1]) - off;
+    pillar_mean(pts_out, ncols, F, csr, off, cnt, 0, lane, mean + (long long)p * F);
   }
 }
 
@@ -231,6 +276,7 @@ extern "C" size_t gdmae_voxelize_workspace_bytes(long long n_points, int batch_s
   b += gd_align(sizeof(int) * n_points) * 3;                        // key, pos, csr_raw
   b += gd_align(sizeof(unsigned long long) * gd_scan_ws_elems(cells > n_points ? cells : n_points));
   b += gd_align(sizeof(unsigned long long) * 2) + gd_align(sizeof(int) * 2);
+  b += gd_align(sizeof(int) * (2 + 3 * (n_points / 32 + 2)));          // big-pillar work items
   return b + 4096;
 }
 
@@ -267,8 +313,11 @@ extern "C" int gdmae_voxelize(const float* points, long long n_points, int n_col
   unsigned long long* scan_ws = A.take<unsigned long long>(gd_scan_ws_elems(cells > n_points ? cells : n_points));
   unsigned long long* total = A.take<unsigned long long>(2);
   int* n_keep = A.take<int>(2);
+  const int big_cap = (int)(n_points / 32 + 2);
+  int* big = A.take<int>(2 + 3 * (size_t)big_cap);
 
   GD_CHECK(hipMemsetAsync(cell_cnt, 0, sizeof(int) * cells, st));
+  GD_CHECK(hipMemsetAsync(big, 0, sizeof(int) * 2, st));
   const int grid_pts = n_points > 0 ? (gd_div_up(n_points, 256) < 4096 ? gd_div_up(n_points, 256) : 4096) : 1;
   if (n_points > 0) {
     hipLaunchKernelGGL(k_point_keys, dim3(grid_pts), dim3(256), 0, st, points, n_points, P, key, cell_cnt);
@@ -279,7 +328,7 @@ extern "C" int gdmae_voxelize(const float* points, long long n_points, int n_col
     if (rc) return rc;
   }
   {
-    CellStore cs{P, cell2pillar, pillar_pt_off, pillar_cell, voxel_coords, sample_pillar_off};
+    CellStore cs{P, cell2pillar, pillar_pt_off, pillar_cell, voxel_coords, sample_pillar_off, big, big_cap};
     int rc = gd_device_scan<unsigned long long>(cells, CellLoad{cell_cnt}, cs, total, scan_ws, st);
     if (rc) return rc;
   }
@@ -290,8 +339,13 @@ extern "C" int gdmae_voxelize(const float* points, long long n_points, int n_col
     hipLaunchKernelGGL(k_point_fill, dim3(grid_pts), dim3(256), 0, st, points, n_points, P, key, pos, cell2pillar,
                        pillar_pt_off, cell_cnt, points_out, point_coords, inverse, inverse32, csr_raw);
     GD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_pillar_sort_mean, dim3(2048), dim3(256), 0, st, counts, pillar_pt_off, csr_raw, pillar_pts,
+    hipLaunchKernelGGL(k_pillar_sort_mean, dim3(4096), dim3(256), 0, st, counts, pillar_pt_off, csr_raw, pillar_pts,
                        point_rank, points_out, n_cols, pillar_mean);
+    GD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_big_rank, dim3(2048), dim3(256), 0, st, big, pillar_pt_off, csr_raw, pillar_pts, point_rank);
+    GD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_big_mean, dim3(1024), dim3(256), 0, st, big, big_cap, pillar_pt_off, pillar_pts, points_out, n_cols,
+                       pillar_mean);
     GD_LAUNCH_CHECK();
   }
   return 0;
@@ -359,7 +413,21 @@ __global__ __launch_bounds__(256) void k_group_inner(const int* __restrict__ off
 
 extern "C" size_t gdmae_group_workspace_bytes(long long n, long long n_groups) {
   return gd_align(sizeof(int) * (n_groups + 1)) * 2 + gd_align(sizeof(int) * n) * 3 +
-         gd_align(sizeof(int) * (gd_scan_ws_elems(n_groups) + 8)) + 4096;
+         gd_align(sizeof(int) * (gd_scan_ws_elems(n_groups) + 8)) + gd_align(sizeof(int) * (2 + 2 * (n / 32 + 2))) + 4096;
+}
+
+__global__ __launch_bounds__(256) void k_group_big_items(const int* __restrict__ off, long long n_groups, int* __restrict__ big) {
+  for (long long g = blockIdx.x * (long long)blockDim.x + threadIdx.x; g < n_groups; g += (long long)gridDim.x * blockDim.x) {
+    const int cnt = off[g + 1] - off[g];
+    if (cnt > GD_WAVE) {
+      const int nch = (cnt + GD_WAVE - 1) / GD_WAVE;
+      const int base = atomicAdd(&big[0], nch);
+      for (int k = 0; k < nch; ++k) {
+        big[2 + 2 * (base + k)] = (int)g;
+        big[2 + 2 * (base + k) + 1] = k;
+      }
+    }
+  }
 }
 
 static int gd_group_csr(const long long* gid, long long n, long long n_groups, GdArena& A, int** off_out, int** csr_out,
@@ -374,7 +442,9 @@ static int gd_group_csr(const long long* gid, long long n, long long n_groups, G
   int* total = scan_ws + gd_scan_ws_elems(n_groups);
   int* counts = total + 2;
   int* bad = total + 4;
+  int* big = A.take<int>(2 + 2 * (size_t)(n / 32 + 2));
   GD_REQUIRE(A.ok(), "group workspace too small");
+  GD_CHECK(hipMemsetAsync(big, 0, sizeof(int) * 2, st));
   GD_CHECK(hipMemsetAsync(cnt, 0, sizeof(int) * (n_groups + 1), st));
   GD_CHECK(hipMemsetAsync(bad, 0, sizeof(int), st));
   int grid = gd_div_up(n > 0 ? n : 1, 256);
@@ -389,6 +459,11 @@ static int gd_group_csr(const long long* gid, long long n, long long n_groups, G
   GD_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_pillar_sort_mean, dim3(2048), dim3(256), 0, st, counts, off, csr_raw, csr, rank,
                      (const float*)nullptr, 1, (float*)nullptr);
+  GD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_group_big_items, dim3(gd_div_up(n_groups, 256) < 2048 ? gd_div_up(n_groups, 256) : 2048), dim3(256), 0,
+                     st, off, n_groups, big);
+  GD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_big_rank, dim3(2048), dim3(256), 0, st, big, off, csr_raw, csr, rank);
   GD_LAUNCH_CHECK();
   *off_out = off;
   *csr_out = csr;
