@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--pool", type=int, default=3, help="distinct pre-generated batches cycled through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--miopen-find", type=int, default=0, help="1: torch.backends.cudnn.benchmark (MIOpen find mode)")
+    ap.add_argument("--miopen-find", type=int, default=1, help="1: torch.backends.cudnn.benchmark (MIOpen find mode)")
     return ap.parse_args()
 
 

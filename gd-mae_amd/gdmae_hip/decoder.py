@@ -58,39 +58,75 @@ def _scatter_slice(src2d, idx, table2d, col0):
            table2d.shape[1] * es, col0 * es, L.ptr(table2d), L.stream())
 
 
-class BuildDenseCat(torch.autograd.Function):
-    """Z (R, sum C_i) = per-channel background everywhere, token rows written into column slices.
+def _bf(t):
+    return int(t.dtype == torch.bfloat16)
 
-    forward(R, dtype, idx_0, vals_0, bg_0, idx_1, vals_1, bg_1, ...):  vals_i (n_i, C_i) rows for the
-    unique sites idx_i (int32), bg_i (C_i,) the value of every other site."""
+
+class StagesBNToDense(torch.autograd.Function):
+    """All decoder source stages at once: BatchNorm2d(train) + ReLU of the (implicit) dense deconvolution maps,
+    written as ONE channels-last concatenated map Z (R, sum C_i).
+
+    forward(R, zdtype, eps, sites_0, P_0, gamma_0, beta_0, sites_1, ...): P_i (n_i, C_i) are the deconvolution
+    outputs of the active sites (unique full-resolution cells sites_i); every other site of map i is zero before
+    BN, so the batch statistics over all R sites are column sums of P_i and the post-BN/ReLU value of every other
+    site is the constant relu(beta - gamma * mean * rstd).  Returns (Z, mean_0, var_0, mean_1, var_1, ...).
+    The backward is the hand-derived BatchNorm chain rule on column sums (three row kernels per stage)."""
 
     @staticmethod
-    def forward(ctx, R, dtype, *args):
-        k = len(args) // 3
-        idxs, vals, bgs = args[0::3], args[1::3], args[2::3]
-        widths = [int(v.shape[1]) for v in vals]
-        Z = torch.cat([b.detach() for b in bgs]).to(dtype).expand(R, sum(widths)).contiguous()
+    def forward(ctx, R, zdtype, eps, *args):
+        k = len(args) // 4
+        sites, Ps, gammas, betas = args[0::4], args[1::4], args[2::4], args[3::4]
+        widths = [int(P.shape[1]) for P in Ps]
+        a_l, b_l, mean_l, r_l, stats_out = [], [], [], [], []
+        for P, g, be in zip(Ps, gammas, betas):
+            s1, s2 = colstats(P)
+            mean = s1 / R
+            var = (s2 / R - mean * mean).clamp_(min=0)
+            r = torch.rsqrt(var + eps)
+            a = g.detach().double() * r
+            b = be.detach().double() - a * mean
+            a_l.append(a.float()), b_l.append(b.float()), mean_l.append(mean), r_l.append(r)
+            stats_out += [mean.float(), var.float()]
+        Z = torch.relu(torch.cat(b_l)).to(zdtype).expand(R, sum(widths)).contiguous()
         col = 0
         for i in range(k):
-            _scatter_slice(vals[i].detach().to(dtype), idxs[i], Z, col)
+            L.call("gdmae_rows_affine_relu_scatter", L.ptr(Ps[i]), _bf(Ps[i]), L.ptr(sites[i]), Ps[i].shape[0], widths[i],
+                   L.ptr(a_l[i]), L.ptr(b_l[i]), L.ptr(Z), _bf(Z), Z.shape[1], col, L.stream())
             col += widths[i]
-        ctx.save_for_backward(*idxs)
-        ctx.widths = widths
-        ctx.in_dtypes = [(v.dtype, b.dtype) for v, b in zip(vals, bgs)]
-        return Z
+        ctx.save_for_backward(*sites, *Ps, *a_l, *b_l, *mean_l, *r_l, *[g.detach() for g in gammas])
+        ctx.k, ctx.widths, ctx.R = k, widths, R
+        ctx.mark_non_differentiable(*stats_out)
+        return (Z, *stats_out)
 
     @staticmethod
-    def backward(ctx, dZ):
-        idxs = ctx.saved_tensors
+    def backward(ctx, dZ, *_):
+        k, R = ctx.k, ctx.R
+        sv = ctx.saved_tensors
+        sites, Ps, a_l, b_l, mean_l, r_l, gammas = (sv[i * k:(i + 1) * k] for i in range(7))
         dZ = dZ.contiguous()
-        tot, _ = colstats(dZ)                      # column sums over ALL sites (fp64)
-        grads = [None, None]
+        tot, _ = colstats(dZ)                                   # column sums over ALL sites (fp64)
+        grads = [None, None, None]
         col = 0
         for i, w in enumerate(ctx.widths):
-            g = _gather_slice(dZ, idxs[i], col, w)             # gradient rows of the token sites
-            vd, bd = ctx.in_dtypes[i]
-            dbg = (tot[col:col + w] - g.sum(0, dtype=torch.float64)).to(bd)   # every other site shares bg
-            grads += [None, g.to(vd), dbg]
+            P = Ps[i]
+            n = P.shape[0]
+            st = torch.empty(3 * w, dtype=torch.float64, device=P.device)
+            ws = torch.empty(L.load().gdmae_rows_bwd_stats_workspace_bytes(w), dtype=torch.uint8, device=P.device)
+            L.call("gdmae_rows_bwd_stats", L.ptr(P), _bf(P), L.ptr(sites[i]), n, w, L.ptr(a_l[i]), L.ptr(b_l[i]), L.ptr(dZ),
+                   _bf(dZ), dZ.shape[1], col, L.ptr(st), L.ptr(ws), L.stream())
+            s_dh, s_dhp, s_g = st[:w], st[w:2 * w], st[2 * w:]
+            a, b, mean, r, g = a_l[i].double(), b_l[i].double(), mean_l[i], r_l[i], gammas[i].double()
+            gbg = tot[col:col + w] - s_g                           # every non-token site shares the background value
+            db = s_dh + gbg * (b > 0)
+            da = s_dhp - db * mean                                 # total derivative w.r.t. a (b = beta - a * mean)
+            dgamma = da * r
+            dv = -0.5 * (da * g) * r * r * r                       # a = gamma * rsqrt(var + eps)
+            dmu = -db * a - 2.0 * mean * dv                        # var = s2 / R - mean^2
+            c0, c1 = (dmu / R).float(), (2.0 * dv / R).float()
+            dP = torch.empty_like(P)
+            L.call("gdmae_rows_bwd", L.ptr(P), _bf(P), L.ptr(sites[i]), n, w, L.ptr(a_l[i]), L.ptr(b_l[i]), L.ptr(c0), L.ptr(c1),
+                   L.ptr(dZ), _bf(dZ), dZ.shape[1], col, L.ptr(dP), _bf(dP), L.stream())
+            grads += [None, dP, dgamma.to(gammas[i].dtype), db.to(gammas[i].dtype)]
             col += w
         return tuple(grads)
 
@@ -163,7 +199,7 @@ def sparse_decoder(model_cfg, deblocks, conv_out, hidden, pillar_cell, B, Y, X, 
     """hidden: list of SparseConvTensor per stage.  Returns (features at the pillar sites (M, C) fp32,
     dense spatial_features (B, C, Y, X) or None)."""
     R = B * Y * X
-    args = []
+    args, bns = [], []
     cdt = torch.bfloat16 if torch.is_autocast_enabled() else torch.float32
     for i, src in enumerate(model_cfg.FEATURES_SOURCE):
         h = hidden[int(src[-1]) - 1]
@@ -173,21 +209,17 @@ def sparse_decoder(model_cfg, deblocks, conv_out, hidden, pillar_cell, B, Y, X, 
         assert deconv.kernel_size == (s, s) and sp.Y * s == Y and sp.X * s == X and deconv.bias is None
         cin, cout = deconv.weight.shape[0], deconv.weight.shape[1]
         wmat = deconv.weight.permute(0, 2, 3, 1).reshape(cin, s * s * cout)      # columns ordered (dy, dx, c)
-        P = ops.linear(h.features, wmat.t()).view(-1, cout).float()             # (n_tok * s*s, cout)
-        s1 = P.sum(0, dtype=torch.float64)
-        s2 = (P.double() ** 2).sum(0)
-        mean64 = s1 / R
-        var64 = (s2 / R - mean64 * mean64).clamp(min=0)
-        mean, var = mean64.float(), var64.float()
-        a = bn.weight * torch.rsqrt(var + bn.eps)
-        b = bn.bias - a * mean
+        P = ops.linear(h.features, wmat.t()).view(-1, cout)                      # (n_tok * s*s, cout)
+        args += [upsampled_sites(sp, s, Y, X), P, bn.weight, bn.bias]
+        bns.append(bn)
+    outs = StagesBNToDense.apply(R, cdt, bns[0].eps, *args)                      # Z (R, 384) channels-last
+    Z = outs[0]
+    for i, bn in enumerate(bns):
         if bn.training:
-            _update_running(bn, mean.detach(), var.detach(), R)
-        args += [upsampled_sites(sp, s, Y, X), torch.relu(P * a + b), torch.relu(b)]
-    Z = BuildDenseCat.apply(R, cdt, *args)                                       # (R, 384) channels-last
+            _update_running(bn, outs[1 + 2 * i], outs[2 + 2 * i], R)
     conv, bn2 = conv_out[0], conv_out[1]
     zin = Z.view(B, Y, X, -1).permute(0, 3, 1, 2)                                # NCHW view of NHWC memory
-    y2 = F.conv2d(zin, conv.weight.to(cdt) if cdt != conv.weight.dtype else conv.weight, None, 1, 1)
+    y2 = F.conv2d(zin, ops.shadow(conv.weight, cdt), None, 1, 1)
     y2 = y2.permute(0, 2, 3, 1)
     if not y2.is_contiguous():
         y2 = y2.contiguous()

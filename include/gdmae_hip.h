@@ -135,6 +135,21 @@ int gdmae_scatter_rows_strided(const void* src, const int* idx, long long n_rows
 size_t gdmae_colstats_workspace_bytes(int C);
 int gdmae_colstats(const void* x, long long R, int C, int is_bf16, double* out, void* workspace, void* stream);
 
+/* ---- a16 (token side of the sparse-aware decoder) ----------------------------------------------- *
+ * Replace ConvTranspose2d -> BatchNorm2d -> ReLU -> cat (spt_backbone_mae.py:30-44,125-132) on the active-site
+ * rows P (n, C) (fp32 or bf16), C <= 256; a, b, c0, c1 are per-channel fp32 vectors from the BatchNorm algebra.
+ *   gdmae_rows_affine_relu_scatter: Z[site[r], col0:col0+C] = relu(a*P[r]+b)   (Z rows of z_row_elems elements)
+ *   gdmae_rows_bwd_stats: out double[3C] = column sums of {dh, dh*P, g},  g = dZ[site[r], slice], dh = g*(aP+b>0)
+ *   gdmae_rows_bwd: dP[r] = a*dh + c0 + c1*P[r] */
+int gdmae_rows_affine_relu_scatter(const void* P, int p_bf16, const int* site, long long n, int C, const float* a,
+                                   const float* b, void* Z, int z_bf16, int z_row_elems, int col0, void* stream);
+size_t gdmae_rows_bwd_stats_workspace_bytes(int C);
+int gdmae_rows_bwd_stats(const void* P, int p_bf16, const int* site, long long n, int C, const float* a, const float* b,
+                         const void* dZ, int z_bf16, int z_row_elems, int col0, double* out, void* workspace, void* stream);
+int gdmae_rows_bwd(const void* P, int p_bf16, const int* site, long long n, int C, const float* a, const float* b,
+                   const float* c0, const float* c1, const void* dZ, int z_bf16, int z_row_elems, int col0, void* dP,
+                   int dp_bf16, void* stream);
+
 /* ---- a11, a13: windowed cosine attention ------------------------------------------------------ *
  * Replaces flat2window_v2/window2flat_v2 (sst_utils.py:107-180), WindowAttention.forward
  * (pcdet/models/model_utils/sst_basic_block.py:22-54) and _scaled_cosine_attention
