@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void k_rows_affine_relu_scatter(const void* __
     const long long r = e / C;
     const int c = (int)(e % C);
     const float h = fmaf(a[c], dec_ld<PBF>(P, e), b[c]);
-    dec_st<ZBF>(Z, (long long)site[r] * zrow + col0 + c, h > 0.f ? h : 0.f);
+    dec_st<ZBF>(Z, (site ? (long long)site[r] : r) * zrow + col0 + c, h > 0.f ? h : 0.f);
   }
 }
 
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void k_rows_bwd_stats(const void* __restrict__
     const float ac = a[c], bc = b[c];
     for (long long r = r0 + tr; r < r1; r += rows_per_iter) {
       const float p = dec_ld<PBF>(P, r * C + c);
-      const float g = dec_ld<ZBF>(dZ, (long long)site[r] * zrow + col0 + c);
+      const float g = dec_ld<ZBF>(dZ, (site ? (long long)site[r] : r) * zrow + col0 + c);
       const float dh = fmaf(ac, p, bc) > 0.f ? g : 0.f;
       s0 += dh;
       s1 = fmaf(dh, p, s1);
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void k_rows_bwd(const void* __restrict__ P, co
     const long long r = e / C;
     const int c = (int)(e % C);
     const float p = dec_ld<PBF>(P, e);
-    const float g = dec_ld<ZBF>(dZ, (long long)site[r] * zrow + col0 + c);
+    const float g = dec_ld<ZBF>(dZ, (site ? (long long)site[r] : r) * zrow + col0 + c);
     const float dh = fmaf(a[c], p, b[c]) > 0.f ? g : 0.f;
     dec_st<OBF>(dP, e, fmaf(a[c], dh, fmaf(c1[c], p, c0[c])));
   }
@@ -169,6 +169,177 @@ extern "C" int gdmae_rows_bwd(const void* P, int p_bf16, const int* site, long l
     else { if (dp_bf16) GD_LAUNCH(false, false, true); else GD_LAUNCH(false, false, false); }
   }
 #undef GD_LAUNCH
+  GD_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// DynVFE tail: BatchNorm1d(train) + ReLU + per-pillar max fused (reference dyn_vfe.py:107-109,
+// network_utils.py:7-21).  x (N, C) is the second Linear's output (fp32 or bf16), a/b the BatchNorm affine
+// from the column statistics of x:  out[p, c] = max_{i in pillar p} relu(a_c x[i, c] + b_c), arg = that i
+// (lowest id on ties, canonical CSR order).  One wavefront per pillar, LPP lanes per point (4 channels per lane).
+// ------------------------------------------------------------------------------------------------
+template <int LPP, bool XBF>
+__global__ __launch_bounds__(256) void k_segmax_affine(const void* __restrict__ x, const int* __restrict__ pt_off,
+                                                       const int* __restrict__ csr, int M, const float* __restrict__ a,
+                                                       const float* __restrict__ b, float* __restrict__ out,
+                                                       int* __restrict__ arg) {
+  constexpr int C = LPP * 4;
+  constexpr int G = GD_WAVE / LPP;
+  const int lane = threadIdx.x & (GD_WAVE - 1);
+  const int wib = threadIdx.x / GD_WAVE;
+  const int grp = lane / LPP, cl = lane % LPP;
+  float av[4], bv[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    av[e] = a[cl * 4 + e];
+    bv[e] = b[cl * 4 + e];
+  }
+  for (int p = blockIdx.x * 4 + wib; p < M; p += gridDim.x * 4) {
+    const int off = pt_off[p];
+    const int cnt = pt_off[p + 1] - off;
+    float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    int bi[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
+#pragma unroll 4
+    for (int j = grp; j < cnt; j += G) {
+      const int i = csr[off + j];
+      float vv[4];
+      if (XBF) {
+        const uint2 u = *reinterpret_cast<const uint2*>((const unsigned short*)x + (long long)i * C + cl * 4);
+        vv[0] = __uint_as_float(u.x << 16);
+        vv[1] = __uint_as_float(u.x & 0xFFFF0000u);
+        vv[2] = __uint_as_float(u.y << 16);
+        vv[3] = __uint_as_float(u.y & 0xFFFF0000u);
+      } else {
+        const float4 v = *reinterpret_cast<const float4*>((const float*)x + (long long)i * C + cl * 4);
+        vv[0] = v.x; vv[1] = v.y; vv[2] = v.z; vv[3] = v.w;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float h = fmaxf(fmaf(av[e], vv[e], bv[e]), 0.f);
+        if (h > best[e] || bi[e] == 0x7fffffff) {
+          best[e] = h;
+          bi[e] = i;
+        }
+      }
+    }
+#pragma unroll
+    for (int d = LPP; d < GD_WAVE; d <<= 1) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float ob = __shfl_xor(best[e], d, GD_WAVE);
+        const int oi = __shfl_xor(bi[e], d, GD_WAVE);
+        const bool take = (oi != 0x7fffffff) && (bi[e] == 0x7fffffff || ob > best[e] || (ob == best[e] && oi < bi[e]));
+        if (take) {
+          best[e] = ob;
+          bi[e] = oi;
+        }
+      }
+    }
+    if (grp == 0) {
+      *reinterpret_cast<float4*>(out + (long long)p * C + cl * 4) = make_float4(best[0], best[1], best[2], best[3]);
+      *reinterpret_cast<int4*>(arg + (long long)p * C + cl * 4) = make_int4(bi[0], bi[1], bi[2], bi[3]);
+    }
+  }
+}
+
+extern "C" int gdmae_segment_max_affine(const void* x, int x_bf16, const int* pillar_pt_off, const int* pillar_pts, int M,
+                                        int C, const float* a, const float* b, float* out, int* arg, void* stream) {
+  if (M <= 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  int g = gd_div_up(M, 4);
+  if (g > 16384) g = 16384;
+  const dim3 grid(g), block(256);
+#define GD_SM(L, B) hipLaunchKernelGGL((k_segmax_affine<L, B>), grid, block, 0, st, x, pillar_pt_off, pillar_pts, M, a, b, out, arg)
+  if (C == 64) { if (x_bf16) GD_SM(16, true); else GD_SM(16, false); }
+  else if (C == 128) { if (x_bf16) GD_SM(32, true); else GD_SM(32, false); }
+  else if (C == 256) { if (x_bf16) GD_SM(64, true); else GD_SM(64, false); }
+  else GD_REQUIRE(false, "segment_max_affine supports C in {64, 128, 256}");
+#undef GD_SM
+  GD_LAUNCH_CHECK();
+  return 0;
+}
+
+// Backward of the fused tail.  dh[i, c] = dout[p, c] if (arg[p, c] == i and out[p, c] > 0) else 0.
+// (1) column sums of {dh, dh * x} - only arg-max points contribute, so this walks the (M, C) outputs;
+// (2) dx[i, c] = a_c dh[i, c] + c0_c + c1_c x[i, c]  for every point (BatchNorm chain rule), one dense pass.
+template <bool XBF>
+__global__ __launch_bounds__(256) void k_segmax_bwd_stats(const void* __restrict__ x, const float* __restrict__ out,
+                                                          const int* __restrict__ arg, const float* __restrict__ dout,
+                                                          long long M, int C, float* __restrict__ part) {
+  extern __shared__ float sh[];  // (rows_per_iter, 2, C)
+  const int rows_per_iter = 256 / C > 0 ? 256 / C : 1;
+  const int tr = threadIdx.x / C, c = threadIdx.x % C;
+  const bool live = tr < rows_per_iter;
+  const long long chunk = (M + gridDim.x - 1) / gridDim.x;
+  const long long r0 = blockIdx.x * chunk, r1 = r0 + chunk < M ? r0 + chunk : M;
+  float s0 = 0.f, s1 = 0.f;
+  if (live) {
+    for (long long p = r0 + tr; p < r1; p += rows_per_iter) {
+      const long long q = p * C + c;
+      if (out[q] > 0.f) {
+        const float g = dout[q];
+        const float xv = dec_ld<XBF>(x, (long long)arg[q] * C + c);
+        s0 += g;
+        s1 = fmaf(g, xv, s1);
+      }
+    }
+    sh[(tr * 2 + 0) * C + c] = s0;
+    sh[(tr * 2 + 1) * C + c] = s1;
+  }
+  __syncthreads();
+  for (int q = threadIdx.x; q < 2 * C; q += 256) {
+    float acc = 0.f;
+    for (int rr = 0; rr < rows_per_iter; ++rr) acc += sh[rr * 2 * C + q];
+    part[(long long)blockIdx.x * 2 * C + q] = acc;
+  }
+}
+
+template <bool XBF, bool OBF>
+__global__ __launch_bounds__(256) void k_segmax_bn_bwd(const void* __restrict__ x, const float* __restrict__ out,
+                                                       const int* __restrict__ arg, const float* __restrict__ dout,
+                                                       const int* __restrict__ inv, long long N, int C,
+                                                       const float* __restrict__ a, const float* __restrict__ c0,
+                                                       const float* __restrict__ c1, void* __restrict__ dx) {
+  const long long total = N * C;
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const long long i = e / C;
+    const int c = (int)(e % C);
+    const long long q = (long long)inv[i] * C + c;
+    const float dh = (arg[q] == (int)i && out[q] > 0.f) ? dout[q] : 0.f;
+    dec_st<OBF>(dx, e, fmaf(a[c], dh, fmaf(c1[c], dec_ld<XBF>(x, e), c0[c])));
+  }
+}
+
+extern "C" int gdmae_segmax_bwd_stats(const void* x, int x_bf16, const float* out, const int* arg, const float* dout,
+                                      long long M, int C, double* sums /* 2C: {sum dh, sum dh*x} */, void* workspace,
+                                      void* stream) {
+  GD_REQUIRE(C >= 1 && C <= 256, "C <= 256");
+  hipStream_t st = (hipStream_t)stream;
+  int nblk = (int)(M / 32 > 512 ? 512 : (M / 32 > 0 ? M / 32 : 1));
+  const int rpi = 256 / C > 0 ? 256 / C : 1;
+  const size_t lds = (size_t)rpi * 2 * C * sizeof(float);
+  float* part = (float*)workspace;
+  if (x_bf16)
+    hipLaunchKernelGGL((k_segmax_bwd_stats<true>), dim3(nblk), dim3(256), lds, st, x, out, arg, dout, M, C, part);
+  else
+    hipLaunchKernelGGL((k_segmax_bwd_stats<false>), dim3(nblk), dim3(256), lds, st, x, out, arg, dout, M, C, part);
+  GD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_partials_to_f64, dim3(gd_div_up(2 * C, 16)), dim3(256), 0, st, part, nblk, 2 * C, sums);
+  GD_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gdmae_segmax_bn_bwd(const void* x, int x_bf16, const float* out, const int* arg, const float* dout,
+                                   const int* inverse32, long long N, int C, const float* a, const float* c0, const float* c1,
+                                   void* dx, int dx_bf16, void* stream) {
+  if (N <= 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid(dec_grid(N * C)), block(256);
+#define GD_SB(XB, OB) hipLaunchKernelGGL((k_segmax_bn_bwd<XB, OB>), grid, block, 0, st, x, out, arg, dout, inverse32, N, C, a, c0, c1, dx)
+  if (x_bf16) { if (dx_bf16) GD_SB(true, true); else GD_SB(true, false); }
+  else { if (dx_bf16) GD_SB(false, true); else GD_SB(false, false); }
+#undef GD_SB
   GD_LAUNCH_CHECK();
   return 0;
 }

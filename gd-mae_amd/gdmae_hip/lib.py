@@ -46,6 +46,9 @@ SIGNATURES = {
     "gdmae_rows_bwd_stats_workspace_bytes": (_Z, [_I]),
     "gdmae_rows_bwd_stats": (_I, [_P, _I, _P, _L, _I, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
     "gdmae_rows_bwd": (_I, [_P, _I, _P, _L, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P, _I, _P]),
+    "gdmae_segment_max_affine": (_I, [_P, _I, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
+    "gdmae_segmax_bwd_stats": (_I, [_P, _I, _P, _P, _P, _L, _I, _P, _P, _P]),
+    "gdmae_segmax_bn_bwd": (_I, [_P, _I, _P, _P, _P, _P, _L, _I, _P, _P, _P, _P, _I, _P]),
     "gdmae_window_attention_fwd": (_I, [_P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P, _F, _P]),
     "gdmae_window_attention_bwd": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P, _F, _P]),
     "gdmae_add_layernorm_workspace_bytes": (_Z, [_I]),

@@ -11,10 +11,13 @@ import torch.nn as nn
 
 from .vfe_template import VFETemplate
 from ...model_utils.network_utils import make_fc_layers
-from gdmae_hip import ops, plan as gplan
+from gdmae_hip import ops, plan as gplan, vfe as gvfe
+from gdmae_hip.decoder import _update_running
 
 
 class DynVFE(VFETemplate):
+    fused = True      # fused BN+ReLU(+max) row kernels; False = torch BatchNorm1d / ReLU modules + segment max
+
     def __init__(self, model_cfg, num_point_features, voxel_size, point_cloud_range, grid_size, **kwargs):
         super().__init__(model_cfg=model_cfg)
         self.sample_type = model_cfg.get('TYPE', 'mean')
@@ -37,9 +40,22 @@ class DynVFE(VFETemplate):
         vox = gplan.voxelize(batch_dict['points'], self.point_cloud_range, self.voxel_size, self.grid_size,
                              int(batch_dict['batch_size']))
         x = ops.decorate_points(vox)
-        for m in self.dvfe_mlps[0]:                      # Linear(no bias) -> BN1d -> ReLU, twice
-            x = ops.linear(x, m.weight, m.bias) if isinstance(m, nn.Linear) else m(x)
-        x = ops.SegmentMax.apply(x.float(), vox.pt_off, vox.pillar_pts, vox.inverse32)
+        mlp = self.dvfe_mlps[0]
+        if self.fused and self.training:
+            nl = len(mlp) // 3
+            for k in range(nl):
+                lin, bn = mlp[3 * k], mlp[3 * k + 1]
+                x = ops.linear(x, lin.weight, lin.bias)
+                if k < nl - 1:
+                    x, mean, var = gvfe.BNReLURows.apply(x, bn.weight, bn.bias, bn.eps)
+                else:
+                    x, mean, var = gvfe.BNReLUSegmentMax.apply(x, bn.weight, bn.bias, bn.eps, vox.pt_off, vox.pillar_pts,
+                                                               vox.inverse32)
+                _update_running(bn, mean, var, vox.N)
+        else:
+            for m in mlp:                                # Linear(no bias) -> BN1d -> ReLU, twice
+                x = ops.linear(x, m.weight, m.bias) if isinstance(m, nn.Linear) else m(x)
+            x = ops.SegmentMax.apply(x.float(), vox.pt_off, vox.pillar_pts, vox.inverse32)
         batch_dict.update({'points': vox.points, 'point_coords': vox.point_coords,
                            'point_inverse_indices': vox.inverse, 'voxel_coords': vox.voxel_coords,
                            'pillar_features': x, 'voxel_features': x, '_gdmae_vox': vox})

@@ -150,6 +150,19 @@ int gdmae_rows_bwd(const void* P, int p_bf16, const int* site, long long n, int 
                    const float* c0, const float* c1, const void* dZ, int z_bf16, int z_row_elems, int col0, void* dP,
                    int dp_bf16, void* stream);
 
+/* The three row kernels above also serve BatchNorm1d + ReLU of the DynVFE point MLP (site = NULL: identity rows,
+ * Z/dZ = a plain (n, C) matrix with z_row_elems = C, col0 = 0).  Fused DynVFE tail (dyn_vfe.py:107-109):
+ *   gdmae_segment_max_affine: out[p,c] = max_{i in pillar p} relu(a_c x[i,c] + b_c), arg = arg-max point id
+ *   gdmae_segmax_bwd_stats:   sums double[2C] = column sums of {dh, dh*x}, dh = dout*[arg==i]*[out>0]
+ *   gdmae_segmax_bn_bwd:      dx[i,c] = a_c dh[i,c] + c0_c + c1_c x[i,c]  (BatchNorm chain rule, all N points) */
+int gdmae_segment_max_affine(const void* x, int x_bf16, const int* pillar_pt_off, const int* pillar_pts, int M, int C,
+                             const float* a, const float* b, float* out, int* arg, void* stream);
+int gdmae_segmax_bwd_stats(const void* x, int x_bf16, const float* out, const int* arg, const float* dout, long long M,
+                           int C, double* sums, void* workspace, void* stream);
+int gdmae_segmax_bn_bwd(const void* x, int x_bf16, const float* out, const int* arg, const float* dout,
+                        const int* inverse32, long long N, int C, const float* a, const float* c0, const float* c1,
+                        void* dx, int dx_bf16, void* stream);
+
 /* ---- a11, a13: windowed cosine attention ------------------------------------------------------ *
  * Replaces flat2window_v2/window2flat_v2 (sst_utils.py:107-180), WindowAttention.forward
  * (pcdet/models/model_utils/sst_basic_block.py:22-54) and _scaled_cosine_attention

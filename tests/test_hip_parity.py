@@ -433,3 +433,49 @@ def test_fused_add_layernorm_matches_torch(d, bdt):
     assert (bg.grad.float().cpu() - br.grad).abs().max() < tol * br.grad.abs().max() + 1e-6
     assert (lng.weight.grad.cpu() - ln.weight.grad).abs().max() < 1e-4 * ln.weight.grad.abs().max()
     assert (lng.bias.grad.cpu() - ln.bias.grad).abs().max() < 1e-4 * ln.bias.grad.abs().max()
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_fused_vfe_bn_relu_and_segment_max_match_torch(dt):
+    """gdmae_hip.vfe: fused BatchNorm1d(train)+ReLU rows and the fused BN+ReLU+per-pillar-max tail vs torch modules."""
+    from gdmae_hip import plan, vfe as gvfe
+    z, ds, cfg, _ = load_case("kitti_b2")
+    pts = torch.from_numpy(z["points"])
+    vox = plan.voxelize(pts.to(dev()), ds.point_cloud_range, ds.voxel_size, ds.grid_size, int(z["batch_size"]))
+    keep, coords = orc.point_coords(pts, ds.point_cloud_range, ds.voxel_size, ds.grid_size)
+    vc, inv, rank, cnt = orc.unique_pillars(coords, ds.grid_size)
+    g = torch.Generator().manual_seed(3)
+    N, C = vox.N, 128
+    x = (torch.randn(N, C, generator=g) * 2 + 0.3).to(dt)
+    gamma = torch.rand(C, generator=g) + 0.5
+    gamma[3] = -0.7                                   # negative scale: max must follow relu(a x + b), not a*max(x)
+    beta = torch.randn(C, generator=g) * 0.2
+    tol = 2e-2 if dt == torch.bfloat16 else 2e-4
+    # ---- rows
+    xr = x.float().clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    ref = torch.relu(torch.nn.functional.batch_norm(xr, None, None, gr, br, True, 0.01, 1e-3))
+    go = torch.randn(N, C, generator=g)
+    (ref * go).sum().backward()
+    xg = x.to(dev()).requires_grad_(True)
+    gg, bg = gamma.to(dev()).requires_grad_(True), beta.to(dev()).requires_grad_(True)
+    out, mean, var = gvfe.BNReLURows.apply(xg, gg, bg, 1e-3)
+    (out.float() * go.to(dev())).sum().backward()
+    assert (out.float().cpu() - ref.detach()).abs().max() <= tol * ref.abs().max()
+    assert (mean.cpu() - x.float().mean(0)).abs().max() < 1e-4 and (var.cpu() - x.float().var(0, unbiased=False)).abs().max() < 1e-3
+    assert (xg.grad.float().cpu() - xr.grad).norm() <= tol * xr.grad.norm()
+    assert (gg.grad.cpu() - gr.grad).norm() <= tol * gr.grad.norm() and (bg.grad.cpu() - br.grad).norm() <= tol * br.grad.norm()
+    # ---- fused tail
+    xr = x.float().clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    h = torch.relu(torch.nn.functional.batch_norm(xr, None, None, gr, br, True, 0.01, 1e-3))
+    ref, _ = tp.scatter_max(h, inv, vox.M)
+    go = torch.randn(vox.M, C, generator=g)
+    (ref * go).sum().backward()
+    xg = x.to(dev()).requires_grad_(True)
+    gg, bg = gamma.to(dev()).requires_grad_(True), beta.to(dev()).requires_grad_(True)
+    out, mean, var = gvfe.BNReLUSegmentMax.apply(xg, gg, bg, 1e-3, vox.pt_off, vox.pillar_pts, vox.inverse32)
+    (out * go.to(dev())).sum().backward()
+    assert (out.cpu() - ref.detach()).abs().max() <= tol * ref.abs().max()
+    assert (xg.grad.float().cpu() - xr.grad).norm() <= tol * xr.grad.norm()
+    assert (gg.grad.cpu() - gr.grad).norm() <= tol * gr.grad.norm() and (bg.grad.cpu() - br.grad).norm() <= tol * br.grad.norm()
