@@ -465,6 +465,20 @@ static int dispatch_bwd(const AttnBwdArgs& A, int T, int DH, hipStream_t st) {
   return launch_bwd<64, 32, IO>(A, st);
 }
 
+// MFMA variant for the dense levels (attention_mfma.hip)
+int gd_attn_mfma_fwd(const void* qk, const void* v, void* out, int io_bf16, const int* csr_tok, const int* win_start,
+                     const int* win_len, int n_win, int T, int d, int H, const float* tau, float tau_min, hipStream_t st);
+int gd_attn_mfma_bwd(const void* qk, const void* v, const void* dout, void* dqk, void* dv, int io_bf16, float* dtau_part,
+                     const int* csr_tok, const int* win_start, const int* win_len, int n_win, int T, int d, int H,
+                     const float* tau, float tau_min, hipStream_t st);
+
+static int g_attn_impl = 0;   // 0: MFMA kernels for T >= 32, lane-per-query VALU kernels for T = 16; 1: VALU kernels only
+extern "C" int gdmae_set_attention_impl(int impl) {
+  GD_REQUIRE(impl == 0 || impl == 1, "attention impl: 0 (auto) or 1 (VALU only)");
+  g_attn_impl = impl;
+  return 0;
+}
+
 // One occupancy level: windows [0, n_win) of (win_start, win_len); T = padded tokens of the level.
 // io_bf16 = 0: qk / v / out are fp32; 1: bf16 (arithmetic is fp32 in registers either way).
 extern "C" int gdmae_window_attention_fwd(const void* qk, const void* v, void* out, int io_bf16, const int* csr_tok,
@@ -476,12 +490,14 @@ extern "C" int gdmae_window_attention_fwd(const void* qk, const void* v, void* o
   GD_REQUIRE(DH == 16 || DH == 32, "head dim must be 16 or 32");
   GD_REQUIRE(T == 16 || T == 32 || T == 64, "T must be 16/32/64");
   GD_REQUIRE(H % (GD_WAVE / T) == 0, "heads must pack evenly into a wavefront");
-  AttnArgs A{qk, v, out, csr_tok, win_start, win_len, n_win, d, H, tau, tau_min};
   hipStream_t st = (hipStream_t)stream;
+  if (g_attn_impl == 0 && T >= 32)
+    return gd_attn_mfma_fwd(qk, v, out, io_bf16, csr_tok, win_start, win_len, n_win, T, d, H, tau, tau_min, st);
+  AttnArgs A{qk, v, out, csr_tok, win_start, win_len, n_win, d, H, tau, tau_min};
   return io_bf16 ? dispatch_fwd<IoBF16>(A, T, DH, st) : dispatch_fwd<IoF32>(A, T, DH, st);
 }
 
-// dtau_part must hold n_win * H / (64 / T) floats.
+// dtau_part must hold n_win * H floats (one partial per (window, head) at most).
 extern "C" int gdmae_window_attention_bwd(const void* qk, const void* v, const void* dout, void* dqk, void* dv, int io_bf16,
                                           float* dtau_part, const int* csr_tok, const int* win_start, const int* win_len,
                                           int n_win, int T, int d, int H, const float* tau, float tau_min, void* stream) {
@@ -491,7 +507,10 @@ extern "C" int gdmae_window_attention_bwd(const void* qk, const void* v, const v
   GD_REQUIRE(DH == 16 || DH == 32, "head dim must be 16 or 32");
   GD_REQUIRE(T == 16 || T == 32 || T == 64, "T must be 16/32/64");
   GD_REQUIRE(H % (GD_WAVE / T) == 0, "heads must pack evenly into a wavefront");
-  AttnBwdArgs A{qk, v, dout, dqk, dv, dtau_part, csr_tok, win_start, win_len, n_win, d, H, tau, tau_min};
   hipStream_t st = (hipStream_t)stream;
+  if (g_attn_impl == 0 && T >= 32)
+    return gd_attn_mfma_bwd(qk, v, dout, dqk, dv, io_bf16, dtau_part, csr_tok, win_start, win_len, n_win, T, d, H, tau,
+                            tau_min, st);
+  AttnBwdArgs A{qk, v, dout, dqk, dv, dtau_part, csr_tok, win_start, win_len, n_win, d, H, tau, tau_min};
   return io_bf16 ? dispatch_bwd<IoBF16>(A, T, DH, st) : dispatch_bwd<IoF32>(A, T, DH, st);
 }

@@ -1,0 +1,504 @@
+// MFMA (matrix-core) variant of the windowed cosine attention for the dense occupancy levels (T = 32 / 64).
+//
+// Same contract as k_win_attn_fwd / k_win_attn_bwd in attention.hip (reference
+// pcdet/models/model_utils/cosine_msa.py:114-176, sst_basic_block.py:22-54); used where a window holds up to
+// 32 / 64 tokens, i.e. where the per-(window, head) products are full 32x32 tiles.  The "lane = query row" VALU
+// kernel is latency bound there (one wavefront per SIMD at 256 VGPRs, every FMA quad waits on a broadcast LDS
+// read: ~90 us per (window, head) backward); on the matrix pipe the same work is 448 MFMAs = ~12 us.
+//
+// Arithmetic is EXACT fp32: v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate; bit-identical to an fmaf chain),
+// so the fp32 parity tolerance of the VALU kernel carries over.  bf16 MFMA is deliberately not used: logits are
+// cosines divided by tau >= 0.01, which amplifies bf16 operand rounding (4e-3) to O(0.4) in the logits.
+//
+// Layout (one wavefront = one (window, head), NT = 1 or 2 row tiles of 32 tokens):
+//  * operands Q^, K^, V, dO are held as "half rows" in registers: lane l keeps, for row (l & 31) of each tile,
+//    the DH/2 columns [ (l>>5)*DH/2, +DH/2 ).  For D += A B the K index of step s is "column s for lanes 0-31,
+//    column DH/2+s for lanes 32-63" on BOTH operands, so no shuffles and no LDS are needed for Q K^T / dO V^T;
+//  * S^T = K^ Q^T puts the query on the lane (C layout: col = lane & 31) and 16 keys per tile in the lane's
+//    accumulator registers -> softmax statistics are in-lane reductions plus ONE xor-32 exchange;
+//  * for P V (and dS K^, dS^T Q^, P^T dO) the accumulator registers of P / dS are fed back AS the B operand:
+//    register r of a C tile holds rows rowmap(r, half) for the two half-waves, which is exactly the k = 0 / 1
+//    pairing of one MFMA step (the sum over keys is order independent), so P never leaves registers.  The A
+//    operand of those steps is a row of V / K^ / Q^ / dO read from an LDS tile (conflict-free 128-byte rows);
+//  * the backward evaluates S both ways (query-on-lane for dQ, key-on-lane for dK / dV) instead of transposing
+//    a 64x64 tile through LDS: 128 extra MFMAs, no bank conflicts, no atomics, deterministic.
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define AM_EPS 1e-12f
+
+__device__ inline float am_bf2f(unsigned v) { return __uint_as_float(v << 16); }
+__device__ inline unsigned am_f2bf(float f) {
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7F800000u) == 0x7F800000u) return u >> 16;
+  return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+
+struct AmF32 {
+  typedef float T;
+  template <int N>
+  static __device__ inline void load(const T* __restrict__ p, float (&r)[N]) {
+#pragma unroll
+    for (int c = 0; c < N; c += 4) {
+      float4 v = *reinterpret_cast<const float4*>(p + c);
+      r[c] = v.x; r[c + 1] = v.y; r[c + 2] = v.z; r[c + 3] = v.w;
+    }
+  }
+  static __device__ inline void load4(const T* __restrict__ p, float (&r)[4]) {
+    float4 v = *reinterpret_cast<const float4*>(p);
+    r[0] = v.x; r[1] = v.y; r[2] = v.z; r[3] = v.w;
+  }
+  static __device__ inline void store4(T* __restrict__ p, float a, float b, float c, float d) {
+    *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
+  }
+};
+struct AmBF16 {
+  typedef unsigned short T;
+  template <int N>
+  static __device__ inline void load(const T* __restrict__ p, float (&r)[N]) {
+#pragma unroll
+    for (int c = 0; c < N; c += 8) {
+      uint4 v = *reinterpret_cast<const uint4*>(p + c);
+      const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        r[c + 2 * k] = am_bf2f(w[k] & 0xFFFFu);
+        r[c + 2 * k + 1] = __uint_as_float(w[k] & 0xFFFF0000u);
+      }
+    }
+  }
+  static __device__ inline void load4(const T* __restrict__ p, float (&r)[4]) {
+    uint2 v = *reinterpret_cast<const uint2*>(p);
+    r[0] = am_bf2f(v.x & 0xFFFFu); r[1] = __uint_as_float(v.x & 0xFFFF0000u);
+    r[2] = am_bf2f(v.y & 0xFFFFu); r[3] = __uint_as_float(v.y & 0xFFFF0000u);
+  }
+  static __device__ inline void store4(T* __restrict__ p, float a, float b, float c, float d) {
+    uint2 v;
+    v.x = am_f2bf(a) | (am_f2bf(b) << 16);
+    v.y = am_f2bf(c) | (am_f2bf(d) << 16);
+    *reinterpret_cast<uint2*>(p) = v;
+  }
+};
+
+// row of a 32x32 C tile held in accumulator register `reg` by a lane of half-wave `half`
+__device__ __forceinline__ int am_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
+
+template <int N>
+__device__ inline void am_store_lds(float* __restrict__ p, const float (&r)[N]) {
+#pragma unroll
+  for (int c = 0; c < N; c += 4) *reinterpret_cast<float4*>(p + c) = make_float4(r[c], r[c + 1], r[c + 2], r[c + 3]);
+}
+
+struct AmArgs {
+  const void* qk;
+  const void* v;
+  void* out;
+  const int* csr_tok;
+  const int* win_start;
+  const int* win_len;
+  int n_win, d, H;
+  const float* tau;
+  float tau_min;
+};
+
+template <int NT, int DH, typename IO>
+__global__ __launch_bounds__(256) void k_attn_mfma_fwd(AmArgs A) {
+  typedef typename IO::T io_t;
+  constexpr int HD = DH / 2;
+  constexpr int LD = DH + 4;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+  const int rho = lane & 31, half = lane >> 5;
+  float* sV = smem + wib * (32 * NT * LD);
+  const long long item = (long long)blockIdx.x * 4 + wib;
+  if (item >= (long long)A.n_win * A.H) return;
+  const int w = (int)(item / A.H), h = (int)(item % A.H);
+  const int n = A.win_len[w], start = A.win_start[w];
+  const float inv_tau = 1.f / fmaxf(*A.tau, A.tau_min);
+  const io_t* gqk = (const io_t*)A.qk;
+  const io_t* gv = (const io_t*)A.v;
+  io_t* gout = (io_t*)A.out;
+  const int d = A.d;
+
+  float qh[NT][HD], kh[NT][HD];
+  int tok[NT];
+#pragma unroll
+  for (int ti = 0; ti < NT; ++ti) {
+    const int r = 32 * ti + rho;
+    const bool act = r < n;
+    tok[ti] = act ? A.csr_tok[start + r] : 0;
+    float vh[HD];
+    if (act) {
+      IO::template load<HD>(gqk + (long long)tok[ti] * 2 * d + h * DH + half * HD, qh[ti]);
+      IO::template load<HD>(gqk + (long long)tok[ti] * 2 * d + d + h * DH + half * HD, kh[ti]);
+      IO::template load<HD>(gv + (long long)tok[ti] * d + h * DH + half * HD, vh);
+    } else {
+#pragma unroll
+      for (int c = 0; c < HD; ++c) qh[ti][c] = kh[ti][c] = vh[c] = 0.f;
+    }
+    am_store_lds<HD>(sV + r * LD + half * HD, vh);
+    float sq = 0.f, sk = 0.f;
+#pragma unroll
+    for (int c = 0; c < HD; ++c) {
+      sq = fmaf(qh[ti][c], qh[ti][c], sq);
+      sk = fmaf(kh[ti][c], kh[ti][c], sk);
+    }
+    sq += __shfl_xor(sq, 32, 64);
+    sk += __shfl_xor(sk, 32, 64);
+    const float iq = 1.f / fmaxf(sqrtf(sq), AM_EPS), ik = 1.f / fmaxf(sqrtf(sk), AM_EPS);
+#pragma unroll
+    for (int c = 0; c < HD; ++c) {
+      qh[ti][c] *= iq;
+      kh[ti][c] *= ik;
+    }
+  }
+  // S^T[key][query] tiles
+  f32x16 acc[NT][NT];
+#pragma unroll
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+#pragma unroll
+  for (int s = 0; s < HD; ++s)
+#pragma unroll
+    for (int kj = 0; kj < NT; ++kj)
+#pragma unroll
+      for (int qi = 0; qi < NT; ++qi)
+        acc[kj][qi] = __builtin_amdgcn_mfma_f32_32x32x2f32(kh[kj][s], qh[qi][s], acc[kj][qi], 0, 0, 0);
+  // softmax over keys per query column (lane)
+  float linv[NT];
+#pragma unroll
+  for (int qi = 0; qi < NT; ++qi) {
+    float m = -INFINITY;
+#pragma unroll
+    for (int kj = 0; kj < NT; ++kj)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = 32 * kj + am_row(r, half);
+        const float a = key < n ? acc[kj][qi][r] * inv_tau : -INFINITY;
+        acc[kj][qi][r] = a;
+        m = fmaxf(m, a);
+      }
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float l = 0.f;
+#pragma unroll
+    for (int kj = 0; kj < NT; ++kj)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = expf(acc[kj][qi][r] - m);   // exp(-inf) = 0 for padded keys
+        acc[kj][qi][r] = p;
+        l += p;
+      }
+    l += __shfl_xor(l, 32, 64);
+    linv[qi] = 1.f / l;
+  }
+  __builtin_amdgcn_wave_barrier();
+  // O^T[dh][query] = sum_keys V[key][dh] * P^T[key][query]; P fed back from its accumulator registers
+  f32x16 o[NT];
+#pragma unroll
+  for (int qi = 0; qi < NT; ++qi)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[qi][r] = 0.f;
+#pragma unroll
+  for (int kj = 0; kj < NT; ++kj)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = 32 * kj + am_row(r, half);
+      const float a = rho < DH ? sV[key * LD + rho] : 0.f;
+#pragma unroll
+      for (int qi = 0; qi < NT; ++qi) o[qi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, acc[kj][qi][r], o[qi], 0, 0, 0);
+    }
+#pragma unroll
+  for (int qi = 0; qi < NT; ++qi) {
+    if (32 * qi + rho < n) {
+      io_t* dst = gout + (long long)tok[qi] * d + h * DH;
+#pragma unroll
+      for (int g = 0; g < DH / 8; ++g)
+        IO::store4(dst + 8 * g + 4 * half, o[qi][4 * g] * linv[qi], o[qi][4 * g + 1] * linv[qi], o[qi][4 * g + 2] * linv[qi],
+                   o[qi][4 * g + 3] * linv[qi]);
+    }
+  }
+}
+
+struct AmBwdArgs {
+  const void* qk;
+  const void* v;
+  const void* dout;
+  void* dqk;
+  void* dv;
+  float* dtau_part;
+  const int* csr_tok;
+  const int* win_start;
+  const int* win_len;
+  int n_win, d, H;
+  const float* tau;
+  float tau_min;
+};
+
+template <int NT, int DH, typename IO>
+__global__ __launch_bounds__(256) void k_attn_mfma_bwd(AmBwdArgs A) {
+  typedef typename IO::T io_t;
+  constexpr int HD = DH / 2;
+  constexpr int LD = DH + 4;
+  constexpr int TILE = 32 * NT * LD;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+  const int rho = lane & 31, half = lane >> 5;
+  float* sA = smem + wib * (2 * TILE + 2 * 64);
+  float* sB = sA + TILE;
+  float* sLse = sB + TILE;
+  float* sD = sLse + 64;
+  const long long item = (long long)blockIdx.x * 4 + wib;
+  if (item >= (long long)A.n_win * A.H) return;
+  const int w = (int)(item / A.H), h = (int)(item % A.H);
+  const int n = A.win_len[w], start = A.win_start[w];
+  const float inv_tau = 1.f / fmaxf(*A.tau, A.tau_min);
+  const io_t* gqk = (const io_t*)A.qk;
+  const io_t* gv = (const io_t*)A.v;
+  const io_t* gdo = (const io_t*)A.dout;
+  io_t* gdqk = (io_t*)A.dqk;
+  io_t* gdv = (io_t*)A.dv;
+  const int d = A.d;
+
+  float qh[NT][HD], kh[NT][HD], vh[NT][HD], doh[NT][HD];
+  float qin[NT], kin[NT];
+  int tok[NT];
+#pragma unroll
+  for (int ti = 0; ti < NT; ++ti) {
+    const int r = 32 * ti + rho;
+    const bool act = r < n;
+    tok[ti] = act ? A.csr_tok[start + r] : 0;
+    if (act) {
+      IO::template load<HD>(gqk + (long long)tok[ti] * 2 * d + h * DH + half * HD, qh[ti]);
+      IO::template load<HD>(gqk + (long long)tok[ti] * 2 * d + d + h * DH + half * HD, kh[ti]);
+      IO::template load<HD>(gv + (long long)tok[ti] * d + h * DH + half * HD, vh[ti]);
+      IO::template load<HD>(gdo + (long long)tok[ti] * d + h * DH + half * HD, doh[ti]);
+    } else {
+#pragma unroll
+      for (int c = 0; c < HD; ++c) qh[ti][c] = kh[ti][c] = vh[ti][c] = doh[ti][c] = 0.f;
+    }
+    float sq = 0.f, sk = 0.f;
+#pragma unroll
+    for (int c = 0; c < HD; ++c) {
+      sq = fmaf(qh[ti][c], qh[ti][c], sq);
+      sk = fmaf(kh[ti][c], kh[ti][c], sk);
+    }
+    sq += __shfl_xor(sq, 32, 64);
+    sk += __shfl_xor(sk, 32, 64);
+    qin[ti] = 1.f / fmaxf(sqrtf(sq), AM_EPS);
+    kin[ti] = 1.f / fmaxf(sqrtf(sk), AM_EPS);
+#pragma unroll
+    for (int c = 0; c < HD; ++c) {
+      qh[ti][c] *= qin[ti];
+      kh[ti][c] *= kin[ti];
+    }
+    am_store_lds<HD>(sA + r * LD + half * HD, kh[ti]);   // K^ tile: A operand of dQ^T
+  }
+
+  float dtau = 0.f;
+  __builtin_amdgcn_wave_barrier();
+  // ================= phase 1: query on the lane (S^T, dP^T) -> dQ, one query tile at a time =================
+#pragma unroll
+  for (int qi = 0; qi < NT; ++qi) {
+    f32x16 aS[NT], aP[NT];   // [kj]: S^T / dP^T tiles (keys in registers, query = lane)
+#pragma unroll
+    for (int kj = 0; kj < NT; ++kj)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) aS[kj][r] = aP[kj][r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < HD; ++s)
+#pragma unroll
+      for (int kj = 0; kj < NT; ++kj) {
+        aS[kj] = __builtin_amdgcn_mfma_f32_32x32x2f32(kh[kj][s], qh[qi][s], aS[kj], 0, 0, 0);
+        aP[kj] = __builtin_amdgcn_mfma_f32_32x32x2f32(vh[kj][s], doh[qi][s], aP[kj], 0, 0, 0);
+      }
+    float m = -INFINITY;
+#pragma unroll
+    for (int kj = 0; kj < NT; ++kj)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = 32 * kj + am_row(r, half);
+        const float a = key < n ? aS[kj][r] * inv_tau : -INFINITY;
+        aS[kj][r] = a;
+        m = fmaxf(m, a);
+      }
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float l = 0.f;
+#pragma unroll
+    for (int kj = 0; kj < NT; ++kj)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) l += expf(aS[kj][r] - m);
+    l += __shfl_xor(l, 32, 64);
+    const float lse = m + logf(l);
+    float D = 0.f;
+#pragma unroll
+    for (int kj = 0; kj < NT; ++kj)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) D = fmaf(expf(aS[kj][r] - lse), aP[kj][r], D);   // exp(-inf) = 0 for padded keys
+    D += __shfl_xor(D, 32, 64);
+    const bool qact = 32 * qi + rho < n;
+#pragma unroll
+    for (int kj = 0; kj < NT; ++kj)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float a = aS[kj][r];
+        const float p = expf(a - lse);
+        const float dS = p * (aP[kj][r] - D);
+        if (qact && p > 0.f) dtau = fmaf(-dS, a * inv_tau, dtau);   // d a / d tau_c = -a / tau_c
+        aS[kj][r] = dS * inv_tau;                                   // gradient w.r.t. the cosine q^.k^
+      }
+    if (half == 0) {
+      sLse[32 * qi + rho] = lse;
+      sD[32 * qi + rho] = D;
+    }
+    f32x16 oq;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oq[r] = 0.f;
+#pragma unroll
+    for (int kj = 0; kj < NT; ++kj)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = 32 * kj + am_row(r, half);
+        const float a = rho < DH ? sA[key * LD + rho] : 0.f;       // K^[key][dh = rho]
+        oq = __builtin_amdgcn_mfma_f32_32x32x2f32(a, aS[kj][r], oq, 0, 0, 0);
+      }
+    // through q^ = q / max(|q|, eps): dq = (dq^ - q^ (q^ . dq^)) / max(|q|, eps), q^ re-read in the C-tile row layout
+    float qv[DH / 8][4];
+    float pr = 0.f;
+#pragma unroll
+    for (int g = 0; g < DH / 8; ++g) {
+      if (qact) IO::load4(gqk + (long long)tok[qi] * 2 * d + h * DH + 8 * g + 4 * half, qv[g]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        qv[g][e] = qact ? qv[g][e] * qin[qi] : 0.f;
+        pr = fmaf(qv[g][e], oq[4 * g + e], pr);
+      }
+    }
+    pr += __shfl_xor(pr, 32, 64);
+    if (qact) {
+      io_t* dst = gdqk + (long long)tok[qi] * 2 * d + h * DH;
+#pragma unroll
+      for (int g = 0; g < DH / 8; ++g)
+        IO::store4(dst + 8 * g + 4 * half, (oq[4 * g] - qv[g][0] * pr) * qin[qi], (oq[4 * g + 1] - qv[g][1] * pr) * qin[qi],
+                   (oq[4 * g + 2] - qv[g][2] * pr) * qin[qi], (oq[4 * g + 3] - qv[g][3] * pr) * qin[qi]);
+    }
+  }
+  // ================= phase 2: key on the lane (S, dP) -> dK, dV, one key tile at a time =================
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int ti = 0; ti < NT; ++ti) {
+    const int r = 32 * ti + rho;
+    am_store_lds<HD>(sA + r * LD + half * HD, qh[ti]);    // Q^ tile
+    am_store_lds<HD>(sB + r * LD + half * HD, doh[ti]);   // dO tile
+  }
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int kj = 0; kj < NT; ++kj) {
+    f32x16 aS[NT], aP[NT];   // [qi]: S / dP tiles (queries in registers, key = lane)
+#pragma unroll
+    for (int qi = 0; qi < NT; ++qi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) aS[qi][r] = aP[qi][r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < HD; ++s)
+#pragma unroll
+      for (int qi = 0; qi < NT; ++qi) {
+        aS[qi] = __builtin_amdgcn_mfma_f32_32x32x2f32(qh[qi][s], kh[kj][s], aS[qi], 0, 0, 0);    // S[q][key]
+        aP[qi] = __builtin_amdgcn_mfma_f32_32x32x2f32(doh[qi][s], vh[kj][s], aP[qi], 0, 0, 0);   // dP[q][key]
+      }
+    const bool kact = 32 * kj + rho < n;
+#pragma unroll
+    for (int qi = 0; qi < NT; ++qi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int q = 32 * qi + am_row(r, half);
+        const bool ok = kact && q < n;
+        const float p = ok ? expf(aS[qi][r] * inv_tau - sLse[q]) : 0.f;
+        aS[qi][r] = p * (aP[qi][r] - sD[q]) * inv_tau;   // dS / tau_c
+        aP[qi][r] = p;
+      }
+    f32x16 okk, ov;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) okk[r] = ov[r] = 0.f;
+#pragma unroll
+    for (int qi = 0; qi < NT; ++qi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int q = 32 * qi + am_row(r, half);
+        const float aq = rho < DH ? sA[q * LD + rho] : 0.f;   // Q^[q][dh = rho]
+        const float ad = rho < DH ? sB[q * LD + rho] : 0.f;   // dO[q][dh = rho]
+        okk = __builtin_amdgcn_mfma_f32_32x32x2f32(aq, aS[qi][r], okk, 0, 0, 0);
+        ov = __builtin_amdgcn_mfma_f32_32x32x2f32(ad, aP[qi][r], ov, 0, 0, 0);
+      }
+    float kv[DH / 8][4];
+    float pr = 0.f;
+#pragma unroll
+    for (int g = 0; g < DH / 8; ++g) {
+      if (kact) IO::load4(gqk + (long long)tok[kj] * 2 * d + d + h * DH + 8 * g + 4 * half, kv[g]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        kv[g][e] = kact ? kv[g][e] * kin[kj] : 0.f;
+        pr = fmaf(kv[g][e], okk[4 * g + e], pr);
+      }
+    }
+    pr += __shfl_xor(pr, 32, 64);
+    if (kact) {
+      io_t* dk = gdqk + (long long)tok[kj] * 2 * d + d + h * DH;
+      io_t* dvp = gdv + (long long)tok[kj] * d + h * DH;
+#pragma unroll
+      for (int g = 0; g < DH / 8; ++g) {
+        IO::store4(dk + 8 * g + 4 * half, (okk[4 * g] - kv[g][0] * pr) * kin[kj], (okk[4 * g + 1] - kv[g][1] * pr) * kin[kj],
+                   (okk[4 * g + 2] - kv[g][2] * pr) * kin[kj], (okk[4 * g + 3] - kv[g][3] * pr) * kin[kj]);
+        IO::store4(dvp + 8 * g + 4 * half, ov[4 * g], ov[4 * g + 1], ov[4 * g + 2], ov[4 * g + 3]);
+      }
+    }
+  }
+  dtau = gd_wave_sum(dtau);
+  if (lane == 0) A.dtau_part[item] = dtau;
+}
+
+template <int NT, int DH, typename IO>
+static int am_launch_fwd(const AmArgs& A, hipStream_t st) {
+  const long long items = (long long)A.n_win * A.H;
+  const size_t lds = (size_t)4 * 32 * NT * (DH + 4) * sizeof(float);
+  hipLaunchKernelGGL((k_attn_mfma_fwd<NT, DH, IO>), dim3(gd_div_up(items, 4)), dim3(256), lds, st, A);
+  GD_LAUNCH_CHECK();
+  return 0;
+}
+template <int NT, int DH, typename IO>
+static int am_launch_bwd(const AmBwdArgs& A, hipStream_t st) {
+  const long long items = (long long)A.n_win * A.H;
+  const size_t lds = (size_t)4 * (2 * 32 * NT * (DH + 4) + 128) * sizeof(float);
+  hipLaunchKernelGGL((k_attn_mfma_bwd<NT, DH, IO>), dim3(gd_div_up(items, 4)), dim3(256), lds, st, A);
+  GD_LAUNCH_CHECK();
+  return 0;
+}
+
+// called from attention.hip's dispatchers for T = 32 (NT = 1) and T = 64 (NT = 2); dtau_part holds n_win * H floats
+int gd_attn_mfma_fwd(const void* qk, const void* v, void* out, int io_bf16, const int* csr_tok, const int* win_start,
+                     const int* win_len, int n_win, int T, int d, int H, const float* tau, float tau_min, hipStream_t st) {
+  AmArgs A{qk, v, out, csr_tok, win_start, win_len, n_win, d, H, tau, tau_min};
+  const int DH = d / H;
+  if (T == 32) {
+    if (DH == 16) return io_bf16 ? am_launch_fwd<1, 16, AmBF16>(A, st) : am_launch_fwd<1, 16, AmF32>(A, st);
+    return io_bf16 ? am_launch_fwd<1, 32, AmBF16>(A, st) : am_launch_fwd<1, 32, AmF32>(A, st);
+  }
+  if (DH == 16) return io_bf16 ? am_launch_fwd<2, 16, AmBF16>(A, st) : am_launch_fwd<2, 16, AmF32>(A, st);
+  return io_bf16 ? am_launch_fwd<2, 32, AmBF16>(A, st) : am_launch_fwd<2, 32, AmF32>(A, st);
+}
+
+int gd_attn_mfma_bwd(const void* qk, const void* v, const void* dout, void* dqk, void* dv, int io_bf16, float* dtau_part,
+                     const int* csr_tok, const int* win_start, const int* win_len, int n_win, int T, int d, int H,
+                     const float* tau, float tau_min, hipStream_t st) {
+  AmBwdArgs A{qk, v, dout, dqk, dv, dtau_part, csr_tok, win_start, win_len, n_win, d, H, tau, tau_min};
+  const int DH = d / H;
+  if (T == 32) {
+    if (DH == 16) return io_bf16 ? am_launch_bwd<1, 16, AmBF16>(A, st) : am_launch_bwd<1, 16, AmF32>(A, st);
+    return io_bf16 ? am_launch_bwd<1, 32, AmBF16>(A, st) : am_launch_bwd<1, 32, AmF32>(A, st);
+  }
+  if (DH == 16) return io_bf16 ? am_launch_bwd<2, 16, AmBF16>(A, st) : am_launch_bwd<2, 16, AmF32>(A, st);
+  return io_bf16 ? am_launch_bwd<2, 32, AmBF16>(A, st) : am_launch_bwd<2, 32, AmF32>(A, st);
+}

@@ -298,7 +298,7 @@ class WindowCosineAttention(torch.autograd.Function):
         es = v.element_size()
         dqk = torch.empty_like(qk)
         dv = torch.empty_like(v)
-        n_items = [nw * H // (64 // T) for nw, T in zip(wplan.n_win, wplan.max_tokens)]
+        n_items = [nw * H for nw in wplan.n_win]      # one partial per (window, head) at most
         part = torch.empty(max(sum(n_items), 1), dtype=torch.float32, device=v.device)
         base, pbase = 0, 0
         for lvl, nw in enumerate(wplan.n_win):

@@ -204,9 +204,13 @@ def test_sparse_conv_matches_oracle():
     assert torch.equal(dense.cpu(), tp.densify(x, idx0, [s0.Y, s0.X], B))
 
 
+@pytest.mark.parametrize("impl", [0, 1])
 @pytest.mark.parametrize("d,nhead", [(128, 8), (256, 8)])
-def test_window_attention_fwd_bwd_matches_oracle(d, nhead):
+def test_window_attention_fwd_bwd_matches_oracle(d, nhead, impl):
+    """impl 0: MFMA kernels for the T = 32 / 64 levels + VALU kernel for T = 16 (product default); 1: VALU everywhere."""
+    from gdmae_hip import lib as L
     from gdmae_hip import ops, plan
+    L.call("gdmae_set_attention_impl", impl)
     from pcdet.models.backbones_3d.spt_backbone import SSTInputLayer
     z, ds, cfg, _ = load_case("waymo_b1")
     B = int(z["batch_size"])
@@ -257,6 +261,17 @@ def test_window_attention_fwd_bwd_matches_oracle(d, nhead):
             assert abs(float(tau.grad.cpu().reshape(-1)[0] - dtau.reshape(-1)[0])) <= 2e-3 * abs(float(dtau.reshape(-1)[0])) + 1e-6
         else:
             assert float(tau.grad.abs().sum()) == 0.0 and float(dtau.abs().sum()) == 0.0
+        # bf16 token rows (throughput mode): same kernels, bf16 HBM I/O, fp32 arithmetic
+        qkb, vb = qk.detach().to(torch.bfloat16).requires_grad_(True), v.detach().to(torch.bfloat16).requires_grad_(True)
+        outb = ops.WindowCosineAttention.apply(qkb, vb, tau.detach(), w, nhead, 0.01)
+        assert outb.dtype == torch.bfloat16
+        errb = (outb.float().cpu() - ref.detach()).abs().max() / ref.abs().max()
+        assert errb < (3e-2 if shift == 0 else 0.5), errb      # tau = 0.004 -> clamp 0.01 amplifies bf16 q/k rounding 100x
+        (outb.float() * go.to(dev())).sum().backward()
+        assert torch.isfinite(qkb.grad.float()).all() and torch.isfinite(vb.grad.float()).all()
+        if shift == 0:
+            assert (vb.grad.float().cpu() - v.grad.cpu()).norm() < 3e-2 * v.grad.norm()
+    L.call("gdmae_set_attention_impl", 0)
 
 
 def test_chamfer_matches_oracle():
