@@ -299,7 +299,7 @@ class WindowCosineAttention(torch.autograd.Function):
         dqk = torch.empty_like(qk)
         dv = torch.empty_like(v)
         n_items = [nw * H for nw in wplan.n_win]      # one partial per (window, head) at most
-        part = torch.empty(max(sum(n_items), 1), dtype=torch.float32, device=v.device)
+        part = torch.zeros(max(sum(n_items), 1), dtype=torch.float32, device=v.device)   # VALU levels fill fewer slots
         base, pbase = 0, 0
         for lvl, nw in enumerate(wplan.n_win):
             if nw > 0:
