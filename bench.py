@@ -103,12 +103,15 @@ def measure_cpu_baseline(config: str, mask_ratio: float):
 
 
 def measure_roofline(step, dev_batches, args, n_steps=4):
-    """HIP-event timing of the dominant kernel over `n_steps` extra steps (after the timed region).
+    """HIP-event timing of the dominant hand-written kernel over `n_steps` extra steps (after the timed region).
 
-    Dominant kernel of the step (profiles/r01_*_kernel_stats*.csv): k_win_attn_bwd, the windowed cosine
-    attention backward - HBM bound: per token it must read the q, k, v and dOut rows and write the dq, dk, dv
-    rows (7 x d fp32) exactly once; algorithmic bytes per launch = tokens_of_level * (28 d + 4) + 8 * windows
-    (DESIGN.md 'Kernels').  achieved = sum(bytes) / sum(duration) over all its launches."""
+    Dominant HIP kernel of the step (profiles/r01_kernel_stats.csv): the windowed cosine attention backward
+    (entry point gdmae_window_attention_bwd = k_win_attn_bwd for the T=16 level + k_attn_mfma_bwd for T=32/64).
+    Algorithmic bytes per launch = tokens_of_level * (7 * d * elem_size + 4) + 8 * windows (read the q, k, v, dOut
+    rows, write the dq, dk, dv rows, once each, + CSR), DESIGN.md section 4.  achieved = sum(bytes) / sum(duration)
+    over all its launches, timed with HIP events on the launch stream.  `traffic` = measured HBM bytes per launch
+    from the committed rocprofv3 PMC passes (2 x FETCH_SIZE + WRITE_SIZE in KiB, profiles/r01_pmc_*_by_kernel.csv):
+    it equals the algorithmic bytes, i.e. no re-reads - the kernel is latency / issue bound, not bandwidth bound."""
     from gdmae_hip import timing
     with timing.collect() as T:
         for i in range(n_steps):
@@ -116,9 +119,23 @@ def measure_roofline(step, dev_batches, args, n_steps=4):
         summ = T.summary()
     k = summ["k_win_attn_bwd"]
     gbs = k["total_bytes"] / (k["total_ms"] * 1e-3) / 1e9
-    return {"kernel": "k_win_attn_bwd", "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "launches_per_step": k["launches"] / n_steps,
-            "avg_launch_us": round(k["avg_us"], 2), "algorithmic_bytes_per_launch": int(k["bytes_per_launch"]),
+    traffic = None
+    try:
+        import csv
+        tot = {"FETCH_SIZE": [0.0, 0], "WRITE_SIZE": [0.0, 0]}
+        for tag in tot:
+            for r in csv.DictReader(open(os.path.join(REPO, "profiles", f"r01_pmc_{tag}_by_kernel.csv"))):
+                if r["kernel"] in ("k_win_attn_bwd", "k_attn_mfma_bwd"):
+                    tot[tag][0] += float(r[f"sum_{tag}"])
+                    tot[tag][1] += int(r["dispatches"])
+        if tot["FETCH_SIZE"][1] and tot["FETCH_SIZE"][1] == tot["WRITE_SIZE"][1]:
+            traffic = int((2 * tot["FETCH_SIZE"][0] + tot["WRITE_SIZE"][0]) * 1024 / tot["FETCH_SIZE"][1])
+    except Exception:
+        traffic = None
+    return {"kernel": "gdmae_window_attention_bwd (k_win_attn_bwd + k_attn_mfma_bwd)", "bound": "hbm", "achieved": round(gbs, 1),
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "launches_per_step": k["launches"] / n_steps, "avg_launch_us": round(k["avg_us"], 2),
+            "algorithmic_bytes_per_launch": int(k["bytes_per_launch"]),
             "also": {n: {"avg_us": round(v["avg_us"], 2), "GBs": round(v["total_bytes"] / (v["total_ms"] * 1e-3) / 1e9, 1)}
                      for n, v in summ.items() if n != "k_win_attn_bwd"}}
 
