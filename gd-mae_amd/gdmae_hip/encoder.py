@@ -1,0 +1,211 @@
+"""Hand-written forward/backward of one post-norm encoder layer.
+
+Same arithmetic as ``EncoderLayer.forward`` of the reference (pcdet/models/model_utils/sst_basic_block.py:77-84 with
+``WindowAttention`` :22-54 and the cosine attention of cosine_msa.py): q = k = x + pos, v = x, packed in-projection
+used as separate q/k and v slices, windowed cosine attention, out-projection, LN(x + attn), FFN with GELU(erf),
+LN(x + ffn).  What differs is only the schedule: at 20-40 k tokens per stage every kernel of the layer runs for
+5-30 us, so the step is bound by launch granularity.  Going through autograd op by op costs ~140 launches per layer
+(dtype casts, bias-gradient reductions, gradient accumulation adds, split-K tails); this Function issues ~55:
+
+* one ``gdmae_prep_tokens`` writes x and x + pos in the GEMM dtype (instead of an add and two casts);
+* the fused add+LayerNorm kernels emit the bf16 copy the next GEMM needs, accept the second gradient branch on load
+  (no accumulation kernels) and return the column sums that are the bias gradient of the preceding GEMM;
+* activations that are operands of a weight-gradient GEMM live in buffers padded to a multiple of 2048 rows (pad
+  rows zero), so dW = g^T x is ONE batched GEMM over K-chunks + one reduction, without a tail GEMM;
+* the residual-stream gradient is assembled by one ``gdmae_add3``.
+GEMMs are hipBLASLt through torch (bf16 under autocast, fp32 otherwise); attention, LayerNorm, prep/add kernels are
+libgdmae_hip.so.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+from . import lib as L
+from . import ops, timing
+
+PAD = 2048
+
+
+def _bf(t):
+    return int(t.dtype == torch.bfloat16)
+
+
+def _padded(n, cols, dtype, dev):
+    n_pad = (n + PAD - 1) // PAD * PAD
+    t = torch.empty(n_pad, cols, dtype=dtype, device=dev)
+    if n_pad > n:
+        t[n:].zero_()
+    return t
+
+
+def _dw(g_full: torch.Tensor, x_any: torch.Tensor, n: int, out: torch.Tensor | None = None) -> torch.Tensor:
+    """g^T x (fp32) with K = tokens split over a batched GEMM; both operands padded (zero rows) -> no tail GEMM."""
+    if x_any.shape[0] != g_full.shape[0]:
+        r = ops.splitk_tn(g_full[:n], x_any[:n])
+        if out is not None:
+            out.copy_(r)
+            return out
+        return r
+    K, m = g_full.shape
+    nn = x_any.shape[1]
+    tiles = max(1, (m + 127) // 128) * max(1, (nn + 127) // 128)
+    S = 1
+    while S * 2 <= min(K // 256, max(1, 1024 // tiles), 256) and K % (S * 2) == 0:
+        S *= 2
+    a3 = g_full.view(S, K // S, m).transpose(1, 2)
+    b3 = x_any.view(S, K // S, nn)
+    if g_full.dtype != torch.float32 and ops._BMM_OUT_DTYPE_OK is not False:
+        try:
+            part = torch.bmm(a3, b3, out_dtype=torch.float32)
+            ops._BMM_OUT_DTYPE_OK = True
+        except (TypeError, RuntimeError):
+            ops._BMM_OUT_DTYPE_OK = False
+            part = torch.bmm(a3, b3).float()
+    else:
+        part = torch.bmm(a3, b3)
+        if part.dtype != torch.float32:
+            part = part.float()
+    if out is not None:
+        return torch.sum(part, 0, out=out)
+    return part.sum(0)
+
+
+def _ln_fwd(a, b, gamma, beta, eps, want_copy_dtype):
+    n, d = a.shape
+    y = torch.empty_like(a)
+    stats = torch.empty(n, 2, dtype=torch.float32, device=a.device)
+    yb = _padded(n, d, torch.bfloat16, a.device) if want_copy_dtype == torch.bfloat16 else None
+    L.call("gdmae_add_layernorm_fwd", L.ptr(a), L.ptr(b), _bf(b), L.ptr(gamma), L.ptr(beta), n, d, float(eps), L.ptr(y),
+           L.ptr(stats), None if yb is None else L.ptr(yb), L.stream())
+    return y, stats, yb
+
+
+def _ln_bwd(a, b, gamma, stats, dy, dy2, cdt):
+    n, d = a.shape
+    dx = torch.empty_like(a)
+    dxb = _padded(n, d, torch.bfloat16, a.device) if cdt == torch.bfloat16 else None
+    sums = torch.empty(3 * d, dtype=torch.float32, device=a.device)
+    ws = torch.empty(L.load().gdmae_add_layernorm_workspace_bytes(d), dtype=torch.uint8, device=a.device)
+    L.call("gdmae_add_layernorm_bwd", L.ptr(a), L.ptr(b), _bf(b), L.ptr(gamma), L.ptr(stats), L.ptr(dy),
+           None if dy2 is None else L.ptr(dy2), 0 if dy2 is None else _bf(dy2), n, d, L.ptr(dx),
+           None if dxb is None else L.ptr(dxb), L.ptr(sums), L.ptr(ws), L.stream())
+    return dx, dxb, sums
+
+
+def attn_forward_into(qk, v, out, tau_flat, wplan, nhead, tau_min):
+    bf, es, d = _bf(qk), qk.element_size(), v.shape[1]
+    base = 0
+    for lvl, nw in enumerate(wplan.n_win):
+        if nw > 0:
+            with timing.kernel("k_win_attn_fwd", wplan.n_tok[lvl] * (4 * d * es + 4) + 8 * nw):
+                L.call("gdmae_window_attention_fwd", L.ptr(qk), L.ptr(v), L.ptr(out), bf, L.ptr(wplan.csr_tok),
+                       L.ptr(wplan.win_start[base:]), L.ptr(wplan.win_len[base:]), nw, wplan.max_tokens[lvl], d, nhead,
+                       L.ptr(tau_flat), float(tau_min), L.stream())
+        base += nw
+
+
+def attn_backward_into(qk, v, g, dqk, dv, tau_flat, wplan, nhead, tau_min):
+    bf, es, d = _bf(qk), qk.element_size(), v.shape[1]
+    n_items = [nw * nhead for nw in wplan.n_win]
+    part = torch.zeros(max(sum(n_items), 1), dtype=torch.float32, device=v.device)
+    base, pbase = 0, 0
+    for lvl, nw in enumerate(wplan.n_win):
+        if nw > 0:
+            with timing.kernel("k_win_attn_bwd", wplan.n_tok[lvl] * (7 * d * es + 4) + 8 * nw):
+                L.call("gdmae_window_attention_bwd", L.ptr(qk), L.ptr(v), L.ptr(g), L.ptr(dqk), L.ptr(dv), bf,
+                       L.ptr(part[pbase:]), L.ptr(wplan.csr_tok), L.ptr(wplan.win_start[base:]),
+                       L.ptr(wplan.win_len[base:]), nw, wplan.max_tokens[lvl], d, nhead, L.ptr(tau_flat), float(tau_min),
+                       L.stream())
+        base += nw
+        pbase += n_items[lvl]
+    dtau = torch.empty(1, dtype=torch.float32, device=v.device)
+    L.call("gdmae_sum_partials_gated", L.ptr(part), pbase, 1.0, L.ptr(dtau), L.ptr(tau_flat), float(tau_min), L.stream())
+    return dtau
+
+
+class EncoderLayerFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, Win, bin_, tau, Wo, bo, W1, b1, W2, b2, g1, be1, g2, be2, wplan, pos_table, nhead, tau_min, eps, act):
+        assert act == "gelu", "hot path uses ACTIVATION gelu (gd_mae_ssl.yaml:66)"
+        x = x.float().contiguous()
+        n, d = x.shape
+        dev = x.device
+        cdt = torch.bfloat16 if torch.is_autocast_enabled() else torch.float32
+        sh = lambda t: ops.shadow(t, cdt)   # noqa: E731
+        # q/k and v inputs in the GEMM dtype
+        if cdt == torch.bfloat16:
+            xb, xpb = _padded(n, d, cdt, dev), _padded(n, d, cdt, dev)
+            L.call("gdmae_prep_tokens", L.ptr(x), L.ptr(pos_table), L.ptr(wplan.tok_pos), n, d, L.ptr(xb), L.ptr(xpb), 1, L.stream())
+        else:
+            xb, xpb = x, _padded(n, d, cdt, dev)
+            L.call("gdmae_prep_tokens", L.ptr(x), L.ptr(pos_table), L.ptr(wplan.tok_pos), n, d, None, L.ptr(xpb), 0, L.stream())
+        qk = F.linear(xpb[:n], sh(Win[:2 * d]), sh(bin_[:2 * d]))
+        v = F.linear(xb[:n], sh(Win[2 * d:]), sh(bin_[2 * d:]))
+        tau_flat = tau.detach().reshape(1).float().contiguous()
+        o = _padded(n, d, cdt, dev)
+        attn_forward_into(qk, v, o, tau_flat, wplan, nhead, tau_min)
+        a = F.linear(o[:n], sh(Wo), sh(bo))
+        x1, st1, x1b = _ln_fwd(x, a, g1.detach(), be1.detach(), eps, cdt)
+        x1g = x1b if x1b is not None else x1
+        h = F.linear(x1g[:n], sh(W1), sh(b1))
+        gact = _padded(n, h.shape[1], cdt, dev)
+        torch.ops.aten.gelu.out(h, out=gact[:n])
+        f = F.linear(gact[:n], sh(W2), sh(b2))
+        y, st2, _ = _ln_fwd(x1, f, g2.detach(), be2.detach(), eps, None)
+        ctx.save_for_backward(x, xb, xpb, qk, v, o, a, x1, st1, x1g, h, gact, f, st2, tau_flat,
+                              sh(Win), sh(Wo), sh(W1), sh(W2), g1.detach(), g2.detach())
+        ctx.meta = (wplan, nhead, tau_min, cdt, n, d, tau.shape, tau.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x, xb, xpb, qk, v, o, a, x1, st1, x1g, h, gact, f, st2, tau_flat, Win_s, Wo_s, W1_s, W2_s, g1, g2) = ctx.saved_tensors
+        wplan, nhead, tau_min, cdt, n, d, tau_shape, tau_dtype = ctx.meta
+        dev = x.device
+        dy = dy.float().contiguous()
+        ff = h.shape[1]
+        # ---- LN2 and FFN
+        dx1_res, dfb, s2 = _ln_bwd(x1, f, g2, st2, dy, None, cdt)
+        df = dfb if dfb is not None else dx1_res
+        dW2 = _dw(df if dfb is not None else _as_padded(df, n), gact, n)
+        dg = df[:n] @ W2_s
+        dh = _padded(n, ff, cdt, dev)
+        torch.ops.aten.gelu_backward.grad_input(dg, h, grad_input=dh[:n])
+        db1 = ops.colsum_f32(dh[:n])
+        dW1 = _dw(dh, x1g, n)
+        dx1_b = dh[:n] @ W1_s
+        # ---- LN1 (gradient = residual branch + FFN branch) and out-projection
+        dx_res, dab, s1 = _ln_bwd(x, a, g1, st1, dx1_res, dx1_b, cdt)
+        da = dab if dab is not None else dx_res
+        dWo = _dw(da if dab is not None else _as_padded(da, n), o, n)
+        do = da[:n] @ Wo_s
+        # ---- attention
+        dqk, dv = _padded(n, 2 * d, cdt, dev), _padded(n, d, cdt, dev)
+        dtau = attn_backward_into(qk, v, do.contiguous(), dqk, dv, tau_flat, wplan, nhead, tau_min)
+        dWin = torch.empty(3 * d, d, dtype=torch.float32, device=dev)
+        _dw(dqk, xpb, n, out=dWin[:2 * d])
+        _dw(dv, xb, n, out=dWin[2 * d:])
+        dbin = torch.cat([ops.colsum_f32(dqk[:n]), ops.colsum_f32(dv[:n])])
+        dx_qk = dqk[:n] @ Win_s[:2 * d]
+        dx_v = dv[:n] @ Win_s[2 * d:]
+        dx = torch.empty_like(x)
+        L.call("gdmae_add3", L.ptr(dx_res), L.ptr(dx_qk), _bf(dx_qk), L.ptr(dx_v), _bf(dx_v), n * d, L.ptr(dx), L.stream())
+        return (dx, dWin, dbin, dtau.view(tau_shape).to(tau_dtype), dWo, s1[2 * d:], dW1, db1, dW2, s2[2 * d:],
+                s1[:d], s1[d:2 * d], s2[:d], s2[d:2 * d], None, None, None, None, None, None)
+
+
+def _as_padded(t, n):
+    """fp32 mode: copy an unpadded (n, C) gradient into a zero-padded buffer so _dw can use the no-tail path."""
+    p = _padded(n, t.shape[1], t.dtype, t.device)
+    p[:n].copy_(t[:n])
+    return p
+
+
+def encoder_layer(layer, x, wplan, pos_table):
+    """``layer``: pcdet EncoderLayer module (parameter container); returns LN(x1 + FFN(x1)), x1 = LN(x + attn(x))."""
+    sa = layer.win_attn.self_attn
+    return EncoderLayerFn.apply(x, sa.in_proj_weight, sa.in_proj_bias, sa.tau, sa.out_proj.weight, sa.out_proj.bias,
+                                layer.linear1.weight, layer.linear1.bias, layer.linear2.weight, layer.linear2.bias,
+                                layer.norm1.weight, layer.norm1.bias, layer.norm2.weight, layer.norm2.bias,
+                                wplan, pos_table, sa.num_heads, sa.tau_min, layer.norm1.eps, layer.activation_name)

@@ -52,8 +52,10 @@ SIGNATURES = {
     "gdmae_window_attention_fwd": (_I, [_P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P, _F, _P]),
     "gdmae_window_attention_bwd": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P, _F, _P]),
     "gdmae_add_layernorm_workspace_bytes": (_Z, [_I]),
-    "gdmae_add_layernorm_fwd": (_I, [_P, _P, _I, _P, _P, _L, _I, _F, _P, _P, _P]),
-    "gdmae_add_layernorm_bwd": (_I, [_P, _P, _I, _P, _P, _P, _L, _I, _P, _P, _P, _P]),
+    "gdmae_add_layernorm_fwd": (_I, [_P, _P, _I, _P, _P, _L, _I, _F, _P, _P, _P, _P]),
+    "gdmae_add_layernorm_bwd": (_I, [_P, _P, _I, _P, _P, _P, _P, _I, _L, _I, _P, _P, _P, _P, _P]),
+    "gdmae_prep_tokens": (_I, [_P, _P, _P, _L, _I, _P, _P, _I, _P]),
+    "gdmae_add3": (_I, [_P, _P, _I, _P, _I, _L, _P, _P]),
     "gdmae_set_attention_impl": (_I, [_I]),
     "gdmae_sum_partials": (_I, [_P, _L, _F, _P, _I, _P]),
     "gdmae_sum_partials_gated": (_I, [_P, _L, _F, _P, _P, _F, _P]),

@@ -240,7 +240,7 @@ class AddLayerNorm(torch.autograd.Function):
         y = torch.empty_like(a)
         stats = torch.empty(n, 2, dtype=torch.float32, device=a.device)
         L.call("gdmae_add_layernorm_fwd", L.ptr(a), L.ptr(b), int(b.dtype == torch.bfloat16), L.ptr(gamma.detach().contiguous()),
-               L.ptr(beta.detach().contiguous()), n, d, float(eps), L.ptr(y), L.ptr(stats), L.stream())
+               L.ptr(beta.detach().contiguous()), n, d, float(eps), L.ptr(y), L.ptr(stats), None, L.stream())
         ctx.save_for_backward(a, b, gamma, stats)
         return y
 
@@ -249,11 +249,11 @@ class AddLayerNorm(torch.autograd.Function):
         a, b, gamma, stats = ctx.saved_tensors
         n, d = a.shape
         dx = torch.empty_like(a)
-        dgb = torch.empty(2 * d, dtype=torch.float32, device=a.device)
+        dgb = torch.empty(3 * d, dtype=torch.float32, device=a.device)
         ws = torch.empty(L.load().gdmae_add_layernorm_workspace_bytes(d), dtype=torch.uint8, device=a.device)
         L.call("gdmae_add_layernorm_bwd", L.ptr(a), L.ptr(b), int(b.dtype == torch.bfloat16), L.ptr(gamma.detach().contiguous()),
-               L.ptr(stats), L.ptr(_f32c(g)), n, d, L.ptr(dx), L.ptr(dgb), L.ptr(ws), L.stream())
-        return dx.to(ctx.a_dtype), dx.to(b.dtype), dgb[:d], dgb[d:], None
+               L.ptr(stats), L.ptr(_f32c(g)), None, 0, n, d, L.ptr(dx), None, L.ptr(dgb), L.ptr(ws), L.stream())
+        return dx.to(ctx.a_dtype), dx.to(b.dtype), dgb[:d], dgb[d:2 * d], None
 
 
 def add_layer_norm(a, b, norm: torch.nn.LayerNorm):

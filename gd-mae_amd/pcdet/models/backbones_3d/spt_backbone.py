@@ -79,10 +79,9 @@ class SSTBlockV1(nn.Module):
         feat = sp_tensor.features
         wplans = sp_tensor.stage_plan.windows
         table = self.sst_input_layer.pos_table(feat.shape[1], feat.device)
-        pos = [torch.index_select(table, 0, w.tok_pos) for w in wplans]
         out = feat
         for block in self.encoder_blocks:
-            out = block(out, pos, wplans)
+            out = block(out, table, wplans)
         sp_tensor = replace_feature(sp_tensor, feat + out)      # token drop is the identity (no un-shuffle)
         return self.conv_out(sp_tensor)
 

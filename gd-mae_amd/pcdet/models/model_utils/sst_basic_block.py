@@ -6,7 +6,9 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .cosine_msa import CosineMultiheadAttention
-from gdmae_hip import ops
+import torch
+
+from gdmae_hip import encoder as genc, ops
 
 
 class WindowAttention(nn.Module):
@@ -24,6 +26,10 @@ class WindowAttention(nn.Module):
 
 
 class EncoderLayer(nn.Module):
+    # True: hand-written forward/backward of the whole layer (gdmae_hip/encoder.py, ~55 launches);
+    # False: the same arithmetic op by op through autograd (~140 launches) - kept as the A/B reference.
+    fused = True
+
     def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1, activation="relu", batch_first=False,
                  mlp_dropout=0, layer_cfg=None):
         super().__init__()
@@ -37,8 +43,12 @@ class EncoderLayer(nn.Module):
         if activation not in ("gelu", "relu"):
             raise RuntimeError(f"activation should be relu/gelu, not {activation}.")
         self.activation = F.gelu if activation == "gelu" else F.relu
+        self.activation_name = activation
 
-    def forward(self, src, pos, wplan):
+    def forward(self, src, pos_table, wplan):
+        if self.fused and self.activation_name == "gelu":
+            return genc.encoder_layer(self, src, wplan, pos_table)
+        pos = torch.index_select(pos_table, 0, wplan.tok_pos)
         src = ops.add_layer_norm(src, self.win_attn(src, pos, wplan), self.norm1)
         h = self.activation(ops.linear(src, self.linear1.weight, self.linear1.bias))
         return ops.add_layer_norm(src, ops.linear(h, self.linear2.weight, self.linear2.bias), self.norm2)
@@ -52,8 +62,7 @@ class BasicShiftBlockV2(nn.Module):
             EncoderLayer(d_model, nhead, dim_feedforward, dropout, activation, batch_first, layer_cfg=layer_cfg)
             for _ in range(2)])
 
-    def forward(self, src, pos_list, wplan_list):
+    def forward(self, src, pos_table, wplan_list):
         for i, layer in enumerate(self.encoder_list):
-            k = i % len(wplan_list)
-            src = layer(src, pos_list[k], wplan_list[k])
+            src = layer(src, pos_table, wplan_list[i % len(wplan_list)])
         return src

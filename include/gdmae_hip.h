@@ -190,10 +190,19 @@ int gdmae_sum_partials_gated(const float* part, long long n, float scale, float*
  * Backward: dx (n,d) = gradient w.r.t. (a + b) (goes to both), dgamma_dbeta (2d) = {dgamma, dbeta}. */
 size_t gdmae_add_layernorm_workspace_bytes(int d);
 int gdmae_add_layernorm_fwd(const float* a, const void* b, int b_is_bf16, const float* gamma, const float* beta,
-                            long long n, int d, float eps, float* y, float* stats, void* stream);
-int gdmae_add_layernorm_bwd(const float* a, const void* b, int b_is_bf16, const float* gamma, const float* stats,
-                            const float* dy, long long n, int d, float* dx, float* dgamma_dbeta, void* workspace,
+                            long long n, int d, float eps, float* y, float* stats, void* y_bf16 /* optional copy */,
                             void* stream);
+/* dy2 (optional, fp32/bf16): second upstream gradient summed on load; dx_bf16 (optional): bf16 copy of dx;
+ * sums (3d) = {dgamma, dbeta, column sums of dx (= bias gradient of the GEMM that produced b)}. */
+int gdmae_add_layernorm_bwd(const float* a, const void* b, int b_is_bf16, const float* gamma, const float* stats,
+                            const float* dy, const void* dy2, int dy2_bf16, long long n, int d, float* dx, void* dx_bf16,
+                            float* sums, void* workspace, void* stream);
+/* gdmae_prep_tokens: x_out = x, xpos_out = x + pos_table[tok_pos] in the GEMM input dtype (out_bf16; with fp32 only
+ * xpos_out is written) - the q/k input of WindowAttention.forward (sst_basic_block.py:44-49).
+ * gdmae_add3: out(fp32) = a(fp32) + b + c, b/c optional fp32 or bf16 (gradient accumulation of the residual stream). */
+int gdmae_prep_tokens(const float* x, const float* pos_table, const int* tok_pos, long long n, int d, void* x_out,
+                      void* xpos_out, int out_bf16, void* stream);
+int gdmae_add3(const float* a, const void* b, int b_bf16, const void* c, int c_bf16, long long total, float* out, void* stream);
 
 /* ---- a17-a19: reconstruction targets and Chamfer loss ----------------------------------------- *
  * gdmae_group_gt_points replaces sst_ops_cuda.group_inner_inds_wrapper (sst_ops_api.cpp:8;

@@ -496,3 +496,45 @@ def test_fused_vfe_bn_relu_and_segment_max_match_torch(dt):
     assert (out.cpu() - ref.detach()).abs().max() <= tol * ref.abs().max()
     assert (xg.grad.float().cpu() - xr.grad).norm() <= tol * xr.grad.norm()
     assert (gg.grad.cpu() - gr.grad).norm() <= tol * gr.grad.norm() and (bg.grad.cpu() - br.grad).norm() <= tol * br.grad.norm()
+
+
+@pytest.mark.parametrize("autocast", [False, True])
+def test_fused_encoder_layer_equals_autograd_layer(autocast):
+    """gdmae_hip.encoder.EncoderLayerFn (hand-written backward) vs the same layer op by op through autograd."""
+    from gdmae_hip import plan
+    from pcdet.models.backbones_3d.spt_backbone import SSTInputLayer
+    from pcdet.models.model_utils.sst_basic_block import EncoderLayer
+    z, ds, cfg, _ = load_case("waymo_b1")
+    B = int(z["batch_size"])
+    vox = plan.voxelize(torch.from_numpy(z["points"]).to(dev()), ds.point_cloud_range, ds.voxel_size, ds.grid_size, B)
+    ep = plan.encoder_plan(vox, *_stage_args(cfg), keep_frac=0.8, noise=torch.from_numpy(z["noise"]).to(dev()))
+    st = ep.stages[1]
+    bcfg = cfg.BACKBONE_3D.SST_BLOCK_LIST[1]
+    d = 256
+    table = SSTInputLayer(bcfg.PREPROCESS).pos_table(d, dev())
+    torch.manual_seed(3)
+    layer = EncoderLayer(d, 8, 512, 0.0, "gelu", layer_cfg={"cosine": True, "tau_min": 0.01}).to(dev())
+    with torch.no_grad():
+        layer.win_attn.self_attn.tau.fill_(0.6)
+        layer.win_attn.self_attn.in_proj_bias.normal_(0, 0.1)
+        layer.norm1.weight.uniform_(0.5, 1.5)
+        layer.norm2.bias.normal_(0, 0.1)
+    x = torch.randn(st.n_tok, d, device=dev())
+    go = torch.randn(st.n_tok, d, device=dev())
+    res = {}
+    for fused in (False, True):
+        layer.fused = fused
+        layer.zero_grad()
+        xi = x.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+            y = layer(xi, table, st.windows[1])
+        (y.float() * go).sum().backward()
+        res[fused] = (y.detach().float(), xi.grad.clone(), {k: p.grad.clone() for k, p in layer.named_parameters()})
+    y0, dx0, g0 = res[False]
+    y1, dx1, g1 = res[True]
+    tol = 3e-2 if autocast else 2e-4
+    assert (y1 - y0).abs().max() <= tol * y0.abs().max()
+    assert (dx1 - dx0).norm() <= tol * dx0.norm()
+    for k in g0:
+        t = 0.15 if k.endswith("tau") else tol
+        assert (g1[k] - g0[k]).norm() <= t * g0[k].norm() + 1e-6, (k, float((g1[k] - g0[k]).norm() / g0[k].norm()))
