@@ -132,32 +132,26 @@ __global__ __launch_bounds__(256) void k_add_ln_bwd(const float* __restrict__ a,
   }
 }
 
-// out[c] = sum_b part[b, c] (fixed order), c in [0, C2); one workgroup per 16 columns, 16 partial slices per column
+// out[c] = sum_b part[b, c] (fixed order), c in [0, C2); one workgroup per 4 columns, 64 partial slices per column
 __global__ __launch_bounds__(256) void k_reduce_partials_f32(const float* __restrict__ part, int nblk, int C2,
                                                              float* __restrict__ out) {
-  __shared__ float sh[16][17];
-  const int cl = threadIdx.x & 15, ps = threadIdx.x >> 4;
-  const int c = blockIdx.x * 16 + cl;
+  const int cl = threadIdx.x >> 6, ps = threadIdx.x & 63;   // one wavefront per column
+  const int c = blockIdx.x * 4 + cl;
   float acc = 0.f;
   if (c < C2)
-    for (int b = ps; b < nblk; b += 16) acc += part[(long long)b * C2 + c];
-  sh[ps][cl] = acc;
-  __syncthreads();
-  if (ps == 0 && c < C2) {
-    float s = 0.f;
-    for (int k = 0; k < 16; ++k) s += sh[k][cl];
-    out[c] = s;
-  }
+    for (int b = ps; b < nblk; b += 64) acc += part[(long long)b * C2 + c];
+  acc = gd_wave_sum(acc);
+  if (ps == 0 && c < C2) out[c] = acc;
 }
 
 static inline int ln_grid(long long n) {
   long long g = (n + 3) / 4;
-  if (g > 256) g = 256;     // few partial blocks: the dgamma/dbeta reduction stays a handful of iterations
+  if (g > 1024) g = 1024;
   if (g < 1) g = 1;
   return (int)g;
 }
 
-extern "C" size_t gdmae_add_layernorm_workspace_bytes(int d) { return (size_t)256 * 3 * d * sizeof(float); }
+extern "C" size_t gdmae_add_layernorm_workspace_bytes(int d) { return (size_t)1024 * 3 * d * sizeof(float); }
 
 // y = LayerNorm(a + b) * gamma + beta over rows of d in {64, 128, 256}; b_is_bf16: dtype of b.  stats (n,2) out.
 // y_bf16 (optional, may be NULL): bf16 copy of y for the next GEMM
@@ -194,7 +188,7 @@ extern "C" int gdmae_add_layernorm_bwd(const float* a, const void* b, int b_is_b
   else GD_REQUIRE(false, "add_layernorm supports d in {64, 128, 256}");
 #undef GD_LN_BWD
   GD_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_reduce_partials_f32, dim3(gd_div_up(3 * d, 16)), dim3(256), 0, st, part, nblk, 3 * d, sums);
+  hipLaunchKernelGGL(k_reduce_partials_f32, dim3(gd_div_up(3 * d, 4)), dim3(256), 0, st, part, nblk, 3 * d, sums);
   GD_LAUNCH_CHECK();
   return 0;
 }

@@ -124,9 +124,17 @@ def attn_backward_into(qk, v, g, dqk, dv, tau_flat, wplan, nhead, tau_min):
     return dtau
 
 
+def _direct(p):
+    """Flat-gradient view of a parameter owned by gdmae_hip.optim.FlatAdamOneCycle (zeroed at the start of the step,
+    written exactly once per step by this layer) or None -> return the gradient through autograd as usual."""
+    g = getattr(p, "_gd_flat_grad", None)
+    return g if (g is not None and p.grad is g) else None
+
+
 class EncoderLayerFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, Win, bin_, tau, Wo, bo, W1, b1, W2, b2, g1, be1, g2, be2, wplan, pos_table, nhead, tau_min, eps, act):
+        ctx.direct = [_direct(p) for p in (Win, bin_, tau, Wo, bo, W1, b1, W2, b2, g1, be1, g2, be2)]
         assert act == "gelu", "hot path uses ACTIVATION gelu (gd_mae_ssl.yaml:66)"
         x = x.float().contiguous()
         n, d = x.shape
@@ -191,8 +199,13 @@ class EncoderLayerFn(torch.autograd.Function):
         dx_v = dv[:n] @ Win_s[2 * d:]
         dx = torch.empty_like(x)
         L.call("gdmae_add3", L.ptr(dx_res), L.ptr(dx_qk), _bf(dx_qk), L.ptr(dx_v), _bf(dx_v), n * d, L.ptr(dx), L.stream())
-        return (dx, dWin, dbin, dtau.view(tau_shape).to(tau_dtype), dWo, s1[2 * d:], dW1, db1, dW2, s2[2 * d:],
-                s1[:d], s1[d:2 * d], s2[:d], s2[d:2 * d], None, None, None, None, None, None)
+        grads = [dWin, dbin, dtau.view(tau_shape).to(tau_dtype), dWo, s1[2 * d:], dW1, db1, dW2, s2[2 * d:],
+                 s1[:d], s1[d:2 * d], s2[:d], s2[d:2 * d]]
+        if all(t is not None for t in ctx.direct):
+            # parameters live in a flat optimizer buffer: one fused copy per layer instead of 13 AccumulateGrad adds
+            torch._foreach_add_(list(ctx.direct), [g_.view_as(t) for g_, t in zip(grads, ctx.direct)])
+            grads = [None] * 13
+        return (dx, *grads, None, None, None, None, None, None)
 
 
 def _as_padded(t, n):

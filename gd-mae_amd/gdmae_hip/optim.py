@@ -55,6 +55,7 @@ class FlatAdamOneCycle:
             self.flat_param[off:off + k].copy_(p.data.reshape(-1))
             p.data = self.flat_param[off:off + k].view_as(p.data)
             p.grad = self.flat_grad[off:off + k].view_as(p.data)     # autograd accumulates in place
+            p._gd_flat_grad = p.grad                                  # hand-written backwards write here directly
             off += k
         self.params = params
         self.flat_param_bf16 = torch.empty(n, dtype=torch.bfloat16, device=dev)

@@ -88,13 +88,25 @@ class SparseConv2d(SparseConvolution):
 
 
 class SparseSequential(SparseModule):
+    fused_bn_relu = True     # conv -> BatchNorm1d(train) -> ReLU as one statistics pass + one fused row pass
+
     def __init__(self, *mods):
         super().__init__()
         for i, m in enumerate(mods):
             self.add_module(str(i), m)
 
     def forward(self, x):
-        for m in self._modules.values():
+        mods = list(self._modules.values())
+        if (self.fused_bn_relu and self.training and len(mods) == 3 and isinstance(mods[1], nn.BatchNorm1d)
+                and isinstance(mods[2], nn.ReLU) and mods[1].affine):
+            from gdmae_hip import vfe as gvfe
+            from gdmae_hip.decoder import _update_running
+            x = mods[0](x)
+            bn = mods[1]
+            f, mean, var = gvfe.BNReLURows.apply(x.features, bn.weight, bn.bias, bn.eps)
+            _update_running(bn, mean, var, x.features.shape[0])
+            return x.replace_feature(f)
+        for m in mods:
             x = m(x) if isinstance(m, SparseModule) else x.replace_feature(m(x.features))
         return x
 
