@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--pool", type=int, default=3, help="distinct pre-generated batches cycled through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--prefetch", type=int, default=1, help="1: build the geometry plan of batch t+1 on a side stream")
     ap.add_argument("--miopen-find", type=int, default=1, help="1: torch.backends.cudnn.benchmark (MIOpen find mode)")
     return ap.parse_args()
 
@@ -174,9 +175,16 @@ def main():
     torch.cuda.synchronize()
     use_bf16 = args.dtype == "bf16"
 
-    def step(i, pts):
+    pending = {}
+
+    def step(i, pts, nxt=None):
         opt.zero_grad()
         bd = {"points": pts, "batch_size": B}
+        if args.prefetch:
+            pf = pending.pop(id(pts), None) or net.backbone_3d.prefetch_plan(pts, B)
+            bd["_gdmae_vox"], bd["_gdmae_plan"] = pf.finish()
+            if nxt is not None:                      # plan of the NEXT batch overlaps this step's GPU work
+                pending[id(nxt)] = net.backbone_3d.prefetch_plan(nxt, B)
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=use_bf16):
             ret, tb, _ = net(bd)
         ret["loss"].backward()
@@ -191,11 +199,11 @@ def main():
         torch.cuda.synchronize()
 
     for i in range(args.warmup):
-        loss, bd = step(i, dev_batches[i % args.pool])
+        loss, bd = step(i, dev_batches[i % args.pool], dev_batches[(i + 1) % args.pool] if i + 1 < args.warmup else None)
     sync_all()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        loss, bd = step(args.warmup + i, dev_batches[i % args.pool])
+        loss, bd = step(args.warmup + i, dev_batches[i % args.pool], dev_batches[(i + 1) % args.pool] if i + 1 < args.steps else None)
     sync_all()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)

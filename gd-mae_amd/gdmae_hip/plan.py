@@ -47,8 +47,8 @@ class VoxelPlan:
     counts: torch.Tensor          # device int32[2]
 
 
-def voxelize(points: torch.Tensor, point_cloud_range, voxel_size, grid_size, batch_size: int) -> VoxelPlan:
-    """points (N0, 1+F) fp32 on the GPU -> VoxelPlan (one host sync for N, M)."""
+def _voxelize_launch(points: torch.Tensor, point_cloud_range, voxel_size, grid_size, batch_size: int) -> dict:
+    """Enqueue gdmae_voxelize on the current stream with capacity-sized outputs; no host sync."""
     assert points.is_cuda and points.dtype == torch.float32 and points.dim() == 2
     points = points.contiguous()
     dev = points.device
@@ -59,30 +59,36 @@ def voxelize(points: torch.Tensor, point_cloud_range, voxel_size, grid_size, bat
     vs = tuple(float(v) for v in voxel_size)
     F = ncols - 1
     cap = max(n0, 1)
-    pts_out = _empty(cap * ncols, torch.float32, dev)
-    pcoords = _empty(cap * 4, torch.int64, dev)
-    inverse = _empty(cap, torch.int64, dev)
-    inverse32 = _empty(cap, I32, dev)
-    vcoords = _empty(cap * 4, torch.int64, dev)
-    pillar_cell = _empty(cap, I32, dev)
-    pt_off = _empty(cap + 1, I32, dev)
-    pillar_pts = _empty(cap, I32, dev)
-    prank = _empty(cap, I32, dev)
-    sample_off = _empty(batch_size + 1, I32, dev)
-    mean = _empty(cap * F, torch.float32, dev)
-    cell2pillar = _empty(cells, I32, dev)
-    counts = _empty(2, I32, dev)
+    r = dict(batch_size=batch_size, grid=(gx, gy, gz), lo=lo, vs=vs, ncols=ncols, n0=n0, src=points,
+             pts_out=_empty(cap * ncols, torch.float32, dev), pcoords=_empty(cap * 4, torch.int64, dev),
+             inverse=_empty(cap, torch.int64, dev), inverse32=_empty(cap, I32, dev), vcoords=_empty(cap * 4, torch.int64, dev),
+             pillar_cell=_empty(cap, I32, dev), pt_off=_empty(cap + 1, I32, dev), pillar_pts=_empty(cap, I32, dev),
+             prank=_empty(cap, I32, dev), sample_off=_empty(batch_size + 1, I32, dev), mean=_empty(cap * F, torch.float32, dev),
+             cell2pillar=_empty(cells, I32, dev), counts=_empty(2, I32, dev))
     wsb = L.load().gdmae_voxelize_workspace_bytes(n0, batch_size, gx, gy, gz)
-    ws = _empty(wsb, torch.uint8, dev)
+    r["ws"] = _empty(wsb, torch.uint8, dev)
     L.call("gdmae_voxelize", L.ptr(points), n0, ncols, L.host_f32(lo), L.host_f32(vs), L.host_i32((gx, gy, gz)),
-           batch_size, L.ptr(pts_out), L.ptr(pcoords), L.ptr(inverse), L.ptr(inverse32), L.ptr(vcoords),
-           L.ptr(pillar_cell), L.ptr(pt_off), L.ptr(pillar_pts), L.ptr(prank), L.ptr(sample_off), L.ptr(mean),
-           L.ptr(cell2pillar), L.ptr(counts), L.ptr(ws), wsb, L.stream())
-    N, M = (int(v) for v in counts.tolist())      # the one host sync of this phase
-    return VoxelPlan(batch_size, (gx, gy, gz), lo, vs, ncols, N, M,
-                     pts_out[:N * ncols].view(N, ncols), pcoords[:N * 4].view(N, 4), inverse[:N], inverse32[:N],
-                     vcoords[:M * 4].view(M, 4), pillar_cell[:M], pt_off[:M + 1], pillar_pts[:N], prank[:N],
-                     sample_off, mean[:M * F].view(M, F), cell2pillar, counts)
+           batch_size, L.ptr(r["pts_out"]), L.ptr(r["pcoords"]), L.ptr(r["inverse"]), L.ptr(r["inverse32"]), L.ptr(r["vcoords"]),
+           L.ptr(r["pillar_cell"]), L.ptr(r["pt_off"]), L.ptr(r["pillar_pts"]), L.ptr(r["prank"]), L.ptr(r["sample_off"]),
+           L.ptr(r["mean"]), L.ptr(r["cell2pillar"]), L.ptr(r["counts"]), L.ptr(r["ws"]), wsb, L.stream())
+    return r
+
+
+def _voxelize_finalize(r: dict, N: int, M: int) -> VoxelPlan:
+    ncols = r["ncols"]
+    F = ncols - 1
+    return VoxelPlan(r["batch_size"], r["grid"], r["lo"], r["vs"], ncols, N, M,
+                     r["pts_out"][:N * ncols].view(N, ncols), r["pcoords"][:N * 4].view(N, 4), r["inverse"][:N],
+                     r["inverse32"][:N], r["vcoords"][:M * 4].view(M, 4), r["pillar_cell"][:M], r["pt_off"][:M + 1],
+                     r["pillar_pts"][:N], r["prank"][:N], r["sample_off"], r["mean"][:M * F].view(M, F), r["cell2pillar"],
+                     r["counts"])
+
+
+def voxelize(points: torch.Tensor, point_cloud_range, voxel_size, grid_size, batch_size: int) -> VoxelPlan:
+    """points (N0, 1+F) fp32 on the GPU -> VoxelPlan (one host sync for N, M)."""
+    r = _voxelize_launch(points, point_cloud_range, voxel_size, grid_size, batch_size)
+    N, M = (int(v) for v in r["counts"].tolist())      # the one host sync of this phase
+    return _voxelize_finalize(r, N, M)
 
 
 @dataclass
@@ -137,34 +143,33 @@ def _drop_arrays(drop_info):
     return lo, hi, T
 
 
-def encoder_plan(vox: VoxelPlan, strides, window_shapes, drop_infos, keep_frac: Optional[float] = None,
-                 noise: Optional[torch.Tensor] = None) -> EncoderPlan:
-    """Masking + token sets + rulebooks + window partitions for all stages; ONE host sync at the end.
-
-    strides: per stage conv_down stride (1 or 2); window_shapes: per stage [wx, wy, wz];
-    drop_infos: per stage DROP_INFO['train'] dict; keep_frac = 1 - MASK RATIO (python double) or None
-    for no masking (fine-tune backbone); noise: (M,) fp32 masking noise (drawn if None).
-    """
-    dev = vox.points.device
-    gx, gy, gz = vox.grid
+def _encoder_launch(vox, m_cap: int, strides, window_shapes, drop_infos, keep_frac, noise) -> dict:
+    """Enqueue masking + token sets + rulebooks + window partitions on the current stream; no host sync.
+    ``vox``: VoxelPlan or the raw dict of _voxelize_launch; m_cap >= number of pillars (capacity)."""
+    if isinstance(vox, dict):
+        dev, grid, B = vox["src"].device, vox["grid"], vox["batch_size"]
+        sample_off, pillar_cell, vcounts = vox["sample_off"], vox["pillar_cell"], vox["counts"]
+    else:
+        dev, grid, B = vox.points.device, vox.grid, vox.batch_size
+        sample_off, pillar_cell, vcounts = vox.sample_off, vox.pillar_cell, vox.counts
+    gx, gy, gz = grid
     assert gz == 1, "the SST backbone works on single-layer pillar grids (spt_backbone_mae.py:94)"
-    B, M = vox.batch_size, vox.M
     lib = L.load()
     st = L.stream()
+    M = m_cap
     scan_ws = _empty(8 * (max(B * gx * gy, M) // 4096 + 4), torch.int64, dev)
-    pending = []   # (device counts tensor) read back together at the end
 
     # ---- a5 masking
     if keep_frac is not None:
         if noise is None:
-            noise = torch.rand(max(M, 1), device=dev, dtype=torch.float32)[:M]
-        assert noise.shape == (M,) and noise.dtype == torch.float32
-        mask = _empty(max(M, 1), torch.float32, dev)[:M]
+            noise = torch.rand(max(M, 1), device=dev, dtype=torch.float32)
+        assert noise.numel() >= 1 and noise.dtype == torch.float32
+        mask = _empty(max(M, 1), torch.float32, dev)
         len_keep = _empty(B, I32, dev)
-        L.call("gdmae_random_mask", L.ptr(noise.contiguous()), L.ptr(vox.sample_off), B, float(keep_frac), L.ptr(mask),
+        L.call("gdmae_random_mask", L.ptr(noise.contiguous()), L.ptr(sample_off), B, float(keep_frac), L.ptr(mask),
                L.ptr(len_keep), st)
     else:
-        mask = torch.zeros(max(M, 1), dtype=torch.float32, device=dev)[:M]
+        mask = torch.zeros(max(M, 1), dtype=torch.float32, device=dev)
 
     # ---- stage-1 tokens = visible pillars
     cap = max(M, 1)
@@ -173,11 +178,10 @@ def encoder_plan(vox: VoxelPlan, strides, window_shapes, drop_infos, keep_frac: 
     tok_cell = _empty(cap, I32, dev)
     smap = _empty(B * Y * X, I32, dev)
     n_tok = _empty(1, I32, dev)
-    L.call("gdmae_visible_tokens", L.ptr(mask), L.ptr(vox.pillar_cell), L.ptr(vox.counts), M, B * Y * X,
+    L.call("gdmae_visible_tokens", L.ptr(mask), L.ptr(pillar_cell), L.ptr(vcounts), M, B * Y * X,
            L.ptr(tok_pillar), L.ptr(tok_cell), L.ptr(smap), L.ptr(n_tok), L.ptr(scan_ws), st)
 
     raw = []   # per stage dict of capacity-sized tensors
-    prev = None
     for si, stride in enumerate(strides):
         if stride > 1:
             assert stride == 2, "only the k3 s2 p1 strided sparse conv of the shipped configs is implemented"
@@ -222,11 +226,14 @@ def encoder_plan(vox: VoxelPlan, strides, window_shapes, drop_infos, keep_frac: 
             w["_ws"] = ws
             wins.append(w)
         raw.append(dict(B=B, Y=Y, X=X, cap=cap, tok_cell=tok_cell, map=smap, n_tok=n_tok, nbr_subm=nbr_subm,
-                        nbr_down=nbr_down, nbr_down_t=nbr_down_t, wins=wins, prev=prev))
-        prev = raw[-1]
+                        nbr_down=nbr_down, nbr_down_t=nbr_down_t, wins=wins))
+    counts = torch.cat([r["n_tok"] for r in raw] + [w["counts"] for r in raw for w in r["wins"]])
+    return dict(stages=raw, mask=mask, tok_pillar=tok_pillar, masked=keep_frac is not None, counts=counts,
+                keep=(noise, scan_ws))
 
-    # ---- the one host sync of this phase: all counts in one copy
-    allc = torch.cat([r["n_tok"] for r in raw] + [w["counts"] for r in raw for w in r["wins"]]).tolist()
+
+def _encoder_finalize(e: dict, allc, M: int) -> EncoderPlan:
+    raw = e["stages"]
     ns = len(raw)
     stages = []
     for si, r in enumerate(raw):
@@ -245,4 +252,73 @@ def encoder_plan(vox: VoxelPlan, strides, window_shapes, drop_infos, keep_frac: 
                                 None if r["nbr_down"] is None else r["nbr_down"][:n * 9].view(n, 9),
                                 None if r["nbr_down_t"] is None else r["nbr_down_t"][:n_prev * 9].view(n_prev, 9),
                                 wps))
-    return EncoderPlan(mask if keep_frac is not None else None, tok_pillar[:stages[0].n_tok], stages)
+    return EncoderPlan(e["mask"][:M] if e["masked"] else None, e["tok_pillar"][:stages[0].n_tok], stages)
+
+
+def encoder_plan(vox: VoxelPlan, strides, window_shapes, drop_infos, keep_frac: Optional[float] = None,
+                 noise: Optional[torch.Tensor] = None) -> EncoderPlan:
+    """Masking + token sets + rulebooks + window partitions for all stages; ONE host sync at the end.
+
+    strides: per stage conv_down stride (1 or 2); window_shapes: per stage [wx, wy, wz];
+    drop_infos: per stage DROP_INFO['train'] dict; keep_frac = 1 - MASK RATIO (python double) or None
+    for no masking (fine-tune backbone); noise: (M,) fp32 masking noise (drawn if None).
+    """
+    if noise is not None:
+        assert noise.shape == (vox.M,)
+    e = _encoder_launch(vox, vox.M, strides, window_shapes, drop_infos, keep_frac, noise)
+    return _encoder_finalize(e, e["counts"].tolist(), vox.M)   # the one host sync of this phase
+
+
+class PlanPrefetch:
+    """Geometry plan of a batch built ahead of time on a side stream (the analogue of a data-loader prefetch: the
+    plan depends only on the input points, never on the weights).  All kernels of gdmae_voxelize and the encoder
+    plan are enqueued back-to-back with capacity-sized buffers, the few int32 counts are copied to pinned host
+    memory asynchronously, and ``finish()`` only waits for THAT stream - so the training step of batch t+1 never
+    stalls the host behind the backward of batch t, and the host can run a full step ahead of the GPU."""
+
+    _side = {}
+
+    def __init__(self, points, point_cloud_range, voxel_size, grid_size, batch_size, strides, window_shapes, drop_infos,
+                 keep_frac=None, noise=None):
+        dev = points.device
+        main = torch.cuda.current_stream(dev)
+        side = PlanPrefetch._side.setdefault(dev.index, torch.cuda.Stream(device=dev))
+        side.wait_stream(main)                      # `points` (and `noise`) were produced on the main stream
+        with torch.cuda.stream(side):
+            self.vraw = _voxelize_launch(points, point_cloud_range, voxel_size, grid_size, batch_size)
+            gx, gy, gz = self.vraw["grid"]
+            m_cap = max(1, min(self.vraw["n0"], batch_size * gx * gy * gz))
+            self.eraw = _encoder_launch(self.vraw, m_cap, strides, window_shapes, drop_infos, keep_frac, noise)
+            allc = torch.cat([self.vraw["counts"], self.eraw["counts"]])
+            self.host = torch.empty(allc.numel(), dtype=torch.int32).pin_memory()
+            self.host.copy_(allc, non_blocking=True)
+            self.event = torch.cuda.Event()
+            self.event.record(side)
+        self.side, self.keep = side, allc
+
+    def finish(self):
+        """-> (VoxelPlan, EncoderPlan); the current (main) stream is ordered after the plan stream."""
+        self.event.synchronize()
+        torch.cuda.current_stream().wait_event(self.event)
+        c = self.host.tolist()
+        N, M = int(c[0]), int(c[1])
+        vox = _voxelize_finalize(self.vraw, N, M)
+        ep = _encoder_finalize(self.eraw, c[2:], M)
+        main = torch.cuda.current_stream()
+        for t in _tensors_of(self.vraw) + _tensors_of(self.eraw):
+            t.record_stream(main)                   # allocated on the side stream, consumed on the main stream
+        return vox, ep
+
+
+def _tensors_of(obj):
+    out = []
+    if isinstance(obj, torch.Tensor):
+        if obj.is_cuda:
+            out.append(obj)
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            out += _tensors_of(v)
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            out += _tensors_of(v)
+    return out

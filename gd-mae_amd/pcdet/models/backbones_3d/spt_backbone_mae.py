@@ -44,8 +44,10 @@ class SPTBackboneMAE(nn.Module):
         masking noise (one value per pillar, samples concatenated) for bit-exact mask parity tests."""
         vox = batch_dict['_gdmae_vox']
         all_feat, all_coords = batch_dict['voxel_features'], batch_dict['voxel_coords']
-        ep = gplan.encoder_plan(vox, *stage_plan_args(self.model_cfg.SST_BLOCK_LIST),
-                                keep_frac=1 - self.mask_ratio, noise=batch_dict.get('mae_noise', None))
+        ep = batch_dict.get('_gdmae_plan', None)          # prefetched geometry plan (gdmae_hip.plan.PlanPrefetch)
+        if ep is None:
+            ep = gplan.encoder_plan(vox, *stage_plan_args(self.model_cfg.SST_BLOCK_LIST),
+                                    keep_frac=1 - self.mask_ratio, noise=batch_dict.get('mae_noise', None))
         batch_dict['voxel_mae_mask'] = ep.mask
         batch_dict['_gdmae_plan'] = ep
         x = SparseConvTensor(ops.GatherUnique.apply(all_feat, ep.tok_pillar), ep, 0)
@@ -75,6 +77,12 @@ class SPTBackboneMAE(nn.Module):
                            'voxel_shuffle_inds': torch.arange(all_coords.shape[0], device=all_coords.device)})
         self.forward_ret_dict = self.target_assigner(batch_dict)
         return batch_dict
+
+    def prefetch_plan(self, points, batch_size, noise=None):
+        """Start building the geometry plan of a batch on a side stream; ``.finish()`` -> (vox, plan) to be placed
+        in batch_dict['_gdmae_vox'] / ['_gdmae_plan'] before calling the detector."""
+        return gplan.PlanPrefetch(points, self.point_cloud_range, self.voxel_size, self.grid_size, int(batch_size),
+                                  *stage_plan_args(self.model_cfg.SST_BLOCK_LIST), keep_frac=1 - self.mask_ratio, noise=noise)
 
     def target_assigner(self, batch_dict):
         vox = batch_dict['_gdmae_vox']

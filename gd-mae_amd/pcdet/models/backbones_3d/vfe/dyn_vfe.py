@@ -37,8 +37,10 @@ class DynVFE(VFETemplate):
         return self.num_point_features
 
     def forward(self, batch_dict, **kwargs):
-        vox = gplan.voxelize(batch_dict['points'], self.point_cloud_range, self.voxel_size, self.grid_size,
-                             int(batch_dict['batch_size']))
+        vox = batch_dict.get('_gdmae_vox', None)          # prefetched geometry plan (gdmae_hip.plan.PlanPrefetch)
+        if vox is None:
+            vox = gplan.voxelize(batch_dict['points'], self.point_cloud_range, self.voxel_size, self.grid_size,
+                                 int(batch_dict['batch_size']))
         x = ops.decorate_points(vox)
         mlp = self.dvfe_mlps[0]
         if self.fused and self.training:

@@ -538,3 +538,57 @@ def test_fused_encoder_layer_equals_autograd_layer(autocast):
     for k in g0:
         t = 0.15 if k.endswith("tau") else tol
         assert (g1[k] - g0[k]).norm() <= t * g0[k].norm() + 1e-6, (k, float((g1[k] - g0[k]).norm() / g0[k].norm()))
+
+
+def test_prefetched_plan_is_identical_to_inline_plan():
+    """PlanPrefetch (side stream, capacity-sized buffers, async counts readback) must yield exactly the inline
+    geometry plan and therefore bit-identical loss; also while the main stream is busy."""
+    import dataclasses
+    import logging
+    from pcdet.models import build_network
+    from gdmae_hip import plan as gplan
+    z, ds, cfg, shapes = load_case("kitti_b2")
+    torch.manual_seed(0)
+    net = build_network(cfg, len(ds.class_names), ds, logging.getLogger("t")).to(dev())
+    net.load_state_dict(orc.seeded_state_dict(shapes, seed=int(z["seed"])), strict=False)
+    net.train()
+    pts = torch.from_numpy(z["points"]).to(dev())
+    noise = torch.from_numpy(z["noise"]).to(dev())
+    B = int(z["batch_size"])
+
+    def same(a, b, path):
+        if isinstance(a, torch.Tensor):
+            assert a.shape == b.shape and torch.equal(a, b), path
+        elif dataclasses.is_dataclass(a):
+            for f in dataclasses.fields(a):
+                same(getattr(a, f.name), getattr(b, f.name), f"{path}.{f.name}")
+        elif isinstance(a, (list, tuple)):
+            assert len(a) == len(b), path
+            for i, (x, y) in enumerate(zip(a, b)):
+                same(x, y, f"{path}[{i}]")
+        else:
+            assert a == b, (path, a, b)
+
+    bb = net.backbone_3d
+    vox0 = gplan.voxelize(pts, bb.point_cloud_range, bb.voxel_size, bb.grid_size, B)
+    from pcdet.models.backbones_3d.spt_backbone import stage_plan_args
+    ep0 = gplan.encoder_plan(vox0, *stage_plan_args(bb.model_cfg.SST_BLOCK_LIST), keep_frac=1 - bb.mask_ratio, noise=noise)
+    busy = torch.randn(4096, 4096, device=dev())
+    for _ in range(20):
+        busy = busy @ busy * 1e-3                     # main stream busy while the plan is built
+    noise_cap = torch.cat([noise, torch.rand(pts.shape[0] - noise.numel(), device=dev())])   # capacity-sized noise
+    pf = bb.prefetch_plan(pts, B, noise=noise_cap)
+    vox1, ep1 = pf.finish()
+    for name in ("N", "M", "points", "point_coords", "inverse", "voxel_coords", "pillar_cell", "pt_off", "sample_off", "pillar_mean"):
+        same(getattr(vox0, name), getattr(vox1, name), f"vox.{name}")
+    same(ep0.mask, ep1.mask, "mask")
+    same(ep0.tok_pillar, ep1.tok_pillar, "tok_pillar")
+    for i, (a, b) in enumerate(zip(ep0.stages, ep1.stages)):
+        for f in dataclasses.fields(a):
+            if f.name == "map":
+                assert torch.equal(a.map, b.map)
+            else:
+                same(getattr(a, f.name), getattr(b, f.name), f"stage{i}.{f.name}")
+    ret0, _, _ = net({"points": pts, "batch_size": B, "mae_noise": noise})
+    ret1, _, _ = net({"points": pts, "batch_size": B, "_gdmae_vox": vox1, "_gdmae_plan": ep1})
+    assert float(ret0["loss"]) == float(ret1["loss"])
