@@ -246,8 +246,10 @@ def main():
         if world == 1:
             t1 = time.perf_counter()
             k = max(3, args.steps // 4)
+            nxt = pinned[0].to(dev, non_blocking=True)
             for i in range(k):
-                step(args.warmup + args.steps, pinned[i % args.pool].to(dev, non_blocking=True))
+                cur, nxt = nxt, (pinned[(i + 1) % args.pool].to(dev, non_blocking=True) if i + 1 < k else None)
+                step(args.warmup + args.steps, cur, nxt)
             sync_all_local()
             out["h2d_inclusive"] = {"value": round(B * k / (time.perf_counter() - t1), 2), "unit": "frames/s"}
         if not args.no_cpu_baseline:

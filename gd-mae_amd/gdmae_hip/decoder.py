@@ -170,6 +170,29 @@ class DenseBNReLUGather(torch.autograd.Function):
         return dY, dgamma, dbeta, None, None
 
 
+class DenseConv3x3(torch.autograd.Function):
+    """conv2d(k3 s1 p1, no bias) of the channels-last map with the weight's bf16 shadow under autocast.  An explicit
+    Function because the shadow (gdmae_hip.optim) is a detached copy: the weight gradient has to be routed back to
+    the fp32 parameter by hand (MIOpen backward-data + backward-weights in one convolution_backward call)."""
+
+    @staticmethod
+    def forward(ctx, zin, weight):
+        cdt = torch.bfloat16 if torch.is_autocast_enabled() else weight.dtype
+        wc = ops.shadow(weight, cdt)
+        zc = zin.to(cdt)
+        ctx.save_for_backward(zc, wc)
+        ctx.in_dtype = zin.dtype
+        with torch.autocast("cuda", enabled=False):
+            return F.conv2d(zc, wc, None, 1, 1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        zc, wc = ctx.saved_tensors
+        dz, dw, _ = torch.ops.aten.convolution_backward(dy.to(zc.dtype), zc, wc, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                                        [ctx.needs_input_grad[0], True, False])
+        return (None if dz is None else dz.to(ctx.in_dtype)), dw.float()
+
+
 def _update_running(bn, mean, var_biased, n):
     """nn.BatchNorm running statistics (momentum 0.01, unbiased variance) for checkpoint parity."""
     if bn.running_mean is None:
@@ -219,7 +242,7 @@ def sparse_decoder(model_cfg, deblocks, conv_out, hidden, pillar_cell, B, Y, X, 
             _update_running(bn, outs[1 + 2 * i], outs[2 + 2 * i], R)
     conv, bn2 = conv_out[0], conv_out[1]
     zin = Z.view(B, Y, X, -1).permute(0, 3, 1, 2)                                # NCHW view of NHWC memory
-    y2 = F.conv2d(zin, ops.shadow(conv.weight, cdt), None, 1, 1)
+    y2 = DenseConv3x3.apply(zin, conv.weight)
     y2 = y2.permute(0, 2, 3, 1)
     if not y2.is_contiguous():
         y2 = y2.contiguous()
