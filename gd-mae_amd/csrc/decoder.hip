@@ -343,3 +343,89 @@ extern "C" int gdmae_segmax_bn_bwd(const void* x, int x_bf16, const float* out, 
   GD_LAUNCH_CHECK();
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------
+// Backward of the decoder's dense 3x3 convolution restricted to the sites that need it.
+//
+// The reference back-propagates conv_out (spt_backbone_mae.py:46-52) densely.  Here the output gradient is
+//   dY[u] = k0 + k1 * Y[u] + (u is a pillar site ? rows[pillar(u)] : 0)       (BatchNorm2d chain rule, per channel)
+// and the input gradient / weight gradient are only needed at the active sites of each source stage, so the
+// caller asks for the 9 shifted output-gradient rows of those sites ("taps"):
+//   out[t, k, :] = dY[site[t] - k],  k = (ky+1)*3 + (kx+1),  zero outside the map
+// and feeds them to two GEMMs (dZ rows = taps @ W^T-matrix, dW = taps^T @ Z-rows).  dY itself is never
+// materialised.  One thread = 8 channels of one (site, tap): 16-byte bf16 (or 2x16-byte fp32) accesses.
+// ------------------------------------------------------------------------------------------
+template <bool BF>
+__global__ __launch_bounds__(256) void k_conv_grad_taps(const void* __restrict__ Ymap, const float* __restrict__ k0,
+                                                        const float* __restrict__ k1, const float* __restrict__ rows,
+                                                        const int* __restrict__ cell2pillar, const int* __restrict__ site,
+                                                        long long n, int H, int W, int C, void* __restrict__ out) {
+  const int cv = C >> 3;
+  const long long total = n * 9 * cv;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int v = (int)(i % cv);
+    const long long tk = i / cv;
+    const int k = (int)(tk % 9);
+    const long long t = tk / 9;
+    const int s = site[t];
+    const int x = s % W;
+    const int r = s / W;
+    const int y = r % H;
+    const int uy = y - (k / 3 - 1), ux = x - (k % 3 - 1);
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = 0.f;
+    if (uy >= 0 && uy < H && ux >= 0 && ux < W) {
+      const long long u = (long long)(r - y + uy) * W + ux;
+      const int c0 = v * 8;
+      float yv[8];
+      if (BF) {
+        const uint4 q = ((const uint4*)Ymap)[(u * C + c0) >> 3];
+        const unsigned w4[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          yv[2 * j] = __uint_as_float(w4[j] << 16);
+          yv[2 * j + 1] = __uint_as_float(w4[j] & 0xFFFF0000u);
+        }
+      } else {
+        const float4 q0 = ((const float4*)Ymap)[(u * C + c0) >> 2], q1 = ((const float4*)Ymap)[((u * C + c0) >> 2) + 1];
+        yv[0] = q0.x; yv[1] = q0.y; yv[2] = q0.z; yv[3] = q0.w; yv[4] = q1.x; yv[5] = q1.y; yv[6] = q1.z; yv[7] = q1.w;
+      }
+      const float4 ka = ((const float4*)k0)[c0 >> 2], kb = ((const float4*)k0)[(c0 >> 2) + 1];
+      const float4 la = ((const float4*)k1)[c0 >> 2], lb = ((const float4*)k1)[(c0 >> 2) + 1];
+      const float kk0[8] = {ka.x, ka.y, ka.z, ka.w, kb.x, kb.y, kb.z, kb.w};
+      const float kk1[8] = {la.x, la.y, la.z, la.w, lb.x, lb.y, lb.z, lb.w};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = fmaf(kk1[j], yv[j], kk0[j]);
+      const int p = cell2pillar[u];
+      if (p >= 0) {
+        const float4 r0 = ((const float4*)rows)[((long long)p * C + c0) >> 2], r1 = ((const float4*)rows)[(((long long)p * C + c0) >> 2) + 1];
+        o[0] += r0.x; o[1] += r0.y; o[2] += r0.z; o[3] += r0.w; o[4] += r1.x; o[5] += r1.y; o[6] += r1.z; o[7] += r1.w;
+      }
+    }
+    if (BF) {
+      uint4 q;
+      q.x = dec_f2bf(o[0]) | ((unsigned)dec_f2bf(o[1]) << 16);
+      q.y = dec_f2bf(o[2]) | ((unsigned)dec_f2bf(o[3]) << 16);
+      q.z = dec_f2bf(o[4]) | ((unsigned)dec_f2bf(o[5]) << 16);
+      q.w = dec_f2bf(o[6]) | ((unsigned)dec_f2bf(o[7]) << 16);
+      ((uint4*)out)[i] = q;
+    } else {
+      ((float4*)out)[2 * i] = make_float4(o[0], o[1], o[2], o[3]);
+      ((float4*)out)[2 * i + 1] = make_float4(o[4], o[5], o[6], o[7]);
+    }
+  }
+}
+
+extern "C" int gdmae_conv3x3_grad_taps(const void* Ymap, int y_bf16, const float* k0, const float* k1, const float* rows,
+                                       const int* cell2pillar, const int* site, long long n, int H, int W, int C, void* out,
+                                       void* stream) {
+  GD_REQUIRE(C % 8 == 0, "C must be a multiple of 8");
+  if (n <= 0) return 0;
+  long long g = (n * 9 * (C / 8) + 255) / 256;
+  if (g > 65536) g = 65536;
+  if (y_bf16) hipLaunchKernelGGL(k_conv_grad_taps<true>, dim3((int)g), dim3(256), 0, (hipStream_t)stream, Ymap, k0, k1, rows, cell2pillar, site, n, H, W, C, out);
+  else hipLaunchKernelGGL(k_conv_grad_taps<false>, dim3((int)g), dim3(256), 0, (hipStream_t)stream, Ymap, k0, k1, rows, cell2pillar, site, n, H, W, C, out);
+  GD_LAUNCH_CHECK();
+  return 0;
+}

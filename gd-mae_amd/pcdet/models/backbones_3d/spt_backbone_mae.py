@@ -63,7 +63,8 @@ class SPTBackboneMAE(nn.Module):
         B, X, Y = int(batch_dict['batch_size']), int(self.grid_size[0]), int(self.grid_size[1])
         if self.decoder_impl == 'sparse':
             pyramid, sf = gdec.sparse_decoder(self.model_cfg, self.decoder_deblocks, self.decoder_conv_out, hidden,
-                                              vox.pillar_cell, B, Y, X, want_dense=self.dense_spatial_features)
+                                              vox.pillar_cell, vox.cell2pillar, B, Y, X,
+                                              want_dense=self.dense_spatial_features)
         else:
             sf = run_decoder(self.model_cfg, self.decoder_deblocks, self.decoder_conv_out, hidden)   # (B, C, Y, X)
             assert sf.shape[0] == B and sf.shape[2] == Y and sf.shape[3] == X

@@ -150,6 +150,14 @@ int gdmae_rows_bwd(const void* P, int p_bf16, const int* site, long long n, int 
                    const float* c0, const float* c1, const void* dZ, int z_bf16, int z_row_elems, int col0, void* dP,
                    int dp_bf16, void* stream);
 
+/* Backward of the decoder's dense 3x3 conv_out (spt_backbone_mae.py:46-52) restricted to the sites that need it:
+ * out[t, k, :] = dY[site[t] - k] for the 9 taps k = (ky+1)*3 + (kx+1) (zero outside the H x W map), where the
+ * output gradient dY[u] = k0 + k1 * Y[u] + (cell2pillar[u] >= 0 ? rows[cell2pillar[u]] : 0) is never materialised.
+ * Y (B*H*W, C) fp32 or bf16 (out has the same type), k0/k1 (C) fp32, rows (M, C) fp32, C % 8 == 0. */
+int gdmae_conv3x3_grad_taps(const void* Y, int y_bf16, const float* k0, const float* k1, const float* rows,
+                            const int* cell2pillar, const int* site, long long n, int H, int W, int C, void* out,
+                            void* stream);
+
 /* The three row kernels above also serve BatchNorm1d + ReLU of the DynVFE point MLP (site = NULL: identity rows,
  * Z/dZ = a plain (n, C) matrix with z_row_elems = C, col0 = 0).  Fused DynVFE tail (dyn_vfe.py:107-109):
  *   gdmae_segment_max_affine: out[p,c] = max_{i in pillar p} relu(a_c x[i,c] + b_c), arg = arg-max point id
