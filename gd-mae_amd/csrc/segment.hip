@@ -333,3 +333,109 @@ extern "C" int gdmae_colstats(const void* x, long long R, int C, int is_bf16, do
   GD_LAUNCH_CHECK();
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------
+// BatchNorm(train) bookkeeping as ONE launch each (instead of ~25 C-sized torch vector ops per BatchNorm):
+//   gdmae_bn_fold       : column statistics of x -> mean, rstd, folded affine a = gamma*rstd, b = beta - a*mean,
+//                         and the running_mean / running_var / num_batches_tracked update of nn.BatchNorm
+//   gdmae_bn_bwd_coeffs : column sums of the row-kernel backward -> dgamma, dbeta and the per-channel c0, c1 of
+//                         dx = a*dh + c0 + c1*x   (chain rule through mean and variance)
+// `count` is the number of samples the statistics are over (rows of x, or ALL dense sites when x holds only the
+// non-zero rows of an implicit dense map).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bn_fold_final(const float* __restrict__ part, int nblk, int C, double count,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       double eps, double momentum, float* __restrict__ running_mean,
+                                                       float* __restrict__ running_var, long long* __restrict__ num_batches,
+                                                       double* __restrict__ stats, float* __restrict__ ab,
+                                                       float* __restrict__ mv) {
+  __shared__ double sh[2][16][17];
+  const int cl = threadIdx.x & 15, ps = threadIdx.x >> 4;   // 16 columns x 16 partial slices per workgroup
+  const int c = blockIdx.x * 16 + cl;
+  double a1 = 0.0, a2 = 0.0;
+  if (c < C)
+    for (int b = ps; b < nblk; b += 16) {
+      a1 += (double)part[(long long)b * 2 * C + c];
+      a2 += (double)part[(long long)b * 2 * C + C + c];
+    }
+  sh[0][ps][cl] = a1;
+  sh[1][ps][cl] = a2;
+  __syncthreads();
+  if (ps == 0 && c < C) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < 16; ++k) { s1 += sh[0][k][cl]; s2 += sh[1][k][cl]; }
+    const double mean = s1 / count;
+    double var = s2 / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double r = 1.0 / sqrt(var + eps);
+    const double a = (double)gamma[c] * r;
+    stats[c] = mean;
+    stats[C + c] = r;
+    ab[c] = (float)a;
+    ab[C + c] = (float)((double)beta[c] - a * mean);
+    mv[c] = (float)mean;
+    mv[C + c] = (float)var;
+    if (running_mean) {
+      const float m = (float)momentum;
+      const float unb = (float)(var * (count / (count > 1.0 ? count - 1.0 : 1.0)));
+      running_mean[c] = running_mean[c] * (1.f - m) + m * (float)mean;
+      running_var[c] = running_var[c] * (1.f - m) + m * unb;
+      if (c == 0 && num_batches) *num_batches += 1;
+    }
+  }
+}
+
+extern "C" int gdmae_bn_fold(const void* x, long long R, int C, int is_bf16, double count, const float* gamma,
+                             const float* beta, double eps, double momentum, float* running_mean, float* running_var,
+                             long long* num_batches, double* stats, float* ab, float* mv, void* workspace, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const int epv = is_bf16 ? 8 : 4;
+  GD_REQUIRE(C % epv == 0 && (C / epv) <= 256, "C must be a multiple of 8 (bf16) / 4 (fp32) and <= 2048 / 1024");
+  int nblk = (int)(R / 64 > 512 ? 512 : (R / 64 > 0 ? R / 64 : 1));
+  const int rows_per_iter = 256 / (C / epv);
+  const size_t lds = (size_t)rows_per_iter * 2 * C * sizeof(float);
+  GD_REQUIRE(lds <= 64 * 1024, "colstats LDS");
+  if (is_bf16)
+    hipLaunchKernelGGL((k_colstats_partial<true>), dim3(nblk), dim3(256), lds, st, (const uint4*)x, R, C, (float*)workspace);
+  else
+    hipLaunchKernelGGL((k_colstats_partial<false>), dim3(nblk), dim3(256), lds, st, (const uint4*)x, R, C, (float*)workspace);
+  GD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_bn_fold_final, dim3(gd_div_up(C, 16)), dim3(256), 0, st, (const float*)workspace, nblk, C, count, gamma,
+                     beta, eps, momentum, running_mean, running_var, num_batches, stats, ab, mv);
+  GD_LAUNCH_CHECK();
+  return 0;
+}
+
+// st: double[n_st * C] column sums {dh, dh*x, (g)};  tot (optional, needs n_st == 3): column sums of the incoming
+// gradient over ALL dense sites - every site that is not a row of x holds the constant relu(b), so the background's
+// share of dbeta is (tot - sum g) * [b > 0].
+__global__ __launch_bounds__(256) void k_bn_bwd_coeffs(const double* __restrict__ st, int n_st, const double* __restrict__ stats,
+                                                       const float* __restrict__ ab, const float* __restrict__ gamma, int C,
+                                                       double count, const double* __restrict__ tot,
+                                                       float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate,
+                                                       float* __restrict__ c01) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double mean = stats[c], r = stats[C + c];
+  const double a = (double)ab[c], b = (double)ab[C + c];
+  double db = st[c];
+  if (tot && n_st >= 3 && b > 0.0) db += tot[c] - st[2 * C + c];
+  const double da = st[C + c] - db * mean;                 // total derivative w.r.t. a (b = beta - a * mean)
+  const double dv = -0.5 * (da * (double)gamma[c]) * r * r * r;   // a = gamma * rsqrt(var + eps)
+  const double dmu = -db * a - 2.0 * mean * dv;            // var = s2 / count - mean^2
+  c01[c] = (float)(dmu / count);
+  c01[C + c] = (float)(2.0 * dv / count);
+  const float dg = (float)(da * r), dbf = (float)db;
+  if (accumulate) { dgamma[c] += dg; dbeta[c] += dbf; }
+  else { dgamma[c] = dg; dbeta[c] = dbf; }
+}
+
+extern "C" int gdmae_bn_bwd_coeffs(const double* st, int n_st, const double* stats, const float* ab, const float* gamma, int C,
+                                   double count, const double* tot, float* dgamma, float* dbeta, int accumulate, float* c01,
+                                   void* stream) {
+  GD_REQUIRE(n_st == 2 || n_st == 3, "n_st must be 2 or 3");
+  hipLaunchKernelGGL(k_bn_bwd_coeffs, dim3(gd_div_up(C, 256)), dim3(256), 0, (hipStream_t)stream, st, n_st, stats, ab, gamma, C,
+                     count, tot, dgamma, dbeta, accumulate, c01);
+  GD_LAUNCH_CHECK();
+  return 0;
+}

@@ -29,6 +29,7 @@ from __future__ import annotations
 import torch
 import torch.nn.functional as F
 
+from . import bn as gbn
 from . import lib as L
 from . import ops
 
@@ -99,29 +100,27 @@ class DecoderHead(torch.autograd.Function):
       and two GEMMs per stage finish the job; dY / dZ are never materialised."""
 
     @staticmethod
-    def forward(ctx, geom, conv_w, gamma2, beta2, pillar_cell, cell2pillar, *args):
+    def forward(ctx, geom, conv_w, gamma2, beta2, pillar_cell, cell2pillar, bn_mods, *args):
         B, H, W, eps1, eps2, cdt = geom
         R = B * H * W
         k = len(args) // 4
         sites, Ps, gammas, betas = args[0::4], args[1::4], args[2::4], args[3::4]
         widths = [int(P.shape[1]) for P in Ps]
-        a_l, b_l, mean_l, r_l, stats_out = [], [], [], [], []
-        for P, g, be in zip(Ps, gammas, betas):
-            s1, s2 = colstats(P)
-            mean = s1 / R
-            var = (s2 / R - mean * mean).clamp_(min=0)
-            r = torch.rsqrt(var + eps1)
-            a = g.detach().double() * r
-            b = be.detach().double() - a * mean
-            a_l.append(a.float()), b_l.append(b.float()), mean_l.append(mean), r_l.append(r)
-            stats_out += [mean.float(), var.float()]
-        bgz = torch.relu(torch.cat(b_l)).to(cdt)                      # background value of every non-active site
+        dev = Ps[0].device
+        bns = list(bn_mods) if bn_mods is not None else [None] * (k + 1)
+        ab_l, stats_l, mv_out = [], [], []
+        for i in range(k):
+            stats, ab, mv = gbn.fold(Ps[i].contiguous(), R, gammas[i], betas[i], eps1, bns[i])
+            ab_l.append(ab), stats_l.append(stats)
+            mv_out += [mv[:widths[i]], mv[widths[i]:]]
+        bgz = torch.relu(torch.cat([ab[w:] for ab, w in zip(ab_l, widths)])).to(cdt)   # value of every non-active site
         Z = bgz.expand(R, sum(widths)).contiguous()
         col = 0
         for i in range(k):
-            L.call("gdmae_rows_affine_relu_scatter", L.ptr(Ps[i]), _bf(Ps[i]), L.ptr(sites[i]), Ps[i].shape[0], widths[i],
-                   L.ptr(a_l[i]), L.ptr(b_l[i]), L.ptr(Z), _bf(Z), Z.shape[1], col, L.stream())
-            col += widths[i]
+            w = widths[i]
+            L.call("gdmae_rows_affine_relu_scatter", L.ptr(Ps[i]), _bf(Ps[i]), L.ptr(sites[i]), Ps[i].shape[0], w,
+                   L.ptr(ab_l[i]), L.ptr(ab_l[i][w:]), L.ptr(Z), _bf(Z), Z.shape[1], col, L.stream())
+            col += w
         wc = ops.shadow(conv_w, cdt)
         with torch.autocast("cuda", enabled=False):
             y2 = F.conv2d(Z.view(B, H, W, -1).permute(0, 3, 1, 2), wc, None, 1, 1)
@@ -129,18 +128,21 @@ class DecoderHead(torch.autograd.Function):
         if not y2.is_contiguous():
             y2 = y2.contiguous()
         y2 = y2.view(R, -1)
-        s1, s2 = colstats(y2)
-        mean64 = s1 / R
-        var64 = (s2 / R - mean64 * mean64).clamp_(min=0)
-        mean2, var2 = mean64.float(), var64.float()
-        inv = torch.rsqrt(var2 + eps2)
-        yhat = (ops.gather_rows_raw(y2, pillar_cell).float() - mean2) * inv
-        out = torch.relu(yhat * gamma2 + beta2)
-        ctx.save_for_backward(*sites, *Ps, *a_l, *b_l, *mean_l, *r_l, *[g.detach() for g in gammas], Z, y2, bgz, s1,
-                              pillar_cell, cell2pillar, yhat, out > 0, inv, mean2, gamma2.detach(), conv_w.detach())
+        C2 = y2.shape[1]
+        stats2, ab2, mv2 = gbn.fold(y2, R, gamma2, beta2, eps2, bns[k])
+        yrows = ops.gather_rows_raw(y2, pillar_cell)                       # (M, C2) conv outputs at the pillar sites
+        M = yrows.shape[0]
+        out = torch.empty(M, C2, dtype=torch.float32, device=dev)
+        L.call("gdmae_rows_affine_relu_scatter", L.ptr(yrows), _bf(yrows), None, M, C2, L.ptr(ab2), L.ptr(ab2[C2:]), L.ptr(out), 0,
+               C2, 0, L.stream())
+        ctx.save_for_backward(*sites, *Ps, *ab_l, *stats_l, *[g.detach() for g in gammas], Z, y2, bgz, yrows, ab2, stats2,
+                              pillar_cell, cell2pillar, gamma2.detach(), conv_w.detach())
         ctx.k, ctx.widths, ctx.geom = k, widths, geom
-        ctx.mark_non_differentiable(y2, mean2, var2, *stats_out)
-        return (out, y2, mean2, var2, *stats_out)
+        ctx.direct = [gbn.direct_pair(g, be) for g, be in zip(gammas, betas)] + [gbn.direct_pair(gamma2, beta2)]
+        ctx.direct_w = ops.direct_grad(conv_w)
+        mean2, var2 = mv2[:C2], mv2[C2:]
+        ctx.mark_non_differentiable(y2, mean2, var2, *mv_out)
+        return (out, y2, mean2, var2, *mv_out)
 
     @staticmethod
     def backward(ctx, dout, *_):
@@ -148,26 +150,27 @@ class DecoderHead(torch.autograd.Function):
         B, H, W, eps1, eps2, cdt = ctx.geom
         R = B * H * W
         sv = ctx.saved_tensors
-        sites, Ps, a_l, b_l, mean_l, r_l, gammas = (sv[i * k:(i + 1) * k] for i in range(7))
-        Z, y2, bgz, s1, pillar_cell, cell2pillar, yhat, mask, inv, mean2, gamma2, conv_w = sv[7 * k:]
+        sites, Ps, ab_l, stats_l, gammas = (sv[i * k:(i + 1) * k] for i in range(5))
+        Z, y2, bgz, yrows, ab2, stats2, pillar_cell, cell2pillar, gamma2, conv_w = sv[5 * k:]
         C2, Cin = y2.shape[1], Z.shape[1]
+        M = yrows.shape[0]
         dev = y2.device
-        # ---- BatchNorm2d #2 (+ReLU) at the pillar rows: dY = k0 + k1*Y + rows[pillar sites]
-        g = dout * mask
-        dgamma2 = (g * yhat).sum(0)
-        dbeta2 = g.sum(0)
-        dyh = g * gamma2
-        m1 = dyh.sum(0, dtype=torch.float64) / R
-        m2 = (dyh * yhat).sum(0, dtype=torch.float64) / R
-        inv64, mean64 = inv.double(), mean2.double()
-        k1 = -(inv64 * inv64) * m2
-        k0 = -inv64 * m1 - k1 * mean64
-        rows = (dyh * inv).contiguous()
-        k0f, k1f = k0.float(), k1.float()
+        f64 = torch.float64
+        # ---- BatchNorm2d #2 (+ReLU) at the pillar rows: dY = c0 + c1*Y + rows[pillar sites], rows = a*dh
+        dout = dout.float().contiguous()
+        st2 = torch.empty(3 * C2, dtype=f64, device=dev)
+        ws = torch.empty(L.load().gdmae_rows_bwd_stats_workspace_bytes(C2), dtype=torch.uint8, device=dev)
+        L.call("gdmae_rows_bwd_stats", L.ptr(yrows), _bf(yrows), None, M, C2, L.ptr(ab2), L.ptr(ab2[C2:]), L.ptr(dout), 0, C2, 0,
+               L.ptr(st2), L.ptr(ws), L.stream())
+        dgamma2, dbeta2, k01 = gbn.bwd_coeffs(st2, 3, stats2, ab2, gamma2, R, None, ctx.direct[k])
+        zero = torch.zeros(2 * C2, dtype=torch.float32, device=dev)
+        rows = torch.empty(M, C2, dtype=torch.float32, device=dev)
+        L.call("gdmae_rows_bwd", L.ptr(yrows), _bf(yrows), None, M, C2, L.ptr(ab2), L.ptr(ab2[C2:]), L.ptr(zero), L.ptr(zero[C2:]),
+               L.ptr(dout), 0, C2, 0, L.ptr(rows), 0, L.stream())
+        k0, k1 = k01[:C2].double(), k01[C2:].double()
         # ---- region sums of dY (all / border rows / border columns / corners) -> S_k per tap
         Yv = y2.view(B, H, W, C2)
-        f64 = torch.float64
-        regY = torch.stack([s1, Yv[:, 0].sum((0, 1), dtype=f64), Yv[:, H - 1].sum((0, 1), dtype=f64),
+        regY = torch.stack([stats2[:C2] * R, Yv[:, 0].sum((0, 1), dtype=f64), Yv[:, H - 1].sum((0, 1), dtype=f64),
                             Yv[:, :, 0].sum((0, 1), dtype=f64), Yv[:, :, W - 1].sum((0, 1), dtype=f64),
                             Yv[:, 0, 0].sum(0, dtype=f64), Yv[:, 0, W - 1].sum(0, dtype=f64),
                             Yv[:, H - 1, 0].sum(0, dtype=f64), Yv[:, H - 1, W - 1].sum(0, dtype=f64)])
@@ -180,54 +183,41 @@ class DecoderHead(torch.autograd.Function):
         regD = cnt[:, None] * k0[None, :] + regY * k1[None, :] + regR
         S = _TAP_REGION.to(dev) @ regD                                     # (9, C2)
         Wk = conv_w.permute(2, 3, 0, 1).reshape(9, C2, Cin)              # W_k[o, i], k = (ky+1)*3 + (kx+1)
-        tot = torch.einsum('ko,koi->i', S, Wk.double())                   # column sums of dZ over ALL sites
+        tot = torch.einsum('ko,koi->i', S, Wk.double()).contiguous()      # column sums of dZ over ALL sites
         dWk = (S[:, :, None] * bgz.double()[None, None, :]).float()       # background part of the weight gradient
         Wd = Wk.to(cdt)
-        grads = [None] * 6
+        grads = [None] * 7
         dW_rows = []
         col = 0
         for i, w in enumerate(ctx.widths):
             P = Ps[i]
             n = P.shape[0]
+            ab = ab_l[i]
             G = torch.empty(n, 9 * C2, dtype=cdt, device=dev)
-            L.call("gdmae_conv3x3_grad_taps", L.ptr(y2), _bf(y2), L.ptr(k0f), L.ptr(k1f), L.ptr(rows), L.ptr(cell2pillar),
+            L.call("gdmae_conv3x3_grad_taps", L.ptr(y2), _bf(y2), L.ptr(k01), L.ptr(k01[C2:]), L.ptr(rows), L.ptr(cell2pillar),
                    L.ptr(sites[i]), n, H, W, C2, L.ptr(G), L.stream())
             dX = G @ Wd[:, :, col:col + w].reshape(9 * C2, w)             # dZ rows of this stage's active sites
             Zd = _gather_slice(Z, sites[i], col, w) - bgz[col:col + w]
             dW_rows.append(ops.splitk_tn(G, Zd))                          # (9*C2, w) fp32
             del G
-            st = torch.empty(3 * w, dtype=torch.float64, device=dev)
+            st = torch.empty(3 * w, dtype=f64, device=dev)
             ws = torch.empty(L.load().gdmae_rows_bwd_stats_workspace_bytes(w), dtype=torch.uint8, device=dev)
-            L.call("gdmae_rows_bwd_stats", L.ptr(P), _bf(P), None, n, w, L.ptr(a_l[i]), L.ptr(b_l[i]), L.ptr(dX), _bf(dX), w, 0,
+            L.call("gdmae_rows_bwd_stats", L.ptr(P), _bf(P), None, n, w, L.ptr(ab), L.ptr(ab[w:]), L.ptr(dX), _bf(dX), w, 0,
                    L.ptr(st), L.ptr(ws), L.stream())
-            s_dh, s_dhp, s_g = st[:w], st[w:2 * w], st[2 * w:]
-            a, b, mean, r, gm = a_l[i].double(), b_l[i].double(), mean_l[i], r_l[i], gammas[i].double()
-            gbg = tot[col:col + w] - s_g                           # every non-active site shares the background value
-            db = s_dh + gbg * (b > 0)
-            da = s_dhp - db * mean                                 # total derivative w.r.t. a (b = beta - a * mean)
-            dgamma = da * r
-            dv = -0.5 * (da * gm) * r * r * r                      # a = gamma * rsqrt(var + eps)
-            dmu = -db * a - 2.0 * mean * dv                        # var = s2 / R - mean^2
-            c0, c1 = (dmu / R).float(), (2.0 * dv / R).float()
+            dgamma, dbeta, c01 = gbn.bwd_coeffs(st, 3, stats_l[i], ab, gammas[i], R, tot[col:col + w], ctx.direct[i])
             dP = torch.empty_like(P)
-            L.call("gdmae_rows_bwd", L.ptr(P), _bf(P), None, n, w, L.ptr(a_l[i]), L.ptr(b_l[i]), L.ptr(c0), L.ptr(c1), L.ptr(dX),
+            L.call("gdmae_rows_bwd", L.ptr(P), _bf(P), None, n, w, L.ptr(ab), L.ptr(ab[w:]), L.ptr(c01), L.ptr(c01[w:]), L.ptr(dX),
                    _bf(dX), w, 0, L.ptr(dP), _bf(dP), L.stream())
-            grads += [None, dP, dgamma.to(gammas[i].dtype), db.to(gammas[i].dtype)]
+            grads += [None, dP, dgamma, dbeta]
             col += w
         dWk = dWk + torch.cat(dW_rows, dim=1).view(9, C2, Cin)
-        grads[1] = dWk.permute(1, 2, 0).reshape(C2, Cin, 3, 3).to(conv_w.dtype)
+        dW = dWk.permute(1, 2, 0).reshape(C2, Cin, 3, 3)
+        if ctx.direct_w is not None:
+            ctx.direct_w.add_(dW)
+        else:
+            grads[1] = dW.to(conv_w.dtype)
         grads[2], grads[3] = dgamma2, dbeta2
         return tuple(grads)
-
-
-def _update_running(bn, mean, var_biased, n):
-    """nn.BatchNorm running statistics (momentum 0.01, unbiased variance) for checkpoint parity."""
-    if bn.running_mean is None:
-        return
-    with torch.no_grad():
-        bn.running_mean.mul_(1 - bn.momentum).add_(mean.to(bn.running_mean.dtype), alpha=bn.momentum)
-        bn.running_var.mul_(1 - bn.momentum).add_(var_biased.to(bn.running_var.dtype) * (n / max(n - 1, 1)), alpha=bn.momentum)
-        bn.num_batches_tracked += 1
 
 
 def upsampled_sites(stage_plan, s: int, Y: int, X: int) -> torch.Tensor:
@@ -264,13 +254,8 @@ def sparse_decoder(model_cfg, deblocks, conv_out, hidden, pillar_cell, cell2pill
         bns.append(bn)
     conv, bn2 = conv_out[0], conv_out[1]
     outs = DecoderHead.apply((B, Y, X, bns[0].eps, bn2.eps, cdt), conv.weight, bn2.weight, bn2.bias, pillar_cell, cell2pillar,
-                             *args)
+                             tuple(bns) + (bn2,), *args)
     out, y2, mean2, var2 = outs[:4]
-    for i, bn in enumerate(bns):
-        if bn.training:
-            _update_running(bn, outs[4 + 2 * i], outs[5 + 2 * i], R)
-    if bn2.training:
-        _update_running(bn2, mean2, var2, R)
     dense = None
     if want_dense:
         with torch.no_grad():

@@ -124,11 +124,7 @@ def attn_backward_into(qk, v, g, dqk, dv, tau_flat, wplan, nhead, tau_min):
     return dtau
 
 
-def _direct(p):
-    """Flat-gradient view of a parameter owned by gdmae_hip.optim.FlatAdamOneCycle (zeroed at the start of the step,
-    written exactly once per step by this layer) or None -> return the gradient through autograd as usual."""
-    g = getattr(p, "_gd_flat_grad", None)
-    return g if (g is not None and p.grad is g) else None
+_direct = ops.direct_grad
 
 
 class EncoderLayerFn(torch.autograd.Function):

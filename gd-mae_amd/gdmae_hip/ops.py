@@ -122,6 +122,13 @@ def shadow(t: torch.Tensor, dtype) -> torch.Tensor:
     return t.to(dtype)
 
 
+def direct_grad(p):
+    """Flat-gradient view of a parameter owned by gdmae_hip.optim.FlatAdamOneCycle (zeroed at the start of the step;
+    hand-written backwards accumulate into it directly) or None -> return the gradient through autograd as usual."""
+    g = getattr(p, "_gd_flat_grad", None)
+    return g if (g is not None and p.grad is g) else None
+
+
 def colsum_f32(x2d: torch.Tensor) -> torch.Tensor:
     """Column sums (fp32) of a contiguous (R, C) fp32/bf16 matrix via gdmae_colstats (deterministic, fp64 combine)."""
     R, C = x2d.shape

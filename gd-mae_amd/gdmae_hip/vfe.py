@@ -13,95 +13,78 @@ from __future__ import annotations
 
 import torch
 
+from . import bn as gbn
 from . import lib as L
-from .decoder import colstats
 
 
 def _bf(t):
     return int(t.dtype == torch.bfloat16)
 
 
-def _bn_fold(x, gamma, beta, eps):
-    n = x.shape[0]
-    s1, s2 = colstats(x)
-    mean = s1 / n
-    var = (s2 / n - mean * mean).clamp_(min=0)
-    r = torch.rsqrt(var + eps)
-    a = gamma.detach().double() * r
-    b = beta.detach().double() - a * mean
-    return mean, var, r, a.float(), b.float()
-
-
-def _bn_chain(s_dh, s_dhx, mean, r, a, gamma, n):
-    """BatchNorm backward on column sums: returns (dgamma, dbeta, c0, c1) with dx = a*dh + c0 + c1*x."""
-    da = s_dhx - s_dh * mean                  # total derivative w.r.t. a (b = beta - a * mean)
-    dgamma = da * r
-    dv = -0.5 * (da * gamma.double()) * r * r * r
-    dmu = -s_dh * a.double() - 2.0 * mean * dv
-    return dgamma, s_dh, (dmu / n).float(), (2.0 * dv / n).float()
-
-
 class BNReLURows(torch.autograd.Function):
-    """relu(BatchNorm1d_train(x)) for x (N, C) fp32/bf16; returns (out [x.dtype], mean, biased var)."""
+    """relu(BatchNorm1d_train(x)) for x (N, C) fp32/bf16; returns (out [x.dtype], mean, biased var).
+    ``bn``: the nn.BatchNorm1d module (running statistics updated in the statistics launch) or None."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps):
+    def forward(ctx, x, gamma, beta, eps, bn=None):
         x = x.contiguous()
         n, C = x.shape
-        mean, var, r, a, b = _bn_fold(x, gamma, beta, eps)
+        stats, ab, mv = gbn.fold(x, n, gamma, beta, eps, bn)
         out = torch.empty_like(x)
-        L.call("gdmae_rows_affine_relu_scatter", L.ptr(x), _bf(x), None, n, C, L.ptr(a), L.ptr(b), L.ptr(out), _bf(out), C, 0,
+        L.call("gdmae_rows_affine_relu_scatter", L.ptr(x), _bf(x), None, n, C, L.ptr(ab), L.ptr(ab[C:]), L.ptr(out), _bf(out), C, 0,
                L.stream())
-        ctx.save_for_backward(x, a, b, mean, r, gamma.detach())
-        mf, vf = mean.float(), var.float()
+        ctx.save_for_backward(x, ab, stats, gamma.detach())
+        ctx.direct = gbn.direct_pair(gamma, beta)
+        mf, vf = mv[:C], mv[C:]
         ctx.mark_non_differentiable(mf, vf)
         return out, mf, vf
 
     @staticmethod
     def backward(ctx, g, _m, _v):
-        x, a, b, mean, r, gamma = ctx.saved_tensors
+        x, ab, stats, gamma = ctx.saved_tensors
         n, C = x.shape
         g = g.contiguous()
         st = torch.empty(3 * C, dtype=torch.float64, device=x.device)
         ws = torch.empty(L.load().gdmae_rows_bwd_stats_workspace_bytes(C), dtype=torch.uint8, device=x.device)
-        L.call("gdmae_rows_bwd_stats", L.ptr(x), _bf(x), None, n, C, L.ptr(a), L.ptr(b), L.ptr(g), _bf(g), C, 0, L.ptr(st),
+        L.call("gdmae_rows_bwd_stats", L.ptr(x), _bf(x), None, n, C, L.ptr(ab), L.ptr(ab[C:]), L.ptr(g), _bf(g), C, 0, L.ptr(st),
                L.ptr(ws), L.stream())
-        dgamma, dbeta, c0, c1 = _bn_chain(st[:C], st[C:2 * C], mean, r, a, gamma, n)
+        dgamma, dbeta, c01 = gbn.bwd_coeffs(st, 3, stats, ab, gamma, n, None, ctx.direct)
         dx = torch.empty_like(x)
-        L.call("gdmae_rows_bwd", L.ptr(x), _bf(x), None, n, C, L.ptr(a), L.ptr(b), L.ptr(c0), L.ptr(c1), L.ptr(g), _bf(g), C, 0,
-               L.ptr(dx), _bf(dx), L.stream())
-        return dx, dgamma.to(gamma.dtype), dbeta.to(gamma.dtype), None
+        L.call("gdmae_rows_bwd", L.ptr(x), _bf(x), None, n, C, L.ptr(ab), L.ptr(ab[C:]), L.ptr(c01), L.ptr(c01[C:]), L.ptr(g),
+               _bf(g), C, 0, L.ptr(dx), _bf(dx), L.stream())
+        return dx, dgamma, dbeta, None, None
 
 
 class BNReLUSegmentMax(torch.autograd.Function):
     """max over each pillar's points of relu(BatchNorm1d_train(x)); returns (out (M, C) fp32, mean, biased var)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, pt_off, pillar_pts, inverse32):
+    def forward(ctx, x, gamma, beta, eps, pt_off, pillar_pts, inverse32, bn=None):
         x = x.contiguous()
         n, C = x.shape
         M = pt_off.numel() - 1
-        mean, var, r, a, b = _bn_fold(x, gamma, beta, eps)
+        stats, ab, mv = gbn.fold(x, n, gamma, beta, eps, bn)
         out = torch.empty(M, C, dtype=torch.float32, device=x.device)
         arg = torch.empty(M, C, dtype=torch.int32, device=x.device)
-        L.call("gdmae_segment_max_affine", L.ptr(x), _bf(x), L.ptr(pt_off), L.ptr(pillar_pts), M, C, L.ptr(a), L.ptr(b),
+        L.call("gdmae_segment_max_affine", L.ptr(x), _bf(x), L.ptr(pt_off), L.ptr(pillar_pts), M, C, L.ptr(ab), L.ptr(ab[C:]),
                L.ptr(out), L.ptr(arg), L.stream())
-        ctx.save_for_backward(x, out, arg, inverse32, a, mean, r, gamma.detach())
-        mf, vf = mean.float(), var.float()
+        ctx.save_for_backward(x, out, arg, inverse32, ab, stats, gamma.detach())
+        ctx.direct = gbn.direct_pair(gamma, beta)
+        mf, vf = mv[:C], mv[C:]
         ctx.mark_non_differentiable(mf, vf)
         return out, mf, vf
 
     @staticmethod
     def backward(ctx, g, _m, _v):
-        x, out, arg, inv, a, mean, r, gamma = ctx.saved_tensors
+        x, out, arg, inv, ab, stats, gamma = ctx.saved_tensors
         n, C = x.shape
         M = out.shape[0]
         g = g.float().contiguous()
         st = torch.empty(2 * C, dtype=torch.float64, device=x.device)
         ws = torch.empty(L.load().gdmae_rows_bwd_stats_workspace_bytes(C), dtype=torch.uint8, device=x.device)
         L.call("gdmae_segmax_bwd_stats", L.ptr(x), _bf(x), L.ptr(out), L.ptr(arg), L.ptr(g), M, C, L.ptr(st), L.ptr(ws), L.stream())
-        dgamma, dbeta, c0, c1 = _bn_chain(st[:C], st[C:], mean, r, a, gamma, n)
+        dgamma, dbeta, c01 = gbn.bwd_coeffs(st, 2, stats, ab, gamma, n, None, ctx.direct)
         dx = torch.empty_like(x)
-        L.call("gdmae_segmax_bn_bwd", L.ptr(x), _bf(x), L.ptr(out), L.ptr(arg), L.ptr(g), L.ptr(inv), n, C, L.ptr(a), L.ptr(c0),
-               L.ptr(c1), L.ptr(dx), _bf(dx), L.stream())
-        return dx, dgamma.to(gamma.dtype), dbeta.to(gamma.dtype), None, None, None, None
+        L.call("gdmae_segmax_bn_bwd", L.ptr(x), _bf(x), L.ptr(out), L.ptr(arg), L.ptr(g), L.ptr(inv), n, C, L.ptr(ab), L.ptr(c01),
+               L.ptr(c01[C:]), L.ptr(dx), _bf(dx), L.stream())
+        return dx, dgamma, dbeta, None, None, None, None, None

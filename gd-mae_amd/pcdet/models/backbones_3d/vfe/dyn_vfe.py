@@ -12,7 +12,6 @@ import torch.nn as nn
 from .vfe_template import VFETemplate
 from ...model_utils.network_utils import make_fc_layers
 from gdmae_hip import ops, plan as gplan, vfe as gvfe
-from gdmae_hip.decoder import _update_running
 
 
 class DynVFE(VFETemplate):
@@ -49,11 +48,10 @@ class DynVFE(VFETemplate):
                 lin, bn = mlp[3 * k], mlp[3 * k + 1]
                 x = ops.linear(x, lin.weight, lin.bias)
                 if k < nl - 1:
-                    x, mean, var = gvfe.BNReLURows.apply(x, bn.weight, bn.bias, bn.eps)
+                    x, _, _ = gvfe.BNReLURows.apply(x, bn.weight, bn.bias, bn.eps, bn)
                 else:
-                    x, mean, var = gvfe.BNReLUSegmentMax.apply(x, bn.weight, bn.bias, bn.eps, vox.pt_off, vox.pillar_pts,
-                                                               vox.inverse32)
-                _update_running(bn, mean, var, vox.N)
+                    x, _, _ = gvfe.BNReLUSegmentMax.apply(x, bn.weight, bn.bias, bn.eps, vox.pt_off, vox.pillar_pts,
+                                                          vox.inverse32, bn)
         else:
             for m in mlp:                                # Linear(no bias) -> BN1d -> ReLU, twice
                 x = ops.linear(x, m.weight, m.bias) if isinstance(m, nn.Linear) else m(x)

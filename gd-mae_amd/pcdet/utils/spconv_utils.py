@@ -100,11 +100,9 @@ class SparseSequential(SparseModule):
         if (self.fused_bn_relu and self.training and len(mods) == 3 and isinstance(mods[1], nn.BatchNorm1d)
                 and isinstance(mods[2], nn.ReLU) and mods[1].affine):
             from gdmae_hip import vfe as gvfe
-            from gdmae_hip.decoder import _update_running
             x = mods[0](x)
             bn = mods[1]
-            f, mean, var = gvfe.BNReLURows.apply(x.features, bn.weight, bn.bias, bn.eps)
-            _update_running(bn, mean, var, x.features.shape[0])
+            f, _, _ = gvfe.BNReLURows.apply(x.features, bn.weight, bn.bias, bn.eps, bn)
             return x.replace_feature(f)
         for m in mods:
             x = m(x) if isinstance(m, SparseModule) else x.replace_feature(m(x.features))

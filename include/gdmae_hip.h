@@ -150,6 +150,21 @@ int gdmae_rows_bwd(const void* P, int p_bf16, const int* site, long long n, int 
                    const float* c0, const float* c1, const void* dZ, int z_bf16, int z_row_elems, int col0, void* dP,
                    int dp_bf16, void* stream);
 
+/* BatchNorm(train) bookkeeping, one launch each (network_utils.py:7-21 / spt_backbone_mae.py:30-52 BatchNorm1d/2d):
+ *   gdmae_bn_fold: column statistics of x (R, C) over `count` samples (count > R when x holds only the non-zero rows
+ *     of an implicit dense map) -> stats double[2C] = {mean, rstd}, ab float[2C] = {a = gamma*rstd, b = beta - a*mean},
+ *     mv float[2C] = {mean, biased var}; if running_mean != NULL also the nn.BatchNorm running-statistics update
+ *     (momentum, unbiased variance) and ++*num_batches.  workspace: gdmae_colstats_workspace_bytes(C).
+ *   gdmae_bn_bwd_coeffs: st double[n_st*C] = column sums {dh, dh*x, (g)} of the row backward -> dgamma, dbeta
+ *     (written, or added when accumulate != 0) and c01 float[2C] = {c0, c1} of dx = a*dh + c0 + c1*x.  tot (C,
+ *     optional, n_st == 3): column sums of the incoming gradient over ALL sites (background share of dbeta). */
+int gdmae_bn_fold(const void* x, long long R, int C, int is_bf16, double count, const float* gamma, const float* beta,
+                  double eps, double momentum, float* running_mean, float* running_var, long long* num_batches,
+                  double* stats, float* ab, float* mv, void* workspace, void* stream);
+int gdmae_bn_bwd_coeffs(const double* st, int n_st, const double* stats, const float* ab, const float* gamma, int C,
+                        double count, const double* tot, float* dgamma, float* dbeta, int accumulate, float* c01,
+                        void* stream);
+
 /* Backward of the decoder's dense 3x3 conv_out (spt_backbone_mae.py:46-52) restricted to the sites that need it:
  * out[t, k, :] = dY[site[t] - k] for the 9 taps k = (ky+1)*3 + (kx+1) (zero outside the H x W map), where the
  * output gradient dY[u] = k0 + k1 * Y[u] + (cell2pillar[u] >= 0 ? rows[cell2pillar[u]] : 0) is never materialised.
