@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.abspath(os.path.join(HERE, "..", "csrc"))
 LIB = os.path.join(CSRC, "libgdmae_hip.so")
 SOURCES = ["capi.hip", "voxelize.hip", "mask.hip", "partition.hip", "segment.hip", "attention.hip", "attention_mfma.hip", "layernorm.hip", "decoder.hip", "chamfer.hip",
-           "optim.hip"]
+           "optim.hip", "encoder_layer.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-Wno-unused-result"]
 
@@ -27,7 +27,7 @@ def _newer(src, dst):
 def build(force: bool = False, verbose: bool = True) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
-    deps = [os.path.join(CSRC, "common.h")]
+    deps = [os.path.join(CSRC, "common.h"), os.path.abspath(os.path.join(CSRC, "..", "..", "include", "gdmae_hip.h"))]
     procs = []
     for s in SOURCES:
         src = os.path.join(CSRC, s)
@@ -49,7 +49,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     if failed:
         raise RuntimeError("hipcc failed")
     if force or procs or not os.path.exists(LIB):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-L/opt/rocm/lib", "-lhipblaslt"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

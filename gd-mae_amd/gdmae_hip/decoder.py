@@ -81,6 +81,20 @@ for _ky in (-1, 0, 1):
             _TAP_REGION[_k, 5 + (0 if _ky < 0 else 2) + (0 if _kx < 0 else 1)] = 1
 
 
+_REGION_CONSTS = {}
+
+
+def _region_consts(dev, B, H, W):
+    """Device copies of the tap/region matrix and the region site counts (cached: a host->device copy inside the
+    backward would stall the host until the GPU has caught up)."""
+    key = (dev, B, H, W)
+    if key not in _REGION_CONSTS:
+        R = B * H * W
+        cnt = torch.tensor([R, B * W, B * W, B * H, B * H, B, B, B, B], dtype=torch.float64)
+        _REGION_CONSTS[key] = (_TAP_REGION.to(dev), cnt.to(dev))
+    return _REGION_CONSTS[key]
+
+
 class DecoderHead(torch.autograd.Function):
     """The whole generative-decoder head on the token rows (reference spt_backbone_mae.py:30-52,125-135):
     ConvTranspose2d(k=s) outputs P_i of the active sites -> BatchNorm2d(train)+ReLU of the (implicit) dense maps ->
@@ -179,9 +193,9 @@ class DecoderHead(torch.autograd.Function):
         y0, yl, x0, xl = py == 0, py == H - 1, px == 0, px == W - 1
         pm = torch.stack([torch.ones_like(y0), y0, yl, x0, xl, y0 & x0, y0 & xl, yl & x0, yl & xl]).to(rows.dtype)
         regR = (pm @ rows).double()
-        cnt = torch.tensor([R, B * W, B * W, B * H, B * H, B, B, B, B], dtype=f64, device=dev)
+        tap_region, cnt = _region_consts(dev, B, H, W)
         regD = cnt[:, None] * k0[None, :] + regY * k1[None, :] + regR
-        S = _TAP_REGION.to(dev) @ regD                                     # (9, C2)
+        S = tap_region @ regD                                     # (9, C2)
         Wk = conv_w.permute(2, 3, 0, 1).reshape(9, C2, Cin)              # W_k[o, i], k = (ky+1)*3 + (kx+1)
         tot = torch.einsum('ko,koi->i', S, Wk.double()).contiguous()      # column sums of dZ over ALL sites
         dWk = (S[:, :, None] * bgz.double()[None, None, :]).float()       # background part of the weight gradient

@@ -211,10 +211,99 @@ def _as_padded(t, n):
     return p
 
 
+# ------------------------------------------------------------------------------------------------
+# native executor: the whole layer forward / backward as ONE C-ABI call each (csrc/encoder_layer.hip)
+# ------------------------------------------------------------------------------------------------
+IMPL = "native"      # "native": gdmae_encoder_layer_fwd/bwd;  "python": EncoderLayerFn above (same arithmetic, op by op)
+
+_GRAD_FIELDS = ("dWin", "dbin", "dtau", "dWo", "dbo", "dW1", "db1", "dW2", "db2", "dg1", "dbe1", "dg2", "dbe2")
+
+
+def _layer_args(x, wplan, pos_table, nhead, tau_min, eps, cdt, ff, params):
+    n, d = x.shape
+    a = L.LayerArgs()
+    a.n, a.d, a.ff, a.nhead, a.bf16 = n, d, ff, nhead, int(cdt == torch.bfloat16)
+    a.eps, a.tau_min = float(eps), float(tau_min)
+    nl = len(wplan.n_win)
+    a.n_levels = nl
+    for i in range(nl):
+        a.n_win[i], a.max_tokens[i] = int(wplan.n_win[i]), int(wplan.max_tokens[i])
+    a.tok_pos, a.csr_tok, a.win_start, a.win_len = (L.ptr(wplan.tok_pos), L.ptr(wplan.csr_tok), L.ptr(wplan.win_start),
+                                                    L.ptr(wplan.win_len))
+    a.pos_table, a.x = L.ptr(pos_table), L.ptr(x)
+    for k, t in params.items():
+        setattr(a, k, L.ptr(t))
+    return a
+
+
+def _layer_bytes(n, d, ff, nhead, bf, wplan):
+    import ctypes as C
+    out = (C.c_size_t * 3)()
+    nw = L.host_i32(wplan.n_win)
+    L.call("gdmae_encoder_layer_bytes", n, d, ff, nhead, bf, nw, len(wplan.n_win), C.byref(out, 0),
+           C.byref(out, C.sizeof(C.c_size_t)), C.byref(out, 2 * C.sizeof(C.c_size_t)))
+    return int(out[0]), int(out[1]), int(out[2])
+
+
+class EncoderLayerNativeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, Win, bin_, tau, Wo, bo, W1, b1, W2, b2, g1, be1, g2, be2, wplan, pos_table, nhead, tau_min, eps, act):
+        import ctypes as C
+        assert act == "gelu", "hot path uses ACTIVATION gelu (gd_mae_ssl.yaml:66)"
+        ctx.direct = [_direct(p) for p in (Win, bin_, tau, Wo, bo, W1, b1, W2, b2, g1, be1, g2, be2)]
+        x = x.float().contiguous()
+        n, d = x.shape
+        dev = x.device
+        ff = W1.shape[0]
+        cdt = torch.bfloat16 if torch.is_autocast_enabled() else torch.float32
+        sh = lambda t: ops.shadow(t, cdt).contiguous()   # noqa: E731
+        params = {"Win": sh(Win), "bin": sh(bin_), "Wo": sh(Wo), "bo": sh(bo), "W1": sh(W1), "b1": sh(b1), "W2": sh(W2), "b2": sh(b2),
+                  "g1": g1.detach(), "be1": be1.detach(), "g2": g2.detach(), "be2": be2.detach(),
+                  "tau": tau.detach().reshape(1).float().contiguous()}
+        sb, fb, bb = _layer_bytes(n, d, ff, nhead, int(cdt == torch.bfloat16), wplan)
+        saved = torch.empty(sb, dtype=torch.uint8, device=dev)
+        scratch = torch.empty(fb, dtype=torch.uint8, device=dev)
+        y = torch.empty_like(x)
+        a = _layer_args(x, wplan, pos_table, nhead, tau_min, eps, cdt, ff, params)
+        a.y, a.saved, a.scratch = L.ptr(y), L.ptr(saved), L.ptr(scratch)
+        L.call("gdmae_encoder_layer_fwd", C.byref(a), L.stream())
+        ctx.save_for_backward(x, saved, pos_table, *params.values())
+        ctx.meta = (wplan, nhead, tau_min, eps, cdt, ff, bb, [t.shape for t in (Win, bin_, tau, Wo, bo, W1, b1, W2, b2, g1, be1, g2, be2)],
+                    tau.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        import ctypes as C
+        x, saved, pos_table, *pv = ctx.saved_tensors
+        wplan, nhead, tau_min, eps, cdt, ff, bb, shapes, tau_dtype = ctx.meta
+        params = dict(zip(("Win", "bin", "Wo", "bo", "W1", "b1", "W2", "b2", "g1", "be1", "g2", "be2", "tau"), pv))
+        dev = x.device
+        dy = dy.float().contiguous()
+        dx = torch.empty_like(x)
+        scratch = torch.empty(bb, dtype=torch.uint8, device=dev)
+        a = _layer_args(x, wplan, pos_table, nhead, tau_min, eps, cdt, ff, params)
+        a.dy, a.dx, a.saved, a.scratch = L.ptr(dy), L.ptr(dx), L.ptr(saved), L.ptr(scratch)
+        if all(t is not None for t in ctx.direct):
+            gl = list(ctx.direct)                      # accumulate straight into the flat optimizer gradient buffer
+            ret = [None] * 13
+        else:
+            sizes = [int(torch.Size(s).numel()) for s in shapes]
+            flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+            gl = list(torch.split(flat, sizes))
+            ret = [g.view(s) for g, s in zip(gl, shapes)]
+            ret[2] = ret[2].to(tau_dtype)
+        for k, g in zip(_GRAD_FIELDS, gl):
+            setattr(a, k, L.ptr(g))
+        L.call("gdmae_encoder_layer_bwd", C.byref(a), L.stream())
+        return (dx, *ret, None, None, None, None, None, None)
+
+
 def encoder_layer(layer, x, wplan, pos_table):
     """``layer``: pcdet EncoderLayer module (parameter container); returns LN(x1 + FFN(x1)), x1 = LN(x + attn(x))."""
     sa = layer.win_attn.self_attn
-    return EncoderLayerFn.apply(x, sa.in_proj_weight, sa.in_proj_bias, sa.tau, sa.out_proj.weight, sa.out_proj.bias,
-                                layer.linear1.weight, layer.linear1.bias, layer.linear2.weight, layer.linear2.bias,
-                                layer.norm1.weight, layer.norm1.bias, layer.norm2.weight, layer.norm2.bias,
-                                wplan, pos_table, sa.num_heads, sa.tau_min, layer.norm1.eps, layer.activation_name)
+    fn = EncoderLayerNativeFn if (IMPL == "native" and not timing.enabled()) else EncoderLayerFn
+    return fn.apply(x, sa.in_proj_weight, sa.in_proj_bias, sa.tau, sa.out_proj.weight, sa.out_proj.bias,
+                    layer.linear1.weight, layer.linear1.bias, layer.linear2.weight, layer.linear2.bias,
+                    layer.norm1.weight, layer.norm1.bias, layer.norm2.weight, layer.norm2.bias,
+                    wplan, pos_table, sa.num_heads, sa.tau_min, layer.norm1.eps, layer.activation_name)

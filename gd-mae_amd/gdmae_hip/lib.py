@@ -62,6 +62,9 @@ SIGNATURES = {
     "gdmae_set_attention_impl": (_I, [_I]),
     "gdmae_sum_partials": (_I, [_P, _L, _F, _P, _I, _P]),
     "gdmae_sum_partials_gated": (_I, [_P, _L, _F, _P, _P, _F, _P]),
+    "gdmae_encoder_layer_bytes": (_I, [_L, _I, _I, _I, _I, _P, _I, _P, _P, _P]),
+    "gdmae_encoder_layer_fwd": (_I, [_P, _P]),
+    "gdmae_encoder_layer_bwd": (_I, [_P, _P]),
     "gdmae_group_gt_points": (_I, [_P, _I, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
     "gdmae_chamfer": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P]),
     "gdmae_group_workspace_bytes": (_Z, [_L, _L]),
@@ -70,6 +73,15 @@ SIGNATURES = {
     "gdmae_grad_sq_norm": (_I, [_P, _L, _P, _P, _P]),
     "gdmae_adam_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _P, _P]),
 }
+
+class LayerArgs(C.Structure):
+    """ctypes mirror of ``gdmae_layer_args`` (include/gdmae_hip.h)."""
+    _fields_ = ([("n", _L), ("d", _I), ("ff", _I), ("nhead", _I), ("bf16", _I), ("eps", _F), ("tau_min", _F), ("n_levels", _I),
+                 ("n_win", _I * 4), ("max_tokens", _I * 4)]
+                + [(k, _P) for k in ("tok_pos", "csr_tok", "win_start", "win_len", "pos_table", "Win", "bin", "Wo", "bo", "W1", "b1",
+                                     "W2", "b2", "g1", "be1", "g2", "be2", "tau", "x", "y", "dy", "dx", "dWin", "dbin", "dtau", "dWo",
+                                     "dbo", "dW1", "db1", "dW2", "db2", "dg1", "dbe1", "dg2", "dbe2", "saved", "scratch")])
+
 
 _lib = None
 

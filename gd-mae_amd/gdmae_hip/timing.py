@@ -26,6 +26,10 @@ class KernelTimers:
         return out
 
 
+def enabled() -> bool:
+    return _ACTIVE is not None
+
+
 @contextlib.contextmanager
 def collect():
     global _ACTIVE

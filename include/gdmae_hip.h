@@ -227,6 +227,40 @@ int gdmae_prep_tokens(const float* x, const float* pos_table, const int* tok_pos
                       void* xpos_out, int out_bf16, void* stream);
 int gdmae_add3(const float* a, const void* b, int b_bf16, const void* c, int c_bf16, long long total, float* out, void* stream);
 
+/* ---- a13/a14 as one call: native executor of a whole encoder layer ------------------------------ *
+ * EncoderLayer.forward (sst_basic_block.py:77-84; WindowAttention :22-54; cosine_msa.py): q = k = x + pos, v = x,
+ * in-projection, windowed cosine attention, out-projection, LN(x + attn), FFN(GELU erf), LN(x + ffn) - forward or
+ * backward enqueued by ONE call (hipBLASLt GEMMs with cached algorithms + the kernels above).  All pointers are
+ * device pointers unless noted; weights and biases are in the GEMM dtype (bf16 != 0: bf16, else fp32), LayerNorm
+ * parameters, tau, x, y, dy, dx and every parameter gradient are fp32.  Parameter gradients are ACCUMULATED (+=).
+ * `saved` (gdmae_encoder_layer_bytes: saved_bytes) is written by the forward and read by the backward; `scratch`
+ * needs fwd_scratch_bytes / bwd_scratch_bytes. */
+typedef struct gdmae_layer_args {
+  long long n;                 /* tokens */
+  int d, ff, nhead, bf16;
+  float eps, tau_min;
+  int n_levels;                /* window-size levels of the partition (<= 4) */
+  int n_win[4], max_tokens[4];
+  const int* tok_pos;          /* (n) row of pos_table per token */
+  const int* csr_tok;          /* tokens ordered by (level, window) */
+  const int* win_start;
+  const int* win_len;          /* per window, levels concatenated */
+  const float* pos_table;      /* (window cells, d) */
+  const void *Win, *bin, *Wo, *bo, *W1, *b1, *W2, *b2;
+  const float *g1, *be1, *g2, *be2, *tau;
+  const float* x;              /* (n, d) layer input */
+  float* y;                    /* (n, d) layer output            [forward]  */
+  const float* dy;             /* (n, d)                         [backward] */
+  float* dx;                   /* (n, d)                         [backward] */
+  float *dWin, *dbin, *dtau, *dWo, *dbo, *dW1, *db1, *dW2, *db2, *dg1, *dbe1, *dg2, *dbe2;   /* [backward] */
+  void* saved;
+  void* scratch;
+} gdmae_layer_args;
+int gdmae_encoder_layer_bytes(long long n, int d, int ff, int nhead, int bf16, const int* n_win /* host */, int n_levels,
+                              size_t* saved_bytes, size_t* fwd_scratch_bytes, size_t* bwd_scratch_bytes);
+int gdmae_encoder_layer_fwd(const gdmae_layer_args* args /* host */, void* stream);
+int gdmae_encoder_layer_bwd(const gdmae_layer_args* args /* host */, void* stream);
+
 /* ---- a17-a19: reconstruction targets and Chamfer loss ----------------------------------------- *
  * gdmae_group_gt_points replaces sst_ops_cuda.group_inner_inds_wrapper (sst_ops_api.cpp:8;
  * sst_ops_gpu.cu:22-39) + points[group_inds] + get_voxel_centers (common_utils.py:130-145):

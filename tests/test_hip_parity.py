@@ -499,9 +499,13 @@ def test_fused_vfe_bn_relu_and_segment_max_match_torch(dt):
 
 
 @pytest.mark.parametrize("autocast", [False, True])
-def test_fused_encoder_layer_equals_autograd_layer(autocast):
-    """gdmae_hip.encoder.EncoderLayerFn (hand-written backward) vs the same layer op by op through autograd."""
+@pytest.mark.parametrize("impl", ["native", "python"])
+def test_fused_encoder_layer_equals_autograd_layer(autocast, impl):
+    """gdmae_hip.encoder (native one-call executor / op-by-op Function, both with hand-written backward) vs the same
+    layer op by op through autograd."""
+    from gdmae_hip import encoder as genc
     from gdmae_hip import plan
+    genc.IMPL = impl
     from pcdet.models.backbones_3d.spt_backbone import SSTInputLayer
     from pcdet.models.model_utils.sst_basic_block import EncoderLayer
     z, ds, cfg, _ = load_case("waymo_b1")
@@ -530,6 +534,7 @@ def test_fused_encoder_layer_equals_autograd_layer(autocast):
             y = layer(xi, table, st.windows[1])
         (y.float() * go).sum().backward()
         res[fused] = (y.detach().float(), xi.grad.clone(), {k: p.grad.clone() for k, p in layer.named_parameters()})
+    genc.IMPL = "native"
     y0, dx0, g0 = res[False]
     y1, dx1, g1 = res[True]
     tol = 3e-2 if autocast else 2e-4
