@@ -12,6 +12,8 @@
 // Parameter gradients are ACCUMULATED into the caller's fp32 buffers (flat optimizer buffer or zeroed temporaries).
 #include <hipblaslt/hipblaslt.h>
 
+#include <stdlib.h>
+
 #include <map>
 #include <mutex>
 #include <tuple>
@@ -134,12 +136,30 @@ __global__ __launch_bounds__(256) void k_acc_f64(const double* __restrict__ src,
   if (c < C) dst[c] += (float)src[c];
 }
 
-// dst[i] += sum_s part[s * P + i]
-__global__ __launch_bounds__(256) void k_splitk_acc(const float* __restrict__ part, int S, long long P, float* __restrict__ dst) {
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < P; i += (long long)gridDim.x * blockDim.x) {
-    float acc = 0.f;
-    for (int s = 0; s < S; ++s) acc += part[(long long)s * P + i];
-    dst[i] += acc;
+// dst[i] += sum_s part[s * P + i]   (P % 4 == 0).  64 float4 columns x 4 slices of S per workgroup: every lane
+// streams S/4 independent 16-byte loads, the 4 slices meet in LDS (fixed order -> deterministic).
+__global__ __launch_bounds__(256) void k_splitk_acc(const float* __restrict__ part, int S, long long P4, float* __restrict__ dst) {
+  __shared__ float4 sh[3][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const long long i = blockIdx.x * 64ll + tx;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < P4) {
+    const int s0 = (S * ty) / 4, s1 = (S * (ty + 1)) / 4;
+    const float4* p = (const float4*)part + i;
+#pragma unroll 4
+    for (int s = s0; s < s1; ++s) {
+      const float4 v = p[(long long)s * P4];
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+  }
+  if (ty > 0) sh[ty - 1][tx] = acc;
+  __syncthreads();
+  if (ty == 0 && i < P4) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { const float4 v = sh[k][tx]; acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+    float4 d = ((float4*)dst)[i];
+    d.x += acc.x; d.y += acc.y; d.z += acc.z; d.w += acc.w;
+    ((float4*)dst)[i] = d;
   }
 }
 
@@ -204,16 +224,47 @@ int gd_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const void* A
     LT_CHECK(hipblasLtMatmulPreferenceCreate(&pref));
     const uint64_t wsz = ws_bytes;
     LT_CHECK(hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &wsz, sizeof(wsz)));
-    hipblasLtMatmulHeuristicResult_t res[1];
+    // First use of a shape: ask for several candidate algorithms and time them on the caller's buffers (the GEMM is
+    // idempotent: beta = 0).  The heuristic's first choice is tuned for large square problems; these are tall-skinny
+    // (20-40 k rows, K and N of 128-512) and the best candidate is often not the first.  Shapes repeat (rows are
+    // padded to 2048), so the one-off cost (a few ms, with stream syncs) is paid during warm-up only.
+    constexpr int kMaxAlgo = 16;
+    hipblasLtMatmulHeuristicResult_t res[kMaxAlgo];
     int found = 0;
-    LT_CHECK(hipblasLtMatmulAlgoGetHeuristic(g_lt, p.desc, p.la, p.lb, p.lc, p.lc, pref, 1, res, &found));
+    static const bool tune = !(getenv("GDMAE_GEMM_TUNE") && atoi(getenv("GDMAE_GEMM_TUNE")) == 0);
+    LT_CHECK(hipblasLtMatmulAlgoGetHeuristic(g_lt, p.desc, p.la, p.lb, p.lc, p.lc, pref, tune ? kMaxAlgo : 1, res, &found));
     hipblasLtMatmulPreferenceDestroy(pref);
     if (found < 1) {
       gd_set_error(-2, __FILE__, __LINE__, "hipBLASLt: no algorithm for this GEMM shape");
       return -2;
     }
-    p.algo = res[0].algo;
-    p.ws = res[0].workspaceSize;
+    int best = 0;
+    if (found > 1) {
+      const float alpha = 1.f, beta = 0.f;
+      hipEvent_t e0, e1;
+      GD_CHECK(hipEventCreate(&e0));
+      GD_CHECK(hipEventCreate(&e1));
+      float best_ms = 1e30f;
+      for (int i = 0; i < found; ++i) {
+        if (res[i].workspaceSize > ws_bytes) continue;
+        bool ok = true;
+        for (int rep = 0; rep < 4 && ok; ++rep) {     // rep 0 = warm-up
+          if (rep == 1) hipEventRecord(e0, st);
+          ok = hipblasLtMatmul(g_lt, p.desc, &alpha, A, p.la, B, p.lb, &beta, C, p.lc, C, p.lc, &res[i].algo, ws, res[i].workspaceSize,
+                               st) == HIPBLAS_STATUS_SUCCESS;
+        }
+        if (!ok) continue;
+        hipEventRecord(e1, st);
+        GD_CHECK(hipEventSynchronize(e1));
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best_ms) { best_ms = ms; best = i; }
+      }
+      hipEventDestroy(e0);
+      hipEventDestroy(e1);
+    }
+    p.algo = res[best].algo;
+    p.ws = res[best].workspaceSize;
     it = g_plans.emplace(key, p).first;
   }
   GemmPlan& p = it->second;
@@ -260,8 +311,8 @@ int linear_dw(const Ctx& c, const void* G, const void* X, float* dW, long long n
   const long long kc = n_pad / S;
   GD_TRY(gd_gemm(c.st, false, true, k, m, (int)kc, X, k, G, m, part, k, c.ty, HIP_R_32F, nullptr, S, kc * k, kc * m, (long long)m * k,
                  c.lt_ws, kLtWorkspace));
-  const long long P = (long long)m * k;
-  hipLaunchKernelGGL(k_splitk_acc, dim3((int)((P + 255) / 256)), dim3(256), 0, c.st, part, S, P, dW);
+  const long long P4 = (long long)m * k / 4;
+  hipLaunchKernelGGL(k_splitk_acc, dim3((int)((P4 + 63) / 64)), dim3(256), 0, c.st, part, S, P4, dW);
   GD_LAUNCH_CHECK();
   return 0;
 }
