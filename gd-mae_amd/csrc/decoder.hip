@@ -28,6 +28,129 @@ __device__ inline void dec_st(void* p, long long i, float v) {
   else ((float*)p)[i] = v;
 }
 
+// 8 consecutive elements (index i is a multiple of 8): one 16-byte (bf16) or two 16-byte (fp32) accesses
+template <bool BF>
+__device__ inline void dec_ld8(const void* p, long long i, float (&v)[8]) {
+  if (BF) {
+    const uint4 q = *reinterpret_cast<const uint4*>((const unsigned short*)p + i);
+    const unsigned w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      v[2 * j] = __uint_as_float(w[j] << 16);
+      v[2 * j + 1] = __uint_as_float(w[j] & 0xFFFF0000u);
+    }
+  } else {
+    const float4 a = *reinterpret_cast<const float4*>((const float*)p + i), b = *reinterpret_cast<const float4*>((const float*)p + i + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  }
+}
+template <bool BF>
+__device__ inline void dec_st8(void* p, long long i, const float (&v)[8]) {
+  if (BF) {
+    uint4 q;
+    q.x = dec_f2bf(v[0]) | ((unsigned)dec_f2bf(v[1]) << 16);
+    q.y = dec_f2bf(v[2]) | ((unsigned)dec_f2bf(v[3]) << 16);
+    q.z = dec_f2bf(v[4]) | ((unsigned)dec_f2bf(v[5]) << 16);
+    q.w = dec_f2bf(v[6]) | ((unsigned)dec_f2bf(v[7]) << 16);
+    *reinterpret_cast<uint4*>((unsigned short*)p + i) = q;
+  } else {
+    *reinterpret_cast<float4*>((float*)p + i) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>((float*)p + i + 4) = make_float4(v[4], v[5], v[6], v[7]);
+  }
+}
+
+// ---- 8-channels-per-thread variants of the three row kernels (C % 8 == 0, zrow % 8 == 0, col0 % 8 == 0) ----
+template <bool PBF, bool ZBF>
+__global__ __launch_bounds__(256) void k_rows_affine_relu_scatter_v8(const void* __restrict__ P, const int* __restrict__ site,
+                                                                     long long n, int C, const float* __restrict__ a,
+                                                                     const float* __restrict__ b, void* __restrict__ Z,
+                                                                     int zrow, int col0) {
+  const int cv = C >> 3;
+  const long long total = n * cv;
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+    const long long r = t / cv;
+    const int c = (int)(t % cv) << 3;
+    float p[8], av[8], bv[8], o[8];
+    dec_ld8<PBF>(P, r * C + c, p);
+    dec_ld8<false>(a, c, av);
+    dec_ld8<false>(b, c, bv);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float h = fmaf(av[j], p[j], bv[j]);
+      o[j] = h > 0.f ? h : 0.f;
+    }
+    dec_st8<ZBF>(Z, (site ? (long long)site[r] : r) * zrow + col0 + c, o);
+  }
+}
+
+template <bool PBF, bool ZBF>
+__global__ __launch_bounds__(256) void k_rows_bwd_stats_v8(const void* __restrict__ P, const int* __restrict__ site, long long n,
+                                                           int C, const float* __restrict__ a, const float* __restrict__ b,
+                                                           const void* __restrict__ dZ, int zrow, int col0,
+                                                           float* __restrict__ part) {
+  extern __shared__ float sh[];  // (rows_per_iter, 3, C)
+  const int cv = C >> 3;                       // C <= 256 -> cv <= 32
+  const int rows_per_iter = 256 / cv;
+  const int tr = threadIdx.x / cv, c = (threadIdx.x % cv) << 3;
+  const long long chunk = (n + gridDim.x - 1) / gridDim.x;
+  const long long r0 = blockIdx.x * chunk, r1 = r0 + chunk < n ? r0 + chunk : n;
+  float s0[8], s1[8], s2[8], av[8], bv[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s0[j] = s1[j] = s2[j] = 0.f;
+  dec_ld8<false>(a, c, av);
+  dec_ld8<false>(b, c, bv);
+  for (long long r = r0 + tr; r < r1; r += rows_per_iter) {
+    float p[8], g[8];
+    dec_ld8<PBF>(P, r * C + c, p);
+    dec_ld8<ZBF>(dZ, (site ? (long long)site[r] : r) * zrow + col0 + c, g);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float dh = fmaf(av[j], p[j], bv[j]) > 0.f ? g[j] : 0.f;
+      s0[j] += dh;
+      s1[j] = fmaf(dh, p[j], s1[j]);
+      s2[j] += g[j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    sh[(tr * 3 + 0) * C + c + j] = s0[j];
+    sh[(tr * 3 + 1) * C + c + j] = s1[j];
+    sh[(tr * 3 + 2) * C + c + j] = s2[j];
+  }
+  __syncthreads();
+  for (int q = threadIdx.x; q < 3 * C; q += 256) {
+    float acc = 0.f;
+    for (int rr = 0; rr < rows_per_iter; ++rr) acc += sh[rr * 3 * C + q];
+    part[(long long)blockIdx.x * 3 * C + q] = acc;
+  }
+}
+
+template <bool PBF, bool ZBF, bool OBF>
+__global__ __launch_bounds__(256) void k_rows_bwd_v8(const void* __restrict__ P, const int* __restrict__ site, long long n, int C,
+                                                     const float* __restrict__ a, const float* __restrict__ b,
+                                                     const float* __restrict__ c0, const float* __restrict__ c1,
+                                                     const void* __restrict__ dZ, int zrow, int col0, void* __restrict__ dP) {
+  const int cv = C >> 3;
+  const long long total = n * cv;
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+    const long long r = t / cv;
+    const int c = (int)(t % cv) << 3;
+    float p[8], g[8], av[8], bv[8], k0[8], k1[8], o[8];
+    dec_ld8<PBF>(P, r * C + c, p);
+    dec_ld8<ZBF>(dZ, (site ? (long long)site[r] : r) * zrow + col0 + c, g);
+    dec_ld8<false>(a, c, av);
+    dec_ld8<false>(b, c, bv);
+    dec_ld8<false>(c0, c, k0);
+    dec_ld8<false>(c1, c, k1);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float dh = fmaf(av[j], p[j], bv[j]) > 0.f ? g[j] : 0.f;
+      o[j] = fmaf(av[j], dh, fmaf(k1[j], p[j], k0[j]));
+    }
+    dec_st8<OBF>(dP, r * C + c, o);
+  }
+}
+
 // C = 128 channels: a wavefront covers a row with 2 channels per lane
 template <bool PBF, bool ZBF>
 __global__ __launch_bounds__(256) void k_rows_affine_relu_scatter(const void* __restrict__ P, const int* __restrict__ site,
@@ -123,7 +246,13 @@ extern "C" int gdmae_rows_affine_relu_scatter(const void* P, int p_bf16, const i
   if (n <= 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid(dec_grid(n * C)), block(256);
-#define GD_LAUNCH(PB, ZB) hipLaunchKernelGGL((k_rows_affine_relu_scatter<PB, ZB>), grid, block, 0, st, P, site, n, C, a, b, Z, z_row_elems, col0)
+  const bool v8 = (C % 8 == 0) && (z_row_elems % 8 == 0) && (col0 % 8 == 0);
+  const dim3 grid8(dec_grid(n * C / 8));
+#define GD_LAUNCH(PB, ZB)                                                                                                         \
+  do {                                                                                                                            \
+    if (v8) hipLaunchKernelGGL((k_rows_affine_relu_scatter_v8<PB, ZB>), grid8, block, 0, st, P, site, n, C, a, b, Z, z_row_elems, col0); \
+    else hipLaunchKernelGGL((k_rows_affine_relu_scatter<PB, ZB>), grid, block, 0, st, P, site, n, C, a, b, Z, z_row_elems, col0);  \
+  } while (0)
   if (p_bf16) { if (z_bf16) GD_LAUNCH(true, true); else GD_LAUNCH(true, false); }
   else { if (z_bf16) GD_LAUNCH(false, true); else GD_LAUNCH(false, false); }
 #undef GD_LAUNCH
@@ -144,7 +273,13 @@ extern "C" int gdmae_rows_bwd_stats(const void* P, int p_bf16, const int* site, 
   const size_t lds = (size_t)rpi * 3 * C * sizeof(float);
   float* part = (float*)workspace;
   const dim3 grid(nblk), block(256);
-#define GD_LAUNCH(PB, ZB) hipLaunchKernelGGL((k_rows_bwd_stats<PB, ZB>), grid, block, lds, st, P, site, n, C, a, b, dZ, z_row_elems, col0, part)
+  const bool v8 = (C % 8 == 0) && (256 % (C / 8) == 0) && (z_row_elems % 8 == 0) && (col0 % 8 == 0);
+  const size_t lds8 = v8 ? (size_t)(256 / (C / 8)) * 3 * C * sizeof(float) : 0;
+#define GD_LAUNCH(PB, ZB)                                                                                                                 \
+  do {                                                                                                                                    \
+    if (v8) hipLaunchKernelGGL((k_rows_bwd_stats_v8<PB, ZB>), grid, block, lds8, st, P, site, n, C, a, b, dZ, z_row_elems, col0, part);    \
+    else hipLaunchKernelGGL((k_rows_bwd_stats<PB, ZB>), grid, block, lds, st, P, site, n, C, a, b, dZ, z_row_elems, col0, part);           \
+  } while (0)
   if (p_bf16) { if (z_bf16) GD_LAUNCH(true, true); else GD_LAUNCH(true, false); }
   else { if (z_bf16) GD_LAUNCH(false, true); else GD_LAUNCH(false, false); }
 #undef GD_LAUNCH
@@ -160,7 +295,13 @@ extern "C" int gdmae_rows_bwd(const void* P, int p_bf16, const int* site, long l
   if (n <= 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid(dec_grid(n * C)), block(256);
-#define GD_LAUNCH(PB, ZB, OB) hipLaunchKernelGGL((k_rows_bwd<PB, ZB, OB>), grid, block, 0, st, P, site, n, C, a, b, c0, c1, dZ, z_row_elems, col0, dP)
+  const bool v8 = (C % 8 == 0) && (z_row_elems % 8 == 0) && (col0 % 8 == 0);
+  const dim3 grid8(dec_grid(n * C / 8));
+#define GD_LAUNCH(PB, ZB, OB)                                                                                                                 \
+  do {                                                                                                                                        \
+    if (v8) hipLaunchKernelGGL((k_rows_bwd_v8<PB, ZB, OB>), grid8, block, 0, st, P, site, n, C, a, b, c0, c1, dZ, z_row_elems, col0, dP);      \
+    else hipLaunchKernelGGL((k_rows_bwd<PB, ZB, OB>), grid, block, 0, st, P, site, n, C, a, b, c0, c1, dZ, z_row_elems, col0, dP);             \
+  } while (0)
   if (p_bf16) {
     if (z_bf16) { if (dp_bf16) GD_LAUNCH(true, true, true); else GD_LAUNCH(true, true, false); }
     else { if (dp_bf16) GD_LAUNCH(true, false, true); else GD_LAUNCH(true, false, false); }
@@ -311,6 +452,37 @@ __global__ __launch_bounds__(256) void k_segmax_bn_bwd(const void* __restrict__ 
   }
 }
 
+// 8 channels per thread (C % 8 == 0): the pillar rows (out / arg / dout) are read as 32-byte vectors
+template <bool XBF, bool OBF>
+__global__ __launch_bounds__(256) void k_segmax_bn_bwd_v8(const void* __restrict__ x, const float* __restrict__ out,
+                                                          const int* __restrict__ arg, const float* __restrict__ dout,
+                                                          const int* __restrict__ inv, long long N, int C,
+                                                          const float* __restrict__ a, const float* __restrict__ c0,
+                                                          const float* __restrict__ c1, void* __restrict__ dx) {
+  const int cv = C >> 3;
+  const long long total = N * cv;
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+    const long long i = t / cv;
+    const int c = (int)(t % cv) << 3;
+    const long long q = (long long)inv[i] * C + c;
+    float xv[8], ov[8], gv[8], av[8], k0[8], k1[8], o[8];
+    dec_ld8<XBF>(x, i * C + c, xv);
+    dec_ld8<false>(out, q, ov);
+    dec_ld8<false>(dout, q, gv);
+    dec_ld8<false>(a, c, av);
+    dec_ld8<false>(c0, c, k0);
+    dec_ld8<false>(c1, c, k1);
+    const int4 a0 = *reinterpret_cast<const int4*>(arg + q), a1 = *reinterpret_cast<const int4*>(arg + q + 4);
+    const int ai[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float dh = (ai[j] == (int)i && ov[j] > 0.f) ? gv[j] : 0.f;
+      o[j] = fmaf(av[j], dh, fmaf(k1[j], xv[j], k0[j]));
+    }
+    dec_st8<OBF>(dx, i * C + c, o);
+  }
+}
+
 extern "C" int gdmae_segmax_bwd_stats(const void* x, int x_bf16, const float* out, const int* arg, const float* dout,
                                       long long M, int C, double* sums /* 2C: {sum dh, sum dh*x} */, void* workspace,
                                       void* stream) {
@@ -336,7 +508,13 @@ extern "C" int gdmae_segmax_bn_bwd(const void* x, int x_bf16, const float* out, 
   if (N <= 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid(dec_grid(N * C)), block(256);
-#define GD_SB(XB, OB) hipLaunchKernelGGL((k_segmax_bn_bwd<XB, OB>), grid, block, 0, st, x, out, arg, dout, inverse32, N, C, a, c0, c1, dx)
+  const bool v8 = C % 8 == 0;
+  const dim3 grid8(dec_grid(N * C / 8));
+#define GD_SB(XB, OB)                                                                                                              \
+  do {                                                                                                                             \
+    if (v8) hipLaunchKernelGGL((k_segmax_bn_bwd_v8<XB, OB>), grid8, block, 0, st, x, out, arg, dout, inverse32, N, C, a, c0, c1, dx); \
+    else hipLaunchKernelGGL((k_segmax_bn_bwd<XB, OB>), grid, block, 0, st, x, out, arg, dout, inverse32, N, C, a, c0, c1, dx);      \
+  } while (0)
   if (x_bf16) { if (dx_bf16) GD_SB(true, true); else GD_SB(true, false); }
   else { if (dx_bf16) GD_SB(false, true); else GD_SB(false, false); }
 #undef GD_SB
