@@ -607,3 +607,111 @@ extern "C" int gdmae_conv3x3_grad_taps(const void* Ymap, int y_bf16, const float
   GD_LAUNCH_CHECK();
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------
+// Border-region sums for the closed-form background share of the 3x3 conv backward (gdmae_hip/decoder.py):
+//   regions 1..8 = row 0, row H-1, column 0, column W-1, corners (0,0), (0,W-1), (H-1,0), (H-1,W-1)
+//   out[r-1][c]     = sum of Y[b, y, x, c] over the sites of region r                (r = 1..8)
+//   out[8 + r-1][c] = sum of rows[p, c] over the pillars whose cell lies in region r
+// Deterministic (fixed summation order).  k_border_partial: blocks [0, 4B) = one (edge, batch) each, blocks
+// 4B, 4B+1 = four wavefronts each, one wavefront per pillar region (ballot scan of the pillar list).
+// ------------------------------------------------------------------------------------------
+template <bool BF>
+__global__ __launch_bounds__(256) void k_border_partial(const void* __restrict__ Y, const float* __restrict__ rows,
+                                                        const int* __restrict__ pillar_cell, int M, int B, int H, int W, int C,
+                                                        float* __restrict__ part_edge, float* __restrict__ part_rows) {
+  extern __shared__ float sh[];
+  const int cv = C >> 3;
+  if ((int)blockIdx.x < 4 * B) {
+    const int e = blockIdx.x / B, b = blockIdx.x % B;      // e: 0 = row 0, 1 = row H-1, 2 = col 0, 3 = col W-1
+    const int len = e < 2 ? W : H;
+    const int slots = 256 / cv;
+    const int tr = threadIdx.x / cv, c = (threadIdx.x % cv) << 3;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    if (tr < slots)
+      for (int i = tr; i < len; i += slots) {
+        const int y = e == 0 ? 0 : (e == 1 ? H - 1 : i);
+        const int x = e == 2 ? 0 : (e == 3 ? W - 1 : i);
+        float v[8];
+        dec_ld8<BF>(Y, ((long long)(b * H + y) * W + x) * C + c, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += v[j];
+      }
+    if (tr < slots) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sh[tr * C + c + j] = acc[j];
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < C; q += 256) {
+      float s = 0.f;
+      for (int r = 0; r < slots; ++r) s += sh[r * C + q];
+      part_edge[(long long)blockIdx.x * C + q] = s;
+    }
+    return;
+  }
+  // pillar rows: one wavefront per region; lanes own channels lane, lane + 64, ...
+  const int lane = threadIdx.x & 63;
+  const int reg = ((int)blockIdx.x - 4 * B) * 4 + (threadIdx.x >> 6);   // 0..7
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};                                   // C <= 256
+  for (int p0 = 0; p0 < M; p0 += 64) {
+    const int p = p0 + lane;
+    bool in = false;
+    if (p < M) {
+      const int cell = pillar_cell[p];
+      const int x = cell % W, y = (cell / W) % H;
+      const bool y0 = y == 0, yl = y == H - 1, x0 = x == 0, xl = x == W - 1;
+      in = reg == 0 ? y0 : reg == 1 ? yl : reg == 2 ? x0 : reg == 3 ? xl : reg == 4 ? (y0 && x0) : reg == 5 ? (y0 && xl)
+                                                                         : reg == 6 ? (yl && x0) : (yl && xl);
+    }
+    unsigned long long m = __ballot(in);
+    while (m) {
+      const int k = __ffsll((long long)m) - 1;
+      m &= m - 1;
+      const float* rp = rows + (long long)(p0 + k) * C;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (lane + 64 * j < C) acc[j] += rp[lane + 64 * j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (lane + 64 * j < C) part_rows[reg * C + lane + 64 * j] = acc[j];
+}
+
+template <bool BF>
+__global__ __launch_bounds__(256) void k_border_final(const void* __restrict__ Y, const float* __restrict__ part_edge,
+                                                      const float* __restrict__ part_rows, int B, int H, int W, int C,
+                                                      double* __restrict__ out) {
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < 8 * C; q += gridDim.x * blockDim.x) {
+    const int r = q / C, c = q % C;
+    double s = 0.0;
+    if (r < 4) {
+      for (int b = 0; b < B; ++b) s += (double)part_edge[(long long)(r * B + b) * C + c];
+    } else {
+      const int y = (r == 4 || r == 5) ? 0 : H - 1, x = (r == 4 || r == 6) ? 0 : W - 1;
+      for (int b = 0; b < B; ++b) s += (double)dec_ld<BF>(Y, ((long long)(b * H + y) * W + x) * C + c);
+    }
+    out[q] = s;
+    out[8 * C + q] = (double)part_rows[q];
+  }
+}
+
+extern "C" size_t gdmae_border_sums_workspace_bytes(int B, int C) { return (size_t)(4 * B + 8) * C * sizeof(float); }
+
+extern "C" int gdmae_border_sums(const void* Y, int y_bf16, const float* rows, const int* pillar_cell, int M, int B, int H, int W,
+                                 int C, double* out /* [16][C] */, void* workspace, void* stream) {
+  GD_REQUIRE(C % 8 == 0 && C <= 256 && 256 % (C / 8) == 0, "border_sums: C in {64, 128, 256}");
+  hipStream_t st = (hipStream_t)stream;
+  float* part_edge = (float*)workspace;
+  float* part_rows = part_edge + (size_t)4 * B * C;
+  const size_t lds = (size_t)(256 / (C / 8)) * C * sizeof(float);
+  if (y_bf16) hipLaunchKernelGGL((k_border_partial<true>), dim3(4 * B + 2), dim3(256), lds, st, Y, rows, pillar_cell, M, B, H, W, C, part_edge, part_rows);
+  else hipLaunchKernelGGL((k_border_partial<false>), dim3(4 * B + 2), dim3(256), lds, st, Y, rows, pillar_cell, M, B, H, W, C, part_edge, part_rows);
+  GD_LAUNCH_CHECK();
+  if (y_bf16) hipLaunchKernelGGL((k_border_final<true>), dim3(gd_div_up(8 * C, 256)), dim3(256), 0, st, Y, part_edge, part_rows, B, H, W, C, out);
+  else hipLaunchKernelGGL((k_border_final<false>), dim3(gd_div_up(8 * C, 256)), dim3(256), 0, st, Y, part_edge, part_rows, B, H, W, C, out);
+  GD_LAUNCH_CHECK();
+  return 0;
+}

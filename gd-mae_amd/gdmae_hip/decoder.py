@@ -183,16 +183,13 @@ class DecoderHead(torch.autograd.Function):
                L.ptr(dout), 0, C2, 0, L.ptr(rows), 0, L.stream())
         k0, k1 = k01[:C2].double(), k01[C2:].double()
         # ---- region sums of dY (all / border rows / border columns / corners) -> S_k per tap
-        Yv = y2.view(B, H, W, C2)
-        regY = torch.stack([stats2[:C2] * R, Yv[:, 0].sum((0, 1), dtype=f64), Yv[:, H - 1].sum((0, 1), dtype=f64),
-                            Yv[:, :, 0].sum((0, 1), dtype=f64), Yv[:, :, W - 1].sum((0, 1), dtype=f64),
-                            Yv[:, 0, 0].sum(0, dtype=f64), Yv[:, 0, W - 1].sum(0, dtype=f64),
-                            Yv[:, H - 1, 0].sum(0, dtype=f64), Yv[:, H - 1, W - 1].sum(0, dtype=f64)])
-        px = pillar_cell % W
-        py = torch.div(pillar_cell, W, rounding_mode='floor') % H
-        y0, yl, x0, xl = py == 0, py == H - 1, px == 0, px == W - 1
-        pm = torch.stack([torch.ones_like(y0), y0, yl, x0, xl, y0 & x0, y0 & xl, yl & x0, yl & xl]).to(rows.dtype)
-        regR = (pm @ rows).double()
+        reg = torch.empty(16, C2, dtype=f64, device=dev)
+        ws = torch.empty(L.load().gdmae_border_sums_workspace_bytes(B, C2), dtype=torch.uint8, device=dev)
+        L.call("gdmae_border_sums", L.ptr(y2), _bf(y2), L.ptr(rows), L.ptr(pillar_cell), M, B, H, W, C2, L.ptr(reg), L.ptr(ws),
+               L.stream())
+        # region 0 = all sites: sum Y = mean * R;  sum rows = a * sum dh
+        regY = torch.cat([(stats2[:C2] * R)[None], reg[:8]])
+        regR = torch.cat([(ab2[:C2].double() * st2[:C2])[None], reg[8:]])
         tap_region, cnt = _region_consts(dev, B, H, W)
         regD = cnt[:, None] * k0[None, :] + regY * k1[None, :] + regR
         S = tap_region @ regD                                     # (9, C2)

@@ -173,6 +173,13 @@ int gdmae_conv3x3_grad_taps(const void* Y, int y_bf16, const float* k0, const fl
                             const int* cell2pillar, const int* site, long long n, int H, int W, int C, void* out,
                             void* stream);
 
+/* Border-region sums for the closed-form background share of that backward.  Regions 1..8 = row 0, row H-1,
+ * column 0, column W-1, corners (0,0), (0,W-1), (H-1,0), (H-1,W-1) of every H x W map:
+ * out[r-1][c] = sum of Y over the sites of region r; out[8+r-1][c] = sum of rows[p] over the pillars in region r. */
+size_t gdmae_border_sums_workspace_bytes(int B, int C);
+int gdmae_border_sums(const void* Y, int y_bf16, const float* rows, const int* pillar_cell, int M, int B, int H, int W, int C,
+                      double* out, void* workspace, void* stream);
+
 /* The three row kernels above also serve BatchNorm1d + ReLU of the DynVFE point MLP (site = NULL: identity rows,
  * Z/dZ = a plain (n, C) matrix with z_row_elems = C, col0 = 0).  Fused DynVFE tail (dyn_vfe.py:107-109):
  *   gdmae_segment_max_affine: out[p,c] = max_{i in pillar p} relu(a_c x[i,c] + b_c), arg = arg-max point id

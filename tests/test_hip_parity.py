@@ -630,3 +630,32 @@ def test_bench_mode_gradients_reach_every_parameter(name):
     tol = np.array([np.inf if k.endswith("tau") else 0.12 for k in names])
     assert np.isfinite(gn).all()
     assert (rel <= tol).all(), [(names[i], rel[i]) for i in np.flatnonzero(rel > tol)]
+
+
+@pytest.mark.parametrize("bdt", [torch.float32, torch.bfloat16])
+def test_border_sums_match_torch(bdt):
+    """gdmae_border_sums (edge / corner sums of the conv output map and of the pillar rows on the border)."""
+    from gdmae_hip import lib as L
+    torch.manual_seed(5)
+    B, H, W, C = 3, 20, 28, 128
+    Y = torch.randn(B, H, W, C, device=dev()).to(bdt)
+    cells = torch.randperm(B * H * W, device=dev())[:700].sort().values.int()
+    cells = torch.unique(torch.cat([cells, torch.tensor([0, W - 1, (H - 1) * W, H * W - 1, H * W + 5, 2 * H * W + W * 3],
+                                                        device=dev(), dtype=torch.int32)])).int()
+    M = cells.numel()
+    rows = torch.randn(M, C, device=dev())
+    out = torch.empty(16, C, dtype=torch.float64, device=dev())
+    ws = torch.empty(L.load().gdmae_border_sums_workspace_bytes(B, C), dtype=torch.uint8, device=dev())
+    L.call("gdmae_border_sums", L.ptr(Y.view(-1, C)), int(bdt == torch.bfloat16), L.ptr(rows), L.ptr(cells), M, B, H, W, C, L.ptr(out),
+           L.ptr(ws), L.stream())
+    Yd = Y.double()
+    refY = torch.stack([Yd[:, 0].sum((0, 1)), Yd[:, H - 1].sum((0, 1)), Yd[:, :, 0].sum((0, 1)), Yd[:, :, W - 1].sum((0, 1)),
+                        Yd[:, 0, 0].sum(0), Yd[:, 0, W - 1].sum(0), Yd[:, H - 1, 0].sum(0), Yd[:, H - 1, W - 1].sum(0)])
+    x = cells.long() % W
+    y = (cells.long() // W) % H
+    y0, yl, x0, xl = y == 0, y == H - 1, x == 0, x == W - 1
+    masks = torch.stack([y0, yl, x0, xl, y0 & x0, y0 & xl, yl & x0, yl & xl]).double()
+    refR = masks @ rows.double()
+    assert int(masks.sum()) > 20
+    assert torch.allclose(out[:8], refY, rtol=1e-5, atol=1e-4)
+    assert torch.allclose(out[8:], refR, rtol=1e-5, atol=1e-4)
