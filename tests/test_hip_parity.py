@@ -274,12 +274,15 @@ def test_window_attention_fwd_bwd_matches_oracle(d, nhead, impl):
     L.call("gdmae_set_attention_impl", 0)
 
 
-def test_chamfer_matches_oracle():
+@pytest.mark.parametrize("P1,P2", [(16, 64), (16, 40), (8, 64), (24, 33)])
+def test_chamfer_matches_oracle(P1, P2):
+    """(16, *) is the NUM_PRD_POINTS = 16 fast path (transposed-butterfly minima), the others the generic kernel."""
     from gdmae_hip import ops
     g = torch.Generator().manual_seed(2)
     M = 777
-    pred = torch.randn(M, 16, 3, generator=g)
-    gt = torch.randn(M, 64, 3, generator=g)
+    pred = torch.randn(M, P1, 3, generator=g)
+    gt = torch.randn(M, P2, 3, generator=g)
+    gt[5, 1] = gt[5, 0]                     # exact tie between two ground-truth points -> lowest index wins
     w = (torch.rand(M, generator=g) < 0.8).float()
     pr = pred.clone().requires_grad_(True)
     ref, _ = tp.chamfer_distance(pr, gt, w)
