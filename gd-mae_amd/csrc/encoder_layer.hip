@@ -130,10 +130,60 @@ __global__ __launch_bounds__(256) void k_gelu_bwd(const void* __restrict__ dg, c
   }
 }
 
-// dst[c] += (float)src[c]   (src: fp64 column sums from gdmae_colstats)
-__global__ __launch_bounds__(256) void k_acc_f64(const double* __restrict__ src, int C, float* __restrict__ dst) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c < C) dst[c] += (float)src[c];
+// Bias gradients of the three GEMM groups of the layer in ONE launch pair: column sums of the first n rows of up to
+// 4 matrices (job = blockIdx.y), fp32 partials per row chunk, then one wavefront per column accumulates into dst.
+struct ColsumJobs {
+  const void* x[4];
+  float* dst[4];
+  int C[4];
+  int count;
+};
+template <bool BF>
+__global__ __launch_bounds__(256) void k_colsum_jobs_partial(ColsumJobs J, long long n, float* __restrict__ part, int cmax) {
+  extern __shared__ float sh[];
+  const int job = blockIdx.y;
+  const int C = J.C[job];
+  const int cv = C >> 3;                       // C in {64, ..., 2048}, cv divides 256
+  const int rpi = 256 / cv;
+  const int tr = threadIdx.x / cv, c = (threadIdx.x % cv) << 3;
+  const long long chunk = (n + gridDim.x - 1) / gridDim.x;
+  const long long r0 = blockIdx.x * chunk, r1 = r0 + chunk < n ? r0 + chunk : n;
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  for (long long r = r0 + tr; r < r1; r += rpi) {
+    if (BF) {
+      const uint4 q = *reinterpret_cast<const uint4*>((const unsigned short*)J.x[job] + r * C + c);
+      const unsigned w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { acc[2 * j] += __uint_as_float(w[j] << 16); acc[2 * j + 1] += __uint_as_float(w[j] & 0xFFFF0000u); }
+    } else {
+      const float4 a = *reinterpret_cast<const float4*>((const float*)J.x[job] + r * C + c);
+      const float4 b = *reinterpret_cast<const float4*>((const float*)J.x[job] + r * C + c + 4);
+      acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w; acc[4] += b.x; acc[5] += b.y; acc[6] += b.z; acc[7] += b.w;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) sh[tr * C + c + j] = acc[j];
+  __syncthreads();
+  float* dstp = part + ((long long)job * gridDim.x + blockIdx.x) * cmax;
+  for (int q = threadIdx.x; q < C; q += 256) {
+    float s = 0.f;
+    for (int rr = 0; rr < rpi; ++rr) s += sh[rr * C + q];
+    dstp[q] = s;
+  }
+}
+__global__ __launch_bounds__(256) void k_colsum_jobs_final(ColsumJobs J, const float* __restrict__ part, int nblk, int cmax) {
+  const int lane = threadIdx.x & 63;
+  int col = blockIdx.x * 4 + (threadIdx.x >> 6);     // global column over the concatenated jobs
+  int job = 0;
+  while (job < J.count && col >= J.C[job]) { col -= J.C[job]; ++job; }
+  if (job >= J.count) return;
+  double acc = 0.0;
+  for (int b = lane; b < nblk; b += 64) acc += (double)part[((long long)job * nblk + b) * cmax + col];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+  if (lane == 0) J.dst[job][col] += (float)acc;
 }
 
 // dst[i] += sum_s part[s * P + i]   (P % 4 == 0).  64 float4 columns x 4 slices of S per workgroup: every lane
@@ -316,12 +366,21 @@ int linear_dw(const Ctx& c, const void* G, const void* X, float* dW, long long n
   GD_LAUNCH_CHECK();
   return 0;
 }
-// dst (C) += column sums of the first n rows of x (rows of C elements)
-int colsum_acc(const Ctx& c, const void* x, long long n, int C, float* dst, char* cs) {
-  double* out = (double*)cs;                       // [2C] doubles, then the colstats workspace
-  char* ws = cs + gd_align((size_t)2 * C * sizeof(double));
-  GD_TRY(gdmae_colstats(x, n, C, c.es == 2, out, ws, c.st));
-  hipLaunchKernelGGL(k_acc_f64, dim3((C + 255) / 256), dim3(256), 0, c.st, out, C, dst);
+constexpr int kColsumBlocks = 128;
+int colsum_jobs(const Ctx& c, ColsumJobs& J, long long n, int cmax, float* part) {
+  size_t lds = 0;
+  int ctot = 0;
+  for (int j = 0; j < J.count; ++j) {
+    GD_REQUIRE(J.C[j] % 8 == 0 && 256 % (J.C[j] / 8) == 0 && J.C[j] <= cmax, "colsum_jobs: unsupported width");
+    const size_t l = (size_t)(256 / (J.C[j] / 8)) * J.C[j] * sizeof(float);
+    lds = l > lds ? l : lds;
+    ctot += J.C[j];
+  }
+  const dim3 grid(kColsumBlocks, J.count);
+  if (c.es == 2) hipLaunchKernelGGL((k_colsum_jobs_partial<true>), grid, dim3(256), lds, c.st, J, n, part, cmax);
+  else hipLaunchKernelGGL((k_colsum_jobs_partial<false>), grid, dim3(256), lds, c.st, J, n, part, cmax);
+  GD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_colsum_jobs_final, dim3((ctot + 3) / 4), dim3(256), 0, c.st, J, (const float*)part, kColsumBlocks, cmax);
   GD_LAUNCH_CHECK();
   return 0;
 }
@@ -395,7 +454,7 @@ Scratch scratch_layout(void* base, long long n_pad, int d, int ff, int es, long 
   s.ln_ws = take(gdmae_add_layernorm_workspace_bytes(d));
   {
     const int cm = ff > 2 * d ? ff : 2 * d;
-    s.cs_part = take(gd_align((size_t)2 * cm * sizeof(double)) + gdmae_colstats_workspace_bytes(cm));
+    s.cs_part = take((size_t)3 * kColsumBlocks * cm * sizeof(float));
   }
   s.bytes = off;
   return s;
@@ -482,7 +541,6 @@ extern "C" int gdmae_encoder_layer_bwd(const gdmae_layer_args* a, void* stream) 
   GD_TRY(linear_dw(c, w.dfb, s.gact, a->dW2, n_pad, d, ff, (float*)w.part));
   GD_TRY(linear_dx(c, w.dfb, a->W2, w.dg, n_pad, d, ff));
   GD_TRY(gelu(c, false, w.dg, s.h, w.dh, n_pad * ff));
-  GD_TRY(colsum_acc(c, w.dh, n, ff, a->db1, w.cs_part));
   GD_TRY(linear_dw(c, w.dh, s.x1b, a->dW1, n_pad, ff, d, (float*)w.part));
   GD_TRY(linear_dx(c, w.dh, a->W1, w.dx1_b, n_pad, ff, d));
   // ---- LN1 (gradient = residual branch + FFN branch) and out-projection
@@ -505,8 +563,14 @@ extern "C" int gdmae_encoder_layer_bwd(const gdmae_layer_args* a, void* stream) 
   const char* Win = (const char*)a->Win;
   GD_TRY(linear_dw(c, w.dqk, s.xpb, a->dWin, n_pad, 2 * d, d, (float*)w.part));
   GD_TRY(linear_dw(c, w.dv, s.xb, a->dWin + (size_t)2 * d * d, n_pad, d, d, (float*)w.part));
-  GD_TRY(colsum_acc(c, w.dqk, n, 2 * d, a->dbin, w.cs_part));
-  GD_TRY(colsum_acc(c, w.dv, n, d, a->dbin + 2 * d, w.cs_part));
+  {
+    ColsumJobs J;
+    J.count = 3;
+    J.x[0] = w.dh;  J.dst[0] = a->db1;           J.C[0] = ff;
+    J.x[1] = w.dqk; J.dst[1] = a->dbin;          J.C[1] = 2 * d;
+    J.x[2] = w.dv;  J.dst[2] = a->dbin + 2 * d;  J.C[2] = d;
+    GD_TRY(colsum_jobs(c, J, n, ff > 2 * d ? ff : 2 * d, (float*)w.cs_part));
+  }
   GD_TRY(linear_dx(c, w.dqk, Win, w.dx_qk, n_pad, 2 * d, d));
   GD_TRY(linear_dx(c, w.dv, Win + (size_t)2 * d * d * es, w.dx_v, n_pad, d, d));
   GD_TRY(gdmae_add3((const float*)w.dx_res, w.dx_qk, a->bf16, w.dx_v, a->bf16, n * d, a->dx, stream));

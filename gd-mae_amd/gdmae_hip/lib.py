@@ -52,7 +52,7 @@ SIGNATURES = {
     "gdmae_conv3x3_grad_taps": (_I, [_P, _I, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P, _P]),
     "gdmae_rows_bwd": (_I, [_P, _I, _P, _L, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P, _I, _P]),
     "gdmae_segment_max_affine": (_I, [_P, _I, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
-    "gdmae_segmax_bwd_stats": (_I, [_P, _I, _P, _P, _P, _L, _I, _P, _P, _P]),
+    "gdmae_segmax_bwd_stats": (_I, [_P, _I, _P, _P, _P, _L, _I, _P, _P, _P, _P, _P]),
     "gdmae_segmax_bn_bwd": (_I, [_P, _I, _P, _P, _P, _P, _L, _I, _P, _P, _P, _P, _I, _P]),
     "gdmae_window_attention_fwd": (_I, [_P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P, _F, _P]),
     "gdmae_window_attention_bwd": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P, _F, _P]),

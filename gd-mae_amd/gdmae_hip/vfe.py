@@ -82,7 +82,8 @@ class BNReLUSegmentMax(torch.autograd.Function):
         g = g.float().contiguous()
         st = torch.empty(2 * C, dtype=torch.float64, device=x.device)
         ws = torch.empty(L.load().gdmae_rows_bwd_stats_workspace_bytes(C), dtype=torch.uint8, device=x.device)
-        L.call("gdmae_segmax_bwd_stats", L.ptr(x), _bf(x), L.ptr(out), L.ptr(arg), L.ptr(g), M, C, L.ptr(st), L.ptr(ws), L.stream())
+        L.call("gdmae_segmax_bwd_stats", L.ptr(x), _bf(x), L.ptr(out), L.ptr(arg), L.ptr(g), M, C, L.ptr(ab), L.ptr(ab[C:]),
+               L.ptr(st), L.ptr(ws), L.stream())
         dgamma, dbeta, c01 = gbn.bwd_coeffs(st, 2, stats, ab, gamma, n, None, ctx.direct)
         dx = torch.empty_like(x)
         L.call("gdmae_segmax_bn_bwd", L.ptr(x), _bf(x), L.ptr(out), L.ptr(arg), L.ptr(g), L.ptr(inv), n, C, L.ptr(ab), L.ptr(c01),

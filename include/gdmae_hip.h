@@ -188,7 +188,8 @@ int gdmae_border_sums(const void* Y, int y_bf16, const float* rows, const int* p
 int gdmae_segment_max_affine(const void* x, int x_bf16, const int* pillar_pt_off, const int* pillar_pts, int M, int C,
                              const float* a, const float* b, float* out, int* arg, void* stream);
 int gdmae_segmax_bwd_stats(const void* x, int x_bf16, const float* out, const int* arg, const float* dout, long long M,
-                           int C, double* sums, void* workspace, void* stream);
+                           int C, const float* a /* optional: the forward's affine, lets x = (out-b)/a */,
+                           const float* b, double* sums, void* workspace, void* stream);
 int gdmae_segmax_bn_bwd(const void* x, int x_bf16, const float* out, const int* arg, const float* dout,
                         const int* inverse32, long long N, int C, const float* a, const float* c0, const float* c1,
                         void* dx, int dx_bf16, void* stream);
