@@ -10,21 +10,14 @@
 //  * the GEMM shapes repeat from step to step (token counts differ per batch; hipBLASLt heuristics are cached), and
 //  * every weight gradient g^T x is ONE batched split-K GEMM over equal K chunks + one reduce-accumulate kernel.
 // Parameter gradients are ACCUMULATED into the caller's fp32 buffers (flat optimizer buffer or zeroed temporaries).
-#include <hipblaslt/hipblaslt.h>
-
-#include <stdlib.h>
-
-#include <map>
-#include <mutex>
-#include <tuple>
-
 #include "../../include/gdmae_hip.h"
 #include "common.h"
+#include "gemm.h"
 
 namespace {
 
 constexpr long long kPad = 2048;
-constexpr size_t kLtWorkspace = 32u << 20;
+constexpr size_t kLtWorkspace = GD_LT_WORKSPACE;
 
 __device__ inline float el_bf2f(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
 __device__ inline unsigned short el_f2bf(float f) {
@@ -186,144 +179,6 @@ __global__ __launch_bounds__(256) void k_colsum_jobs_final(ColsumJobs J, const f
   if (lane == 0) J.dst[job][col] += (float)acc;
 }
 
-// dst[i] += sum_s part[s * P + i]   (P % 4 == 0).  64 float4 columns x 4 slices of S per workgroup: every lane
-// streams S/4 independent 16-byte loads, the 4 slices meet in LDS (fixed order -> deterministic).
-__global__ __launch_bounds__(256) void k_splitk_acc(const float* __restrict__ part, int S, long long P4, float* __restrict__ dst) {
-  __shared__ float4 sh[3][64];
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const long long i = blockIdx.x * 64ll + tx;
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (i < P4) {
-    const int s0 = (S * ty) / 4, s1 = (S * (ty + 1)) / 4;
-    const float4* p = (const float4*)part + i;
-#pragma unroll 4
-    for (int s = s0; s < s1; ++s) {
-      const float4 v = p[(long long)s * P4];
-      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-    }
-  }
-  if (ty > 0) sh[ty - 1][tx] = acc;
-  __syncthreads();
-  if (ty == 0 && i < P4) {
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { const float4 v = sh[k][tx]; acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
-    float4 d = ((float4*)dst)[i];
-    d.x += acc.x; d.y += acc.y; d.z += acc.z; d.w += acc.w;
-    ((float4*)dst)[i] = d;
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// hipBLASLt GEMM with a per-shape algorithm cache (column-major semantics: C(MxN) = op(A) op(B) [+ bias(M)])
-// ------------------------------------------------------------------------------------------
-struct GemmPlan {
-  hipblasLtMatmulDesc_t desc = nullptr;
-  hipblasLtMatrixLayout_t la = nullptr, lb = nullptr, lc = nullptr;
-  hipblasLtMatmulAlgo_t algo;
-  size_t ws = 0;
-};
-typedef std::tuple<int, int, int, int, int, int, int, int, int, int, int, int> GemmKey;
-
-hipblasLtHandle_t g_lt = nullptr;
-std::map<GemmKey, GemmPlan> g_plans;
-std::mutex g_lt_mu;
-
-#define LT_CHECK(x)                                                         \
-  do {                                                                      \
-    hipblasStatus_t s_ = (x);                                               \
-    if (s_ != HIPBLAS_STATUS_SUCCESS) {                                     \
-      gd_set_error(1000 + (int)s_, __FILE__, __LINE__, "hipBLASLt: " #x);   \
-      return 1000 + (int)s_;                                                \
-    }                                                                       \
-  } while (0)
-
-int gd_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
-            hipDataType tab, hipDataType tc, const void* bias, int batch, long long sA, long long sB, long long sC, void* ws,
-            size_t ws_bytes) {
-  std::lock_guard<std::mutex> lock(g_lt_mu);
-  if (!g_lt) LT_CHECK(hipblasLtCreate(&g_lt));
-  const GemmKey key((int)ta, (int)tb, M, N, K, lda, ldb, ldc, (int)tab, (int)tc, bias ? 1 : 0, batch);
-  auto it = g_plans.find(key);
-  if (it == g_plans.end()) {
-    GemmPlan p;
-    LT_CHECK(hipblasLtMatmulDescCreate(&p.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F));
-    const int32_t opa = ta ? HIPBLAS_OP_T : HIPBLAS_OP_N, opb = tb ? HIPBLAS_OP_T : HIPBLAS_OP_N;
-    LT_CHECK(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_TRANSA, &opa, sizeof(opa)));
-    LT_CHECK(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_TRANSB, &opb, sizeof(opb)));
-    if (bias) {
-      const uint32_t epi = HIPBLASLT_EPILOGUE_BIAS;
-      LT_CHECK(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_EPILOGUE, &epi, sizeof(epi)));
-      const int32_t bt = (int32_t)tc;   // bias in the output dtype (bf16 shadow / fp32 master)
-      LT_CHECK(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_DATA_TYPE, &bt, sizeof(bt)));
-      LT_CHECK(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias)));
-    }
-    LT_CHECK(hipblasLtMatrixLayoutCreate(&p.la, tab, ta ? K : M, ta ? M : K, lda));
-    LT_CHECK(hipblasLtMatrixLayoutCreate(&p.lb, tab, tb ? N : K, tb ? K : N, ldb));
-    LT_CHECK(hipblasLtMatrixLayoutCreate(&p.lc, tc, M, N, ldc));
-    if (batch > 1) {
-      const int32_t bc = batch;
-      const int64_t s_a = sA, s_b = sB, s_c = sC;
-      LT_CHECK(hipblasLtMatrixLayoutSetAttribute(p.la, HIPBLASLT_MATRIX_LAYOUT_BATCH_COUNT, &bc, sizeof(bc)));
-      LT_CHECK(hipblasLtMatrixLayoutSetAttribute(p.lb, HIPBLASLT_MATRIX_LAYOUT_BATCH_COUNT, &bc, sizeof(bc)));
-      LT_CHECK(hipblasLtMatrixLayoutSetAttribute(p.lc, HIPBLASLT_MATRIX_LAYOUT_BATCH_COUNT, &bc, sizeof(bc)));
-      LT_CHECK(hipblasLtMatrixLayoutSetAttribute(p.la, HIPBLASLT_MATRIX_LAYOUT_STRIDED_BATCH_OFFSET, &s_a, sizeof(s_a)));
-      LT_CHECK(hipblasLtMatrixLayoutSetAttribute(p.lb, HIPBLASLT_MATRIX_LAYOUT_STRIDED_BATCH_OFFSET, &s_b, sizeof(s_b)));
-      LT_CHECK(hipblasLtMatrixLayoutSetAttribute(p.lc, HIPBLASLT_MATRIX_LAYOUT_STRIDED_BATCH_OFFSET, &s_c, sizeof(s_c)));
-    }
-    hipblasLtMatmulPreference_t pref;
-    LT_CHECK(hipblasLtMatmulPreferenceCreate(&pref));
-    const uint64_t wsz = ws_bytes;
-    LT_CHECK(hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &wsz, sizeof(wsz)));
-    // First use of a shape: ask for several candidate algorithms and time them on the caller's buffers (the GEMM is
-    // idempotent: beta = 0).  The heuristic's first choice is tuned for large square problems; these are tall-skinny
-    // (20-40 k rows, K and N of 128-512) and the best candidate is often not the first.  Shapes repeat (rows are
-    // padded to 2048), so the one-off cost (a few ms, with stream syncs) is paid during warm-up only.
-    constexpr int kMaxAlgo = 16;
-    hipblasLtMatmulHeuristicResult_t res[kMaxAlgo];
-    int found = 0;
-    static const bool tune = !(getenv("GDMAE_GEMM_TUNE") && atoi(getenv("GDMAE_GEMM_TUNE")) == 0);
-    LT_CHECK(hipblasLtMatmulAlgoGetHeuristic(g_lt, p.desc, p.la, p.lb, p.lc, p.lc, pref, tune ? kMaxAlgo : 1, res, &found));
-    hipblasLtMatmulPreferenceDestroy(pref);
-    if (found < 1) {
-      gd_set_error(-2, __FILE__, __LINE__, "hipBLASLt: no algorithm for this GEMM shape");
-      return -2;
-    }
-    int best = 0;
-    if (found > 1) {
-      const float alpha = 1.f, beta = 0.f;
-      hipEvent_t e0, e1;
-      GD_CHECK(hipEventCreate(&e0));
-      GD_CHECK(hipEventCreate(&e1));
-      float best_ms = 1e30f;
-      for (int i = 0; i < found; ++i) {
-        if (res[i].workspaceSize > ws_bytes) continue;
-        bool ok = true;
-        for (int rep = 0; rep < 4 && ok; ++rep) {     // rep 0 = warm-up
-          if (rep == 1) hipEventRecord(e0, st);
-          ok = hipblasLtMatmul(g_lt, p.desc, &alpha, A, p.la, B, p.lb, &beta, C, p.lc, C, p.lc, &res[i].algo, ws, res[i].workspaceSize,
-                               st) == HIPBLAS_STATUS_SUCCESS;
-        }
-        if (!ok) continue;
-        hipEventRecord(e1, st);
-        GD_CHECK(hipEventSynchronize(e1));
-        float ms = 0.f;
-        hipEventElapsedTime(&ms, e0, e1);
-        if (ms < best_ms) { best_ms = ms; best = i; }
-      }
-      hipEventDestroy(e0);
-      hipEventDestroy(e1);
-    }
-    p.algo = res[best].algo;
-    p.ws = res[best].workspaceSize;
-    it = g_plans.emplace(key, p).first;
-  }
-  GemmPlan& p = it->second;
-  if (bias) LT_CHECK(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias)));
-  const float alpha = 1.f, beta = 0.f;
-  LT_CHECK(hipblasLtMatmul(g_lt, p.desc, &alpha, A, p.la, B, p.lb, &beta, C, p.lc, C, p.lc, &p.algo, ws, p.ws <= ws_bytes ? p.ws : ws_bytes, st));
-  return 0;
-}
-
 #define GD_TRY(x)          \
   do {                     \
     int rc_ = (x);         \
@@ -361,9 +216,7 @@ int linear_dw(const Ctx& c, const void* G, const void* X, float* dW, long long n
   const long long kc = n_pad / S;
   GD_TRY(gd_gemm(c.st, false, true, k, m, (int)kc, X, k, G, m, part, k, c.ty, HIP_R_32F, nullptr, S, kc * k, kc * m, (long long)m * k,
                  c.lt_ws, kLtWorkspace));
-  const long long P4 = (long long)m * k / 4;
-  hipLaunchKernelGGL(k_splitk_acc, dim3((int)((P4 + 63) / 64)), dim3(256), 0, c.st, part, S, P4, dW);
-  GD_LAUNCH_CHECK();
+  GD_TRY(gd_splitk_acc(c.st, part, S, (long long)m * k, dW, 1));
   return 0;
 }
 constexpr int kColsumBlocks = 128;

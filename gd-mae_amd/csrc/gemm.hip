@@ -1,0 +1,266 @@
+// hipBLASLt front end: every library GEMM of the path goes through here (the encoder-layer executor directly, the
+// interpreter-issued parts through the row-major C-ABI entry points at the bottom).  Going through the framework's
+// matmul costs ~55 us of host time per call on this path (descriptor setup + heuristic query every time, measured
+// with torch.profiler); a cached plan costs ~10 us.
+#include <hipblaslt/hipblaslt.h>
+#include <stdlib.h>
+
+#include <map>
+#include <mutex>
+#include <tuple>
+
+#include "../../include/gdmae_hip.h"
+#include "common.h"
+#include "gemm.h"
+
+namespace {
+
+// dst[i] += sum_s part[s * P + i]   (P % 4 == 0).  64 float4 columns x 4 slices of S per workgroup: every lane
+// streams S/4 independent 16-byte loads, the 4 slices meet in LDS (fixed order -> deterministic).
+__global__ __launch_bounds__(256) void k_splitk_acc(const float* __restrict__ part, int S, long long P4, float* __restrict__ dst,
+                                                    int accumulate) {
+  __shared__ float4 sh[3][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const long long i = blockIdx.x * 64ll + tx;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < P4) {
+    const int s0 = (S * ty) / 4, s1 = (S * (ty + 1)) / 4;
+    const float4* p = (const float4*)part + i;
+#pragma unroll 4
+    for (int s = s0; s < s1; ++s) {
+      const float4 v = p[(long long)s * P4];
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+  }
+  if (ty > 0) sh[ty - 1][tx] = acc;
+  __syncthreads();
+  if (ty == 0 && i < P4) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { const float4 v = sh[k][tx]; acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+    if (accumulate) {
+      const float4 d = ((float4*)dst)[i];
+      acc.x += d.x; acc.y += d.y; acc.z += d.z; acc.w += d.w;
+    }
+    ((float4*)dst)[i] = acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// hipBLASLt GEMM with a per-shape algorithm cache (column-major semantics: C(MxN) = op(A) op(B) [+ bias(M)])
+// ------------------------------------------------------------------------------------------
+struct GemmPlan {
+  hipblasLtMatmulDesc_t desc = nullptr;
+  hipblasLtMatrixLayout_t la = nullptr, lb = nullptr, lc = nullptr;
+  hipblasLtMatmulAlgo_t algo;
+  size_t ws = 0;
+};
+typedef std::tuple<int, int, int, int, int, int, int, int, int, int, int, int, int> GemmKey;
+
+hipblasLtHandle_t g_lt = nullptr;
+std::map<GemmKey, GemmPlan> g_plans;
+std::mutex g_lt_mu;
+
+#define LT_CHECK(x)                                                         \
+  do {                                                                      \
+    hipblasStatus_t s_ = (x);                                               \
+    if (s_ != HIPBLAS_STATUS_SUCCESS) {                                     \
+      gd_set_error(1000 + (int)s_, __FILE__, __LINE__, "hipBLASLt: " #x);   \
+      return 1000 + (int)s_;                                                \
+    }                                                                       \
+  } while (0)
+
+}  // namespace
+
+int gd_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
+            hipDataType tab, hipDataType tc, const void* bias, int batch, long long sA, long long sB, long long sC, void* ws,
+            size_t ws_bytes, bool loose) {
+  std::lock_guard<std::mutex> lock(g_lt_mu);
+  if (!g_lt) LT_CHECK(hipblasLtCreate(&g_lt));
+  // loose shapes: extents are bucketed to 3 significant bits (<= 25 % apart; extents <= 64 to multiples of 16), so the
+  // number of cached (and timed) plans stays bounded whatever token / point / site counts the batches have
+  auto bucket = [loose](int x) {
+    if (!loose) return x;
+    if (x <= 64) return (x + 15) / 16 * 16;
+    int g = 1;
+    while ((g << 3) < x) g <<= 1;      // g = 2^(floor(log2(x-1)) - 2)
+    return (x + g - 1) / g * g;
+  };
+  const GemmKey key((int)ta, (int)tb, bucket(M), bucket(N), bucket(K), lda, ldb, ldc, (int)tab, (int)tc, bias ? 1 : 0, batch,
+                    loose ? 1 : 0);
+  auto it = g_plans.find(key);
+  if (it == g_plans.end()) {
+    GemmPlan p;
+    LT_CHECK(hipblasLtMatmulDescCreate(&p.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F));
+    const int32_t opa = ta ? HIPBLAS_OP_T : HIPBLAS_OP_N, opb = tb ? HIPBLAS_OP_T : HIPBLAS_OP_N;
+    LT_CHECK(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_TRANSA, &opa, sizeof(opa)));
+    LT_CHECK(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_TRANSB, &opb, sizeof(opb)));
+    if (bias) {
+      const uint32_t epi = HIPBLASLT_EPILOGUE_BIAS;
+      LT_CHECK(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_EPILOGUE, &epi, sizeof(epi)));
+      const int32_t bt = (int32_t)tc;   // bias in the output dtype (bf16 shadow / fp32 master)
+      LT_CHECK(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_DATA_TYPE, &bt, sizeof(bt)));
+      LT_CHECK(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias)));
+    }
+    LT_CHECK(hipblasLtMatrixLayoutCreate(&p.la, tab, ta ? K : M, ta ? M : K, lda));
+    LT_CHECK(hipblasLtMatrixLayoutCreate(&p.lb, tab, tb ? N : K, tb ? K : N, ldb));
+    LT_CHECK(hipblasLtMatrixLayoutCreate(&p.lc, tc, M, N, ldc));
+    if (batch > 1) {
+      const int32_t bc = batch;
+      const int64_t s_a = sA, s_b = sB, s_c = sC;
+      LT_CHECK(hipblasLtMatrixLayoutSetAttribute(p.la, HIPBLASLT_MATRIX_LAYOUT_BATCH_COUNT, &bc, sizeof(bc)));
+      LT_CHECK(hipblasLtMatrixLayoutSetAttribute(p.lb, HIPBLASLT_MATRIX_LAYOUT_BATCH_COUNT, &bc, sizeof(bc)));
+      LT_CHECK(hipblasLtMatrixLayoutSetAttribute(p.lc, HIPBLASLT_MATRIX_LAYOUT_BATCH_COUNT, &bc, sizeof(bc)));
+      LT_CHECK(hipblasLtMatrixLayoutSetAttribute(p.la, HIPBLASLT_MATRIX_LAYOUT_STRIDED_BATCH_OFFSET, &s_a, sizeof(s_a)));
+      LT_CHECK(hipblasLtMatrixLayoutSetAttribute(p.lb, HIPBLASLT_MATRIX_LAYOUT_STRIDED_BATCH_OFFSET, &s_b, sizeof(s_b)));
+      LT_CHECK(hipblasLtMatrixLayoutSetAttribute(p.lc, HIPBLASLT_MATRIX_LAYOUT_STRIDED_BATCH_OFFSET, &s_c, sizeof(s_c)));
+    }
+    hipblasLtMatmulPreference_t pref;
+    LT_CHECK(hipblasLtMatmulPreferenceCreate(&pref));
+    const uint64_t wsz = ws_bytes;
+    LT_CHECK(hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &wsz, sizeof(wsz)));
+    // First use of a shape: ask for several candidate algorithms and time them on the caller's buffers (the GEMM is
+    // idempotent: beta = 0).  The heuristic's first choice is tuned for large square problems; these are tall-skinny
+    // (20-40 k rows, K and N of 128-512) and the best candidate is often not the first.  Shapes repeat (rows are
+    // padded to 2048), so the one-off cost (a few ms, with stream syncs) is paid during warm-up only.
+    constexpr int kMaxAlgo = 16;
+    hipblasLtMatmulHeuristicResult_t res[kMaxAlgo];
+    int found = 0;
+    static const bool tune = !(getenv("GDMAE_GEMM_TUNE") && atoi(getenv("GDMAE_GEMM_TUNE")) == 0);
+    LT_CHECK(hipblasLtMatmulAlgoGetHeuristic(g_lt, p.desc, p.la, p.lb, p.lc, p.lc, pref, tune ? kMaxAlgo : 1, res, &found));
+    hipblasLtMatmulPreferenceDestroy(pref);
+    if (found < 1) {
+      gd_set_error(-2, __FILE__, __LINE__, "hipBLASLt: no algorithm for this GEMM shape");
+      return -2;
+    }
+    int best = 0;
+    if (found > 1) {
+      const float alpha = 1.f, beta = 0.f;
+      hipEvent_t e0, e1;
+      GD_CHECK(hipEventCreate(&e0));
+      GD_CHECK(hipEventCreate(&e1));
+      float best_ms = 1e30f;
+      for (int i = 0; i < found; ++i) {
+        if (res[i].workspaceSize > ws_bytes) continue;
+        bool ok = true;
+        for (int rep = 0; rep < 4 && ok; ++rep) {     // rep 0 = warm-up
+          if (rep == 1) hipEventRecord(e0, st);
+          ok = hipblasLtMatmul(g_lt, p.desc, &alpha, A, p.la, B, p.lb, &beta, C, p.lc, C, p.lc, &res[i].algo, ws, res[i].workspaceSize,
+                               st) == HIPBLAS_STATUS_SUCCESS;
+        }
+        if (!ok) continue;
+        hipEventRecord(e1, st);
+        GD_CHECK(hipEventSynchronize(e1));
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best_ms) { best_ms = ms; best = i; }
+      }
+      hipEventDestroy(e0);
+      hipEventDestroy(e1);
+    }
+    p.algo = res[best].algo;
+    p.ws = res[best].workspaceSize;
+    it = g_plans.emplace(key, p).first;
+  }
+  GemmPlan& p = it->second;
+  if (bias) LT_CHECK(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias)));
+  const float alpha = 1.f, beta = 0.f;
+  if (!loose) {
+    LT_CHECK(hipblasLtMatmul(g_lt, p.desc, &alpha, A, p.la, B, p.lb, &beta, C, p.lc, C, p.lc, &p.algo, ws, p.ws <= ws_bytes ? p.ws : ws_bytes, st));
+    return 0;
+  }
+  // loose: this call's exact extents (the cached layouts describe the first shape of the bucket)
+  hipblasLtMatrixLayout_t la, lb, lc;
+  LT_CHECK(hipblasLtMatrixLayoutCreate(&la, tab, ta ? K : M, ta ? M : K, lda));
+  LT_CHECK(hipblasLtMatrixLayoutCreate(&lb, tab, tb ? N : K, tb ? K : N, ldb));
+  LT_CHECK(hipblasLtMatrixLayoutCreate(&lc, tc, M, N, ldc));
+  if (batch > 1) {
+    const int32_t bc = batch;
+    const int64_t s_a = sA, s_b = sB, s_c = sC;
+    hipblasLtMatrixLayoutSetAttribute(la, HIPBLASLT_MATRIX_LAYOUT_BATCH_COUNT, &bc, sizeof(bc));
+    hipblasLtMatrixLayoutSetAttribute(lb, HIPBLASLT_MATRIX_LAYOUT_BATCH_COUNT, &bc, sizeof(bc));
+    hipblasLtMatrixLayoutSetAttribute(lc, HIPBLASLT_MATRIX_LAYOUT_BATCH_COUNT, &bc, sizeof(bc));
+    hipblasLtMatrixLayoutSetAttribute(la, HIPBLASLT_MATRIX_LAYOUT_STRIDED_BATCH_OFFSET, &s_a, sizeof(s_a));
+    hipblasLtMatrixLayoutSetAttribute(lb, HIPBLASLT_MATRIX_LAYOUT_STRIDED_BATCH_OFFSET, &s_b, sizeof(s_b));
+    hipblasLtMatrixLayoutSetAttribute(lc, HIPBLASLT_MATRIX_LAYOUT_STRIDED_BATCH_OFFSET, &s_c, sizeof(s_c));
+  }
+  hipblasStatus_t rc = hipblasLtMatmul(g_lt, p.desc, &alpha, A, la, B, lb, &beta, C, lc, C, lc, &p.algo, ws, p.ws <= ws_bytes ? p.ws : ws_bytes, st);
+  if (rc != HIPBLAS_STATUS_SUCCESS) {
+    // the bucket's algorithm does not support these extents: ask for one that does (not cached)
+    hipblasLtMatmulPreference_t pref;
+    LT_CHECK(hipblasLtMatmulPreferenceCreate(&pref));
+    const uint64_t wsz = ws_bytes;
+    LT_CHECK(hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &wsz, sizeof(wsz)));
+    hipblasLtMatmulHeuristicResult_t res[1];
+    int found = 0;
+    rc = hipblasLtMatmulAlgoGetHeuristic(g_lt, p.desc, la, lb, lc, lc, pref, 1, res, &found);
+    hipblasLtMatmulPreferenceDestroy(pref);
+    if (rc == HIPBLAS_STATUS_SUCCESS && found > 0)
+      rc = hipblasLtMatmul(g_lt, p.desc, &alpha, A, la, B, lb, &beta, C, lc, C, lc, &res[0].algo, ws, res[0].workspaceSize, st);
+    else if (rc == HIPBLAS_STATUS_SUCCESS)
+      rc = HIPBLAS_STATUS_NOT_SUPPORTED;
+  }
+  hipblasLtMatrixLayoutDestroy(la);
+  hipblasLtMatrixLayoutDestroy(lb);
+  hipblasLtMatrixLayoutDestroy(lc);
+  LT_CHECK(rc);
+  return 0;
+}
+
+int gd_splitk_acc(hipStream_t st, const float* part, int S, long long P, float* dst, int accumulate) {
+  const long long P4 = P / 4;
+  hipLaunchKernelGGL(k_splitk_acc, dim3((int)((P4 + 63) / 64)), dim3(256), 0, st, part, S, P4, dst, accumulate);
+  GD_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// row-major C-ABI entry points
+// ------------------------------------------------------------------------------------------
+extern "C" size_t gdmae_gemm_workspace_bytes(void) { return GD_LT_WORKSPACE; }
+
+extern "C" int gdmae_gemm(const void* A, const void* B, void* C, long long M, long long N, long long K, int trans_a, int trans_b,
+                          int ab_bf16, int c_f32, const void* bias, void* workspace, void* stream) {
+  GD_REQUIRE(M > 0 && N > 0 && K > 0 && M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31), "gemm: bad extents");
+  const hipDataType tab = ab_bf16 ? HIP_R_16BF : HIP_R_32F, tc = (c_f32 || !ab_bf16) ? HIP_R_32F : HIP_R_16BF;
+  // row-major C = op(A) op(B)  <=>  column-major C^T (N x M) = op(B)^T op(A)^T on the same buffers
+  return gd_gemm((hipStream_t)stream, trans_b != 0, trans_a != 0, (int)N, (int)M, (int)K, B, trans_b ? (int)K : (int)N, A,
+                 trans_a ? (int)M : (int)K, C, (int)N, tab, tc, bias, 1, 0, 0, 0, workspace, GD_LT_WORKSPACE, true);
+}
+
+static int splitk_slices(long long K, int m, int n) {
+  const int tiles = ((m + 127) / 128) * ((n + 127) / 128);
+  long long S = K / 256;
+  if (S > (1024 + tiles - 1) / tiles) S = (1024 + tiles - 1) / tiles;
+  if (S > 256) S = 256;
+  if (S < 1) S = 1;
+  return (int)S;
+}
+
+extern "C" size_t gdmae_gemm_tn_splitk_workspace_bytes(long long K, int m, int n) {
+  return GD_LT_WORKSPACE + (size_t)(splitk_slices(K, m, n) + 1) * m * n * sizeof(float);
+}
+
+// C (m, n) fp32 (+)= A^T B, A (K, m), B (K, n) row-major: S equal K-slices as one batched GEMM (+ the remainder rows
+// as one more partial product), reduced in a fixed order.
+extern "C" int gdmae_gemm_tn_splitk(const void* A, const void* B, float* C, long long K, int m, int n, int ab_bf16, int accumulate,
+                                    void* workspace, void* stream) {
+  GD_REQUIRE(K > 0 && m > 0 && n > 0 && ((long long)m * n) % 4 == 0, "gemm_tn_splitk: bad extents");
+  hipStream_t st = (hipStream_t)stream;
+  const hipDataType tab = ab_bf16 ? HIP_R_16BF : HIP_R_32F;
+  const int es = ab_bf16 ? 2 : 4;
+  const int S = splitk_slices(K, m, n);
+  const long long kc = K / S, K0 = kc * S;
+  float* part = (float*)((char*)workspace + GD_LT_WORKSPACE);
+  // column-major: C^T (n x m) = B^T (n x kc) A (kc x m) per slice:  A' = B buffer (ld n, op N), B' = A buffer (ld m, op T)
+  int rc = gd_gemm(st, false, true, n, m, (int)kc, B, n, A, m, part, n, tab, HIP_R_32F, nullptr, S, kc * n, kc * m, (long long)m * n,
+                   workspace, GD_LT_WORKSPACE, true);
+  if (rc != 0) return rc;
+  int np = S;
+  if (K0 < K) {
+    rc = gd_gemm(st, false, true, n, m, (int)(K - K0), (const char*)B + (size_t)K0 * n * es, n, (const char*)A + (size_t)K0 * m * es, m,
+                 part + (size_t)S * m * n, n, tab, HIP_R_32F, nullptr, 1, 0, 0, 0, workspace, GD_LT_WORKSPACE, true);
+    if (rc != 0) return rc;
+    ++np;
+  }
+  return gd_splitk_acc(st, part, np, (long long)m * n, C, accumulate);
+}

@@ -207,7 +207,7 @@ class DecoderHead(torch.autograd.Function):
             G = torch.empty(n, 9 * C2, dtype=cdt, device=dev)
             L.call("gdmae_conv3x3_grad_taps", L.ptr(y2), _bf(y2), L.ptr(k01), L.ptr(k01[C2:]), L.ptr(rows), L.ptr(cell2pillar),
                    L.ptr(sites[i]), n, H, W, C2, L.ptr(G), L.stream())
-            dX = G @ Wd[:, :, col:col + w].reshape(9 * C2, w)             # dZ rows of this stage's active sites
+            dX = ops.mm(G, Wd[:, :, col:col + w].reshape(9 * C2, w))      # dZ rows of this stage's active sites
             Zd = _gather_slice(Z, sites[i], col, w) - bgz[col:col + w]
             dW_rows.append(ops.splitk_tn(G, Zd))                          # (9*C2, w) fp32
             del G

@@ -64,6 +64,10 @@ SIGNATURES = {
     "gdmae_set_attention_impl": (_I, [_I]),
     "gdmae_sum_partials": (_I, [_P, _L, _F, _P, _I, _P]),
     "gdmae_sum_partials_gated": (_I, [_P, _L, _F, _P, _P, _F, _P]),
+    "gdmae_gemm_workspace_bytes": (_Z, []),
+    "gdmae_gemm": (_I, [_P, _P, _P, _L, _L, _L, _I, _I, _I, _I, _P, _P, _P]),
+    "gdmae_gemm_tn_splitk_workspace_bytes": (_Z, [_L, _I, _I]),
+    "gdmae_gemm_tn_splitk": (_I, [_P, _P, _P, _L, _I, _I, _I, _I, _P, _P]),
     "gdmae_encoder_layer_bytes": (_I, [_L, _I, _I, _I, _I, _P, _I, _P, _P, _P]),
     "gdmae_encoder_layer_fwd": (_I, [_P, _P]),
     "gdmae_encoder_layer_bwd": (_I, [_P, _P]),

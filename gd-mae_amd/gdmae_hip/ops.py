@@ -74,13 +74,56 @@ class GatherUnique(torch.autograd.Function):
 # token-wise linear layers: split-K weight gradients
 # ------------------------------------------------------------------------------------------------
 _BMM_OUT_DTYPE_OK = None
+_GEMM_WS = {}
+
+
+def _gemm_ws(dev, nbytes):
+    t = _GEMM_WS.get(dev.index)
+    if t is None or t.numel() < nbytes:
+        t = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+        _GEMM_WS[dev.index] = t
+    return t
+
+
+def _gemm_ok(*ts):
+    dt = ts[0].dtype
+    return dt in (torch.bfloat16, torch.float32) and all(t.dtype == dt and t.is_contiguous() and t.dim() == 2 for t in ts)
+
+
+def mm(a: torch.Tensor, b: torch.Tensor, trans_b: bool = False, bias: torch.Tensor | None = None) -> torch.Tensor:
+    """a (M, K) @ b (K, N)   [or @ b^T for b (N, K) with trans_b]  (+ bias (N)), result in the operand dtype.
+    Library GEMM through gdmae_gemm (hipBLASLt with one cached algorithm per shape bucket, ~10 us of host time per
+    call instead of ~55 us through the framework's matmul); operands whose inner extents are not multiples of 8
+    (the 11-feature DynVFE input) stay on the framework's GEMM."""
+    M, K = a.shape
+    N = b.shape[0] if trans_b else b.shape[1]
+    if not (_gemm_ok(a, b) and K % 8 == 0 and N % 8 == 0 and M > 0 and (bias is None or (bias.dtype == a.dtype and bias.is_contiguous()))):
+        y = a @ (b.t() if trans_b else b)
+        return y if bias is None else y + bias
+    out = torch.empty(M, N, dtype=a.dtype, device=a.device)
+    ws = _gemm_ws(a.device, L.load().gdmae_gemm_workspace_bytes())
+    L.call("gdmae_gemm", L.ptr(a), L.ptr(b), L.ptr(out), M, N, K, 0, int(trans_b), int(a.dtype == torch.bfloat16), 0,
+           None if bias is None else L.ptr(bias), L.ptr(ws), L.stream())
+    return out
 
 
 def splitk_tn(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     """a (K, m), b (K, n) -> a^T @ b (m, n) in fp32, with the long K (= tokens / points / sites) dimension
-    split over a batched GEMM.  Weight gradients of this model are (<=512 x <=2304) outputs with K = 20 k ... 1.4 M:
+    split into slices.  Weight gradients of this model are (<=512 x <=2304) outputs with K = 20 k ... 1.4 M:
     as one GEMM they fill 16-72 output tiles, i.e. a few CUs of 256 (measured 130-1950 us each on MI355X);
-    as S batched partial products + one small reduction every CU is busy."""
+    as S batched partial products + one fixed-order reduction every CU is busy (gdmae_gemm_tn_splitk)."""
+    K, m = a.shape
+    n = b.shape[1]
+    if not (_gemm_ok(a, b) and m % 8 == 0 and n % 8 == 0 and K >= 1):
+        return _splitk_tn_torch(a, b)
+    out = torch.empty(m, n, dtype=torch.float32, device=a.device)
+    ws = _gemm_ws(a.device, L.load().gdmae_gemm_tn_splitk_workspace_bytes(K, m, n))
+    L.call("gdmae_gemm_tn_splitk", L.ptr(a), L.ptr(b), L.ptr(out), K, m, n, int(a.dtype == torch.bfloat16), 0, L.ptr(ws), L.stream())
+    return out
+
+
+def _splitk_tn_torch(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """Same contraction on the framework's batched GEMM (operands the library path does not take: odd widths)."""
     global _BMM_OUT_DTYPE_OK
     K, m = a.shape
     n = b.shape[1]
@@ -146,9 +189,14 @@ class LinearSplitK(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
         cdt = torch.bfloat16 if torch.is_autocast_enabled() else x.dtype
-        xc = x.to(cdt)
+        xc = x.to(cdt).contiguous()
         wc = shadow(weight, cdt)
-        y = torch.nn.functional.linear(xc, wc, None if bias is None else shadow(bias, cdt))
+        ctx.w_t = not wc.is_contiguous() and wc.t().is_contiguous()       # weight given as the transpose of a (k, m) matrix
+        if ctx.w_t:
+            wc = wc.t()
+        elif not wc.is_contiguous():
+            wc = wc.contiguous()
+        y = mm(xc, wc, trans_b=not ctx.w_t, bias=None if bias is None else shadow(bias, cdt).contiguous())
         ctx.save_for_backward(xc, wc)
         ctx.has_bias = bias is not None
         ctx.w_dtype = weight.dtype
@@ -158,7 +206,7 @@ class LinearSplitK(torch.autograd.Function):
     def backward(ctx, g):
         xc, wc = ctx.saved_tensors
         g = g.contiguous().to(xc.dtype)
-        dx = g @ wc
+        dx = mm(g, wc, trans_b=ctx.w_t)
         dw = splitk_tn(g, xc).to(ctx.w_dtype)
         db = colsum_f32(g) if ctx.has_bias else None
         return dx, dw, db
@@ -183,18 +231,20 @@ class SparseConv3x3(torch.autograd.Function):
         cout, _, _, cin = weight.shape
         cdt = torch.bfloat16 if torch.is_autocast_enabled() else x.dtype      # bf16 throughput mode under autocast
         cols = gather_rows_raw(x.to(cdt), nbr).view(nbr.shape[0], 9 * cin)
-        ctx.save_for_backward(cols, weight, nbr_t)
-        return cols @ weight.reshape(cout, 9 * cin).t().to(cdt)
+        wc = shadow(weight, cdt)
+        ctx.save_for_backward(cols, wc, nbr_t)
+        ctx.w_dtype = weight.dtype
+        return mm(cols, wc.reshape(cout, 9 * cin), trans_b=True)
 
     @staticmethod
     def backward(ctx, g):
-        cols, weight, nbr_t = ctx.saved_tensors
-        cout, _, _, cin = weight.shape
+        cols, wc, nbr_t = ctx.saved_tensors
+        cout, _, _, cin = wc.shape
         g = g.contiguous().to(cols.dtype)
-        dw = splitk_tn(g, cols).view(cout, 3, 3, cin).to(weight.dtype)
+        dw = splitk_tn(g, cols).view(cout, 3, 3, cin).to(ctx.w_dtype)
         gcols = gather_rows_raw(g, nbr_t).view(nbr_t.shape[0], 9 * cout)
-        wt = weight.permute(1, 2, 0, 3).reshape(9 * cout, cin).to(g.dtype)
-        return gcols @ wt, dw, None, None
+        wt = wc.permute(1, 2, 0, 3).reshape(9 * cout, cin)
+        return mm(gcols, wt), dw, None, None
 
 
 # ------------------------------------------------------------------------------------------------

@@ -235,6 +235,21 @@ int gdmae_prep_tokens(const float* x, const float* pos_table, const int* tok_pos
                       void* xpos_out, int out_bf16, void* stream);
 int gdmae_add3(const float* a, const void* b, int b_bf16, const void* c, int c_bf16, long long total, float* out, void* stream);
 
+/* ---- library GEMMs (hipBLASLt, one cached algorithm per shape bucket) ------------------------------ *
+ * The token / point / site GEMMs of the path outside the encoder-layer executor (nn.Linear of DynVFE, the
+ * spconv im2col products, the deconvolution token GEMM, their gradients); row-major operands.
+ *   gdmae_gemm: C (M,N) = op(A) op(B) + bias(N); A is (M,K), or (K,M) with trans_a; B is (K,N), or (N,K) with
+ *     trans_b; A/B bf16 (ab_bf16) or fp32; C has the operand type, or fp32 if c_f32; bias (optional) in C's type.
+ *   gdmae_gemm_tn_splitk: C (m,n) fp32 (+)= A^T B for A (K,m), B (K,n) with the long K dimension (20 k ... 1.4 M
+ *     rows) split into equal slices = one batched GEMM + a fixed-order reduction (weight gradients).
+ * workspace: gdmae_gemm_workspace_bytes() / gdmae_gemm_tn_splitk_workspace_bytes(K, m, n). */
+size_t gdmae_gemm_workspace_bytes(void);
+int gdmae_gemm(const void* A, const void* B, void* C, long long M, long long N, long long K, int trans_a, int trans_b,
+               int ab_bf16, int c_f32, const void* bias, void* workspace, void* stream);
+size_t gdmae_gemm_tn_splitk_workspace_bytes(long long K, int m, int n);
+int gdmae_gemm_tn_splitk(const void* A, const void* B, float* C, long long K, int m, int n, int ab_bf16, int accumulate,
+                         void* workspace, void* stream);
+
 /* ---- a13/a14 as one call: native executor of a whole encoder layer ------------------------------ *
  * EncoderLayer.forward (sst_basic_block.py:77-84; WindowAttention :22-54; cosine_msa.py): q = k = x + pos, v = x,
  * in-projection, windowed cosine attention, out-projection, LN(x + attn), FFN(GELU erf), LN(x + ffn) - forward or
