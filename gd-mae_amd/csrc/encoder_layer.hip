@@ -289,7 +289,8 @@ struct Scratch {
       *cs_part;
   size_t bytes;
 };
-Scratch scratch_layout(void* base, long long n_pad, int d, int ff, int es, long long n_attn_items) {
+Scratch scratch_layout(void* base, long long n_pad, int d, int ff, int es, int nhead) {
+  const long long n_attn_items = n_pad * nhead;   // upper bound: every window holds at least one token
   Scratch s;
   size_t off = 0;
   auto take = [&](size_t b) { char* p = (char*)base + off; off += gd_align(b); return p; };
@@ -316,14 +317,12 @@ long long pad_rows(long long n) { return (n + kPad - 1) / kPad * kPad; }
 
 }  // namespace
 
-extern "C" int gdmae_encoder_layer_bytes(long long n, int d, int ff, int nhead, int bf16, const int* n_win, int n_levels,
-                                         size_t* saved_bytes, size_t* fwd_scratch_bytes, size_t* bwd_scratch_bytes) {
+extern "C" int gdmae_encoder_layer_bytes(long long n, int d, int ff, int nhead, int bf16, size_t* saved_bytes,
+                                         size_t* fwd_scratch_bytes, size_t* bwd_scratch_bytes) {
   const long long n_pad = pad_rows(n);
-  long long items = 0;
-  for (int l = 0; l < n_levels; ++l) items += (long long)n_win[l] * nhead;
   *saved_bytes = saved_layout(nullptr, n_pad, d, ff, bf16 ? 2 : 4).bytes;
   *fwd_scratch_bytes = gd_align(kLtWorkspace);
-  *bwd_scratch_bytes = scratch_layout(nullptr, n_pad, d, ff, bf16 ? 2 : 4, items).bytes;
+  *bwd_scratch_bytes = scratch_layout(nullptr, n_pad, d, ff, bf16 ? 2 : 4, nhead).bytes;
   return 0;
 }
 
@@ -376,7 +375,7 @@ extern "C" int gdmae_encoder_layer_bwd(const gdmae_layer_args* a, void* stream) 
   long long items = 0;
   for (int l = 0; l < a->n_levels; ++l) items += (long long)a->n_win[l] * a->nhead;
   Saved s = saved_layout(a->saved, n_pad, d, ff, es);
-  Scratch w = scratch_layout(a->scratch, n_pad, d, ff, es, items);
+  Scratch w = scratch_layout(a->scratch, n_pad, d, ff, es, a->nhead);
   Ctx c{(hipStream_t)stream, a->bf16 ? HIP_R_16BF : HIP_R_32F, es, w.lt_ws};
   ZeroJobs z;
   z.count = 0;

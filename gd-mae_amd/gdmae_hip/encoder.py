@@ -219,83 +219,116 @@ IMPL = "native"      # "native": gdmae_encoder_layer_fwd/bwd;  "python": Encoder
 _GRAD_FIELDS = ("dWin", "dbin", "dtau", "dWo", "dbo", "dW1", "db1", "dW2", "db2", "dg1", "dbe1", "dg2", "dbe2")
 
 
-def _layer_args(x, wplan, pos_table, nhead, tau_min, eps, cdt, ff, params):
-    n, d = x.shape
+import ctypes as _C
+
+_PARAM_FIELDS = ("Win", "bin", "Wo", "bo", "W1", "b1", "W2", "b2", "g1", "be1", "g2", "be2", "tau")
+_BYTES_CACHE = {}
+
+
+def _layer_bytes(n, d, ff, nhead, bf):
+    key = ((n + PAD - 1) // PAD, d, ff, nhead, bf)
+    r = _BYTES_CACHE.get(key)
+    if r is None:
+        out = (_C.c_size_t * 3)()
+        L.call("gdmae_encoder_layer_bytes", n, d, ff, nhead, bf, _C.byref(out, 0), _C.byref(out, _C.sizeof(_C.c_size_t)),
+               _C.byref(out, 2 * _C.sizeof(_C.c_size_t)))
+        r = _BYTES_CACHE[key] = (int(out[0]), int(out[1]), int(out[2]))
+    return r
+
+
+def _param_args(plist, cdt, direct):
+    """LayerArgs pre-filled with parameter (and, with a flat optimizer, gradient) pointers.  With a flat optimizer the
+    fp32 masters, their bf16 shadows and the gradient views are persistent buffers, so the struct is built once per
+    layer; otherwise (plain autograd use) it is rebuilt on every call."""
+    Win, bin_, tau, Wo, bo, W1, b1, W2, b2, g1, be1, g2, be2 = plist
+    def _persistent(t):      # fp32 master used as is, or a bf16 shadow that is current
+        if cdt == t.dtype:
+            return True
+        base = t._base if t._base is not None else t
+        sh = getattr(base, "_gd_shadow", None)
+        return sh is not None and sh[1] == base._version
+    stable = all(t is not None for t in direct) and all(_persistent(t) for t in (Win, bin_, Wo, bo, W1, b1, W2, b2))
+    cache = getattr(Win, "_gd_layer_args", None)       # lives (and dies) with the layer's in-projection parameter
+    if stable and cache is not None:
+        hit = cache.get(cdt)
+        if hit is not None and hit[2] == Win._version and hit[3] == direct[0].data_ptr():
+            return hit[0], hit[1]
+    sh = lambda t: ops.shadow(t, cdt).contiguous()   # noqa: E731
+    tensors = {"Win": sh(Win), "bin": sh(bin_), "Wo": sh(Wo), "bo": sh(bo), "W1": sh(W1), "b1": sh(b1), "W2": sh(W2), "b2": sh(b2),
+               "g1": g1.detach(), "be1": be1.detach(), "g2": g2.detach(), "be2": be2.detach(),
+               "tau": tau.detach().reshape(1).float().contiguous()}
     a = L.LayerArgs()
+    for k, t in tensors.items():
+        setattr(a, k, L.ptr(t))
+    if stable:
+        for k, g in zip(_GRAD_FIELDS, direct):
+            setattr(a, k, L.ptr(g))
+        # the shadows are refreshed in place by the optimizer; a changed version only matters for pointer identity
+        if cache is None:
+            cache = Win._gd_layer_args = {}
+        cache[cdt] = (a, tensors, Win._version, direct[0].data_ptr())
+    return a, tensors
+
+
+def _call_args(base, x, wplan, pos_table, nhead, tau_min, eps, cdt, ff):
+    a = L.LayerArgs.from_buffer_copy(base)
+    n, d = x.shape
     a.n, a.d, a.ff, a.nhead, a.bf16 = n, d, ff, nhead, int(cdt == torch.bfloat16)
     a.eps, a.tau_min = float(eps), float(tau_min)
     nl = len(wplan.n_win)
     a.n_levels = nl
     for i in range(nl):
         a.n_win[i], a.max_tokens[i] = int(wplan.n_win[i]), int(wplan.max_tokens[i])
-    a.tok_pos, a.csr_tok, a.win_start, a.win_len = (L.ptr(wplan.tok_pos), L.ptr(wplan.csr_tok), L.ptr(wplan.win_start),
-                                                    L.ptr(wplan.win_len))
-    a.pos_table, a.x = L.ptr(pos_table), L.ptr(x)
-    for k, t in params.items():
-        setattr(a, k, L.ptr(t))
+    a.tok_pos, a.csr_tok, a.win_start, a.win_len = (wplan.tok_pos.data_ptr(), wplan.csr_tok.data_ptr(), wplan.win_start.data_ptr(),
+                                                    wplan.win_len.data_ptr())
+    a.pos_table, a.x = pos_table.data_ptr(), x.data_ptr()
     return a
-
-
-def _layer_bytes(n, d, ff, nhead, bf, wplan):
-    import ctypes as C
-    out = (C.c_size_t * 3)()
-    nw = L.host_i32(wplan.n_win)
-    L.call("gdmae_encoder_layer_bytes", n, d, ff, nhead, bf, nw, len(wplan.n_win), C.byref(out, 0),
-           C.byref(out, C.sizeof(C.c_size_t)), C.byref(out, 2 * C.sizeof(C.c_size_t)))
-    return int(out[0]), int(out[1]), int(out[2])
 
 
 class EncoderLayerNativeFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, Win, bin_, tau, Wo, bo, W1, b1, W2, b2, g1, be1, g2, be2, wplan, pos_table, nhead, tau_min, eps, act):
-        import ctypes as C
         assert act == "gelu", "hot path uses ACTIVATION gelu (gd_mae_ssl.yaml:66)"
-        ctx.direct = [_direct(p) for p in (Win, bin_, tau, Wo, bo, W1, b1, W2, b2, g1, be1, g2, be2)]
+        plist = (Win, bin_, tau, Wo, bo, W1, b1, W2, b2, g1, be1, g2, be2)
+        direct = [_direct(p) for p in plist]
         x = x.float().contiguous()
         n, d = x.shape
         dev = x.device
         ff = W1.shape[0]
         cdt = torch.bfloat16 if torch.is_autocast_enabled() else torch.float32
-        sh = lambda t: ops.shadow(t, cdt).contiguous()   # noqa: E731
-        params = {"Win": sh(Win), "bin": sh(bin_), "Wo": sh(Wo), "bo": sh(bo), "W1": sh(W1), "b1": sh(b1), "W2": sh(W2), "b2": sh(b2),
-                  "g1": g1.detach(), "be1": be1.detach(), "g2": g2.detach(), "be2": be2.detach(),
-                  "tau": tau.detach().reshape(1).float().contiguous()}
-        sb, fb, bb = _layer_bytes(n, d, ff, nhead, int(cdt == torch.bfloat16), wplan)
+        base, keep = _param_args(plist, cdt, direct)
+        sb, fb, bb = _layer_bytes(n, d, ff, nhead, int(cdt == torch.bfloat16))
         saved = torch.empty(sb, dtype=torch.uint8, device=dev)
         scratch = torch.empty(fb, dtype=torch.uint8, device=dev)
         y = torch.empty_like(x)
-        a = _layer_args(x, wplan, pos_table, nhead, tau_min, eps, cdt, ff, params)
-        a.y, a.saved, a.scratch = L.ptr(y), L.ptr(saved), L.ptr(scratch)
-        L.call("gdmae_encoder_layer_fwd", C.byref(a), L.stream())
-        ctx.save_for_backward(x, saved, pos_table, *params.values())
-        ctx.meta = (wplan, nhead, tau_min, eps, cdt, ff, bb, [t.shape for t in (Win, bin_, tau, Wo, bo, W1, b1, W2, b2, g1, be1, g2, be2)],
-                    tau.dtype)
+        a = _call_args(base, x, wplan, pos_table, nhead, tau_min, eps, cdt, ff)
+        a.y, a.saved, a.scratch = y.data_ptr(), saved.data_ptr(), scratch.data_ptr()
+        L.call("gdmae_encoder_layer_fwd", _C.byref(a), L.stream())
+        ctx.save_for_backward(x, saved, pos_table)
+        ctx.meta = (wplan, nhead, tau_min, eps, cdt, ff, bb, base, keep, direct, [t.shape for t in plist], tau.dtype)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        import ctypes as C
-        x, saved, pos_table, *pv = ctx.saved_tensors
-        wplan, nhead, tau_min, eps, cdt, ff, bb, shapes, tau_dtype = ctx.meta
-        params = dict(zip(("Win", "bin", "Wo", "bo", "W1", "b1", "W2", "b2", "g1", "be1", "g2", "be2", "tau"), pv))
+        x, saved, pos_table = ctx.saved_tensors
+        wplan, nhead, tau_min, eps, cdt, ff, bb, base, keep, direct, shapes, tau_dtype = ctx.meta
         dev = x.device
         dy = dy.float().contiguous()
         dx = torch.empty_like(x)
         scratch = torch.empty(bb, dtype=torch.uint8, device=dev)
-        a = _layer_args(x, wplan, pos_table, nhead, tau_min, eps, cdt, ff, params)
-        a.dy, a.dx, a.saved, a.scratch = L.ptr(dy), L.ptr(dx), L.ptr(saved), L.ptr(scratch)
-        if all(t is not None for t in ctx.direct):
-            gl = list(ctx.direct)                      # accumulate straight into the flat optimizer gradient buffer
-            ret = [None] * 13
+        a = _call_args(base, x, wplan, pos_table, nhead, tau_min, eps, cdt, ff)
+        a.dy, a.dx, a.saved, a.scratch = dy.data_ptr(), dx.data_ptr(), saved.data_ptr(), scratch.data_ptr()
+        if all(t is not None for t in direct):
+            ret = [None] * 13                          # gradients accumulate straight into the flat optimizer buffer
         else:
             sizes = [int(torch.Size(s).numel()) for s in shapes]
             flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
             gl = list(torch.split(flat, sizes))
+            for k, g in zip(_GRAD_FIELDS, gl):
+                setattr(a, k, L.ptr(g))
             ret = [g.view(s) for g, s in zip(gl, shapes)]
             ret[2] = ret[2].to(tau_dtype)
-        for k, g in zip(_GRAD_FIELDS, gl):
-            setattr(a, k, L.ptr(g))
-        L.call("gdmae_encoder_layer_bwd", C.byref(a), L.stream())
+        L.call("gdmae_encoder_layer_bwd", _C.byref(a), L.stream())
         return (dx, *ret, None, None, None, None, None, None)
 
 

@@ -68,7 +68,7 @@ SIGNATURES = {
     "gdmae_gemm": (_I, [_P, _P, _P, _L, _L, _L, _I, _I, _I, _I, _P, _P, _P]),
     "gdmae_gemm_tn_splitk_workspace_bytes": (_Z, [_L, _I, _I]),
     "gdmae_gemm_tn_splitk": (_I, [_P, _P, _P, _L, _I, _I, _I, _I, _P, _P]),
-    "gdmae_encoder_layer_bytes": (_I, [_L, _I, _I, _I, _I, _P, _I, _P, _P, _P]),
+    "gdmae_encoder_layer_bytes": (_I, [_L, _I, _I, _I, _I, _P, _P, _P]),
     "gdmae_encoder_layer_fwd": (_I, [_P, _P]),
     "gdmae_encoder_layer_bwd": (_I, [_P, _P]),
     "gdmae_group_gt_points": (_I, [_P, _I, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P]),

@@ -279,8 +279,8 @@ typedef struct gdmae_layer_args {
   void* saved;
   void* scratch;
 } gdmae_layer_args;
-int gdmae_encoder_layer_bytes(long long n, int d, int ff, int nhead, int bf16, const int* n_win /* host */, int n_levels,
-                              size_t* saved_bytes, size_t* fwd_scratch_bytes, size_t* bwd_scratch_bytes);
+int gdmae_encoder_layer_bytes(long long n, int d, int ff, int nhead, int bf16, size_t* saved_bytes,
+                              size_t* fwd_scratch_bytes, size_t* bwd_scratch_bytes);   /* depend on n only through ceil(n / 2048) */
 int gdmae_encoder_layer_fwd(const gdmae_layer_args* args /* host */, void* stream);
 int gdmae_encoder_layer_bwd(const gdmae_layer_args* args /* host */, void* stream);
 
