@@ -204,10 +204,12 @@ def test_sparse_conv_matches_oracle():
     assert torch.equal(dense.cpu(), tp.densify(x, idx0, [s0.Y, s0.X], B))
 
 
-@pytest.mark.parametrize("impl", [0, 1])
+@pytest.mark.parametrize("impl", [0, 1, 2])
 @pytest.mark.parametrize("d,nhead", [(128, 8), (256, 8)])
 def test_window_attention_fwd_bwd_matches_oracle(d, nhead, impl):
-    """impl 0: MFMA kernels for the T = 32 / 64 levels + VALU kernel for T = 16 (product default); 1: VALU everywhere."""
+    """impl 0 (product default): T = 32 / 64 levels on the matrix cores - exact-fp32 MFMA for fp32 rows, bf16 MFMA with
+    split-bf16 logits for bf16 rows - and the VALU kernel for T = 16; 1: VALU everywhere; 2: exact-fp32 MFMA also for
+    bf16 rows.  The bf16-row results of the three implementations must agree with each other far below bf16 noise."""
     from gdmae_hip import lib as L
     from gdmae_hip import ops, plan
     L.call("gdmae_set_attention_impl", impl)
@@ -271,6 +273,21 @@ def test_window_attention_fwd_bwd_matches_oracle(d, nhead, impl):
         assert torch.isfinite(qkb.grad.float()).all() and torch.isfinite(vb.grad.float()).all()
         if shift == 0:
             assert (vb.grad.float().cpu() - v.grad.cpu()).norm() < 3e-2 * v.grad.norm()
+            # same bf16 inputs through the VALU kernels (fp32 arithmetic): implementation differences only
+            L.call("gdmae_set_attention_impl", 1)
+            qk1, v1 = qkb.detach().clone().requires_grad_(True), vb.detach().clone().requires_grad_(True)
+            tau1 = tau.detach().clone().requires_grad_(True)
+            out1 = ops.WindowCosineAttention.apply(qk1, v1, tau1, w, nhead, 0.01)
+            (out1.float() * go.to(dev())).sum().backward()
+            L.call("gdmae_set_attention_impl", impl)
+            tau0 = tau.detach().clone().requires_grad_(True)
+            qk0, v0 = qkb.detach().clone().requires_grad_(True), vb.detach().clone().requires_grad_(True)
+            out0 = ops.WindowCosineAttention.apply(qk0, v0, tau0, w, nhead, 0.01)
+            (out0.float() * go.to(dev())).sum().backward()
+            for a, b, nm in ((out0, out1, "out"), (qk0.grad, qk1.grad, "dqk"), (v0.grad, v1.grad, "dv")):
+                rel = float((a.float() - b.float()).norm() / b.float().norm())
+                assert rel < 6e-3, (nm, rel)          # bf16 output rounding is 4e-3 per element
+            assert abs(float(tau0.grad.sum() - tau1.grad.sum())) <= 2e-2 * abs(float(tau1.grad.sum())) + 1e-5
     L.call("gdmae_set_attention_impl", 0)
 
 
