@@ -172,22 +172,26 @@ def main():
     host_batches = [synth.synth_batch(100000 * rank + 97 * k, B, ds.point_cloud_range, **skw) for k in range(args.pool)]
     pinned = [torch.from_numpy(b).pin_memory() for b in host_batches]
     dev_batches = [p.to(dev, non_blocking=True) for p in pinned]
+    resident = torch.cuda.Event()
+    resident.record()                              # every pooled batch is in HBM once this event has completed
     torch.cuda.synchronize()
     use_bf16 = args.dtype == "bf16"
 
     pending = {}
 
-    def step(i, pts, nxt=None):
+    def step(i, pts, nxt=None, nxt_ready=None):
         opt.zero_grad()
         bd = {"points": pts, "batch_size": B}
         if args.prefetch:
             pf = pending.pop(id(pts), None) or net.backbone_3d.prefetch_plan(pts, B)
             bd["_gdmae_vox"], bd["_gdmae_plan"] = pf.finish()
-            if nxt is not None:                      # plan of the NEXT batch overlaps this step's GPU work
-                pending[id(nxt)] = net.backbone_3d.prefetch_plan(nxt, B)
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=use_bf16):
             ret, tb, _ = net(bd)
         ret["loss"].backward()
+        if args.prefetch and nxt is not None:
+            # geometry plan of the NEXT batch: issued while the GPU is still busy with this backward (the host is ahead
+            # here), on a side stream that only waits for that batch's points to be resident
+            pending[id(nxt)] = net.backbone_3d.prefetch_plan(nxt, B, ready=nxt_ready)
         opt.all_reduce_grads()
         opt.step(i)
         return ret["loss"], bd
@@ -199,11 +203,12 @@ def main():
         torch.cuda.synchronize()
 
     for i in range(args.warmup):
-        loss, bd = step(i, dev_batches[i % args.pool], dev_batches[(i + 1) % args.pool] if i + 1 < args.warmup else None)
+        loss, bd = step(i, dev_batches[i % args.pool], dev_batches[(i + 1) % args.pool] if i + 1 < args.warmup else None, resident)
     sync_all()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        loss, bd = step(args.warmup + i, dev_batches[i % args.pool], dev_batches[(i + 1) % args.pool] if i + 1 < args.steps else None)
+        loss, bd = step(args.warmup + i, dev_batches[i % args.pool], dev_batches[(i + 1) % args.pool] if i + 1 < args.steps else None,
+                        resident)
     sync_all()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -248,8 +253,12 @@ def main():
             k = max(3, args.steps // 4)
             nxt = pinned[0].to(dev, non_blocking=True)
             for i in range(k):
-                cur, nxt = nxt, (pinned[(i + 1) % args.pool].to(dev, non_blocking=True) if i + 1 < k else None)
-                step(args.warmup + args.steps, cur, nxt)
+                cur, nxt, ev = nxt, None, None
+                if i + 1 < k:                          # next batch's H2D copy is queued before this step's kernels
+                    nxt = pinned[(i + 1) % args.pool].to(dev, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record()
+                step(args.warmup + args.steps, cur, nxt, ev)
             sync_all_local()
             out["h2d_inclusive"] = {"value": round(B * k / (time.perf_counter() - t1), 2), "unit": "frames/s"}
         if not args.no_cpu_baseline:

@@ -36,11 +36,12 @@ __device__ __forceinline__ unsigned short ah_f2bf(float f) {
   return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
 }
 // 8 accumulator registers [r0, r0 + 8) -> bf16 B fragment
+typedef float f32x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ bf16x8 ah_pack(const f32x16& a, int r0) {
-  AhFrag f;
+  f32x8 t;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) f.s[j] = ah_f2bf(a[r0 + j]);
-  return f.v;
+  for (int j = 0; j < 8; ++j) t[j] = a[r0 + j];
+  return __builtin_convertvector(t, bf16x8);     // v_cvt_pk_bf16_f32 (round to nearest even)
 }
 __device__ __forceinline__ f32x16 ah_mfma(bf16x8 a, bf16x8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
@@ -84,14 +85,15 @@ __device__ __forceinline__ float ah_normalize(const AhFrag (&raw)[KS], AhFrag (&
   ss += __shfl_xor(ss, 32, 64);
   const float inv = 1.f / fmaxf(sqrtf(ss), AH_EPS);
 #pragma unroll
-  for (int s = 0; s < KS; ++s)
+  for (int s = 0; s < KS; ++s) {
+    f32x8 x, r;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float x = ah_bf2f(raw[s].s[j]) * inv;
-      const unsigned short h = ah_f2bf(x);
-      hi[s].s[j] = h;
-      lo[s].s[j] = ah_f2bf(x - ah_bf2f(h));
-    }
+    for (int j = 0; j < 8; ++j) x[j] = ah_bf2f(raw[s].s[j]) * inv;
+    hi[s].v = __builtin_convertvector(x, bf16x8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = x[j] - ah_bf2f(hi[s].s[j]);
+    lo[s].v = __builtin_convertvector(r, bf16x8);
+  }
   return inv;
 }
 

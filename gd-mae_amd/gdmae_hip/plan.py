@@ -279,11 +279,20 @@ class PlanPrefetch:
     _side = {}
 
     def __init__(self, points, point_cloud_range, voxel_size, grid_size, batch_size, strides, window_shapes, drop_infos,
-                 keep_frac=None, noise=None):
+                 keep_frac=None, noise=None, ready=None):
+        """``ready``: event recorded after ``points`` (and ``noise``) were produced; the plan stream then waits for that
+        event only and the plan can be built while the main stream is still busy with the previous batch's backward.
+        Without it the plan stream is ordered after everything queued on the main stream so far."""
         dev = points.device
         main = torch.cuda.current_stream(dev)
         side = PlanPrefetch._side.setdefault(dev.index, torch.cuda.Stream(device=dev))
-        side.wait_stream(main)                      # `points` (and `noise`) were produced on the main stream
+        if ready is not None:
+            side.wait_event(ready)
+        else:
+            side.wait_stream(main)                  # `points` (and `noise`) were produced on the main stream
+        points.record_stream(side)
+        if noise is not None:
+            noise.record_stream(side)
         with torch.cuda.stream(side):
             self.vraw = _voxelize_launch(points, point_cloud_range, voxel_size, grid_size, batch_size)
             gx, gy, gz = self.vraw["grid"]

@@ -79,11 +79,12 @@ class SPTBackboneMAE(nn.Module):
         self.forward_ret_dict = self.target_assigner(batch_dict)
         return batch_dict
 
-    def prefetch_plan(self, points, batch_size, noise=None):
+    def prefetch_plan(self, points, batch_size, noise=None, ready=None):
         """Start building the geometry plan of a batch on a side stream; ``.finish()`` -> (vox, plan) to be placed
         in batch_dict['_gdmae_vox'] / ['_gdmae_plan'] before calling the detector."""
         return gplan.PlanPrefetch(points, self.point_cloud_range, self.voxel_size, self.grid_size, int(batch_size),
-                                  *stage_plan_args(self.model_cfg.SST_BLOCK_LIST), keep_frac=1 - self.mask_ratio, noise=noise)
+                                  *stage_plan_args(self.model_cfg.SST_BLOCK_LIST), keep_frac=1 - self.mask_ratio, noise=noise,
+                                  ready=ready)
 
     def target_assigner(self, batch_dict):
         vox = batch_dict['_gdmae_vox']

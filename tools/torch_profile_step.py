@@ -15,16 +15,17 @@ net.backbone_3d.dense_spatial_features = False
 opt = optim.FlatAdamOneCycle(net, configs.optimization_cfg(8), total_steps=100)
 batches = [torch.from_numpy(synth.synth_batch(5 + i, 8, ds.point_cloud_range, **skw)).to(dev) for i in range(2)]
 pend = {}
+resident = torch.cuda.Event(); resident.record()
 def step(i):
     pts, nxt = batches[i % 2], batches[(i + 1) % 2]
     opt.zero_grad()
     pf = pend.pop(i, None) or net.backbone_3d.prefetch_plan(pts, 8)
     bd = {"points": pts, "batch_size": 8}
     bd["_gdmae_vox"], bd["_gdmae_plan"] = pf.finish()
-    pend[i + 1] = net.backbone_3d.prefetch_plan(nxt, 8)
     with torch.autocast("cuda", dtype=torch.bfloat16):
         ret, _, _ = net(bd)
     ret["loss"].backward()
+    pend[i + 1] = net.backbone_3d.prefetch_plan(nxt, 8, ready=resident)
     opt.step(i)
 for i in range(6): step(i)
 torch.cuda.synchronize()
