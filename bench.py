@@ -107,7 +107,8 @@ def measure_roofline(step, dev_batches, args, n_steps=4):
     """HIP-event timing of the dominant hand-written kernel over `n_steps` extra steps (after the timed region).
 
     Dominant HIP kernel of the step (profiles/r01_kernel_stats.csv): the windowed cosine attention backward
-    (entry point gdmae_window_attention_bwd = k_win_attn_bwd for the T=16 level + k_attn_mfma_bwd for T=32/64).
+    (entry point gdmae_window_attention_bwd = k_win_attn_bwd for the T=16 level + k_attn_mfma16_bwd for T=32/64 with
+    bf16 rows; k_attn_mfma_bwd with fp32 rows).
     Algorithmic bytes per launch = tokens_of_level * (7 * d * elem_size + 4) + 8 * windows (read the q, k, v, dOut
     rows, write the dq, dk, dv rows, once each, + CSR), DESIGN.md section 4.  achieved = sum(bytes) / sum(duration)
     over all its launches, timed with HIP events on the launch stream.  `traffic` = measured HBM bytes per launch
@@ -126,14 +127,14 @@ def measure_roofline(step, dev_batches, args, n_steps=4):
         tot = {"FETCH_SIZE": [0.0, 0], "WRITE_SIZE": [0.0, 0]}
         for tag in tot:
             for r in csv.DictReader(open(os.path.join(REPO, "profiles", f"r01_pmc_{tag}_by_kernel.csv"))):
-                if r["kernel"] in ("k_win_attn_bwd", "k_attn_mfma_bwd"):
+                if r["kernel"] in ("k_win_attn_bwd", "k_attn_mfma_bwd", "k_attn_mfma16_bwd"):
                     tot[tag][0] += float(r[f"sum_{tag}"])
                     tot[tag][1] += int(r["dispatches"])
         if tot["FETCH_SIZE"][1] and tot["FETCH_SIZE"][1] == tot["WRITE_SIZE"][1]:
             traffic = int((2 * tot["FETCH_SIZE"][0] + tot["WRITE_SIZE"][0]) * 1024 / tot["FETCH_SIZE"][1])
     except Exception:
         traffic = None
-    return {"kernel": "gdmae_window_attention_bwd (k_win_attn_bwd + k_attn_mfma_bwd)", "bound": "hbm", "achieved": round(gbs, 1),
+    return {"kernel": "gdmae_window_attention_bwd (k_win_attn_bwd + k_attn_mfma16_bwd)", "bound": "hbm", "achieved": round(gbs, 1),
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
             "launches_per_step": k["launches"] / n_steps, "avg_launch_us": round(k["avg_us"], 2),
             "algorithmic_bytes_per_launch": int(k["bytes_per_launch"]),
