@@ -2,12 +2,14 @@
 // interpreter-issued parts through the row-major C-ABI entry points at the bottom).  Going through the framework's
 // matmul costs ~55 us of host time per call on this path (descriptor setup + heuristic query every time, measured
 // with torch.profiler); a cached plan costs ~10 us.
+#include <hipblaslt/hipblaslt-ext.hpp>
 #include <hipblaslt/hipblaslt.h>
 #include <stdlib.h>
 
 #include <map>
 #include <mutex>
 #include <tuple>
+#include <vector>
 
 #include "../../include/gdmae_hip.h"
 #include "common.h"
@@ -122,43 +124,68 @@ int gd_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const void* A
     // idempotent: beta = 0).  The heuristic's first choice is tuned for large square problems; these are tall-skinny
     // (20-40 k rows, K and N of 128-512) and the best candidate is often not the first.  Shapes repeat (rows are
     // padded to 2048), so the one-off cost (a few ms, with stream syncs) is paid during warm-up only.
+    // GDMAE_GEMM_TUNE: 0 = heuristic's first choice, 1 (default) = time its 16 best, 2 = time EVERY algorithm of the
+    // library that supports the problem (hipblaslt_ext::getAllAlgos + matmulIsAlgoSupported; ~50 ms per shape, once -
+    // measured on this workload: no better than 1, the 16 best already contain the fastest kernels).
+    static const int tune = getenv("GDMAE_GEMM_TUNE") ? atoi(getenv("GDMAE_GEMM_TUNE")) : 1;
     constexpr int kMaxAlgo = 16;
-    hipblasLtMatmulHeuristicResult_t res[kMaxAlgo];
+    std::vector<hipblasLtMatmulHeuristicResult_t> cand(kMaxAlgo);
     int found = 0;
-    static const bool tune = !(getenv("GDMAE_GEMM_TUNE") && atoi(getenv("GDMAE_GEMM_TUNE")) == 0);
-    LT_CHECK(hipblasLtMatmulAlgoGetHeuristic(g_lt, p.desc, p.la, p.lb, p.lc, p.lc, pref, tune ? kMaxAlgo : 1, res, &found));
+    LT_CHECK(hipblasLtMatmulAlgoGetHeuristic(g_lt, p.desc, p.la, p.lb, p.lc, p.lc, pref, tune ? kMaxAlgo : 1, cand.data(), &found));
     hipblasLtMatmulPreferenceDestroy(pref);
     if (found < 1) {
       gd_set_error(-2, __FILE__, __LINE__, "hipBLASLt: no algorithm for this GEMM shape");
       return -2;
     }
-    int best = 0;
-    if (found > 1) {
-      const float alpha = 1.f, beta = 0.f;
+    cand.resize(found);
+    const float alpha = 1.f, beta = 0.f;
+    if (tune >= 2) {
+      std::vector<hipblasLtMatmulHeuristicResult_t> all;
+      if (hipblaslt_ext::getAllAlgos(g_lt, hipblaslt_ext::GemmType::HIPBLASLT_GEMM, ta ? HIPBLAS_OP_T : HIPBLAS_OP_N,
+                                     tb ? HIPBLAS_OP_T : HIPBLAS_OP_N, tab, tab, tc, tc, HIPBLAS_COMPUTE_32F, all) == HIPBLAS_STATUS_SUCCESS)
+        for (auto& r : all) {
+          size_t need = 0;
+          if (hipblaslt_ext::matmulIsAlgoSupported(g_lt, p.desc, &alpha, p.la, p.lb, &beta, p.lc, p.lc, r.algo, need) ==
+                  HIPBLAS_STATUS_SUCCESS && need <= ws_bytes) {
+            r.workspaceSize = need;
+            cand.push_back(r);
+          }
+        }
+    }
+    size_t best = 0;
+    if (cand.size() > 1) {
       hipEvent_t e0, e1;
       GD_CHECK(hipEventCreate(&e0));
       GD_CHECK(hipEventCreate(&e1));
       float best_ms = 1e30f;
-      for (int i = 0; i < found; ++i) {
-        if (res[i].workspaceSize > ws_bytes) continue;
+      for (size_t i = 0; i < cand.size(); ++i) {
+        if (cand[i].workspaceSize > ws_bytes) continue;
         bool ok = true;
-        for (int rep = 0; rep < 4 && ok; ++rep) {     // rep 0 = warm-up
-          if (rep == 1) hipEventRecord(e0, st);
-          ok = hipblasLtMatmul(g_lt, p.desc, &alpha, A, p.la, B, p.lb, &beta, C, p.lc, C, p.lc, &res[i].algo, ws, res[i].workspaceSize,
-                               st) == HIPBLAS_STATUS_SUCCESS;
-        }
-        if (!ok) continue;
-        hipEventRecord(e1, st);
-        GD_CHECK(hipEventSynchronize(e1));
         float ms = 0.f;
-        hipEventElapsedTime(&ms, e0, e1);
-        if (ms < best_ms) { best_ms = ms; best = i; }
+        // pass 0: warm-up + one timed run (drops hopeless candidates); pass 1: three timed runs
+        for (int pass = 0; pass < 2 && ok; ++pass) {
+          const int reps = pass == 0 ? 1 : 3;
+          if (pass == 0)
+            ok = hipblasLtMatmul(g_lt, p.desc, &alpha, A, p.la, B, p.lb, &beta, C, p.lc, C, p.lc, &cand[i].algo, ws, cand[i].workspaceSize,
+                                 st) == HIPBLAS_STATUS_SUCCESS;
+          if (!ok) break;
+          hipEventRecord(e0, st);
+          for (int rep = 0; rep < reps && ok; ++rep)
+            ok = hipblasLtMatmul(g_lt, p.desc, &alpha, A, p.la, B, p.lb, &beta, C, p.lc, C, p.lc, &cand[i].algo, ws, cand[i].workspaceSize,
+                                 st) == HIPBLAS_STATUS_SUCCESS;
+          hipEventRecord(e1, st);
+          GD_CHECK(hipEventSynchronize(e1));
+          hipEventElapsedTime(&ms, e0, e1);
+          ms /= reps;
+          if (pass == 0 && ms > 1.3f * best_ms) break;      // clearly slower than the best so far
+        }
+        if (ok && ms < best_ms) { best_ms = ms; best = i; }
       }
       hipEventDestroy(e0);
       hipEventDestroy(e1);
     }
-    p.algo = res[best].algo;
-    p.ws = res[best].workspaceSize;
+    p.algo = cand[best].algo;
+    p.ws = cand[best].workspaceSize;
     it = g_plans.emplace(key, p).first;
   }
   GemmPlan& p = it->second;
