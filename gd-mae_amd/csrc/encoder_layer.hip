@@ -317,6 +317,13 @@ long long pad_rows(long long n) { return (n + kPad - 1) / kPad * kPad; }
 
 }  // namespace
 
+int gd_add_layernorm_fwd_ex(const float* a, const void* b, int b_is_bf16, const float* gamma, const float* beta, long long n, int d,
+                            float eps, float* y, float* stats, void* y_bf16, const float* pos_table, const int* tok_pos,
+                            void* ypos_bf16, hipStream_t st);
+int gd_add_layernorm_bwd_ex(const float* a, const void* b, int b_is_bf16, const float* gamma, const float* stats, const float* dy,
+                            const void* dy2, int dy2_bf16, const void* dy3, int dy3_bf16, long long n, int d, float* dx,
+                            void* dx_bf16, float* sums, void* workspace, hipStream_t st);
+
 extern "C" int gdmae_encoder_layer_bytes(long long n, int d, int ff, int nhead, int bf16, size_t* saved_bytes,
                                          size_t* fwd_scratch_bytes, size_t* bwd_scratch_bytes) {
   const long long n_pad = pad_rows(n);
@@ -326,7 +333,10 @@ extern "C" int gdmae_encoder_layer_bytes(long long n, int d, int ff, int nhead, 
   return 0;
 }
 
-extern "C" int gdmae_encoder_layer_fwd(const gdmae_layer_args* a, void* stream) {
+// One layer forward.  `next` (bf16 mode only): the layer that consumes this one's output - its q/k and v inputs
+// (x, x + pos in bf16) are then written by this layer's second LayerNorm pass; `prepped`: this layer's inputs were
+// written that way by the previous layer (its gdmae_prep_tokens pass is skipped).
+static int layer_fwd(const gdmae_layer_args* a, const gdmae_layer_args* next, bool prepped, void* stream) {
   GD_REQUIRE(a->n > 0 && a->d % 8 == 0 && a->ff % 8 == 0, "encoder layer: bad sizes");
   GD_REQUIRE(a->n_levels >= 1 && a->n_levels <= 4, "encoder layer: 1..4 window levels");
   const long long n = a->n, n_pad = pad_rows(n);
@@ -342,7 +352,7 @@ extern "C" int gdmae_encoder_layer_fwd(const gdmae_layer_args* a, void* stream) 
   add_zero(z, s.x1b, n, n_pad, (long long)d * es);   // fp32 mode: x1 itself
   GD_TRY(zero_regions(c, z));
   if (a->bf16) {
-    GD_TRY(gdmae_prep_tokens(a->x, a->pos_table, a->tok_pos, n, d, s.xb, s.xpb, 1, stream));
+    if (!prepped) GD_TRY(gdmae_prep_tokens(a->x, a->pos_table, a->tok_pos, n, d, s.xb, s.xpb, 1, stream));
   } else {
     GD_CHECK(hipMemcpyAsync(s.xb, a->x, (size_t)n * d * 4, hipMemcpyDeviceToDevice, c.st));
     GD_TRY(gdmae_prep_tokens(a->x, a->pos_table, a->tok_pos, n, d, nullptr, s.xpb, 0, stream));
@@ -364,11 +374,35 @@ extern "C" int gdmae_encoder_layer_fwd(const gdmae_layer_args* a, void* stream) 
   GD_TRY(linear_fwd(c, s.x1b, a->W1, a->b1, s.h, n_pad, ff, d));
   GD_TRY(gelu(c, true, nullptr, s.h, s.gact, n_pad * ff));
   GD_TRY(linear_fwd(c, s.gact, a->W2, a->b2, s.f, n_pad, d, ff));
-  GD_TRY(gdmae_add_layernorm_fwd((const float*)s.x1, s.f, a->bf16, a->g2, a->be2, n, d, a->eps, a->y, (float*)s.st2, nullptr, stream));
+  if (next && a->bf16) {
+    Saved sn = saved_layout(next->saved, n_pad, d, ff, es);
+    GD_TRY(gd_add_layernorm_fwd_ex((const float*)s.x1, s.f, 1, a->g2, a->be2, n, d, a->eps, a->y, (float*)s.st2, sn.xb, next->pos_table,
+                                   next->tok_pos, sn.xpb, c.st));
+  } else {
+    GD_TRY(gdmae_add_layernorm_fwd((const float*)s.x1, s.f, a->bf16, a->g2, a->be2, n, d, a->eps, a->y, (float*)s.st2, nullptr, stream));
+  }
   return 0;
 }
 
-extern "C" int gdmae_encoder_layer_bwd(const gdmae_layer_args* a, void* stream) {
+extern "C" int gdmae_encoder_layer_fwd(const gdmae_layer_args* a, void* stream) { return layer_fwd(a, nullptr, false, stream); }
+
+// L consecutive layers of one stage (same n, d, ff; layer i + 1 reads layer i's y): one call, and in bf16 mode the
+// prep_tokens pass of layers 1.. is folded into the previous layer's second LayerNorm.
+extern "C" int gdmae_encoder_stage_fwd(const gdmae_layer_args* layers, int n_layers, void* stream) {
+  GD_REQUIRE(n_layers >= 1, "encoder stage: no layers");
+  for (int i = 0; i < n_layers; ++i) {
+    GD_REQUIRE(i == 0 || (layers[i].x == layers[i - 1].y && layers[i].n == layers[0].n && layers[i].d == layers[0].d &&
+                          layers[i].ff == layers[0].ff && layers[i].bf16 == layers[0].bf16),
+               "encoder stage: layers must chain (x[i] = y[i-1]) and share n, d, ff, dtype");
+    GD_TRY(layer_fwd(&layers[i], i + 1 < n_layers ? &layers[i + 1] : nullptr, i > 0 && layers[i].bf16, stream));
+  }
+  return 0;
+}
+
+// One layer backward.  `upstream3`: the upstream gradient is the sum of three tensors left in `scratch` by the
+// backward of the NEXT layer (its residual-stream gradient, dx_qk, dx_v - that layer skipped its add3 pass) instead of
+// a->dy; `defer_add3`: leave this layer's own three pieces in scratch for the previous layer the same way.
+static int layer_bwd(const gdmae_layer_args* a, bool upstream3, bool defer_add3, void* stream) {
   GD_REQUIRE(a->n > 0 && a->d % 8 == 0 && a->ff % 8 == 0, "encoder layer: bad sizes");
   const long long n = a->n, n_pad = pad_rows(n);
   const int d = a->d, ff = a->ff, es = a->bf16 ? 2 : 4;
@@ -388,8 +422,12 @@ extern "C" int gdmae_encoder_layer_bwd(const gdmae_layer_args* a, void* stream) 
   ++z.count;
   GD_TRY(zero_regions(c, z));
   // ---- LN2 and FFN
-  GD_TRY(gdmae_add_layernorm_bwd((const float*)s.x1, s.f, a->bf16, a->g2, (const float*)s.st2, a->dy, nullptr, 0, n, d,
-                                 (float*)w.dx1_res, a->bf16 ? w.dfb : nullptr, (float*)w.s2, w.ln_ws, stream));
+  if (upstream3)   // dx_res / dx_qk / dx_v of the next layer are consumed here, before anything overwrites them
+    GD_TRY(gd_add_layernorm_bwd_ex((const float*)s.x1, s.f, a->bf16, a->g2, (const float*)s.st2, (const float*)w.dx_res, w.dx_qk, a->bf16,
+                                   w.dx_v, a->bf16, n, d, (float*)w.dx1_res, a->bf16 ? w.dfb : nullptr, (float*)w.s2, w.ln_ws, c.st));
+  else
+    GD_TRY(gdmae_add_layernorm_bwd((const float*)s.x1, s.f, a->bf16, a->g2, (const float*)s.st2, a->dy, nullptr, 0, n, d,
+                                   (float*)w.dx1_res, a->bf16 ? w.dfb : nullptr, (float*)w.s2, w.ln_ws, stream));
   GD_TRY(linear_dw(c, w.dfb, s.gact, a->dW2, n_pad, d, ff, (float*)w.part));
   GD_TRY(linear_dx(c, w.dfb, a->W2, w.dg, n_pad, d, ff));
   GD_TRY(gelu(c, false, w.dg, s.h, w.dh, n_pad * ff));
@@ -425,7 +463,7 @@ extern "C" int gdmae_encoder_layer_bwd(const gdmae_layer_args* a, void* stream) 
   }
   GD_TRY(linear_dx(c, w.dqk, Win, w.dx_qk, n_pad, 2 * d, d));
   GD_TRY(linear_dx(c, w.dv, Win + (size_t)2 * d * d * es, w.dx_v, n_pad, d, d));
-  GD_TRY(gdmae_add3((const float*)w.dx_res, w.dx_qk, a->bf16, w.dx_v, a->bf16, n * d, a->dx, stream));
+  if (!defer_add3) GD_TRY(gdmae_add3((const float*)w.dx_res, w.dx_qk, a->bf16, w.dx_v, a->bf16, n * d, a->dx, stream));
   // ---- LayerNorm / bias / temperature gradients
   AccJobs j;
   const float* s1 = (const float*)w.s1;
@@ -436,5 +474,20 @@ extern "C" int gdmae_encoder_layer_bwd(const gdmae_layer_args* a, void* stream) 
   j.count = 7;
   hipLaunchKernelGGL(k_acc_vectors, dim3((d + 255) / 256), dim3(256), 0, c.st, j);
   GD_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gdmae_encoder_layer_bwd(const gdmae_layer_args* a, void* stream) { return layer_bwd(a, false, false, stream); }
+
+// Backward of gdmae_encoder_stage_fwd (layers in reverse); all layers MUST share one scratch buffer: the three pieces
+// of a layer's input gradient stay there and are summed on load by the previous layer's LayerNorm backward.
+// layers[n_layers - 1].dy = upstream gradient of the stage, layers[0].dx = gradient of the stage input.
+extern "C" int gdmae_encoder_stage_bwd(const gdmae_layer_args* layers, int n_layers, void* stream) {
+  GD_REQUIRE(n_layers >= 1, "encoder stage: no layers");
+  for (int i = 0; i < n_layers; ++i)
+    GD_REQUIRE(layers[i].scratch == layers[0].scratch && layers[i].n == layers[0].n && layers[i].d == layers[0].d &&
+                   layers[i].ff == layers[0].ff && layers[i].bf16 == layers[0].bf16,
+               "encoder stage: layers must share scratch, n, d, ff, dtype");
+  for (int i = n_layers - 1; i >= 0; --i) GD_TRY(layer_bwd(&layers[i], i + 1 < n_layers, i > 0, stream));
   return 0;
 }

@@ -34,7 +34,9 @@ __global__ __launch_bounds__(256) void k_add_ln_fwd(const float* __restrict__ a,
                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
                                                     long long n, float eps, float* __restrict__ y,
                                                     float* __restrict__ stats /* (n, 2): mean, rstd */,
-                                                    unsigned short* __restrict__ y_bf16 /* optional copy */) {
+                                                    unsigned short* __restrict__ y_bf16 /* optional copy */,
+                                                    const float* __restrict__ pos_table, const int* __restrict__ tok_pos,
+                                                    unsigned short* __restrict__ ypos_bf16 /* optional: bf16(y + pos) */) {
   constexpr int D = VPL * GD_WAVE;
   const int lane = threadIdx.x & (GD_WAVE - 1);
   const int wib = threadIdx.x / GD_WAVE;
@@ -64,6 +66,8 @@ __global__ __launch_bounds__(256) void k_add_ln_fwd(const float* __restrict__ a,
       const float o = (s[k] - mean) * rstd * g[k] + bt[k];
       y[row * D + k * GD_WAVE + lane] = o;
       if (y_bf16) y_bf16[row * D + k * GD_WAVE + lane] = f_to_bf16(o);
+      if (ypos_bf16)   // q/k input of the NEXT layer (its gdmae_prep_tokens folded into this pass)
+        ypos_bf16[row * D + k * GD_WAVE + lane] = f_to_bf16(o + pos_table[(long long)tok_pos[row] * D + k * GD_WAVE + lane]);
     }
     if (lane == 0) {
       stats[row * 2] = mean;
@@ -78,7 +82,8 @@ __global__ __launch_bounds__(256) void k_add_ln_bwd(const float* __restrict__ a,
                                                     const float* __restrict__ dy, long long n, float* __restrict__ dx,
                                                     float* __restrict__ part /* (grid, 3, D) */,
                                                     const void* __restrict__ dy2 /* optional 2nd gradient */, int dy2_bf16,
-                                                    unsigned short* __restrict__ dx_bf16 /* optional copy */) {
+                                                    unsigned short* __restrict__ dx_bf16 /* optional copy */,
+                                                    const void* __restrict__ dy3 /* optional 3rd gradient */, int dy3_bf16) {
   constexpr int D = VPL * GD_WAVE;
   __shared__ float sh[4][3][D];
   const int lane = threadIdx.x & (GD_WAVE - 1);
@@ -102,6 +107,8 @@ __global__ __launch_bounds__(256) void k_add_ln_bwd(const float* __restrict__ a,
       float d = dy[row * D + k * GD_WAVE + lane];
       if (dy2) d += dy2_bf16 ? bf16_to_f(((const unsigned short*)dy2)[row * D + k * GD_WAVE + lane])
                              : ((const float*)dy2)[row * D + k * GD_WAVE + lane];
+      if (dy3) d += dy3_bf16 ? bf16_to_f(((const unsigned short*)dy3)[row * D + k * GD_WAVE + lane])
+                             : ((const float*)dy3)[row * D + k * GD_WAVE + lane];
       xh[k] = (s[k] - mean) * rstd;
       gy[k] = d * g[k];
       m1 += gy[k];
@@ -154,13 +161,13 @@ static inline int ln_grid(long long n) {
 extern "C" size_t gdmae_add_layernorm_workspace_bytes(int d) { return (size_t)1024 * 3 * d * sizeof(float); }
 
 // y = LayerNorm(a + b) * gamma + beta over rows of d in {64, 128, 256}; b_is_bf16: dtype of b.  stats (n,2) out.
-// y_bf16 (optional, may be NULL): bf16 copy of y for the next GEMM
-extern "C" int gdmae_add_layernorm_fwd(const float* a, const void* b, int b_is_bf16, const float* gamma, const float* beta,
-                                       long long n, int d, float eps, float* y, float* stats, void* y_bf16, void* stream) {
+// y_bf16 (optional, may be NULL): bf16 copy of y for the next GEMM; ypos_bf16 (optional): bf16(y + pos_table[tok_pos])
+int gd_add_layernorm_fwd_ex(const float* a, const void* b, int b_is_bf16, const float* gamma, const float* beta, long long n, int d,
+                            float eps, float* y, float* stats, void* y_bf16, const float* pos_table, const int* tok_pos,
+                            void* ypos_bf16, hipStream_t st) {
   if (n <= 0) return 0;
-  hipStream_t st = (hipStream_t)stream;
   const dim3 grid(ln_grid(n)), block(256);
-#define GD_LN_FWD(V, BF) hipLaunchKernelGGL((k_add_ln_fwd<V, BF>), grid, block, 0, st, a, b, gamma, beta, n, eps, y, stats, (unsigned short*)y_bf16)
+#define GD_LN_FWD(V, BF) hipLaunchKernelGGL((k_add_ln_fwd<V, BF>), grid, block, 0, st, a, b, gamma, beta, n, eps, y, stats, (unsigned short*)y_bf16, pos_table, tok_pos, (unsigned short*)ypos_bf16)
   if (d == 64) { if (b_is_bf16) GD_LN_FWD(1, true); else GD_LN_FWD(1, false); }
   else if (d == 128) { if (b_is_bf16) GD_LN_FWD(2, true); else GD_LN_FWD(2, false); }
   else if (d == 256) { if (b_is_bf16) GD_LN_FWD(4, true); else GD_LN_FWD(4, false); }
@@ -169,19 +176,23 @@ extern "C" int gdmae_add_layernorm_fwd(const float* a, const void* b, int b_is_b
   GD_LAUNCH_CHECK();
   return 0;
 }
+extern "C" int gdmae_add_layernorm_fwd(const float* a, const void* b, int b_is_bf16, const float* gamma, const float* beta,
+                                       long long n, int d, float eps, float* y, float* stats, void* y_bf16, void* stream) {
+  return gd_add_layernorm_fwd_ex(a, b, b_is_bf16, gamma, beta, n, d, eps, y, stats, y_bf16, nullptr, nullptr, nullptr,
+                                 (hipStream_t)stream);
+}
 
-// dx (n,d) = gradient w.r.t. (a + b) for upstream gradient dy (+ dy2 if not NULL); sums (3*d) = {dgamma, dbeta,
+// dx (n,d) = gradient w.r.t. (a + b) for upstream gradient dy (+ dy2, + dy3 if not NULL); sums (3*d) = {dgamma, dbeta,
 // column sums of dx (= bias gradient of the GEMM that produced b)}; dx_bf16 (optional): bf16 copy of dx;
 // workspace from ..._workspace_bytes(d)
-extern "C" int gdmae_add_layernorm_bwd(const float* a, const void* b, int b_is_bf16, const float* gamma, const float* stats,
-                                       const float* dy, const void* dy2, int dy2_bf16, long long n, int d, float* dx,
-                                       void* dx_bf16, float* sums, void* workspace, void* stream) {
+int gd_add_layernorm_bwd_ex(const float* a, const void* b, int b_is_bf16, const float* gamma, const float* stats, const float* dy,
+                            const void* dy2, int dy2_bf16, const void* dy3, int dy3_bf16, long long n, int d, float* dx,
+                            void* dx_bf16, float* sums, void* workspace, hipStream_t st) {
   if (n <= 0) return 0;
-  hipStream_t st = (hipStream_t)stream;
   const int nblk = ln_grid(n);
   const dim3 grid(nblk), block(256);
   float* part = (float*)workspace;
-#define GD_LN_BWD(V, BF) hipLaunchKernelGGL((k_add_ln_bwd<V, BF>), grid, block, 0, st, a, b, gamma, stats, dy, n, dx, part, dy2, dy2_bf16, (unsigned short*)dx_bf16)
+#define GD_LN_BWD(V, BF) hipLaunchKernelGGL((k_add_ln_bwd<V, BF>), grid, block, 0, st, a, b, gamma, stats, dy, n, dx, part, dy2, dy2_bf16, (unsigned short*)dx_bf16, dy3, dy3_bf16)
   if (d == 64) { if (b_is_bf16) GD_LN_BWD(1, true); else GD_LN_BWD(1, false); }
   else if (d == 128) { if (b_is_bf16) GD_LN_BWD(2, true); else GD_LN_BWD(2, false); }
   else if (d == 256) { if (b_is_bf16) GD_LN_BWD(4, true); else GD_LN_BWD(4, false); }
@@ -191,6 +202,12 @@ extern "C" int gdmae_add_layernorm_bwd(const float* a, const void* b, int b_is_b
   hipLaunchKernelGGL(k_reduce_partials_f32, dim3(gd_div_up(3 * d, 4)), dim3(256), 0, st, part, nblk, 3 * d, sums);
   GD_LAUNCH_CHECK();
   return 0;
+}
+extern "C" int gdmae_add_layernorm_bwd(const float* a, const void* b, int b_is_bf16, const float* gamma, const float* stats,
+                                       const float* dy, const void* dy2, int dy2_bf16, long long n, int d, float* dx,
+                                       void* dx_bf16, float* sums, void* workspace, void* stream) {
+  return gd_add_layernorm_bwd_ex(a, b, b_is_bf16, gamma, stats, dy, dy2, dy2_bf16, nullptr, 0, n, d, dx, dx_bf16, sums, workspace,
+                                 (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------------------------

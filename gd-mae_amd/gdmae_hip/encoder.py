@@ -18,6 +18,8 @@ libgdmae_hip.so.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -330,6 +332,87 @@ class EncoderLayerNativeFn(torch.autograd.Function):
             ret[2] = ret[2].to(tau_dtype)
         L.call("gdmae_encoder_layer_bwd", _C.byref(a), L.stream())
         return (dx, *ret, None, None, None, None, None, None)
+
+
+# ------------------------------------------------------------------------------------------------
+# stage executor: all layers of a stage (NUM_BLOCKS x 2) as ONE call per direction
+# ------------------------------------------------------------------------------------------------
+STAGE = os.environ.get("GDMAE_STAGE", "1") != "0"     # False / GDMAE_STAGE=0: one call per layer (A/B reference)
+
+
+def _plist(layer):
+    sa = layer.win_attn.self_attn
+    return (sa.in_proj_weight, sa.in_proj_bias, sa.tau, sa.out_proj.weight, sa.out_proj.bias, layer.linear1.weight,
+            layer.linear1.bias, layer.linear2.weight, layer.linear2.bias, layer.norm1.weight, layer.norm1.bias, layer.norm2.weight,
+            layer.norm2.bias)
+
+
+class EncoderStageFn(torch.autograd.Function):
+    """x -> layer_L(... layer_1(x)) through gdmae_encoder_stage_fwd / _bwd.  Only used when every parameter lives in a
+    flat optimizer buffer (gradients are accumulated there directly, so the parameters are not autograd inputs)."""
+
+    @staticmethod
+    def forward(ctx, x, info):
+        layers, wplans, pos_table, plists, directs = info
+        x = x.float().contiguous()
+        n, d = x.shape
+        dev = x.device
+        nl = len(layers)
+        l0 = layers[0]
+        sa = l0.win_attn.self_attn
+        nhead, tau_min, eps, ff = sa.num_heads, sa.tau_min, l0.norm1.eps, l0.linear1.weight.shape[0]
+        cdt = torch.bfloat16 if torch.is_autocast_enabled() else torch.float32
+        sb, fb, bb = _layer_bytes(n, d, ff, nhead, int(cdt == torch.bfloat16))
+        ys = torch.empty(nl, n, d, dtype=torch.float32, device=dev)
+        saved = torch.empty(nl, sb, dtype=torch.uint8, device=dev)
+        scratch = torch.empty(fb, dtype=torch.uint8, device=dev)
+        arr = (L.LayerArgs * nl)()
+        bases = []
+        for i in range(nl):
+            base, keep = _param_args(plists[i], cdt, directs[i])
+            bases.append((base, keep))
+            a = _call_args(base, x if i == 0 else ys[i - 1], wplans[i], pos_table, nhead, tau_min, eps, cdt, ff)
+            a.y, a.saved, a.scratch = ys[i].data_ptr(), saved[i].data_ptr(), scratch.data_ptr()
+            arr[i] = a
+        L.call("gdmae_encoder_stage_fwd", arr, nl, L.stream())
+        ctx.save_for_backward(x, ys, saved, pos_table)
+        ctx.meta = (wplans, nhead, tau_min, eps, cdt, ff, bb, bases)
+        return ys[nl - 1]
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, ys, saved, pos_table = ctx.saved_tensors
+        wplans, nhead, tau_min, eps, cdt, ff, bb, bases = ctx.meta
+        nl = ys.shape[0]
+        dy = dy.float().contiguous()
+        dx = torch.empty_like(x)
+        scratch = torch.empty(bb, dtype=torch.uint8, device=x.device)
+        arr = (L.LayerArgs * nl)()
+        for i in range(nl):
+            a = _call_args(bases[i][0], x if i == 0 else ys[i - 1], wplans[i], pos_table, nhead, tau_min, eps, cdt, ff)
+            a.saved, a.scratch = saved[i].data_ptr(), scratch.data_ptr()
+            if i == nl - 1:
+                a.dy = dy.data_ptr()
+            if i == 0:
+                a.dx = dx.data_ptr()
+            arr[i] = a
+        L.call("gdmae_encoder_stage_bwd", arr, nl, L.stream())
+        return dx, None
+
+
+def encoder_stage(blocks, x, pos_table, wplans):
+    """``blocks``: the stage's BasicShiftBlockV2 modules (layer k of a block uses window partition k % len(wplans))."""
+    pairs = [(layer, wplans[k % len(wplans)]) for block in blocks for k, layer in enumerate(block.encoder_list)]
+    layers = [p[0] for p in pairs]
+    if (STAGE and IMPL == "native" and not timing.enabled() and x.is_cuda and
+            all(getattr(l, "fused", False) and l.activation_name == "gelu" for l in layers)):
+        plists = [_plist(l) for l in layers]
+        directs = [[_direct(p) for p in pl] for pl in plists]
+        if all(t is not None for dl in directs for t in dl):
+            return EncoderStageFn.apply(x, (layers, [p[1] for p in pairs], pos_table, plists, directs))
+    for layer, wp in pairs:
+        x = layer(x, pos_table, wp)
+    return x
 
 
 def encoder_layer(layer, x, wplan, pos_table):

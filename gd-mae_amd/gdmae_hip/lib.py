@@ -71,6 +71,8 @@ SIGNATURES = {
     "gdmae_encoder_layer_bytes": (_I, [_L, _I, _I, _I, _I, _P, _P, _P]),
     "gdmae_encoder_layer_fwd": (_I, [_P, _P]),
     "gdmae_encoder_layer_bwd": (_I, [_P, _P]),
+    "gdmae_encoder_stage_fwd": (_I, [_P, _I, _P]),
+    "gdmae_encoder_stage_bwd": (_I, [_P, _I, _P]),
     "gdmae_group_gt_points": (_I, [_P, _I, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
     "gdmae_chamfer": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P]),
     "gdmae_group_workspace_bytes": (_Z, [_L, _L]),

@@ -15,6 +15,7 @@ import torch.nn as nn
 
 from ..model_utils.sst_basic_block import BasicShiftBlockV2
 from ...utils.spconv_utils import post_act_block, replace_feature, SparseConvTensor
+from gdmae_hip import encoder as genc
 from gdmae_hip import ops, plan as gplan
 
 
@@ -79,9 +80,7 @@ class SSTBlockV1(nn.Module):
         feat = sp_tensor.features
         wplans = sp_tensor.stage_plan.windows
         table = self.sst_input_layer.pos_table(feat.shape[1], feat.device)
-        out = feat
-        for block in self.encoder_blocks:
-            out = block(out, table, wplans)
+        out = genc.encoder_stage(self.encoder_blocks, feat, table, wplans)   # = block_k(... block_1(feat)), one call per stage
         sp_tensor = replace_feature(sp_tensor, feat + out)      # token drop is the identity (no un-shuffle)
         return self.conv_out(sp_tensor)
 

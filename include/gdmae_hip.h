@@ -285,6 +285,13 @@ int gdmae_encoder_layer_bytes(long long n, int d, int ff, int nhead, int bf16, s
                               size_t* fwd_scratch_bytes, size_t* bwd_scratch_bytes);   /* depend on n only through ceil(n / 2048) */
 int gdmae_encoder_layer_fwd(const gdmae_layer_args* args /* host */, void* stream);
 int gdmae_encoder_layer_bwd(const gdmae_layer_args* args /* host */, void* stream);
+/* n_layers consecutive layers of one stage in one call (BasicShiftBlockV2 x NUM_BLOCKS, sst_basic_block.py:100-114):
+ * layers[i+1].x == layers[i].y, same n / d / ff / dtype.  In bf16 mode the q/k and v inputs of layers 1.. are written
+ * by the previous layer's second LayerNorm, and in the backward (all layers sharing ONE scratch buffer) the three
+ * pieces of a layer's input gradient are summed on load by the previous layer instead of being added and re-read.
+ * Backward: layers[n_layers-1].dy = upstream gradient, layers[0].dx = gradient of the stage input. */
+int gdmae_encoder_stage_fwd(const gdmae_layer_args* layers /* host array */, int n_layers, void* stream);
+int gdmae_encoder_stage_bwd(const gdmae_layer_args* layers /* host array */, int n_layers, void* stream);
 
 /* ---- a17-a19: reconstruction targets and Chamfer loss ----------------------------------------- *
  * gdmae_group_gt_points replaces sst_ops_cuda.group_inner_inds_wrapper (sst_ops_api.cpp:8;

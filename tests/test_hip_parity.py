@@ -679,3 +679,32 @@ def test_border_sums_match_torch(bdt):
     assert int(masks.sum()) > 20
     assert torch.allclose(out[:8], refY, rtol=1e-5, atol=1e-4)
     assert torch.allclose(out[8:], refR, rtol=1e-5, atol=1e-4)
+
+
+def test_stage_executor_equals_per_layer_calls():
+    """gdmae_encoder_stage_fwd/bwd (4 layers per call, prep_tokens / add3 folded into the neighbouring LayerNorm passes)
+    vs one gdmae_encoder_layer call per layer, in the bench configuration: identical arithmetic -> identical results."""
+    import logging
+    from gdmae_hip import configs, optim
+    from gdmae_hip import encoder as genc
+    from pcdet.models import build_network
+    z, ds, cfg, shapes = load_case("waymo_b1")
+    res = {}
+    for stage in (True, False):
+        genc.STAGE = stage
+        torch.manual_seed(0)
+        net = build_network(cfg, len(ds.class_names), ds, logging.getLogger("t")).to(dev())
+        net.load_state_dict(orc.seeded_state_dict(shapes, seed=int(z["seed"])), strict=False)
+        net.train()
+        opt = optim.FlatAdamOneCycle(net, configs.optimization_cfg(8), total_steps=10)
+        opt.zero_grad()
+        bd = {"points": torch.from_numpy(z["points"]).to(dev()), "batch_size": int(z["batch_size"]),
+              "mae_noise": torch.from_numpy(z["noise"]).to(dev())}
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            ret, _, _ = net(bd)
+        ret["loss"].backward()
+        res[stage] = (float(ret["loss"]), opt.flat_grad.clone())
+    genc.STAGE = True
+    assert res[True][0] == res[False][0]
+    g1, g0 = res[True][1], res[False][1]
+    assert float((g1 - g0).norm()) <= 1e-6 * float(g0.norm()), float((g1 - g0).norm() / g0.norm())
