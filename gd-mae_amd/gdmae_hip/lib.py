@@ -75,6 +75,8 @@ SIGNATURES = {
     "gdmae_encoder_stage_bwd": (_I, [_P, _I, _P]),
     "gdmae_group_gt_points": (_I, [_P, _I, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
     "gdmae_chamfer": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P]),
+    "gdmae_augment_collate_workspace_bytes": (_Z, [_L]),
+    "gdmae_augment_collate": (_I, [_P, _L, _I, _P, _I, _P, _P, _P, _P, _P, _P]),
     "gdmae_group_workspace_bytes": (_Z, [_L, _L]),
     "gdmae_ingroup_inds": (_I, [_P, _L, _L, _P, _P, _Z, _P]),
     "gdmae_group_inner_inds": (_I, [_P, _L, _L, _I, _P, _P, _Z, _P]),

@@ -307,6 +307,18 @@ int gdmae_group_gt_points(const float* points, int n_cols, const int* pillar_pt_
 int gdmae_chamfer(const float* pred, const float* gt, const float* weights, int M, int P1, int P2, float* term,
                   float* dpred, void* stream);
 
+/* ---- f2 (next row): on-GPU input pipeline ------------------------------------------------------- *
+ * World flip / rotation / scaling (data_augmentor.py:54-143, common_utils.py:99-121), xy range mask
+ * (data_processor.py:77-88, common_utils.py:124-127) and collate with the batch index in column 0 (dataset.py:181-186)
+ * of the B raw frames of a batch in one pass.  raw (n_raw, F) fp32, frames back to back; frame_off (B+1) int32 device;
+ * frame_params (B, 8) fp32 device = [flip_x, flip_y, cos, sin, scale, 0, 0, 0] per frame (drawn on the host like the
+ * reference draws them); xy_range host {xmin, ymin, xmax, ymax}.  out (n_raw, 1+F) receives the kept points in
+ * input order; kept_off (B+1) int32 device: first output row of every non-empty frame (-1 for an empty one),
+ * kept_off[B] = number of rows written.  shuffle_points is a row permutation applied afterwards (gdmae_gather_rows). */
+size_t gdmae_augment_collate_workspace_bytes(long long n_raw);
+int gdmae_augment_collate(const float* raw, long long n_raw, int F, const int* frame_off, int B, const float* frame_params,
+                          const float* xy_range /* host */, float* out, int* kept_off, void* workspace, void* stream);
+
 /* ---- the reference's own native op API for this path, for arbitrary group ids ------------------- *
  * Drop-in equivalents of pybind module pcdet.ops.sst_ops.sst_ops_cuda (pcdet/ops/sst_ops/src/sst_ops_api.cpp:6-9):
  *   int ingroup_inds_wrapper(at::Tensor group_inds, at::Tensor out_inds)          (sst_ops.cpp:21-33)
