@@ -39,12 +39,30 @@ def one_cycle(step: int, total_step: int, lr_max: float, moms, div_factor: float
 class FlatAdamOneCycle:
     """Owns flat fp32 parameter / gradient / moment buffers; model parameters become views into them."""
 
-    def __init__(self, model: torch.nn.Module, optim_cfg, total_steps: int, process_group=None):
+    def __init__(self, model: torch.nn.Module, optim_cfg, total_steps: int, process_group=None,
+                 reference_layer_groups: bool = True):
+        """``reference_layer_groups`` (default, = what the reference trains): build_optimizer('adam_onecycle') collects
+        the optimizer's parameters with ``flatten_model`` = the LEAF modules of the model
+        (tools/train_utils/optimization/__init__.py:20-31, fastai_optim.py:16-27,115-122), so parameters registered
+        directly on a module that also has children are never updated: for this model the 36 tensors
+        ``win_attn.self_attn.{in_proj_weight, in_proj_bias, tau}`` (1.78 M of 8.09 M parameters; verified against the
+        imported reference, tests/golden/optimizer_params.json).  Their gradients still enter the global clip norm
+        (``clip_grad_norm_(model.parameters())``, train_utils.py:52) and the all-reduce.  They are placed at the end of
+        the flat buffers and the Adam launch stops before them.  False: every parameter is optimised."""
         params = [p for p in model.parameters() if p.requires_grad]
         assert params and all(p.dtype == torch.float32 for p in params)
+        if reference_layer_groups:
+            leaf_owned = {id(p) for m in model.modules() if not any(True for _ in m.children())
+                          for p in m.parameters(recurse=False)}
+            frozen = [p for p in params if id(p) not in leaf_owned]
+            params = [p for p in params if id(p) in leaf_owned] + frozen
+        else:
+            frozen = []
+        self.frozen = frozen
         dev = params[0].device
         n = sum(p.numel() for p in params)
         self.n = n
+        self.n_opt = n - sum(p.numel() for p in frozen)
         self.flat_param = torch.empty(n, dtype=torch.float32, device=dev)
         self.flat_grad = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
@@ -96,7 +114,7 @@ class FlatAdamOneCycle:
         st = L.stream()
         L.call("gdmae_grad_sq_norm", L.ptr(self.flat_grad), self.n, L.ptr(self._part), L.ptr(self._sq), st)
         L.call("gdmae_adam_step", L.ptr(self.flat_param), L.ptr(self.flat_grad), L.ptr(self.exp_avg),
-               L.ptr(self.exp_avg_sq), self.n, float(lr), float(beta1), 0.99, 1e-8, float(c.WEIGHT_DECAY), self.t,
+               L.ptr(self.exp_avg_sq), self.n_opt, float(lr), float(beta1), 0.99, 1e-8, float(c.WEIGHT_DECAY), self.t,
                float(c.GRAD_NORM_CLIP), L.ptr(self._sq), st)
         self._refresh_shadows()
         return lr, beta1

@@ -85,3 +85,52 @@ def test_hip_flat_adam_matches_reference_trajectory():
     a = np.concatenate([p.detach().cpu().numpy().ravel() for p in m2.parameters()])
     b = np.concatenate([p.detach().numpy().ravel() for p in ref_ps])
     assert np.abs(a - b).max() <= 5e-6 * np.abs(b).max()
+
+
+def test_optimised_parameter_set_equals_the_reference():
+    """The reference's 'adam_onecycle' optimiser only holds the parameters of LEAF modules (flatten_model): the golden
+    lists what the imported reference optimises for this model; FlatAdamOneCycle must freeze exactly the rest."""
+    import json
+    import logging
+    from pcdet.models import build_network
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "optimizer_params.json")))
+    cfg, ds, _ = configs.named_config("B", mask_ratio=0.75)
+    net = build_network(cfg, len(ds.class_names), ds, logging.getLogger("t"))
+    names = {id(p): n for n, p in net.named_parameters()}
+    opt = optim.FlatAdamOneCycle(net, configs.optimization_cfg(8), total_steps=10)
+    assert sorted(names[id(p)] for p in opt.frozen) == g["skipped"]
+    frozen_ids = {id(q) for q in opt.frozen}
+    assert sorted(names[id(p)] for p in opt.params if id(p) not in frozen_ids) == sorted(g["optimised_non_bn"] + g["optimised_bn"])
+    assert opt.n == g["numel_total"] and opt.n - opt.n_opt == g["numel_skipped"]
+    assert all(n.endswith(("in_proj_weight", "in_proj_bias", "tau")) for n in g["skipped"])
+    # the frozen tensors are the tail of the flat buffers
+    tail = opt.flat_param[opt.n_opt:]
+    assert opt.frozen[0].data_ptr() == tail.data_ptr()
+
+
+@pytest.mark.gpu
+def test_frozen_parameters_keep_their_values_but_count_in_the_clip_norm():
+    dev = torch.device("cuda:0")
+    net = torch.nn.Module()
+    net.attn = torch.nn.MultiheadAttention(8, 2)                 # in_proj_* are direct parameters, out_proj is a child
+    net.lin = torch.nn.Linear(8, 8)
+    net = net.to(dev)
+    cfgo = configs.optimization_cfg(8)
+    res = {}
+    for ref_groups in (True, False):
+        torch.manual_seed(0)
+        for p in net.parameters():
+            p.data = torch.randn_like(p)                          # fresh storage (the previous optimizer owns the old views)
+        opt = optim.FlatAdamOneCycle(net, cfgo, total_steps=10, reference_layer_groups=ref_groups)
+        before = {n: p.detach().clone() for n, p in net.named_parameters()}
+        opt.zero_grad()
+        torch.manual_seed(1)
+        for p in net.parameters():
+            p.grad.copy_(torch.randn_like(p) * 100)               # large: the global clip is active
+        opt.step(0)
+        res[ref_groups] = {n: (p.detach() - before[n]).abs().max().item() for n, p in net.named_parameters()}
+    assert res[True]["attn.in_proj_weight"] == 0 and res[True]["attn.in_proj_bias"] == 0
+    assert res[True]["attn.out_proj.weight"] > 0 and res[True]["lin.weight"] > 0
+    assert res[False]["attn.in_proj_weight"] > 0
+    # same clip factor in both modes (the frozen gradients are part of the norm): identical updates of the others
+    assert res[True]["lin.weight"] == res[False]["lin.weight"]
