@@ -59,6 +59,7 @@ class FlatAdamOneCycle:
         else:
             frozen = []
         self.frozen = frozen
+        self.model = model
         dev = params[0].device
         n = sum(p.numel() for p in params)
         self.n = n
@@ -119,10 +120,62 @@ class FlatAdamOneCycle:
         self._refresh_shadows()
         return lr, beta1
 
+    # ---- checkpoint wire format: the reference stores OptimWrapper.opt.state_dict(), i.e. the state_dict of a
+    #      torch.optim.Adam with two param groups [non-BatchNorm leaf parameters, BatchNorm parameters] in flatten_model
+    #      order (tools/train_utils/train_utils.py:147-163; fastai_optim.py:16-27,115-122)
+    def _reference_groups(self):
+        bn = (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d, torch.nn.BatchNorm3d, torch.nn.SyncBatchNorm)
+        leaves = [m for m in self.model.modules() if not any(True for _ in m.children())]
+        g0 = [p for m in leaves if not isinstance(m, bn) for p in m.parameters(recurse=False) if p.requires_grad]
+        g1 = [p for m in leaves if isinstance(m, bn) for p in m.parameters(recurse=False) if p.requires_grad]
+        return [g0, g1]
+
+    def _offsets(self):
+        off, table = 0, {}
+        for p in self.params:
+            table[id(p)] = (off, p.numel())
+            off += p.numel()
+        return table
+
     def state_dict(self):
-        return {"t": self.t, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq}
+        """torch.optim.Adam-compatible state of the parameters the reference optimises (loadable by the reference's
+        ``optimizer.load_state_dict`` and vice versa)."""
+        groups = self._reference_groups()
+        table = self._offsets()
+        lr, beta1 = one_cycle(max(self.t - 1, 0), self.total_steps, self.cfg.LR, list(self.cfg.MOMS), self.cfg.DIV_FACTOR,
+                              self.cfg.PCT_START)
+        state, pgs, idx = {}, [], 0
+        for g in groups:
+            ids = []
+            for p in g:
+                o, k = table[id(p)]
+                if self.t > 0:
+                    state[idx] = {"step": self.t, "exp_avg": self.exp_avg[o:o + k].view(p.shape).clone(),
+                                  "exp_avg_sq": self.exp_avg_sq[o:o + k].view(p.shape).clone()}
+                ids.append(idx)
+                idx += 1
+            pgs.append({"lr": lr, "betas": (beta1, 0.99), "eps": 1e-8, "weight_decay": 0, "amsgrad": False, "params": ids})
+        return {"state": state, "param_groups": pgs}
 
     def load_state_dict(self, sd):
-        self.t = int(sd["t"])
-        self.exp_avg.copy_(sd["exp_avg"])
-        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        if "param_groups" not in sd:                     # flat layout written by earlier versions of this class
+            self.t = int(sd["t"])
+            self.exp_avg.copy_(sd["exp_avg"])
+            self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+            return
+        groups = self._reference_groups()
+        table = self._offsets()
+        assert [len(g["params"]) for g in sd["param_groups"]] == [len(g) for g in groups], "optimizer state: group sizes differ"
+        flat = [p for g in groups for p in g]
+        steps = set()
+        for idx, p in enumerate(flat):
+            st = sd["state"].get(idx)
+            if st is None:
+                continue
+            o, k = table[id(p)]
+            assert tuple(st["exp_avg"].shape) == tuple(p.shape), (idx, st["exp_avg"].shape, p.shape)
+            self.exp_avg[o:o + k].copy_(st["exp_avg"].reshape(-1))
+            self.exp_avg_sq[o:o + k].copy_(st["exp_avg_sq"].reshape(-1))
+            steps.add(int(st["step"]))
+        assert len(steps) <= 1, f"optimizer state with different step counts per tensor: {steps}"
+        self.t = steps.pop() if steps else 0

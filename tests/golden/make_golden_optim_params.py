@@ -43,6 +43,9 @@ opt = fastai_optim.OptimWrapper.create(partial(torch.optim.Adam, betas=(0.9, 0.9
 ids = [{id(p) for p in g["params"]} for g in opt.opt.param_groups]
 names = {id(p): n for n, p in net.named_parameters()}
 out = {"optimised_non_bn": sorted(names[i] for i in ids[0]), "optimised_bn": sorted(names[i] for i in ids[1]),
+       # order of the tensors inside the two torch.optim.Adam param groups (= index space of optimizer_state['state'])
+       "group_order": [[names[id(p)] for p in g["params"]] for g in opt.opt.param_groups],
+       "group_keys": sorted(k for k in opt.opt.state_dict()["param_groups"][0] if k != "params"),
        "skipped": sorted(n for n, p in net.named_parameters() if id(p) not in ids[0] | ids[1]),
        "numel_skipped": int(sum(p.numel() for p in net.parameters() if id(p) not in ids[0] | ids[1])),
        "numel_total": int(sum(p.numel() for p in net.parameters()))}

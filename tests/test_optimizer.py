@@ -134,3 +134,43 @@ def test_frozen_parameters_keep_their_values_but_count_in_the_clip_norm():
     assert res[False]["attn.in_proj_weight"] > 0
     # same clip factor in both modes (the frozen gradients are part of the norm): identical updates of the others
     assert res[True]["lin.weight"] == res[False]["lin.weight"]
+
+
+def test_checkpoint_wire_format_round_trips_through_torch_adam(tmp_path):
+    """f4: optimizer_state written by FlatAdamOneCycle is a torch.optim.Adam state_dict with the reference's two param
+    groups in the reference's order (golden from the imported reference) - a real torch Adam built the reference way
+    loads it, and what that Adam saves loads back."""
+    import json
+    import logging
+    from gdmae_hip import checkpoint as ck
+    from pcdet.models import build_network
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "optimizer_params.json")))
+    cfg, ds, _ = configs.named_config("B", mask_ratio=0.75)
+    log = logging.getLogger("t")
+    net = build_network(cfg, len(ds.class_names), ds, log)
+    names = {id(p): n for n, p in net.named_parameters()}
+    opt = optim.FlatAdamOneCycle(net, configs.optimization_cfg(8), total_steps=10)
+    groups = opt._reference_groups()
+    assert [[names[id(p)] for p in gr] for gr in groups] == g["group_order"]
+    # fake a few steps worth of state
+    opt.t = 3
+    opt.exp_avg.copy_(torch.randn(opt.n))
+    opt.exp_avg_sq.copy_(torch.rand(opt.n))
+    ck.save_checkpoint(ck.checkpoint_state(net, opt, epoch=2, it=3), str(tmp_path / "checkpoint_epoch_2"))
+    disk = torch.load(str(tmp_path / "checkpoint_epoch_2.pth"), weights_only=False)
+    assert set(disk) == {"epoch", "it", "model_state", "optimizer_state", "version"}
+    assert set(disk["optimizer_state"]["param_groups"][0]) >= set(g["group_keys"]) - {"maximize", "foreach", "capturable",
+                                                                                     "differentiable", "fused", "decoupled_weight_decay"}
+    adam = torch.optim.Adam([{"params": gr, "lr": 0} for gr in groups], betas=(0.9, 0.99))
+    adam.load_state_dict(disk["optimizer_state"])                      # the reference's resume path
+    p0 = groups[0][5]
+    o, k = opt._offsets()[id(p0)]
+    assert torch.equal(adam.state[p0]["exp_avg"].reshape(-1), opt.exp_avg[o:o + k])
+    # and back: a fresh model / optimizer resumes from what torch Adam writes
+    net2 = build_network(cfg, len(ds.class_names), ds, log)
+    opt2 = optim.FlatAdamOneCycle(net2, configs.optimization_cfg(8), total_steps=10)
+    torch.save({"epoch": 2, "it": 3, "model_state": net.state_dict(), "optimizer_state": adam.state_dict(), "version": "x"},
+               str(tmp_path / "ref.pth"))
+    it, ep = net2.load_params_with_optimizer(str(tmp_path / "ref.pth"), to_cpu=True, optimizer=opt2, logger=log)
+    assert (it, ep) == (3, 2) and opt2.t == 3
+    assert torch.equal(opt2.exp_avg[:opt2.n_opt], opt.exp_avg[:opt.n_opt]) and torch.equal(opt2.flat_param, opt.flat_param)
