@@ -49,6 +49,14 @@ def gdmae_ssl_model_cfg(mask_ratio=0.85, d_models=(128, 256, 256), ffs=(256, 512
     })
 
 
+def gdmae_finetune_backbone_cfg(**kw):
+    """BACKBONE_3D section of the fine-tune configs (tools/cfgs/{kitti,waymo}_models/gd_mae.yaml:81-133): SPTBackbone with
+    the same SST block list / decoder sources as the pre-training backbone, no masking."""
+    b = gdmae_ssl_model_cfg(**kw).BACKBONE_3D
+    return AttrDict({'NAME': 'SPTBackbone', 'SST_BLOCK_LIST': b.SST_BLOCK_LIST, 'FEATURES_SOURCE': b.FEATURES_SOURCE,
+                     'FUSE_LAYER': b.FUSE_LAYER})
+
+
 def optimization_cfg(batch_size_per_gpu=8, num_epochs=30):
     """OPTIMIZATION section of the ssl yamls (gd_mae_ssl.yaml:183-203)."""
     return AttrDict({'BATCH_SIZE_PER_GPU': batch_size_per_gpu, 'NUM_EPOCHS': num_epochs, 'OPTIMIZER': 'adam_onecycle',

@@ -2,6 +2,8 @@
 
 Integer/index outputs must be bit-exact; floating point within the tolerance written next to each check
 (north_star: Chamfer loss within 1e-4 relative in fp32)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -708,3 +710,47 @@ def test_stage_executor_equals_per_layer_calls():
     assert res[True][0] == res[False][0]
     g1, g0 = res[True][1], res[False][1]
     assert float((g1 - g0).norm()) <= 1e-6 * float(g0.norm()), float((g1 - g0).norm() / g0.norm())
+
+
+def test_finetune_backbone_vs_reference_golden():
+    """Next row f1 (encoder part): DynVFE + SPTBackbone without masking (all pillars are tokens, every occupancy level
+    populated, dense decoder dataflow) against the reference golden (tests/golden/make_golden_finetune.py): active sets
+    bit-exact, stage features / spatial_features / every parameter-gradient norm within fp32 round-off."""
+    from gdmae_hip import configs
+    from pcdet.models.backbones_3d import SPTBackbone
+    from pcdet.models.backbones_3d.vfe import DynVFE
+    z = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "finetune_kitti_b2.npz")))
+    ds = configs.SyntheticDatasetInfo(**configs.KITTI)
+    cfg = configs.gdmae_ssl_model_cfg(eval_metric="kitti")
+    F = int(z["num_point_features"])
+    vfe = DynVFE(model_cfg=cfg.VFE, num_point_features=F, voxel_size=ds.voxel_size, point_cloud_range=ds.point_cloud_range,
+                 grid_size=ds.grid_size)
+    bb = SPTBackbone(model_cfg=configs.gdmae_finetune_backbone_cfg(eval_metric="kitti"), input_channels=vfe.get_output_feature_dim(),
+                     grid_size=ds.grid_size, voxel_size=ds.voxel_size, point_cloud_range=ds.point_cloud_range)
+
+    class Wrap(torch.nn.Module):
+        def __init__(s):
+            super().__init__()
+            s.vfe, s.backbone_3d = vfe, bb
+    net = Wrap().to(dev())
+    names = [str(n) for n in z["param_names"]]
+    shapes = {n: tuple(int(v) for v in s if v > 0) for n, s in zip(names, z["param_shapes"])}
+    assert {k: tuple(v.shape) for k, v in net.named_parameters()} == shapes
+    net.load_state_dict(orc.seeded_state_dict(shapes, seed=int(z["seed"])), strict=False)
+    net.train()
+    B = int(z["batch_size"])
+    bd = bb(vfe({"points": torch.from_numpy(z["points"]).to(dev()), "batch_size": B}))
+    assert np.array_equal(bd["voxel_coords"].cpu().numpy(), z["voxel_coords"])
+    for i in range(3):
+        t = bd["multi_scale_3d_features"][f"x_conv{i + 1}"]
+        assert np.array_equal(t.indices.cpu().numpy(), z[f"st{i}_indices"])
+        assert_sampled_close(t.features, z[f"st{i}_features_s"], z[f"st{i}_features_c"], 5e-4, f"stage {i}")
+    sf = bd["spatial_features"]
+    assert_sampled_close(sf, z["spatial_features_s"], z["spatial_features_c"], 5e-4, "spatial_features")
+    wgt = torch.randn(tuple(sf.shape), generator=torch.Generator().manual_seed(int(z["seed"]) + 1)).to(dev())
+    ((sf * wgt).sum() / sf.numel()).backward()
+    g = dict(net.named_parameters())
+    gn = np.array([float(g[k].grad.double().norm()) for k in names])
+    rel = np.abs(gn - z["grad_norm"]) / (z["grad_norm"] + 1e-12)
+    tol = np.array([2.5e-1 if k.endswith("tau") else 2e-2 for k in names])
+    assert (rel <= tol).all(), [(names[i], rel[i]) for i in np.flatnonzero(rel > tol)]
