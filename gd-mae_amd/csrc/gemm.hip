@@ -210,7 +210,16 @@ int gd_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const void* A
     hipblasLtMatrixLayoutSetAttribute(lb, HIPBLASLT_MATRIX_LAYOUT_STRIDED_BATCH_OFFSET, &s_b, sizeof(s_b));
     hipblasLtMatrixLayoutSetAttribute(lc, HIPBLASLT_MATRIX_LAYOUT_STRIDED_BATCH_OFFSET, &s_c, sizeof(s_c));
   }
-  hipblasStatus_t rc = hipblasLtMatmul(g_lt, p.desc, &alpha, A, la, B, lb, &beta, C, lc, C, lc, &p.algo, ws, p.ws <= ws_bytes ? p.ws : ws_bytes, st);
+  // The algorithm object carries problem-specific state: re-validate a COPY of the bucket's algorithm against this
+  // call's extents (matmulIsAlgoSupported also refreshes that state and returns the workspace it needs); running a
+  // stale copy on other extents was observed to give wrong results once in a full test-suite run.
+  hipblasLtMatmulAlgo_t algo = p.algo;
+  size_t need = 0;
+  hipblasStatus_t rc = hipblaslt_ext::matmulIsAlgoSupported(g_lt, p.desc, &alpha, la, lb, &beta, lc, lc, algo, need);
+  if (rc == HIPBLAS_STATUS_SUCCESS && need <= ws_bytes)
+    rc = hipblasLtMatmul(g_lt, p.desc, &alpha, A, la, B, lb, &beta, C, lc, C, lc, &algo, ws, need, st);
+  else if (rc == HIPBLAS_STATUS_SUCCESS)
+    rc = HIPBLAS_STATUS_NOT_SUPPORTED;
   if (rc != HIPBLAS_STATUS_SUCCESS) {
     // the bucket's algorithm does not support these extents: ask for one that does (not cached)
     hipblasLtMatmulPreference_t pref;
