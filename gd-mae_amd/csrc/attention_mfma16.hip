@@ -72,8 +72,10 @@ struct AhArgs {
 };
 
 // normalise a row held as KS fragments (this lane's 8 * KS columns; the partner half-wave holds the rest), split hi/lo
+// `post`: extra factor folded into the split operands (1 / tau for the queries: the MFMA then yields the logits
+// directly and no per-element scaling is needed); the returned 1/|x| is the plain normalisation factor
 template <int KS>
-__device__ __forceinline__ float ah_normalize(const AhFrag (&raw)[KS], AhFrag (&hi)[KS], AhFrag (&lo)[KS]) {
+__device__ __forceinline__ float ah_normalize(const AhFrag (&raw)[KS], AhFrag (&hi)[KS], AhFrag (&lo)[KS], float post = 1.f) {
   float ss = 0.f;
 #pragma unroll
   for (int s = 0; s < KS; ++s)
@@ -88,7 +90,7 @@ __device__ __forceinline__ float ah_normalize(const AhFrag (&raw)[KS], AhFrag (&
   for (int s = 0; s < KS; ++s) {
     f32x8 x, r;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) x[j] = ah_bf2f(raw[s].s[j]) * inv;
+    for (int j = 0; j < 8; ++j) x[j] = ah_bf2f(raw[s].s[j]) * (inv * post);
     hi[s].v = __builtin_convertvector(x, bf16x8);
 #pragma unroll
     for (int j = 0; j < 8; ++j) r[j] = x[j] - ah_bf2f(hi[s].s[j]);
@@ -142,18 +144,19 @@ __global__ __launch_bounds__(256) void k_attn_mfma16_fwd(AhArgs A) {
         qr[s].u = kr[s].u = vr[s].u = make_uint4(0, 0, 0, 0);
       }
     }
-    ah_normalize<KS>(qr, qhi[ti], qlo[ti]);
+    ah_normalize<KS>(qr, qhi[ti], qlo[ti], inv_tau);       // logits = (q^ / tau) . k^
     ah_normalize<KS>(kr, khi[ti], klo[ti]);
     ah_store_t<KS>(sV, LDT, r, half, vr);
   }
   // S^T[key][query] tiles
+  // padded keys start at -1e30 instead of 0: exp() of their logits is exactly 0, no per-element masking afterwards
   f32x16 acc[NT][NT];
 #pragma unroll
   for (int a = 0; a < NT; ++a)
 #pragma unroll
     for (int b = 0; b < NT; ++b)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = (32 * a + ah_row(r, half) < n) ? 0.f : -1e30f;
 #pragma unroll
   for (int s = 0; s < KS; ++s)
 #pragma unroll
@@ -171,12 +174,7 @@ __global__ __launch_bounds__(256) void k_attn_mfma16_fwd(AhArgs A) {
 #pragma unroll
     for (int kj = 0; kj < NT; ++kj)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = 32 * kj + ah_row(r, half);
-        const float a = key < n ? acc[kj][qi][r] * inv_tau : -INFINITY;
-        acc[kj][qi][r] = a;
-        m = fmaxf(m, a);
-      }
+      for (int r = 0; r < 16; ++r) m = fmaxf(m, acc[kj][qi][r]);
     m = fmaxf(m, __shfl_xor(m, 32, 64));
     float l = 0.f;
 #pragma unroll
@@ -293,7 +291,7 @@ __global__ __launch_bounds__(256) void k_attn_mfma16_bwd(AhBwdArgs A) {
         qr[s].u = kr[s].u = vf[ti][s].u = dof[ti][s].u = make_uint4(0, 0, 0, 0);
       }
     }
-    qin[ti] = ah_normalize<KS>(qr, qhi[ti], qlo[ti]);
+    qin[ti] = ah_normalize<KS>(qr, qhi[ti], qlo[ti], inv_tau);     // logits = (q^ / tau) . k^
     kin[ti] = ah_normalize<KS>(kr, khi[ti], klo[ti]);
     ah_store_t<KS>(sA, LDT, r, half, khi[ti]);     // K^^T tile: A operand of dQ^T
   }
@@ -307,7 +305,10 @@ __global__ __launch_bounds__(256) void k_attn_mfma16_bwd(AhBwdArgs A) {
 #pragma unroll
     for (int kj = 0; kj < NT; ++kj)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) aS[kj][r] = aP[kj][r] = 0.f;
+      for (int r = 0; r < 16; ++r) {
+        aS[kj][r] = (32 * kj + ah_row(r, half) < n) ? 0.f : -1e30f;    // padded keys: exp() = 0 without masking
+        aP[kj][r] = 0.f;
+      }
 #pragma unroll
     for (int s = 0; s < KS; ++s)
 #pragma unroll
@@ -321,12 +322,7 @@ __global__ __launch_bounds__(256) void k_attn_mfma16_bwd(AhBwdArgs A) {
 #pragma unroll
     for (int kj = 0; kj < NT; ++kj)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = 32 * kj + ah_row(r, half);
-        const float a = key < n ? aS[kj][r] * inv_tau : -INFINITY;
-        aS[kj][r] = a;
-        m = fmaxf(m, a);
-      }
+      for (int r = 0; r < 16; ++r) m = fmaxf(m, aS[kj][r]);
     m = fmaxf(m, __shfl_xor(m, 32, 64));
     float l = 0.f, Dn = 0.f, E1 = 0.f, E2 = 0.f;
 #pragma unroll
@@ -334,12 +330,11 @@ __global__ __launch_bounds__(256) void k_attn_mfma16_bwd(AhBwdArgs A) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float a = aS[kj][r];
-        const float e = ah_exp(a - m);
-        const float af = e > 0.f ? a : 0.f;
+        const float e = ah_exp(a - m);                   // exactly 0 for padded keys (a = -1e30: finite, 0 * a = -0)
         l += e;
         Dn = fmaf(e, aP[kj][r], Dn);
-        E1 = fmaf(e * aP[kj][r], af, E1);
-        E2 = fmaf(e, af, E2);
+        E1 = fmaf(e * aP[kj][r], a, E1);
+        E2 = fmaf(e, a, E2);
         aS[kj][r] = e;
       }
     l += __shfl_xor(l, 32, 64);
@@ -352,9 +347,9 @@ __global__ __launch_bounds__(256) void k_attn_mfma16_bwd(AhBwdArgs A) {
 #pragma unroll
     for (int kj = 0; kj < NT; ++kj)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) aS[kj][r] = aS[kj][r] * il * (aP[kj][r] - D) * inv_tau;   // dS / tau_c
+      for (int r = 0; r < 16; ++r) aS[kj][r] = aS[kj][r] * il * (aP[kj][r] - D);   // dS (the 1/tau factor is applied to dq / dk)
     if (half == 0) {
-      sLse[32 * qi + rho] = lse;
+      sLse[32 * qi + rho] = qact ? lse : 1e30f;       // padded queries: exp(a - 1e30) = 0 in phase 2 without masking
       sD[32 * qi + rho] = D;
     }
     f32x16 oq;
@@ -379,10 +374,11 @@ __global__ __launch_bounds__(256) void k_attn_mfma16_bwd(AhBwdArgs A) {
     pr += __shfl_xor(pr, 32, 64);
     if (qact) {
       unsigned short* dst = gdqk + (long long)tok[qi] * 2 * d + h * DH;
+      const float sc = qin[qi] * inv_tau;
 #pragma unroll
       for (int g = 0; g < DH / 8; ++g)
-        ah_store4(dst + 8 * g + 4 * half, (oq[4 * g] - qv[g][0] * pr) * qin[qi], (oq[4 * g + 1] - qv[g][1] * pr) * qin[qi],
-                  (oq[4 * g + 2] - qv[g][2] * pr) * qin[qi], (oq[4 * g + 3] - qv[g][3] * pr) * qin[qi]);
+        ah_store4(dst + 8 * g + 4 * half, (oq[4 * g] - qv[g][0] * pr) * sc, (oq[4 * g + 1] - qv[g][1] * pr) * sc,
+                  (oq[4 * g + 2] - qv[g][2] * pr) * sc, (oq[4 * g + 3] - qv[g][3] * pr) * sc);
     }
   }
   // ================= phase 2: key on the lane (S, dP) -> dK, dV, one key tile at a time =================
@@ -396,11 +392,16 @@ __global__ __launch_bounds__(256) void k_attn_mfma16_bwd(AhBwdArgs A) {
   __builtin_amdgcn_wave_barrier();
 #pragma unroll
   for (int kj = 0; kj < NT; ++kj) {
+    const bool kact = 32 * kj + rho < n;
+    const float ini = kact ? 0.f : -1e30f;              // padded key (lane): probabilities exactly 0
     f32x16 aS[NT], aP[NT];
 #pragma unroll
     for (int qi = 0; qi < NT; ++qi)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) aS[qi][r] = aP[qi][r] = 0.f;
+      for (int r = 0; r < 16; ++r) {
+        aS[qi][r] = ini;
+        aP[qi][r] = 0.f;
+      }
 #pragma unroll
     for (int s = 0; s < KS; ++s)
 #pragma unroll
@@ -410,17 +411,25 @@ __global__ __launch_bounds__(256) void k_attn_mfma16_bwd(AhBwdArgs A) {
         aS[qi] = ah_mfma(qlo[qi][s].v, khi[kj][s].v, aS[qi]);
         aP[qi] = ah_mfma(dof[qi][s].v, vf[kj][s].v, aP[qi]);     // dP[q][key]
       }
-    const bool kact = 32 * kj + rho < n;
 #pragma unroll
-    for (int qi = 0; qi < NT; ++qi)
+    for (int qi = 0; qi < NT; ++qi) {
+      // row statistics of this lane-half's 16 query rows: read unconditionally (all 32 NT rows were written in phase 1;
+      // a conditional read costs an exec-mask branch per element)
+      float lq[16], dq[16];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 a = *reinterpret_cast<const float4*>(sLse + 32 * qi + 8 * g + 4 * half);
+        const float4 b = *reinterpret_cast<const float4*>(sD + 32 * qi + 8 * g + 4 * half);
+        lq[4 * g] = a.x; lq[4 * g + 1] = a.y; lq[4 * g + 2] = a.z; lq[4 * g + 3] = a.w;
+        dq[4 * g] = b.x; dq[4 * g + 1] = b.y; dq[4 * g + 2] = b.z; dq[4 * g + 3] = b.w;
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int q = 32 * qi + ah_row(r, half);
-        const bool ok = kact && q < n;
-        const float p = ok ? ah_exp(aS[qi][r] * inv_tau - sLse[q]) : 0.f;
-        aS[qi][r] = p * (aP[qi][r] - sD[q]) * inv_tau;   // dS / tau_c
+        const float p = ah_exp(aS[qi][r] - lq[r]);       // 0 for padded keys (logit -1e30) and padded queries (lse +1e30)
+        aS[qi][r] = p * (aP[qi][r] - dq[r]);             // dS
         aP[qi][r] = p;
       }
+    }
     f32x16 okk, ov;
 #pragma unroll
     for (int r = 0; r < 16; ++r) okk[r] = ov[r] = 0.f;
@@ -446,10 +455,11 @@ __global__ __launch_bounds__(256) void k_attn_mfma16_bwd(AhBwdArgs A) {
     if (kact) {
       unsigned short* dk = gdqk + (long long)tok[kj] * 2 * d + d + h * DH;
       unsigned short* dvp = gdv + (long long)tok[kj] * d + h * DH;
+      const float ksc = kin[kj];                  // the 1/tau factor of dk is already in the Q^^T operand (q^ / tau)
 #pragma unroll
       for (int g = 0; g < DH / 8; ++g) {
-        ah_store4(dk + 8 * g + 4 * half, (okk[4 * g] - kv[g][0] * pr) * kin[kj], (okk[4 * g + 1] - kv[g][1] * pr) * kin[kj],
-                  (okk[4 * g + 2] - kv[g][2] * pr) * kin[kj], (okk[4 * g + 3] - kv[g][3] * pr) * kin[kj]);
+        ah_store4(dk + 8 * g + 4 * half, (okk[4 * g] - kv[g][0] * pr) * ksc, (okk[4 * g + 1] - kv[g][1] * pr) * ksc,
+                  (okk[4 * g + 2] - kv[g][2] * pr) * ksc, (okk[4 * g + 3] - kv[g][3] * pr) * ksc);
         ah_store4(dvp + 8 * g + 4 * half, ov[4 * g], ov[4 * g + 1], ov[4 * g + 2], ov[4 * g + 3]);
       }
     }

@@ -20,6 +20,12 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
          "-Wno-unused-result"]
 
 
+# per-file additions.  -amdgpu-mfma-vgpr-form: MFMA results land in VGPRs instead of AGPRs; the attention kernels read
+# every accumulator element with VALU right after the MFMA, and the AGPR form costs one v_accvgpr_read per element
+# (551 -> 177 of ~5000 instructions in the T = 64 backward)
+EXTRA_FLAGS = {"attention_mfma16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+
+
 def _newer(src, dst):
     return not os.path.exists(dst) or os.path.getmtime(src) > os.path.getmtime(dst)
 
@@ -34,7 +40,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         obj = os.path.join(CSRC, s.replace(".hip", ".o"))
         objs.append(obj)
         if force or _newer(src, obj) or any(_newer(d, obj) for d in deps):
-            cmd = [hipcc, *FLAGS, "-c", src, "-o", obj]
+            cmd = [hipcc, *FLAGS, *EXTRA_FLAGS.get(s, []), "-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
