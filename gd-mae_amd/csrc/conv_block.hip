@@ -1,0 +1,135 @@
+// Native executor of one sparse-convolution block  SparseConv2d / SubMConv2d (k3) -> BatchNorm1d(train) -> ReLU
+// (reference post_act_block, pcdet/utils/spconv_utils.py:37-56; used as conv_down / conv_out of every SSTBlockV1,
+// spt_backbone.py:206,217,256-263): forward or backward enqueued by ONE C-ABI call instead of ~12 interpreter-issued ops
+// per direction (the forward of the training step is host-bound).  Same arithmetic as
+// gdmae_hip.ops.SparseConv3x3 + gdmae_hip.vfe.BNReLURows: rulebook gather (im2col) -> one GEMM -> column statistics ->
+// folded affine + ReLU rows; backward = BatchNorm chain rule on column sums, split-K weight gradient, transposed
+// rulebook gather + GEMM for the input gradient.  Parameter gradients are ACCUMULATED into the caller's fp32 buffers.
+#include "../../include/gdmae_hip.h"
+#include "common.h"
+#include "gemm.h"
+
+namespace {
+
+__device__ inline unsigned short cb_f2bf(float f) {
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7F800000u) == 0x7F800000u) return (unsigned short)(u >> 16);
+  return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+
+// out[s, :] = bf16(src[idx[s], :]) (0 for idx < 0): im2col gather of fp32 token rows with the cast folded in
+__global__ __launch_bounds__(256) void k_gather_rows_f32_bf16(const float* __restrict__ src, const int* __restrict__ idx,
+                                                              long long n_slots, int C, unsigned short* __restrict__ out) {
+  const int cv = C >> 3;
+  const long long total = n_slots * cv;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long s = i / cv;
+    const int c = (int)(i % cv) << 3;
+    const int j = idx[s];
+    uint4 q = make_uint4(0, 0, 0, 0);
+    if (j >= 0) {
+      const float4 a = *reinterpret_cast<const float4*>(src + (long long)j * C + c);
+      const float4 b = *reinterpret_cast<const float4*>(src + (long long)j * C + c + 4);
+      q.x = cb_f2bf(a.x) | ((unsigned)cb_f2bf(a.y) << 16);
+      q.y = cb_f2bf(a.z) | ((unsigned)cb_f2bf(a.w) << 16);
+      q.z = cb_f2bf(b.x) | ((unsigned)cb_f2bf(b.y) << 16);
+      q.w = cb_f2bf(b.z) | ((unsigned)cb_f2bf(b.w) << 16);
+    }
+    *reinterpret_cast<uint4*>(out + s * C + c) = q;
+  }
+}
+
+// Wt[(k, o), i] = W[o, k, i]  for W (cout, 9, cin): the B operand of the input-gradient GEMM
+template <typename T>
+__global__ __launch_bounds__(256) void k_permute_w(const T* __restrict__ W, int cout, int cin, T* __restrict__ Wt) {
+  const int total = cout * 9 * cin;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    const int i = e % cin, ko = e / cin, o = ko % cout, k = ko / cout;
+    Wt[e] = W[((long long)o * 9 + k) * cin + i];
+  }
+}
+
+struct Scratch {
+  char *gemm_ws, *cs_ws, *st, *rs_ws, *c01, *dy, *gcols, *wt, *sk_ws;
+  size_t bytes;
+};
+Scratch layout(void* base, long long n_in, long long n_out, int cin, int cout, int es) {
+  Scratch s;
+  size_t off = 0;
+  auto take = [&](size_t b) { char* p = (char*)base + off; off += gd_align(b); return p; };
+  s.gemm_ws = take(GD_LT_WORKSPACE);
+  s.cs_ws = take(gdmae_colstats_workspace_bytes(cout));
+  s.st = take((size_t)3 * cout * sizeof(double));
+  s.rs_ws = take(gdmae_rows_bwd_stats_workspace_bytes(cout));
+  s.c01 = take((size_t)2 * cout * sizeof(float));
+  s.dy = take((size_t)n_out * cout * es);
+  s.gcols = take((size_t)n_in * 9 * cout * es);
+  s.wt = take((size_t)9 * cout * cin * es);
+  s.sk_ws = take(gdmae_gemm_tn_splitk_workspace_bytes(n_out, cout, 9 * cin));
+  s.bytes = off;
+  return s;
+}
+
+#define CB_TRY(x)             \
+  do {                        \
+    int rc_ = (x);            \
+    if (rc_ != 0) return rc_; \
+  } while (0)
+
+}  // namespace
+
+extern "C" size_t gdmae_conv_block_scratch_bytes(long long n_in, long long n_out, int cin, int cout, int bf16) {
+  return layout(nullptr, n_in, n_out, cin, cout, bf16 ? 2 : 4).bytes;
+}
+
+extern "C" int gdmae_conv_block_fwd(const gdmae_conv_block_args* a, void* stream) {
+  GD_REQUIRE(a->cin % 8 == 0 && a->cout % 8 == 0 && a->cout <= 256, "conv block: channels must be multiples of 8, cout <= 256");
+  if (a->n_out <= 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const int es = a->bf16 ? 2 : 4;
+  Scratch s = layout(a->scratch, a->n_in, a->n_out, a->cin, a->cout, es);
+  const long long slots = a->n_out * 9;
+  if (a->bf16 && a->x_f32) {
+    long long g = (slots * (a->cin / 8) + 255) / 256;
+    if (g > 16384) g = 16384;
+    hipLaunchKernelGGL(k_gather_rows_f32_bf16, dim3((int)g), dim3(256), 0, st, (const float*)a->x, a->nbr, slots, a->cin,
+                       (unsigned short*)a->cols);
+    GD_LAUNCH_CHECK();
+  } else {
+    CB_TRY(gdmae_gather_rows(a->x, a->nbr, slots, a->cin * es, a->cols, stream));
+  }
+  CB_TRY(gdmae_gemm(a->cols, a->W, a->y, a->n_out, a->cout, 9ll * a->cin, 0, 1, a->bf16, 0, nullptr, s.gemm_ws, stream));
+  CB_TRY(gdmae_bn_fold(a->y, a->n_out, a->cout, a->bf16, (double)a->n_out, a->gamma, a->beta, a->eps, a->momentum, a->running_mean,
+                       a->running_var, a->num_batches, a->stats, a->ab, a->mv, s.cs_ws, stream));
+  CB_TRY(gdmae_rows_affine_relu_scatter(a->y, a->bf16, nullptr, a->n_out, a->cout, a->ab, a->ab + a->cout, a->out, a->bf16, a->cout, 0,
+                                        stream));
+  return 0;
+}
+
+extern "C" int gdmae_conv_block_bwd(const gdmae_conv_block_args* a, void* stream) {
+  GD_REQUIRE(a->cin % 8 == 0 && a->cout % 8 == 0 && a->cout <= 256, "conv block: channels must be multiples of 8, cout <= 256");
+  if (a->n_out <= 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const int es = a->bf16 ? 2 : 4;
+  Scratch s = layout(a->scratch, a->n_in, a->n_out, a->cin, a->cout, es);
+  const int C = a->cout;
+  // ---- BatchNorm1d + ReLU backward on the rows of y
+  CB_TRY(gdmae_rows_bwd_stats(a->y, a->bf16, nullptr, a->n_out, C, a->ab, a->ab + C, a->g, a->g_f32 ? 0 : a->bf16, C, 0, (double*)s.st,
+                              s.rs_ws, stream));
+  CB_TRY(gdmae_bn_bwd_coeffs((const double*)s.st, 3, a->stats, a->ab, a->gamma, C, (double)a->n_out, nullptr, a->dgamma, a->dbeta, 1,
+                             (float*)s.c01, stream));
+  CB_TRY(gdmae_rows_bwd(a->y, a->bf16, nullptr, a->n_out, C, a->ab, a->ab + C, (const float*)s.c01, (const float*)s.c01 + C, a->g,
+                        a->g_f32 ? 0 : a->bf16, C, 0, s.dy, a->bf16, stream));
+  // ---- weight gradient: dW (cout, 9 cin) += dy^T cols
+  CB_TRY(gdmae_gemm_tn_splitk(s.dy, a->cols, a->dW, a->n_out, C, 9 * a->cin, a->bf16, 1, s.sk_ws, stream));
+  // ---- input gradient: dx (n_in, cin) = gather(dy, nbr_t) (n_in, 9 cout) @ Wt (9 cout, cin)
+  if (a->dx) {
+    CB_TRY(gdmae_gather_rows(s.dy, a->nbr_t, a->n_in * 9, C * es, s.gcols, stream));
+    const int total = C * 9 * a->cin;
+    if (a->bf16) hipLaunchKernelGGL((k_permute_w<unsigned short>), dim3((total + 255) / 256), dim3(256), 0, st, (const unsigned short*)a->W, C, a->cin, (unsigned short*)s.wt);
+    else hipLaunchKernelGGL((k_permute_w<float>), dim3((total + 255) / 256), dim3(256), 0, st, (const float*)a->W, C, a->cin, (float*)s.wt);
+    GD_LAUNCH_CHECK();
+    CB_TRY(gdmae_gemm(s.gcols, s.wt, a->dx, a->n_in, a->cin, 9ll * C, 0, 0, a->bf16, 0, nullptr, s.gemm_ws, stream));
+  }
+  return 0;
+}

@@ -68,6 +68,9 @@ SIGNATURES = {
     "gdmae_gemm": (_I, [_P, _P, _P, _L, _L, _L, _I, _I, _I, _I, _P, _P, _P]),
     "gdmae_gemm_tn_splitk_workspace_bytes": (_Z, [_L, _I, _I]),
     "gdmae_gemm_tn_splitk": (_I, [_P, _P, _P, _L, _I, _I, _I, _I, _P, _P]),
+    "gdmae_conv_block_scratch_bytes": (_Z, [_L, _L, _I, _I, _I]),
+    "gdmae_conv_block_fwd": (_I, [_P, _P]),
+    "gdmae_conv_block_bwd": (_I, [_P, _P]),
     "gdmae_encoder_layer_bytes": (_I, [_L, _I, _I, _I, _I, _P, _P, _P]),
     "gdmae_encoder_layer_fwd": (_I, [_P, _P]),
     "gdmae_encoder_layer_bwd": (_I, [_P, _P]),
@@ -91,6 +94,14 @@ class LayerArgs(C.Structure):
                 + [(k, _P) for k in ("tok_pos", "csr_tok", "win_start", "win_len", "pos_table", "Win", "bin", "Wo", "bo", "W1", "b1",
                                      "W2", "b2", "g1", "be1", "g2", "be2", "tau", "x", "y", "dy", "dx", "dWin", "dbin", "dtau", "dWo",
                                      "dbo", "dW1", "db1", "dW2", "db2", "dg1", "dbe1", "dg2", "dbe2", "saved", "scratch")])
+
+
+class ConvBlockArgs(C.Structure):
+    """ctypes mirror of ``gdmae_conv_block_args`` (include/gdmae_hip.h)."""
+    _fields_ = ([("n_in", _L), ("n_out", _L), ("cin", _I), ("cout", _I), ("bf16", _I), ("x_f32", _I), ("g_f32", _I),
+                 ("eps", _F), ("momentum", _F)]
+                + [(k, _P) for k in ("x", "nbr", "nbr_t", "W", "gamma", "beta", "running_mean", "running_var", "num_batches", "cols",
+                                     "y", "stats", "ab", "mv", "out", "g", "dx", "dW", "dgamma", "dbeta", "scratch")])
 
 
 _lib = None

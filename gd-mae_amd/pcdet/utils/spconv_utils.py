@@ -11,6 +11,7 @@ Weights use the spconv-2.x layout ``(Cout, kH, kW, Cin)`` so reference checkpoin
 from __future__ import annotations
 
 import math
+import os
 import types
 from typing import Set
 
@@ -66,15 +67,20 @@ class SparseConvolution(SparseModule):
         self.weight = nn.Parameter(torch.empty(out_channels, 3, 3, in_channels))
         nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
 
-    def forward(self, x: SparseConvTensor) -> SparseConvTensor:
+    def rulebooks(self, x: SparseConvTensor):
+        """(nbr, nbr_t, output stage index) of this convolution on ``x``'s active set."""
         if self.subm:
-            nbr = x.stage_plan.nbr_subm
-            # transposed rulebook of a submanifold conv = tap-reversed rulebook
-            f = ops.SparseConv3x3.apply(x.features, self.weight, nbr, torch.flip(nbr, dims=[1]).contiguous())
-            return x.replace_feature(f)
+            sp = x.stage_plan
+            if getattr(sp, "_nbr_subm_t", None) is None:      # transposed rulebook of a submanifold conv = tap-reversed rulebook
+                sp._nbr_subm_t = torch.flip(sp.nbr_subm, dims=[1]).contiguous()
+            return sp.nbr_subm, sp._nbr_subm_t, x._stage
         nxt = x._plan.stages[x._stage + 1]
-        f = ops.SparseConv3x3.apply(x.features, self.weight, nxt.nbr_down, nxt.nbr_down_t)
-        return SparseConvTensor(f, x._plan, x._stage + 1)
+        return nxt.nbr_down, nxt.nbr_down_t, x._stage + 1
+
+    def forward(self, x: SparseConvTensor) -> SparseConvTensor:
+        nbr, nbr_t, stage = self.rulebooks(x)
+        f = ops.SparseConv3x3.apply(x.features, self.weight, nbr, nbr_t)
+        return x.replace_feature(f) if stage == x._stage else SparseConvTensor(f, x._plan, stage)
 
 
 class SubMConv2d(SparseConvolution):
@@ -89,6 +95,7 @@ class SparseConv2d(SparseConvolution):
 
 class SparseSequential(SparseModule):
     fused_bn_relu = True     # conv -> BatchNorm1d(train) -> ReLU as one statistics pass + one fused row pass
+    native_block = os.environ.get("GDMAE_CONV_BLOCK", "1") != "0"   # whole block as one native call when a flat optimizer owns it
 
     def __init__(self, *mods):
         super().__init__()
@@ -99,9 +106,14 @@ class SparseSequential(SparseModule):
         mods = list(self._modules.values())
         if (self.fused_bn_relu and self.training and len(mods) == 3 and isinstance(mods[1], nn.BatchNorm1d)
                 and isinstance(mods[2], nn.ReLU) and mods[1].affine):
-            from gdmae_hip import vfe as gvfe
-            x = mods[0](x)
-            bn = mods[1]
+            from gdmae_hip import convblock, vfe as gvfe
+            conv, bn = mods[0], mods[1]
+            if self.native_block and isinstance(conv, SparseConvolution):
+                nbr, nbr_t, stage = conv.rulebooks(x)
+                f = convblock.conv_bn_relu(x.features, conv, bn, nbr, nbr_t)     # one native call per direction
+                if f is not None:
+                    return x.replace_feature(f) if stage == x._stage else SparseConvTensor(f, x._plan, stage)
+            x = conv(x)
             f, _, _ = gvfe.BNReLURows.apply(x.features, bn.weight, bn.bias, bn.eps, bn)
             return x.replace_feature(f)
         for m in mods:

@@ -252,6 +252,39 @@ size_t gdmae_gemm_tn_splitk_workspace_bytes(long long K, int m, int n);
 int gdmae_gemm_tn_splitk(const void* A, const void* B, float* C, long long K, int m, int n, int ab_bf16, int accumulate,
                          void* workspace, void* stream);
 
+/* ---- a6 as one call: sparse conv (k3) -> BatchNorm1d(train) -> ReLU block -------------------------- *
+ * post_act_block (spconv_utils.py:37-56; conv_down / conv_out of SSTBlockV1, spt_backbone.py:206,217,256-263).
+ * x (n_in, cin) rows in the compute dtype (bf16 != 0: bf16, else fp32) or fp32 with x_f32 (cast folded into the
+ * gather); nbr (n_out, 9) / nbr_t (n_in, 9): rulebook and transposed rulebook (gdmae_rulebook); W (cout, 9*cin) in the
+ * compute dtype (spconv-2.x layout (cout, 3, 3, cin)).  cols / y / stats / ab / mv are written by the forward and read
+ * by the backward.  g: upstream gradient (n_out, cout), compute dtype or fp32 (g_f32).  dW / dgamma / dbeta are
+ * ACCUMULATED; dx may be NULL.  running_* may be NULL (no running-statistics update). */
+typedef struct gdmae_conv_block_args {
+  long long n_in, n_out;
+  int cin, cout, bf16, x_f32, g_f32;
+  float eps, momentum;
+  const void* x;
+  const int* nbr;
+  const int* nbr_t;
+  const void* W;
+  const float *gamma, *beta;
+  float *running_mean, *running_var;
+  long long* num_batches;
+  void* cols;      /* (n_out, 9*cin) compute dtype */
+  void* y;         /* (n_out, cout) conv output before BatchNorm */
+  double* stats;   /* [2*cout] mean | rstd */
+  float* ab;       /* [2*cout] folded affine */
+  float* mv;       /* [2*cout] mean | biased var */
+  void* out;       /* (n_out, cout) compute dtype                  [forward]  */
+  const void* g;   /*                                              [backward] */
+  void* dx;        /* (n_in, cin) compute dtype                    [backward] */
+  float *dW, *dgamma, *dbeta;
+  void* scratch;   /* gdmae_conv_block_scratch_bytes */
+} gdmae_conv_block_args;
+size_t gdmae_conv_block_scratch_bytes(long long n_in, long long n_out, int cin, int cout, int bf16);
+int gdmae_conv_block_fwd(const gdmae_conv_block_args* args /* host */, void* stream);
+int gdmae_conv_block_bwd(const gdmae_conv_block_args* args /* host */, void* stream);
+
 /* ---- a13/a14 as one call: native executor of a whole encoder layer ------------------------------ *
  * EncoderLayer.forward (sst_basic_block.py:77-84; WindowAttention :22-54; cosine_msa.py): q = k = x + pos, v = x,
  * in-projection, windowed cosine attention, out-projection, LN(x + attn), FFN(GELU erf), LN(x + ffn) - forward or

@@ -755,3 +755,36 @@ def test_finetune_backbone_vs_reference_golden():
     rel = np.abs(gn - z["grad_norm"]) / (z["grad_norm"] + 1e-12)
     tol = np.array([2.5e-1 if k.endswith("tau") else 2e-2 for k in names])
     assert (rel <= tol).all(), [(names[i], rel[i]) for i in np.flatnonzero(rel > tol)]
+
+
+def test_native_conv_block_equals_op_by_op_block():
+    """gdmae_conv_block_fwd/bwd (sparse conv + BatchNorm1d + ReLU as one call per direction) vs the op-by-op path
+    (ops.SparseConv3x3 + vfe.BNReLURows) in the bench configuration: same arithmetic, same kernels."""
+    import logging
+    from gdmae_hip import configs, optim
+    from pcdet.models import build_network
+    from pcdet.utils.spconv_utils import SparseSequential
+    z, ds, cfg, shapes = load_case("kitti_b2_m75")
+    res = {}
+    try:
+        for native in (True, False):
+            SparseSequential.native_block = native
+            torch.manual_seed(0)
+            net = build_network(cfg, len(ds.class_names), ds, logging.getLogger("t")).to(dev())
+            net.load_state_dict(orc.seeded_state_dict(shapes, seed=int(z["seed"])), strict=False)
+            net.train()
+            opt = optim.FlatAdamOneCycle(net, configs.optimization_cfg(8), total_steps=10)
+            opt.zero_grad()
+            bd = {"points": torch.from_numpy(z["points"]).to(dev()), "batch_size": int(z["batch_size"]),
+                  "mae_noise": torch.from_numpy(z["noise"]).to(dev())}
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                ret, _, _ = net(bd)
+            ret["loss"].backward()
+            rs = torch.cat([v.float().reshape(-1) for k, v in net.state_dict().items() if "running_" in k])
+            res[native] = (float(ret["loss"]), opt.flat_grad.clone(), rs)
+    finally:
+        SparseSequential.native_block = True
+    assert abs(res[True][0] - res[False][0]) <= 1e-6 * abs(res[False][0])
+    g1, g0 = res[True][1], res[False][1]
+    assert float((g1 - g0).norm()) <= 2e-3 * float(g0.norm()), float((g1 - g0).norm() / g0.norm())
+    assert torch.allclose(res[True][2], res[False][2], rtol=1e-5, atol=1e-7)
