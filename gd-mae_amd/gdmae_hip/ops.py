@@ -107,6 +107,19 @@ def mm(a: torch.Tensor, b: torch.Tensor, trans_b: bool = False, bias: torch.Tens
     return out
 
 
+def splitk_tn_acc(a: torch.Tensor, b: torch.Tensor, dst: torch.Tensor) -> bool:
+    """dst (m, n) fp32 += a^T @ b through gdmae_gemm_tn_splitk (accumulating reduce); False if the operands are not served by
+    the library path (caller falls back to ``dst += splitk_tn(a, b)``)."""
+    K, m = a.shape
+    n = b.shape[1]
+    if not (_gemm_ok(a, b) and m % 8 == 0 and n % 8 == 0 and K >= 1 and dst.is_contiguous() and dst.dtype == torch.float32
+            and dst.numel() == m * n):
+        return False
+    ws = _gemm_ws(a.device, L.load().gdmae_gemm_tn_splitk_workspace_bytes(K, m, n))
+    L.call("gdmae_gemm_tn_splitk", L.ptr(a), L.ptr(b), L.ptr(dst), K, m, n, int(a.dtype == torch.bfloat16), 1, L.ptr(ws), L.stream())
+    return True
+
+
 def splitk_tn(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     """a (K, m), b (K, n) -> a^T @ b (m, n) in fp32, with the long K (= tokens / points / sites) dimension
     split into slices.  Weight gradients of this model are (<=512 x <=2304) outputs with K = 20 k ... 1.4 M:
@@ -200,15 +213,25 @@ class LinearSplitK(torch.autograd.Function):
         ctx.save_for_backward(xc, wc)
         ctx.has_bias = bias is not None
         ctx.w_dtype = weight.dtype
+        # weight gradient accumulated straight into the flat optimizer buffer when the parameter is given as stored
+        ctx.direct_w = direct_grad(weight) if (not ctx.w_t and weight.is_contiguous()) else None
+        ctx.direct_b = direct_grad(bias) if bias is not None else None
         return y
 
     @staticmethod
     def backward(ctx, g):
         xc, wc = ctx.saved_tensors
         g = g.contiguous().to(xc.dtype)
-        dx = mm(g, wc, trans_b=ctx.w_t)
-        dw = splitk_tn(g, xc).to(ctx.w_dtype)
-        db = colsum_f32(g) if ctx.has_bias else None
+        dx = mm(g, wc, trans_b=ctx.w_t) if ctx.needs_input_grad[0] else None
+        dw = None
+        if not (ctx.direct_w is not None and splitk_tn_acc(g, xc, ctx.direct_w)):
+            dw = splitk_tn(g, xc).to(ctx.w_dtype)
+        db = None
+        if ctx.has_bias:
+            db = colsum_f32(g)
+            if ctx.direct_b is not None:
+                ctx.direct_b.add_(db)
+                db = None
         return dx, dw, db
 
 
