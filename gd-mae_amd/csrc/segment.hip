@@ -302,8 +302,10 @@ __global__ __launch_bounds__(256) void k_colstats_final(const float* __restrict_
   const int cl = threadIdx.x & 15, ps = threadIdx.x >> 4;   // 16 columns x 16 partial slices per workgroup
   const int c = blockIdx.x * 16 + cl;
   double acc = 0.0;
-  if (c < C2)
+  if (c < C2) {
+#pragma unroll 8
     for (int b = ps; b < nblk; b += 16) acc += (double)part[(long long)b * C2 + c];
+  }
   sh[ps][cl] = acc;
   __syncthreads();
   if (ps == 0 && c < C2) {
@@ -354,6 +356,7 @@ __global__ __launch_bounds__(256) void k_bn_fold_final(const float* __restrict__
   const int c = blockIdx.x * 16 + cl;
   double a1 = 0.0, a2 = 0.0;
   if (c < C)
+#pragma unroll 8
     for (int b = ps; b < nblk; b += 16) {
       a1 += (double)part[(long long)b * 2 * C + c];
       a2 += (double)part[(long long)b * 2 * C + C + c];
@@ -402,6 +405,22 @@ extern "C" int gdmae_bn_fold(const void* x, long long R, int C, int is_bf16, dou
   GD_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_bn_fold_final, dim3(gd_div_up(C, 16)), dim3(256), 0, st, (const float*)workspace, nblk, C, count, gamma,
                      beta, eps, momentum, running_mean, running_var, num_batches, stats, ab, mv);
+  GD_LAUNCH_CHECK();
+  return 0;
+}
+
+// the second halves of gdmae_bn_fold / gdmae_colstats for kernels that produce their own per-workgroup partials
+// (part[(nblk, 2, C)] resp. part[(nblk, C2)], fp32), e.g. vfe_fused.hip
+int gd_bn_fold_from_partials(hipStream_t st, const float* part, int nblk, int C, double count, const float* gamma,
+                             const float* beta, double eps, double momentum, float* running_mean, float* running_var,
+                             long long* num_batches, double* stats, float* ab, float* mv) {
+  hipLaunchKernelGGL(k_bn_fold_final, dim3(gd_div_up(C, 16)), dim3(256), 0, st, part, nblk, C, count, gamma, beta, eps, momentum,
+                     running_mean, running_var, num_batches, stats, ab, mv);
+  GD_LAUNCH_CHECK();
+  return 0;
+}
+int gd_partials_to_f64(hipStream_t st, const float* part, int nblk, int C2, double* out) {
+  hipLaunchKernelGGL(k_colstats_final, dim3(gd_div_up(C2, 16)), dim3(256), 0, st, part, nblk, C2, out);
   GD_LAUNCH_CHECK();
   return 0;
 }

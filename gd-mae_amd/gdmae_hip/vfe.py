@@ -15,6 +15,7 @@ import torch
 
 from . import bn as gbn
 from . import lib as L
+from . import ops
 
 
 def _bf(t):
@@ -89,3 +90,59 @@ class BNReLUSegmentMax(torch.autograd.Function):
         L.call("gdmae_segmax_bn_bwd", L.ptr(x), _bf(x), L.ptr(out), L.ptr(arg), L.ptr(g), L.ptr(inv), n, C, L.ptr(ab), L.ptr(c01),
                L.ptr(c01[C:]), L.ptr(dx), _bf(dx), L.stream())
         return dx, dgamma, dbeta, None, None, None, None, None
+
+
+class PointLayer1(torch.autograd.Function):
+    """relu(BatchNorm1d_train(decorate(points) W^T)) for the first DynVFE layer (64 channels, Linear without bias) as
+    gdmae_vfe_point_layer_fwd / _bwd: the decorated features and the (N, 64) pre-activation are recomputed from the
+    points in registers wherever they are needed (csrc/vfe_fused.hip), the only (N, 64) tensors are the output and its
+    gradient.  Returns (out [bf16 under autocast, else fp32], mean, biased var)."""
+
+    @staticmethod
+    def forward(ctx, vox, weight, gamma, beta, eps, bn=None):
+        dev = weight.device
+        C, D = weight.shape
+        assert weight.dtype == torch.float32 and weight.is_contiguous() and D == vox.n_cols + 5
+        odt = torch.bfloat16 if torch.is_autocast_enabled() else torch.float32
+        n = int(vox.N)
+        out = torch.empty(n, C, dtype=odt, device=dev)
+        stats = torch.empty(2 * C, dtype=torch.float64, device=dev)
+        ab = torch.empty(2 * C, dtype=torch.float32, device=dev)
+        mv = torch.empty(2 * C, dtype=torch.float32, device=dev)
+        ws = torch.empty(L.load().gdmae_vfe_point_layer_workspace_bytes(vox.n_cols), dtype=torch.uint8, device=dev)
+        rm = rv = nb = None
+        mom = 0.0
+        if bn is not None and bn.training and bn.running_mean is not None:
+            rm, rv, nb, mom = bn.running_mean, bn.running_var, bn.num_batches_tracked, float(bn.momentum)
+        geo = (L.ptr(vox.points), L.ptr(vox.point_coords), L.ptr(vox.inverse32), L.ptr(vox.pillar_mean), n, vox.n_cols,
+               L.host_f32(vox.lo), L.host_f32(vox.vs))
+        L.call("gdmae_vfe_point_layer_fwd", *geo, L.ptr(weight), C, L.ptr(gamma), L.ptr(beta), float(eps), mom,
+               L.ptr(rm) if rm is not None else None, L.ptr(rv) if rv is not None else None,
+               L.ptr(nb) if nb is not None else None, L.ptr(stats), L.ptr(ab), L.ptr(mv), L.ptr(out), _bf(out), L.ptr(ws),
+               L.stream())
+        ctx.vox, ctx.ws = vox, ws
+        ctx.save_for_backward(weight, gamma.detach(), stats, ab)
+        ctx.direct = (ops.direct_grad(weight), *gbn.direct_pair(gamma, beta))
+        mf, vf = mv[:C], mv[C:]
+        ctx.mark_non_differentiable(mf, vf)
+        return out, mf, vf
+
+    @staticmethod
+    def backward(ctx, g, _m, _v):
+        weight, gamma, stats, ab = ctx.saved_tensors
+        vox, C = ctx.vox, weight.shape[0]
+        g = g.contiguous()
+        assert g.dtype in (torch.float32, torch.bfloat16)
+        dw, dg, db = ctx.direct
+        acc = int(dw is not None and dg is not None and db is not None)
+        if not acc:
+            dw = torch.empty_like(weight)
+            dgb = torch.empty(2 * C, dtype=torch.float32, device=weight.device)
+            dg, db = dgb[:C], dgb[C:]
+        L.call("gdmae_vfe_point_layer_bwd", L.ptr(vox.points), L.ptr(vox.point_coords), L.ptr(vox.inverse32),
+               L.ptr(vox.pillar_mean), int(vox.N), vox.n_cols, L.host_f32(vox.lo), L.host_f32(vox.vs), L.ptr(weight), C,
+               L.ptr(gamma), L.ptr(stats), L.ptr(ab), L.ptr(g), _bf(g), L.ptr(dg), L.ptr(db), L.ptr(dw), acc, L.ptr(ctx.ws),
+               L.stream())
+        if acc:
+            return None, None, None, None, None, None
+        return None, dw, dg, db, None, None

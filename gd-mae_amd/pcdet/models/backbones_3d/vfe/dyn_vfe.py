@@ -4,6 +4,7 @@ pcdet/models/backbones_3d/vfe/dyn_vfe.py:11-124; parameters ``dvfe_mlps.0.{0,1,3
 forward: one ``gdmae_voxelize`` call (range filter, pillar table, canonical point CSR, per-pillar mean),
 one decoration kernel, the two Linear/BN/ReLU layers as token GEMMs, and a segmented max over the CSR.
 """
+import os
 from functools import partial
 
 import torch
@@ -16,6 +17,7 @@ from gdmae_hip import ops, plan as gplan, vfe as gvfe
 
 class DynVFE(VFETemplate):
     fused = True      # fused BN+ReLU(+max) row kernels; False = torch BatchNorm1d / ReLU modules + segment max
+    point_layer = os.environ.get("GDMAE_VFE_POINT_LAYER", "1") != "0"    # first layer as gdmae_vfe_point_layer_*
 
     def __init__(self, model_cfg, num_point_features, voxel_size, point_cloud_range, grid_size, **kwargs):
         super().__init__(model_cfg=model_cfg)
@@ -40,12 +42,18 @@ class DynVFE(VFETemplate):
         if vox is None:
             vox = gplan.voxelize(batch_dict['points'], self.point_cloud_range, self.voxel_size, self.grid_size,
                                  int(batch_dict['batch_size']))
-        x = ops.decorate_points(vox)
         mlp = self.dvfe_mlps[0]
         if self.fused and self.training:
             nl = len(mlp) // 3
+            # first layer: decoration + Linear + BatchNorm + ReLU in one call, nothing but its output stored
+            first = (self.point_layer and nl > 1 and mlp[0].bias is None and mlp[0].out_features == 64
+                     and 3 <= vox.n_cols - 1 <= 5 and vox.N > 0)
+            x = None if first else ops.decorate_points(vox)
             for k in range(nl):
                 lin, bn = mlp[3 * k], mlp[3 * k + 1]
+                if k == 0 and first:
+                    x, _, _ = gvfe.PointLayer1.apply(vox, lin.weight, bn.weight, bn.bias, bn.eps, bn)
+                    continue
                 x = ops.linear(x, lin.weight, lin.bias)
                 if k < nl - 1:
                     x, _, _ = gvfe.BNReLURows.apply(x, bn.weight, bn.bias, bn.eps, bn)
@@ -53,6 +61,7 @@ class DynVFE(VFETemplate):
                     x, _, _ = gvfe.BNReLUSegmentMax.apply(x, bn.weight, bn.bias, bn.eps, vox.pt_off, vox.pillar_pts,
                                                           vox.inverse32, bn)
         else:
+            x = ops.decorate_points(vox)
             for m in mlp:                                # Linear(no bias) -> BN1d -> ReLU, twice
                 x = ops.linear(x, m.weight, m.bias) if isinstance(m, nn.Linear) else m(x)
             x = ops.SegmentMax.apply(x.float(), vox.pt_off, vox.pillar_pts, vox.inverse32)

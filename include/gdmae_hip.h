@@ -69,6 +69,22 @@ int gdmae_voxelize(const float* points, long long n_points, int n_cols, const fl
 int gdmae_decorate_points(const float* points, const long long* point_coords, const int* inverse32,
                           const float* pillar_mean, long long N, int n_cols, const float* lo, const float* vs,
                           float* out, void* stream);
+/* First DynVFE point layer as one call per direction (dyn_vfe.py:74-109 + network_utils.py:7-21: decoration,
+ * Linear(6+F -> 64, no bias), BatchNorm1d(train), ReLU).  The (N, 64) pre-activation is never stored: it is
+ * recomputed from the points in MFMA accumulators for the statistics, the output, the backward statistics and the
+ * weight gradient.  W (64, 6+F) fp32; out / g (N, 64) bf16 or fp32; stats / ab / mv as gdmae_bn_fold;
+ * dgamma / dbeta / dW written, or accumulated into when `accumulate`. */
+size_t gdmae_vfe_point_layer_workspace_bytes(int n_cols);
+int gdmae_vfe_point_layer_fwd(const float* points, const long long* point_coords, const int* inverse32,
+                              const float* pillar_mean, long long N, int n_cols, const float* lo, const float* vs,
+                              const float* W, int C, const float* gamma, const float* beta, double eps, double momentum,
+                              float* running_mean, float* running_var, long long* num_batches, double* stats, float* ab,
+                              float* mv, void* out, int out_bf16, void* workspace, void* stream);
+int gdmae_vfe_point_layer_bwd(const float* points, const long long* point_coords, const int* inverse32,
+                              const float* pillar_mean, long long N, int n_cols, const float* lo, const float* vs,
+                              const float* W, int C, const float* gamma, const double* stats, const float* ab,
+                              const void* g, int g_bf16, float* dgamma, float* dbeta, float* dW, int accumulate,
+                              void* workspace, void* stream);
 int gdmae_segment_max(const float* x, const int* pillar_pt_off, const int* pillar_pts, int M, int C, float* out,
                       int* arg, void* stream);
 int gdmae_segment_max_bwd(const float* dout, const int* arg, const int* inverse32, long long N, int C, float* dx,

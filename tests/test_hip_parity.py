@@ -788,3 +788,59 @@ def test_native_conv_block_equals_op_by_op_block():
     g1, g0 = res[True][1], res[False][1]
     assert float((g1 - g0).norm()) <= 2e-3 * float(g0.norm()), float((g1 - g0).norm() / g0.norm())
     assert torch.allclose(res[True][2], res[False][2], rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("autocast", [False, True])
+@pytest.mark.parametrize("name", ["kitti_b2", "waymo_b1"])
+def test_vfe_point_layer_equals_op_by_op_layer(name, autocast):
+    """gdmae_vfe_point_layer_fwd/bwd (decoration + Linear + BatchNorm1d + ReLU with the pre-activation recomputed in
+    MFMA accumulators) vs the op-by-op first DynVFE layer (decorate kernel, hipBLASLt GEMM, fold + row kernels):
+    pillar features, every VFE parameter gradient and the running statistics.
+    fp32: 1e-4 relative (summation order).  bf16 mode: the op-by-op path rounds the decorated features (absolute
+    coordinates of up to 75 m) and the pre-activation to bf16, the fused one keeps both in fp32 - so the check is
+    that the fused result is at least as close to the fp32 result as the op-by-op bf16 result is."""
+    import logging
+    from pcdet.models import build_network
+    from pcdet.models.backbones_3d.vfe.dyn_vfe import DynVFE
+    z, ds, cfg, shapes = load_case(name)
+
+    def run(fused, ac):
+        DynVFE.point_layer = fused
+        torch.manual_seed(0)
+        net = build_network(cfg, len(ds.class_names), ds, logging.getLogger("t")).to(dev())
+        net.load_state_dict(orc.seeded_state_dict(shapes, seed=int(z["seed"])), strict=False)
+        net.train()
+        vfe = net.vfe
+        bd = {"points": torch.from_numpy(z["points"]).to(dev()), "batch_size": int(z["batch_size"])}
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=ac):
+            out = vfe(bd)["pillar_features"]
+        gen = torch.Generator(device="cpu").manual_seed(1)
+        up = torch.randn(out.shape, generator=gen).to(dev())
+        (out.float() * up).sum().backward()
+        res = {"out": out.detach().float().clone()}
+        res.update({k: p.grad.detach().float().clone() for k, p in vfe.named_parameters()})
+        rs = {k: v.detach().float().clone() for k, v in vfe.state_dict().items() if "running_" in k or "num_batches" in k}
+        return res, rs
+
+    def rel(a, b):
+        return float((a - b).norm()) / float(b.norm())
+
+    try:
+        fused, fused_rs = run(True, autocast)
+        plain, plain_rs = run(False, autocast)
+        exact, exact_rs = run(False, False) if autocast else (plain, plain_rs)
+    finally:
+        DynVFE.point_layer = True
+    assert set(fused) == set(plain) and len(fused) == 7
+    for k in plain:
+        assert fused[k].shape == plain[k].shape and torch.isfinite(fused[k]).all() and float(plain[k].norm()) > 0, k
+        if autocast:
+            assert rel(fused[k], exact[k]) <= 1.25 * rel(plain[k], exact[k]) + 1e-3, (k, rel(fused[k], exact[k]),
+                                                                                      rel(plain[k], exact[k]))
+        else:
+            assert rel(fused[k], plain[k]) <= 1e-4, (k, rel(fused[k], plain[k]))
+    for k, r0 in plain_rs.items():
+        if autocast:
+            assert rel(fused_rs[k], exact_rs[k]) <= 1.25 * rel(r0, exact_rs[k]) + 1e-5, k
+        else:
+            assert torch.allclose(fused_rs[k], r0, rtol=1e-5, atol=1e-6), k
