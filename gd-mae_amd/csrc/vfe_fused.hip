@@ -43,16 +43,19 @@ __device__ inline unsigned short vf_f2bf(float f) {   // round to nearest even (
 }
 
 // decorated features of point i (all zero past the end): the arithmetic of k_decorate (segment.hip), kept in registers
+// `cpp` (coords per pillar): `coords` holds one row per PILLAR (voxel_coords) instead of one per point - the layout of
+// the pillar-major rows (gdmae_pillar_major_rows), where the per-point coordinate table is not needed
 template <int F>
 __device__ inline void vf_features(const float* __restrict__ pts, const long long* __restrict__ coords,
-                                   const int* __restrict__ inv, const float* __restrict__ mean, long long i, long long N,
-                                   const VfeGeom& G, float (&f)[F + 6]) {
+                                   const int* __restrict__ inv, const float* __restrict__ mean, int cpp, long long i,
+                                   long long N, const VfeGeom& G, float (&f)[F + 6]) {
   // branch-free (clamped index, zeroed afterwards): the loads of a tile are issued back to back
   const bool live = i < N;
   if (!live) i = N - 1;
   const float* r = pts + i * (F + 1);
-  const long long* c = coords + 4 * i;   // b, z, y, x
-  const float* m = mean + (long long)inv[i] * F;
+  const int pil = inv[i];
+  const long long* c = coords + 4 * (cpp ? (long long)pil : i);   // b, z, y, x
+  const float* m = mean + (long long)pil * F;
   const float x = r[1], y = r[2], z = r[3];
   f[0] = __fsub_rn(x, __fadd_rn(__fmul_rn(__fadd_rn((float)c[3], 0.5f), G.vs[0]), G.lo[0]));
   f[1] = __fsub_rn(y, __fadd_rn(__fmul_rn(__fadd_rn((float)c[2], 0.5f), G.vs[1]), G.lo[1]));
@@ -73,7 +76,7 @@ __device__ inline void vf_features(const float* __restrict__ pts, const long lon
 template <int F, int MODE, bool BF>
 __global__ __launch_bounds__(VF_WAVES * 64) void k_vfe1(const float* __restrict__ pts, const long long* __restrict__ coords,
                                                         const int* __restrict__ inv, const float* __restrict__ mean,
-                                                        long long N, VfeGeom G, const float* __restrict__ W,
+                                                        int cpp, long long N, VfeGeom G, const float* __restrict__ W,
                                                         const float* __restrict__ ab, const float* __restrict__ c01,
                                                         const void* __restrict__ g, void* __restrict__ out,
                                                         float* __restrict__ part) {
@@ -133,7 +136,7 @@ __global__ __launch_bounds__(VF_WAVES * 64) void k_vfe1(const float* __restrict_
       }
     }
     float f[D];
-    vf_features<F>(pts, coords, inv, mean, base + n, N, G, f);
+    vf_features<F>(pts, coords, inv, mean, cpp, base + n, N, G, f);
     f32x16 h[2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) h[0][r] = h[1][r] = 0.f;
@@ -262,7 +265,7 @@ int vf_resident_blocks(K kernel, int slot) {
 // *grid_out: the number of workgroups launched = the number of partial rows written
 template <int MODE>
 int vf_launch(hipStream_t st, int F, bool bf, const float* pts, const long long* coords, const int* inv, const float* mean,
-              long long N, const VfeGeom& G, const float* W, const float* ab, const float* c01, const void* g, void* out,
+              int cpp, long long N, const VfeGeom& G, const float* W, const float* ab, const float* c01, const void* g, void* out,
               float* part, int* grid_out = nullptr) {
   const long long tiles = (N + 31) / 32, blocks = (tiles + VF_WAVES - 1) / VF_WAVES;
   const dim3 block(VF_WAVES * 64);
@@ -271,7 +274,7 @@ int vf_launch(hipStream_t st, int F, bool bf, const float* pts, const long long*
     const int cap = vf_resident_blocks(k_vfe1<FF, MODE, BB>, ((FF - 3) * 4 + MODE) * 2 + (BB ? 1 : 0));                 \
     const dim3 grid((unsigned)(blocks < cap ? blocks : cap));                                                           \
     if (grid_out) *grid_out = (int)grid.x;                                                                              \
-    hipLaunchKernelGGL((k_vfe1<FF, MODE, BB>), grid, block, 0, st, pts, coords, inv, mean, N, G, W, ab, c01, g, out, part); \
+    hipLaunchKernelGGL((k_vfe1<FF, MODE, BB>), grid, block, 0, st, pts, coords, inv, mean, cpp, N, G, W, ab, c01, g, out, part); \
   } while (0)
   if (F == 5) { if (bf) VF_GO(5, true); else VF_GO(5, false); }
   else if (F == 4) { if (bf) VF_GO(4, true); else VF_GO(4, false); }
@@ -284,6 +287,29 @@ int vf_launch(hipStream_t st, int F, bool bf, const float* pts, const long long*
 
 }  // namespace
 
+// rows of the kept points in pillar-major (CSR) order: points_pm[q] = points[pillar_pts[q]], row_pillar[q] = its pillar.
+// n_dev: the device-side point count (gdmae_voxelize counts[0]) - the buffers are capacity-sized, no host sync needed.
+__global__ __launch_bounds__(256) void k_pillar_major_rows(const float* __restrict__ pts, int ncols, const int* __restrict__ csr,
+                                                           const int* __restrict__ inv, const int* __restrict__ n_dev,
+                                                           float* __restrict__ pts_pm, int* __restrict__ rowpil) {
+  const long long N = *n_dev;
+  for (long long q = blockIdx.x * (long long)blockDim.x + threadIdx.x; q < N; q += (long long)gridDim.x * blockDim.x) {
+    const int i = csr[q];
+    rowpil[q] = inv[i];
+    for (int k = 0; k < ncols; ++k) pts_pm[q * ncols + k] = pts[(long long)i * ncols + k];
+  }
+}
+
+extern "C" int gdmae_pillar_major_rows(const float* points, int n_cols, const int* pillar_pts, const int* inverse32,
+                                       const int* n_dev, long long capacity, float* points_pm, int* row_pillar,
+                                       void* stream) {
+  if (capacity <= 0) return 0;
+  hipLaunchKernelGGL(k_pillar_major_rows, dim3((unsigned)(capacity / 256 + 1 > 8192 ? 8192 : capacity / 256 + 1)), dim3(256), 0, (hipStream_t)stream, points, n_cols,
+                     pillar_pts, inverse32, n_dev, points_pm, row_pillar);
+  GD_LAUNCH_CHECK();
+  return 0;
+}
+
 // workspace: per-workgroup partials (the larger of the statistics and the dW partials) + f64 column sums + c0|c1
 extern "C" size_t gdmae_vfe_point_layer_workspace_bytes(int n_cols) {
   const int D = n_cols - 1 + 6;
@@ -291,10 +317,13 @@ extern "C" size_t gdmae_vfe_point_layer_workspace_bytes(int n_cols) {
          gd_align(2 * VF_C * sizeof(float));
 }
 
-// y (N, 64) = relu(BatchNorm1d_train(decorate(points) W^T)); also the BatchNorm bookkeeping of gdmae_bn_fold
+// y (N, 64) = relu(BatchNorm1d_train(decorate(points) W^T)), row i of y is row i of `points`.  coords_per_pillar: the rows
+// are the pillar-major ones of gdmae_pillar_major_rows - `points` = points_pm, `inverse32` = row_pillar and `point_coords`
+// = the (M, 4) voxel_coords table, read through the pillar id.  Also the BatchNorm bookkeeping
 // (stats f64[128] = mean | rstd, ab f32[128] = a | b, mv f32[128] = mean | biased var, running statistics update).
 extern "C" int gdmae_vfe_point_layer_fwd(const float* points, const long long* point_coords, const int* inverse32,
-                                         const float* pillar_mean, long long N, int n_cols, const float* lo, const float* vs,
+                                         const float* pillar_mean, int coords_per_pillar, long long N, int n_cols,
+                                         const float* lo, const float* vs,
                                          const float* W, int C, const float* gamma, const float* beta, double eps,
                                          double momentum, float* running_mean, float* running_var, long long* num_batches,
                                          double* stats, float* ab, float* mv, void* out, int out_bf16, void* workspace,
@@ -307,19 +336,20 @@ extern "C" int gdmae_vfe_point_layer_fwd(const float* points, const long long* p
   float* part = (float*)workspace;
   const int F = n_cols - 1;
   int grid = 0;
-  int rc = vf_launch<VF_STATS>(st, F, false, points, point_coords, inverse32, pillar_mean, N, G, W, nullptr, nullptr, nullptr,
+  int rc = vf_launch<VF_STATS>(st, F, false, points, point_coords, inverse32, pillar_mean, coords_per_pillar, N, G, W, nullptr, nullptr, nullptr,
                                nullptr, part, &grid);
   if (rc) return rc;
   rc = gd_bn_fold_from_partials(st, part, grid, C, (double)N, gamma, beta, eps, momentum, running_mean, running_var,
                                 num_batches, stats, ab, mv);
   if (rc) return rc;
-  return vf_launch<VF_APPLY>(st, F, out_bf16 != 0, points, point_coords, inverse32, pillar_mean, N, G, W, ab, nullptr, nullptr,
+  return vf_launch<VF_APPLY>(st, F, out_bf16 != 0, points, point_coords, inverse32, pillar_mean, coords_per_pillar, N, G, W, ab, nullptr, nullptr,
                              out, nullptr);
 }
 
 // g (N, 64): gradient of y.  dgamma / dbeta / dW (64, 6 + F) are written, or accumulated into when `accumulate`.
 extern "C" int gdmae_vfe_point_layer_bwd(const float* points, const long long* point_coords, const int* inverse32,
-                                         const float* pillar_mean, long long N, int n_cols, const float* lo, const float* vs,
+                                         const float* pillar_mean, int coords_per_pillar, long long N, int n_cols,
+                                         const float* lo, const float* vs,
                                          const float* W, int C, const float* gamma, const double* stats, const float* ab,
                                          const void* g, int g_bf16, float* dgamma, float* dbeta, float* dW, int accumulate,
                                          void* workspace, void* stream) {
@@ -336,14 +366,14 @@ extern "C" int gdmae_vfe_point_layer_bwd(const float* points, const long long* p
   p += gd_align(2 * VF_C * sizeof(double));
   float* c01 = (float*)p;
   int grid = 0;
-  int rc = vf_launch<VF_BSTATS>(st, F, g_bf16 != 0, points, point_coords, inverse32, pillar_mean, N, G, W, ab, nullptr, g,
+  int rc = vf_launch<VF_BSTATS>(st, F, g_bf16 != 0, points, point_coords, inverse32, pillar_mean, coords_per_pillar, N, G, W, ab, nullptr, g,
                                 nullptr, part, &grid);
   if (rc) return rc;
   rc = gd_partials_to_f64(st, part, grid, 2 * C, sums);
   if (rc) return rc;
   rc = gdmae_bn_bwd_coeffs(sums, 2, stats, ab, gamma, C, (double)N, nullptr, dgamma, dbeta, accumulate, c01, stream);
   if (rc) return rc;
-  rc = vf_launch<VF_DW>(st, F, g_bf16 != 0, points, point_coords, inverse32, pillar_mean, N, G, W, ab, c01, g, nullptr, part, &grid);
+  rc = vf_launch<VF_DW>(st, F, g_bf16 != 0, points, point_coords, inverse32, pillar_mean, coords_per_pillar, N, G, W, ab, c01, g, nullptr, part, &grid);
   if (rc) return rc;
   return gd_splitk_acc(st, part, grid, (long long)VF_C * D, dW, accumulate);
 }

@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.abspath(os.path.join(HERE, "..", "csrc"))
 LIB = os.path.join(CSRC, "libgdmae_hip.so")
 SOURCES = ["capi.hip", "voxelize.hip", "mask.hip", "partition.hip", "segment.hip", "attention.hip", "attention_mfma.hip", "attention_mfma16.hip", "layernorm.hip", "decoder.hip", "chamfer.hip",
-           "optim.hip", "input_pipeline.hip", "gemm.hip", "encoder_layer.hip", "conv_block.hip", "vfe_fused.hip"]
+           "optim.hip", "input_pipeline.hip", "gemm.hip", "encoder_layer.hip", "conv_block.hip", "vfe_fused.hip", "vfe_layer2.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-Wno-unused-result"]
 
@@ -24,7 +24,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 # every accumulator element with VALU right after the MFMA, and the AGPR form costs one v_accvgpr_read per element
 # (551 -> 177 of ~5000 instructions in the T = 64 backward)
 EXTRA_FLAGS = {"attention_mfma16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
-               "vfe_fused.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+               "vfe_fused.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
+               "vfe_layer2.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 def _newer(src, dst):

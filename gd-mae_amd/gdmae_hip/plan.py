@@ -45,6 +45,8 @@ class VoxelPlan:
     pillar_mean: torch.Tensor     # (M, F)
     cell2pillar: torch.Tensor     # (B*Z*Y*X,) int32
     counts: torch.Tensor          # device int32[2]
+    points_pm: torch.Tensor = None    # (N, 1+F) the kept points in pillar-major order: points[pillar_pts]
+    row_pillar: torch.Tensor = None   # (N,) int32 pillar of each pillar-major row: inverse32[pillar_pts]
 
 
 def _voxelize_launch(points: torch.Tensor, point_cloud_range, voxel_size, grid_size, batch_size: int) -> dict:
@@ -71,6 +73,11 @@ def _voxelize_launch(points: torch.Tensor, point_cloud_range, voxel_size, grid_s
            batch_size, L.ptr(r["pts_out"]), L.ptr(r["pcoords"]), L.ptr(r["inverse"]), L.ptr(r["inverse32"]), L.ptr(r["vcoords"]),
            L.ptr(r["pillar_cell"]), L.ptr(r["pt_off"]), L.ptr(r["pillar_pts"]), L.ptr(r["prank"]), L.ptr(r["sample_off"]),
            L.ptr(r["mean"]), L.ptr(r["cell2pillar"]), L.ptr(r["counts"]), L.ptr(r["ws"]), wsb, L.stream())
+    # pillar-major copy of the kept points (rows of a pillar contiguous) for the DynVFE point layers
+    r["pts_pm"] = _empty(cap * ncols, torch.float32, dev)
+    r["row_pillar"] = _empty(cap, I32, dev)
+    L.call("gdmae_pillar_major_rows", L.ptr(r["pts_out"]), ncols, L.ptr(r["pillar_pts"]), L.ptr(r["inverse32"]), L.ptr(r["counts"]),
+           cap, L.ptr(r["pts_pm"]), L.ptr(r["row_pillar"]), L.stream())
     return r
 
 
@@ -81,7 +88,7 @@ def _voxelize_finalize(r: dict, N: int, M: int) -> VoxelPlan:
                      r["pts_out"][:N * ncols].view(N, ncols), r["pcoords"][:N * 4].view(N, 4), r["inverse"][:N],
                      r["inverse32"][:N], r["vcoords"][:M * 4].view(M, 4), r["pillar_cell"][:M], r["pt_off"][:M + 1],
                      r["pillar_pts"][:N], r["prank"][:N], r["sample_off"], r["mean"][:M * F].view(M, F), r["cell2pillar"],
-                     r["counts"])
+                     r["counts"], r["pts_pm"][:N * ncols].view(N, ncols), r["row_pillar"][:N])
 
 
 def voxelize(points: torch.Tensor, point_cloud_range, voxel_size, grid_size, batch_size: int) -> VoxelPlan:

@@ -96,10 +96,12 @@ class PointLayer1(torch.autograd.Function):
     """relu(BatchNorm1d_train(decorate(points) W^T)) for the first DynVFE layer (64 channels, Linear without bias) as
     gdmae_vfe_point_layer_fwd / _bwd: the decorated features and the (N, 64) pre-activation are recomputed from the
     points in registers wherever they are needed (csrc/vfe_fused.hip), the only (N, 64) tensors are the output and its
-    gradient.  Returns (out [bf16 under autocast, else fp32], mean, biased var)."""
+    gradient.  ``pillar_major``: row q of the output is point ``vox.pillar_pts[q]`` (the rows of a pillar contiguous,
+    as PointLayer2Max wants them; inputs ``vox.points_pm`` / ``vox.row_pillar``) instead of point q.
+    Returns (out [bf16 under autocast, else fp32], mean, biased var)."""
 
     @staticmethod
-    def forward(ctx, vox, weight, gamma, beta, eps, bn=None):
+    def forward(ctx, vox, weight, gamma, beta, eps, bn=None, pillar_major=False):
         dev = weight.device
         C, D = weight.shape
         assert weight.dtype == torch.float32 and weight.is_contiguous() and D == vox.n_cols + 5
@@ -110,14 +112,13 @@ class PointLayer1(torch.autograd.Function):
         ab = torch.empty(2 * C, dtype=torch.float32, device=dev)
         mv = torch.empty(2 * C, dtype=torch.float32, device=dev)
         ws = torch.empty(L.load().gdmae_vfe_point_layer_workspace_bytes(vox.n_cols), dtype=torch.uint8, device=dev)
+        ctx.pm = bool(pillar_major)
         rm = rv = nb = None
         mom = 0.0
         if bn is not None and bn.training and bn.running_mean is not None:
             rm, rv, nb, mom = bn.running_mean, bn.running_var, bn.num_batches_tracked, float(bn.momentum)
-        geo = (L.ptr(vox.points), L.ptr(vox.point_coords), L.ptr(vox.inverse32), L.ptr(vox.pillar_mean), n, vox.n_cols,
-               L.host_f32(vox.lo), L.host_f32(vox.vs))
-        L.call("gdmae_vfe_point_layer_fwd", *geo, L.ptr(weight), C, L.ptr(gamma), L.ptr(beta), float(eps), mom,
-               L.ptr(rm) if rm is not None else None, L.ptr(rv) if rv is not None else None,
+        L.call("gdmae_vfe_point_layer_fwd", *PointLayer1._geometry(vox, ctx.pm), L.ptr(weight), C, L.ptr(gamma), L.ptr(beta),
+               float(eps), mom, L.ptr(rm) if rm is not None else None, L.ptr(rv) if rv is not None else None,
                L.ptr(nb) if nb is not None else None, L.ptr(stats), L.ptr(ab), L.ptr(mv), L.ptr(out), _bf(out), L.ptr(ws),
                L.stream())
         ctx.vox, ctx.ws = vox, ws
@@ -126,6 +127,16 @@ class PointLayer1(torch.autograd.Function):
         mf, vf = mv[:C], mv[C:]
         ctx.mark_non_differentiable(mf, vf)
         return out, mf, vf
+
+    @staticmethod
+    def _geometry(vox, pm):
+        """leading arguments of gdmae_vfe_point_layer_*: per-point tables, or the pillar-major rows of the plan"""
+        if pm:
+            assert vox.points_pm is not None and vox.row_pillar is not None
+            return (L.ptr(vox.points_pm), L.ptr(vox.voxel_coords), L.ptr(vox.row_pillar), L.ptr(vox.pillar_mean), 1,
+                    int(vox.N), vox.n_cols, L.host_f32(vox.lo), L.host_f32(vox.vs))
+        return (L.ptr(vox.points), L.ptr(vox.point_coords), L.ptr(vox.inverse32), L.ptr(vox.pillar_mean), 0, int(vox.N),
+                vox.n_cols, L.host_f32(vox.lo), L.host_f32(vox.vs))
 
     @staticmethod
     def backward(ctx, g, _m, _v):
@@ -139,10 +150,65 @@ class PointLayer1(torch.autograd.Function):
             dw = torch.empty_like(weight)
             dgb = torch.empty(2 * C, dtype=torch.float32, device=weight.device)
             dg, db = dgb[:C], dgb[C:]
-        L.call("gdmae_vfe_point_layer_bwd", L.ptr(vox.points), L.ptr(vox.point_coords), L.ptr(vox.inverse32),
-               L.ptr(vox.pillar_mean), int(vox.N), vox.n_cols, L.host_f32(vox.lo), L.host_f32(vox.vs), L.ptr(weight), C,
-               L.ptr(gamma), L.ptr(stats), L.ptr(ab), L.ptr(g), _bf(g), L.ptr(dg), L.ptr(db), L.ptr(dw), acc, L.ptr(ctx.ws),
-               L.stream())
+        L.call("gdmae_vfe_point_layer_bwd", *PointLayer1._geometry(vox, ctx.pm), L.ptr(weight), C, L.ptr(gamma), L.ptr(stats),
+               L.ptr(ab), L.ptr(g), _bf(g), L.ptr(dg), L.ptr(db), L.ptr(dw), acc, L.ptr(ctx.ws), L.stream())
         if acc:
-            return None, None, None, None, None, None
-        return None, dw, dg, db, None, None
+            return None, None, None, None, None, None, None
+        return None, dw, dg, db, None, None, None
+
+
+class PointLayer2Max(torch.autograd.Function):
+    """Per-pillar max of relu(BatchNorm1d_train(y1 W^T)) for the last DynVFE layer (64 -> 128, Linear without bias) in
+    the bf16 throughput mode, as gdmae_vfe_max_layer_fwd / _bwd (csrc/vfe_layer2.hip): the (N, 128) pre-activation is
+    recomputed from y1 in MFMA accumulators, never stored.  y1 (N, 64) bf16 with its rows in pillar-major order and
+    row_pillar (N,) int32 = ``vox.row_pillar`` (PointLayer1(pillar_major=True)).  Returns (out (M, 128) fp32, mean, var)."""
+
+    @staticmethod
+    def forward(ctx, y1, row_pillar, weight, gamma, beta, eps, pt_off, bn=None):
+        dev = y1.device
+        C, K = weight.shape
+        assert (C, K) == (128, 64) and y1.dtype == torch.bfloat16 and y1.is_contiguous() and y1.shape[1] == K
+        assert row_pillar.dtype == torch.int32 and row_pillar.numel() == y1.shape[0]
+        n, M = y1.shape[0], pt_off.numel() - 1
+        wb = ops.shadow(weight, torch.bfloat16).contiguous()
+        out = torch.empty(M, C, dtype=torch.float32, device=dev)
+        hmax = torch.empty(M, C, dtype=torch.float32, device=dev)
+        arg = torch.empty(M, C, dtype=torch.int32, device=dev)
+        stats = torch.empty(2 * C, dtype=torch.float64, device=dev)
+        ab = torch.empty(2 * C, dtype=torch.float32, device=dev)
+        mv = torch.empty(2 * C, dtype=torch.float32, device=dev)
+        ws = torch.empty(L.load().gdmae_vfe_max_layer_workspace_bytes(), dtype=torch.uint8, device=dev)
+        rm = rv = nb = None
+        mom = 0.0
+        if bn is not None and bn.training and bn.running_mean is not None:
+            rm, rv, nb, mom = bn.running_mean, bn.running_var, bn.num_batches_tracked, float(bn.momentum)
+        L.call("gdmae_vfe_max_layer_fwd", L.ptr(y1), n, L.ptr(wb), L.ptr(pt_off), L.ptr(row_pillar), M, L.ptr(gamma),
+               L.ptr(beta), float(eps), mom, L.ptr(rm) if rm is not None else None, L.ptr(rv) if rv is not None else None,
+               L.ptr(nb) if nb is not None else None, L.ptr(stats), L.ptr(ab), L.ptr(mv), L.ptr(out), L.ptr(arg), L.ptr(hmax),
+               L.ptr(ws), L.stream())
+        ctx.ws = ws
+        ctx.save_for_backward(y1, row_pillar, wb, gamma.detach(), stats, ab, out, arg, hmax)
+        ctx.direct = (ops.direct_grad(weight), *gbn.direct_pair(gamma, beta))
+        mf, vf = mv[:C], mv[C:]
+        ctx.mark_non_differentiable(mf, vf)
+        return out, mf, vf
+
+    @staticmethod
+    def backward(ctx, g, _m, _v):
+        y1, row_pillar, wb, gamma, stats, ab, out, arg, hmax = ctx.saved_tensors
+        n, (M, C) = y1.shape[0], out.shape
+        g = g.float().contiguous()
+        dw, dg, db = ctx.direct
+        acc = int(dw is not None and dg is not None and db is not None)
+        if not acc:
+            dw = torch.empty(C, y1.shape[1], dtype=torch.float32, device=y1.device)
+            dgb = torch.empty(2 * C, dtype=torch.float32, device=y1.device)
+            dg, db = dgb[:C], dgb[C:]
+        gm = torch.empty_like(out)
+        dy1 = torch.empty_like(y1)
+        L.call("gdmae_vfe_max_layer_bwd", L.ptr(y1), n, L.ptr(wb), L.ptr(row_pillar), M, L.ptr(gamma), L.ptr(stats), L.ptr(ab),
+               L.ptr(out), L.ptr(arg), L.ptr(hmax), L.ptr(g), L.ptr(gm), L.ptr(dy1), L.ptr(dg), L.ptr(db), L.ptr(dw), acc,
+               L.ptr(ctx.ws), L.stream())
+        if acc:
+            return dy1, None, None, None, None, None, None, None
+        return dy1, None, dw, dg, db, None, None, None

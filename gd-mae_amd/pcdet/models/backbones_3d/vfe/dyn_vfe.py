@@ -18,6 +18,7 @@ from gdmae_hip import ops, plan as gplan, vfe as gvfe
 class DynVFE(VFETemplate):
     fused = True      # fused BN+ReLU(+max) row kernels; False = torch BatchNorm1d / ReLU modules + segment max
     point_layer = os.environ.get("GDMAE_VFE_POINT_LAYER", "1") != "0"    # first layer as gdmae_vfe_point_layer_*
+    max_layer = os.environ.get("GDMAE_VFE_MAX_LAYER", "1") != "0"        # last layer as gdmae_vfe_max_layer_* (bf16 mode)
 
     def __init__(self, model_cfg, num_point_features, voxel_size, point_cloud_range, grid_size, **kwargs):
         super().__init__(model_cfg=model_cfg)
@@ -48,11 +49,18 @@ class DynVFE(VFETemplate):
             # first layer: decoration + Linear + BatchNorm + ReLU in one call, nothing but its output stored
             first = (self.point_layer and nl > 1 and mlp[0].bias is None and mlp[0].out_features == 64
                      and 3 <= vox.n_cols - 1 <= 5 and vox.N > 0)
+            # last layer (bf16 mode): Linear + BatchNorm + ReLU + pillar max with the pre-activation never stored; it wants
+            # the rows of the first layer in pillar-major order
+            last = (first and self.max_layer and nl == 2 and torch.is_autocast_enabled() and mlp[3].bias is None
+                    and tuple(mlp[3].weight.shape) == (128, 64) and vox.points_pm is not None)
             x = None if first else ops.decorate_points(vox)
             for k in range(nl):
                 lin, bn = mlp[3 * k], mlp[3 * k + 1]
                 if k == 0 and first:
-                    x, _, _ = gvfe.PointLayer1.apply(vox, lin.weight, bn.weight, bn.bias, bn.eps, bn)
+                    x, _, _ = gvfe.PointLayer1.apply(vox, lin.weight, bn.weight, bn.bias, bn.eps, bn, last)
+                    continue
+                if k == nl - 1 and last:
+                    x, _, _ = gvfe.PointLayer2Max.apply(x, vox.row_pillar, lin.weight, bn.weight, bn.bias, bn.eps, vox.pt_off, bn)
                     continue
                 x = ops.linear(x, lin.weight, lin.bias)
                 if k < nl - 1:

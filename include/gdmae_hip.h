@@ -73,18 +73,43 @@ int gdmae_decorate_points(const float* points, const long long* point_coords, co
  * Linear(6+F -> 64, no bias), BatchNorm1d(train), ReLU).  The (N, 64) pre-activation is never stored: it is
  * recomputed from the points in MFMA accumulators for the statistics, the output, the backward statistics and the
  * weight gradient.  W (64, 6+F) fp32; out / g (N, 64) bf16 or fp32; stats / ab / mv as gdmae_bn_fold;
- * dgamma / dbeta / dW written, or accumulated into when `accumulate`. */
+ * dgamma / dbeta / dW written, or accumulated into when `accumulate`.  Row i of out / g is row i of `points`.
+ * coords_per_pillar != 0: the rows are the pillar-major ones of gdmae_pillar_major_rows (rows of a pillar contiguous,
+ * as gdmae_vfe_max_layer_* wants them): points = points_pm, inverse32 = row_pillar, point_coords = the (M, 4)
+ * voxel_coords table read through the pillar id.
+ * gdmae_pillar_major_rows: points_pm[q] = points[pillar_pts[q]], row_pillar[q] = inverse32[pillar_pts[q]] for q < *n_dev
+ * (device-side count, e.g. gdmae_voxelize counts[0]; buffers sized for `capacity` rows). */
+int gdmae_pillar_major_rows(const float* points, int n_cols, const int* pillar_pts, const int* inverse32, const int* n_dev,
+                            long long capacity, float* points_pm, int* row_pillar, void* stream);
 size_t gdmae_vfe_point_layer_workspace_bytes(int n_cols);
 int gdmae_vfe_point_layer_fwd(const float* points, const long long* point_coords, const int* inverse32,
-                              const float* pillar_mean, long long N, int n_cols, const float* lo, const float* vs,
+                              const float* pillar_mean, int coords_per_pillar, long long N, int n_cols, const float* lo,
+                              const float* vs,
                               const float* W, int C, const float* gamma, const float* beta, double eps, double momentum,
                               float* running_mean, float* running_var, long long* num_batches, double* stats, float* ab,
                               float* mv, void* out, int out_bf16, void* workspace, void* stream);
 int gdmae_vfe_point_layer_bwd(const float* points, const long long* point_coords, const int* inverse32,
-                              const float* pillar_mean, long long N, int n_cols, const float* lo, const float* vs,
+                              const float* pillar_mean, int coords_per_pillar, long long N, int n_cols, const float* lo,
+                              const float* vs,
                               const float* W, int C, const float* gamma, const double* stats, const float* ab,
                               const void* g, int g_bf16, float* dgamma, float* dbeta, float* dW, int accumulate,
                               void* workspace, void* stream);
+/* Second DynVFE point layer + per-pillar maximum as one call per direction, bf16 throughput mode (dyn_vfe.py:107-112:
+ * Linear(64 -> 128, no bias), BatchNorm1d(train), ReLU, torch_scatter.scatter_max).  The (N, 128) pre-activation is
+ * recomputed from y1 in MFMA accumulators by every kernel.  y1 (N, 64) bf16 with rows in pillar-major order and
+ * row_pillar (N) from gdmae_pillar_major_rows + gdmae_vfe_point_layer_fwd(coords_per_pillar = 1); pillar_pt_off (M + 1) = first row of each
+ * pillar; W (128, 64) bf16; out (M, 128) fp32, arg = row of the maximum (first row on ties = lowest point id),
+ * hmax = pre-activation at that row; g = gradient of out; gm = scratch of
+ * M * 128 floats; dy1 (N, 64) bf16 written; dgamma / dbeta / dW (128, 64) fp32 written, or accumulated into. */
+size_t gdmae_vfe_max_layer_workspace_bytes(void);
+int gdmae_vfe_max_layer_fwd(const void* y1, long long N, const void* W, const int* pillar_pt_off, const int* row_pillar,
+                            int M, const float* gamma, const float* beta, double eps, double momentum,
+                            float* running_mean, float* running_var, long long* num_batches, double* stats, float* ab,
+                            float* mv, float* out, int* arg, float* hmax, void* workspace, void* stream);
+int gdmae_vfe_max_layer_bwd(const void* y1, long long N, const void* W, const int* row_pillar, int M, const float* gamma,
+                            const double* stats, const float* ab, const float* out, const int* arg, const float* hmax,
+                            const float* g, void* gm, void* dy1, float* dgamma, float* dbeta, float* dW, int accumulate,
+                            void* workspace, void* stream);
 int gdmae_segment_max(const float* x, const int* pillar_pt_off, const int* pillar_pts, int M, int C, float* out,
                       int* arg, void* stream);
 int gdmae_segment_max_bwd(const float* dout, const int* arg, const int* inverse32, long long N, int C, float* dx,

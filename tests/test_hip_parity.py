@@ -794,7 +794,8 @@ def test_native_conv_block_equals_op_by_op_block():
 @pytest.mark.parametrize("name", ["kitti_b2", "waymo_b1"])
 def test_vfe_point_layer_equals_op_by_op_layer(name, autocast):
     """gdmae_vfe_point_layer_fwd/bwd (decoration + Linear + BatchNorm1d + ReLU with the pre-activation recomputed in
-    MFMA accumulators) vs the op-by-op first DynVFE layer (decorate kernel, hipBLASLt GEMM, fold + row kernels):
+    MFMA accumulators) and, in bf16 mode, gdmae_vfe_max_layer_fwd/bwd (Linear + BatchNorm1d + ReLU + pillar max, same
+    idea) vs the op-by-op DynVFE layers (decorate kernel, hipBLASLt GEMM, fold + row kernels):
     pillar features, every VFE parameter gradient and the running statistics.
     fp32: 1e-4 relative (summation order).  bf16 mode: the op-by-op path rounds the decorated features (absolute
     coordinates of up to 75 m) and the pre-activation to bf16, the fused one keeps both in fp32 - so the check is
@@ -805,7 +806,7 @@ def test_vfe_point_layer_equals_op_by_op_layer(name, autocast):
     z, ds, cfg, shapes = load_case(name)
 
     def run(fused, ac):
-        DynVFE.point_layer = fused
+        DynVFE.point_layer = DynVFE.max_layer = fused
         torch.manual_seed(0)
         net = build_network(cfg, len(ds.class_names), ds, logging.getLogger("t")).to(dev())
         net.load_state_dict(orc.seeded_state_dict(shapes, seed=int(z["seed"])), strict=False)
@@ -830,7 +831,7 @@ def test_vfe_point_layer_equals_op_by_op_layer(name, autocast):
         plain, plain_rs = run(False, autocast)
         exact, exact_rs = run(False, False) if autocast else (plain, plain_rs)
     finally:
-        DynVFE.point_layer = True
+        DynVFE.point_layer = DynVFE.max_layer = True
     assert set(fused) == set(plain) and len(fused) == 7
     for k in plain:
         assert fused[k].shape == plain[k].shape and torch.isfinite(fused[k]).all() and float(plain[k].norm()) > 0, k
