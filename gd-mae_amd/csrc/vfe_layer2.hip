@@ -226,24 +226,32 @@ __global__ __launch_bounds__(V2_WAVES * 64) void k_v2_max(const unsigned short* 
     const int cur_in = cur;
 #pragma unroll
     for (int r = 0; r < 16; ++r) cur = r < nrows ? prow[r] : cur;
+    f32x16 h[4];
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const f32x16 h = v2_h(ya, sW, n, half, b);
-      if (st[0] && cur_in >= 0) {                // the pillar carried over from the previous tile ends here
+    for (int b = 0; b < 4; ++b) h[b] = v2_h(ya, sW, n, half, b);
+    if (st[0] && cur_in >= 0) {                  // the pillar carried over from the previous tile ends here
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
         const long long o = (long long)cur_in * V2_CO + 32 * b + n;
         out[o] = best[b];
         arg[o] = bi[b];
         hmax[o] = bh[b];
       }
+    }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
+    for (int r = 0; r < 16; ++r) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
         const float bin = st[r] ? -1.f : best[b];
-        const float v = fmaxf(fmaf(ca[b], h[r], cb[b]), 0.f);
+        const float v = fmaxf(fmaf(ca[b], h[b][r], cb[b]), 0.f);
         const bool up = r < nrows && v > bin;    // strict: the first row of a pillar (lowest point id) wins ties
         best[b] = up ? v : bin;
-        bh[b] = up ? h[r] : bh[b];
+        bh[b] = up ? h[b][r] : bh[b];
         bi[b] = up ? qt + r : bi[b];
-        if (r < 15 && st[r < 15 ? r + 1 : 15]) {
+      }
+      if (r < 15 && st[r < 15 ? r + 1 : 15]) {   // row r closes its pillar: one branch for the four column blocks
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
           const long long o = (long long)prow[r] * V2_CO + 32 * b + n;
           out[o] = best[b];
           arg[o] = bi[b];
