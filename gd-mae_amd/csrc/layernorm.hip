@@ -3,8 +3,8 @@
 // Replaces, per EncoderLayer (reference pcdet/models/model_utils/sst_basic_block.py:77-84):
 //   src = src + src2 ; src = self.norm1(src)      and      src = src + src2 ; src = self.norm2(src)
 // i.e. an elementwise add followed by nn.LayerNorm(d, eps=1e-5) (torch: RowwiseMoments + LayerNormForward,
-// and three kernels in the backward).  Token tensors are only (n, d <= 256): one wavefront per row, the row
-// lives in registers (d/64 floats per lane), mean / variance by xor-shuffles, one pass over HBM.
+// and three kernels in the backward).  Token tensors are only (n, d <= 256): the row lives in registers (4 consecutive
+// columns per lane, 16-byte accesses), mean / variance by xor-shuffles inside the d/4-lane group, one pass over HBM.
 // The residual branch `b` may be bf16 (GEMM output under autocast) or fp32; `a` and the output are fp32.
 // Backward: dx = rstd * (g*gamma - mean(g*gamma) - xhat * mean(g*gamma*xhat)) goes to both inputs; dgamma / dbeta
 // are accumulated per lane over the workgroup's rows and reduced in a fixed order by a second kernel.
@@ -17,19 +17,38 @@ __device__ inline unsigned short f_to_bf16(float f) {
   return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
 }
 
-template <int VPL /* values per lane = d / 64 */, bool B_BF16>
-__device__ inline void ln_load_sum(const float* __restrict__ a, const void* __restrict__ b, long long row, int lane,
-                                   float (&s)[VPL]) {
-  constexpr int D = VPL * GD_WAVE;
+// Layout: a lane owns 4 consecutive columns (one 16-byte access per fp32 operand, 8 bytes per bf16 operand), LPR = d / 4
+// lanes form a row, a wavefront holds 64 / LPR rows (4 / 2 / 1 for d = 64 / 128 / 256); reductions are xor-shuffles
+// inside the LPR-lane group.
+template <int LPR>
+__device__ inline float ln_group_sum(float v) {
 #pragma unroll
-  for (int k = 0; k < VPL; ++k) {
-    const int c = k * GD_WAVE + lane;
-    float bv = B_BF16 ? bf16_to_f(((const unsigned short*)b)[row * D + c]) : ((const float*)b)[row * D + c];
-    s[k] = a[row * D + c] + bv;
-  }
+  for (int d = LPR / 2; d > 0; d >>= 1) v += __shfl_xor(v, d, GD_WAVE);
+  return v;
+}
+__device__ inline void ln_ld4(const float* __restrict__ p, long long e, float (&v)[4]) {
+  const float4 q = *reinterpret_cast<const float4*>(p + e);
+  v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+}
+__device__ inline void ln_ld4_bf(const void* __restrict__ p, long long e, float (&v)[4]) {
+  const uint2 q = *reinterpret_cast<const uint2*>((const unsigned short*)p + e);
+  v[0] = __uint_as_float(q.x << 16); v[1] = __uint_as_float(q.x & 0xFFFF0000u);
+  v[2] = __uint_as_float(q.y << 16); v[3] = __uint_as_float(q.y & 0xFFFF0000u);
+}
+__device__ inline void ln_ld4_any(const void* __restrict__ p, int bf, long long e, float (&v)[4]) {
+  if (bf) ln_ld4_bf(p, e, v); else ln_ld4((const float*)p, e, v);
+}
+__device__ inline void ln_st4(float* __restrict__ p, long long e, const float (&v)[4]) {
+  *reinterpret_cast<float4*>(p + e) = make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ inline void ln_st4_bf(unsigned short* __restrict__ p, long long e, const float (&v)[4]) {
+  uint2 q;
+  q.x = (unsigned)f_to_bf16(v[0]) | ((unsigned)f_to_bf16(v[1]) << 16);
+  q.y = (unsigned)f_to_bf16(v[2]) | ((unsigned)f_to_bf16(v[3]) << 16);
+  *reinterpret_cast<uint2*>(p + e) = q;
 }
 
-template <int VPL, bool B_BF16>
+template <int D, bool B_BF16>
 __global__ __launch_bounds__(256) void k_add_ln_fwd(const float* __restrict__ a, const void* __restrict__ b,
                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
                                                     long long n, float eps, float* __restrict__ y,
@@ -37,46 +56,47 @@ __global__ __launch_bounds__(256) void k_add_ln_fwd(const float* __restrict__ a,
                                                     unsigned short* __restrict__ y_bf16 /* optional copy */,
                                                     const float* __restrict__ pos_table, const int* __restrict__ tok_pos,
                                                     unsigned short* __restrict__ ypos_bf16 /* optional: bf16(y + pos) */) {
-  constexpr int D = VPL * GD_WAVE;
-  const int lane = threadIdx.x & (GD_WAVE - 1);
-  const int wib = threadIdx.x / GD_WAVE;
-  float g[VPL], bt[VPL];
+  constexpr int LPR = D / 4, RPW = GD_WAVE / LPR, RPB = 4 * RPW;   // lanes per row, rows per wavefront / workgroup
+  const int lane = threadIdx.x & (GD_WAVE - 1), wib = threadIdx.x / GD_WAVE;
+  const int c0 = 4 * (lane % LPR), rl = wib * RPW + lane / LPR;
+  float g[4], bt[4];
+  ln_ld4(gamma, c0, g);
+  ln_ld4(beta, c0, bt);
+  for (long long r0 = (long long)blockIdx.x * RPB; r0 < n; r0 += (long long)gridDim.x * RPB) {
+    const long long row = r0 + rl;
+    const bool live = row < n;
+    const long long e = (live ? row : n - 1) * D + c0;
+    float s[4], bv[4];
+    ln_ld4(a, e, s);
+    if (B_BF16) ln_ld4_bf(b, e, bv); else ln_ld4((const float*)b, e, bv);
 #pragma unroll
-  for (int k = 0; k < VPL; ++k) {
-    g[k] = gamma[k * GD_WAVE + lane];
-    bt[k] = beta[k * GD_WAVE + lane];
-  }
-  for (long long row = blockIdx.x * 4ll + wib; row < n; row += gridDim.x * 4ll) {
-    float s[VPL];
-    ln_load_sum<VPL, B_BF16>(a, b, row, lane, s);
-    float sum = 0.f;
-#pragma unroll
-    for (int k = 0; k < VPL; ++k) sum += s[k];
-    const float mean = gd_wave_sum(sum) * (1.f / D);
+    for (int k = 0; k < 4; ++k) s[k] += bv[k];
+    const float mean = ln_group_sum<LPR>((s[0] + s[1]) + (s[2] + s[3])) * (1.f / D);
     float sq = 0.f;
 #pragma unroll
-    for (int k = 0; k < VPL; ++k) {
+    for (int k = 0; k < 4; ++k) {
       const float dlt = s[k] - mean;
       sq = fmaf(dlt, dlt, sq);
     }
-    const float var = gd_wave_sum(sq) * (1.f / D);
-    const float rstd = rsqrtf(var + eps);
+    const float rstd = rsqrtf(ln_group_sum<LPR>(sq) * (1.f / D) + eps);
+    if (!live) continue;
+    float o[4];
 #pragma unroll
-    for (int k = 0; k < VPL; ++k) {
-      const float o = (s[k] - mean) * rstd * g[k] + bt[k];
-      y[row * D + k * GD_WAVE + lane] = o;
-      if (y_bf16) y_bf16[row * D + k * GD_WAVE + lane] = f_to_bf16(o);
-      if (ypos_bf16)   // q/k input of the NEXT layer (its gdmae_prep_tokens folded into this pass)
-        ypos_bf16[row * D + k * GD_WAVE + lane] = f_to_bf16(o + pos_table[(long long)tok_pos[row] * D + k * GD_WAVE + lane]);
+    for (int k = 0; k < 4; ++k) o[k] = (s[k] - mean) * rstd * g[k] + bt[k];
+    ln_st4(y, e, o);
+    if (y_bf16) ln_st4_bf(y_bf16, e, o);
+    if (ypos_bf16) {   // q/k input of the NEXT layer (its gdmae_prep_tokens folded into this pass)
+      float pv[4];
+      ln_ld4(pos_table, (long long)tok_pos[row] * D + c0, pv);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) pv[k] += o[k];
+      ln_st4_bf(ypos_bf16, e, pv);
     }
-    if (lane == 0) {
-      stats[row * 2] = mean;
-      stats[row * 2 + 1] = rstd;
-    }
+    if (c0 == 0) *reinterpret_cast<float2*>(stats + row * 2) = make_float2(mean, rstd);
   }
 }
 
-template <int VPL, bool B_BF16>
+template <int D, bool B_BF16>
 __global__ __launch_bounds__(256) void k_add_ln_bwd(const float* __restrict__ a, const void* __restrict__ b,
                                                     const float* __restrict__ gamma, const float* __restrict__ stats,
                                                     const float* __restrict__ dy, long long n, float* __restrict__ dx,
@@ -84,58 +104,71 @@ __global__ __launch_bounds__(256) void k_add_ln_bwd(const float* __restrict__ a,
                                                     const void* __restrict__ dy2 /* optional 2nd gradient */, int dy2_bf16,
                                                     unsigned short* __restrict__ dx_bf16 /* optional copy */,
                                                     const void* __restrict__ dy3 /* optional 3rd gradient */, int dy3_bf16) {
-  constexpr int D = VPL * GD_WAVE;
-  __shared__ float sh[4][3][D];
-  const int lane = threadIdx.x & (GD_WAVE - 1);
-  const int wib = threadIdx.x / GD_WAVE;
-  float g[VPL], dg[VPL], db[VPL], dsx[VPL];
+  constexpr int LPR = D / 4, RPW = GD_WAVE / LPR, RPB = 4 * RPW;
+  __shared__ float sh[RPB][3][D];
+  const int lane = threadIdx.x & (GD_WAVE - 1), wib = threadIdx.x / GD_WAVE;
+  const int c0 = 4 * (lane % LPR), rl = wib * RPW + lane / LPR;
+  float g[4], dg[4], db[4], dsx[4];
+  ln_ld4(gamma, c0, g);
 #pragma unroll
-  for (int k = 0; k < VPL; ++k) {
-    g[k] = gamma[k * GD_WAVE + lane];
-    dg[k] = 0.f;
-    db[k] = 0.f;
-    dsx[k] = 0.f;
-  }
-  for (long long row = blockIdx.x * 4ll + wib; row < n; row += gridDim.x * 4ll) {
-    float s[VPL];
-    ln_load_sum<VPL, B_BF16>(a, b, row, lane, s);
-    const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
-    float gy[VPL], xh[VPL];
+  for (int k = 0; k < 4; ++k) dg[k] = db[k] = dsx[k] = 0.f;
+  for (long long r0 = (long long)blockIdx.x * RPB; r0 < n; r0 += (long long)gridDim.x * RPB) {
+    const long long row = r0 + rl;
+    const bool live = row < n;
+    const long long e = (live ? row : n - 1) * D + c0;
+    float s[4], bv[4], d[4], t[4];
+    ln_ld4(a, e, s);
+    if (B_BF16) ln_ld4_bf(b, e, bv); else ln_ld4((const float*)b, e, bv);
+    ln_ld4(dy, e, d);
+    if (dy2) {
+      ln_ld4_any(dy2, dy2_bf16, e, t);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) d[k] += t[k];
+    }
+    if (dy3) {
+      ln_ld4_any(dy3, dy3_bf16, e, t);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) d[k] += t[k];
+    }
+    const float2 mr = *reinterpret_cast<const float2*>(stats + (live ? row : n - 1) * 2);
+    const float mean = mr.x, rstd = mr.y;
+    float gy[4], xh[4];
     float m1 = 0.f, m2 = 0.f;
 #pragma unroll
-    for (int k = 0; k < VPL; ++k) {
-      float d = dy[row * D + k * GD_WAVE + lane];
-      if (dy2) d += dy2_bf16 ? bf16_to_f(((const unsigned short*)dy2)[row * D + k * GD_WAVE + lane])
-                             : ((const float*)dy2)[row * D + k * GD_WAVE + lane];
-      if (dy3) d += dy3_bf16 ? bf16_to_f(((const unsigned short*)dy3)[row * D + k * GD_WAVE + lane])
-                             : ((const float*)dy3)[row * D + k * GD_WAVE + lane];
-      xh[k] = (s[k] - mean) * rstd;
-      gy[k] = d * g[k];
+    for (int k = 0; k < 4; ++k) {
+      if (!live) d[k] = 0.f;
+      xh[k] = (s[k] + bv[k] - mean) * rstd;
+      gy[k] = d[k] * g[k];
       m1 += gy[k];
       m2 = fmaf(gy[k], xh[k], m2);
-      dg[k] = fmaf(d, xh[k], dg[k]);
-      db[k] += d;
+      dg[k] = fmaf(d[k], xh[k], dg[k]);
+      db[k] += d[k];
     }
-    m1 = gd_wave_sum(m1) * (1.f / D);
-    m2 = gd_wave_sum(m2) * (1.f / D);
+    m1 = ln_group_sum<LPR>(m1) * (1.f / D);
+    m2 = ln_group_sum<LPR>(m2) * (1.f / D);
+    if (!live) continue;
+    float o[4];
 #pragma unroll
-    for (int k = 0; k < VPL; ++k) {
-      const float o = rstd * (gy[k] - m1 - xh[k] * m2);
-      dx[row * D + k * GD_WAVE + lane] = o;
-      if (dx_bf16) dx_bf16[row * D + k * GD_WAVE + lane] = f_to_bf16(o);
-      dsx[k] += o;
+    for (int k = 0; k < 4; ++k) {
+      o[k] = rstd * (gy[k] - m1 - xh[k] * m2);
+      dsx[k] += o[k];
     }
+    ln_st4(dx, e, o);
+    if (dx_bf16) ln_st4_bf(dx_bf16, e, o);
   }
 #pragma unroll
-  for (int k = 0; k < VPL; ++k) {
-    sh[wib][0][k * GD_WAVE + lane] = dg[k];
-    sh[wib][1][k * GD_WAVE + lane] = db[k];
-    sh[wib][2][k * GD_WAVE + lane] = dsx[k];
+  for (int k = 0; k < 4; ++k) {
+    sh[rl][0][c0 + k] = dg[k];
+    sh[rl][1][c0 + k] = db[k];
+    sh[rl][2][c0 + k] = dsx[k];
   }
   __syncthreads();
   for (int c = threadIdx.x; c < 3 * D; c += 256) {
     const int which = c / D, col = c % D;
-    part[(long long)blockIdx.x * 3 * D + c] = sh[0][which][col] + sh[1][which][col] + sh[2][which][col] + sh[3][which][col];
+    float acc = 0.f;
+#pragma unroll
+    for (int r = 0; r < RPB; ++r) acc += sh[r][which][col];
+    part[(long long)blockIdx.x * 3 * D + c] = acc;
   }
 }
 
@@ -151,8 +184,9 @@ __global__ __launch_bounds__(256) void k_reduce_partials_f32(const float* __rest
   if (ps == 0 && c < C2) out[c] = acc;
 }
 
-static inline int ln_grid(long long n) {
-  long long g = (n + 3) / 4;
+static inline int ln_grid(long long n, int d) {
+  const int rpb = 4 * (64 / (d / 4));            // rows per workgroup pass
+  long long g = (n + rpb - 1) / rpb;
   if (g > 1024) g = 1024;
   if (g < 1) g = 1;
   return (int)g;
@@ -166,11 +200,11 @@ int gd_add_layernorm_fwd_ex(const float* a, const void* b, int b_is_bf16, const 
                             float eps, float* y, float* stats, void* y_bf16, const float* pos_table, const int* tok_pos,
                             void* ypos_bf16, hipStream_t st) {
   if (n <= 0) return 0;
-  const dim3 grid(ln_grid(n)), block(256);
+  const dim3 grid(ln_grid(n, d)), block(256);
 #define GD_LN_FWD(V, BF) hipLaunchKernelGGL((k_add_ln_fwd<V, BF>), grid, block, 0, st, a, b, gamma, beta, n, eps, y, stats, (unsigned short*)y_bf16, pos_table, tok_pos, (unsigned short*)ypos_bf16)
-  if (d == 64) { if (b_is_bf16) GD_LN_FWD(1, true); else GD_LN_FWD(1, false); }
-  else if (d == 128) { if (b_is_bf16) GD_LN_FWD(2, true); else GD_LN_FWD(2, false); }
-  else if (d == 256) { if (b_is_bf16) GD_LN_FWD(4, true); else GD_LN_FWD(4, false); }
+  if (d == 64) { if (b_is_bf16) GD_LN_FWD(64, true); else GD_LN_FWD(64, false); }
+  else if (d == 128) { if (b_is_bf16) GD_LN_FWD(128, true); else GD_LN_FWD(128, false); }
+  else if (d == 256) { if (b_is_bf16) GD_LN_FWD(256, true); else GD_LN_FWD(256, false); }
   else GD_REQUIRE(false, "add_layernorm supports d in {64, 128, 256}");
 #undef GD_LN_FWD
   GD_LAUNCH_CHECK();
@@ -189,13 +223,13 @@ int gd_add_layernorm_bwd_ex(const float* a, const void* b, int b_is_bf16, const 
                             const void* dy2, int dy2_bf16, const void* dy3, int dy3_bf16, long long n, int d, float* dx,
                             void* dx_bf16, float* sums, void* workspace, hipStream_t st) {
   if (n <= 0) return 0;
-  const int nblk = ln_grid(n);
+  const int nblk = ln_grid(n, d);
   const dim3 grid(nblk), block(256);
   float* part = (float*)workspace;
 #define GD_LN_BWD(V, BF) hipLaunchKernelGGL((k_add_ln_bwd<V, BF>), grid, block, 0, st, a, b, gamma, stats, dy, n, dx, part, dy2, dy2_bf16, (unsigned short*)dx_bf16, dy3, dy3_bf16)
-  if (d == 64) { if (b_is_bf16) GD_LN_BWD(1, true); else GD_LN_BWD(1, false); }
-  else if (d == 128) { if (b_is_bf16) GD_LN_BWD(2, true); else GD_LN_BWD(2, false); }
-  else if (d == 256) { if (b_is_bf16) GD_LN_BWD(4, true); else GD_LN_BWD(4, false); }
+  if (d == 64) { if (b_is_bf16) GD_LN_BWD(64, true); else GD_LN_BWD(64, false); }
+  else if (d == 128) { if (b_is_bf16) GD_LN_BWD(128, true); else GD_LN_BWD(128, false); }
+  else if (d == 256) { if (b_is_bf16) GD_LN_BWD(256, true); else GD_LN_BWD(256, false); }
   else GD_REQUIRE(false, "add_layernorm supports d in {64, 128, 256}");
 #undef GD_LN_BWD
   GD_LAUNCH_CHECK();
