@@ -170,6 +170,8 @@ def main():
 
     # synthetic frames: frame f of rank r uses seed 1000 * r + f; pool of distinct batches, resident in HBM
     B = args.batch_per_gpu
+    # every pooled batch must pass through the untimed warmup once (first-use GEMM algorithm timing, MIOpen find)
+    args.pool = max(1, min(args.pool, args.warmup))
     host_batches = [synth.synth_batch(100000 * rank + 97 * k, B, ds.point_cloud_range, **skw) for k in range(args.pool)]
     pinned = [torch.from_numpy(b).pin_memory() for b in host_batches]
     dev_batches = [p.to(dev, non_blocking=True) for p in pinned]
