@@ -323,6 +323,7 @@ extern "C" int gdmae_colstats(const void* x, long long R, int C, int is_bf16, do
   const int epv = is_bf16 ? 8 : 4;
   GD_REQUIRE(C % epv == 0 && (C / epv) <= 256, "C must be a multiple of 8 (bf16) / 4 (fp32) and <= 2048 / 1024");
   int nblk = (int)(R / 64 > 512 ? 512 : (R / 64 > 0 ? R / 64 : 1));   // few partials: the fp64 combine stays short
+  if (R >= (1ll << 20)) nblk = 1024;                                   // dense maps (1.7 M rows): 4 workgroups per CU
   const int rows_per_iter = 256 / (C / epv);
   const size_t lds = (size_t)rows_per_iter * 2 * C * sizeof(float);
   GD_REQUIRE(lds <= 64 * 1024, "colstats LDS");
@@ -395,6 +396,7 @@ extern "C" int gdmae_bn_fold(const void* x, long long R, int C, int is_bf16, dou
   const int epv = is_bf16 ? 8 : 4;
   GD_REQUIRE(C % epv == 0 && (C / epv) <= 256, "C must be a multiple of 8 (bf16) / 4 (fp32) and <= 2048 / 1024");
   int nblk = (int)(R / 64 > 512 ? 512 : (R / 64 > 0 ? R / 64 : 1));
+  if (R >= (1ll << 20)) nblk = 1024;
   const int rows_per_iter = 256 / (C / epv);
   const size_t lds = (size_t)rows_per_iter * 2 * C * sizeof(float);
   GD_REQUIRE(lds <= 64 * 1024, "colstats LDS");
