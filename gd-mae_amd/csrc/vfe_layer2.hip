@@ -7,8 +7,8 @@
 // 16 v_mfma_f32_32x32x16_bf16 from a 4 KB tile of y1, so every kernel below recomputes it in accumulators:
 //   forward   k_v2_stats  : column sums of h, h^2 (fp32 accumulators)  -> gd_bn_fold_from_partials
 //             k_v2_max    : tiles in pillar (CSR) order; the tile goes through LDS and each lane walks one column
-//                           down the rows, closing a pillar whenever the pillar id changes -> out, arg, hmax
-//   backward  k_v2_gstats : gm = g [out > 0], column sums of gm, gm*hmax (only arg-max entries carry gradient)
+//   (see k_v2_max below)    a pillar is closed whenever the pillar id changes -> out, arg
+//   backward  k_v2_gstats : gm = g [out > 0], column sums of gm, gm*h(arg) with h(arg) = (out - b) / a
 //             k_v2_dy     : dx = a dh + c0 + c1 h  (dh = gm at the arg-max point) -> LDS -> dy1 = dx W  (MFMA)
 //             k_v2_dw     : dW^T += y1^T dx, the dx accumulators are the B operand, y1^T comes from a transposed
 //                           LDS tile; per-workgroup partials, fixed-order reduction
@@ -158,8 +158,7 @@ __global__ __launch_bounds__(V2_WAVES * 64) void k_v2_stats(const unsigned short
 __global__ __launch_bounds__(V2_WAVES * 64) void k_v2_max(const unsigned short* __restrict__ y1, long long N,
                                                           const unsigned short* __restrict__ W, const int* __restrict__ pt_off,
                                                           const int* __restrict__ rowpil, int M, const float* __restrict__ ab,
-                                                          float* __restrict__ out, int* __restrict__ arg,
-                                                          float* __restrict__ hmax) {
+                                                          float* __restrict__ out, int* __restrict__ arg) {
   __shared__ unsigned short sW[V2_CO * V2_LDW];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 31, half = lane >> 5;
   v2_load_w(W, sW);
@@ -189,10 +188,10 @@ __global__ __launch_bounds__(V2_WAVES * 64) void k_v2_max(const unsigned short* 
     ca[b] = ab[32 * b + n];
     cb[b] = ab[V2_CO + 32 * b + n];
   }
-  float best[4], bh[4];
+  float best[4];
   int bi[4];
 #pragma unroll
-  for (int b = 0; b < 4; ++b) { best[b] = -1.f; bh[b] = 0.f; bi[b] = 0; }
+  for (int b = 0; b < 4; ++b) { best[b] = -1.f; bi[b] = 0; }
   int cur = -1;
 
   V2Frag ya[4], yn[4];
@@ -235,7 +234,6 @@ __global__ __launch_bounds__(V2_WAVES * 64) void k_v2_max(const unsigned short* 
         const long long o = (long long)cur_in * V2_CO + 32 * b + n;
         out[o] = best[b];
         arg[o] = bi[b];
-        hmax[o] = bh[b];
       }
     }
 #pragma unroll
@@ -246,7 +244,6 @@ __global__ __launch_bounds__(V2_WAVES * 64) void k_v2_max(const unsigned short* 
         const float v = fmaxf(fmaf(ca[b], h[b][r], cb[b]), 0.f);
         const bool up = r < nrows && v > bin;    // strict: the first row of a pillar (lowest point id) wins ties
         best[b] = up ? v : bin;
-        bh[b] = up ? h[b][r] : bh[b];
         bi[b] = up ? qt + r : bi[b];
       }
       if (r < 15 && st[r < 15 ? r + 1 : 15]) {   // row r closes its pillar: one branch for the four column blocks
@@ -255,7 +252,6 @@ __global__ __launch_bounds__(V2_WAVES * 64) void k_v2_max(const unsigned short* 
           const long long o = (long long)prow[r] * V2_CO + 32 * b + n;
           out[o] = best[b];
           arg[o] = bi[b];
-          hmax[o] = bh[b];
         }
       }
     }
@@ -269,13 +265,14 @@ __global__ __launch_bounds__(V2_WAVES * 64) void k_v2_max(const unsigned short* 
       const long long o = (long long)cur * V2_CO + 32 * b + n;
       out[o] = best[b];
       arg[o] = bi[b];
-      hmax[o] = bh[b];
     }
   }
 }
 
 // ---- backward: masked gradient and its column sums ---------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_v2_gstats(const float* __restrict__ out, const float* __restrict__ hmax,
+// the pre-activation at the arg-max row is recovered from the stored maximum, h = (out - b) / a (out > 0 there, so the
+// ReLU was the identity; a = 0 only for gamma = 0, where the sum it feeds is multiplied by gamma anyway)
+__global__ __launch_bounds__(256) void k_v2_gstats(const float* __restrict__ out, const float* __restrict__ ab,
                                                    const float* __restrict__ g, long long M, float* __restrict__ gm,
                                                    float* __restrict__ part) {
   __shared__ float sR[2 * 2 * V2_CO];
@@ -283,13 +280,16 @@ __global__ __launch_bounds__(256) void k_v2_gstats(const float* __restrict__ out
   const long long chunk = (M + gridDim.x - 1) / gridDim.x;
   const long long r0 = blockIdx.x * chunk, r1 = r0 + chunk < M ? r0 + chunk : M;
   float s0 = 0.f, s1 = 0.f;
+  const float ac = ab[c], bc = ab[V2_CO + c];
+  const float ia = ac != 0.f ? 1.f / ac : 0.f;
 #pragma unroll 4
   for (long long p = r0 + tr; p < r1; p += 2) {
     const long long o = p * V2_CO + c;
-    const float gv = out[o] > 0.f ? g[o] : 0.f;
+    const float ov = out[o];
+    const float gv = ov > 0.f ? g[o] : 0.f;
     gm[o] = gv;
     s0 += gv;
-    s1 = fmaf(gv, hmax[o], s1);
+    s1 = fmaf(gv, (ov - bc) * ia, s1);
   }
   sR[(tr * 2 + 0) * V2_CO + c] = s0;
   sR[(tr * 2 + 1) * V2_CO + c] = s1;
@@ -501,12 +501,12 @@ extern "C" size_t gdmae_vfe_max_layer_workspace_bytes(void) { return v2_ws_bytes
 // y1 (N, 64) bf16 with its rows in pillar-major order (gdmae_pillar_major_rows + gdmae_vfe_point_layer_fwd),
 // row_pillar (N) = pillar of each row, pillar_pt_off (M + 1) = first row of each pillar; W (128, 64) bf16.
 // out (M, 128) fp32 = max over the pillar of relu(BatchNorm1d_train(y1 W^T)), arg = row of the maximum (first row on
-// ties = lowest point id), hmax = the pre-activation at that point (kept for the backward statistics); stats / ab / mv as gdmae_bn_fold.
+// ties = lowest point id); stats / ab / mv as gdmae_bn_fold.
 extern "C" int gdmae_vfe_max_layer_fwd(const void* y1, long long N, const void* W, const int* pillar_pt_off,
                                        const int* row_pillar, int M, const float* gamma,
                                        const float* beta, double eps, double momentum, float* running_mean,
                                        float* running_var, long long* num_batches, double* stats, float* ab, float* mv,
-                                       float* out, int* arg, float* hmax, void* workspace, void* stream) {
+                                       float* out, int* arg, void* workspace, void* stream) {
   GD_REQUIRE(N > 0 && M > 0, "vfe max layer: no points");
   hipStream_t st = (hipStream_t)stream;
   const V2Ws ws = v2_ws(workspace);
@@ -519,7 +519,7 @@ extern "C" int gdmae_vfe_max_layer_fwd(const void* y1, long long N, const void* 
   if (rc) return rc;
   const int g2 = v2_grid(N, v2_resident_blocks(k_v2_max, 1, 4096));
   hipLaunchKernelGGL(k_v2_max, dim3(g2), dim3(V2_WAVES * 64), 0, st, (const unsigned short*)y1, N, (const unsigned short*)W,
-                     pillar_pt_off, row_pillar, M, (const float*)ab, out, arg, hmax);
+                     pillar_pt_off, row_pillar, M, (const float*)ab, out, arg);
   GD_LAUNCH_CHECK();
   return 0;
 }
@@ -528,14 +528,14 @@ extern "C" int gdmae_vfe_max_layer_fwd(const void* y1, long long N, const void* 
 // fp32 are written, or accumulated into when `accumulate`.
 extern "C" int gdmae_vfe_max_layer_bwd(const void* y1, long long N, const void* W, const int* row_pillar, int M,
                                        const float* gamma, const double* stats, const float* ab,
-                                       const float* out, const int* arg, const float* hmax, const float* g, void* gm,
+                                       const float* out, const int* arg, const float* g, void* gm,
                                        void* dy1, float* dgamma, float* dbeta, float* dW, int accumulate, void* workspace,
                                        void* stream) {
   GD_REQUIRE(N > 0 && M > 0, "vfe max layer: no points");
   hipStream_t st = (hipStream_t)stream;
   const V2Ws ws = v2_ws(workspace);
   int g0 = (int)(M / 64 > V2_MAX_GRID ? V2_MAX_GRID : (M / 64 > 0 ? M / 64 : 1));
-  hipLaunchKernelGGL(k_v2_gstats, dim3(g0), dim3(256), 0, st, out, hmax, g, (long long)M, (float*)gm, ws.part);
+  hipLaunchKernelGGL(k_v2_gstats, dim3(g0), dim3(256), 0, st, out, ab, g, (long long)M, (float*)gm, ws.part);
   GD_LAUNCH_CHECK();
   int rc = gd_partials_to_f64(st, ws.part, g0, 2 * V2_CO, ws.sums);
   if (rc) return rc;

@@ -172,7 +172,6 @@ class PointLayer2Max(torch.autograd.Function):
         n, M = y1.shape[0], pt_off.numel() - 1
         wb = ops.shadow(weight, torch.bfloat16).contiguous()
         out = torch.empty(M, C, dtype=torch.float32, device=dev)
-        hmax = torch.empty(M, C, dtype=torch.float32, device=dev)
         arg = torch.empty(M, C, dtype=torch.int32, device=dev)
         stats = torch.empty(2 * C, dtype=torch.float64, device=dev)
         ab = torch.empty(2 * C, dtype=torch.float32, device=dev)
@@ -184,10 +183,10 @@ class PointLayer2Max(torch.autograd.Function):
             rm, rv, nb, mom = bn.running_mean, bn.running_var, bn.num_batches_tracked, float(bn.momentum)
         L.call("gdmae_vfe_max_layer_fwd", L.ptr(y1), n, L.ptr(wb), L.ptr(pt_off), L.ptr(row_pillar), M, L.ptr(gamma),
                L.ptr(beta), float(eps), mom, L.ptr(rm) if rm is not None else None, L.ptr(rv) if rv is not None else None,
-               L.ptr(nb) if nb is not None else None, L.ptr(stats), L.ptr(ab), L.ptr(mv), L.ptr(out), L.ptr(arg), L.ptr(hmax),
-               L.ptr(ws), L.stream())
+               L.ptr(nb) if nb is not None else None, L.ptr(stats), L.ptr(ab), L.ptr(mv), L.ptr(out), L.ptr(arg), L.ptr(ws),
+               L.stream())
         ctx.ws = ws
-        ctx.save_for_backward(y1, row_pillar, wb, gamma.detach(), stats, ab, out, arg, hmax)
+        ctx.save_for_backward(y1, row_pillar, wb, gamma.detach(), stats, ab, out, arg)
         ctx.direct = (ops.direct_grad(weight), *gbn.direct_pair(gamma, beta))
         mf, vf = mv[:C], mv[C:]
         ctx.mark_non_differentiable(mf, vf)
@@ -195,7 +194,7 @@ class PointLayer2Max(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g, _m, _v):
-        y1, row_pillar, wb, gamma, stats, ab, out, arg, hmax = ctx.saved_tensors
+        y1, row_pillar, wb, gamma, stats, ab, out, arg = ctx.saved_tensors
         n, (M, C) = y1.shape[0], out.shape
         g = g.float().contiguous()
         dw, dg, db = ctx.direct
@@ -207,7 +206,7 @@ class PointLayer2Max(torch.autograd.Function):
         gm = torch.empty_like(out)
         dy1 = torch.empty_like(y1)
         L.call("gdmae_vfe_max_layer_bwd", L.ptr(y1), n, L.ptr(wb), L.ptr(row_pillar), M, L.ptr(gamma), L.ptr(stats), L.ptr(ab),
-               L.ptr(out), L.ptr(arg), L.ptr(hmax), L.ptr(g), L.ptr(gm), L.ptr(dy1), L.ptr(dg), L.ptr(db), L.ptr(dw), acc,
+               L.ptr(out), L.ptr(arg), L.ptr(g), L.ptr(gm), L.ptr(dy1), L.ptr(dg), L.ptr(db), L.ptr(dw), acc,
                L.ptr(ctx.ws), L.stream())
         if acc:
             return dy1, None, None, None, None, None, None, None

@@ -98,17 +98,16 @@ int gdmae_vfe_point_layer_bwd(const float* points, const long long* point_coords
  * Linear(64 -> 128, no bias), BatchNorm1d(train), ReLU, torch_scatter.scatter_max).  The (N, 128) pre-activation is
  * recomputed from y1 in MFMA accumulators by every kernel.  y1 (N, 64) bf16 with rows in pillar-major order and
  * row_pillar (N) from gdmae_pillar_major_rows + gdmae_vfe_point_layer_fwd(coords_per_pillar = 1); pillar_pt_off (M + 1) = first row of each
- * pillar; W (128, 64) bf16; out (M, 128) fp32, arg = row of the maximum (first row on ties = lowest point id),
- * hmax = pre-activation at that row; g = gradient of out; gm = scratch of
+ * pillar; W (128, 64) bf16; out (M, 128) fp32, arg = row of the maximum (first row on ties = lowest point id); g = gradient of out; gm = scratch of
  * M * 128 floats; dy1 (N, 64) bf16 written; dgamma / dbeta / dW (128, 64) fp32 written, or accumulated into. */
 size_t gdmae_vfe_max_layer_workspace_bytes(void);
 int gdmae_vfe_max_layer_fwd(const void* y1, long long N, const void* W, const int* pillar_pt_off, const int* row_pillar,
                             int M, const float* gamma, const float* beta, double eps, double momentum,
                             float* running_mean, float* running_var, long long* num_batches, double* stats, float* ab,
-                            float* mv, float* out, int* arg, float* hmax, void* workspace, void* stream);
+                            float* mv, float* out, int* arg, void* workspace, void* stream);
 int gdmae_vfe_max_layer_bwd(const void* y1, long long N, const void* W, const int* row_pillar, int M, const float* gamma,
-                            const double* stats, const float* ab, const float* out, const int* arg, const float* hmax,
-                            const float* g, void* gm, void* dy1, float* dgamma, float* dbeta, float* dW, int accumulate,
+                            const double* stats, const float* ab, const float* out, const int* arg, const float* g, void* gm,
+                            void* dy1, float* dgamma, float* dbeta, float* dW, int accumulate,
                             void* workspace, void* stream);
 int gdmae_segment_max(const float* x, const int* pillar_pt_off, const int* pillar_pts, int M, int C, float* out,
                       int* arg, void* stream);
