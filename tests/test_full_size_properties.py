@@ -1,0 +1,174 @@
+"""GPU parity at BASELINE.json's full size (config B: 8 synthetic Waymo-shape frames, ~1.4 M points, ~127 k pillars)
+through size-independent properties of the domain - the oracle cannot run these sizes in seconds:
+
+* voxelization: the CSR is a permutation grouped by pillar, offsets / inverse / coordinates / means agree with each other
+  and with an independent torch computation (unique cells, index_add means);
+* masking: exact per-sample keep counts; token sets and window partitions: every token exactly once, window sizes
+  within the capacity of their level;
+* window attention: with v = 1 every output row is 1 (softmax rows sum to one), for every level and implementation;
+* Chamfer: zero for identical sets; DynVFE point layers: invariance of the pillar features to a permutation of the
+  input points (fused layers, bf16 mode);
+* the whole training step: finite loss and gradients for every parameter, bit-identical when repeated (deterministic
+  kernels, no atomics in floating point).
+"""
+import logging
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def scene():
+    from gdmae_hip import configs, plan as gplan, synth
+    from pcdet.models.backbones_3d.spt_backbone import stage_plan_args
+    cfg, ds, skw = configs.named_config("B", mask_ratio=0.75)
+    B = 8
+    pts = torch.from_numpy(synth.synth_batch(4242, B, ds.point_cloud_range, **skw)).to(dev())
+    vox = gplan.voxelize(pts, ds.point_cloud_range, ds.voxel_size, ds.grid_size, B)
+    ep = gplan.encoder_plan(vox, *stage_plan_args(cfg.BACKBONE_3D.SST_BLOCK_LIST), keep_frac=0.25)
+    return cfg, ds, skw, B, pts, vox, ep
+
+
+def test_voxelization_invariants_at_full_size(scene):
+    cfg, ds, skw, B, pts, vox, ep = scene
+    N, M = vox.N, vox.M
+    assert N > 1_000_000 and M > 100_000
+    gx, gy, gz = vox.grid
+    # kept points = the in-range points, original order
+    lo = torch.tensor(vox.lo, device=dev())
+    vs = torch.tensor(vox.vs, device=dev())
+    hi = lo + vs * torch.tensor([gx, gy, gz], device=dev(), dtype=torch.float32)
+    xyz = pts[:, 1:4]
+    keep = ((xyz >= lo) & (xyz < hi)).all(1)
+    assert int(keep.sum()) == N
+    assert torch.equal(vox.points, pts[keep])
+    # pillars = unique occupied cells in lexicographic (b, z, y, x) order
+    c = vox.point_coords
+    key = ((c[:, 0] * gz + c[:, 1]) * gy + c[:, 2]) * gx + c[:, 3]
+    uk, inv = torch.unique(key, return_inverse=True)
+    assert uk.numel() == M
+    assert torch.equal(inv, vox.inverse) and torch.equal(vox.inverse32.long(), vox.inverse)
+    vk = ((vox.voxel_coords[:, 0] * gz + vox.voxel_coords[:, 1]) * gy + vox.voxel_coords[:, 2]) * gx + vox.voxel_coords[:, 3]
+    assert torch.equal(vk, uk) and torch.equal(vox.pillar_cell.long(), uk)
+    # CSR: a permutation of the points, grouped by pillar, ascending ids inside a pillar
+    csr = vox.pillar_pts.long()
+    assert torch.equal(torch.sort(csr).values, torch.arange(N, device=dev()))
+    cnt = torch.bincount(vox.inverse, minlength=M)
+    assert int(vox.pt_off[0]) == 0 and torch.equal(vox.pt_off[1:].long(), torch.cumsum(cnt, 0))
+    rowpil = vox.inverse[csr]
+    assert bool((rowpil[1:] >= rowpil[:-1]).all())
+    same = rowpil[1:] == rowpil[:-1]
+    assert bool((csr[1:][same] > csr[:-1][same]).all())
+    assert torch.equal(vox.row_pillar.long(), rowpil) and torch.equal(vox.points_pm, vox.points[csr])
+    # scatter-mean (the kernel sums in canonical order; torch's index_add order differs: fp32 tolerance 1e-4 m)
+    F = vox.n_cols - 1
+    ref = torch.zeros(M, F, device=dev(), dtype=torch.float64).index_add_(0, vox.inverse, vox.points[:, 1:].double())
+    ref = (ref / cnt[:, None]).float()
+    assert torch.allclose(vox.pillar_mean, ref, rtol=0, atol=1e-4)
+    assert int(vox.sample_off[-1]) == M and (cnt > 0).all()
+
+
+def test_mask_tokens_and_windows_at_full_size(scene):
+    cfg, ds, skw, B, pts, vox, ep = scene
+    M = vox.M
+    so = vox.sample_off.tolist()
+    mask = ep.mask[:M]
+    assert set(torch.unique(mask).tolist()) <= {0.0, 1.0}
+    for b in range(B):
+        n = so[b + 1] - so[b]
+        assert int((mask[so[b]:so[b + 1]] == 0).sum()) == int(n * 0.25)      # common_utils.random_masking: int(L * keep)
+    vis = torch.nonzero(mask == 0)[:, 0]
+    assert torch.equal(ep.tok_pillar.long(), vis)
+    for st in ep.stages:
+        assert st.n_tok > 0 and bool((st.tok_cell[1:] > st.tok_cell[:-1]).all())
+        assert torch.equal(st.map[st.tok_cell.long()], torch.arange(st.n_tok, device=dev(), dtype=torch.int32))
+        assert int((st.map >= 0).sum()) == st.n_tok
+        for wp in st.windows:
+            assert torch.equal(torch.sort(wp.csr_tok.long()).values, torch.arange(st.n_tok, device=dev()))
+            assert sum(wp.n_tok) == st.n_tok and int(wp.win_len.sum()) == st.n_tok
+            base = 0
+            for lvl, nw in enumerate(wp.n_win):
+                ln = wp.win_len[base:base + nw]
+                assert nw == 0 or (int(ln.min()) >= 1 and int(ln.max()) <= wp.max_tokens[lvl])
+                base += nw
+            # tokens of one window are contiguous in csr_tok and share tok_win
+            tw = wp.tok_win[wp.csr_tok.long()]
+            assert int((tw[1:] != tw[:-1]).sum()) + 1 == sum(wp.n_win)
+
+
+@pytest.mark.parametrize("impl", [0, 1, 2])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_attention_rows_sum_to_one_at_full_size(scene, impl, dt):
+    from gdmae_hip import lib as L, ops
+    cfg, ds, skw, B, pts, vox, ep = scene
+    st = ep.stages[1]
+    d, nhead = 256, 8
+    gen = torch.Generator(device="cpu").manual_seed(3)
+    qk = torch.randn(st.n_tok, 2 * d, generator=gen).to(dev()).to(dt)
+    v = torch.ones(st.n_tok, d, device=dev(), dtype=dt)
+    tau = torch.full((1, 1, 1), 0.07, device=dev())
+    L.call("gdmae_set_attention_impl", impl)
+    try:
+        for wp in st.windows:
+            out = ops.WindowCosineAttention.apply(qk, v, tau, wp, nhead, 0.01)
+            assert torch.allclose(out.float(), torch.ones_like(out, dtype=torch.float32), rtol=0, atol=2e-5 if dt == torch.float32 else 8e-3)
+    finally:
+        L.call("gdmae_set_attention_impl", 2)
+
+
+def test_chamfer_and_point_layers_at_full_size(scene):
+    from gdmae_hip import ops, plan as gplan
+    from pcdet.models import build_network
+    cfg, ds, skw, B, pts, vox, ep = scene
+    gt = ops.group_gt_points(vox, 64)[:, :16].contiguous()
+    w = torch.ones(vox.M, device=dev())
+    loss = ops.ChamferLoss.apply(gt.clone(), gt, w)
+    assert float(loss) == 0.0
+    # pillar features do not depend on the order of the input points (fused point layers, bf16 mode)
+    torch.manual_seed(0)
+    net = build_network(cfg, len(ds.class_names), ds, logging.getLogger("t")).to(dev()).train()
+    perm = torch.randperm(pts.shape[0], generator=torch.Generator(device="cpu").manual_seed(5)).to(dev())
+    outs = []
+    for p in (pts, pts[perm]):
+        bd = {"points": p, "batch_size": B}
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            outs.append(net.vfe(bd)["pillar_features"].float())
+    assert outs[0].shape == (vox.M, 128)
+    # the pillar means and the BatchNorm statistics are sums in a different order: fp32 / bf16-input rounding only
+    assert float((outs[0] - outs[1]).abs().max()) <= 2e-2 * float(outs[0].abs().max())
+    assert float((outs[0] - outs[1]).norm()) <= 2e-3 * float(outs[0].norm())
+
+
+def test_train_step_is_finite_and_deterministic_at_full_size(scene):
+    from gdmae_hip import configs, optim
+    from pcdet.models import build_network
+    cfg, ds, skw, B, pts, vox, ep = scene
+    gen = torch.Generator(device="cpu").manual_seed(11)
+    noise = torch.rand(vox.M, generator=gen).to(dev())
+    res = []
+    for rep in range(2):
+        torch.manual_seed(7)
+        net = build_network(cfg, len(ds.class_names), ds, logging.getLogger("t")).to(dev()).train()
+        net.sync_loss_scalar = False
+        net.backbone_3d.dense_spatial_features = False
+        opt = optim.FlatAdamOneCycle(net, configs.optimization_cfg(B), total_steps=10)
+        opt.zero_grad()
+        bd = {"points": pts, "batch_size": B, "mae_noise": noise}
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            ret, _, _ = net(bd)
+        ret["loss"].backward()
+        res.append((ret["loss"].detach().clone(), opt.flat_grad.clone()))
+        if rep == 0:
+            missing = [k for k, p in net.named_parameters() if p.grad is None]
+            assert not missing, missing
+    loss, grad = res[0]
+    assert torch.isfinite(loss) and 0.0 < float(loss) < 100.0
+    assert torch.isfinite(grad).all() and float(grad.norm()) > 0
+    assert torch.equal(res[0][0], res[1][0]), (float(res[0][0]), float(res[1][0]))
+    assert torch.equal(res[0][1], res[1][1]), float((res[0][1] - res[1][1]).abs().max())
