@@ -435,7 +435,8 @@ class ChamferLoss(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, pred, gt, weights):
-        pred, gt, weights = _f32c(pred), _f32c(gt), _f32c(weights)
+        ctx.pred_dtype = pred.dtype       # bf16 rows of the prediction head under autocast: gradient returned in bf16
+        pred, gt, weights = _f32c(pred.float()), _f32c(gt), _f32c(weights)
         M, P1, _ = pred.shape
         P2 = gt.shape[1]
         term = torch.empty(max(M, 1), dtype=torch.float32, device=pred.device)
@@ -452,4 +453,8 @@ class ChamferLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         dpred, inv = ctx.saved_tensors
-        return dpred * (g * inv), None, None
+        if ctx.pred_dtype == torch.float32:
+            return dpred * (g * inv), None, None
+        out = torch.empty_like(dpred, dtype=ctx.pred_dtype)
+        torch.mul(dpred, g * inv, out=out)       # scale and cast in one pass
+        return out, None, None
