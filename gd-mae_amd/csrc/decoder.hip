@@ -241,6 +241,33 @@ static inline int dec_grid(long long total) {
   return (int)g;
 }
 
+// Z (R, C) = the row vector v (C elements, C * element size a multiple of 16 bytes) in every row: the background of the
+// dense decoder map (1.35 GB in bf16 for 8 frames; torch's expand().contiguous() copy runs at 4.6 TB/s).  Each lane
+// keeps ONE 16-byte piece of v and writes it at a fixed stride, so the kernel is nothing but 16-byte stores.
+__global__ __launch_bounds__(256) void k_fill_rows(const uint4* __restrict__ v, int vec_per_row, long long total_vecs,
+                                                   uint4* __restrict__ Z) {
+  // stride = a multiple of vec_per_row, so a thread always lands on the same piece of v
+  const long long stride = ((long long)gridDim.x * blockDim.x / vec_per_row) * vec_per_row;
+  const long long i0 = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i0 >= stride) return;
+  const uint4 q = v[i0 % vec_per_row];
+  for (long long i = i0; i < total_vecs; i += stride) Z[i] = q;
+}
+
+extern "C" int gdmae_fill_rows(const void* v, long long R, int C, int elem_bytes, void* Z, void* stream) {
+  if (R <= 0) return 0;
+  GD_REQUIRE(C > 0 && ((long long)C * elem_bytes) % 16 == 0, "fill_rows: row bytes must be a multiple of 16");
+  const int vpr = (int)((long long)C * elem_bytes / 16);
+  const long long total = R * vpr;
+  long long blocks = (total + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  if (blocks * 256 < vpr) blocks = (vpr + 255) / 256;
+  hipLaunchKernelGGL(k_fill_rows, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)v, vpr, total,
+                     (uint4*)Z);
+  GD_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int gdmae_rows_affine_relu_scatter(const void* P, int p_bf16, const int* site, long long n, int C, const float* a,
                                               const float* b, void* Z, int z_bf16, int z_row_elems, int col0, void* stream) {
   if (n <= 0) return 0;

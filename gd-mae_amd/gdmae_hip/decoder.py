@@ -128,7 +128,8 @@ class DecoderHead(torch.autograd.Function):
             ab_l.append(ab), stats_l.append(stats)
             mv_out += [mv[:widths[i]], mv[widths[i]:]]
         bgz = torch.relu(torch.cat([ab[w:] for ab, w in zip(ab_l, widths)])).to(cdt)   # value of every non-active site
-        Z = bgz.expand(R, sum(widths)).contiguous()
+        Z = torch.empty(R, sum(widths), dtype=cdt, device=dev)
+        L.call("gdmae_fill_rows", L.ptr(bgz), R, Z.shape[1], Z.element_size(), L.ptr(Z), L.stream())
         col = 0
         for i in range(k):
             w = widths[i]

@@ -181,6 +181,9 @@ int gdmae_colstats(const void* x, long long R, int C, int is_bf16, double* out, 
  *   gdmae_rows_affine_relu_scatter: Z[site[r], col0:col0+C] = relu(a*P[r]+b)   (Z rows of z_row_elems elements)
  *   gdmae_rows_bwd_stats: out double[3C] = column sums of {dh, dh*P, g},  g = dZ[site[r], slice], dh = g*(aP+b>0)
  *   gdmae_rows_bwd: dP[r] = a*dh + c0 + c1*P[r] */
+/* Z (R, C) = row vector v in every row (C * elem_bytes a multiple of 16): background of the dense decoder map
+ * (replaces bg.expand(R, C).contiguous(), spt_backbone_mae.py:125-133 densify of the non-active sites). */
+int gdmae_fill_rows(const void* v, long long R, int C, int elem_bytes, void* Z, void* stream);
 int gdmae_rows_affine_relu_scatter(const void* P, int p_bf16, const int* site, long long n, int C, const float* a,
                                    const float* b, void* Z, int z_bf16, int z_row_elems, int col0, void* stream);
 size_t gdmae_rows_bwd_stats_workspace_bytes(int C);
