@@ -32,6 +32,7 @@ import torch.nn.functional as F
 from . import bn as gbn
 from . import lib as L
 from . import ops
+from . import plan as gplan
 
 BN_EPS, BN_MOM = 1e-3, 0.01
 
@@ -233,18 +234,14 @@ class DecoderHead(torch.autograd.Function):
 
 
 def upsampled_sites(stage_plan, s: int, Y: int, X: int) -> torch.Tensor:
-    """(n_tok * s*s,) int32 full-resolution cell of every (token, dy, dx) of a stride-s stage."""
-    c = stage_plan.tok_cell
+    """(n_tok * s*s,) int32 full-resolution cell of every (token, dy, dx) of a stride-s stage (prepared with the geometry
+    plan when the stage's stride matches)."""
     if s == 1:
-        return c
-    x = c % stage_plan.X
-    r = torch.div(c, stage_plan.X, rounding_mode='floor')
-    y = r % stage_plan.Y
-    b = torch.div(r, stage_plan.Y, rounding_mode='floor')
-    d = torch.arange(s, device=c.device, dtype=c.dtype)
-    yy = (y * s).view(-1, 1, 1) + d.view(1, s, 1)
-    xx = (x * s).view(-1, 1, 1) + d.view(1, 1, s)
-    return ((b.view(-1, 1, 1) * Y + yy) * X + xx).reshape(-1).contiguous()
+        return stage_plan.tok_cell
+    pre = getattr(stage_plan, "_up_sites", None)
+    if pre is not None and pre[0] == s and stage_plan.Y * s == Y and stage_plan.X * s == X:
+        return pre[1]
+    return gplan.upsample_cells(stage_plan.tok_cell, stage_plan.Y, stage_plan.X, s).reshape(-1).contiguous()
 
 
 def sparse_decoder(model_cfg, deblocks, conv_out, hidden, pillar_cell, cell2pillar, B, Y, X, want_dense=False):

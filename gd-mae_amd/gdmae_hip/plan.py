@@ -140,6 +140,18 @@ class EncoderPlan:
     stages: List[StagePlan]
 
 
+def upsample_cells(c: torch.Tensor, Ys: int, Xs: int, s: int) -> torch.Tensor:
+    """(len(c), s*s) int32 full-resolution cells ((b*Y + y)*X + x, Y = Ys*s, X = Xs*s) covered by the stride-s cells c."""
+    x = c % Xs
+    r = torch.div(c, Xs, rounding_mode='floor')
+    y = r % Ys
+    b = torch.div(r, Ys, rounding_mode='floor')
+    d = torch.arange(s, device=c.device, dtype=c.dtype)
+    yy = (y * s).view(-1, 1, 1) + d.view(1, s, 1)
+    xx = (x * s).view(-1, 1, 1) + d.view(1, 1, s)
+    return ((b.view(-1, 1, 1) * (Ys * s) + yy) * (Xs * s) + xx).reshape(c.numel(), s * s)
+
+
 def _drop_arrays(drop_info):
     d = {int(k): v for k, v in drop_info.items()}
     keys = sorted(d)
@@ -232,8 +244,14 @@ def _encoder_launch(vox, m_cap: int, strides, window_shapes, drop_infos, keep_fr
                    L.ptr(w["counts"]), L.ptr(ws), wsb, st)
             w["_ws"] = ws
             wins.append(w)
+        # transposed rulebook of the submanifold conv = tap-reversed rulebook (built here, with the plan, so that it is
+        # off the training stream's critical path)
+        nbr_subm_t = torch.flip(nbr_subm.view(cap, 9), dims=[1]).contiguous().view(-1)
+        # full-resolution sites under every token (the decoder's ConvTranspose2d(k = s, stride = s) scatters there)
+        up_s = gy // Y
+        up_sites = upsample_cells(tok_cell, Y, X, up_s) if (up_s > 1 and up_s * Y == gy and up_s * X == gx) else None
         raw.append(dict(B=B, Y=Y, X=X, cap=cap, tok_cell=tok_cell, map=smap, n_tok=n_tok, nbr_subm=nbr_subm,
-                        nbr_down=nbr_down, nbr_down_t=nbr_down_t, wins=wins))
+                        nbr_subm_t=nbr_subm_t, up_s=up_s, up_sites=up_sites, nbr_down=nbr_down, nbr_down_t=nbr_down_t, wins=wins))
     counts = torch.cat([r["n_tok"] for r in raw] + [w["counts"] for r in raw for w in r["wins"]])
     return dict(stages=raw, mask=mask, tok_pillar=tok_pillar, masked=keep_frac is not None, counts=counts,
                 keep=(noise, scan_ws))
@@ -259,6 +277,8 @@ def _encoder_finalize(e: dict, allc, M: int) -> EncoderPlan:
                                 None if r["nbr_down"] is None else r["nbr_down"][:n * 9].view(n, 9),
                                 None if r["nbr_down_t"] is None else r["nbr_down_t"][:n_prev * 9].view(n_prev, 9),
                                 wps))
+        stages[-1]._nbr_subm_t = r["nbr_subm_t"][:n * 9].view(n, 9)
+        stages[-1]._up_sites = None if r["up_sites"] is None else (r["up_s"], r["up_sites"][:n].reshape(-1))
     return EncoderPlan(e["mask"][:M] if e["masked"] else None, e["tok_pillar"][:stages[0].n_tok], stages)
 
 
