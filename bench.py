@@ -186,17 +186,23 @@ def main():
         opt.zero_grad()
         bd = {"points": pts, "batch_size": B}
         if args.prefetch:
-            pf = pending.pop(id(pts), None) or net.backbone_3d.prefetch_plan(pts, B)
-            bd["_gdmae_vox"], bd["_gdmae_plan"] = pf.finish()
+            plan = pending.pop(id(pts), None) or net.backbone_3d.prefetch_plan(pts, B).finish()
+            bd["_gdmae_vox"], bd["_gdmae_plan"] = plan
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=use_bf16):
             ret, tb, _ = net(bd)
         ret["loss"].backward()
+        pf = None
         if args.prefetch and nxt is not None:
             # geometry plan of the NEXT batch: issued while the GPU is still busy with this backward (the host is ahead
             # here), on a side stream that only waits for that batch's points to be resident
-            pending[id(nxt)] = net.backbone_3d.prefetch_plan(nxt, B, ready=nxt_ready)
+            pf = net.backbone_3d.prefetch_plan(nxt, B, ready=nxt_ready)
         opt.all_reduce_grads()
         opt.step(i)
+        if pf is not None:
+            # ... and collected here, still behind the queued backward / optimizer kernels: the host-side part of the plan
+            # (counts to Python ints, ~300 tensor views) is off the next step's critical path, like a data-loader batch
+            # that is ready before it is asked for
+            pending[id(nxt)] = pf.finish()
         return ret["loss"], bd
 
     def sync_all():
