@@ -43,15 +43,68 @@ __global__ __launch_bounds__(256) void k_zero_regions(ZeroJobs z) {
       ((uint4*)z.p[j])[i] = zero;
 }
 
+// dst[j][i] += src[j][i]  (nblk == 0)   or   dst[j][i] += sum_b src[j][b * stride + i]  (nblk partial rows, e.g. the
+// per-workgroup dgamma / dbeta / column-sum partials of the LayerNorm backward).  One wavefront per element: lanes stride
+// over the partial rows, fixed-order wave reduction - the association order of k_reduce_partials_f32.
 struct AccJobs {
   float* dst[8];
   const float* src[8];
-  int len[8];
+  int len[8], nblk[8], stride[8];
   int count;
 };
 __global__ __launch_bounds__(256) void k_acc_vectors(AccJobs a) {
-  for (int j = 0; j < a.count; ++j)
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.len[j]; i += gridDim.x * blockDim.x) a.dst[j][i] += a.src[j][i];
+  const int lane = threadIdx.x & 63;
+  int col = (blockIdx.x * 256 + threadIdx.x) >> 6;
+  int j = 0;
+  while (j < a.count && col >= a.len[j]) col -= a.len[j++];
+  if (j >= a.count) return;
+  float acc = 0.f;
+  if (a.nblk[j] == 0) {
+    if (lane == 0) acc = a.src[j][col];
+  } else {
+    for (int b = lane; b < a.nblk[j]; b += 64) acc += a.src[j][(long long)b * a.stride[j] + col];
+  }
+  acc = gd_wave_sum(acc);
+  if (lane == 0) a.dst[j][col] += acc;
+}
+
+// the split-K reduces of a layer's five weight gradients as ONE launch (blockIdx.y = job):
+// dst[i] += sum_{s < S} part[s * P + i], same slicing and association order as k_splitk_acc (gemm.hip)
+struct SplitkJobs {
+  const float* part[6];
+  float* dst[6];
+  int S[6];
+  long long P4[6];
+  int count;
+};
+__global__ __launch_bounds__(256) void k_splitk_acc_jobs(SplitkJobs J) {
+  __shared__ float4 sh[3][64];
+  const int job = blockIdx.y;
+  const long long P4 = J.P4[job];
+  const int S = J.S[job];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const long long i = blockIdx.x * 64ll + tx;
+  if (blockIdx.x * 64ll >= P4) return;                 // uniform per workgroup
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < P4) {
+    const int s0 = (S * ty) / 4, s1 = (S * (ty + 1)) / 4;
+    const float4* p = (const float4*)J.part[job] + i;
+#pragma unroll 4
+    for (int s = s0; s < s1; ++s) {
+      const float4 v = p[(long long)s * P4];
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+  }
+  if (ty > 0) sh[ty - 1][tx] = acc;
+  __syncthreads();
+  if (ty == 0 && i < P4) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { const float4 v = sh[k][tx]; acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+    float4* d = (float4*)J.dst[job] + i;
+    const float4 o = *d;
+    acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+    *d = acc;
+  }
 }
 
 // exact (erf) GELU, 8 elements per thread
@@ -223,6 +276,26 @@ int linear_dw(const Ctx& c, const void* G, const void* X, float* dW, long long n
   GD_TRY(gd_splitk_acc(c.st, part, S, (long long)m * k, dW, 1));
   return 0;
 }
+// the same with the reduce deferred: the partial products go to their own region and the job is appended to J
+int linear_dw_deferred(const Ctx& c, const void* G, const void* X, float* dW, long long n_pad, int m, int k, float* part,
+                       SplitkJobs& J) {
+  const int S = splitk_for(n_pad, m, k);
+  const long long kc = n_pad / S;
+  GD_TRY(gd_gemm(c.st, false, true, k, m, (int)kc, X, k, G, m, part, k, c.ty, HIP_R_32F, nullptr, S, kc * k, kc * m, (long long)m * k,
+                 c.lt_ws, kLtWorkspace));
+  GD_REQUIRE(J.count < 6 && ((long long)m * k) % 4 == 0, "splitk jobs");
+  J.part[J.count] = part; J.dst[J.count] = dW; J.S[J.count] = S; J.P4[J.count] = (long long)m * k / 4;
+  ++J.count;
+  return 0;
+}
+int splitk_acc_jobs(const Ctx& c, const SplitkJobs& J) {
+  long long mx = 0;
+  for (int j = 0; j < J.count; ++j) mx = J.P4[j] > mx ? J.P4[j] : mx;
+  if (J.count == 0 || mx == 0) return 0;
+  hipLaunchKernelGGL(k_splitk_acc_jobs, dim3((unsigned)((mx + 63) / 64), J.count), dim3(256), 0, c.st, J);
+  GD_LAUNCH_CHECK();
+  return 0;
+}
 constexpr int kColsumBlocks = 128;
 int colsum_jobs(const Ctx& c, ColsumJobs& J, long long n, int cmax, float* part) {
   size_t lds = 0;
@@ -290,7 +363,7 @@ Saved saved_layout(void* base, long long n_pad, int d, int ff, int es) {
 }
 struct Scratch {
   char *lt_ws, *dx1_res, *dfb, *s2, *dg, *dh, *dx1_b, *dx_res, *dab, *s1, *d_o, *dqk, *dv, *apart, *dtau, *dx_qk, *dx_v, *part, *ln_ws,
-      *cs_part;
+      *cs_part, *part_w[5], *ln_ws2;
   size_t bytes;
 };
 Scratch scratch_layout(void* base, long long n_pad, int d, int ff, int es, int nhead) {
@@ -310,6 +383,12 @@ Scratch scratch_layout(void* base, long long n_pad, int d, int ff, int es, int n
   if ((size_t)2 * d * d > mk) mk = (size_t)2 * d * d;
   s.part = take((size_t)256 * mk * 4);      // S * m * k <= 1024 tiles * 128 * 128 ... bounded by 256 * m * k
   s.ln_ws = take(gdmae_add_layernorm_workspace_bytes(d));
+  s.ln_ws2 = take(gdmae_add_layernorm_workspace_bytes(d));
+  {   // one split-K partial region per weight gradient of the backward (reduced together at the end of the layer)
+    const int mk5[5][2] = {{d, ff}, {ff, d}, {d, d}, {2 * d, d}, {d, d}};
+    for (int i = 0; i < 5; ++i)
+      s.part_w[i] = take((size_t)splitk_for(n_pad, mk5[i][0], mk5[i][1]) * mk5[i][0] * mk5[i][1] * sizeof(float));
+  }
   {
     const int cm = ff > 2 * d ? ff : 2 * d;
     s.cs_part = take((size_t)3 * kColsumBlocks * cm * sizeof(float));
@@ -327,6 +406,7 @@ int gd_add_layernorm_fwd_ex(const float* a, const void* b, int b_is_bf16, const 
 int gd_add_layernorm_bwd_ex(const float* a, const void* b, int b_is_bf16, const float* gamma, const float* stats, const float* dy,
                             const void* dy2, int dy2_bf16, const void* dy3, int dy3_bf16, long long n, int d, float* dx,
                             void* dx_bf16, float* sums, void* workspace, hipStream_t st);
+int gd_ln_partial_rows(long long n, int d);
 
 extern "C" int gdmae_encoder_layer_bytes(long long n, int d, int ff, int nhead, int bf16, size_t* saved_bytes,
                                          size_t* fwd_scratch_bytes, size_t* bwd_scratch_bytes) {
@@ -428,19 +508,21 @@ static int layer_bwd(const gdmae_layer_args* a, bool upstream3, bool defer_add3,
   // ---- LN2 and FFN
   if (upstream3)   // dx_res / dx_qk / dx_v of the next layer are consumed here, before anything overwrites them
     GD_TRY(gd_add_layernorm_bwd_ex((const float*)s.x1, s.f, a->bf16, a->g2, (const float*)s.st2, (const float*)w.dx_res, w.dx_qk, a->bf16,
-                                   w.dx_v, a->bf16, n, d, (float*)w.dx1_res, a->bf16 ? w.dfb : nullptr, (float*)w.s2, w.ln_ws, c.st));
+                                   w.dx_v, a->bf16, n, d, (float*)w.dx1_res, a->bf16 ? w.dfb : nullptr, nullptr, w.ln_ws2, c.st));
   else
-    GD_TRY(gdmae_add_layernorm_bwd((const float*)s.x1, s.f, a->bf16, a->g2, (const float*)s.st2, a->dy, nullptr, 0, n, d,
-                                   (float*)w.dx1_res, a->bf16 ? w.dfb : nullptr, (float*)w.s2, w.ln_ws, stream));
-  GD_TRY(linear_dw(c, w.dfb, s.gact, a->dW2, n_pad, d, ff, (float*)w.part));
+    GD_TRY(gd_add_layernorm_bwd_ex((const float*)s.x1, s.f, a->bf16, a->g2, (const float*)s.st2, a->dy, nullptr, 0, nullptr, 0, n, d,
+                                   (float*)w.dx1_res, a->bf16 ? w.dfb : nullptr, nullptr, w.ln_ws2, c.st));
+  SplitkJobs SJ;
+  SJ.count = 0;
+  GD_TRY(linear_dw_deferred(c, w.dfb, s.gact, a->dW2, n_pad, d, ff, (float*)w.part_w[0], SJ));
   GD_TRY(linear_dx(c, w.dfb, a->W2, w.dg, n_pad, d, ff));
   GD_TRY(gelu(c, false, w.dg, s.h, w.dh, n_pad * ff));
-  GD_TRY(linear_dw(c, w.dh, s.x1b, a->dW1, n_pad, ff, d, (float*)w.part));
+  GD_TRY(linear_dw_deferred(c, w.dh, s.x1b, a->dW1, n_pad, ff, d, (float*)w.part_w[1], SJ));
   GD_TRY(linear_dx(c, w.dh, a->W1, w.dx1_b, n_pad, ff, d));
   // ---- LN1 (gradient = residual branch + FFN branch) and out-projection
-  GD_TRY(gdmae_add_layernorm_bwd(a->x, s.a, a->bf16, a->g1, (const float*)s.st1, (const float*)w.dx1_res, w.dx1_b, a->bf16, n, d,
-                                 (float*)w.dx_res, a->bf16 ? w.dab : nullptr, (float*)w.s1, w.ln_ws, stream));
-  GD_TRY(linear_dw(c, w.dab, s.o, a->dWo, n_pad, d, d, (float*)w.part));
+  GD_TRY(gd_add_layernorm_bwd_ex(a->x, s.a, a->bf16, a->g1, (const float*)s.st1, (const float*)w.dx1_res, w.dx1_b, a->bf16, nullptr, 0,
+                                 n, d, (float*)w.dx_res, a->bf16 ? w.dab : nullptr, nullptr, w.ln_ws, c.st));
+  GD_TRY(linear_dw_deferred(c, w.dab, s.o, a->dWo, n_pad, d, d, (float*)w.part_w[2], SJ));
   GD_TRY(linear_dx(c, w.dab, a->Wo, w.d_o, n_pad, d, d));
   // ---- attention
   int base = 0;
@@ -455,8 +537,9 @@ static int layer_bwd(const gdmae_layer_args* a, bool upstream3, bool defer_add3,
   }
   GD_TRY(gdmae_sum_partials_gated((const float*)w.apart, pbase, 1.f, (float*)w.dtau, a->tau, a->tau_min, stream));
   const char* Win = (const char*)a->Win;
-  GD_TRY(linear_dw(c, w.dqk, s.xpb, a->dWin, n_pad, 2 * d, d, (float*)w.part));
-  GD_TRY(linear_dw(c, w.dv, s.xb, a->dWin + (size_t)2 * d * d, n_pad, d, d, (float*)w.part));
+  GD_TRY(linear_dw_deferred(c, w.dqk, s.xpb, a->dWin, n_pad, 2 * d, d, (float*)w.part_w[3], SJ));
+  GD_TRY(linear_dw_deferred(c, w.dv, s.xb, a->dWin + (size_t)2 * d * d, n_pad, d, d, (float*)w.part_w[4], SJ));
+  GD_TRY(splitk_acc_jobs(c, SJ));                      // the five split-K reduces of the layer as one launch
   {
     ColsumJobs J;
     J.count = 3;
@@ -469,14 +552,20 @@ static int layer_bwd(const gdmae_layer_args* a, bool upstream3, bool defer_add3,
   GD_TRY(linear_dx(c, w.dv, Win + (size_t)2 * d * d * es, w.dx_v, n_pad, d, d));
   if (!defer_add3) GD_TRY(gdmae_add3((const float*)w.dx_res, w.dx_qk, a->bf16, w.dx_v, a->bf16, n * d, a->dx, stream));
   // ---- LayerNorm / bias / temperature gradients
+  // the LayerNorm backward partials (workgroup rows x {dgamma, dbeta, column sums of dx}) are reduced here, together with dtau
   AccJobs j;
-  const float* s1 = (const float*)w.s1;
-  const float* s2 = (const float*)w.s2;
+  const int nb = gd_ln_partial_rows(n, d);
+  const float* p1 = (const float*)w.ln_ws;    // LayerNorm 1: dg1, dbe1, bias gradient of the out-projection
+  const float* p2 = (const float*)w.ln_ws2;   // LayerNorm 2: dg2, dbe2, bias gradient of the second FFN linear
   float* dst[7] = {a->dg1, a->dbe1, a->dbo, a->dg2, a->dbe2, a->db2, a->dtau};
-  const float* src[7] = {s1, s1 + d, s1 + 2 * d, s2, s2 + d, s2 + 2 * d, (const float*)w.dtau};
-  for (int i = 0; i < 7; ++i) { j.dst[i] = dst[i]; j.src[i] = src[i]; j.len[i] = i < 6 ? d : 1; }
+  const float* src[7] = {p1, p1 + d, p1 + 2 * d, p2, p2 + d, p2 + 2 * d, (const float*)w.dtau};
+  int cols = 0;
+  for (int i = 0; i < 7; ++i) {
+    j.dst[i] = dst[i]; j.src[i] = src[i]; j.len[i] = i < 6 ? d : 1; j.nblk[i] = i < 6 ? nb : 0; j.stride[i] = 3 * d;
+    cols += j.len[i];
+  }
   j.count = 7;
-  hipLaunchKernelGGL(k_acc_vectors, dim3((d + 255) / 256), dim3(256), 0, c.st, j);
+  hipLaunchKernelGGL(k_acc_vectors, dim3((cols + 3) / 4), dim3(256), 0, c.st, j);
   GD_LAUNCH_CHECK();
   return 0;
 }

@@ -233,10 +233,13 @@ int gd_add_layernorm_bwd_ex(const float* a, const void* b, int b_is_bf16, const 
   else GD_REQUIRE(false, "add_layernorm supports d in {64, 128, 256}");
 #undef GD_LN_BWD
   GD_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_reduce_partials_f32, dim3(gd_div_up(3 * d, 4)), dim3(256), 0, st, part, nblk, 3 * d, sums);
-  GD_LAUNCH_CHECK();
+  if (sums) {   // sums == NULL: the caller reduces the (gd_ln_partial_rows(n, d), 3, d) partials in `workspace` itself
+    hipLaunchKernelGGL(k_reduce_partials_f32, dim3(gd_div_up(3 * d, 4)), dim3(256), 0, st, part, nblk, 3 * d, sums);
+    GD_LAUNCH_CHECK();
+  }
   return 0;
 }
+int gd_ln_partial_rows(long long n, int d) { return ln_grid(n, d); }
 extern "C" int gdmae_add_layernorm_bwd(const float* a, const void* b, int b_is_bf16, const float* gamma, const float* stats,
                                        const float* dy, const void* dy2, int dy2_bf16, long long n, int d, float* dx,
                                        void* dx_bf16, float* sums, void* workspace, void* stream) {
