@@ -158,6 +158,7 @@ class DecoderHead(torch.autograd.Function):
         ctx.direct_w = ops.direct_grad(conv_w)
         mean2, var2 = mv2[:C2], mv2[C2:]
         ctx.mark_non_differentiable(y2, mean2, var2, *mv_out)
+        ctx.set_materialize_grads(False)      # no zero tensors for the unused gradients of those outputs
         return (out, y2, mean2, var2, *mv_out)
 
     @staticmethod

@@ -38,10 +38,13 @@ class BNReLURows(torch.autograd.Function):
         ctx.direct = gbn.direct_pair(gamma, beta)
         mf, vf = mv[:C], mv[C:]
         ctx.mark_non_differentiable(mf, vf)
+        ctx.set_materialize_grads(False)      # no zero tensors for the unused gradients of those outputs
         return out, mf, vf
 
     @staticmethod
     def backward(ctx, g, _m, _v):
+        if g is None:
+            return None, None, None, None, None
         x, ab, stats, gamma = ctx.saved_tensors
         n, C = x.shape
         g = g.contiguous()
@@ -73,10 +76,13 @@ class BNReLUSegmentMax(torch.autograd.Function):
         ctx.direct = gbn.direct_pair(gamma, beta)
         mf, vf = mv[:C], mv[C:]
         ctx.mark_non_differentiable(mf, vf)
+        ctx.set_materialize_grads(False)      # no zero tensors for the unused gradients of those outputs
         return out, mf, vf
 
     @staticmethod
     def backward(ctx, g, _m, _v):
+        if g is None:
+            return (None,) * 8
         x, out, arg, inv, ab, stats, gamma = ctx.saved_tensors
         n, C = x.shape
         M = out.shape[0]
@@ -126,6 +132,7 @@ class PointLayer1(torch.autograd.Function):
         ctx.direct = (ops.direct_grad(weight), *gbn.direct_pair(gamma, beta))
         mf, vf = mv[:C], mv[C:]
         ctx.mark_non_differentiable(mf, vf)
+        ctx.set_materialize_grads(False)      # no zero tensors for the unused gradients of those outputs
         return out, mf, vf
 
     @staticmethod
@@ -140,6 +147,8 @@ class PointLayer1(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g, _m, _v):
+        if g is None:
+            return (None,) * 7
         weight, gamma, stats, ab = ctx.saved_tensors
         vox, C = ctx.vox, weight.shape[0]
         g = g.contiguous()
@@ -190,10 +199,13 @@ class PointLayer2Max(torch.autograd.Function):
         ctx.direct = (ops.direct_grad(weight), *gbn.direct_pair(gamma, beta))
         mf, vf = mv[:C], mv[C:]
         ctx.mark_non_differentiable(mf, vf)
+        ctx.set_materialize_grads(False)      # no zero tensors for the unused gradients of those outputs
         return out, mf, vf
 
     @staticmethod
     def backward(ctx, g, _m, _v):
+        if g is None:
+            return (None,) * 8
         y1, row_pillar, wb, gamma, stats, ab, out, arg = ctx.saved_tensors
         n, (M, C) = y1.shape[0], out.shape
         g = g.float().contiguous()
