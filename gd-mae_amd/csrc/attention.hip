@@ -388,14 +388,10 @@ __global__ __launch_bounds__(256) void k_win_attn_bwd(AttnBwdArgs A) {
   if (lane == 0) A.dtau_part[item] = dtau;
 }
 
-// deterministic sum of `n` partials into out[0] (single workgroup, fixed association order)
-// gate (optional): out is zeroed unless gate[0] >= gate_min (gradient of clamp(tau, min) w.r.t. tau)
-__global__ __launch_bounds__(1024) void k_sum_partials(const float* __restrict__ part, long long n, float scale,
-                                                       float* __restrict__ out, int accumulate,
-                                                       const float* __restrict__ gate, float gate_min) {
-  __shared__ float sh[1024 / GD_WAVE];
-  // four independent accumulators per lane, 8 loads in flight (a single dependent chain made this kernel
-  // latency-bound: 33 us for 127 k partials)
+// sum of `n` values over one 1024-thread workgroup, fixed association order (every thread returns the total)
+__device__ inline float gd_block1024_sum(const float* __restrict__ part, long long n, float* sh /* [16] */) {
+  // four independent accumulators per lane, 8 loads in flight (a single dependent chain made this latency-bound:
+  // 33 us for 127 k partials)
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   long long i = threadIdx.x;
 #pragma unroll 2
@@ -406,16 +402,47 @@ __global__ __launch_bounds__(1024) void k_sum_partials(const float* __restrict__
     a3 += part[i + 3072];
   }
   for (; i < n; i += 1024) a0 += part[i];
-  float acc = gd_wave_sum((a0 + a1) + (a2 + a3));
+  const float acc = gd_wave_sum((a0 + a1) + (a2 + a3));
+  __syncthreads();                       // sh may still be read from a previous call
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x / 64] = acc;
   __syncthreads();
+  float s = 0.f;
+  for (int k = 0; k < 1024 / GD_WAVE; ++k) s += sh[k];
+  return s;
+}
+
+// deterministic sum of `n` partials into out[0] (single workgroup, fixed association order)
+// gate (optional): out is zeroed unless gate[0] >= gate_min (gradient of clamp(tau, min) w.r.t. tau)
+__global__ __launch_bounds__(1024) void k_sum_partials(const float* __restrict__ part, long long n, float scale,
+                                                       float* __restrict__ out, int accumulate,
+                                                       const float* __restrict__ gate, float gate_min) {
+  __shared__ float sh[1024 / GD_WAVE];
+  float s = gd_block1024_sum(part, n, sh);
   if (threadIdx.x == 0) {
-    float s = 0.f;
-    for (int i = 0; i < 1024 / GD_WAVE; ++i) s += sh[i];
     s *= scale;
     if (gate && !(gate[0] >= gate_min)) s = 0.f;
     out[0] = accumulate ? out[0] + s : s;
   }
+}
+
+// weighted-mean finish of the Chamfer loss (pytorch3d point_reduction / batch_reduction "mean" with weights):
+// out = {sum(term) * inv, inv},  inv = 1 / sum(weights) (0 when no weight is positive)
+__global__ __launch_bounds__(1024) void k_weighted_mean_finish(const float* __restrict__ term, const float* __restrict__ weights,
+                                                               long long n, float* __restrict__ out) {
+  __shared__ float sh[1024 / GD_WAVE];
+  const float t = gd_block1024_sum(term, n, sh);
+  const float w = gd_block1024_sum(weights, n, sh);
+  if (threadIdx.x == 0) {
+    const float inv = w > 0.f ? 1.0f / fmaxf(w, 1e-30f) : 0.f;
+    out[0] = t * inv;
+    out[1] = inv;
+  }
+}
+
+extern "C" int gdmae_weighted_mean_finish(const float* term, const float* weights, long long n, float* out, void* stream) {
+  hipLaunchKernelGGL(k_weighted_mean_finish, dim3(1), dim3(1024), 0, (hipStream_t)stream, term, weights, n, out);
+  GD_LAUNCH_CHECK();
+  return 0;
 }
 
 extern "C" int gdmae_sum_partials(const float* part, long long n, float scale, float* out, int accumulate, void* stream) {

@@ -442,17 +442,15 @@ class ChamferLoss(torch.autograd.Function):
         term = torch.empty(max(M, 1), dtype=torch.float32, device=pred.device)
         dpred = torch.empty_like(pred)
         L.call("gdmae_chamfer", L.ptr(pred), L.ptr(gt), L.ptr(weights), M, P1, P2, L.ptr(term), L.ptr(dpred), L.stream())
-        sums = torch.zeros(2, dtype=torch.float32, device=pred.device)
-        if M > 0:
-            L.call("gdmae_sum_partials", L.ptr(term), M, 1.0, L.ptr(sums[0:1]), 0, L.stream())
-            L.call("gdmae_sum_partials", L.ptr(weights), M, 1.0, L.ptr(sums[1:2]), 0, L.stream())
-        inv = torch.where(sums[1] > 0, 1.0 / sums[1].clamp(min=1e-30), torch.zeros_like(sums[1]))
-        ctx.save_for_backward(dpred, inv)
-        return sums[0] * inv
+        res = torch.empty(2, dtype=torch.float32, device=pred.device)       # {loss, 1 / sum of weights}
+        L.call("gdmae_weighted_mean_finish", L.ptr(term), L.ptr(weights), M, L.ptr(res), L.stream())
+        ctx.save_for_backward(dpred, res)
+        return res[0]
 
     @staticmethod
     def backward(ctx, g):
-        dpred, inv = ctx.saved_tensors
+        dpred, res = ctx.saved_tensors
+        inv = res[1]
         if ctx.pred_dtype == torch.float32:
             return dpred * (g * inv), None, None
         out = torch.empty_like(dpred, dtype=ctx.pred_dtype)

@@ -255,6 +255,9 @@ int gdmae_window_attention_fwd(const void* qk, const void* v, void* out, int io_
 int gdmae_window_attention_bwd(const void* qk, const void* v, const void* dout, void* dqk, void* dv, int io_bf16,
                                float* dtau_part, const int* csr_tok, const int* win_start, const int* win_len,
                                int n_win, int T, int d, int H, const float* tau, float tau_min, void* stream);
+/* out[0] = sum(term) / sum(weights), out[1] = 1 / sum(weights) (both 0 when no weight is positive): the weighted mean
+ * that finishes pytorch3d.loss.chamfer_distance (spt_backbone_mae.py:83-89), one single-workgroup launch. */
+int gdmae_weighted_mean_finish(const float* term, const float* weights, long long n, float* out, void* stream);
 int gdmae_sum_partials(const float* part, long long n, float scale, float* out, int accumulate, void* stream);
 int gdmae_sum_partials_gated(const float* part, long long n, float scale, float* out, const float* gate, float gate_min,
                              void* stream); /* out = gate[0] >= gate_min ? scale*sum : 0 (clamp(tau) gradient) */
