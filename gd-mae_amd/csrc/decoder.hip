@@ -805,3 +805,89 @@ extern "C" int gdmae_border_sums(const void* Y, int y_bf16, const float* rows, c
   GD_LAUNCH_CHECK();
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Small algebra of the decoder-head backward (gdmae_hip/decoder.py) as three launches instead of ~20 torch ops:
+//   regD[r][o] = cnt[r] k0[o] + regY[r][o] k1[o] + regR[r][o]        (9 border regions of dY = k0 + k1 Y + rows)
+//                regY[0] = mean2 * R, regY[1..8] = reg[0..7];  regR[0] = a2 * st2[0:C2], regR[1..8] = reg[8..15]
+//   S[k][o]    = sum_r tap_region[k][r] regD[r][o]                   (sum of dY over the sites tap k can reach)
+//   W_k[o][i]  = conv_w[o][i][ky][kx], k = 3 ky + kx
+//   tot[i]     = sum_{k,o} S[k][o] W_k[o][i]        (column sums of dZ over ALL sites, fp64)
+//   dWk[k][o][i] = S[k][o] bg[i]                    (background part of the weight gradient, fp32)
+//   Wd[k][o][i]  = W_k[o][i] in the compute dtype   (B operand of the dZ-row GEMMs)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_dec_region_S(const double* __restrict__ stats2, const float* __restrict__ ab2,
+                                                      const double* __restrict__ st2, const float* __restrict__ k01,
+                                                      const double* __restrict__ reg, const double* __restrict__ tap_region,
+                                                      const double* __restrict__ cnt, double R, int C2, double* __restrict__ S) {
+  const int o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= C2) return;
+  const double k0 = (double)k01[o], k1 = (double)k01[C2 + o];
+  double regD[9];
+#pragma unroll
+  for (int r = 0; r < 9; ++r) {
+    const double y = r == 0 ? stats2[o] * R : reg[(r - 1) * C2 + o];
+    const double rr = r == 0 ? (double)ab2[o] * st2[o] : reg[(8 + r - 1) * C2 + o];
+    regD[r] = cnt[r] * k0 + y * k1 + rr;
+  }
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    double a = 0.0;
+#pragma unroll
+    for (int r = 0; r < 9; ++r) a += tap_region[k * 9 + r] * regD[r];
+    S[k * C2 + o] = a;
+  }
+}
+
+template <bool BF>
+__global__ __launch_bounds__(128) void k_dec_region_W(const double* __restrict__ S, const float* __restrict__ conv_w,
+                                                      const void* __restrict__ bgz, int C2, int Cin, float* __restrict__ dWk,
+                                                      void* __restrict__ Wd, double* __restrict__ tot_part) {
+  const int i = blockIdx.x * 128 + threadIdx.x, oc = blockIdx.y * 8;
+  if (i >= Cin) return;
+  const double bg = (double)dec_ld<BF>(bgz, i);
+  double acc = 0.0;
+  for (int oo = 0; oo < 8; ++oo) {
+    const int o = oc + oo;
+    const float* w = conv_w + ((long long)o * Cin + i) * 9;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const float wv = w[k];
+      const double s = S[k * C2 + o];
+      acc += s * (double)wv;
+      const long long e = ((long long)k * C2 + o) * Cin + i;
+      dWk[e] = (float)(s * bg);
+      dec_st<BF>(Wd, e, wv);
+    }
+  }
+  tot_part[(long long)blockIdx.y * Cin + i] = acc;
+}
+
+__global__ __launch_bounds__(256) void k_dec_region_tot(const double* __restrict__ tot_part, int nchunk, int Cin,
+                                                        double* __restrict__ tot) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Cin) return;
+  double a = 0.0;
+  for (int c = 0; c < nchunk; ++c) a += tot_part[(long long)c * Cin + i];
+  tot[i] = a;
+}
+
+extern "C" size_t gdmae_decoder_region_workspace_bytes(int C2, int Cin) { return (size_t)(C2 / 8 + 1) * Cin * sizeof(double); }
+
+extern "C" int gdmae_decoder_region_algebra(const double* stats2, const float* ab2, const double* st2, const float* k01,
+                                            const double* reg, const double* tap_region, const double* cnt, double R, int C2,
+                                            int Cin, const float* conv_w, const void* bgz, int cdt_bf16, double* S, double* tot,
+                                            float* dWk, void* Wd, void* workspace, void* stream) {
+  GD_REQUIRE(C2 > 0 && C2 % 8 == 0 && Cin > 0, "decoder region algebra: C2 must be a multiple of 8");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_dec_region_S, dim3(gd_div_up(C2, 256)), dim3(256), 0, st, stats2, ab2, st2, k01, reg, tap_region, cnt, R, C2, S);
+  GD_LAUNCH_CHECK();
+  const dim3 grid(gd_div_up(Cin, 128), C2 / 8);
+  double* part = (double*)workspace;
+  if (cdt_bf16) hipLaunchKernelGGL((k_dec_region_W<true>), grid, dim3(128), 0, st, (const double*)S, conv_w, bgz, C2, Cin, dWk, Wd, part);
+  else hipLaunchKernelGGL((k_dec_region_W<false>), grid, dim3(128), 0, st, (const double*)S, conv_w, bgz, C2, Cin, dWk, Wd, part);
+  GD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_dec_region_tot, dim3(gd_div_up(Cin, 256)), dim3(256), 0, st, (const double*)part, C2 / 8, Cin, tot);
+  GD_LAUNCH_CHECK();
+  return 0;
+}

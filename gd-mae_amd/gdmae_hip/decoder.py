@@ -184,22 +184,35 @@ class DecoderHead(torch.autograd.Function):
         rows = torch.empty(M, C2, dtype=torch.float32, device=dev)
         L.call("gdmae_rows_bwd", L.ptr(yrows), _bf(yrows), None, M, C2, L.ptr(ab2), L.ptr(ab2[C2:]), L.ptr(zero), L.ptr(zero[C2:]),
                L.ptr(dout), 0, C2, 0, L.ptr(rows), 0, L.stream())
-        k0, k1 = k01[:C2].double(), k01[C2:].double()
         # ---- region sums of dY (all / border rows / border columns / corners) -> S_k per tap
         reg = torch.empty(16, C2, dtype=f64, device=dev)
         ws = torch.empty(L.load().gdmae_border_sums_workspace_bytes(B, C2), dtype=torch.uint8, device=dev)
         L.call("gdmae_border_sums", L.ptr(y2), _bf(y2), L.ptr(rows), L.ptr(pillar_cell), M, B, H, W, C2, L.ptr(reg), L.ptr(ws),
                L.stream())
-        # region 0 = all sites: sum Y = mean * R;  sum rows = a * sum dh
-        regY = torch.cat([(stats2[:C2] * R)[None], reg[:8]])
-        regR = torch.cat([(ab2[:C2].double() * st2[:C2])[None], reg[8:]])
+        # region 0 = all sites: sum Y = mean * R, sum rows = a * sum dh; S = tap_region @ (cnt k0 + regY k1 + regR), the
+        # column sums of dZ over ALL sites, the background part of the weight gradient and the per-tap weight in the
+        # compute dtype: one call (three launches) instead of ~20 small torch ops
         tap_region, cnt = _region_consts(dev, B, H, W)
-        regD = cnt[:, None] * k0[None, :] + regY * k1[None, :] + regR
-        S = tap_region @ regD                                     # (9, C2)
-        Wk = conv_w.permute(2, 3, 0, 1).reshape(9, C2, Cin)              # W_k[o, i], k = (ky+1)*3 + (kx+1)
-        tot = torch.einsum('ko,koi->i', S, Wk.double()).contiguous()      # column sums of dZ over ALL sites
-        dWk = (S[:, :, None] * bgz.double()[None, None, :]).float()       # background part of the weight gradient
-        Wd = Wk.to(cdt)
+        use_native = conv_w.dtype == torch.float32 and conv_w.is_contiguous() and C2 % 8 == 0
+        if use_native:
+            S = torch.empty(9, C2, dtype=f64, device=dev)
+            tot = torch.empty(Cin, dtype=f64, device=dev)
+            dWk = torch.empty(9, C2, Cin, dtype=torch.float32, device=dev)
+            Wd = torch.empty(9, C2, Cin, dtype=cdt, device=dev)
+            ws = torch.empty(L.load().gdmae_decoder_region_workspace_bytes(C2, Cin), dtype=torch.uint8, device=dev)
+            L.call("gdmae_decoder_region_algebra", L.ptr(stats2), L.ptr(ab2), L.ptr(st2), L.ptr(k01), L.ptr(reg),
+                   L.ptr(tap_region), L.ptr(cnt), float(R), C2, Cin, L.ptr(conv_w), L.ptr(bgz), _bf(Wd), L.ptr(S), L.ptr(tot),
+                   L.ptr(dWk), L.ptr(Wd), L.ptr(ws), L.stream())
+        else:
+            k0, k1 = k01[:C2].double(), k01[C2:].double()
+            regY = torch.cat([(stats2[:C2] * R)[None], reg[:8]])
+            regR = torch.cat([(ab2[:C2].double() * st2[:C2])[None], reg[8:]])
+            regD = cnt[:, None] * k0[None, :] + regY * k1[None, :] + regR
+            S = tap_region @ regD                                     # (9, C2)
+            Wk = conv_w.permute(2, 3, 0, 1).reshape(9, C2, Cin)              # W_k[o, i], k = (ky+1)*3 + (kx+1)
+            tot = torch.einsum('ko,koi->i', S, Wk.double()).contiguous()      # column sums of dZ over ALL sites
+            dWk = (S[:, :, None] * bgz.double()[None, None, :]).float()       # background part of the weight gradient
+            Wd = Wk.to(cdt)
         grads = [None] * 7
         dW_rows = []
         col = 0

@@ -181,6 +181,16 @@ int gdmae_colstats(const void* x, long long R, int C, int is_bf16, double* out, 
  *   gdmae_rows_affine_relu_scatter: Z[site[r], col0:col0+C] = relu(a*P[r]+b)   (Z rows of z_row_elems elements)
  *   gdmae_rows_bwd_stats: out double[3C] = column sums of {dh, dh*P, g},  g = dZ[site[r], slice], dh = g*(aP+b>0)
  *   gdmae_rows_bwd: dP[r] = a*dh + c0 + c1*P[r] */
+/* Small algebra of the decoder-head backward (hand-derived backward of conv_out + BatchNorm2d, spt_backbone_mae.py:46-52):
+ * from the 9 border-region sums of dY it produces S (9, C2) f64 = sum of dY each tap can reach, tot (Cin) f64 = column
+ * sums of dZ over all sites, dWk (9, C2, Cin) fp32 = background part of the weight gradient, Wd (9, C2, Cin) = the conv
+ * weight (C2, Cin, 3, 3) re-laid per tap in the compute dtype.  reg (16, C2) from gdmae_border_sums; tap_region (9, 9) and
+ * cnt (9) f64 constants of the map geometry; R = number of sites. */
+size_t gdmae_decoder_region_workspace_bytes(int C2, int Cin);
+int gdmae_decoder_region_algebra(const double* stats2, const float* ab2, const double* st2, const float* k01,
+                                 const double* reg, const double* tap_region, const double* cnt, double R, int C2, int Cin,
+                                 const float* conv_w, const void* bgz, int cdt_bf16, double* S, double* tot, float* dWk,
+                                 void* Wd, void* workspace, void* stream);
 /* Z (R, C) = row vector v in every row (C * elem_bytes a multiple of 16): background of the dense decoder map
  * (replaces bg.expand(R, C).contiguous(), spt_backbone_mae.py:125-133 densify of the non-active sites). */
 int gdmae_fill_rows(const void* v, long long R, int C, int elem_bytes, void* Z, void* stream);
