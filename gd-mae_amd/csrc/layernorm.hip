@@ -184,10 +184,10 @@ __global__ __launch_bounds__(256) void k_reduce_partials_f32(const float* __rest
   if (ps == 0 && c < C2) out[c] = acc;
 }
 
-static inline int ln_grid(long long n, int d) {
+static inline int ln_grid(long long n, int d, int cap = 1024) {
   const int rpb = 4 * (64 / (d / 4));            // rows per workgroup pass
   long long g = (n + rpb - 1) / rpb;
-  if (g > 1024) g = 1024;
+  if (g > cap) g = cap;                          // backward: one row of partials per workgroup (workspace = 1024 rows)
   if (g < 1) g = 1;
   return (int)g;
 }
@@ -200,7 +200,7 @@ int gd_add_layernorm_fwd_ex(const float* a, const void* b, int b_is_bf16, const 
                             float eps, float* y, float* stats, void* y_bf16, const float* pos_table, const int* tok_pos,
                             void* ypos_bf16, hipStream_t st) {
   if (n <= 0) return 0;
-  const dim3 grid(ln_grid(n, d)), block(256);
+  const dim3 grid(ln_grid(n, d, 4096)), block(256);   // no partials in the forward; per call: 512 blocks 23.9 us, 1024: 17.6 us, 4096: 17.2 us
 #define GD_LN_FWD(V, BF) hipLaunchKernelGGL((k_add_ln_fwd<V, BF>), grid, block, 0, st, a, b, gamma, beta, n, eps, y, stats, (unsigned short*)y_bf16, pos_table, tok_pos, (unsigned short*)ypos_bf16)
   if (d == 64) { if (b_is_bf16) GD_LN_FWD(64, true); else GD_LN_FWD(64, false); }
   else if (d == 128) { if (b_is_bf16) GD_LN_FWD(128, true); else GD_LN_FWD(128, false); }
