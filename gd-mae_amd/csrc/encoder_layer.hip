@@ -44,8 +44,7 @@ __global__ __launch_bounds__(256) void k_zero_regions(ZeroJobs z) {
 }
 
 // dst[j][i] += src[j][i]  (nblk == 0)   or   dst[j][i] += sum_b src[j][b * stride + i]  (nblk partial rows, e.g. the
-// per-workgroup dgamma / dbeta / column-sum partials of the LayerNorm backward).  One wavefront per element: lanes stride
-// over the partial rows, fixed-order wave reduction - the association order of k_reduce_partials_f32.
+// per-workgroup dgamma / dbeta / column-sum partials of the LayerNorm backward), fixed association order.
 struct AccJobs {
   float* dst[8];
   const float* src[8];
@@ -53,19 +52,32 @@ struct AccJobs {
   int count;
 };
 __global__ __launch_bounds__(256) void k_acc_vectors(AccJobs a) {
-  const int lane = threadIdx.x & 63;
-  int col = (blockIdx.x * 256 + threadIdx.x) >> 6;
+  // 16 consecutive elements x 16 slices of the partial rows per workgroup (64-byte row segments, 8 loads in flight per
+  // thread), the slices meet in LDS in a fixed order
+  __shared__ float sh[16][17];
+  const int cl = threadIdx.x & 15, ps = threadIdx.x >> 4;
+  int col = blockIdx.x * 16 + cl;
   int j = 0;
   while (j < a.count && col >= a.len[j]) col -= a.len[j++];
-  if (j >= a.count) return;
   float acc = 0.f;
-  if (a.nblk[j] == 0) {
-    if (lane == 0) acc = a.src[j][col];
-  } else {
-    for (int b = lane; b < a.nblk[j]; b += 64) acc += a.src[j][(long long)b * a.stride[j] + col];
+  if (j < a.count) {
+    if (a.nblk[j] == 0) {
+      if (ps == 0) acc = a.src[j][col];
+    } else {
+      const float* p = a.src[j] + col;
+      const long long st = a.stride[j];
+#pragma unroll 8
+      for (int b = ps; b < a.nblk[j]; b += 16) acc += p[b * st];
+    }
   }
-  acc = gd_wave_sum(acc);
-  if (lane == 0) a.dst[j][col] += acc;
+  sh[ps][cl] = acc;
+  __syncthreads();
+  if (ps == 0 && j < a.count) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += sh[k][cl];
+    a.dst[j][col] += s;
+  }
 }
 
 // the split-K reduces of a layer's five weight gradients as ONE launch (blockIdx.y = job):
@@ -565,7 +577,7 @@ static int layer_bwd(const gdmae_layer_args* a, bool upstream3, bool defer_add3,
     cols += j.len[i];
   }
   j.count = 7;
-  hipLaunchKernelGGL(k_acc_vectors, dim3((cols + 3) / 4), dim3(256), 0, c.st, j);
+  hipLaunchKernelGGL(k_acc_vectors, dim3((cols + 15) / 16), dim3(256), 0, c.st, j);
   GD_LAUNCH_CHECK();
   return 0;
 }
