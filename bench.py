@@ -148,12 +148,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    local = local % torch.cuda.device_count()      # several ranks may share a GPU in the 2-rank smoke run (gloo backend)
     torch.cuda.set_device(local)
     torch.backends.cudnn.benchmark = bool(args.miopen_find)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)   # nccl == RCCL on ROCm
+        # nccl == RCCL on ROCm; GDMAE_DIST_BACKEND=gloo only for the control-flow smoke run of two ranks on one GPU
+        dist.init_process_group(os.environ.get("GDMAE_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
 
     from gdmae_hip import configs, optim, synth
@@ -239,6 +241,8 @@ def main():
                       "frames_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
                       "params": n_params, "mask_ratio": args.mask_ratio, "loss_last": round(final_loss, 5)}}
 
+    # the roofline steps run on EVERY rank: they contain the gradient all-reduce, a collective the other ranks must join
+    roofline = measure_roofline(step, dev_batches, args) if not args.no_roofline else None
     if rank == 0:
         # ---- sizes of the last batch (for the algorithmic byte model)
         vox, ep = bd["_gdmae_vox"], bd["_gdmae_plan"]
@@ -252,8 +256,8 @@ def main():
         out["step_bytes_model"] = {"bytes_train_per_frame": int(bytes_train), "achieved_GBs": round(bytes_train * fps / world / 1e9, 1),
                                    "frac_of_8TBs": round(bytes_train * fps / world / 1e9 / HBM_PEAK_GBS, 4),
                                    "note": "SURVEY §8d whole-step algorithmic bytes x frames/s per GPU"}
-        if not args.no_roofline:
-            out["roofline"] = measure_roofline(step, dev_batches, args)
+        if roofline is not None:
+            out["roofline"] = roofline
         # ---- PCIe-inclusive variant (host buffers handed over every step); never the headline value
         sync_all_local = torch.cuda.synchronize
         sync_all_local()
@@ -270,7 +274,7 @@ def main():
                 step(args.warmup + args.steps, cur, nxt, ev)
             sync_all_local()
             out["h2d_inclusive"] = {"value": round(B * k / (time.perf_counter() - t1), 2), "unit": "frames/s"}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (rank 0's host cores)
             out["cpu_baseline"] = measure_cpu_baseline(args.config, args.mask_ratio)
         print(json.dumps(out), flush=True)
     if world > 1:
