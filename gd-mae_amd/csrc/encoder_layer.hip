@@ -308,7 +308,7 @@ int splitk_acc_jobs(const Ctx& c, const SplitkJobs& J) {
   GD_LAUNCH_CHECK();
   return 0;
 }
-constexpr int kColsumBlocks = 128;
+constexpr int kColsumBlocks = 512;
 int colsum_jobs(const Ctx& c, ColsumJobs& J, long long n, int cmax, float* part) {
   size_t lds = 0;
   int ctot = 0;
