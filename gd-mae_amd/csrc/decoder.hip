@@ -11,6 +11,7 @@
 // All three are single-pass, HBM-bound row kernels: 16-byte loads, lanes on channels, rows strided over the
 // workgroup; Z / dZ may be bf16 (throughput mode) or fp32 rows of `zrow` elements, P / dP fp32 or bf16.
 #include "common.h"
+#include "conv_tiles.h"
 
 __device__ inline float dec_bf2f(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
 __device__ inline unsigned short dec_f2bf(float f) {
@@ -615,7 +616,7 @@ extern "C" int gdmae_segmax_bn_bwd(const void* x, int x_bf16, const float* out, 
 // materialised.  One thread = 8 channels of one (site, tap): 16-byte bf16 (or 2x16-byte fp32) accesses.
 // ------------------------------------------------------------------------------------------
 template <bool BF>
-__global__ __launch_bounds__(256) void k_conv_grad_taps(const void* __restrict__ Ymap, const float* __restrict__ k0,
+__global__ __launch_bounds__(256) void k_conv_grad_taps(const void* __restrict__ Ymap, GdTiles T, const float* __restrict__ k0,
                                                         const float* __restrict__ k1, const float* __restrict__ rows,
                                                         const int* __restrict__ cell2pillar, const int* __restrict__ site,
                                                         long long n, int H, int W, int C, void* __restrict__ out) {
@@ -638,8 +639,9 @@ __global__ __launch_bounds__(256) void k_conv_grad_taps(const void* __restrict__
       const long long u = (long long)(r - y + uy) * W + ux;
       const int c0 = v * 8;
       float yv[8];
+      const char* yrow = gd_y_row<BF ? 2 : 4>(Ymap, T, (r - y) / H, uy, ux, H, W, C);
       if (BF) {
-        const uint4 q = ((const uint4*)Ymap)[(u * C + c0) >> 3];
+        const uint4 q = ((const uint4*)yrow)[c0 >> 3];
         const unsigned w4[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -647,7 +649,7 @@ __global__ __launch_bounds__(256) void k_conv_grad_taps(const void* __restrict__
           yv[2 * j + 1] = __uint_as_float(w4[j] & 0xFFFF0000u);
         }
       } else {
-        const float4 q0 = ((const float4*)Ymap)[(u * C + c0) >> 2], q1 = ((const float4*)Ymap)[((u * C + c0) >> 2) + 1];
+        const float4 q0 = ((const float4*)yrow)[c0 >> 2], q1 = ((const float4*)yrow)[(c0 >> 2) + 1];
         yv[0] = q0.x; yv[1] = q0.y; yv[2] = q0.z; yv[3] = q0.w; yv[4] = q1.x; yv[5] = q1.y; yv[6] = q1.z; yv[7] = q1.w;
       }
       const float4 ka = ((const float4*)k0)[c0 >> 2], kb = ((const float4*)k0)[(c0 >> 2) + 1];
@@ -676,15 +678,16 @@ __global__ __launch_bounds__(256) void k_conv_grad_taps(const void* __restrict__
   }
 }
 
-extern "C" int gdmae_conv3x3_grad_taps(const void* Ymap, int y_bf16, const float* k0, const float* k1, const float* rows,
-                                       const int* cell2pillar, const int* site, long long n, int H, int W, int C, void* out,
-                                       void* stream) {
+extern "C" int gdmae_conv3x3_grad_taps(const void* Ymap, int y_bf16, const int* tile_slot, const void* ybg, const float* k0,
+                                       const float* k1, const float* rows, const int* cell2pillar, const int* site, long long n,
+                                       int H, int W, int C, void* out, void* stream) {
   GD_REQUIRE(C % 8 == 0, "C must be a multiple of 8");
   if (n <= 0) return 0;
   long long g = (n * 9 * (C / 8) + 255) / 256;
   if (g > 65536) g = 65536;
-  if (y_bf16) hipLaunchKernelGGL(k_conv_grad_taps<true>, dim3((int)g), dim3(256), 0, (hipStream_t)stream, Ymap, k0, k1, rows, cell2pillar, site, n, H, W, C, out);
-  else hipLaunchKernelGGL(k_conv_grad_taps<false>, dim3((int)g), dim3(256), 0, (hipStream_t)stream, Ymap, k0, k1, rows, cell2pillar, site, n, H, W, C, out);
+  const GdTiles T{tile_slot, ybg, (H + 7) / 8, (W + 7) / 8};
+  if (y_bf16) hipLaunchKernelGGL(k_conv_grad_taps<true>, dim3((int)g), dim3(256), 0, (hipStream_t)stream, Ymap, T, k0, k1, rows, cell2pillar, site, n, H, W, C, out);
+  else hipLaunchKernelGGL(k_conv_grad_taps<false>, dim3((int)g), dim3(256), 0, (hipStream_t)stream, Ymap, T, k0, k1, rows, cell2pillar, site, n, H, W, C, out);
   GD_LAUNCH_CHECK();
   return 0;
 }
@@ -699,7 +702,7 @@ extern "C" int gdmae_conv3x3_grad_taps(const void* Ymap, int y_bf16, const float
 // ------------------------------------------------------------------------------------------
 #define DEC_BORDER_CHUNKS 64
 template <bool BF>
-__global__ __launch_bounds__(256) void k_border_partial(const void* __restrict__ Y, const float* __restrict__ rows,
+__global__ __launch_bounds__(256) void k_border_partial(const void* __restrict__ Y, GdTiles T, const float* __restrict__ rows,
                                                         const int* __restrict__ pillar_cell, int M, int B, int H, int W, int C,
                                                         float* __restrict__ part_edge, float* __restrict__ part_rows) {
   extern __shared__ float sh[];
@@ -717,7 +720,7 @@ __global__ __launch_bounds__(256) void k_border_partial(const void* __restrict__
         const int y = e == 0 ? 0 : (e == 1 ? H - 1 : i);
         const int x = e == 2 ? 0 : (e == 3 ? W - 1 : i);
         float v[8];
-        dec_ld8<BF>(Y, ((long long)(b * H + y) * W + x) * C + c, v);
+        dec_ld8<BF>(gd_y_row<BF ? 2 : 4>(Y, T, b, y, x, H, W, C), c, v);
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[j] += v[j];
       }
@@ -767,7 +770,7 @@ __global__ __launch_bounds__(256) void k_border_partial(const void* __restrict__
 }
 
 template <bool BF>
-__global__ __launch_bounds__(256) void k_border_final(const void* __restrict__ Y, const float* __restrict__ part_edge,
+__global__ __launch_bounds__(256) void k_border_final(const void* __restrict__ Y, GdTiles T, const float* __restrict__ part_edge,
                                                       const float* __restrict__ part_rows, int B, int H, int W, int C,
                                                       double* __restrict__ out) {
   for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < 8 * C; q += gridDim.x * blockDim.x) {
@@ -777,7 +780,7 @@ __global__ __launch_bounds__(256) void k_border_final(const void* __restrict__ Y
       for (int b = 0; b < B; ++b) s += (double)part_edge[(long long)(r * B + b) * C + c];
     } else {
       const int y = (r == 4 || r == 5) ? 0 : H - 1, x = (r == 4 || r == 6) ? 0 : W - 1;
-      for (int b = 0; b < B; ++b) s += (double)dec_ld<BF>(Y, ((long long)(b * H + y) * W + x) * C + c);
+      for (int b = 0; b < B; ++b) s += (double)dec_ld<BF>(gd_y_row<BF ? 2 : 4>(Y, T, b, y, x, H, W, C), c);
     }
     out[q] = s;
     double t = 0.0;
@@ -790,18 +793,20 @@ extern "C" size_t gdmae_border_sums_workspace_bytes(int B, int C) {
   return (size_t)(4 * B + 8 * DEC_BORDER_CHUNKS) * C * sizeof(float);
 }
 
-extern "C" int gdmae_border_sums(const void* Y, int y_bf16, const float* rows, const int* pillar_cell, int M, int B, int H, int W,
-                                 int C, double* out /* [16][C] */, void* workspace, void* stream) {
+extern "C" int gdmae_border_sums(const void* Y, int y_bf16, const int* tile_slot, const void* ybg, const float* rows,
+                                 const int* pillar_cell, int M, int B, int H, int W, int C, double* out /* [16][C] */,
+                                 void* workspace, void* stream) {
+  const GdTiles T{tile_slot, ybg, (H + 7) / 8, (W + 7) / 8};
   GD_REQUIRE(C % 8 == 0 && C <= 256 && 256 % (C / 8) == 0, "border_sums: C in {64, 128, 256}");
   hipStream_t st = (hipStream_t)stream;
   float* part_edge = (float*)workspace;
   float* part_rows = part_edge + (size_t)4 * B * C;
   const size_t lds = (size_t)(256 / (C / 8)) * C * sizeof(float);
-  if (y_bf16) hipLaunchKernelGGL((k_border_partial<true>), dim3(4 * B + 2 * DEC_BORDER_CHUNKS), dim3(256), lds, st, Y, rows, pillar_cell, M, B, H, W, C, part_edge, part_rows);
-  else hipLaunchKernelGGL((k_border_partial<false>), dim3(4 * B + 2 * DEC_BORDER_CHUNKS), dim3(256), lds, st, Y, rows, pillar_cell, M, B, H, W, C, part_edge, part_rows);
+  if (y_bf16) hipLaunchKernelGGL((k_border_partial<true>), dim3(4 * B + 2 * DEC_BORDER_CHUNKS), dim3(256), lds, st, Y, T, rows, pillar_cell, M, B, H, W, C, part_edge, part_rows);
+  else hipLaunchKernelGGL((k_border_partial<false>), dim3(4 * B + 2 * DEC_BORDER_CHUNKS), dim3(256), lds, st, Y, T, rows, pillar_cell, M, B, H, W, C, part_edge, part_rows);
   GD_LAUNCH_CHECK();
-  if (y_bf16) hipLaunchKernelGGL((k_border_final<true>), dim3(gd_div_up(8 * C, 256)), dim3(256), 0, st, Y, part_edge, part_rows, B, H, W, C, out);
-  else hipLaunchKernelGGL((k_border_final<false>), dim3(gd_div_up(8 * C, 256)), dim3(256), 0, st, Y, part_edge, part_rows, B, H, W, C, out);
+  if (y_bf16) hipLaunchKernelGGL((k_border_final<true>), dim3(gd_div_up(8 * C, 256)), dim3(256), 0, st, Y, T, part_edge, part_rows, B, H, W, C, out);
+  else hipLaunchKernelGGL((k_border_final<false>), dim3(gd_div_up(8 * C, 256)), dim3(256), 0, st, Y, T, part_edge, part_rows, B, H, W, C, out);
   GD_LAUNCH_CHECK();
   return 0;
 }

@@ -13,9 +13,13 @@ Exact identities used (no approximation):
 * The concatenated 384-channel map is therefore "constant background + token rows": it is written once
   (fill + three row scatters into column slices) instead of 3 dense deconvs, 3 dense BN passes, 3 ReLUs
   and a cat copy.
-* The forward 3x3 convolution is the one genuinely dense contraction (MIOpen implicit GEMM, bf16 in throughput
-  mode).  Its BatchNorm needs dense statistics (one read pass, gdmae_colstats) but its output is only
-  consumed at the M pillar sites, so BN + ReLU are applied to the gathered rows only.
+* The forward 3x3 convolution is the one genuinely dense contraction.  In throughput mode (bf16) it is the library's
+  own bf16-MFMA implicit GEMM over the ACTIVE 8x8 TILES of the map (csrc/conv_tiles.hip): the 384-channel input map
+  is never written (the kernel gathers the deconvolution rows through the stages' cell -> token maps and applies
+  BN + ReLU on the way into LDS), sites outside the active tiles hold one of 9 border-class constants, and the
+  BatchNorm statistics of the output come out of the same kernel.  In fp32 parity mode the map is materialised
+  (fill + three row scatters) and convolved by F.conv2d.  Either way the output is only consumed at the M pillar
+  sites, so BN + ReLU are applied to the gathered rows only.
 * In the backward the gradient of the conv output is an affine function of the conv output plus M sparse
   rows, and the conv input gradient is only needed where the input is not background: per source stage the
   9 shifted output-gradient rows of its active sites are gathered (gdmae_conv3x3_grad_taps) and two GEMMs give
@@ -114,9 +118,11 @@ class DecoderHead(torch.autograd.Function):
       backward-weights over all R sites, gdmae_conv3x3_grad_taps gathers the 9 shifted dY rows of the active sites
       and two GEMMs per stage finish the job; dY / dZ are never materialised."""
 
+    last_ybg = None      # class constants of the latest tile-path forward (for the optional dense expansion)
+
     @staticmethod
     def forward(ctx, geom, conv_w, gamma2, beta2, pillar_cell, cell2pillar, bn_mods, *args):
-        B, H, W, eps1, eps2, cdt = geom
+        B, H, W, eps1, eps2, cdt = geom[:6]
         R = B * H * W
         k = len(args) // 4
         sites, Ps, gammas, betas = args[0::4], args[1::4], args[2::4], args[3::4]
@@ -128,31 +134,68 @@ class DecoderHead(torch.autograd.Function):
             stats, ab, mv = gbn.fold(Ps[i].contiguous(), R, gammas[i], betas[i], eps1, bns[i])
             ab_l.append(ab), stats_l.append(stats)
             mv_out += [mv[:widths[i]], mv[widths[i]:]]
-        bgz = torch.relu(torch.cat([ab[w:] for ab, w in zip(ab_l, widths)])).to(cdt)   # value of every non-active site
-        Z = torch.empty(R, sum(widths), dtype=cdt, device=dev)
-        L.call("gdmae_fill_rows", L.ptr(bgz), R, Z.shape[1], Z.element_size(), L.ptr(Z), L.stream())
-        col = 0
-        for i in range(k):
-            w = widths[i]
-            L.call("gdmae_rows_affine_relu_scatter", L.ptr(Ps[i]), _bf(Ps[i]), L.ptr(sites[i]), Ps[i].shape[0], w,
-                   L.ptr(ab_l[i]), L.ptr(ab_l[i][w:]), L.ptr(Z), _bf(Z), Z.shape[1], col, L.stream())
-            col += w
-        wc = ops.shadow(conv_w, cdt)
-        with torch.autocast("cuda", enabled=False):
-            y2 = F.conv2d(Z.view(B, H, W, -1).permute(0, 3, 1, 2), wc, None, 1, 1)
-        y2 = y2.permute(0, 2, 3, 1)
-        if not y2.is_contiguous():
-            y2 = y2.contiguous()
-        y2 = y2.view(R, -1)
-        C2 = y2.shape[1]
-        stats2, ab2, mv2 = gbn.fold(y2, R, gamma2, beta2, eps2, bns[k])
-        yrows = ops.gather_rows_raw(y2, pillar_cell)                       # (M, C2) conv outputs at the pillar sites
-        M = yrows.shape[0]
+        tiles = geom[6] if len(geom) > 6 else None
+        use_tiles = (tiles is not None and cdt == torch.bfloat16 and all(w == 128 for w in widths) and conv_w.shape[0] == 128
+                     and conv_w.dtype == torch.float32 and conv_w.is_contiguous() and all(P.dtype == torch.bfloat16 for P in Ps))
+        if use_tiles:
+            # own bf16-MFMA 3x3 convolution over the active tiles; the dense 384-channel map is never built
+            dt, maps, ups = tiles
+            lib = L.load()
+            Cin = sum(widths)
+            C2 = 128
+            Wp = torch.empty(lib.gdmae_conv3x3_tiles_packed_bytes(k), dtype=torch.uint8, device=dev)
+            bgz = torch.empty(Cin, dtype=cdt, device=dev)
+            ybg = torch.empty(9, C2, dtype=cdt, device=dev)
+            a_l, b_l = [ab[:w] for ab, w in zip(ab_l, widths)], [ab[w:] for ab, w in zip(ab_l, widths)]
+            L.call("gdmae_conv3x3_tiles_pack", L.ptr(conv_w), C2, Cin, L.host_ptrs(b_l), k, L.ptr(Wp), L.ptr(bgz), L.ptr(ybg),
+                   L.stream())
+            y2 = torch.empty(max(dt.n_act, 1) * 64, C2, dtype=cdt, device=dev)
+            stats2 = torch.empty(2 * C2, dtype=torch.float64, device=dev)
+            ab2 = torch.empty(2 * C2, dtype=torch.float32, device=dev)
+            mv2 = torch.empty(2 * C2, dtype=torch.float32, device=dev)
+            ws = torch.empty(lib.gdmae_conv3x3_tiles_workspace_bytes(dt.n_act), dtype=torch.uint8, device=dev)
+            bn2 = bns[k]
+            rm = rv = nb = None
+            mom = 0.0
+            if bn2 is not None and bn2.training and bn2.running_mean is not None:
+                rm, rv, nb, mom = bn2.running_mean, bn2.running_var, bn2.num_batches_tracked, float(bn2.momentum)
+            L.call("gdmae_conv3x3_tiles_fwd", L.host_ptrs([P.contiguous() for P in Ps]), L.host_ptrs(maps), L.host_ptrs(a_l),
+                   L.host_ptrs(b_l), L.host_i32(ups), k, L.ptr(Wp), L.ptr(ybg), L.ptr(dt.tile_list), dt.n_act, B, H, W, L.ptr(y2),
+                   L.ptr(gamma2), L.ptr(beta2), float(eps2), mom, L.ptr(rm), L.ptr(rv), L.ptr(nb), L.ptr(stats2), L.ptr(ab2),
+                   L.ptr(mv2), L.ptr(ws), L.stream())
+            M = pillar_cell.numel()
+            yrows = torch.empty(M, C2, dtype=cdt, device=dev)
+            L.call("gdmae_tiles_gather_rows", L.ptr(y2), L.ptr(dt.tile_slot), L.ptr(ybg), L.ptr(pillar_cell), M, H, W, C2, 2,
+                   L.ptr(yrows), L.stream())
+            Z, tile_slot = None, dt.tile_slot
+            DecoderHead.last_ybg = ybg
+        else:
+            bgz = torch.relu(torch.cat([ab[w:] for ab, w in zip(ab_l, widths)])).to(cdt)   # value of every non-active site
+            Z = torch.empty(R, sum(widths), dtype=cdt, device=dev)
+            L.call("gdmae_fill_rows", L.ptr(bgz), R, Z.shape[1], Z.element_size(), L.ptr(Z), L.stream())
+            col = 0
+            for i in range(k):
+                w = widths[i]
+                L.call("gdmae_rows_affine_relu_scatter", L.ptr(Ps[i]), _bf(Ps[i]), L.ptr(sites[i]), Ps[i].shape[0], w,
+                       L.ptr(ab_l[i]), L.ptr(ab_l[i][w:]), L.ptr(Z), _bf(Z), Z.shape[1], col, L.stream())
+                col += w
+            wc = ops.shadow(conv_w, cdt)
+            with torch.autocast("cuda", enabled=False):
+                y2 = F.conv2d(Z.view(B, H, W, -1).permute(0, 3, 1, 2), wc, None, 1, 1)
+            y2 = y2.permute(0, 2, 3, 1)
+            if not y2.is_contiguous():
+                y2 = y2.contiguous()
+            y2 = y2.view(R, -1)
+            C2 = y2.shape[1]
+            stats2, ab2, mv2 = gbn.fold(y2, R, gamma2, beta2, eps2, bns[k])
+            yrows = ops.gather_rows_raw(y2, pillar_cell)                       # (M, C2) conv outputs at the pillar sites
+            M = yrows.shape[0]
+            tile_slot = ybg = None
         out = torch.empty(M, C2, dtype=torch.float32, device=dev)
         L.call("gdmae_rows_affine_relu_scatter", L.ptr(yrows), _bf(yrows), None, M, C2, L.ptr(ab2), L.ptr(ab2[C2:]), L.ptr(out), 0,
                C2, 0, L.stream())
         ctx.save_for_backward(*sites, *Ps, *ab_l, *stats_l, *[g.detach() for g in gammas], Z, y2, bgz, yrows, ab2, stats2,
-                              pillar_cell, cell2pillar, gamma2.detach(), conv_w.detach())
+                              pillar_cell, cell2pillar, gamma2.detach(), conv_w.detach(), tile_slot, ybg)
         ctx.k, ctx.widths, ctx.geom = k, widths, geom
         ctx.direct = [gbn.direct_pair(g, be) for g, be in zip(gammas, betas)] + [gbn.direct_pair(gamma2, beta2)]
         ctx.direct_w = ops.direct_grad(conv_w)
@@ -164,12 +207,12 @@ class DecoderHead(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout, *_):
         k = ctx.k
-        B, H, W, eps1, eps2, cdt = ctx.geom
+        B, H, W, eps1, eps2, cdt = ctx.geom[:6]
         R = B * H * W
         sv = ctx.saved_tensors
         sites, Ps, ab_l, stats_l, gammas = (sv[i * k:(i + 1) * k] for i in range(5))
-        Z, y2, bgz, yrows, ab2, stats2, pillar_cell, cell2pillar, gamma2, conv_w = sv[5 * k:]
-        C2, Cin = y2.shape[1], Z.shape[1]
+        Z, y2, bgz, yrows, ab2, stats2, pillar_cell, cell2pillar, gamma2, conv_w, tile_slot, ybg = sv[5 * k:]
+        C2, Cin = y2.shape[1], bgz.numel()
         M = yrows.shape[0]
         dev = y2.device
         f64 = torch.float64
@@ -187,8 +230,8 @@ class DecoderHead(torch.autograd.Function):
         # ---- region sums of dY (all / border rows / border columns / corners) -> S_k per tap
         reg = torch.empty(16, C2, dtype=f64, device=dev)
         ws = torch.empty(L.load().gdmae_border_sums_workspace_bytes(B, C2), dtype=torch.uint8, device=dev)
-        L.call("gdmae_border_sums", L.ptr(y2), _bf(y2), L.ptr(rows), L.ptr(pillar_cell), M, B, H, W, C2, L.ptr(reg), L.ptr(ws),
-               L.stream())
+        L.call("gdmae_border_sums", L.ptr(y2), _bf(y2), L.ptr(tile_slot), L.ptr(ybg), L.ptr(rows), L.ptr(pillar_cell), M, B, H, W,
+               C2, L.ptr(reg), L.ptr(ws), L.stream())
         # region 0 = all sites: sum Y = mean * R, sum rows = a * sum dh; S = tap_region @ (cnt k0 + regY k1 + regR), the
         # column sums of dZ over ALL sites, the background part of the weight gradient and the per-tap weight in the
         # compute dtype: one call (three launches) instead of ~20 small torch ops
@@ -221,10 +264,16 @@ class DecoderHead(torch.autograd.Function):
             n = P.shape[0]
             ab = ab_l[i]
             G = torch.empty(n, 9 * C2, dtype=cdt, device=dev)
-            L.call("gdmae_conv3x3_grad_taps", L.ptr(y2), _bf(y2), L.ptr(k01), L.ptr(k01[C2:]), L.ptr(rows), L.ptr(cell2pillar),
-                   L.ptr(sites[i]), n, H, W, C2, L.ptr(G), L.stream())
+            L.call("gdmae_conv3x3_grad_taps", L.ptr(y2), _bf(y2), L.ptr(tile_slot), L.ptr(ybg), L.ptr(k01), L.ptr(k01[C2:]),
+                   L.ptr(rows), L.ptr(cell2pillar), L.ptr(sites[i]), n, H, W, C2, L.ptr(G), L.stream())
             dX = ops.mm(G, Wd[:, :, col:col + w].reshape(9 * C2, w))      # dZ rows of this stage's active sites
-            Zd = _gather_slice(Z, sites[i], col, w) - bgz[col:col + w]
+            if Z is not None:
+                Zrows = _gather_slice(Z, sites[i], col, w)
+            else:                                                         # the map was never built: redo BN + ReLU of the rows
+                Zrows = torch.empty(n, w, dtype=cdt, device=dev)
+                L.call("gdmae_rows_affine_relu_scatter", L.ptr(P), _bf(P), None, n, w, L.ptr(ab), L.ptr(ab[w:]), L.ptr(Zrows),
+                       _bf(Zrows), w, 0, L.stream())
+            Zd = Zrows - bgz[col:col + w]
             dW_rows.append(ops.splitk_tn(G, Zd))                          # (9*C2, w) fp32
             del G
             st = torch.empty(3 * w, dtype=f64, device=dev)
@@ -258,12 +307,18 @@ def upsampled_sites(stage_plan, s: int, Y: int, X: int) -> torch.Tensor:
     return gplan.upsample_cells(stage_plan.tok_cell, stage_plan.Y, stage_plan.X, s).reshape(-1).contiguous()
 
 
-def sparse_decoder(model_cfg, deblocks, conv_out, hidden, pillar_cell, cell2pillar, B, Y, X, want_dense=False):
+def sparse_decoder(model_cfg, deblocks, conv_out, hidden, pillar_cell, cell2pillar, B, Y, X, want_dense=False, conv_impl='tiles'):
     """hidden: list of SparseConvTensor per stage.  Returns (features at the pillar sites (M, C) fp32,
     dense spatial_features (B, C, Y, X) or None)."""
     R = B * Y * X
     args, bns = [], []
     cdt = torch.bfloat16 if torch.is_autocast_enabled() else torch.float32
+    src_idx = [int(src[-1]) - 1 for src in model_cfg.FEATURES_SOURCE]
+    tiles = None
+    if cdt == torch.bfloat16 and conv_impl == 'tiles':
+        ep = hidden[0]._plan
+        dt = gplan.decoder_tiles(ep, src_idx, Y, X)
+        tiles = (dt, [hidden[i].stage_plan.map for i in src_idx], [Y // hidden[i].stage_plan.Y for i in src_idx])
     for i, src in enumerate(model_cfg.FEATURES_SOURCE):
         h = hidden[int(src[-1]) - 1]
         sp = h.stage_plan
@@ -276,12 +331,20 @@ def sparse_decoder(model_cfg, deblocks, conv_out, hidden, pillar_cell, cell2pill
         args += [upsampled_sites(sp, s, Y, X), P, bn.weight, bn.bias]
         bns.append(bn)
     conv, bn2 = conv_out[0], conv_out[1]
-    outs = DecoderHead.apply((B, Y, X, bns[0].eps, bn2.eps, cdt), conv.weight, bn2.weight, bn2.bias, pillar_cell, cell2pillar,
-                             tuple(bns) + (bn2,), *args)
+    outs = DecoderHead.apply((B, Y, X, bns[0].eps, bn2.eps, cdt, tiles), conv.weight, bn2.weight, bn2.bias, pillar_cell,
+                             cell2pillar, tuple(bns) + (bn2,), *args)
     out, y2, mean2, var2 = outs[:4]
     dense = None
     if want_dense:
         with torch.no_grad():
+            if y2.shape[0] != R:      # tile-compact conv output: expand (only callers that want the reference's dense map)
+                dt = tiles[0]
+                C2 = y2.shape[1]
+                ybg = DecoderHead.last_ybg
+                yd = torch.empty(R, C2, dtype=y2.dtype, device=y2.device)
+                L.call("gdmae_tiles_to_dense", L.ptr(y2), L.ptr(dt.tile_slot), L.ptr(ybg), B, Y, X, C2, y2.element_size(), L.ptr(yd),
+                       L.stream())
+                y2 = yd
             a2 = bn2.weight * torch.rsqrt(var2 + bn2.eps)
             dense = torch.relu(y2.float() * a2 + (bn2.bias - a2 * mean2)).view(B, Y, X, -1).permute(0, 3, 1, 2)
     return out, dense

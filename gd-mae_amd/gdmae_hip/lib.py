@@ -59,8 +59,17 @@ SIGNATURES = {
     "gdmae_bn_fold": (_I, [_P, _L, _I, _I, _D, _P, _P, _D, _D, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gdmae_bn_bwd_coeffs": (_I, [_P, _I, _P, _P, _P, _I, _D, _P, _P, _P, _I, _P, _P]),
     "gdmae_border_sums_workspace_bytes": (_Z, [_I, _I]),
-    "gdmae_border_sums": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
-    "gdmae_conv3x3_grad_taps": (_I, [_P, _I, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P, _P]),
+    "gdmae_border_sums": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "gdmae_conv3x3_grad_taps": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P, _P]),
+    "gdmae_decoder_tiles_workspace_bytes": (_Z, [_I, _I, _I]),
+    "gdmae_decoder_tiles": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "gdmae_conv3x3_tiles_packed_bytes": (_Z, [_I]),
+    "gdmae_conv3x3_tiles_pack": (_I, [_P, _I, _I, _P, _I, _P, _P, _P, _P]),
+    "gdmae_conv3x3_tiles_workspace_bytes": (_Z, [_I]),
+    "gdmae_conv3x3_tiles_fwd": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _D, _D, _P, _P, _P, _P, _P, _P,
+                                     _P, _P]),
+    "gdmae_tiles_gather_rows": (_I, [_P, _P, _P, _P, _L, _I, _I, _I, _I, _P, _P]),
+    "gdmae_tiles_to_dense": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "gdmae_rows_bwd": (_I, [_P, _I, _P, _L, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P, _I, _P]),
     "gdmae_segment_max_affine": (_I, [_P, _I, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
     "gdmae_segmax_bwd_stats": (_I, [_P, _I, _P, _P, _P, _L, _I, _P, _P, _P, _P, _P]),
@@ -159,3 +168,8 @@ def host_f32(vals):
 
 def host_i32(vals):
     return (C.c_int * len(vals))(*[int(v) for v in vals])
+
+
+def host_ptrs(tensors):
+    """Host array of device pointers (the `const T* const*` arguments of the C ABI)."""
+    return (C.c_void_p * len(tensors))(*[ptr(t) for t in tensors])

@@ -134,10 +134,24 @@ class StagePlan:
 
 
 @dataclass
+class DecoderTiles:
+    """Active 8x8 tiles of the full-resolution BEV map for the decoder's 3x3 conv_out (csrc/conv_tiles.hip): the tiles
+    whose one-site halo touches a site covered by a token of one of the decoder's source stages."""
+    sources: tuple                     # stage indices the tile set was built for
+    B: int
+    H: int
+    W: int
+    n_act: int
+    tile_slot: torch.Tensor            # (B * ceil(H/8) * ceil(W/8),) int32 tile -> slot / -1
+    tile_list: torch.Tensor            # (n_act,) int32 ascending tile ids
+
+
+@dataclass
 class EncoderPlan:
     mask: Optional[torch.Tensor]       # (M,) fp32 0 visible / 1 masked (None when nothing is masked)
     tok_pillar: torch.Tensor           # (M1,) pillar id of each stage-1 token
     stages: List[StagePlan]
+    dec_tiles: Optional[DecoderTiles] = None
 
 
 def upsample_cells(c: torch.Tensor, Ys: int, Xs: int, s: int) -> torch.Tensor:
@@ -162,7 +176,35 @@ def _drop_arrays(drop_info):
     return lo, hi, T
 
 
-def _encoder_launch(vox, m_cap: int, strides, window_shapes, drop_infos, keep_frac, noise) -> dict:
+def _decoder_tiles_launch(maps, ups, B, H, W, dev) -> dict:
+    """Enqueue gdmae_decoder_tiles on the current stream (capacity-sized outputs, count left on the device)."""
+    nt = B * ((H + 7) // 8) * ((W + 7) // 8)
+    r = dict(tile_slot=_empty(nt, I32, dev), tile_list=_empty(nt, I32, dev), n_act=_empty(1, I32, dev), B=B, H=H, W=W)
+    ws = _empty(L.load().gdmae_decoder_tiles_workspace_bytes(B, H, W), torch.uint8, dev)
+    L.call("gdmae_decoder_tiles", L.host_ptrs(maps), L.host_i32(ups), len(maps), B, H, W, L.ptr(r["tile_slot"]),
+           L.ptr(r["tile_list"]), L.ptr(r["n_act"]), L.ptr(ws), L.stream())
+    r["_ws"] = ws
+    return r
+
+
+def decoder_tiles(ep: "EncoderPlan", sources, H: int, W: int) -> DecoderTiles:
+    """Tile set for the given decoder source stages (cached on the plan; built inline with ONE host sync when the plan was
+    made without it)."""
+    sources = tuple(int(v) for v in sources)
+    dt = ep.dec_tiles
+    if dt is not None and dt.sources == sources and dt.H == H and dt.W == W:
+        return dt
+    st = [ep.stages[i] for i in sources]
+    B = st[0].B
+    ups = [H // sp.Y for sp in st]
+    assert all(sp.Y * u == H and sp.X * u == W for sp, u in zip(st, ups))
+    r = _decoder_tiles_launch([sp.map for sp in st], ups, B, H, W, st[0].map.device)
+    n = int(r["n_act"].item())
+    ep.dec_tiles = DecoderTiles(sources, B, H, W, n, r["tile_slot"], r["tile_list"][:n])
+    return ep.dec_tiles
+
+
+def _encoder_launch(vox, m_cap: int, strides, window_shapes, drop_infos, keep_frac, noise, dec_sources=None) -> dict:
     """Enqueue masking + token sets + rulebooks + window partitions on the current stream; no host sync.
     ``vox``: VoxelPlan or the raw dict of _voxelize_launch; m_cap >= number of pillars (capacity)."""
     if isinstance(vox, dict):
@@ -252,9 +294,17 @@ def _encoder_launch(vox, m_cap: int, strides, window_shapes, drop_infos, keep_fr
         up_sites = upsample_cells(tok_cell, Y, X, up_s) if (up_s > 1 and up_s * Y == gy and up_s * X == gx) else None
         raw.append(dict(B=B, Y=Y, X=X, cap=cap, tok_cell=tok_cell, map=smap, n_tok=n_tok, nbr_subm=nbr_subm,
                         nbr_subm_t=nbr_subm_t, up_s=up_s, up_sites=up_sites, nbr_down=nbr_down, nbr_down_t=nbr_down_t, wins=wins))
-    counts = torch.cat([r["n_tok"] for r in raw] + [w["counts"] for r in raw for w in r["wins"]])
+    dec = None
+    if dec_sources is not None:
+        # active tiles of the decoder's 3x3 conv (geometry only: built here, off the training stream)
+        srcs = [raw[int(i)] for i in dec_sources]
+        if all(r["up_s"] * r["Y"] == gy and r["up_s"] * r["X"] == gx and r["up_s"] in (1, 2, 4, 8) for r in srcs):
+            dec = _decoder_tiles_launch([r["map"] for r in srcs], [r["up_s"] for r in srcs], B, gy, gx, dev)
+            dec["sources"] = tuple(int(i) for i in dec_sources)
+    counts = torch.cat([r["n_tok"] for r in raw] + [w["counts"] for r in raw for w in r["wins"]]
+                       + ([dec["n_act"]] if dec is not None else []))
     return dict(stages=raw, mask=mask, tok_pillar=tok_pillar, masked=keep_frac is not None, counts=counts,
-                keep=(noise, scan_ws))
+                keep=(noise, scan_ws), dec=dec)
 
 
 def _encoder_finalize(e: dict, allc, M: int) -> EncoderPlan:
@@ -279,11 +329,16 @@ def _encoder_finalize(e: dict, allc, M: int) -> EncoderPlan:
                                 wps))
         stages[-1]._nbr_subm_t = r["nbr_subm_t"][:n * 9].view(n, 9)
         stages[-1]._up_sites = None if r["up_sites"] is None else (r["up_s"], r["up_sites"][:n].reshape(-1))
-    return EncoderPlan(e["mask"][:M] if e["masked"] else None, e["tok_pillar"][:stages[0].n_tok], stages)
+    dec = e.get("dec", None)
+    dt = None
+    if dec is not None:
+        n_act = int(allc[ns + 16 * ns])
+        dt = DecoderTiles(dec["sources"], dec["B"], dec["H"], dec["W"], n_act, dec["tile_slot"], dec["tile_list"][:n_act])
+    return EncoderPlan(e["mask"][:M] if e["masked"] else None, e["tok_pillar"][:stages[0].n_tok], stages, dt)
 
 
 def encoder_plan(vox: VoxelPlan, strides, window_shapes, drop_infos, keep_frac: Optional[float] = None,
-                 noise: Optional[torch.Tensor] = None) -> EncoderPlan:
+                 noise: Optional[torch.Tensor] = None, dec_sources=None) -> EncoderPlan:
     """Masking + token sets + rulebooks + window partitions for all stages; ONE host sync at the end.
 
     strides: per stage conv_down stride (1 or 2); window_shapes: per stage [wx, wy, wz];
@@ -292,7 +347,7 @@ def encoder_plan(vox: VoxelPlan, strides, window_shapes, drop_infos, keep_frac: 
     """
     if noise is not None:
         assert noise.shape == (vox.M,)
-    e = _encoder_launch(vox, vox.M, strides, window_shapes, drop_infos, keep_frac, noise)
+    e = _encoder_launch(vox, vox.M, strides, window_shapes, drop_infos, keep_frac, noise, dec_sources)
     return _encoder_finalize(e, e["counts"].tolist(), vox.M)   # the one host sync of this phase
 
 
@@ -306,7 +361,7 @@ class PlanPrefetch:
     _side = {}
 
     def __init__(self, points, point_cloud_range, voxel_size, grid_size, batch_size, strides, window_shapes, drop_infos,
-                 keep_frac=None, noise=None, ready=None):
+                 keep_frac=None, noise=None, ready=None, dec_sources=None):
         """``ready``: event recorded after ``points`` (and ``noise``) were produced; the plan stream then waits for that
         event only and the plan can be built while the main stream is still busy with the previous batch's backward.
         Without it the plan stream is ordered after everything queued on the main stream so far."""
@@ -324,7 +379,7 @@ class PlanPrefetch:
             self.vraw = _voxelize_launch(points, point_cloud_range, voxel_size, grid_size, batch_size)
             gx, gy, gz = self.vraw["grid"]
             m_cap = max(1, min(self.vraw["n0"], batch_size * gx * gy * gz))
-            self.eraw = _encoder_launch(self.vraw, m_cap, strides, window_shapes, drop_infos, keep_frac, noise)
+            self.eraw = _encoder_launch(self.vraw, m_cap, strides, window_shapes, drop_infos, keep_frac, noise, dec_sources)
             allc = torch.cat([self.vraw["counts"], self.eraw["counts"]])
             self.host = torch.empty(allc.numel(), dtype=torch.int32).pin_memory()
             self.host.copy_(allc, non_blocking=True)

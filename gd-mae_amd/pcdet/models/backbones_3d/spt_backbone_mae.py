@@ -17,6 +17,9 @@ class SPTBackboneMAE(nn.Module):
     # (B, C, Y, X) as the reference does; the pre-training step itself only needs the rows at the pillar sites.
     decoder_impl = 'sparse'
     dense_spatial_features = True
+    # bf16 mode of the sparse decoder: 'tiles' = the library's bf16-MFMA 3x3 convolution over the active tiles
+    # (csrc/conv_tiles.hip), 'dense' = materialised input map + F.conv2d (kept for A/B tests; always used in fp32)
+    decoder_conv_impl = 'tiles'
 
     def __init__(self, model_cfg, input_channels, grid_size, voxel_size, point_cloud_range, **kwargs):
         super().__init__()
@@ -47,7 +50,8 @@ class SPTBackboneMAE(nn.Module):
         ep = batch_dict.get('_gdmae_plan', None)          # prefetched geometry plan (gdmae_hip.plan.PlanPrefetch)
         if ep is None:
             ep = gplan.encoder_plan(vox, *stage_plan_args(self.model_cfg.SST_BLOCK_LIST),
-                                    keep_frac=1 - self.mask_ratio, noise=batch_dict.get('mae_noise', None))
+                                    keep_frac=1 - self.mask_ratio, noise=batch_dict.get('mae_noise', None),
+                                    dec_sources=self._dec_sources())
         batch_dict['voxel_mae_mask'] = ep.mask
         batch_dict['_gdmae_plan'] = ep
         x = SparseConvTensor(ops.GatherUnique.apply(all_feat, ep.tok_pillar), ep, 0)
@@ -61,10 +65,11 @@ class SPTBackboneMAE(nn.Module):
             feats[f'x_conv{i + 1}'] = h
             strides[f'x_conv{i + 1}'] = Y0 // h.spatial_shape[0]
         B, X, Y = int(batch_dict['batch_size']), int(self.grid_size[0]), int(self.grid_size[1])
-        if self.decoder_impl == 'sparse':
+        if self.decoder_impl == 'sparse' and self.training:
+            # (eval: the BatchNorm2d layers must use their running statistics -> the module path below)
             pyramid, sf = gdec.sparse_decoder(self.model_cfg, self.decoder_deblocks, self.decoder_conv_out, hidden,
                                               vox.pillar_cell, vox.cell2pillar, B, Y, X,
-                                              want_dense=self.dense_spatial_features)
+                                              want_dense=self.dense_spatial_features, conv_impl=self.decoder_conv_impl)
         else:
             sf = run_decoder(self.model_cfg, self.decoder_deblocks, self.decoder_conv_out, hidden)   # (B, C, Y, X)
             assert sf.shape[0] == B and sf.shape[2] == Y and sf.shape[3] == X
@@ -84,7 +89,14 @@ class SPTBackboneMAE(nn.Module):
         in batch_dict['_gdmae_vox'] / ['_gdmae_plan'] before calling the detector."""
         return gplan.PlanPrefetch(points, self.point_cloud_range, self.voxel_size, self.grid_size, int(batch_size),
                                   *stage_plan_args(self.model_cfg.SST_BLOCK_LIST), keep_frac=1 - self.mask_ratio, noise=noise,
-                                  ready=ready)
+                                  ready=ready, dec_sources=self._dec_sources())
+
+    def _dec_sources(self):
+        """Stage indices feeding the decoder (their active sets define the active tiles of conv_out), or None when the
+        tile convolution is not in use."""
+        if self.decoder_impl != 'sparse' or self.decoder_conv_impl != 'tiles':
+            return None
+        return [int(src[-1]) - 1 for src in self.model_cfg.FEATURES_SOURCE]
 
     def target_assigner(self, batch_dict):
         vox = batch_dict['_gdmae_vox']

@@ -221,17 +221,50 @@ int gdmae_bn_bwd_coeffs(const double* st, int n_st, const double* stats, const f
 /* Backward of the decoder's dense 3x3 conv_out (spt_backbone_mae.py:46-52) restricted to the sites that need it:
  * out[t, k, :] = dY[site[t] - k] for the 9 taps k = (ky+1)*3 + (kx+1) (zero outside the H x W map), where the
  * output gradient dY[u] = k0 + k1 * Y[u] + (cell2pillar[u] >= 0 ? rows[cell2pillar[u]] : 0) is never materialised.
- * Y (B*H*W, C) fp32 or bf16 (out has the same type), k0/k1 (C) fp32, rows (M, C) fp32, C % 8 == 0. */
-int gdmae_conv3x3_grad_taps(const void* Y, int y_bf16, const float* k0, const float* k1, const float* rows,
-                            const int* cell2pillar, const int* site, long long n, int H, int W, int C, void* out,
-                            void* stream);
+ * Y (B*H*W, C) fp32 or bf16 (out has the same type), k0/k1 (C) fp32, rows (M, C) fp32, C % 8 == 0.
+ * tile_slot != NULL: Y is the tile-compact map of gdmae_conv3x3_tiles_fwd (rows of the active 8x8 tiles + the 9
+ * border-class constant rows ybg for every other site); NULL: the plain dense map. */
+int gdmae_conv3x3_grad_taps(const void* Y, int y_bf16, const int* tile_slot, const void* ybg, const float* k0,
+                            const float* k1, const float* rows, const int* cell2pillar, const int* site, long long n, int H,
+                            int W, int C, void* out, void* stream);
 
 /* Border-region sums for the closed-form background share of that backward.  Regions 1..8 = row 0, row H-1,
  * column 0, column W-1, corners (0,0), (0,W-1), (H-1,0), (H-1,W-1) of every H x W map:
  * out[r-1][c] = sum of Y over the sites of region r; out[8+r-1][c] = sum of rows[p] over the pillars in region r. */
 size_t gdmae_border_sums_workspace_bytes(int B, int C);
-int gdmae_border_sums(const void* Y, int y_bf16, const float* rows, const int* pillar_cell, int M, int B, int H, int W, int C,
-                      double* out, void* workspace, void* stream);
+int gdmae_border_sums(const void* Y, int y_bf16, const int* tile_slot, const void* ybg, const float* rows,
+                      const int* pillar_cell, int M, int B, int H, int W, int C, double* out, void* workspace, void* stream);
+
+/* ---- decoder conv_out (Conv2d 3x3 pad 1, spt_backbone_mae.py:46-52,125-133) on the ACTIVE TILES of the BEV map --------
+ * Replaces F.conv2d (MIOpen) + the dense 384-channel input map + the statistics pass over the dense output.
+ * The input map is implicit: source stage g (128 channels, upsampling stride s_g) holds relu(a_g * P_g[row] + b_g) at the
+ * sites covered by one of its tokens (P_g = ConvTranspose2d(k = s) output rows (token, dy, dx), bf16), relu(b_g) at every
+ * other site.  Output: tile-compact map Yc (n_act * 64, 128) bf16 (8x8-site tiles whose one-site halo touches an active
+ * site; tile_slot / tile_list from gdmae_decoder_tiles), every other site = one of the 9 border-class constants ybg.
+ *   gdmae_decoder_tiles      geometry only (maps / strides: host arrays over the k <= 3 source stages); n_act device int
+ *   gdmae_conv3x3_tiles_pack conv_w (128, 128 k, 3, 3) fp32 -> MFMA-fragment-ordered bf16 weights Wp, background row bgz
+ *                            (128 k) bf16, class constants ybg (9, 128) bf16; b = host array of the k shift vectors
+ *   gdmae_conv3x3_tiles_fwd  the bf16-MFMA implicit GEMM + fused BatchNorm2d(train) statistics over all B*H*W sites:
+ *                            stats f64[256] = mean | rstd, ab f32[256] = scale | shift, mv f32[256] = mean | biased var,
+ *                            running statistics updated when running_mean != NULL
+ *   gdmae_tiles_gather_rows  out[i] = Y row of cell[i] = (b*H + y)*W + x   (elem_bytes 2 or 4)
+ *   gdmae_tiles_to_dense     plain (B*H*W, C) copy (only for callers that want the reference's dense spatial_features) */
+size_t gdmae_decoder_tiles_workspace_bytes(int B, int H, int W);
+int gdmae_decoder_tiles(const int* const* maps, const int* strides, int k, int B, int H, int W, int* tile_slot, int* tile_list,
+                        int* n_act, void* workspace, void* stream);
+size_t gdmae_conv3x3_tiles_packed_bytes(int k);
+int gdmae_conv3x3_tiles_pack(const float* conv_w, int C2, int Cin, const float* const* b, int k, void* Wp, void* bgz, void* ybg,
+                             void* stream);
+size_t gdmae_conv3x3_tiles_workspace_bytes(int n_act);
+int gdmae_conv3x3_tiles_fwd(const void* const* P, const int* const* maps, const float* const* a, const float* const* b,
+                            const int* strides, int k, const void* Wp, const void* ybg, const int* tile_list, int n_act, int B,
+                            int H, int W, void* Yc, const float* gamma, const float* beta, double eps, double momentum,
+                            float* running_mean, float* running_var, long long* num_batches, double* stats, float* ab,
+                            float* mv, void* workspace, void* stream);
+int gdmae_tiles_gather_rows(const void* Yc, const int* tile_slot, const void* ybg, const int* cell, long long n, int H, int W,
+                            int C, int elem_bytes, void* out, void* stream);
+int gdmae_tiles_to_dense(const void* Yc, const int* tile_slot, const void* ybg, int B, int H, int W, int C, int elem_bytes,
+                         void* out, void* stream);
 
 /* The three row kernels above also serve BatchNorm1d + ReLU of the DynVFE point MLP (site = NULL: identity rows,
  * Z/dZ = a plain (n, C) matrix with z_row_elems = C, col0 = 0).  Fused DynVFE tail (dyn_vfe.py:107-109):
