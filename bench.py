@@ -37,8 +37,8 @@ MFMA_F32_PEAK_TF = 157.3
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch-per-gpu", type=int, default=8, help="frames per GPU per step (gd_mae_ssl.yaml:184)")
     ap.add_argument("--config", default="B", choices=["A", "B", "E"])
     ap.add_argument("--mask-ratio", type=float, default=0.75)
@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--pool", type=int, default=3, help="distinct pre-generated batches cycled through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="skip the extra fp32 / mask-0.85 / H2D-inclusive legs")
     ap.add_argument("--prefetch", type=int, default=1, help="1: build the geometry plan of batch t+1 on a side stream")
     ap.add_argument("--miopen-find", type=int, default=1, help="1: torch.backends.cudnn.benchmark (MIOpen find mode)")
     return ap.parse_args()
@@ -93,53 +94,100 @@ def measure_cpu_baseline(config: str, mask_ratio: float):
     sd = orc.seeded_state_dict(orc.param_shapes(cfg, F), seed=1, requires_grad=True)
     names = sorted(sd)
     opt = oo.AdamOneCycle([sd[k] for k in names])
-    t0 = time.perf_counter()
-    o = orc.forward(pts, 1, cfg, sd, ds.point_cloud_range, ds.voxel_size, ds.grid_size, noise_seed=0)
-    o["loss"].backward()
-    opt.step(*oo.one_cycle(0, 100, 0.003, [0.95, 0.85], 10, 0.4))
-    dt = time.perf_counter() - t0
+    times = []
+    for it in range(4):                               # one un-timed warm-up (allocator, thread pools), then 3 samples
+        for k in names:
+            sd[k].grad = None
+        t0 = time.perf_counter()
+        o = orc.forward(pts, 1, cfg, sd, ds.point_cloud_range, ds.voxel_size, ds.grid_size, noise_seed=0)
+        o["loss"].backward()
+        opt.step(*oo.one_cycle(it, 100, 0.003, [0.95, 0.85], 10, 0.4))
+        if it:
+            times.append(time.perf_counter() - t0)
+    dt = sorted(times)[1]
     return {"value": round(1.0 / dt, 4), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"1 frame of config {config} ({pts.shape[0]} pts), full train step fwd+bwd+Adam in fp32, {dt:.1f} s, "
-                      f"{cores} threads (best of a probe over 8..128; {avail} logical CPUs available)"}
+            "sample": f"1 frame of config {config} ({pts.shape[0]} pts), full train step fwd+bwd+Adam in fp32; median of 3 after one "
+                      f"warm-up step ({', '.join('%.1f' % t for t in times)} s), {cores} threads (best of a probe over 8..128; "
+                      f"{avail} logical CPUs available)"}
+
+
+def _pmc_traffic(kernels):
+    """HBM bytes per launch of `kernels` from the committed rocprofv3 PMC passes of the current round (separate --pmc runs of
+    this same command, tools/collect_profiles.sh): 2 x FETCH_SIZE + WRITE_SIZE (KiB; the x2 is the guide's gfx950
+    correction for wide coalesced reads).  None when the profile files are not there."""
+    import csv
+    import glob
+    try:
+        tags = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_FETCH_SIZE_by_kernel.csv")))
+        if not tags:
+            return None, None
+        fetch = tags[-1]
+        write = fetch.replace("FETCH_SIZE", "WRITE_SIZE")
+        tot = {"FETCH_SIZE": [0.0, 0], "WRITE_SIZE": [0.0, 0]}
+        for tag, path in (("FETCH_SIZE", fetch), ("WRITE_SIZE", write)):
+            for r in csv.DictReader(open(path)):
+                if r["kernel"] in kernels:
+                    tot[tag][0] += float(r[f"sum_{tag}"])
+                    tot[tag][1] += int(r["dispatches"])
+        if tot["FETCH_SIZE"][1] and tot["FETCH_SIZE"][1] == tot["WRITE_SIZE"][1]:
+            return int((2 * tot["FETCH_SIZE"][0] + tot["WRITE_SIZE"][0]) * 1024 / tot["FETCH_SIZE"][1]), os.path.relpath(fetch, REPO)
+    except Exception:
+        pass
+    return None, None
+
+
+# instrumented entry points (gdmae_hip.timing brackets): what bounds them and which device kernels they launch
+ROOFLINE_KERNELS = {
+    "k_conv3x3_tiles": ("mfma", ("k_conv3x3_tiles",)),
+    "k_conv_grad_taps": ("hbm", ("k_conv_grad_taps",)),
+    "k_win_attn_bwd": ("hbm", ("k_win_attn_bwd", "k_attn_mfma_bwd", "k_attn_mfma16_bwd")),
+    "k_win_attn_fwd": ("hbm", ("k_win_attn_fwd", "k_attn_mfma_fwd", "k_attn_mfma16_fwd")),
+}
 
 
 def measure_roofline(step, dev_batches, args, n_steps=4):
-    """HIP-event timing of the dominant hand-written kernel over `n_steps` extra steps (after the timed region).
-
-    Dominant HIP kernel of the step (profiles/r01_kernel_stats.csv): the windowed cosine attention backward
-    (entry point gdmae_window_attention_bwd = k_win_attn_bwd for the T=16 level + k_attn_mfma16_bwd for T=32/64 with
-    bf16 rows; k_attn_mfma_bwd with fp32 rows).
-    Algorithmic bytes per launch = tokens_of_level * (7 * d * elem_size + 4) + 8 * windows (read the q, k, v, dOut
-    rows, write the dq, dk, dv rows, once each, + CSR), DESIGN.md section 4.  achieved = sum(bytes) / sum(duration)
-    over all its launches, timed with HIP events on the launch stream.  `traffic` = measured HBM bytes per launch
-    from the committed rocprofv3 PMC passes (2 x FETCH_SIZE + WRITE_SIZE in KiB, profiles/r01_pmc_*_by_kernel.csv):
-    it equals the algorithmic bytes, i.e. no re-reads - the kernel is latency / issue bound, not bandwidth bound."""
+    """HIP-event timing (events on the launch stream) of the instrumented hand-written kernels over `n_steps` extra steps
+    after the timed region; `roofline` describes the one with the LARGEST TOTAL TIME in this run, the others are listed
+    under "also".  Algorithmic work per launch:
+      k_conv3x3_tiles   executed MFMA flops = active tiles x 64 sites x 128 channels x (9 x Cin) x 2   (bound: bf16 MFMA);
+                        the dense convolution of SURVEY section 8d would be B x H x W sites - reported as dense_equivalent
+      k_conv_grad_taps  active sites x 9 taps x 128 channels x 2 B read + written
+      k_win_attn_*      tokens x (7 | 4) x d x elem + CSR bytes (q, k, v, dOut rows read, dq, dk, dv rows written, once each)
+    `traffic` = HBM bytes per launch from this round's committed rocprofv3 PMC passes (profiles/, see _pmc_traffic)."""
     from gdmae_hip import timing
     with timing.collect() as T:
         for i in range(n_steps):
             step(args.warmup + args.steps, dev_batches[i % args.pool])
         summ = T.summary()
-    k = summ["k_win_attn_bwd"]
-    gbs = k["total_bytes"] / (k["total_ms"] * 1e-3) / 1e9
-    traffic = None
-    try:
-        import csv
-        tot = {"FETCH_SIZE": [0.0, 0], "WRITE_SIZE": [0.0, 0]}
-        for tag in tot:
-            for r in csv.DictReader(open(os.path.join(REPO, "profiles", f"r01_pmc_{tag}_by_kernel.csv"))):
-                if r["kernel"] in ("k_win_attn_bwd", "k_attn_mfma_bwd", "k_attn_mfma16_bwd"):
-                    tot[tag][0] += float(r[f"sum_{tag}"])
-                    tot[tag][1] += int(r["dispatches"])
-        if tot["FETCH_SIZE"][1] and tot["FETCH_SIZE"][1] == tot["WRITE_SIZE"][1]:
-            traffic = int((2 * tot["FETCH_SIZE"][0] + tot["WRITE_SIZE"][0]) * 1024 / tot["FETCH_SIZE"][1])
-    except Exception:
-        traffic = None
-    return {"kernel": "gdmae_window_attention_bwd (k_win_attn_bwd + k_attn_mfma16_bwd)", "bound": "hbm", "achieved": round(gbs, 1),
-            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
-            "launches_per_step": k["launches"] / n_steps, "avg_launch_us": round(k["avg_us"], 2),
-            "algorithmic_bytes_per_launch": int(k["bytes_per_launch"]),
-            "also": {n: {"avg_us": round(v["avg_us"], 2), "GBs": round(v["total_bytes"] / (v["total_ms"] * 1e-3) / 1e9, 1)}
-                     for n, v in summ.items() if n != "k_win_attn_bwd"}}
+    summ = {k: v for k, v in summ.items() if k in ROOFLINE_KERNELS and v["total_ms"] > 0}
+    if not summ:
+        return None
+
+    def describe(name, v):
+        bound, devk = ROOFLINE_KERNELS[name]
+        sec = v["total_ms"] * 1e-3
+        if bound == "mfma":
+            ach, peak, unit = v["total_flops"] / sec / 1e12, MFMA_BF16_PEAK_TF, "TFLOP/s"
+        else:
+            ach, peak, unit = v["total_bytes"] / sec / 1e9, HBM_PEAK_GBS, "GB/s"
+        d = {"kernel": name, "bound": bound, "achieved": round(ach, 1), "peak": peak, "unit": unit, "frac": round(ach / peak, 4),
+             "launches_per_step": v["launches"] / n_steps, "avg_launch_us": round(v["avg_us"], 2),
+             "total_us_per_step": round(1e3 * v["total_ms"] / n_steps, 1)}
+        if bound == "mfma":
+            d["algorithmic_flops_per_launch"] = int(v["flops_per_launch"])
+        else:
+            d["algorithmic_bytes_per_launch"] = int(v["bytes_per_launch"])
+        for k2, val in v.get("extra", {}).items():
+            d[k2] = val
+        return d, devk
+
+    top = max(summ, key=lambda k: summ[k]["total_ms"])
+    out, devk = describe(top, summ[top])
+    out["traffic"], src = _pmc_traffic(devk)
+    if src:
+        out["traffic_source"] = src + " (2 x FETCH_SIZE + WRITE_SIZE per launch, committed rocprofv3 --pmc passes of this command)"
+    out["also"] = {n: describe(n, v)[0] for n, v in summ.items() if n != top}
+    return out
 
 
 def main():
@@ -180,17 +228,18 @@ def main():
     resident = torch.cuda.Event()
     resident.record()                              # every pooled batch is in HBM once this event has completed
     torch.cuda.synchronize()
-    use_bf16 = args.dtype == "bf16"
+    mode = {"bf16": args.dtype == "bf16"}
+    use_bf16 = mode["bf16"]
 
     pending = {}
 
     def step(i, pts, nxt=None, nxt_ready=None):
         opt.zero_grad()
-        bd = {"points": pts, "batch_size": B}
+        bd = {"points": pts, "batch_size": B, "_gdmae_grad_sync": opt.sync}
         if args.prefetch:
             plan = pending.pop(id(pts), None) or net.backbone_3d.prefetch_plan(pts, B).finish()
             bd["_gdmae_vox"], bd["_gdmae_plan"] = plan
-        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=use_bf16):
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=mode["bf16"]):
             ret, tb, _ = net(bd)
         ret["loss"].backward()
         pf = None
@@ -243,9 +292,54 @@ def main():
 
     # the roofline steps run on EVERY rank: they contain the gradient all-reduce, a collective the other ranks must join
     roofline = measure_roofline(step, dev_batches, args) if not args.no_roofline else None
+    vox, ep = bd["_gdmae_vox"], bd["_gdmae_plan"]
+
+    def timed_leg(n_warm, n_timed, feed=None):
+        """frames/s of `n_timed` more steps after `n_warm` untimed ones (single process; used for the extra legs)."""
+        pending.clear()
+        for i in range(n_warm):
+            step(args.warmup + args.steps, dev_batches[i % args.pool])
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        if feed is None:
+            for i in range(n_timed):
+                step(args.warmup + args.steps, dev_batches[i % args.pool],
+                     dev_batches[(i + 1) % args.pool] if i + 1 < n_timed else None, resident)
+        else:
+            feed(n_timed)
+        torch.cuda.synchronize()
+        dtl = time.perf_counter() - t1
+        return {"value": round(B * n_timed / dtl, 2), "unit": "frames/s", "ms_per_step": round(1e3 * dtl / n_timed, 3), "steps": n_timed}
+
+    also = {}
+    if world == 1 and not args.no_also:
+        # ---- SURVEY section 8d step incl. the H2D copy of the point batch: pinned host buffers handed over every step, the
+        #      copy of batch t+1 queued before the kernels of batch t (never the headline value: inputs there are resident)
+        def h2d_feed(k):
+            nxt = pinned[0].to(dev, non_blocking=True)
+            for i in range(k):
+                cur, nxt, ev = nxt, None, None
+                if i + 1 < k:
+                    nxt = pinned[(i + 1) % args.pool].to(dev, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record()
+                step(args.warmup + args.steps, cur, nxt, ev)
+        also["h2d_inclusive"] = timed_leg(2, args.steps, h2d_feed)
+        also["h2d_inclusive"]["note"] = "same step with the 4.3 MB/frame H2D copy of every batch inside the timed region (SURVEY 8d)"
+        # ---- the reference yaml's own mask ratio (tools/cfgs/waymo_models/gd_mae_ssl.yaml:158)
+        other = 0.85 if abs(args.mask_ratio - 0.85) > 1e-6 else 0.75
+        net.backbone_3d.mask_ratio = other
+        also[f"mask_{other}"] = timed_leg(3, max(5, args.steps // 2))
+        net.backbone_3d.mask_ratio = args.mask_ratio
+        # ---- fp32 parity mode (the mode whose loss is held to 1e-4 of the reference by tests/)
+        if mode["bf16"]:
+            mode["bf16"] = False
+            also["fp32_parity_mode"] = timed_leg(3, max(4, args.steps // 4))
+            also["fp32_parity_mode"]["note"] = "no autocast: fp32 rows / GEMMs, dense F.conv2d decoder convolution"
+            mode["bf16"] = True
+        pending.clear()
     if rank == 0:
-        # ---- sizes of the last batch (for the algorithmic byte model)
-        vox, ep = bd["_gdmae_vox"], bd["_gdmae_plan"]
+        # ---- sizes of the last timed batch (for the algorithmic byte model)
         N, M = vox.N / B, vox.M / B
         Ms = [s.n_tok / B for s in ep.stages]
         dsz = [int(b.ENCODER.D_MODEL) for b in cfg.BACKBONE_3D.SST_BLOCK_LIST]
@@ -253,27 +347,24 @@ def main():
         a = 2 if use_bf16 else 4
         bytes_train = 3 * algorithmic_bytes_per_frame(N, M, Ms, dsz, G, a)
         out["config"].update({"points_per_frame": int(N), "pillars_per_frame": int(M), "tokens_per_frame": [int(m) for m in Ms]})
+        if ep.dec_tiles is not None:
+            nt = B * ((int(ds.grid_size[1]) + 7) // 8) * ((int(ds.grid_size[0]) + 7) // 8)
+            out["config"]["decoder_active_tiles"] = f"{ep.dec_tiles.n_act} of {nt}"
         out["step_bytes_model"] = {"bytes_train_per_frame": int(bytes_train), "achieved_GBs": round(bytes_train * fps / world / 1e9, 1),
                                    "frac_of_8TBs": round(bytes_train * fps / world / 1e9 / HBM_PEAK_GBS, 4),
-                                   "note": "SURVEY §8d whole-step algorithmic bytes x frames/s per GPU"}
+                                   "note": "SURVEY 8d whole-step algorithmic bytes (dense-decoder formula) x frames/s per GPU"}
+        if world > 1:
+            out["grad_sync"] = {"buckets": [[b, hi - lo] for b, lo, hi in opt.buckets], "last_step": opt.sync.log,
+                                "note": "one all-reduce per bucket; 'overlapped' = launched on the communication stream from inside "
+                                        "backward(), 'tail' = after it"}
         if roofline is not None:
             out["roofline"] = roofline
-        # ---- PCIe-inclusive variant (host buffers handed over every step); never the headline value
-        sync_all_local = torch.cuda.synchronize
-        sync_all_local()
-        if world == 1:
-            t1 = time.perf_counter()
-            k = max(3, args.steps // 4)
-            nxt = pinned[0].to(dev, non_blocking=True)
-            for i in range(k):
-                cur, nxt, ev = nxt, None, None
-                if i + 1 < k:                          # next batch's H2D copy is queued before this step's kernels
-                    nxt = pinned[(i + 1) % args.pool].to(dev, non_blocking=True)
-                    ev = torch.cuda.Event()
-                    ev.record()
-                step(args.warmup + args.steps, cur, nxt, ev)
-            sync_all_local()
-            out["h2d_inclusive"] = {"value": round(B * k / (time.perf_counter() - t1), 2), "unit": "frames/s"}
+        shares = os.path.join(REPO, "profiles", "class_shares.json")
+        if os.path.exists(shares):
+            out["kernel_time_shares"] = json.load(open(shares))
+        if also:
+            out["also"] = also
+            out["h2d_inclusive"] = also["h2d_inclusive"]
         if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (rank 0's host cores)
             out["cpu_baseline"] = measure_cpu_baseline(args.config, args.mask_ratio)
         print(json.dumps(out), flush=True)

@@ -19,30 +19,36 @@ __global__ __launch_bounds__(256) void k_sq_partials(const float* __restrict__ g
   if (threadIdx.x == 0) part[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
 }
 
+#define GD_ADAM_MAX_SEG 16
 struct AdamArgs {
   float lr, beta1, beta2, eps, wd, max_norm;
   float bc1, bc2_sqrt;  // 1 - beta1^t, sqrt(1 - beta2^t)
+  float grad_scale;     // 1 / world size: the all-reduce SUMS, the average is folded in here
+  int nseg;
+  long long seg_begin[GD_ADAM_MAX_SEG], seg_end[GD_ADAM_MAX_SEG];   // optimised element ranges of the flat buffers
 };
 
 __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                              float* __restrict__ v, long long n, AdamArgs A,
-                                              const float* __restrict__ sq_norm) {
-  float coef = 1.f;
+                                              float* __restrict__ v, AdamArgs A, const float* __restrict__ sq_norm) {
+  float coef = A.grad_scale;
   if (A.max_norm > 0.f) {
-    const float total = sqrtf(*sq_norm);
-    coef = fminf(A.max_norm / (total + 1e-6f), 1.f);
+    const float total = sqrtf(*sq_norm) * A.grad_scale;      // norm of the AVERAGED gradient
+    coef *= fminf(A.max_norm / (total + 1e-6f), 1.f);
   }
   const float decay = 1.f - A.wd * A.lr;
   const float step = A.lr / A.bc1;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-    const float gi = g[i] * coef;
-    float pi = p[i] * decay;
-    const float mi = A.beta1 * m[i] + (1.f - A.beta1) * gi;
-    const float vi = A.beta2 * v[i] + (1.f - A.beta2) * gi * gi;
-    m[i] = mi;
-    v[i] = vi;
-    const float denom = sqrtf(vi) / A.bc2_sqrt + A.eps;
-    p[i] = pi - step * (mi / denom);
+  for (int s = 0; s < A.nseg; ++s) {
+    const long long e = A.seg_end[s];
+    for (long long i = A.seg_begin[s] + blockIdx.x * (long long)blockDim.x + threadIdx.x; i < e; i += (long long)gridDim.x * blockDim.x) {
+      const float gi = g[i] * coef;
+      float pi = p[i] * decay;
+      const float mi = A.beta1 * m[i] + (1.f - A.beta1) * gi;
+      const float vi = A.beta2 * v[i] + (1.f - A.beta2) * gi * gi;
+      m[i] = mi;
+      v[i] = vi;
+      const float denom = sqrtf(vi) / A.bc2_sqrt + A.eps;
+      p[i] = pi - step * (mi / denom);
+    }
   }
 }
 
@@ -57,10 +63,14 @@ extern "C" int gdmae_grad_sq_norm(const float* grad, long long n, float* partial
   return gdmae_sum_partials(partials, nb, 1.f, sq_norm_out, 0, stream);
 }
 
-extern "C" int gdmae_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr,
-                               float beta1, float beta2, float eps, float weight_decay, int step, float max_norm,
-                               const float* sq_norm, void* stream) {
+// segments: HOST array of 2 * n_segments element offsets [begin, end) into the flat buffers (the parameters that are
+// optimised; everything else only takes part in the norm).  grad_scale multiplies the gradient (and the norm) first:
+// 1 / world size after a SUM all-reduce.
+extern "C" int gdmae_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const long long* segments,
+                               int n_segments, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                               float max_norm, float grad_scale, const float* sq_norm, void* stream) {
   GD_REQUIRE(step >= 1, "step counts from 1");
+  GD_REQUIRE(n_segments >= 0 && n_segments <= GD_ADAM_MAX_SEG, "adam_step: at most 16 segments");
   AdamArgs A;
   A.lr = lr;
   A.beta1 = beta1;
@@ -68,12 +78,24 @@ extern "C" int gdmae_adam_step(float* param, const float* grad, float* exp_avg, 
   A.eps = eps;
   A.wd = weight_decay;
   A.max_norm = max_norm;
+  A.grad_scale = grad_scale;
   A.bc1 = (float)(1.0 - pow((double)beta1, (double)step));
   A.bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
-  int grid = gd_div_up(n, 256);
+  long long longest = 0;
+  A.nseg = 0;
+  for (int s = 0; s < n_segments; ++s) {
+    const long long b = segments[2 * s], e = segments[2 * s + 1];
+    GD_REQUIRE(b >= 0 && e >= b, "adam_step: bad segment");
+    if (e == b) continue;
+    A.seg_begin[A.nseg] = b;
+    A.seg_end[A.nseg] = e;
+    ++A.nseg;
+    if (e - b > longest) longest = e - b;
+  }
+  if (A.nseg == 0) return 0;                       // nothing to optimise
+  int grid = gd_div_up(longest, 256);
   if (grid > 4096) grid = 4096;
-  hipLaunchKernelGGL(k_adam, dim3(grid), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, A,
-                     sq_norm);
+  hipLaunchKernelGGL(k_adam, dim3(grid), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, A, sq_norm);
   GD_LAUNCH_CHECK();
   return 0;
 }

@@ -56,7 +56,9 @@ def build(force: bool = False, verbose: bool = True) -> str:
             print(out.decode())
     if failed:
         raise RuntimeError("hipcc failed")
-    if force or procs or not os.path.exists(LIB):
+    # relink when anything was recompiled, the library is missing, or an object is newer than it (objects travel to the
+    # GPU box separately; an interrupted link must not leave a stale library behind)
+    if force or procs or not os.path.exists(LIB) or any(_newer(o, LIB) for o in objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-L/opt/rocm/lib", "-lhipblaslt"]
         if verbose:
             print(" ".join(cmd), flush=True)

@@ -37,6 +37,7 @@ from . import bn as gbn
 from . import lib as L
 from . import ops
 from . import plan as gplan
+from . import timing
 
 BN_EPS, BN_MOM = 1e-3, 0.01
 
@@ -159,10 +160,13 @@ class DecoderHead(torch.autograd.Function):
             mom = 0.0
             if bn2 is not None and bn2.training and bn2.running_mean is not None:
                 rm, rv, nb, mom = bn2.running_mean, bn2.running_var, bn2.num_batches_tracked, float(bn2.momentum)
-            L.call("gdmae_conv3x3_tiles_fwd", L.host_ptrs([P.contiguous() for P in Ps]), L.host_ptrs(maps), L.host_ptrs(a_l),
-                   L.host_ptrs(b_l), L.host_i32(ups), k, L.ptr(Wp), L.ptr(ybg), L.ptr(dt.tile_list), dt.n_act, B, H, W, L.ptr(y2),
-                   L.ptr(gamma2), L.ptr(beta2), float(eps2), mom, L.ptr(rm), L.ptr(rv), L.ptr(nb), L.ptr(stats2), L.ptr(ab2),
-                   L.ptr(mv2), L.ptr(ws), L.stream())
+            flops = 2.0 * dt.n_act * 64 * C2 * 9 * Cin
+            with timing.kernel("k_conv3x3_tiles", dt.n_act * 64 * (Cin + C2) * 2, flops,
+                               {"dense_equivalent_TFLOPs_per_launch": round(2.0 * R * C2 * 9 * Cin / 1e12, 4), "active_tiles": dt.n_act}):
+                L.call("gdmae_conv3x3_tiles_fwd", L.host_ptrs([P.contiguous() for P in Ps]), L.host_ptrs(maps), L.host_ptrs(a_l),
+                       L.host_ptrs(b_l), L.host_i32(ups), k, L.ptr(Wp), L.ptr(ybg), L.ptr(dt.tile_list), dt.n_act, B, H, W,
+                       L.ptr(y2), L.ptr(gamma2), L.ptr(beta2), float(eps2), mom, L.ptr(rm), L.ptr(rv), L.ptr(nb), L.ptr(stats2),
+                       L.ptr(ab2), L.ptr(mv2), L.ptr(ws), L.stream())
             M = pillar_cell.numel()
             yrows = torch.empty(M, C2, dtype=cdt, device=dev)
             L.call("gdmae_tiles_gather_rows", L.ptr(y2), L.ptr(dt.tile_slot), L.ptr(ybg), L.ptr(pillar_cell), M, H, W, C2, 2,
@@ -264,8 +268,9 @@ class DecoderHead(torch.autograd.Function):
             n = P.shape[0]
             ab = ab_l[i]
             G = torch.empty(n, 9 * C2, dtype=cdt, device=dev)
-            L.call("gdmae_conv3x3_grad_taps", L.ptr(y2), _bf(y2), L.ptr(tile_slot), L.ptr(ybg), L.ptr(k01), L.ptr(k01[C2:]),
-                   L.ptr(rows), L.ptr(cell2pillar), L.ptr(sites[i]), n, H, W, C2, L.ptr(G), L.stream())
+            with timing.kernel("k_conv_grad_taps", 2.0 * n * 9 * C2 * G.element_size()):
+                L.call("gdmae_conv3x3_grad_taps", L.ptr(y2), _bf(y2), L.ptr(tile_slot), L.ptr(ybg), L.ptr(k01), L.ptr(k01[C2:]),
+                       L.ptr(rows), L.ptr(cell2pillar), L.ptr(sites[i]), n, H, W, C2, L.ptr(G), L.stream())
             dX = ops.mm(G, Wd[:, :, col:col + w].reshape(9 * C2, w))      # dZ rows of this stage's active sites
             if Z is not None:
                 Zrows = _gather_slice(Z, sites[i], col, w)

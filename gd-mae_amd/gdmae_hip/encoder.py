@@ -251,9 +251,10 @@ def _param_args(plist, cdt, direct):
         return sh is not None and sh[1] == base._version
     stable = all(t is not None for t in direct) and all(_persistent(t) for t in (Win, bin_, Wo, bo, W1, b1, W2, b2))
     cache = getattr(Win, "_gd_layer_args", None)       # lives (and dies) with the layer's in-projection parameter
+    versions = tuple(t._version for t in (Win, bin_, Wo, bo, W1, b1, W2, b2))   # every shadowed parameter, not only Win
     if stable and cache is not None:
         hit = cache.get(cdt)
-        if hit is not None and hit[2] == Win._version and hit[3] == direct[0].data_ptr():
+        if hit is not None and hit[2] == versions and hit[3] == direct[0].data_ptr():
             return hit[0], hit[1]
     sh = lambda t: ops.shadow(t, cdt).contiguous()   # noqa: E731
     tensors = {"Win": sh(Win), "bin": sh(bin_), "Wo": sh(Wo), "bo": sh(bo), "W1": sh(W1), "b1": sh(b1), "W2": sh(W2), "b2": sh(b2),
@@ -268,7 +269,7 @@ def _param_args(plist, cdt, direct):
         # the shadows are refreshed in place by the optimizer; a changed version only matters for pointer identity
         if cache is None:
             cache = Win._gd_layer_args = {}
-        cache[cdt] = (a, tensors, Win._version, direct[0].data_ptr())
+        cache[cdt] = (a, tensors, versions, direct[0].data_ptr())
     return a, tensors
 
 

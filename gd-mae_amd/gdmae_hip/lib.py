@@ -104,7 +104,7 @@ SIGNATURES = {
     "gdmae_ingroup_inds": (_I, [_P, _L, _L, _P, _P, _Z, _P]),
     "gdmae_group_inner_inds": (_I, [_P, _L, _L, _I, _P, _P, _Z, _P]),
     "gdmae_grad_sq_norm": (_I, [_P, _L, _P, _P, _P]),
-    "gdmae_adam_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _P, _P]),
+    "gdmae_adam_step": (_I, [_P, _P, _P, _P, _P, _I, _F, _F, _F, _F, _F, _I, _F, _F, _P, _P]),
 }
 
 class LayerArgs(C.Structure):
@@ -168,6 +168,10 @@ def host_f32(vals):
 
 def host_i32(vals):
     return (C.c_int * len(vals))(*[int(v) for v in vals])
+
+
+def host_i64(vals):
+    return (C.c_longlong * len(vals))(*[int(v) for v in vals])
 
 
 def host_ptrs(tensors):

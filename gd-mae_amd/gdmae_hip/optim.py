@@ -36,34 +36,74 @@ def one_cycle(step: int, total_step: int, lr_max: float, moms, div_factor: float
     return lr, mom
 
 
+def default_bucket_of(name: str) -> str:
+    """Gradient-exchange bucket of a parameter name = the unit whose backward finishes together: every SST stage
+    (``backbone_3d.sst_blocks.<i>``) is one bucket, everything else goes by its top-level module, with the decoder
+    (``backbone_3d.decoder_*``) as one bucket of its own."""
+    parts = name.split(".")
+    if len(parts) >= 3 and parts[1] == "sst_blocks":
+        return ".".join(parts[:3])
+    if len(parts) >= 2 and parts[1].startswith("decoder"):
+        return parts[0] + ".decoder"
+    return parts[0]
+
+
 class FlatAdamOneCycle:
-    """Owns flat fp32 parameter / gradient / moment buffers; model parameters become views into them."""
+    """Owns flat fp32 parameter / gradient / moment buffers; model parameters become views into them.
+
+    Layout: parameters are grouped into BUCKETS (``bucket_of(name)``, registration order = forward order, so the backward
+    completes them last-to-first); inside a bucket the parameters the reference optimises come first, the ones it leaves
+    untouched (see ``reference_layer_groups``) after them.  Each bucket is one contiguous range of the flat gradient =
+    one all-reduce, which ``GradSync`` launches on a communication stream as soon as the backward has passed the
+    bucket (DDP's bucketed, overlapped reducer - reference tools/train.py:146 - without flatten / unflatten copies)."""
 
     def __init__(self, model: torch.nn.Module, optim_cfg, total_steps: int, process_group=None,
-                 reference_layer_groups: bool = True):
+                 reference_layer_groups: bool = True, bucket_of=default_bucket_of):
         """``reference_layer_groups`` (default, = what the reference trains): build_optimizer('adam_onecycle') collects
         the optimizer's parameters with ``flatten_model`` = the LEAF modules of the model
         (tools/train_utils/optimization/__init__.py:20-31, fastai_optim.py:16-27,115-122), so parameters registered
         directly on a module that also has children are never updated: for this model the 36 tensors
         ``win_attn.self_attn.{in_proj_weight, in_proj_bias, tau}`` (1.78 M of 8.09 M parameters; verified against the
         imported reference, tests/golden/optimizer_params.json).  Their gradients still enter the global clip norm
-        (``clip_grad_norm_(model.parameters())``, train_utils.py:52) and the all-reduce.  They are placed at the end of
-        the flat buffers and the Adam launch stops before them.  False: every parameter is optimised."""
-        params = [p for p in model.parameters() if p.requires_grad]
-        assert params and all(p.dtype == torch.float32 for p in params)
+        (``clip_grad_norm_(model.parameters())``, train_utils.py:52) and the all-reduce.  The Adam launch covers only the
+        optimised range of every bucket.  False: every parameter is optimised."""
+        named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+        assert named and all(p.dtype == torch.float32 for _, p in named)
         if reference_layer_groups:
             leaf_owned = {id(p) for m in model.modules() if not any(True for _ in m.children())
                           for p in m.parameters(recurse=False)}
-            frozen = [p for p in params if id(p) not in leaf_owned]
-            params = [p for p in params if id(p) in leaf_owned] + frozen
         else:
-            frozen = []
+            leaf_owned = {id(p) for _, p in named}
+        order, groups = [], {}
+        for n, p in named:
+            b = bucket_of(n)
+            if b not in groups:
+                groups[b] = ([], [])
+                order.append(b)
+            groups[b][0 if id(p) in leaf_owned else 1].append(p)
+        params, frozen, self.buckets, self.segments = [], [], [], []
+        off = 0
+        for b in order:
+            opt_p, frz_p = groups[b]
+            n_opt = sum(p.numel() for p in opt_p)
+            n_all = n_opt + sum(p.numel() for p in frz_p)
+            self.buckets.append((b, off, off + n_all))
+            self.segments += [off, off + n_opt]
+            params += opt_p + frz_p
+            frozen += frz_p
+            off += n_all
+        assert len(self.buckets) <= 16, "at most 16 gradient buckets (gdmae_adam_step segments)"
         self.frozen = frozen
         self.model = model
         dev = params[0].device
-        n = sum(p.numel() for p in params)
+        n = off
         self.n = n
         self.n_opt = n - sum(p.numel() for p in frozen)
+        if frozen:
+            import logging
+            logging.getLogger(__name__).info(
+                "FlatAdamOneCycle: %d of %d parameters (%d tensors registered on non-leaf modules) are NOT optimised, as in the "
+                "reference's adam_onecycle (pass reference_layer_groups=False to train them)", n - self.n_opt, n, len(frozen))
         self.flat_param = torch.empty(n, dtype=torch.float32, device=dev)
         self.flat_grad = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
@@ -85,6 +125,8 @@ class FlatAdamOneCycle:
         self.pg = process_group
         self._part = torch.empty(1024, dtype=torch.float32, device=dev)
         self._sq = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._grad_scale = 1.0
+        self.sync = GradSync(self)
 
     def _refresh_shadows(self):
         """One cast of the flat buffer -> bf16 views per parameter (consumed by gdmae_hip.ops.shadow)."""
@@ -95,28 +137,42 @@ class FlatAdamOneCycle:
             p._gd_shadow = (self.flat_param_bf16[off:off + k].view(p.shape), p._version)
             off += k
 
+    def _check_views(self):
+        for p in self.params:
+            if p.grad is not p._gd_flat_grad:
+                raise RuntimeError("a parameter lost its flat gradient view (model.zero_grad() / set_to_none=True?): its "
+                                   "gradient would not reach the optimizer - use FlatAdamOneCycle.zero_grad()")
+
     def zero_grad(self):
+        self._check_views()
         self.flat_grad.zero_()
-        for p in self.params:            # keep .grad pointing at the flat views
-            if p.grad is None:
-                raise RuntimeError("a parameter lost its flat gradient view (zero_grad(set_to_none=True)?)")
+        self.sync.begin_step()
+
+    def world_size(self):
+        return dist.get_world_size(self.pg) if (dist.is_available() and dist.is_initialized()) else 1
 
     def all_reduce_grads(self):
-        """Sum-all-reduce the flat gradient over the data-parallel group and average (DDP semantics)."""
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.pg) > 1:
-            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.pg)
-            self.flat_grad.div_(dist.get_world_size(self.pg))
+        """Finish the data-parallel gradient exchange of this step: buckets that ``GradSync`` already launched from inside
+        the backward are waited for, the others are all-reduced now.  The buffer then holds the SUM over ranks; the
+        division by the world size is folded into the Adam launch (DDP averaging semantics without a pass of its own)."""
+        self.sync.finish()
+        self._grad_scale = 1.0 / self.world_size()
 
     def step(self, accumulated_iter: int | None = None):
+        self._check_views()
         it = self.t if accumulated_iter is None else accumulated_iter
         c = self.cfg
         lr, beta1 = one_cycle(it, self.total_steps, c.LR, list(c.MOMS), c.DIV_FACTOR, c.PCT_START)
         self.t += 1
-        st = L.stream()
-        L.call("gdmae_grad_sq_norm", L.ptr(self.flat_grad), self.n, L.ptr(self._part), L.ptr(self._sq), st)
-        L.call("gdmae_adam_step", L.ptr(self.flat_param), L.ptr(self.flat_grad), L.ptr(self.exp_avg),
-               L.ptr(self.exp_avg_sq), self.n_opt, float(lr), float(beta1), 0.99, 1e-8, float(c.WEIGHT_DECAY), self.t,
-               float(c.GRAD_NORM_CLIP), L.ptr(self._sq), st)
+        if self.flat_param.is_cuda:
+            st = L.stream()
+            L.call("gdmae_grad_sq_norm", L.ptr(self.flat_grad), self.n, L.ptr(self._part), L.ptr(self._sq), st)
+            L.call("gdmae_adam_step", L.ptr(self.flat_param), L.ptr(self.flat_grad), L.ptr(self.exp_avg),
+                   L.ptr(self.exp_avg_sq), L.host_i64(self.segments), len(self.segments) // 2, float(lr), float(beta1), 0.99, 1e-8,
+                   float(c.WEIGHT_DECAY), self.t, float(c.GRAD_NORM_CLIP), float(self._grad_scale), L.ptr(self._sq), st)
+        else:
+            raise RuntimeError("FlatAdamOneCycle.step needs the HIP library and device buffers (no CPU fallback)")
+        self._grad_scale = 1.0
         self._refresh_shadows()
         return lr, beta1
 
@@ -179,3 +235,74 @@ class FlatAdamOneCycle:
             steps.add(int(st["step"]))
         assert len(steps) <= 1, f"optimizer state with different step counts per tensor: {steps}"
         self.t = steps.pop() if steps else 0
+
+
+class GradSync:
+    """Bucketed gradient all-reduce overlapped with the backward (north_star: 'RCCL all-reduce of grads over xGMI overlapped
+    with backward'; reference = DDP's reducer, tools/train.py:146).
+
+    The hand-written backwards of this path write most weight gradients straight into the flat buffer, so parameter
+    hooks never fire; instead the model marks ACTIVATIONS: ``mark(tensor, bucket_names)`` registers a tensor hook that
+    runs when autograd delivers the gradient of that tensor, i.e. when every backward node created after it in the forward
+    has been enqueued - at that point the named buckets (the stages after that tensor, the decoder) are complete on the
+    compute stream.  The hook records an event there, makes the communication stream wait for it and launches one
+    asynchronous all-reduce per bucket on it; ``finish()`` (from ``all_reduce_grads``) reduces whatever was not marked and
+    orders the compute stream behind the communication stream.  With one rank nothing is launched."""
+
+    def __init__(self, opt: "FlatAdamOneCycle"):
+        self.opt = opt
+        self.launched = set()
+        self.works = []
+        self._comm = None
+        self.log = []            # (bucket name, 'overlapped' | 'tail') of the last step: what the tests look at
+
+    def _active(self):
+        return self.opt.world_size() > 1
+
+    def begin_step(self):
+        self.launched, self.works, self.log = set(), [], []
+
+    def bucket_names(self):
+        return [b for b, _, _ in self.opt.buckets]
+
+    def mark(self, tensor: torch.Tensor, done_buckets):
+        """Call in the forward: when the backward reaches ``tensor``, the buckets in ``done_buckets`` are complete."""
+        if not (self._active() and tensor.requires_grad):
+            return
+        names = list(done_buckets)
+
+        def hook(_g):
+            self.reduce(names, "overlapped")
+            return None
+        tensor.register_hook(hook)
+
+    def reduce(self, names, how):
+        opt = self.opt
+        cuda = opt.flat_grad.is_cuda
+        if cuda:
+            if self._comm is None:
+                self._comm = torch.cuda.Stream(device=opt.flat_grad.device)
+            ev = torch.cuda.Event()
+            ev.record()                                   # everything enqueued so far on the compute stream
+            self._comm.wait_event(ev)
+        for b, lo, hi in opt.buckets:
+            if b not in names or b in self.launched or hi == lo:
+                continue
+            self.launched.add(b)
+            self.log.append((b, how))
+            view = opt.flat_grad[lo:hi]
+            if cuda:
+                with torch.cuda.stream(self._comm):
+                    self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=opt.pg, async_op=True))
+            else:
+                self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=opt.pg, async_op=True))
+
+    def finish(self):
+        if not self._active():
+            return
+        self.reduce(self.bucket_names(), "tail")
+        for w in self.works:
+            w.wait()                                      # NCCL/RCCL: orders the CURRENT stream behind the collective
+        if self.opt.flat_grad.is_cuda and self._comm is not None:
+            torch.cuda.current_stream().wait_stream(self._comm)
+        self.works = []

@@ -13,16 +13,18 @@ _ACTIVE = None
 
 class KernelTimers:
     def __init__(self):
-        self.records = {}     # name -> list of (start_event, end_event, algorithmic_bytes)
+        self.records = {}     # name -> list of (start_event, end_event, algorithmic_bytes, algorithmic_flops, extra)
 
     def summary(self):
         torch.cuda.synchronize()
         out = {}
         for name, recs in self.records.items():
-            ms = [s.elapsed_time(e) for s, e, _ in recs]
-            by = [b for _, _, b in recs]
+            ms = [r[0].elapsed_time(r[1]) for r in recs]
+            by = [r[2] for r in recs]
+            fl = [r[3] for r in recs]
             out[name] = {"launches": len(recs), "total_ms": sum(ms), "avg_us": 1e3 * sum(ms) / max(len(ms), 1),
-                         "bytes_per_launch": sum(by) / max(len(by), 1), "total_bytes": sum(by)}
+                         "bytes_per_launch": sum(by) / max(len(by), 1), "total_bytes": sum(by),
+                         "flops_per_launch": sum(fl) / max(len(fl), 1), "total_flops": sum(fl), "extra": recs[-1][4]}
         return out
 
 
@@ -41,7 +43,7 @@ def collect():
 
 
 @contextlib.contextmanager
-def kernel(name: str, algorithmic_bytes: float):
+def kernel(name: str, algorithmic_bytes: float, flops: float = 0.0, extra=None):
     if _ACTIVE is None:
         yield
         return
@@ -49,4 +51,4 @@ def kernel(name: str, algorithmic_bytes: float):
     s.record()
     yield
     e.record()
-    _ACTIVE.records.setdefault(name, []).append((s, e, float(algorithmic_bytes)))
+    _ACTIVE.records.setdefault(name, []).append((s, e, float(algorithmic_bytes), float(flops), extra or {}))

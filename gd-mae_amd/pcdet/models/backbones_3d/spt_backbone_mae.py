@@ -55,10 +55,17 @@ class SPTBackboneMAE(nn.Module):
         batch_dict['voxel_mae_mask'] = ep.mask
         batch_dict['_gdmae_plan'] = ep
         x = SparseConvTensor(ops.GatherUnique.apply(all_feat, ep.tok_pillar), ep, 0)
+        # data-parallel gradient exchange overlapped with the backward (gdmae_hip.optim.GradSync): when autograd delivers
+        # the gradient of a stage's INPUT, that stage (and everything after it) has finished its weight gradients
+        sync = batch_dict.get('_gdmae_grad_sync', None)
         hidden = []
-        for blk in self.sst_blocks:
+        for i, blk in enumerate(self.sst_blocks):
+            if sync is not None:
+                sync.mark(x.features, [f'backbone_3d.sst_blocks.{i}'])
             x = blk(x)
             hidden.append(x)
+        if sync is not None:
+            sync.mark(x.features, ['backbone_3d.decoder'])
         feats, strides = {}, {}
         Y0 = int(self.sparse_shape[0])
         for i, h in enumerate(hidden):

@@ -75,10 +75,31 @@ class Detector3DTemplate(nn.Module):
 
     # ---- checkpoints (reference-compatible dict: model_state / optimizer_state / epoch / it / version)
     def _load_state_dict(self, model_state_disk, *, strict=True):
+        """Load by key + shape (reference detector3d_template.py:360-388).  Sparse-conv weights saved by another spconv
+        generation are re-laid first: a tensor whose last two axes are swapped w.r.t. ours (spconv 1.x keeps (..., Cin, Cout))
+        is transposed; failing that, the kernel-first layout (k.., Cin, Cout) is rotated to ours (Cout, k.., Cin) - the
+        reference does this for 5-D (3-D conv) weights only and asserts otherwise, the 2-D convolutions of this path get the
+        same treatment.  With ``strict`` the FILTERED dict is what ``load_state_dict`` sees, so keys of ours that the file
+        does not cover raise, while foreign / mis-shaped keys of the file are ignored - exactly the reference's behaviour."""
+        from ...utils.spconv_utils import find_all_spconv_keys
         state_dict = self.state_dict()
-        update = {k: v for k, v in model_state_disk.items() if k in state_dict and state_dict[k].shape == v.shape}
+        sparse_keys = find_all_spconv_keys(self)
+        update = {}
+        for key, val in model_state_disk.items():
+            want = state_dict.get(key, None)
+            if want is None:
+                continue
+            if key in sparse_keys and want.shape != val.shape and val.dim() == want.dim():
+                swapped = val.transpose(-1, -2)
+                rotated = val.permute(val.dim() - 1, *range(val.dim() - 1))
+                if swapped.shape == want.shape:
+                    val = swapped.contiguous()
+                elif rotated.shape == want.shape:
+                    val = rotated.contiguous()
+            if want.shape == val.shape:
+                update[key] = val
         if strict:
-            self.load_state_dict(model_state_disk)
+            self.load_state_dict(update)
         else:
             state_dict.update(update)
             self.load_state_dict(state_dict)

@@ -461,9 +461,12 @@ int gdmae_group_inner_inds(const long long* inverse_inds, long long n, long long
  * Replaces clip_grad_norm_ (tools/train_utils/train_utils.py:52) and OptimWrapper.step
  * (tools/train_utils/optimization/fastai_optim.py:135-152: p *= 1 - wd*lr, then torch Adam). */
 int gdmae_grad_sq_norm(const float* grad, long long n, float* partials /* >= 1024 */, float* sq_norm_out, void* stream);
-int gdmae_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr,
-                    float beta1, float beta2, float eps, float weight_decay, int step, float max_norm,
-                    const float* sq_norm, void* stream);
+/* segments: HOST array of 2 * n_segments element offsets [begin, end) of the optimised ranges of the flat buffers (<= 16;
+ * parameters outside them only take part in the clip norm); grad_scale multiplies gradient and norm first (1 / world size
+ * after a SUM all-reduce, so that no separate averaging pass over the 32 MB buffer is needed). */
+int gdmae_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const long long* segments,
+                    int n_segments, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                    float max_norm, float grad_scale, const float* sq_norm, void* stream);
 
 #ifdef __cplusplus
 }

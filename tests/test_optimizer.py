@@ -103,9 +103,22 @@ def test_optimised_parameter_set_equals_the_reference():
     assert sorted(names[id(p)] for p in opt.params if id(p) not in frozen_ids) == sorted(g["optimised_non_bn"] + g["optimised_bn"])
     assert opt.n == g["numel_total"] and opt.n - opt.n_opt == g["numel_skipped"]
     assert all(n.endswith(("in_proj_weight", "in_proj_bias", "tau")) for n in g["skipped"])
-    # the frozen tensors are the tail of the flat buffers
-    tail = opt.flat_param[opt.n_opt:]
-    assert opt.frozen[0].data_ptr() == tail.data_ptr()
+    # layout: one contiguous range per gradient bucket (VFE, the three SST stages, the decoder - forward order), inside a
+    # bucket the optimised parameters first; the Adam segments are exactly the optimised ranges
+    assert [b for b, _, _ in opt.buckets] == ["vfe", "backbone_3d.sst_blocks.0", "backbone_3d.sst_blocks.1",
+                                              "backbone_3d.sst_blocks.2", "backbone_3d.decoder"]
+    assert opt.buckets[0][1] == 0 and opt.buckets[-1][2] == opt.n
+    assert all(a[2] == b[1] for a, b in zip(opt.buckets, opt.buckets[1:]))
+    seg = list(zip(opt.segments[0::2], opt.segments[1::2]))
+    assert sum(e - b for b, e in seg) == opt.n_opt
+    table = opt._offsets()
+    for q in opt.params:
+        o, k = table[id(q)]
+        inside = any(b <= o and o + k <= e for b, e in seg)
+        assert inside == (id(q) not in frozen_ids), names[id(q)]
+        bname = optim.default_bucket_of(names[id(q)])
+        lo, hi = next((lo, hi) for b, lo, hi in opt.buckets if b == bname)
+        assert lo <= o and o + k <= hi
 
 
 @pytest.mark.gpu
@@ -173,4 +186,49 @@ def test_checkpoint_wire_format_round_trips_through_torch_adam(tmp_path):
                str(tmp_path / "ref.pth"))
     it, ep = net2.load_params_with_optimizer(str(tmp_path / "ref.pth"), to_cpu=True, optimizer=opt2, logger=log)
     assert (it, ep) == (3, 2) and opt2.t == 3
-    assert torch.equal(opt2.exp_avg[:opt2.n_opt], opt.exp_avg[:opt.n_opt]) and torch.equal(opt2.flat_param, opt.flat_param)
+    for b, e in zip(opt.segments[0::2], opt.segments[1::2]):
+        assert torch.equal(opt2.exp_avg[b:e], opt.exp_avg[b:e])
+    assert opt2.segments == opt.segments and torch.equal(opt2.flat_param, opt.flat_param)
+
+
+def test_checkpoint_loader_adapts_sparse_conv_layouts_and_filters_like_the_reference(tmp_path):
+    """f4: ``_load_state_dict`` (reference detector3d_template.py:360-388): sparse-conv weights stored with the last two axes
+    swapped or kernel-first (another spconv generation) are re-laid, foreign / mis-shaped keys are ignored, and with
+    ``strict`` the FILTERED dict is what must cover the model."""
+    import logging
+    from pcdet.models import build_network
+    from pcdet.utils.spconv_utils import find_all_spconv_keys
+    cfg, ds, _ = configs.named_config("A")
+    log = logging.getLogger("t")
+    torch.manual_seed(0)
+    net = build_network(cfg, len(ds.class_names), ds, log)
+    keys = sorted(find_all_spconv_keys(net))
+    assert keys and all(k.endswith("weight") for k in keys)
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    disk = dict(sd)
+    k0 = keys[0]
+    disk[k0] = sd[k0].permute(1, 2, 3, 0).contiguous()                  # (kH, kW, Cin, Cout): spconv-1.x kernel-first layout
+    disk["some.foreign.key"] = torch.zeros(3)
+    disk["vfe.dvfe_mlps.0.0.weight"] = torch.zeros(5, 5)               # mis-shaped: must be ignored, not loaded
+    torch.manual_seed(1)
+    net2 = build_network(cfg, len(ds.class_names), ds, log)
+    w_before = net2.state_dict()["vfe.dvfe_mlps.0.0.weight"].clone()
+    state, update = net2._load_state_dict(disk, strict=False)
+    assert "some.foreign.key" not in update and "vfe.dvfe_mlps.0.0.weight" not in update and k0 in update
+    assert torch.equal(net2.state_dict()[k0], sd[k0])
+    assert torch.equal(net2.state_dict()["vfe.dvfe_mlps.0.0.weight"], w_before)
+    if sd[k0].shape[0] == sd[k0].shape[3]:                               # square: the swapped-axes form has the same shape
+        pass
+    else:
+        disk2 = dict(sd)
+        disk2[k0] = sd[k0].transpose(-1, -2).contiguous() if sd[k0].transpose(-1, -2).shape != sd[k0].shape else sd[k0]
+        net2._load_state_dict(disk2, strict=False)
+        assert torch.equal(net2.state_dict()[k0], sd[k0])
+    # strict: the filtered dict must cover every key of the model -> the mis-shaped entry makes it incomplete
+    with pytest.raises(RuntimeError):
+        net2._load_state_dict(disk, strict=True)
+    good = dict(sd)
+    good[k0] = sd[k0].permute(1, 2, 3, 0).contiguous()
+    good["some.foreign.key"] = torch.zeros(3)
+    net2._load_state_dict(good, strict=True)                            # foreign keys do not break strict loading
+    assert all(torch.equal(net2.state_dict()[k], sd[k]) for k in sd)
