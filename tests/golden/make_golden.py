@@ -69,7 +69,21 @@ CASES = {
                          synth=dict(beams=24, azimuths=300, extra=500, features=4), ratio=0.75, seed=12),
     "waymo_b1": dict(ds=configs.WAYMO, yaml="cfgs/waymo_models/gd_mae_ssl.yaml", B=1,
                      synth=dict(beams=32, azimuths=500, extra=1500, features=5), ratio=0.75, seed=13),
+    # BASELINE config E (ONCE-shape, 6-layer SRA, d = 256 in every stage, VFE 64 -> 256): the ONCE yaml with the
+    # BASELINE-defined overrides of SURVEY section 8d applied to the reference's own config object
+    "once_e_b1": dict(ds=configs.ONCE, yaml="cfgs/once_models/gd_mae_ssl.yaml", B=1,
+                      synth=dict(beams=24, azimuths=400, extra=1200, features=4), ratio=0.75, seed=14, config_e=True),
 }
+
+
+def apply_config_e(model_cfg):
+    model_cfg.VFE.MLPS = [[64, 256]]
+    for blk in model_cfg.BACKBONE_3D.SST_BLOCK_LIST:
+        blk.ENCODER.NUM_BLOCKS = 1
+        blk.ENCODER.D_MODEL = 256
+        blk.ENCODER.DIM_FEEDFORWARD = 512
+    for src in model_cfg.BACKBONE_3D.FEATURES_SOURCE:
+        model_cfg.BACKBONE_3D.FUSE_LAYER[src].NUM_FILTER = 256
 
 
 def run_case(name, c):
@@ -78,8 +92,12 @@ def run_case(name, c):
     model_cfg = ycfg.MODEL
     if c["ratio"] is not None:
         model_cfg.BACKBONE_3D.MASK_CONFIG.RATIO = c["ratio"]
-    ours = configs.gdmae_ssl_model_cfg(mask_ratio=model_cfg.BACKBONE_3D.MASK_CONFIG.RATIO,
-                                       eval_metric=model_cfg.POST_PROCESSING.EVAL_METRIC)
+    if c.get("config_e"):
+        apply_config_e(model_cfg)
+        ours = configs.named_config("E", mask_ratio=model_cfg.BACKBONE_3D.MASK_CONFIG.RATIO)[0]
+    else:
+        ours = configs.gdmae_ssl_model_cfg(mask_ratio=model_cfg.BACKBONE_3D.MASK_CONFIG.RATIO,
+                                           eval_metric=model_cfg.POST_PROCESSING.EVAL_METRIC)
     ref_plain, our_plain = to_plain(model_cfg), to_plain(ours)
     for k in ("USE_GROUND_MASK", "DIS_THRESH", "NUM_ABOVE_GROUND"):   # dead keys of the ONCE yaml
         ref_plain["BACKBONE_3D"]["MASK_CONFIG"].pop(k, None)

@@ -8,14 +8,17 @@ from gdmae_hip import configs
 from oracle import gdmae_oracle as orc
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-DATASETS = {"kitti_b2": configs.KITTI, "kitti_b2_m75": configs.KITTI, "waymo_b1": configs.WAYMO}
+DATASETS = {"kitti_b2": configs.KITTI, "kitti_b2_m75": configs.KITTI, "waymo_b1": configs.WAYMO, "once_e_b1": configs.ONCE}
 
 
 def load_case(name):
     z = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
     ds = configs.SyntheticDatasetInfo(**DATASETS[name])
-    cfg = configs.gdmae_ssl_model_cfg(mask_ratio=float(z["mask_ratio"]),
-                                      eval_metric="kitti" if name.startswith("kitti") else "waymo_custom")
+    if name.startswith("once_e"):                       # BASELINE config E: d = 256 in every stage, 6 layers, VFE 64 -> 256
+        cfg = configs.named_config("E", mask_ratio=float(z["mask_ratio"]))[0]
+    else:
+        cfg = configs.gdmae_ssl_model_cfg(mask_ratio=float(z["mask_ratio"]),
+                                          eval_metric="kitti" if name.startswith("kitti") else "waymo_custom")
     shapes = orc.param_shapes(cfg, int(z["num_point_features"]))
     return z, ds, cfg, shapes
 

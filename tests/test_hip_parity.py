@@ -317,7 +317,7 @@ def test_chamfer_matches_oracle(P1, P2):
 
 
 @pytest.mark.parametrize("decoder_impl", ["sparse", "dense"])
-@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("name", CASES + ["once_e_b1"])
 def test_full_model_forward_backward_vs_reference_golden(name, decoder_impl):
     """Whole pre-training forward/backward through the pcdet-compatible modules, fp32 mode, with the
     sparse-aware decoder (product default) and with the reference's dense dataflow."""
@@ -627,7 +627,7 @@ def test_prefetched_plan_is_identical_to_inline_plan():
     assert float(ret0["loss"]) == float(ret1["loss"])
 
 
-@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("name", CASES + ["once_e_b1"])
 def test_bench_mode_gradients_reach_every_parameter(name):
     """The configuration bench.py times (flat optimizer with bf16 weight shadows + bf16 autocast + fused layers):
     every parameter must receive its gradient (a detached shadow silently dropping one is 'work skipped'), and the

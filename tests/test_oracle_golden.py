@@ -8,7 +8,7 @@ from helpers import assert_sampled_close, load_case
 from oracle import gdmae_oracle as orc
 
 
-@pytest.mark.parametrize("name", ["kitti_b2", "kitti_b2_m75", "waymo_b1"])
+@pytest.mark.parametrize("name", ["kitti_b2", "kitti_b2_m75", "waymo_b1", "once_e_b1"])
 def test_oracle_forward_backward_matches_reference_golden(name):
     z, ds, cfg, shapes = load_case(name)
     sd = orc.seeded_state_dict(shapes, seed=int(z["seed"]), requires_grad=True)
