@@ -420,6 +420,63 @@ int gd_add_layernorm_bwd_ex(const float* a, const void* b, int b_is_bf16, const 
                             void* dx_bf16, float* sums, void* workspace, hipStream_t st);
 int gd_ln_partial_rows(long long n, int d);
 
+// fused token GEMMs (tok_gemm.hip)
+bool gd_tok_gemm_supported(int K, int N);
+int gd_tok_gemm_plain(hipStream_t st, const void* X, const void* Wp, const void* bias, long long n_pad, int K, int N, void* out);
+int gd_tok_gemm_gelu(hipStream_t st, const void* X, const void* Wp, const void* bias, long long n_pad, int K, int N, void* h, void* gact);
+int gd_tok_gemm_gelu_bwd(hipStream_t st, const void* dY, const void* Wp, const void* h, long long n_pad, int K, int N, void* dh);
+int gd_tok_gemm_res_ln(hipStream_t st, const void* X, const void* Wp, const void* bias, long long n, long long n_pad, int K, int N,
+                       const float* res, const float* gamma, const float* beta, float eps, float* y, float* stats, void* y_bf,
+                       const float* pos_table, const int* tok_pos, void* ypos_bf, void* f_out);
+
+namespace {
+// packed weight image of a layer: element offsets (in bf16 elements) of the ten operands
+struct Packed {
+  const char *qk, *v, *o, *w1, *w2, *w2t, *w1t, *ot, *qkt, *vt;
+  size_t bytes;
+};
+Packed packed_layout(const void* base, int d, int ff) {
+  Packed p;
+  size_t off = 0;
+  auto take = [&](size_t elems) { const char* q = (const char*)base + off; off += gd_align(elems * 2); return q; };
+  const size_t dd = (size_t)d * d, df = (size_t)d * ff;
+  p.qk = take(2 * dd); p.v = take(dd); p.o = take(dd); p.w1 = take(df); p.w2 = take(df);
+  p.w2t = take(df); p.w1t = take(df); p.ot = take(dd); p.qkt = take(2 * dd); p.vt = take(dd);
+  p.bytes = off;
+  return p;
+}
+bool use_fused(const gdmae_layer_args* a) {
+  static const int off = getenv("GDMAE_TOKGEMM") ? atoi(getenv("GDMAE_TOKGEMM")) == 0 : 0;
+  return !off && a->bf16 && a->packed != nullptr && a->d <= 256 && gd_tok_gemm_supported(a->d, a->ff) &&
+         gd_tok_gemm_supported(a->ff, a->d) && gd_tok_gemm_supported(a->d, 2 * a->d) && gd_tok_gemm_supported(a->d, a->d) &&
+         gd_tok_gemm_supported(2 * a->d, a->d);
+}
+}  // namespace
+
+extern "C" size_t gdmae_layer_packed_bytes(int d, int ff) { return packed_layout(nullptr, d, ff).bytes; }
+
+extern "C" int gdmae_layer_pack_jobs(const float* Win, const float* Wo, const float* W1, const float* W2, int d, int ff, void* packed,
+                                     long long* jobs) {
+  GD_REQUIRE(d % 32 == 0 && ff % 32 == 0, "layer_pack_jobs: d and ff must be multiples of 32");
+  const Packed p = packed_layout(packed, d, ff);
+  // {src, dst, M, K, ld, transpose}: A (M, K) = src (M, ld)  or, transposed, A[r][c] = src[c * ld + r]
+  const long long J[10][6] = {
+      {(long long)Win, (long long)p.qk, 2 * d, d, d, 0},
+      {(long long)(Win + (size_t)2 * d * d), (long long)p.v, d, d, d, 0},
+      {(long long)Wo, (long long)p.o, d, d, d, 0},
+      {(long long)W1, (long long)p.w1, ff, d, d, 0},
+      {(long long)W2, (long long)p.w2, d, ff, ff, 0},
+      {(long long)W2, (long long)p.w2t, ff, d, ff, 1},                      // dg  = df  W2   : A = W2^T (ff, d)
+      {(long long)W1, (long long)p.w1t, d, ff, d, 1},                       // dx1 = dh  W1   : A = W1^T (d, ff)
+      {(long long)Wo, (long long)p.ot, d, d, d, 1},                         // do  = da  Wo   : A = Wo^T
+      {(long long)Win, (long long)p.qkt, d, 2 * d, d, 1},                   // dxqk = dqk Win[:2d] : A = Win[:2d]^T (d, 2d)
+      {(long long)(Win + (size_t)2 * d * d), (long long)p.vt, d, d, d, 1},  // dxv = dv Win[2d:]
+  };
+  for (int i = 0; i < 10; ++i)
+    for (int k = 0; k < 6; ++k) jobs[i * 6 + k] = J[i][k];
+  return 0;
+}
+
 extern "C" int gdmae_encoder_layer_bytes(long long n, int d, int ff, int nhead, int bf16, size_t* saved_bytes,
                                          size_t* fwd_scratch_bytes, size_t* bwd_scratch_bytes) {
   const long long n_pad = pad_rows(n);
@@ -455,14 +512,37 @@ static int layer_fwd(const gdmae_layer_args* a, const gdmae_layer_args* next, bo
   }
   const char* Win = (const char*)a->Win;
   const char* bin = (const char*)a->bin;
-  GD_TRY(linear_fwd(c, s.xpb, Win, bin, s.qk, n_pad, 2 * d, d));
-  GD_TRY(linear_fwd(c, s.xb, Win + (size_t)2 * d * d * es, bin + (size_t)2 * d * es, s.v, n_pad, d, d));
+  const bool fused = use_fused(a);
+  const Packed pk = packed_layout(a->packed, d, ff);
+  if (fused) {
+    GD_TRY(gd_tok_gemm_plain(c.st, s.xpb, pk.qk, bin, n_pad, d, 2 * d, s.qk));
+    GD_TRY(gd_tok_gemm_plain(c.st, s.xb, pk.v, bin + (size_t)2 * d * es, n_pad, d, d, s.v));
+  } else {
+    GD_TRY(linear_fwd(c, s.xpb, Win, bin, s.qk, n_pad, 2 * d, d));
+    GD_TRY(linear_fwd(c, s.xb, Win + (size_t)2 * d * d * es, bin + (size_t)2 * d * es, s.v, n_pad, d, d));
+  }
   int base = 0;
   for (int l = 0; l < a->n_levels; ++l) {
     if (a->n_win[l] > 0)
       GD_TRY(gdmae_window_attention_fwd(s.qk, s.v, s.o, a->bf16, a->csr_tok, a->win_start + base, a->win_len + base, a->n_win[l],
                                         a->max_tokens[l], d, a->nhead, a->tau, a->tau_min, stream));
     base += a->n_win[l];
+  }
+  if (fused) {
+    // out-projection + residual + LayerNorm 1; linear1 + GELU; linear2 + residual + LayerNorm 2 (+ the next layer's
+    // q/k/v operands): three launches for what is eight in the unfused sequence
+    GD_TRY(gd_tok_gemm_res_ln(c.st, s.o, pk.o, a->bo, n, n_pad, d, d, a->x, a->g1, a->be1, a->eps, (float*)s.x1, (float*)s.st1, s.x1b,
+                              nullptr, nullptr, nullptr, s.a));
+    GD_TRY(gd_tok_gemm_gelu(c.st, s.x1b, pk.w1, a->b1, n_pad, d, ff, s.h, s.gact));
+    if (next) {
+      Saved sn = saved_layout(next->saved, n_pad, d, ff, es);
+      GD_TRY(gd_tok_gemm_res_ln(c.st, s.gact, pk.w2, a->b2, n, n_pad, ff, d, (const float*)s.x1, a->g2, a->be2, a->eps, a->y,
+                                (float*)s.st2, sn.xb, next->pos_table, next->tok_pos, sn.xpb, s.f));
+    } else {
+      GD_TRY(gd_tok_gemm_res_ln(c.st, s.gact, pk.w2, a->b2, n, n_pad, ff, d, (const float*)s.x1, a->g2, a->be2, a->eps, a->y,
+                                (float*)s.st2, nullptr, nullptr, nullptr, nullptr, s.f));
+    }
+    return 0;
   }
   GD_TRY(linear_fwd(c, s.o, a->Wo, a->bo, s.a, n_pad, d, d));
   GD_TRY(gdmae_add_layernorm_fwd(a->x, s.a, a->bf16, a->g1, a->be1, n, d, a->eps, (float*)s.x1, (float*)s.st1,
@@ -527,15 +607,23 @@ static int layer_bwd(const gdmae_layer_args* a, bool upstream3, bool defer_add3,
   SplitkJobs SJ;
   SJ.count = 0;
   GD_TRY(linear_dw_deferred(c, w.dfb, s.gact, a->dW2, n_pad, d, ff, (float*)w.part_w[0], SJ));
-  GD_TRY(linear_dx(c, w.dfb, a->W2, w.dg, n_pad, d, ff));
-  GD_TRY(gelu(c, false, w.dg, s.h, w.dh, n_pad * ff));
+  const bool fused = use_fused(a);
+  const Packed pk = packed_layout(a->packed, d, ff);
+  if (fused) {
+    GD_TRY(gd_tok_gemm_gelu_bwd(c.st, w.dfb, pk.w2t, s.h, n_pad, d, ff, w.dh));     // dh = (dfb W2) * gelu'(h)
+  } else {
+    GD_TRY(linear_dx(c, w.dfb, a->W2, w.dg, n_pad, d, ff));
+    GD_TRY(gelu(c, false, w.dg, s.h, w.dh, n_pad * ff));
+  }
   GD_TRY(linear_dw_deferred(c, w.dh, s.x1b, a->dW1, n_pad, ff, d, (float*)w.part_w[1], SJ));
-  GD_TRY(linear_dx(c, w.dh, a->W1, w.dx1_b, n_pad, ff, d));
+  if (fused) GD_TRY(gd_tok_gemm_plain(c.st, w.dh, pk.w1t, nullptr, n_pad, ff, d, w.dx1_b));
+  else GD_TRY(linear_dx(c, w.dh, a->W1, w.dx1_b, n_pad, ff, d));
   // ---- LN1 (gradient = residual branch + FFN branch) and out-projection
   GD_TRY(gd_add_layernorm_bwd_ex(a->x, s.a, a->bf16, a->g1, (const float*)s.st1, (const float*)w.dx1_res, w.dx1_b, a->bf16, nullptr, 0,
                                  n, d, (float*)w.dx_res, a->bf16 ? w.dab : nullptr, nullptr, w.ln_ws, c.st));
   GD_TRY(linear_dw_deferred(c, w.dab, s.o, a->dWo, n_pad, d, d, (float*)w.part_w[2], SJ));
-  GD_TRY(linear_dx(c, w.dab, a->Wo, w.d_o, n_pad, d, d));
+  if (fused) GD_TRY(gd_tok_gemm_plain(c.st, w.dab, pk.ot, nullptr, n_pad, d, d, w.d_o));
+  else GD_TRY(linear_dx(c, w.dab, a->Wo, w.d_o, n_pad, d, d));
   // ---- attention
   int base = 0;
   long long pbase = 0;
@@ -560,8 +648,13 @@ static int layer_bwd(const gdmae_layer_args* a, bool upstream3, bool defer_add3,
     J.x[2] = w.dv;  J.dst[2] = a->dbin + 2 * d;  J.C[2] = d;
     GD_TRY(colsum_jobs(c, J, n, ff > 2 * d ? ff : 2 * d, (float*)w.cs_part));
   }
-  GD_TRY(linear_dx(c, w.dqk, Win, w.dx_qk, n_pad, 2 * d, d));
-  GD_TRY(linear_dx(c, w.dv, Win + (size_t)2 * d * d * es, w.dx_v, n_pad, d, d));
+  if (fused) {
+    GD_TRY(gd_tok_gemm_plain(c.st, w.dqk, pk.qkt, nullptr, n_pad, 2 * d, d, w.dx_qk));
+    GD_TRY(gd_tok_gemm_plain(c.st, w.dv, pk.vt, nullptr, n_pad, d, d, w.dx_v));
+  } else {
+    GD_TRY(linear_dx(c, w.dqk, Win, w.dx_qk, n_pad, 2 * d, d));
+    GD_TRY(linear_dx(c, w.dv, Win + (size_t)2 * d * d * es, w.dx_v, n_pad, d, d));
+  }
   if (!defer_add3) GD_TRY(gdmae_add3((const float*)w.dx_res, w.dx_qk, a->bf16, w.dx_v, a->bf16, n * d, a->dx, stream));
   // ---- LayerNorm / bias / temperature gradients
   // the LayerNorm backward partials (workgroup rows x {dgamma, dbeta, column sums of dx}) are reduced here, together with dtau

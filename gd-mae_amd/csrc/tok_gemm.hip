@@ -1,0 +1,375 @@
+// Token GEMMs of the SRA encoder layers with fused row epilogues (reference
+// pcdet/models/model_utils/sst_basic_block.py:57-84: linear1 -> GELU -> linear2 -> residual + LayerNorm, the attention
+// in/out projections and their input-gradient counterparts).
+//
+//   Y (rows, N) = X (rows, K) W^T (N, K)  [+ bias]  -> epilogue
+//
+// These products are skinny: 20-40 k token rows against K, N <= 512, i.e. 8-67 MFLOP per 64-row tile and a weight
+// matrix of at most 512 KB - they are bound by the activation traffic and by launch count, not by the matrix cores.
+// One workgroup (8 wavefronts) therefore owns 64 token rows and the FULL output width, so everything the reference does
+// row-wise after the product happens before the rows leave the CU:
+//   TG_PLAIN     bias (optional), bf16 store
+//   TG_GELU      h = . + bias stored, gelu_erf(h) stored next to it             (linear1 + activation)
+//   TG_GELU_BWD  dh = . * gelu'(h)                                              (input gradient of linear2 + activation)
+//   TG_RES_LN    y = LayerNorm(residual + bf16(. + bias)) in fp32, row statistics, optional bf16 copies y / y + pos
+//                (out-projection or linear2 + the post-norm of the layer, and the next layer's q/k/v operands)
+// Numerics are those of the unfused sequence (GEMM output rounded to bf16, then the row kernels of layernorm.hip /
+// encoder_layer.hip on the rounded values): the fused path is bit-compatible with it up to the fp32 accumulation order
+// of the product.
+//
+// MFMA mapping (v_mfma_f32_32x32x16_bf16, Y^T = W X^T): A = weights, pre-packed once per optimizer step in fragment
+// order (tok_gemm_pack) so a wavefront streams its 1 KB fragments straight from L2 into VGPRs, four k-steps ahead, no
+// LDS and no barrier in the K loop; B = the 64-row activation tile, loaded once with 16-byte coalesced accesses into an
+// LDS image with a (2K + 16)-byte row pitch (conflict-free ds_read_b128).  Accumulators go through an LDS staging tile
+// (channel quads -> row-major bf16) so that the epilogue reads / writes whole rows with 16-byte accesses.
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+union TgFrag {
+  uint4 q;
+  bf16x8 v;
+};
+
+#define TG_ROWS 64
+#define TG_WAVES 8
+#define TG_PF 4       // weight prefetch distance in k-steps
+
+enum { TG_PLAIN = 0, TG_GELU = 1, TG_GELU_BWD = 2, TG_RES_LN = 3 };
+
+__device__ inline float tg_bf2f(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
+__device__ inline unsigned short tg_f2bf(float f) {
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7F800000u) == 0x7F800000u) return (unsigned short)(u >> 16);
+  return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+__device__ inline unsigned tg_pack2(float lo, float hi) { return tg_f2bf(lo) | ((unsigned)tg_f2bf(hi) << 16); }
+__device__ inline void tg_unpack8(const uint4& u, float (&f)[8]) {
+  const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    f[2 * k] = __uint_as_float(w[k] << 16);
+    f[2 * k + 1] = __uint_as_float(w[k] & 0xFFFF0000u);
+  }
+}
+__device__ inline uint4 tg_pack8(const float (&f)[8]) {
+  uint4 q;
+  q.x = tg_pack2(f[0], f[1]); q.y = tg_pack2(f[2], f[3]); q.z = tg_pack2(f[4], f[5]); q.w = tg_pack2(f[6], f[7]);
+  return q;
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight packing: dst[(ks * MB + mb) * 64 + lane] = 8 bf16 of row mb * 32 + (lane & 31), columns ks * 16 + (lane >> 5) * 8 ..
+// of the (M, K) matrix  A[r][c] = transpose ? src[c * M + r] : src[r * ld + c]   (fp32 master weights, rounded here)
+// jobs: device table of n_jobs x 6 int64 {src, dst, M, K, ld, transpose}; blockIdx.y = job
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_tg_pack(const long long* __restrict__ jobs) {
+  const long long* J = jobs + (long long)blockIdx.y * 6;
+  const float* src = (const float*)J[0];
+  uint4* dst = (uint4*)J[1];
+  const int M = (int)J[2], K = (int)J[3], ld = (int)J[4], tr = (int)J[5];
+  const int MB = M / 32, total = (K / 16) * MB * 64;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int lane = i & 63, mb = (i >> 6) % MB, ks = (i >> 6) / MB;
+    const int r = mb * 32 + (lane & 31), c = ks * 16 + (lane >> 5) * 8;
+    float f[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = tr ? src[(long long)(c + j) * ld + r] : src[(long long)r * ld + c + j];
+    dst[i] = tg_pack8(f);
+  }
+}
+
+extern "C" int gdmae_tok_gemm_pack(const long long* jobs_dev, int n_jobs, void* stream) {
+  if (n_jobs <= 0) return 0;
+  hipLaunchKernelGGL(k_tg_pack, dim3(32, n_jobs), dim3(256), 0, (hipStream_t)stream, jobs_dev);
+  GD_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+struct TgArgs {
+  const unsigned short* X;      // (n_pad, K) bf16
+  const uint4* Wp;              // packed (N, K)
+  const unsigned short* bias;   // (N) bf16 or null
+  long long n, n_pad;
+  unsigned short* out0;         // PLAIN / GELU (h) / GELU_BWD (dh): (n_pad, N) bf16
+  unsigned short* out1;         // GELU: gelu(h)
+  const unsigned short* aux;    // GELU_BWD: h (n_pad, N)
+  // RES_LN
+  const float* res;             // (n, N) fp32 residual stream
+  const float* gamma;
+  const float* beta;
+  float eps;
+  float* y;                     // (n, N) fp32
+  float* stats;                 // (n, 2) mean, rstd
+  unsigned short* y_bf;         // optional (n_pad, N) bf16 copy of y
+  const float* pos_table;       // optional: ypos_bf = bf16(y + pos_table[tok_pos[row]])
+  const int* tok_pos;
+  unsigned short* ypos_bf;
+  unsigned short* f_out;        // optional (n_pad, N): the rounded branch output bf16(. + bias) the LayerNorm backward re-reads
+};
+
+template <int LPR>
+__device__ inline float tg_group_sum(float v) {
+#pragma unroll
+  for (int d = LPR / 2; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+  return v;
+}
+
+template <int KD, int ND, int EPI>
+__global__ __launch_bounds__(512, 2) void k_tok_gemm(TgArgs A) {
+  constexpr int KS = KD / 16;                       // k-steps
+  constexpr int MB = ND / 32;                       // 32-channel blocks of the output
+  constexpr int MPW = MB >= TG_WAVES ? MB / TG_WAVES : 1;   // channel blocks per wavefront
+  constexpr int NPW = MB >= TG_WAVES ? 2 : 1;               // 32-row blocks per wavefront
+  constexpr int XP = KD * 2 + 16;                   // LDS row pitch of the activation tile (bytes)
+  constexpr int SP = ND * 2 + 16;                   // LDS row pitch of the staging tile
+  extern __shared__ __align__(16) unsigned char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const long long row0 = (long long)blockIdx.x * TG_ROWS;
+
+  // ---- weight fragments of the first TG_PF k-steps: in flight while the activation tile is loaded
+  const int mb0 = MB >= TG_WAVES ? wv : (wv >> 1);          // first channel block of this wavefront (then + TG_WAVES)
+  const int nb0 = MB >= TG_WAVES ? 0 : (wv & 1);
+  const uint4* __restrict__ wp = A.Wp + (size_t)mb0 * 64 + lane;   // + (ks * MB + j * TG_WAVES) * 64
+  TgFrag wr[TG_PF + 1][MPW];
+#pragma unroll
+  for (int ks = 0; ks < TG_PF; ++ks)
+#pragma unroll
+    for (int j = 0; j < MPW; ++j) wr[ks][j].q = wp[((size_t)ks * MB + j * TG_WAVES) * 64];
+
+  // ---- activation tile: 64 rows x KD bf16, 16 bytes per thread and access
+  {
+    constexpr int CPR = KD / 8;                     // 16-byte chunks per row
+    constexpr int RPP = 512 / CPR;                  // rows per pass
+    const int c = tid % CPR, r = tid / CPR;
+#pragma unroll
+    for (int p = 0; p < TG_ROWS / RPP; ++p) {
+      const int row = p * RPP + r;
+      const uint4 q = *(const uint4*)(A.X + (row0 + row) * KD + c * 8);
+      *(uint4*)(lds + row * XP + c * 16) = q;
+    }
+  }
+  __syncthreads();
+
+  f32x16 acc[MPW][NPW];
+#pragma unroll
+  for (int j = 0; j < MPW; ++j)
+#pragma unroll
+    for (int b = 0; b < NPW; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[j][b][i] = 0.f;
+  {
+    const unsigned char* lb = lds + ((nb0 * 32) + (lane & 31)) * XP + (lane >> 5) * 16;
+    TgFrag sf[2][NPW];
+#pragma unroll
+    for (int b = 0; b < NPW; ++b) sf[0][b].q = *(const uint4*)(lb + b * 32 * XP);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      if (ks + TG_PF < KS) {
+#pragma unroll
+        for (int j = 0; j < MPW; ++j) wr[(ks + TG_PF) % (TG_PF + 1)][j].q = wp[((size_t)(ks + TG_PF) * MB + j * TG_WAVES) * 64];
+      }
+      if (ks + 1 < KS) {
+#pragma unroll
+        for (int b = 0; b < NPW; ++b) sf[(ks + 1) & 1][b].q = *(const uint4*)(lb + b * 32 * XP + (ks + 1) * 32);
+      }
+#pragma unroll
+      for (int j = 0; j < MPW; ++j)
+#pragma unroll
+        for (int b = 0; b < NPW; ++b)
+          acc[j][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[ks % (TG_PF + 1)][j].v, sf[ks & 1][b].v, acc[j][b], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  __syncthreads();      // every wavefront is done with the activation tile: the staging tile may overwrite it
+
+  // ---- accumulators (+ bias) -> bf16 -> staging tile [row][channel]
+#pragma unroll
+  for (int j = 0; j < MPW; ++j) {
+    const int cb = (mb0 + j * TG_WAVES) * 32 + 4 * (lane >> 5);
+#pragma unroll
+    for (int b = 0; b < NPW; ++b) {
+      const int row = (nb0 + b) * 32 + (lane & 31);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[j][b][4 * q + e];
+        if (EPI != TG_GELU_BWD && A.bias) {
+          const uint2 bq = *(const uint2*)(A.bias + cb + 8 * q);
+          v[0] += __uint_as_float(bq.x << 16); v[1] += __uint_as_float(bq.x & 0xFFFF0000u);
+          v[2] += __uint_as_float(bq.y << 16); v[3] += __uint_as_float(bq.y & 0xFFFF0000u);
+        }
+        uint2 o;
+        o.x = tg_pack2(v[0], v[1]);
+        o.y = tg_pack2(v[2], v[3]);
+        *(uint2*)(lds + row * SP + (cb + 8 * q) * 2) = o;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- row epilogue
+  if (EPI == TG_RES_LN) {
+    constexpr int LPR = ND / 4;                     // lanes per row (4 consecutive columns per lane), as layernorm.hip
+    constexpr int RPP = 512 / LPR;
+    const int c0 = 4 * (tid % LPR), r = tid / LPR;
+    const float4 g4 = *(const float4*)(A.gamma + c0), b4 = *(const float4*)(A.beta + c0);
+    const float g[4] = {g4.x, g4.y, g4.z, g4.w}, bt[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+    for (int p = 0; p < TG_ROWS / RPP; ++p) {
+      const int rl = p * RPP + r;
+      const long long row = row0 + rl;
+      const bool live = row < A.n;
+      const long long e = (live ? row : A.n - 1) * ND + c0;
+      const float4 a4 = *(const float4*)(A.res + e);
+      const uint2 fq = *(const uint2*)(lds + rl * SP + c0 * 2);
+      if (A.f_out) *(uint2*)(A.f_out + (row0 + rl) * ND + c0) = fq;
+      float s[4] = {a4.x, a4.y, a4.z, a4.w};
+      s[0] += __uint_as_float(fq.x << 16); s[1] += __uint_as_float(fq.x & 0xFFFF0000u);
+      s[2] += __uint_as_float(fq.y << 16); s[3] += __uint_as_float(fq.y & 0xFFFF0000u);
+      const float mean = tg_group_sum<LPR>((s[0] + s[1]) + (s[2] + s[3])) * (1.f / ND);
+      float sq = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float dlt = s[k] - mean;
+        sq = fmaf(dlt, dlt, sq);
+      }
+      const float rstd = rsqrtf(tg_group_sum<LPR>(sq) * (1.f / ND) + A.eps);
+      if (!live) continue;
+      float o[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[k] = (s[k] - mean) * rstd * g[k] + bt[k];
+      *(float4*)(A.y + e) = make_float4(o[0], o[1], o[2], o[3]);
+      if (A.y_bf) {
+        uint2 q;
+        q.x = tg_pack2(o[0], o[1]); q.y = tg_pack2(o[2], o[3]);
+        *(uint2*)(A.y_bf + e) = q;
+      }
+      if (A.ypos_bf) {
+        const float4 p4 = *(const float4*)(A.pos_table + (long long)A.tok_pos[row] * ND + c0);
+        uint2 q;
+        q.x = tg_pack2(o[0] + p4.x, o[1] + p4.y); q.y = tg_pack2(o[2] + p4.z, o[3] + p4.w);
+        *(uint2*)(A.ypos_bf + e) = q;
+      }
+      if (c0 == 0) *(float2*)(A.stats + row * 2) = make_float2(mean, rstd);
+    }
+  } else {
+    constexpr int CPR = ND / 8;
+    constexpr int RPP = 512 / CPR;
+    const int c = tid % CPR, r = tid / CPR;
+#pragma unroll
+    for (int p = 0; p < TG_ROWS / RPP; ++p) {
+      const int rl = p * RPP + r;
+      const long long e = (row0 + rl) * ND + c * 8;
+      const uint4 q = *(const uint4*)(lds + rl * SP + c * 16);
+      if (EPI == TG_PLAIN) {
+        *(uint4*)(A.out0 + e) = q;
+      } else if (EPI == TG_GELU) {
+        *(uint4*)(A.out0 + e) = q;
+        float v[8];
+        tg_unpack8(q, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = 0.5f * v[j] * (1.f + erff(v[j] * 0.70710678118654752440f));
+        *(uint4*)(A.out1 + e) = tg_pack8(v);
+      } else {   // TG_GELU_BWD: dh = dg * (Phi(h) + h * phi(h))
+        const uint4 hq = *(const uint4*)(A.aux + e);
+        float g[8], v[8];
+        tg_unpack8(q, g);
+        tg_unpack8(hq, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float cdf = 0.5f * (1.f + erff(v[j] * 0.70710678118654752440f));
+          const float pdf = 0.39894228040143267794f * expf(-0.5f * v[j] * v[j]);
+          g[j] = g[j] * (cdf + v[j] * pdf);
+        }
+        *(uint4*)(A.out0 + e) = tg_pack8(g);
+      }
+    }
+  }
+}
+
+template <int KD, int ND, int EPI>
+static int tg_launch(const TgArgs& A, hipStream_t st) {
+  constexpr int lds = TG_ROWS * ((KD > ND ? KD : ND) * 2 + 16);
+  static bool once = false;
+  if (!once) {
+    GD_CHECK(hipFuncSetAttribute((const void*)k_tok_gemm<KD, ND, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    once = true;
+  }
+  hipLaunchKernelGGL((k_tok_gemm<KD, ND, EPI>), dim3((unsigned)(A.n_pad / TG_ROWS)), dim3(512), lds, st, A);
+  GD_LAUNCH_CHECK();
+  return 0;
+}
+
+template <int EPI>
+static int tg_dispatch(int K, int N, const TgArgs& A, hipStream_t st) {
+#define TG_CASE(k_, n_)                                       \
+  if constexpr (!(EPI == TG_RES_LN && n_ > 256)) {            \
+    if (K == k_ && N == n_) return tg_launch<k_, n_, EPI>(A, st); \
+  }
+  TG_CASE(128, 128);
+  TG_CASE(128, 256);
+  TG_CASE(256, 128);
+  TG_CASE(256, 256);
+  TG_CASE(256, 512);
+  TG_CASE(512, 256);
+#undef TG_CASE
+  GD_REQUIRE(false, "tok_gemm: unsupported (K, N)");
+}
+
+// internal front end (encoder_layer.hip)
+bool gd_tok_gemm_supported(int K, int N) {
+  return (K == 128 && (N == 128 || N == 256)) || (K == 256 && (N == 128 || N == 256 || N == 512)) || (K == 512 && N == 256);
+}
+int gd_tok_gemm_plain(hipStream_t st, const void* X, const void* Wp, const void* bias, long long n_pad, int K, int N, void* out) {
+  TgArgs A = {};
+  A.X = (const unsigned short*)X; A.Wp = (const uint4*)Wp; A.bias = (const unsigned short*)bias; A.n = n_pad; A.n_pad = n_pad;
+  A.out0 = (unsigned short*)out;
+  return tg_dispatch<TG_PLAIN>(K, N, A, st);
+}
+int gd_tok_gemm_gelu(hipStream_t st, const void* X, const void* Wp, const void* bias, long long n_pad, int K, int N, void* h, void* gact) {
+  TgArgs A = {};
+  A.X = (const unsigned short*)X; A.Wp = (const uint4*)Wp; A.bias = (const unsigned short*)bias; A.n = n_pad; A.n_pad = n_pad;
+  A.out0 = (unsigned short*)h; A.out1 = (unsigned short*)gact;
+  return tg_dispatch<TG_GELU>(K, N, A, st);
+}
+int gd_tok_gemm_gelu_bwd(hipStream_t st, const void* dY, const void* Wp, const void* h, long long n_pad, int K, int N, void* dh) {
+  TgArgs A = {};
+  A.X = (const unsigned short*)dY; A.Wp = (const uint4*)Wp; A.n = n_pad; A.n_pad = n_pad;
+  A.out0 = (unsigned short*)dh; A.aux = (const unsigned short*)h;
+  return tg_dispatch<TG_GELU_BWD>(K, N, A, st);
+}
+int gd_tok_gemm_res_ln(hipStream_t st, const void* X, const void* Wp, const void* bias, long long n, long long n_pad, int K, int N,
+                       const float* res, const float* gamma, const float* beta, float eps, float* y, float* stats, void* y_bf,
+                       const float* pos_table, const int* tok_pos, void* ypos_bf, void* f_out) {
+  TgArgs A = {};
+  A.f_out = (unsigned short*)f_out;
+  A.X = (const unsigned short*)X; A.Wp = (const uint4*)Wp; A.bias = (const unsigned short*)bias; A.n = n; A.n_pad = n_pad;
+  A.res = res; A.gamma = gamma; A.beta = beta; A.eps = eps; A.y = y; A.stats = stats; A.y_bf = (unsigned short*)y_bf;
+  A.pos_table = pos_table; A.tok_pos = tok_pos; A.ypos_bf = (unsigned short*)ypos_bf;
+  return tg_dispatch<TG_RES_LN>(K, N, A, st);
+}
+
+// ------------------------------------------------------------------------------------------------
+// C ABI (tests and stand-alone use): Y = epilogue(X Wp^T + bias), see the table at the top.  epilogue: 0 plain, 1 GELU
+// (out0 = h, out1 = gelu(h)), 2 GELU backward (aux = h), 3 residual + LayerNorm (out0 optional: the rounded product).
+// ------------------------------------------------------------------------------------------------
+extern "C" int gdmae_tok_gemm(const void* X, const void* Wp, const void* bias, long long n, long long n_pad, int K, int N,
+                              int epilogue, void* out0, void* out1, const void* aux, const float* res, const float* gamma,
+                              const float* beta, float eps, float* y, float* stats, void* y_bf16, const float* pos_table,
+                              const int* tok_pos, void* ypos_bf16, void* stream) {
+  GD_REQUIRE(n_pad > 0 && n_pad % TG_ROWS == 0 && n <= n_pad && n >= 1, "tok_gemm: rows must be padded to a multiple of 64");
+  GD_REQUIRE(gd_tok_gemm_supported(K, N), "tok_gemm: unsupported (K, N)");
+  hipStream_t st = (hipStream_t)stream;
+  switch (epilogue) {
+    case TG_PLAIN: return gd_tok_gemm_plain(st, X, Wp, bias, n_pad, K, N, out0);
+    case TG_GELU: return gd_tok_gemm_gelu(st, X, Wp, bias, n_pad, K, N, out0, out1);
+    case TG_GELU_BWD: return gd_tok_gemm_gelu_bwd(st, X, Wp, aux, n_pad, K, N, out0);
+    case TG_RES_LN:
+      return gd_tok_gemm_res_ln(st, X, Wp, bias, n, n_pad, K, N, res, gamma, beta, eps, y, stats, y_bf16, pos_table, tok_pos, ypos_bf16,
+                                out0);
+  }
+  GD_REQUIRE(false, "tok_gemm: unknown epilogue");
+}

@@ -263,6 +263,12 @@ def _param_args(plist, cdt, direct):
     a = L.LayerArgs()
     for k, t in tensors.items():
         setattr(a, k, L.ptr(t))
+    if cdt == torch.bfloat16 and TOKGEMM:
+        # fragment-ordered weight image for the fused token GEMMs (refreshed by the optimizer for registered layers)
+        packed = (packing.registered if stable else packing.pack_now)(Win, Wo, W1, W2)
+        if packed is not None:
+            tensors["packed"] = packed
+            a.packed = L.ptr(packed)
     if stable:
         for k, g in zip(_GRAD_FIELDS, direct):
             setattr(a, k, L.ptr(g))
@@ -338,6 +344,7 @@ class EncoderLayerNativeFn(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------------
 # stage executor: all layers of a stage (NUM_BLOCKS x 2) as ONE call per direction
 # ------------------------------------------------------------------------------------------------
+TOKGEMM = os.environ.get("GDMAE_TOKGEMM", "1") != "0"   # False: token GEMMs through hipBLASLt + separate row kernels (A/B)
 STAGE = os.environ.get("GDMAE_STAGE", "1") != "0"     # False / GDMAE_STAGE=0: one call per layer (A/B reference)
 
 

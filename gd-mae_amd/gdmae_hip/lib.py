@@ -92,6 +92,10 @@ SIGNATURES = {
     "gdmae_conv_block_fwd": (_I, [_P, _P]),
     "gdmae_conv_block_bwd": (_I, [_P, _P]),
     "gdmae_encoder_layer_bytes": (_I, [_L, _I, _I, _I, _I, _P, _P, _P]),
+    "gdmae_layer_packed_bytes": (_Z, [_I, _I]),
+    "gdmae_layer_pack_jobs": (_I, [_P, _P, _P, _P, _I, _I, _P, _P]),
+    "gdmae_tok_gemm_pack": (_I, [_P, _I, _P]),
+    "gdmae_tok_gemm": (_I, [_P, _P, _P, _L, _L, _I, _I, _I, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P]),
     "gdmae_encoder_layer_fwd": (_I, [_P, _P]),
     "gdmae_encoder_layer_bwd": (_I, [_P, _P]),
     "gdmae_encoder_stage_fwd": (_I, [_P, _I, _P]),
@@ -113,7 +117,7 @@ class LayerArgs(C.Structure):
                  ("n_win", _I * 4), ("max_tokens", _I * 4)]
                 + [(k, _P) for k in ("tok_pos", "csr_tok", "win_start", "win_len", "pos_table", "Win", "bin", "Wo", "bo", "W1", "b1",
                                      "W2", "b2", "g1", "be1", "g2", "be2", "tau", "x", "y", "dy", "dx", "dWin", "dbin", "dtau", "dWo",
-                                     "dbo", "dW1", "db1", "dW2", "db2", "dg1", "dbe1", "dg2", "dbe2", "saved", "scratch")])
+                                     "dbo", "dW1", "db1", "dW2", "db2", "dg1", "dbe1", "dg2", "dbe2", "saved", "scratch", "packed")])
 
 
 class ConvBlockArgs(C.Structure):

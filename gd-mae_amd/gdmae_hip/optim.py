@@ -136,6 +136,9 @@ class FlatAdamOneCycle:
             k = p.numel()
             p._gd_shadow = (self.flat_param_bf16[off:off + k].view(p.shape), p._version)
             off += k
+        if self.flat_param.is_cuda:
+            from . import packing
+            packing.repack_registered()          # fragment-ordered images of the encoder weights (one launch)
 
     def _check_views(self):
         for p in self.params:

@@ -1,0 +1,79 @@
+"""MFMA-fragment-ordered weight images for the fused token GEMMs of the encoder layers (csrc/tok_gemm.hip).
+
+A layer's ten GEMM operands (five forward, five transposed for the input-gradient products) are packed from the fp32
+master weights by ``gdmae_tok_gemm_pack``.  Layers whose parameters live in a flat optimizer buffer are REGISTERED: their
+images are refreshed by ONE launch per optimizer step (``repack_registered``, called next to the bf16 shadow refresh);
+everything else is packed on the fly at every use.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import weakref
+
+import torch
+
+from . import lib as L
+
+_REG = {}          # id(Win) -> dict(ref, packed, jobs)
+_TABLE = {}        # device index -> (signature, device job table, n_jobs)
+
+
+def _jobs_for(Win, Wo, W1, W2, packed):
+    d, ff = Wo.shape[0], W1.shape[0]
+    jobs = (C.c_longlong * 60)()
+    L.call("gdmae_layer_pack_jobs", L.ptr(Win), L.ptr(Wo), L.ptr(W1), L.ptr(W2), d, ff, L.ptr(packed), jobs)
+    return list(jobs)
+
+
+def _ok(Win, Wo, W1, W2):
+    return all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() for t in (Win, Wo, W1, W2))
+
+
+def pack_now(Win, Wo, W1, W2):
+    """Fresh packed image of a layer (one launch); None when the weights are not fp32 device tensors."""
+    if not _ok(Win, Wo, W1, W2):
+        return None
+    d, ff = Wo.shape[0], W1.shape[0]
+    packed = torch.empty(L.load().gdmae_layer_packed_bytes(d, ff), dtype=torch.uint8, device=Win.device)
+    jobs = torch.tensor(_jobs_for(Win.detach(), Wo.detach(), W1.detach(), W2.detach(), packed), dtype=torch.int64).to(Win.device)
+    L.call("gdmae_tok_gemm_pack", L.ptr(jobs), 10, L.stream())
+    packed._gd_jobs = jobs           # keep the table alive until the launch has run
+    return packed
+
+
+def registered(Win, Wo, W1, W2):
+    """Packed image of a layer whose weights are refreshed by the optimizer: packed now, then once per step."""
+    if not _ok(Win, Wo, W1, W2):
+        return None
+    key = id(Win)
+    ent = _REG.get(key)
+    if ent is not None and ent["ref"]() is Win and ent["ptrs"] == tuple(t.data_ptr() for t in (Win, Wo, W1, W2)):
+        return ent["packed"]
+    packed = pack_now(Win, Wo, W1, W2)
+    _REG[key] = dict(ref=weakref.ref(Win), packed=packed, ptrs=tuple(t.data_ptr() for t in (Win, Wo, W1, W2)),
+                     jobs=_jobs_for(Win.detach(), Wo.detach(), W1.detach(), W2.detach(), packed))
+    _TABLE.clear()
+    return packed
+
+
+def repack_registered():
+    """Refresh every registered image with ONE launch per device (called after the optimizer step)."""
+    dead = [k for k, e in _REG.items() if e["ref"]() is None]
+    for k in dead:
+        del _REG[k]
+    if dead:
+        _TABLE.clear()
+    if not _REG:
+        return
+    by_dev = {}
+    for e in _REG.values():
+        by_dev.setdefault(e["packed"].device, []).append(e)
+    for dev, ents in by_dev.items():
+        sig = tuple(id(e["packed"]) for e in ents)
+        tab = _TABLE.get(dev.index)
+        if tab is None or tab[0] != sig:
+            flat = [v for e in ents for v in e["jobs"]]
+            tab = (sig, torch.tensor(flat, dtype=torch.int64).to(dev), len(flat) // 6)
+            _TABLE[dev.index] = tab
+        with torch.cuda.device(dev):
+            L.call("gdmae_tok_gemm_pack", L.ptr(tab[1]), tab[2], L.stream())

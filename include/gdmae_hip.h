@@ -402,7 +402,28 @@ typedef struct gdmae_layer_args {
   float *dWin, *dbin, *dtau, *dWo, *dbo, *dW1, *db1, *dW2, *db2, *dg1, *dbe1, *dg2, *dbe2;   /* [backward] */
   void* saved;
   void* scratch;
+  /* bf16 mode, optional: the layer's weights packed in MFMA-fragment order by gdmae_tok_gemm_pack (layout:
+   * gdmae_layer_packed_bytes / gdmae_layer_pack_jobs).  Non-NULL: the token GEMMs that are not weight gradients run on
+   * the library's own fused kernels (gdmae_tok_gemm: bias + GELU, residual + LayerNorm, GELU backward in the epilogue)
+   * instead of hipBLASLt + separate row kernels. */
+  const void* packed;
 } gdmae_layer_args;
+/* Packed weight image of one layer (bf16 mode): forward operands [Win(q,k rows) | Win(v rows) | Wo | W1 | W2] followed by
+ * the transposed operands of the input-gradient products [W2^T | W1^T | Wo^T | Win(q,k)^T | Win(v)^T].
+ * gdmae_layer_pack_jobs fills a HOST table of 10 x 6 int64 {src, dst, M, K, ld, transpose} for gdmae_tok_gemm_pack
+ * (copy it to the device; one launch packs any number of layers). */
+size_t gdmae_layer_packed_bytes(int d, int ff);
+int gdmae_layer_pack_jobs(const float* Win, const float* Wo, const float* W1, const float* W2, int d, int ff, void* packed,
+                          long long* jobs_host /* 60 */);
+int gdmae_tok_gemm_pack(const long long* jobs_dev, int n_jobs, void* stream);
+/* Y = epilogue(X Wp^T + bias): X (n_pad, K) bf16 rows (n_pad % 64 == 0), Wp = packed (N, K) weights, bias (N) bf16 or
+ * NULL; (K, N) in {128, 256} x {128, 256}, (256, 512), (512, 256).  epilogue 0: out0 = . (bf16); 1: out0 = h = . and
+ * out1 = gelu_erf(h); 2: out0 = . * gelu'(aux) (aux = h); 3: y = LayerNorm(res + bf16(.)) fp32 (first n rows), stats
+ * (n, 2) = mean | rstd, optional bf16 copies y_bf16 = y and ypos_bf16 = y + pos_table[tok_pos[row]]. */
+int gdmae_tok_gemm(const void* X, const void* Wp, const void* bias, long long n, long long n_pad, int K, int N, int epilogue,
+                   void* out0, void* out1, const void* aux, const float* res, const float* gamma, const float* beta, float eps,
+                   float* y, float* stats, void* y_bf16, const float* pos_table, const int* tok_pos, void* ypos_bf16,
+                   void* stream);
 int gdmae_encoder_layer_bytes(long long n, int d, int ff, int nhead, int bf16, size_t* saved_bytes,
                               size_t* fwd_scratch_bytes, size_t* bwd_scratch_bytes);   /* depend on n only through ceil(n / 2048) */
 int gdmae_encoder_layer_fwd(const gdmae_layer_args* args /* host */, void* stream);

@@ -1008,3 +1008,84 @@ def test_tile_conv_decoder_equals_dense_conv_decoder_bf16(name):
         assert d_td <= 0.15 and d_tf <= 1.3 * d_df + 0.02, (k, d_td, d_tf, d_df)
     for k in rt:
         assert torch.allclose(rt[k].float(), rd[k].float(), rtol=2e-3, atol=1e-5), k
+
+
+def _pack_weight(w, transpose=False):
+    """Packed (fragment-ordered) image of a 2-D fp32 weight through gdmae_tok_gemm_pack."""
+    from gdmae_hip import lib as L
+    M, K = (w.shape[1], w.shape[0]) if transpose else w.shape
+    dst = torch.empty(M * K, dtype=torch.bfloat16, device=w.device)
+    jobs = torch.tensor([w.data_ptr(), dst.data_ptr(), M, K, w.shape[1], int(transpose)], dtype=torch.int64).to(w.device)
+    L.call("gdmae_tok_gemm_pack", L.ptr(jobs), 1, L.stream())
+    torch.cuda.synchronize()
+    return dst
+
+
+@pytest.mark.parametrize("K,N", [(128, 128), (128, 256), (256, 128), (256, 256), (256, 512), (512, 256)])
+def test_tok_gemm_epilogues_match_torch(K, N):
+    """gdmae_tok_gemm (bf16 MFMA token GEMM with fused row epilogues) against torch on the same bf16-rounded operands:
+    plain (+bias), bias + GELU (h and gelu(h)), GELU backward, residual + LayerNorm (+ bf16 copies, + positional copy).
+    The product is accumulated in fp32 in a different order than the reference GEMM: results agree to bf16 rounding of
+    the output (2^-8 relative) for the bf16 outputs and to 2e-3 of the row scale for the LayerNorm output."""
+    from gdmae_hip import lib as L
+    d_ = dev()
+    g = torch.Generator().manual_seed(K * 7 + N)
+    n, n_pad = 1000, 1024
+    X = torch.zeros(n_pad, K)
+    X[:n] = torch.randn(n, K, generator=g)
+    Xb = X.bfloat16().to(d_)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(d_)
+    bias = torch.randn(N, generator=g).bfloat16().to(d_)
+    Wp = _pack_weight(W)
+    ref = Xb.float() @ W.bfloat16().float().t() + bias.float()            # fp32 accumulate of bf16 operands
+
+    def call(epi, out0=None, out1=None, aux=None, res=None, gamma=None, beta=None, y=None, stats=None, ybf=None, pos=None, tp=None,
+             ypos=None, b=bias):
+        L.call("gdmae_tok_gemm", L.ptr(Xb), L.ptr(Wp), L.ptr(b), n, n_pad, K, N, epi, L.ptr(out0), L.ptr(out1), L.ptr(aux), L.ptr(res),
+               L.ptr(gamma), L.ptr(beta), 1e-5, L.ptr(y), L.ptr(stats), L.ptr(ybf), L.ptr(pos), L.ptr(tp), L.ptr(ypos), L.stream())
+
+    def close_bf(a, b_, what):
+        err = (a.float() - b_).abs() / (b_.abs() + 0.05 * b_.abs().max())
+        assert float(err.max()) < 1.2e-2, (what, float(err.max()))
+
+    out = torch.empty(n_pad, N, dtype=torch.bfloat16, device=d_)
+    call(0, out0=out)
+    close_bf(out, ref, "plain")
+    # transposed packing: the same product from W^T stored (K, N)
+    Wt = W.t().contiguous()
+    Wp_t = _pack_weight(Wt, transpose=True)
+    out_t = torch.empty_like(out)
+    L.call("gdmae_tok_gemm", L.ptr(Xb), L.ptr(Wp_t), L.ptr(bias), n, n_pad, K, N, 0, L.ptr(out_t), None, None, None, None, None, 1e-5,
+           None, None, None, None, None, None, L.stream())
+    assert torch.equal(out_t, out)
+    # bias + GELU
+    h, ga = torch.empty_like(out), torch.empty_like(out)
+    call(1, out0=h, out1=ga)
+    assert torch.equal(h, out)
+    assert torch.equal(ga, torch.nn.functional.gelu(h.float()).bfloat16())       # GELU of the ROUNDED h, as the unfused path
+    # GELU backward: dh = (X W^T) * gelu'(aux)
+    aux = torch.randn(n_pad, N, generator=g).bfloat16().to(d_)
+    dh = torch.empty_like(out)
+    call(2, out0=dh, aux=aux, b=None)
+    prod = (Xb.float() @ W.bfloat16().float().t())
+    a = aux.float()
+    gp = 0.5 * (1 + torch.erf(a * 0.7071067811865476)) + a * torch.exp(-0.5 * a * a) * 0.3989422804014327
+    close_bf(dh, prod.bfloat16().float() * gp, "gelu_bwd")
+    if N <= 256:
+        res = torch.randn(n, N, generator=g).to(d_)
+        gamma, beta = (torch.rand(N, generator=g) + 0.5).to(d_), torch.randn(N, generator=g).to(d_)
+        pos = torch.randn(64, N, generator=g).to(d_)
+        tp = torch.randint(0, 64, (n,), generator=g).int().to(d_)
+        y = torch.empty(n, N, device=d_)
+        stats = torch.empty(n, 2, device=d_)
+        ybf = torch.zeros(n_pad, N, dtype=torch.bfloat16, device=d_)
+        ypos = torch.zeros(n_pad, N, dtype=torch.bfloat16, device=d_)
+        f = torch.empty(n_pad, N, dtype=torch.bfloat16, device=d_)
+        call(3, out0=f, res=res, gamma=gamma, beta=beta, y=y, stats=stats, ybf=ybf, pos=pos, tp=tp, ypos=ypos)
+        assert torch.equal(f, out)
+        s = res + f[:n].float()
+        yr = torch.nn.functional.layer_norm(s, (N,), gamma, beta, 1e-5)
+        assert float((y - yr).abs().max()) < 2e-5 * float(yr.abs().max()) + 1e-5     # LayerNorm of the SAME rounded branch
+        assert torch.allclose(stats[:, 0], s.mean(1), atol=1e-5) and torch.allclose(stats[:, 1], torch.rsqrt(s.var(1, unbiased=False) + 1e-5), rtol=1e-4)
+        assert torch.equal(ybf[:n], y.bfloat16()) and float(ybf[n:].abs().max()) == 0
+        assert torch.equal(ypos[:n], (y + pos[tp.long()]).bfloat16())
