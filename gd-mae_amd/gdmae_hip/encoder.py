@@ -24,7 +24,7 @@ import torch
 import torch.nn.functional as F
 
 from . import lib as L
-from . import ops, timing
+from . import ops, packing, timing
 
 PAD = 2048
 
