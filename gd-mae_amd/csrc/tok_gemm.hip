@@ -58,6 +58,33 @@ __device__ inline uint4 tg_pack8(const float (&f)[8]) {
   return q;
 }
 
+// erf-GELU for rows that are rounded to bf16 right after: erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, i.e. 2^-13
+// of a bf16 ulp at unit scale) on v_rcp_f32 / v_exp_f32 - about a third of the VALU work of erff(), which at one output
+// row per lane and no MFMA left to hide behind was what the fused epilogues were bound by (exact erff: +12 us per 10 M
+// hidden elements).  Phi(h) = (1 + erf(h / sqrt 2)) / 2 and phi(h) share the exponential exp(-h^2 / 2).
+__device__ inline void tg_phi(float h, float& cdf, float& pdf_e) {
+  const float x = fabsf(h) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.f));
+  const float e = __expf(-x * x);                                   // = exp(-h^2 / 2)
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float q = 0.5f * p * t * e;                                 // (1 - erf(x)) / 2
+  cdf = h >= 0.f ? 1.f - q : q;
+  pdf_e = e;
+}
+__device__ inline float tg_gelu(float h) {
+  float cdf, e;
+  tg_phi(h, cdf, e);
+  return h * cdf;
+}
+__device__ inline float tg_gelu_grad(float h) {
+  float cdf, e;
+  tg_phi(h, cdf, e);
+  return fmaf(h * 0.39894228040143267794f, e, cdf);
+}
+
 // ------------------------------------------------------------------------------------------------
 // weight packing: dst[(ks * MB + mb) * 64 + lane] = 8 bf16 of row mb * 32 + (lane & 31), columns ks * 16 + (lane >> 5) * 8 ..
 // of the (M, K) matrix  A[r][c] = transpose ? src[c * M + r] : src[r * ld + c]   (fp32 master weights, rounded here)
@@ -271,7 +298,7 @@ __global__ __launch_bounds__(512, 2) void k_tok_gemm(TgArgs A) {
         float v[8];
         tg_unpack8(q, v);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = 0.5f * v[j] * (1.f + erff(v[j] * 0.70710678118654752440f));
+        for (int j = 0; j < 8; ++j) v[j] = tg_gelu(v[j]);
         *(uint4*)(A.out1 + e) = tg_pack8(v);
       } else {   // TG_GELU_BWD: dh = dg * (Phi(h) + h * phi(h))
         const uint4 hq = *(const uint4*)(A.aux + e);
@@ -279,11 +306,7 @@ __global__ __launch_bounds__(512, 2) void k_tok_gemm(TgArgs A) {
         tg_unpack8(q, g);
         tg_unpack8(hq, v);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float cdf = 0.5f * (1.f + erff(v[j] * 0.70710678118654752440f));
-          const float pdf = 0.39894228040143267794f * expf(-0.5f * v[j] * v[j]);
-          g[j] = g[j] * (cdf + v[j] * pdf);
-        }
+        for (int j = 0; j < 8; ++j) g[j] = g[j] * tg_gelu_grad(v[j]);
         *(uint4*)(A.out0 + e) = tg_pack8(g);
       }
     }

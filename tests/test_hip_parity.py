@@ -1062,7 +1062,11 @@ def test_tok_gemm_epilogues_match_torch(K, N):
     h, ga = torch.empty_like(out), torch.empty_like(out)
     call(1, out0=h, out1=ga)
     assert torch.equal(h, out)
-    assert torch.equal(ga, torch.nn.functional.gelu(h.float()).bfloat16())       # GELU of the ROUNDED h, as the unfused path
+    # GELU of the ROUNDED h, as the unfused path; erf to 1.5e-7 absolute (Abramowitz-Stegun 7.1.26), far below the bf16
+    # rounding of the result: at most one bf16 ulp apart from the exact-erf GELU, and only on rounding boundaries
+    gr = torch.nn.functional.gelu(h.float())
+    dg = (ga.float() - gr).abs()
+    assert float((dg / (gr.abs() + 1e-3)).max()) < 2 ** -7 and float((ga != gr.bfloat16()).float().mean()) < 1e-2
     # GELU backward: dh = (X W^T) * gelu'(aux)
     aux = torch.randn(n_pad, N, generator=g).bfloat16().to(d_)
     dh = torch.empty_like(out)

@@ -8,7 +8,7 @@ echo "kernel,counter,dispatches,sum,avg" > $OUT
 i=0
 for C in "$@"; do
   i=$((i+1))
-  rocprofv3 --pmc $C -f csv -T -d /tmp/pmc_$i -- python /root/repo/bench.py --steps 3 --warmup 3 --no-cpu-baseline --no-roofline > /tmp/pmc_$i.log 2>&1
+  rocprofv3 --pmc $C -f csv -T -d /tmp/pmc_$i -- python /root/repo/bench.py --steps 3 --warmup 3 --no-cpu-baseline --no-roofline --no-also > /tmp/pmc_$i.log 2>&1
   F=$(find /tmp/pmc_$i -name "*counter_collection.csv" | head -1)
   python - "$F" "$PAT" >> $OUT <<'PY'
 import csv, sys, re, collections
