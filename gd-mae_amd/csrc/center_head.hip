@@ -1,0 +1,132 @@
+// CenterHead target assignment on the GPU (SURVEY next row f1; reference
+// pcdet/models/dense_heads/center_head.py:106-221 `assign_target_of_single_head` / `assign_targets`, and
+// pcdet/models/model_utils/centernet_utils.py:9-70 `gaussian_radius` / `gaussian2D` / `draw_gaussian_to_heatmap`).
+//
+// The reference moves the boxes to the CPU and loops over them in Python: per box a handful of scalar tensor ops, a numpy
+// Gaussian patch and an in-place torch.max on a heat-map slice (B x ~50-500 iterations per step, plus the D2H / H2D
+// copies).  Here: k_ch_prepare compacts the boxes of a head per sample in input order (ballot scan), computes the integer
+// centre, the Gaussian radius (the reference's fp32 operation order, so the truncations agree) and the regression targets;
+// k_ch_draw rasterises one box per workgroup with an atomic max on the (non-negative) float bit patterns - a maximum is
+// order independent, so the heat map is deterministic.
+#include "common.h"
+
+struct ChBox {
+  int cx, cy, r, cls;     // integer centre (feature-map cells), Gaussian radius, class index inside the head (0-based) / -1
+};
+
+// class_map: (n_class_total + 1) int: global class id (1-based, 0 = padding) -> 1-based id inside this head, 0 = not in this head
+__global__ __launch_bounds__(64) void k_ch_prepare(const float* __restrict__ gt, int n_max, int box_dim, const int* __restrict__ class_map,
+                                                   int n_class_total, float x0, float y0, float vsx, float vsy, float stride, int fw, int fh,
+                                                   int num_max_objs, double overlap_d, int min_radius, ChBox* __restrict__ boxes,
+                                                   float* __restrict__ ret_boxes, long long* __restrict__ inds, long long* __restrict__ mask,
+                                                   int ret_dim) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const float* g = gt + (long long)b * n_max * box_dim;
+  int base = 0;
+  for (int i0 = 0; i0 < n_max; i0 += 64) {
+    const int i = i0 + lane;
+    int hc = 0;
+    if (i < n_max) {
+      const int c = (int)g[(long long)i * box_dim + box_dim - 1];       // .long() truncation of the class column
+      hc = (c >= 0 && c <= n_class_total) ? class_map[c] : 0;
+    }
+    const unsigned long long m = __ballot(hc > 0);
+    const int k = base + __popcll(m & ((1ull << lane) - 1ull));
+    base += __popcll(m);
+    if (hc > 0 && k < num_max_objs) {
+      const float* bx = g + (long long)i * box_dim;
+      const float x = bx[0], y = bx[1], z = bx[2];
+      float cxf = ((x - x0) / vsx) / stride, cyf = ((y - y0) / vsy) / stride;
+      cxf = fminf(fmaxf(cxf, 0.f), (float)fw - 0.5f);
+      cyf = fminf(fmaxf(cyf, 0.f), (float)fh - 0.5f);
+      const int cxi = (int)cxf, cyi = (int)cyf;
+      const float w = (bx[3] / vsx) / stride, h = (bx[4] / vsy) / stride;      // reference: dx, dy in cells; radius(height = dx, width = dy)
+      ChBox rec;
+      rec.cx = cxi; rec.cy = cyi; rec.cls = -1; rec.r = 0;
+      if (w > 0.f && h > 0.f && cxi >= 0 && cxi <= fw && cyi >= 0 && cyi <= fh) {
+        // gaussian_radius(height = w_, width = h_) in the reference's fp32 operation order
+        // (python scalars such as 1 - min_overlap are doubles that enter the fp32 tensor arithmetic rounded to fp32)
+        const float omo = (float)(1.0 - overlap_d), opo = (float)(1.0 + overlap_d), omn = (float)(overlap_d - 1.0);
+        const float hh = w, ww = h;
+        const float hw = hh + ww;
+        const float c1 = ((ww * hh) * omo) / opo;
+        const float r1 = (hw + sqrtf(hw * hw - 4.f * c1)) / 2.f;
+        const float b2 = 2.f * hw;
+        const float c2 = (omo * ww) * hh;
+        const float r2 = (b2 + sqrtf(b2 * b2 - 16.f * c2)) / 2.f;
+        const float a3x4 = (float)(4.0 * (4.0 * overlap_d));      // python: 4 * a3 with a3 = 4 * min_overlap, both doubles
+        const float b3 = (float)(-2.0 * overlap_d) * hw;
+        const float c3 = (omn * ww) * hh;
+        const float r3 = (b3 + sqrtf(b3 * b3 - a3x4 * c3)) / 2.f;
+        int r = (int)fminf(fminf(r1, r2), r3);
+        r = r < min_radius ? min_radius : r;
+        rec.r = r;
+        rec.cls = hc - 1;
+        inds[(long long)b * num_max_objs + k] = (long long)cyi * fw + cxi;
+        mask[(long long)b * num_max_objs + k] = 1;
+        float* rb = ret_boxes + ((long long)b * num_max_objs + k) * ret_dim;
+        rb[0] = cxf - (float)cxi;
+        rb[1] = cyf - (float)cyi;
+        rb[2] = z;
+        rb[3] = logf(bx[3]); rb[4] = logf(bx[4]); rb[5] = logf(bx[5]);
+        rb[6] = cosf(bx[6]); rb[7] = sinf(bx[6]);
+        for (int e = 8; e < ret_dim; ++e) rb[e] = bx[e - 1];               // extra regression targets (velocity ...)
+      }
+      boxes[(long long)b * num_max_objs + k] = rec;
+    }
+  }
+  // slots that received no box
+  for (int k = base + lane; k < num_max_objs; k += 64) boxes[(long long)b * num_max_objs + k] = ChBox{0, 0, 0, -1};
+}
+
+__global__ __launch_bounds__(256) void k_ch_draw(const ChBox* __restrict__ boxes, int num_max_objs, int n_cls, int fw, int fh,
+                                                 float* __restrict__ heatmap) {
+  const int b = blockIdx.y, k = blockIdx.x;
+  const ChBox rec = boxes[(long long)b * num_max_objs + k];
+  if (rec.cls < 0) return;
+  const int r = rec.r, x = rec.cx, y = rec.cy;
+  const int left = x < r ? x : r, right = (fw - x) < (r + 1) ? (fw - x) : (r + 1);
+  const int top = y < r ? y : r, bottom = (fh - y) < (r + 1) ? (fh - y) : (r + 1);
+  const int wdt = left + right, hgt = top + bottom;
+  if (wdt <= 0 || hgt <= 0) return;
+  const double sigma = (double)(2 * r + 1) / 6.0;
+  const double den = 2.0 * sigma * sigma;
+  unsigned* hm = (unsigned*)(heatmap + ((long long)b * n_cls + rec.cls) * fh * fw);
+  for (int i = threadIdx.x; i < wdt * hgt; i += blockDim.x) {
+    const int dy = i / wdt - top, dx = i % wdt - left;
+    double v = exp(-(double)(dx * dx + dy * dy) / den);
+    if (v < 2.220446049250313e-16) v = 0.0;          // gaussian2D: h[h < eps * h.max()] = 0 (the patch maximum is 1)
+    const float f = (float)v;
+    atomicMax(hm + (long long)(y + dy) * fw + (x + dx), __float_as_uint(f));
+  }
+}
+
+extern "C" size_t gdmae_center_head_targets_workspace_bytes(int B, int num_max_objs) {
+  return gd_align((size_t)B * num_max_objs * sizeof(ChBox));
+}
+
+// gt_boxes (B, n_max, box_dim) fp32 device [x, y, z, dx, dy, dz, heading, (extras,) class]; class_map device int
+// (n_class_total + 1): global class id -> 1-based id inside this head or 0.  Outputs (zero-filled here): heatmap
+// (B, n_cls, fh, fw) fp32, ret_boxes (B, num_max_objs, box_dim) fp32, inds / mask (B, num_max_objs) int64.
+extern "C" int gdmae_center_head_targets(const float* gt_boxes, int B, int n_max, int box_dim, const int* class_map, int n_class_total,
+                                         int n_cls, const float* pc_range /* host [x0, y0] */, const float* voxel_size /* host [vx, vy] */,
+                                         float feature_map_stride, int fw, int fh, int num_max_objs, double gaussian_overlap, int min_radius,
+                                         float* heatmap, float* ret_boxes, long long* inds, long long* mask, void* workspace, void* stream) {
+  GD_REQUIRE(B >= 1 && box_dim >= 8 && n_cls >= 1 && fw >= 1 && fh >= 1 && num_max_objs >= 1, "center_head_targets: bad sizes");
+  hipStream_t st = (hipStream_t)stream;
+  GD_CHECK(hipMemsetAsync(heatmap, 0, (size_t)B * n_cls * fh * fw * sizeof(float), st));
+  GD_CHECK(hipMemsetAsync(ret_boxes, 0, (size_t)B * num_max_objs * box_dim * sizeof(float), st));
+  GD_CHECK(hipMemsetAsync(inds, 0, (size_t)B * num_max_objs * sizeof(long long), st));
+  GD_CHECK(hipMemsetAsync(mask, 0, (size_t)B * num_max_objs * sizeof(long long), st));
+  ChBox* boxes = (ChBox*)workspace;
+  if (n_max > 0) {
+    hipLaunchKernelGGL(k_ch_prepare, dim3(B), dim3(64), 0, st, gt_boxes, n_max, box_dim, class_map, n_class_total, pc_range[0], pc_range[1],
+                       voxel_size[0], voxel_size[1], feature_map_stride, fw, fh, num_max_objs, gaussian_overlap, min_radius, boxes, ret_boxes,
+                       inds, mask, box_dim);
+    GD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_ch_draw, dim3(num_max_objs < n_max ? num_max_objs : n_max, B), dim3(256), 0, st, (const ChBox*)boxes, num_max_objs,
+                       n_cls, fw, fh, heatmap);
+    GD_LAUNCH_CHECK();
+  }
+  return 0;
+}

@@ -57,6 +57,27 @@ def gdmae_finetune_backbone_cfg(**kw):
                      'FUSE_LAYER': b.FUSE_LAYER})
 
 
+def sst_bev_backbone_cfg():
+    """BACKBONE_2D section of tools/cfgs/waymo_models/gd_mae.yaml:205-213."""
+    k = lambda dil: {'out_channels': 128, 'kernel_size': 3, 'dilation': dil, 'padding': dil, 'stride': 1}   # noqa: E731
+    return AttrDict({'NAME': 'SSTBEVBackbone', 'NUM_FILTER': 128, 'CONV_KWARGS': [k(1), k(1), k(2), k(1)], 'CONV_SHORTCUT': [0, 1, 2]})
+
+
+def center_head_cfg(class_names=('Vehicle', 'Pedestrian', 'Cyclist'), post_range=(-75.2, -75.2, -2, 75.2, 75.2, 4)):
+    """DENSE_HEAD section of tools/cfgs/waymo_models/gd_mae.yaml:215-258 (CenterHead)."""
+    return AttrDict({
+        'NAME': 'CenterHead', 'CLASS_AGNOSTIC': False, 'CLASS_NAMES_EACH_HEAD': [list(class_names)],
+        'SHARED_CONV_CHANNEL': 64, 'USE_BIAS_BEFORE_NORM': True, 'NUM_HM_CONV': 2,
+        'SEPARATE_HEAD_CFG': {'HEAD_ORDER': ['center', 'center_z', 'dim', 'rot'],
+                              'HEAD_DICT': {'center': {'out_channels': 2, 'num_conv': 2}, 'center_z': {'out_channels': 1, 'num_conv': 2},
+                                            'dim': {'out_channels': 3, 'num_conv': 2}, 'rot': {'out_channels': 2, 'num_conv': 2}}},
+        'TARGET_ASSIGNER_CONFIG': {'FEATURE_MAP_STRIDE': 1, 'NUM_MAX_OBJS': 500, 'GAUSSIAN_OVERLAP': 0.1, 'MIN_RADIUS': 2},
+        'LOSS_CONFIG': {'LOSS_WEIGHTS': {'cls_weight': 1.0, 'loc_weight': 2.0, 'code_weights': [1.0] * 8}},
+        'POST_PROCESSING': {'SCORE_THRESH': 0.1, 'POST_CENTER_LIMIT_RANGE': list(post_range), 'MAX_OBJ_PER_SAMPLE': 500,
+                            'NMS_CONFIG': {'NMS_TYPE': 'nms_gpu', 'NMS_THRESH': 0.7, 'NMS_PRE_MAXSIZE': 4096, 'NMS_POST_MAXSIZE': 500}},
+    })
+
+
 def optimization_cfg(batch_size_per_gpu=8, num_epochs=30):
     """OPTIMIZATION section of the ssl yamls (gd_mae_ssl.yaml:183-203)."""
     return AttrDict({'BATCH_SIZE_PER_GPU': batch_size_per_gpu, 'NUM_EPOCHS': num_epochs, 'OPTIMIZER': 'adam_onecycle',
@@ -96,6 +117,17 @@ def named_config(name: str, mask_ratio=None):
     if name == 'B':
         m = gdmae_ssl_model_cfg(0.75 if mask_ratio is None else mask_ratio)
         return m, SyntheticDatasetInfo(**WAYMO), dict(beams=64, azimuths=2650, extra=10400, features=5)
+    if name == 'D':
+        # KITTI-shape fine-tune config (BASELINE-defined): 0.16 m pillars (432 x 496), SPTBackbone ->
+        # SSTBEVBackbone -> CenterHead behind the CenterPoint detector; head / BEV sections = waymo_models/gd_mae.yaml
+        ds = SyntheticDatasetInfo(point_cloud_range=KITTI['point_cloud_range'], voxel_size=[0.16, 0.16, 4], num_point_features=4,
+                                  class_names=KITTI['class_names'])
+        ssl = gdmae_ssl_model_cfg(0.0, eval_metric='kitti')
+        m = AttrDict({'NAME': 'CenterPoint', 'VFE': ssl.VFE, 'BACKBONE_3D': gdmae_finetune_backbone_cfg(),
+                      'BACKBONE_2D': sst_bev_backbone_cfg(),
+                      'DENSE_HEAD': center_head_cfg(KITTI['class_names'], post_range=(0, -40, -3, 70.4, 40, 1)),
+                      'POST_PROCESSING': ssl.POST_PROCESSING})
+        return m, ds, dict(beams=32, azimuths=600, extra=800, features=4)
     if name == 'E':
         m = gdmae_ssl_model_cfg(0.75 if mask_ratio is None else mask_ratio, d_models=(256, 256, 256), ffs=(512, 512, 512),
                                 num_blocks=1, vfe_mlps=(64, 256), eval_metric='once')

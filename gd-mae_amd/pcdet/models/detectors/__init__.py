@@ -1,9 +1,11 @@
 from .detector3d_template import Detector3DTemplate
+from .centerpoint import CenterPoint
 from .gd_mae import GDMAE
 
 __all__ = {
     'Detector3DTemplate': Detector3DTemplate,
     'GDMAE': GDMAE,
+    'CenterPoint': CenterPoint,
 }
 
 

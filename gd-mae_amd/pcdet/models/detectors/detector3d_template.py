@@ -8,7 +8,7 @@ import os
 import torch
 import torch.nn as nn
 
-from .. import backbones_3d
+from .. import backbones_2d, backbones_3d, dense_heads
 from ..backbones_3d import vfe
 
 
@@ -68,6 +68,27 @@ class Detector3DTemplate(nn.Module):
         model_info_dict['module_list'].append(m)
         model_info_dict['num_point_features'] = m.num_point_features
         model_info_dict['backbone_channels'] = getattr(m, 'backbone_channels', None)
+        return m, model_info_dict
+
+    def build_backbone_2d(self, model_info_dict):
+        if self.model_cfg.get('BACKBONE_2D', None) is None:
+            return None, model_info_dict
+        m = backbones_2d.__all__[self.model_cfg.BACKBONE_2D.NAME](
+            model_cfg=self.model_cfg.BACKBONE_2D, input_channels=model_info_dict.get('num_bev_features', None))
+        model_info_dict['module_list'].append(m)
+        model_info_dict['num_bev_features'] = m.num_bev_features
+        return m, model_info_dict
+
+    def build_dense_head(self, model_info_dict):
+        if self.model_cfg.get('DENSE_HEAD', None) is None:
+            return None, model_info_dict
+        m = dense_heads.__all__[self.model_cfg.DENSE_HEAD.NAME](
+            model_cfg=self.model_cfg.DENSE_HEAD, input_channels=model_info_dict['num_bev_features'],
+            num_class=self.num_class if not self.model_cfg.DENSE_HEAD.CLASS_AGNOSTIC else 1, class_names=self.class_names,
+            grid_size=model_info_dict['grid_size'], point_cloud_range=model_info_dict['point_cloud_range'],
+            predict_boxes_when_training=self.model_cfg.get('ROI_HEAD', False), voxel_size=model_info_dict.get('voxel_size', False),
+            backbone_channels=model_info_dict.get('backbone_channels', None))
+        model_info_dict['module_list'].append(m)
         return m, model_info_dict
 
     def forward(self, **kwargs):

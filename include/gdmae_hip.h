@@ -478,6 +478,20 @@ int gdmae_ingroup_inds(const long long* group_inds, long long n, long long n_gro
 int gdmae_group_inner_inds(const long long* inverse_inds, long long n, long long M, int K, long long* group_inds,
                            void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- f1 (next row): CenterHead target assignment --------------------------------------------------- *
+ * Replaces the per-box Python / CPU loop of CenterHead.assign_targets (pcdet/models/dense_heads/center_head.py:106-221;
+ * centernet_utils.py:9-70 gaussian_radius / gaussian2D / draw_gaussian_to_heatmap) for one head: boxes of the head's
+ * classes are compacted per sample in input order; per box the clamped centre, the Gaussian radius (reference fp32
+ * operation order), inds / mask / regression targets [dx, dy, z, log dims, cos, sin, extras]; the heat map is the
+ * per-class maximum of the Gaussian patches (atomic max on non-negative floats: order independent).
+ * gt_boxes (B, n_max, box_dim >= 8) fp32 device, class in the last column (0 = padding); class_map (n_class_total + 1)
+ * device int: global class id -> 1-based id inside this head / 0.  Outputs are zero-filled by the call. */
+size_t gdmae_center_head_targets_workspace_bytes(int B, int num_max_objs);
+int gdmae_center_head_targets(const float* gt_boxes, int B, int n_max, int box_dim, const int* class_map, int n_class_total,
+                              int n_cls, const float* pc_range /* host [x0, y0] */, const float* voxel_size /* host [vx, vy] */,
+                              float feature_map_stride, int fw, int fh, int num_max_objs, double gaussian_overlap, int min_radius,
+                              float* heatmap, float* ret_boxes, long long* inds, long long* mask, void* workspace, void* stream);
+
 /* ---- a21: fused optimizer step over one flat buffer ------------------------------------------- *
  * Replaces clip_grad_norm_ (tools/train_utils/train_utils.py:52) and OptimWrapper.step
  * (tools/train_utils/optimization/fastai_optim.py:135-152: p *= 1 - wd*lr, then torch Adam). */

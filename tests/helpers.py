@@ -38,3 +38,6 @@ def assert_sampled_close(t, s_ref, c_ref, rtol, what):
     for i in (1, 2):
         e = abs(c[i] - c_ref[i]) / (abs(c_ref[i]) + 1e-12)
         assert e <= rtol, f"{what}: checksum[{i}] rel err {e:.3e} > {rtol}"
+
+
+from head_seed import seeded_head_state  # noqa: E402,F401  (stand-alone module: the golden generator imports it too)
