@@ -99,8 +99,11 @@ def test_bev_backbone_and_center_head_match_reference_golden():
     assert_sampled_close(sf.grad, z["sf_grad_s"], z["sf_grad_c"], 2e-3, "input gradient")
     gp = dict(net.named_parameters())
     gn = np.array([float(gp[str(k)].grad.double().norm()) for k in z["param_names"]])
-    rel = np.abs(gn - z["grad_norm"]) / (z["grad_norm"] + 1e-12)
-    assert (rel <= 5e-3).all(), [(str(z["param_names"][i]), rel[i]) for i in np.flatnonzero(rel > 5e-3)]
+    # (conv biases in front of a BatchNorm have an exactly-zero mathematical gradient: both sides hold round-off noise there,
+    #  hence the absolute slack relative to the largest gradient)
+    err = np.abs(gn - z["grad_norm"])
+    tol = 5e-3 * z["grad_norm"] + 1e-6 * z["grad_norm"].max()
+    assert (err <= tol).all(), [(str(z["param_names"][i]), gn[i], z["grad_norm"][i]) for i in np.flatnonzero(err > tol)]
 
 
 @pytest.mark.gpu
