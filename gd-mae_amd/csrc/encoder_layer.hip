@@ -15,9 +15,6 @@
 #include "gemm.h"
 #include <stdlib.h>
 
-bool gd_dw_gemm_supported(int M, int K);
-int gd_dw_gemm_slices(long long rows, int M, int K);
-
 namespace {
 
 constexpr long long kPad = 2048;
@@ -86,10 +83,10 @@ __global__ __launch_bounds__(256) void k_acc_vectors(AccJobs a) {
 // the split-K reduces of a layer's five weight gradients as ONE launch (blockIdx.y = job):
 // dst[i] += sum_{s < S} part[s * P + i], same slicing and association order as k_splitk_acc (gemm.hip)
 struct SplitkJobs {
-  const float* part[8];
-  float* dst[8];
-  int S[8];
-  long long P4[8];
+  const float* part[6];
+  float* dst[6];
+  int S[6];
+  long long P4[6];
   int count;
 };
 __global__ __launch_bounds__(256) void k_splitk_acc_jobs(SplitkJobs J) {
@@ -292,21 +289,6 @@ int linear_dw(const Ctx& c, const void* G, const void* X, float* dW, long long n
   return 0;
 }
 // the same with the reduce deferred: the partial products go to their own region and the job is appended to J
-int gd_dw_gemm_fwd_decl(hipStream_t st, const void* G, const void* X, long long rows, int M, int K, float* part, float* colpart);
-// own TN kernel: partial tiles (+ optional per-slice column sums of G = the bias gradient) and their reduce jobs
-int linear_dw_own(hipStream_t st, const void* G, const void* X, float* dW, long long n_pad, int m, int k, float* part, float* dbias,
-                  float* colpart, SplitkJobs& J) {
-  const int S = gd_dw_gemm_slices(n_pad, m, k);
-  GD_TRY(gd_dw_gemm_fwd_decl(st, G, X, n_pad, m, k, part, dbias ? colpart : nullptr));
-  GD_REQUIRE(J.count + (dbias ? 2 : 1) <= 8 && ((long long)m * k) % 4 == 0 && m % 4 == 0, "splitk jobs");
-  J.part[J.count] = part; J.dst[J.count] = dW; J.S[J.count] = S; J.P4[J.count] = (long long)m * k / 4;
-  ++J.count;
-  if (dbias) {
-    J.part[J.count] = colpart; J.dst[J.count] = dbias; J.S[J.count] = S; J.P4[J.count] = m / 4;
-    ++J.count;
-  }
-  return 0;
-}
 int linear_dw_deferred(const Ctx& c, const void* G, const void* X, float* dW, long long n_pad, int m, int k, float* part,
                        SplitkJobs& J) {
   const int S = splitk_for(n_pad, m, k);
@@ -417,12 +399,7 @@ Scratch scratch_layout(void* base, long long n_pad, int d, int ff, int es, int n
   {   // one split-K partial region per weight gradient of the backward (reduced together at the end of the layer)
     const int mk5[5][2] = {{d, ff}, {ff, d}, {d, d}, {2 * d, d}, {d, d}};
     for (int i = 0; i < 5; ++i)
-    {
-      int S = splitk_for(n_pad, mk5[i][0], mk5[i][1]);
-      if (gd_dw_gemm_supported(mk5[i][0], mk5[i][1]) && gd_dw_gemm_slices(n_pad, mk5[i][0], mk5[i][1]) > S)
-        S = gd_dw_gemm_slices(n_pad, mk5[i][0], mk5[i][1]);
-      s.part_w[i] = take((size_t)S * mk5[i][0] * mk5[i][1] * sizeof(float));
-    }
+      s.part_w[i] = take((size_t)splitk_for(n_pad, mk5[i][0], mk5[i][1]) * mk5[i][0] * mk5[i][1] * sizeof(float));
   }
   {
     const int cm = ff > 2 * d ? ff : 2 * d;
@@ -452,11 +429,7 @@ int gd_tok_gemm_res_ln(hipStream_t st, const void* X, const void* Wp, const void
                        const float* res, const float* gamma, const float* beta, float eps, float* y, float* stats, void* y_bf,
                        const float* pos_table, const int* tok_pos, void* ypos_bf, void* f_out);
 
-int gd_dw_gemm(hipStream_t st, const void* G, const void* X, long long rows, int M, int K, float* part, float* colpart);
 namespace {
-int gd_dw_gemm_fwd_decl(hipStream_t st, const void* G, const void* X, long long rows, int M, int K, float* part, float* colpart) {
-  return gd_dw_gemm(st, G, X, rows, M, K, part, colpart);
-}
 // packed weight image of a layer: element offsets (in bf16 elements) of the ten operands
 struct Packed {
   const char *qk, *v, *o, *w1, *w2, *w2t, *w1t, *ot, *qkt, *vt;
@@ -633,12 +606,7 @@ static int layer_bwd(const gdmae_layer_args* a, bool upstream3, bool defer_add3,
                                    (float*)w.dx1_res, a->bf16 ? w.dfb : nullptr, nullptr, w.ln_ws2, c.st));
   SplitkJobs SJ;
   SJ.count = 0;
-  const bool own_dw = use_fused(a) && gd_dw_gemm_supported(d, ff) && gd_dw_gemm_supported(ff, d) && gd_dw_gemm_supported(2 * d, d) &&
-                      gd_dw_gemm_supported(d, d);
-  const int cm_ = ff > 2 * d ? ff : 2 * d;
-  float* cpart[3] = {(float*)w.cs_part, (float*)w.cs_part + (size_t)kColsumBlocks * cm_, (float*)w.cs_part + (size_t)2 * kColsumBlocks * cm_};
-  if (own_dw) GD_TRY(linear_dw_own(c.st, w.dfb, s.gact, a->dW2, n_pad, d, ff, (float*)w.part_w[0], nullptr, nullptr, SJ));
-  else GD_TRY(linear_dw_deferred(c, w.dfb, s.gact, a->dW2, n_pad, d, ff, (float*)w.part_w[0], SJ));
+  GD_TRY(linear_dw_deferred(c, w.dfb, s.gact, a->dW2, n_pad, d, ff, (float*)w.part_w[0], SJ));
   const bool fused = use_fused(a);
   const Packed pk = packed_layout(a->packed, d, ff);
   if (fused) {
@@ -647,15 +615,13 @@ static int layer_bwd(const gdmae_layer_args* a, bool upstream3, bool defer_add3,
     GD_TRY(linear_dx(c, w.dfb, a->W2, w.dg, n_pad, d, ff));
     GD_TRY(gelu(c, false, w.dg, s.h, w.dh, n_pad * ff));
   }
-  if (own_dw) GD_TRY(linear_dw_own(c.st, w.dh, s.x1b, a->dW1, n_pad, ff, d, (float*)w.part_w[1], a->db1, cpart[0], SJ));
-  else GD_TRY(linear_dw_deferred(c, w.dh, s.x1b, a->dW1, n_pad, ff, d, (float*)w.part_w[1], SJ));
+  GD_TRY(linear_dw_deferred(c, w.dh, s.x1b, a->dW1, n_pad, ff, d, (float*)w.part_w[1], SJ));
   if (fused) GD_TRY(gd_tok_gemm_plain(c.st, w.dh, pk.w1t, nullptr, n_pad, ff, d, w.dx1_b));
   else GD_TRY(linear_dx(c, w.dh, a->W1, w.dx1_b, n_pad, ff, d));
   // ---- LN1 (gradient = residual branch + FFN branch) and out-projection
   GD_TRY(gd_add_layernorm_bwd_ex(a->x, s.a, a->bf16, a->g1, (const float*)s.st1, (const float*)w.dx1_res, w.dx1_b, a->bf16, nullptr, 0,
                                  n, d, (float*)w.dx_res, a->bf16 ? w.dab : nullptr, nullptr, w.ln_ws, c.st));
-  if (own_dw) GD_TRY(linear_dw_own(c.st, w.dab, s.o, a->dWo, n_pad, d, d, (float*)w.part_w[2], nullptr, nullptr, SJ));
-  else GD_TRY(linear_dw_deferred(c, w.dab, s.o, a->dWo, n_pad, d, d, (float*)w.part_w[2], SJ));
+  GD_TRY(linear_dw_deferred(c, w.dab, s.o, a->dWo, n_pad, d, d, (float*)w.part_w[2], SJ));
   if (fused) GD_TRY(gd_tok_gemm_plain(c.st, w.dab, pk.ot, nullptr, n_pad, d, d, w.d_o));
   else GD_TRY(linear_dx(c, w.dab, a->Wo, w.d_o, n_pad, d, d));
   // ---- attention
@@ -671,15 +637,10 @@ static int layer_bwd(const gdmae_layer_args* a, bool upstream3, bool defer_add3,
   }
   GD_TRY(gdmae_sum_partials_gated((const float*)w.apart, pbase, 1.f, (float*)w.dtau, a->tau, a->tau_min, stream));
   const char* Win = (const char*)a->Win;
-  if (own_dw) {
-    GD_TRY(linear_dw_own(c.st, w.dqk, s.xpb, a->dWin, n_pad, 2 * d, d, (float*)w.part_w[3], a->dbin, cpart[1], SJ));
-    GD_TRY(linear_dw_own(c.st, w.dv, s.xb, a->dWin + (size_t)2 * d * d, n_pad, d, d, (float*)w.part_w[4], a->dbin + 2 * d, cpart[2], SJ));
-  } else {
-    GD_TRY(linear_dw_deferred(c, w.dqk, s.xpb, a->dWin, n_pad, 2 * d, d, (float*)w.part_w[3], SJ));
-    GD_TRY(linear_dw_deferred(c, w.dv, s.xb, a->dWin + (size_t)2 * d * d, n_pad, d, d, (float*)w.part_w[4], SJ));
-  }
-  GD_TRY(splitk_acc_jobs(c, SJ));                      // the split-K reduces of the layer (weights + biases) as one launch
-  if (!own_dw) {
+  GD_TRY(linear_dw_deferred(c, w.dqk, s.xpb, a->dWin, n_pad, 2 * d, d, (float*)w.part_w[3], SJ));
+  GD_TRY(linear_dw_deferred(c, w.dv, s.xb, a->dWin + (size_t)2 * d * d, n_pad, d, d, (float*)w.part_w[4], SJ));
+  GD_TRY(splitk_acc_jobs(c, SJ));                      // the five split-K reduces of the layer as one launch
+  {
     ColsumJobs J;
     J.count = 3;
     J.x[0] = w.dh;  J.dst[0] = a->db1;           J.C[0] = ff;

@@ -416,13 +416,6 @@ size_t gdmae_layer_packed_bytes(int d, int ff);
 int gdmae_layer_pack_jobs(const float* Win, const float* Wo, const float* W1, const float* W2, int d, int ff, void* packed,
                           long long* jobs_host /* 60 */);
 int gdmae_tok_gemm_pack(const long long* jobs_dev, int n_jobs, void* stream);
-/* Weight gradient of a token-wise linear layer: dW (M, K) fp32 = G^T X over `rows` token rows (a multiple of 2048; G
- * (rows, M), X (rows, K) bf16 row-major, M and K multiples of 128), dbias (M) fp32 = column sums of G (optional).  Own
- * bf16-MFMA "TN" kernel, split over row slices, fixed-order reduce (deterministic); replaces the batched hipBLASLt
- * split-K product + the separate bias column-sum launches. */
-size_t gdmae_dw_gemm_workspace_bytes(long long rows, int M, int K);
-int gdmae_dw_gemm(const void* G, const void* X, long long rows, int M, int K, float* dW, float* dbias, void* workspace,
-                  void* stream);
 /* Y = epilogue(X Wp^T + bias): X (n_pad, K) bf16 rows (n_pad % 64 == 0), Wp = packed (N, K) weights, bias (N) bf16 or
  * NULL; (K, N) in {128, 256} x {128, 256}, (256, 512), (512, 256).  epilogue 0: out0 = . (bf16); 1: out0 = h = . and
  * out1 = gelu_erf(h); 2: out0 = . * gelu'(aux) (aux = h); 3: y = LayerNorm(res + bf16(.)) fp32 (first n rows), stats
