@@ -109,6 +109,9 @@ SIGNATURES = {
     "gdmae_group_inner_inds": (_I, [_P, _L, _L, _I, _P, _P, _Z, _P]),
     "gdmae_center_head_targets_workspace_bytes": (_Z, [_I, _I]),
     "gdmae_center_head_targets": (_I, [_P, _I, _I, _I, _P, _I, _I, _P, _P, _F, _I, _I, _I, _D, _I, _P, _P, _P, _P, _P, _P]),
+    "gdmae_boxes_bev_pairs": (_I, [_P, _I, _P, _I, _I, _P, _P]),
+    "gdmae_nms_workspace_bytes": (_Z, [_I]),
+    "gdmae_nms_bev": (_I, [_P, _I, _F, _I, _P, _P, _P, _P]),
     "gdmae_grad_sq_norm": (_I, [_P, _L, _P, _P, _P]),
     "gdmae_adam_step": (_I, [_P, _P, _P, _P, _P, _I, _F, _F, _F, _F, _F, _I, _F, _F, _P, _P]),
 }

@@ -7,8 +7,8 @@ regression maps).  What differs is where the work happens: the reference assigns
 the CPU (numpy Gaussian patches, a D2H + H2D round trip per sample); here ``assign_targets`` is two launches of
 libgdmae_hip.so per head (``gdmae_center_head_targets``), no host transfer.
 
-Evaluation-time box decoding + rotated NMS (``generate_predicted_boxes``: centernet_utils.decode_bbox_from_heatmap,
-iou3d_nms) is outside the training hot path and raises."""
+Evaluation: ``generate_predicted_boxes`` (center_head.py:279-342) decodes the K best heat-map cells
+(model_utils/centernet_utils.py) and runs the rotated NMS of csrc/iou3d_nms.hip through ``model_nms_utils``."""
 import copy
 
 import torch
@@ -16,6 +16,7 @@ import torch.nn as nn
 from torch.nn.init import kaiming_normal_
 
 from gdmae_hip import lib as L
+from ..model_utils import centernet_utils, model_nms_utils
 
 
 class SeparateHead(nn.Module):
@@ -142,7 +143,34 @@ class CenterHead(nn.Module):
         return loss, tb_dict
 
     def generate_predicted_boxes(self, batch_size, pred_dicts):
-        raise NotImplementedError("box decoding + rotated NMS (iou3d_nms) belong to evaluation, outside the training hot path")
+        cfg = self.model_cfg.POST_PROCESSING
+        dev = pred_dicts[0]['hm'].device
+        limit = torch.tensor(cfg.POST_CENTER_LIMIT_RANGE, dtype=torch.float32, device=dev)
+        ret = [{'pred_boxes': [], 'pred_scores': [], 'pred_labels': []} for _ in range(batch_size)]
+        for idx, pd in enumerate(pred_dicts):
+            hm = pd['hm'].float().sigmoid()
+            vel = pd['vel'].float() if 'vel' in self.separate_head_cfg.HEAD_ORDER else None
+            finals = centernet_utils.decode_bbox_from_heatmap(
+                heatmap=hm, rot_cos=pd['rot'][:, 0:1].float(), rot_sin=pd['rot'][:, 1:2].float(), center=pd['center'].float(),
+                center_z=pd['center_z'].float(), dim=pd['dim'].float().exp(), vel=vel, iou=torch.ones_like(hm[:, 0:1]),
+                point_cloud_range=self.point_cloud_range, voxel_size=self.voxel_size, feature_map_stride=self.feature_map_stride,
+                K=cfg.MAX_OBJ_PER_SAMPLE, circle_nms=(cfg.NMS_CONFIG.NMS_TYPE == 'circle_nms'), score_thresh=cfg.SCORE_THRESH,
+                post_center_limit_range=limit)
+            cmap = torch.tensor([self.class_names.index(c) for c in self.class_names_each_head[idx]], dtype=torch.int64, device=dev)
+            for k, fd in enumerate(finals):
+                labels = cmap[fd['pred_labels'].long()]
+                if cfg.NMS_CONFIG.NMS_TYPE != 'nms_gpu':
+                    raise NotImplementedError(cfg.NMS_CONFIG.NMS_TYPE)
+                selected, selected_scores = model_nms_utils.class_agnostic_nms(box_scores=fd['pred_scores'], box_preds=fd['pred_boxes'],
+                                                                               nms_config=cfg.NMS_CONFIG, score_thresh=None)
+                ret[k]['pred_boxes'].append(fd['pred_boxes'][selected])
+                ret[k]['pred_scores'].append(selected_scores)
+                ret[k]['pred_labels'].append(labels[selected])
+        for k in range(batch_size):
+            ret[k]['pred_boxes'] = torch.cat(ret[k]['pred_boxes'], dim=0)
+            ret[k]['pred_scores'] = torch.cat(ret[k]['pred_scores'], dim=0)
+            ret[k]['pred_labels'] = torch.cat(ret[k]['pred_labels'], dim=0) + 1
+        return ret
 
     def forward(self, data_dict):
         x = self.shared_conv(data_dict['spatial_features_2d'])

@@ -17,7 +17,17 @@ class CenterPoint(Detector3DTemplate):
         if self.training:
             loss, tb_dict, disp_dict = self.get_training_loss()
             return {'loss': loss}, tb_dict, disp_dict
-        raise NotImplementedError("evaluation post-processing (box decoding, rotated NMS, recall) is outside the training hot path")
+        return self.post_processing(batch_dict)
+
+    def post_processing(self, batch_dict):
+        """(pred_dicts, recall_dict) as the reference's CenterPoint.post_processing (centerpoint.py:37-52)."""
+        cfg = self.model_cfg.POST_PROCESSING
+        final = batch_dict['final_box_dicts']
+        recall = {}
+        for index in range(batch_dict['batch_size']):
+            recall = self.generate_recall_record(box_preds=final[index]['pred_boxes'], recall_dict=recall, batch_index=index,
+                                                 data_dict=batch_dict, thresh_list=cfg.RECALL_THRESH_LIST)
+        return final, recall
 
     def get_training_loss(self):
         loss_rpn, tb_dict = self.dense_head.get_loss()

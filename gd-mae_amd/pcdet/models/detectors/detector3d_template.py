@@ -91,6 +91,33 @@ class Detector3DTemplate(nn.Module):
         model_info_dict['module_list'].append(m)
         return m, model_info_dict
 
+    @staticmethod
+    def generate_recall_record(box_preds, recall_dict, batch_index, data_dict=None, thresh_list=None):
+        """Recall bookkeeping of the evaluation loop (reference detector3d_template.py:318-358): ground-truth boxes matched by
+        a predicted box with 3-D IoU above each threshold (``recall_rcnn_*``; ``recall_roi_*`` when RoIs are present)."""
+        from ...ops.iou3d_nms import iou3d_nms_utils
+        if 'gt_boxes' not in data_dict:
+            return recall_dict
+        rois = data_dict['rois'][batch_index] if 'rois' in data_dict else None
+        gt = data_dict['gt_boxes'][batch_index]
+        if len(recall_dict) == 0:
+            recall_dict = {'gt_num': 0}
+            for t in thresh_list:
+                recall_dict['recall_roi_%s' % str(t)] = 0
+                recall_dict['recall_rcnn_%s' % str(t)] = 0
+        nz = (gt.abs().sum(dim=1) != 0).nonzero()
+        gt = gt[:int(nz.max()) + 1] if nz.numel() else gt[:0]       # trailing all-zero rows are padding
+        if gt.shape[0] > 0:
+            iou_rcnn = iou3d_nms_utils.boxes_iou3d_gpu(box_preds[:, 0:7], gt[:, 0:7]) if box_preds.shape[0] > 0 else None
+            iou_roi = iou3d_nms_utils.boxes_iou3d_gpu(rois[:, 0:7], gt[:, 0:7]) if rois is not None else None
+            for t in thresh_list:
+                if iou_rcnn is not None:
+                    recall_dict['recall_rcnn_%s' % str(t)] += int((iou_rcnn.max(dim=0)[0] > t).sum().item())
+                if iou_roi is not None:
+                    recall_dict['recall_roi_%s' % str(t)] += int((iou_roi.max(dim=0)[0] > t).sum().item())
+            recall_dict['gt_num'] += gt.shape[0]
+        return recall_dict
+
     def forward(self, **kwargs):
         raise NotImplementedError
 

@@ -492,6 +492,18 @@ int gdmae_center_head_targets(const float* gt_boxes, int B, int n_max, int box_d
                               float feature_map_stride, int fw, int fh, int num_max_objs, double gaussian_overlap, int min_radius,
                               float* heatmap, float* ret_boxes, long long* inds, long long* mask, void* workspace, void* stream);
 
+/* ---- f4 (next row): rotated BEV IoU and NMS for evaluation ------------------------------------------ *
+ * Replace the iou3d_nms CUDA extension (pcdet/ops/iou3d_nms/src/iou3d_nms_kernel.cu:236-414; iou3d_nms.cpp): boxes
+ * (n, 7) fp32 device [x, y, z, dx, dy, dz, heading].  The overlap is the reference's: intersection polygon from proper
+ * edge crossings + corners inside the other box with a 1e-2 margin, ordered by angle, shoelace area (fp32).
+ * gdmae_boxes_bev_pairs: out (n, m) = BEV overlap area (mode 0) or BEV IoU (mode 1).
+ * gdmae_nms_bev: boxes sorted by descending score -> keep (n) int64 kept indices in order, n_keep device int; rotated 1 =
+ * rotated IoU (nms_gpu), 0 = axis-aligned footprints (nms_normal_gpu).  The suppression masks are scanned on the device. */
+int gdmae_boxes_bev_pairs(const float* boxes_a, int n, const float* boxes_b, int m, int mode, float* out, void* stream);
+size_t gdmae_nms_workspace_bytes(int n);
+int gdmae_nms_bev(const float* boxes, int n, float thresh, int rotated, long long* keep, int* n_keep, void* workspace,
+                  void* stream);
+
 /* ---- a21: fused optimizer step over one flat buffer ------------------------------------------- *
  * Replaces clip_grad_norm_ (tools/train_utils/train_utils.py:52) and OptimWrapper.step
  * (tools/train_utils/optimization/fastai_optim.py:135-152: p *= 1 - wd*lr, then torch Adam). */
