@@ -22,12 +22,15 @@ def _boxes(rng, n, spread=6.0):
 
 def test_oracle_overlap_agrees_with_exact_clipping():
     """The restated reference algorithm (edge crossings + corners inside with a 1e-2 margin) vs exact Sutherland-Hodgman
-    clipping in float64: equal up to the margin's slivers (<= 5e-3 m^2 on boxes of 0.5 .. 12.5 m^2); identical boxes give
+    clipping in float64: equal up to the margin's slivers (a touching corner counted as inside adds at most a triangle of
+    ~margin x edge: <= 1.5e-2 m^2 on boxes of 0.5 .. 12.5 m^2, relative to the exact value <= 2 % where it exceeds 1 m^2);
+    identical boxes give
     IoU 1, disjoint boxes 0, and containment the inner area."""
     rng = np.random.default_rng(1)
     A, B = _boxes(rng, 40), _boxes(rng, 40)
-    worst = max(abs(float(orc.overlap(a, b)) - orc.exact_overlap(a, b)) for a in A for b in B)
-    assert worst <= 5e-3, worst
+    pairs = [(float(orc.overlap(a, b)), orc.exact_overlap(a, b)) for a in A for b in B]
+    assert max(abs(r - e) for r, e in pairs) <= 1.5e-2
+    assert max(abs(r - e) / e for r, e in pairs if e > 1.0) <= 2e-2 and sum(e > 1.0 for _, e in pairs) > 100
     a = A[0]
     assert abs(float(orc.iou_bev(a, a)) - 1.0) < 1e-4
     far = a.copy()
