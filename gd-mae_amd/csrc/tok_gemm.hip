@@ -31,7 +31,7 @@ union TgFrag {
   bf16x8 v;
 };
 
-#define TG_ROWS 64
+#define TG_ROWS 64     // row padding granule of the callers; the kernel's own tile is TG_R<ND> rows
 #define TG_WAVES 8
 #define TG_PF 4       // weight prefetch distance in k-steps
 
@@ -143,17 +143,26 @@ __device__ inline float tg_group_sum(float v) {
   return v;
 }
 
+// rows per workgroup: 32 for the wide outputs (one 32-row MFMA block per wavefront: twice the workgroups, half the
+// per-workgroup latency - the kernels are bound by how many load / compute / store phases overlap on a CU, not by bytes),
+// 64 for ND = 128 where the 8 wavefronts would otherwise not all have an output block
+template <int ND>
+struct TgRows {
+  static constexpr int value = ND >= 256 ? 32 : 64;
+};
+
 template <int KD, int ND, int EPI>
-__global__ __launch_bounds__(512, 2) void k_tok_gemm(TgArgs A) {
+__global__ __launch_bounds__(512, 4) void k_tok_gemm(TgArgs A) {
+  constexpr int ROWS = TgRows<ND>::value;   // 4 waves per SIMD = two workgroups per CU: <= 128 VGPRs
   constexpr int KS = KD / 16;                       // k-steps
   constexpr int MB = ND / 32;                       // 32-channel blocks of the output
   constexpr int MPW = MB >= TG_WAVES ? MB / TG_WAVES : 1;   // channel blocks per wavefront
-  constexpr int NPW = MB >= TG_WAVES ? 2 : 1;               // 32-row blocks per wavefront
+  constexpr int NPW = MB >= TG_WAVES ? ROWS / 32 : 1;       // 32-row blocks per wavefront
   constexpr int XP = KD * 2 + 16;                   // LDS row pitch of the activation tile (bytes)
   constexpr int SP = ND * 2 + 16;                   // LDS row pitch of the staging tile
   extern __shared__ __align__(16) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const long long row0 = (long long)blockIdx.x * TG_ROWS;
+  const long long row0 = (long long)blockIdx.x * ROWS;
 
   // ---- weight fragments of the first TG_PF k-steps: in flight while the activation tile is loaded
   const int mb0 = MB >= TG_WAVES ? wv : (wv >> 1);          // first channel block of this wavefront (then + TG_WAVES)
@@ -165,13 +174,30 @@ __global__ __launch_bounds__(512, 2) void k_tok_gemm(TgArgs A) {
 #pragma unroll
     for (int j = 0; j < MPW; ++j) wr[ks][j].q = wp[((size_t)ks * MB + j * TG_WAVES) * 64];
 
+  // ---- row-epilogue operands that do not depend on the product (residual rows, positional-table rows, GELU-backward
+  //      pre-activations) are requested NOW: their latency hides behind the tile load and the K loop instead of being paid
+  //      once per epilogue pass (the LayerNorm epilogue ran at half its HBM roof when it fetched them just in time)
+  constexpr int LN_LPR = ND / 4, LN_RPP = 512 / (LN_LPR > 0 ? LN_LPR : 1), LN_PASSES = (ROWS / LN_RPP) > 0 ? ROWS / LN_RPP : 1;
+  float4 res_pf[EPI == TG_RES_LN ? LN_PASSES : 1];
+  int pos_pf[EPI == TG_RES_LN ? LN_PASSES : 1];
+  if (EPI == TG_RES_LN) {
+    const int c0 = 4 * (tid % LN_LPR), r = tid / LN_LPR;
+#pragma unroll
+    for (int p = 0; p < LN_PASSES; ++p) {
+      const long long row = row0 + p * LN_RPP + r;
+      const long long rr = row < A.n ? row : A.n - 1;
+      res_pf[p] = *(const float4*)(A.res + rr * ND + c0);
+      pos_pf[p] = A.ypos_bf ? A.tok_pos[rr] : 0;
+    }
+  }
+
   // ---- activation tile: 64 rows x KD bf16, 16 bytes per thread and access
   {
     constexpr int CPR = KD / 8;                     // 16-byte chunks per row
     constexpr int RPP = 512 / CPR;                  // rows per pass
     const int c = tid % CPR, r = tid / CPR;
 #pragma unroll
-    for (int p = 0; p < TG_ROWS / RPP; ++p) {
+    for (int p = 0; p < (ROWS + RPP - 1) / RPP; ++p) {
       const int row = p * RPP + r;
       const uint4 q = *(const uint4*)(A.X + (row0 + row) * KD + c * 8);
       *(uint4*)(lds + row * XP + c * 16) = q;
@@ -245,12 +271,12 @@ __global__ __launch_bounds__(512, 2) void k_tok_gemm(TgArgs A) {
     const float4 g4 = *(const float4*)(A.gamma + c0), b4 = *(const float4*)(A.beta + c0);
     const float g[4] = {g4.x, g4.y, g4.z, g4.w}, bt[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
-    for (int p = 0; p < TG_ROWS / RPP; ++p) {
+    for (int p = 0; p < (ROWS + RPP - 1) / RPP; ++p) {
       const int rl = p * RPP + r;
       const long long row = row0 + rl;
       const bool live = row < A.n;
       const long long e = (live ? row : A.n - 1) * ND + c0;
-      const float4 a4 = *(const float4*)(A.res + e);
+      const float4 a4 = res_pf[p];
       const uint2 fq = *(const uint2*)(lds + rl * SP + c0 * 2);
       if (A.f_out) *(uint2*)(A.f_out + (row0 + rl) * ND + c0) = fq;
       float s[4] = {a4.x, a4.y, a4.z, a4.w};
@@ -275,7 +301,7 @@ __global__ __launch_bounds__(512, 2) void k_tok_gemm(TgArgs A) {
         *(uint2*)(A.y_bf + e) = q;
       }
       if (A.ypos_bf) {
-        const float4 p4 = *(const float4*)(A.pos_table + (long long)A.tok_pos[row] * ND + c0);
+        const float4 p4 = *(const float4*)(A.pos_table + (long long)pos_pf[p] * ND + c0);
         uint2 q;
         q.x = tg_pack2(o[0] + p4.x, o[1] + p4.y); q.y = tg_pack2(o[2] + p4.z, o[3] + p4.w);
         *(uint2*)(A.ypos_bf + e) = q;
@@ -287,7 +313,7 @@ __global__ __launch_bounds__(512, 2) void k_tok_gemm(TgArgs A) {
     constexpr int RPP = 512 / CPR;
     const int c = tid % CPR, r = tid / CPR;
 #pragma unroll
-    for (int p = 0; p < TG_ROWS / RPP; ++p) {
+    for (int p = 0; p < (ROWS + RPP - 1) / RPP; ++p) {
       const int rl = p * RPP + r;
       const long long e = (row0 + rl) * ND + c * 8;
       const uint4 q = *(const uint4*)(lds + rl * SP + c * 16);
@@ -315,13 +341,14 @@ __global__ __launch_bounds__(512, 2) void k_tok_gemm(TgArgs A) {
 
 template <int KD, int ND, int EPI>
 static int tg_launch(const TgArgs& A, hipStream_t st) {
-  constexpr int lds = TG_ROWS * ((KD > ND ? KD : ND) * 2 + 16);
+  constexpr int ROWS = TgRows<ND>::value;
+  constexpr int lds = ROWS * ((KD > ND ? KD : ND) * 2 + 16);
   static bool once = false;
   if (!once) {
     GD_CHECK(hipFuncSetAttribute((const void*)k_tok_gemm<KD, ND, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     once = true;
   }
-  hipLaunchKernelGGL((k_tok_gemm<KD, ND, EPI>), dim3((unsigned)(A.n_pad / TG_ROWS)), dim3(512), lds, st, A);
+  hipLaunchKernelGGL((k_tok_gemm<KD, ND, EPI>), dim3((unsigned)(A.n_pad / ROWS)), dim3(512), lds, st, A);
   GD_LAUNCH_CHECK();
   return 0;
 }
