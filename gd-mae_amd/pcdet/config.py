@@ -40,65 +40,91 @@ class AttrDict(dict):
         for k, v in dict(d or {}, **kw).items():
             self[k] = v
 
+    def setdefault(self, k, default=None):
+        if k not in self:
+            self[k] = default
+        return self[k]
+
 
 EasyDict = AttrDict  # name used by code written against the reference
 
 
 def log_config_to_file(cfg, pre='cfg', logger=None):
-    for key, val in cfg.items():
-        if isinstance(val, AttrDict):
-            logger.info('\n%s.%s = edict()' % (pre, key))
-            log_config_to_file(val, pre=pre + '.' + key, logger=logger)
-            continue
-        logger.info('%s.%s: %s' % (pre, key, val))
+    """One log line per leaf (``pre.KEY: value``), a header line per nested section - the lines ``tools/train.py`` writes at
+    start-up (API of reference pcdet/config.py:7-13)."""
+    stack = [(pre, cfg)]
+    while stack:
+        prefix, node = stack.pop()
+        nested = []
+        for key, val in node.items():
+            path = f'{prefix}.{key}'
+            if isinstance(val, AttrDict):
+                nested.append((path, val))
+            else:
+                logger.info('%s: %s' % (path, val))
+        for path, val in reversed(nested):               # depth first, sections in file order
+            logger.info('\n%s = edict()' % path)
+            stack.append((path, val))
+
+
+def _parse_scalar(text):
+    try:
+        return literal_eval(text)
+    except (ValueError, SyntaxError):
+        return text
+
+
+def _coerce(new, old, path, raw):
+    """Value written by a ``--set`` override: it must keep the type of the value it replaces; strings are split into the
+    existing container's shape (``a:1,b:2`` for a section, ``1,2,3`` for a list)."""
+    if isinstance(new, type(old)) and isinstance(old, type(new)):
+        return new
+    if isinstance(old, AttrDict):
+        out = AttrDict(old)
+        for item in raw.split(','):
+            sub, _, raw = item.partition(':')
+            out[sub] = type(old[sub])(raw)
+        return out
+    if isinstance(old, list):
+        return [type(old[0])(x) for x in raw.split(',')]
+    raise AssertionError('type {} does not match original type {} at {}'.format(type(new), type(old), path))
 
 
 def cfg_from_list(cfg_list, config):
-    """``--set A.B.C value`` overrides with literal_eval + type check (reference config.py:16-48)."""
-    assert len(cfg_list) % 2 == 0
-    for k, v in zip(cfg_list[0::2], cfg_list[1::2]):
-        keys = k.split('.')
-        d = config
-        for sub in keys[:-1]:
-            assert sub in d, 'NotFoundKey: %s' % sub
-            d = d[sub]
-        sub = keys[-1]
-        assert sub in d, 'NotFoundKey: %s' % sub
-        try:
-            value = literal_eval(v)
-        except Exception:
-            value = v
-        cur = d[sub]
-        if type(value) != type(cur) and isinstance(cur, AttrDict):
-            for src in value.split(','):
-                ck, cv = src.split(':')
-                cur[ck] = type(cur[ck])(cv)
-        elif type(value) != type(cur) and isinstance(cur, list):
-            d[sub] = [type(cur[0])(x) for x in value.split(',')]
-        else:
-            assert type(value) == type(cur), 'type {} does not match original type {}'.format(type(value), type(cur))
-            d[sub] = value
+    """``--set A.B.C value [A.D value ...]``: dotted paths must exist, values are python literals when they parse
+    (API and semantics of reference pcdet/config.py:16-48)."""
+    assert len(cfg_list) % 2 == 0, 'overrides come in (key, value) pairs'
+    for dotted, text in zip(cfg_list[0::2], cfg_list[1::2]):
+        *parents, leaf = dotted.split('.')
+        node = config
+        for name in parents + [leaf]:
+            assert name in node, 'NotFoundKey: %s' % name
+            if name is not leaf:
+                node = node[name]
+        node[leaf] = _coerce(_parse_scalar(text), node[leaf], dotted, text)
+
+
+def _load_yaml(path):
+    with open(path, 'r') as f:
+        return yaml.safe_load(f) or {}
 
 
 def merge_new_config(config, new_config):
-    """Recursive merge; non-dict values (lists included) replace wholesale (reference :51-68)."""
-    if '_BASE_CONFIG_' in new_config:
-        with open(new_config['_BASE_CONFIG_'], 'r') as f:
-            config.update(AttrDict(yaml.safe_load(f)))
+    """Overlay ``new_config`` on ``config``: sections merge recursively, everything else (lists included) replaces; a
+    ``_BASE_CONFIG_`` entry first pulls in that yaml file at the same level (reference pcdet/config.py:51-68)."""
+    base = new_config.get('_BASE_CONFIG_') if isinstance(new_config, dict) else None
+    if base is not None:
+        config.update(AttrDict(_load_yaml(base)))
     for key, val in new_config.items():
-        if not isinstance(val, dict):
+        if isinstance(val, dict):
+            merge_new_config(config.setdefault(key, AttrDict()), val)
+        else:
             config[key] = val
-            continue
-        if key not in config:
-            config[key] = AttrDict()
-        merge_new_config(config[key], val)
     return config
 
 
 def cfg_from_yaml_file(cfg_file, config):
-    with open(cfg_file, 'r') as f:
-        merge_new_config(config=config, new_config=yaml.safe_load(f))
-    return config
+    return merge_new_config(config=config, new_config=_load_yaml(cfg_file))
 
 
 cfg = AttrDict()
