@@ -20,6 +20,7 @@ import os
 import sys
 import time
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs on this driver (set before HIP starts)
 REPO = os.path.dirname(os.path.abspath(__file__))
 for p in (REPO, os.path.join(REPO, "gd-mae_amd")):
     if p not in sys.path:
@@ -205,6 +206,13 @@ def main():
         # nccl == RCCL on ROCm; GDMAE_DIST_BACKEND=gloo only for the control-flow smoke run of two ranks on one GPU
         dist.init_process_group(os.environ.get("GDMAE_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    if world > 1:
+        # create the communicator HERE, on the main thread and the current stream: the bucketed gradient exchange issues its
+        # first collectives from tensor hooks inside backward() (autograd thread, communication stream)
+        warm = torch.ones(1, device=dev)
+        dist.all_reduce(warm)
+        torch.cuda.synchronize()
+        assert int(warm.item()) == world
 
     from gdmae_hip import configs, optim, synth
     from pcdet.models import build_network
