@@ -141,8 +141,8 @@ def _pmc_traffic(kernels):
 ROOFLINE_KERNELS = {
     "k_conv3x3_tiles": ("mfma", ("k_conv3x3_tiles",)),
     "k_conv_grad_taps": ("hbm", ("k_conv_grad_taps",)),
-    "k_win_attn_bwd": ("hbm", ("k_win_attn_bwd", "k_attn_mfma_bwd", "k_attn_mfma16_bwd")),
-    "k_win_attn_fwd": ("hbm", ("k_win_attn_fwd", "k_attn_mfma_fwd", "k_attn_mfma16_fwd")),
+    "k_win_attn_bwd": ("hbm", ("k_win_attn_bwd", "k_attn_mfma_bwd", "k_attn_t16_bwd", "k_attn_t32_bwd", "k_attn_t64_bwd")),
+    "k_win_attn_fwd": ("hbm", ("k_win_attn_fwd", "k_attn_mfma_fwd", "k_attn_t16_fwd", "k_attn_t32_fwd", "k_attn_t64_fwd")),
 }
 
 

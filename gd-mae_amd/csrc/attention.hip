@@ -509,15 +509,22 @@ int gd_attn_mfma_bwd(const void* qk, const void* v, const void* dout, void* dqk,
                      const int* csr_tok, const int* win_start, const int* win_len, int n_win, int T, int d, int H,
                      const float* tau, float tau_min, hipStream_t st);
 
-// bf16-MFMA variant for bf16 token I/O (attention_mfma16.hip)
-int gd_attn_mfma16_fwd(const void* qk, const void* v, void* out, const int* csr_tok, const int* win_start, const int* win_len,
-                       int n_win, int T, int d, int H, const float* tau, float tau_min, hipStream_t st);
-int gd_attn_mfma16_bwd(const void* qk, const void* v, const void* dout, void* dqk, void* dv, float* dtau_part, const int* csr_tok,
-                       const int* win_start, const int* win_len, int n_win, int T, int d, int H, const float* tau, float tau_min,
-                       hipStream_t st);
+// bf16-MFMA variant of the T = 32 / 64 levels for bf16 token I/O (attention_t32.hip)
+int gd_attn_t32_fwd(const void* qk, const void* v, void* out, const int* csr_tok, const int* win_start, const int* win_len, int n_win,
+                    int T, int d, int H, const float* tau, float tau_min, hipStream_t st);
+int gd_attn_t32_bwd(const void* qk, const void* v, const void* dout, void* dqk, void* dv, float* dtau_part, const int* csr_tok,
+                    const int* win_start, const int* win_len, int n_win, int T, int d, int H, const float* tau, float tau_min,
+                    hipStream_t st);
 
-// 0: T >= 32 on the matrix cores (bf16 MFMA with split-bf16 logits for bf16 I/O, exact-fp32 MFMA for fp32 I/O), T = 16 on
-//    the lane-per-query VALU kernels;  1: VALU kernels only;  2: like 0 but always the exact-fp32 MFMA kernels
+// bf16-MFMA variant of the T = 16 level for bf16 token I/O (attention_t16.hip)
+int gd_attn_t16_fwd(const void* qk, const void* v, void* out, const int* csr_tok, const int* win_start, const int* win_len, int n_win,
+                    int d, int H, const float* tau, float tau_min, hipStream_t st);
+int gd_attn_t16_bwd(const void* qk, const void* v, const void* dout, void* dqk, void* dv, float* dtau_part, const int* csr_tok,
+                    const int* win_start, const int* win_len, int n_win, int d, int H, const float* tau, float tau_min, hipStream_t st);
+
+// 0: bf16 I/O on the bf16 matrix-core kernels at every level (attention_t16.hip, attention_t32.hip), fp32 I/O
+//    on the exact-fp32 MFMA kernels for T >= 32 and the lane-per-query VALU kernels for T = 16;
+// 1: VALU kernels only;  2: like 0 but always the exact-fp32 MFMA kernels for T >= 32 and the VALU kernels for T = 16
 static int g_attn_impl = 0;
 extern "C" int gdmae_set_attention_impl(int impl) {
   GD_REQUIRE(impl >= 0 && impl <= 2, "attention impl: 0 (auto), 1 (VALU only) or 2 (fp32 MFMA)");
@@ -537,8 +544,10 @@ extern "C" int gdmae_window_attention_fwd(const void* qk, const void* v, void* o
   GD_REQUIRE(T == 16 || T == 32 || T == 64, "T must be 16/32/64");
   GD_REQUIRE(H % (GD_WAVE / T) == 0, "heads must pack evenly into a wavefront");
   hipStream_t st = (hipStream_t)stream;
+  if (g_attn_impl == 0 && T == 16 && io_bf16 && H % 4 == 0)
+    return gd_attn_t16_fwd(qk, v, out, csr_tok, win_start, win_len, n_win, d, H, tau, tau_min, st);
   if (g_attn_impl == 0 && T >= 32 && io_bf16)
-    return gd_attn_mfma16_fwd(qk, v, out, csr_tok, win_start, win_len, n_win, T, d, H, tau, tau_min, st);
+    return gd_attn_t32_fwd(qk, v, out, csr_tok, win_start, win_len, n_win, T, d, H, tau, tau_min, st);
   if (g_attn_impl != 1 && T >= 32)
     return gd_attn_mfma_fwd(qk, v, out, io_bf16, csr_tok, win_start, win_len, n_win, T, d, H, tau, tau_min, st);
   AttnArgs A{qk, v, out, csr_tok, win_start, win_len, n_win, d, H, tau, tau_min};
@@ -556,8 +565,10 @@ extern "C" int gdmae_window_attention_bwd(const void* qk, const void* v, const v
   GD_REQUIRE(T == 16 || T == 32 || T == 64, "T must be 16/32/64");
   GD_REQUIRE(H % (GD_WAVE / T) == 0, "heads must pack evenly into a wavefront");
   hipStream_t st = (hipStream_t)stream;
+  if (g_attn_impl == 0 && T == 16 && io_bf16 && H % 4 == 0)
+    return gd_attn_t16_bwd(qk, v, dout, dqk, dv, dtau_part, csr_tok, win_start, win_len, n_win, d, H, tau, tau_min, st);
   if (g_attn_impl == 0 && T >= 32 && io_bf16)
-    return gd_attn_mfma16_bwd(qk, v, dout, dqk, dv, dtau_part, csr_tok, win_start, win_len, n_win, T, d, H, tau, tau_min, st);
+    return gd_attn_t32_bwd(qk, v, dout, dqk, dv, dtau_part, csr_tok, win_start, win_len, n_win, T, d, H, tau, tau_min, st);
   if (g_attn_impl != 1 && T >= 32)
     return gd_attn_mfma_bwd(qk, v, dout, dqk, dv, io_bf16, dtau_part, csr_tok, win_start, win_len, n_win, T, d, H, tau,
                             tau_min, st);

@@ -14,7 +14,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.abspath(os.path.join(HERE, "..", "csrc"))
 LIB = os.path.join(CSRC, "libgdmae_hip.so")
-SOURCES = ["capi.hip", "voxelize.hip", "mask.hip", "partition.hip", "segment.hip", "attention.hip", "attention_mfma.hip", "attention_mfma16.hip", "layernorm.hip", "decoder.hip", "chamfer.hip",
+SOURCES = ["capi.hip", "voxelize.hip", "mask.hip", "partition.hip", "segment.hip", "attention.hip", "attention_mfma.hip", "attention_t32.hip", "attention_t16.hip", "layernorm.hip", "decoder.hip", "chamfer.hip",
            "optim.hip", "input_pipeline.hip", "gemm.hip", "encoder_layer.hip", "conv_block.hip", "vfe_fused.hip", "vfe_layer2.hip", "conv_tiles.hip", "tok_gemm.hip", "center_head.hip", "iou3d_nms.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-Wno-unused-result"]
@@ -23,7 +23,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 # per-file additions.  -amdgpu-mfma-vgpr-form: MFMA results land in VGPRs instead of AGPRs; the attention kernels read
 # every accumulator element with VALU right after the MFMA, and the AGPR form costs one v_accvgpr_read per element
 # (551 -> 177 of ~5000 instructions in the T = 64 backward)
-EXTRA_FLAGS = {"attention_mfma16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
+EXTRA_FLAGS = {"attention_t32.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
+               "attention_t16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
                "vfe_fused.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
                "vfe_layer2.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 

@@ -287,10 +287,12 @@ int gdmae_segmax_bn_bwd(const void* x, int x_bf16, const float* out, const int* 
  * qk (Ms, 2d): projected queries [0,d) and keys [d,2d); v (Ms, d); out (Ms, d) written at token rows;
  * io_bf16 selects fp32 (0) or bf16 (1) rows in HBM - arithmetic is fp32 in registers either way.
  * Backward: dqk (Ms,2d), dv (Ms,d), dtau_part: n_win*H floats (partials of d loss / d clamp(tau)).
- * Levels with T >= 32 run on the matrix cores: exact fp32 v_mfma_f32_32x32x2_f32 for fp32 rows (attention_mfma.hip),
- * v_mfma_f32_32x32x16_bf16 with split-bf16 logits for bf16 rows (attention_mfma16.hip); T = 16 on the lane-per-query
- * VALU kernel.  gdmae_set_attention_impl: 0 = that default, 1 = VALU kernels everywhere, 2 = fp32 MFMA also for bf16
- * rows (A/B tests). */
+ * bf16 rows run on the bf16 matrix cores at every level: v_mfma_f32_16x16x{16,32}_bf16 with one wavefront per
+ * window x 4 heads at T = 16 (attention_t16.hip), v_mfma_f32_32x32x16_bf16 at T = 32 (one wavefront per window x head)
+ * and T = 64 (two wavefronts per window x head) (attention_t32.hip); logits come from the raw bf16 rows (exact products,
+ * fp32 accumulation) and are normalised afterwards.  fp32 rows: exact fp32 v_mfma_f32_32x32x2_f32 for T >= 32
+ * (attention_mfma.hip), lane-per-query VALU kernel for T = 16.  gdmae_set_attention_impl: 0 = that default, 1 = VALU
+ * kernels everywhere, 2 = fp32 MFMA (T >= 32) / VALU (T = 16) also for bf16 rows (A/B tests). */
 int gdmae_set_attention_impl(int impl);
 int gdmae_window_attention_fwd(const void* qk, const void* v, void* out, int io_bf16, const int* csr_tok,
                                const int* win_start, const int* win_len, int n_win, int T, int d, int H,

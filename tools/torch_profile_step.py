@@ -33,7 +33,23 @@ t0 = time.perf_counter()
 for i in range(6, 16): step(i)
 t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
 print(f"host issue time/step {(t1-t0)/10*1e3:.2f} ms; wall/step {(t2-t0)/10*1e3:.2f} ms")
-with profile(activities=[ProfilerActivity.CPU]) as prof:
-    for i in range(16, 19): step(i)
-    torch.cuda.synchronize()
-print(prof.key_averages().table(sort_by="self_cpu_time_total", row_limit=45, max_name_column_width=60))
+if "--aten" in sys.argv:
+    # which ATen operators still launch device kernels inside a step, and from which python line
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+        for i in range(16, 19): step(i)
+        torch.cuda.synchronize()
+    agg = {}
+    for e in prof.events():
+        dt = getattr(e, "self_device_time_total", 0)
+        if not dt or e.name.startswith(("hip", "Cijk", "Custom_Cijk")) or "k_" in e.name[:24] or "gd_scan" in e.name:
+            continue
+        src = next((f for f in (e.stack or []) if "/repo/" in f), "")
+        key = (e.name[:48], src.replace(REPO, "")[:100])
+        t = agg.setdefault(key, [0, 0.0]); t[0] += 1; t[1] += dt
+    for (name, src), (cnt, us) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:70]:
+        print(f"{us / 3:9.1f} us/step {cnt / 3:6.1f} calls/step  {name:48s} {src}")
+else:
+    with profile(activities=[ProfilerActivity.CPU]) as prof:
+        for i in range(16, 19): step(i)
+        torch.cuda.synchronize()
+    print(prof.key_averages().table(sort_by="self_cpu_time_total", row_limit=45, max_name_column_width=60))
