@@ -1,11 +1,11 @@
 // bf16-MFMA windowed cosine attention for the sparse occupancy level (T = 16 padded tokens), bf16 token I/O.
 //
 // Same contract as the lane-per-query kernels of attention.hip (reference cosine_msa.py:114-176 through
-// sst_basic_block.py:22-54): one wavefront = one window x 4 heads; the level holds windows of 1 ... 16 tokens.  The VALU
+// sst_basic_block.py:22-54): one wavefront = a 16-row tile (1 ... 4 consecutive windows of the level, packed) x one head.  The VALU
 // kernels spend ~4 k fp32 FMAs and ~1 k 16-byte LDS reads per wavefront on a 16 x 16 x DH problem; here every product is one
 // v_mfma_f32_16x16x{32,16}_bf16 per head:
 //
-//  * lane l = (c, g) = (l & 15, l >> 4) loads, for each of the 4 heads, the 4-element pieces dh = 16 p + 4 g + {0..3}
+//  * lane l = (c, g) = (l & 15, l >> 4) loads the 4-element pieces dh = 16 p + 4 g + {0..3}
 //    (p < DH / 16) of token row c - as A operand that is "row c, k-slots of group g", as B operand "column c", and it is
 //    exactly the piece of row c that the token-contracted outputs (dQ^T, dK^T, dV^T, O^T tiles: column c, rows 4 g + j of
 //    tile p) hand back to the lane, so epilogues are lane-local;
@@ -137,8 +137,51 @@ __device__ __forceinline__ void piece_f32(const uint2& w, float (&x)[4]) {
   x[0] = lo_f(w.x); x[1] = hi_f(w.x); x[2] = lo_f(w.y); x[3] = hi_f(w.y);
 }
 
-// LDS per wavefront: 4 heads x {tile A, tile B} + 4 heads x 4 x 16 floats
-constexpr int kWaveLds = 4 * 2 * kTile * 2 + 4 * 64 * 4;      // bytes
+// LDS per wavefront (= one head): {tile A, tile B} + 4 x 16 floats + 16 window ids
+constexpr int kWaveLds = 2 * kTile * 2 + 64 * 4 + 64;              // bytes
+constexpr int kWinPerWave = 4;       // consecutive windows of the level handled by one wavefront
+constexpr int kPadWin = 31;          // window id of a padding row
+
+// The level's windows hold 1 ... 16 tokens but ~5 on average, so a wavefront takes kWinPerWave consecutive windows and
+// packs them greedily (in order) into 16-row tiles: one pass = the windows [a, b) whose tokens fit one tile.  Rows of
+// different windows never attend to each other (their logits are masked like padded keys), so the results are those of
+// the one-window-per-tile kernel; 16 / 4.7 tokens would allow 3.4 windows per tile, four consecutive windows give ~2.4.
+struct Pass {
+  int a, b;        // windows [a, b) of the wave's kWinPerWave
+  int wid;         // this lane's row c: window (0 ... 3) or kPadWin
+  int tok;         // token index of row c (0 for padding rows)
+};
+__device__ __forceinline__ bool next_pass(Pass& ps, const int (&len)[kWinPerWave], const int (&start)[kWinPerWave], const int* __restrict__ csr_tok,
+                                          int c) {
+  int a = ps.b;
+  // skip windows past the end of the level (length 0)
+#pragma unroll
+  for (int i = 0; i < kWinPerWave; ++i)
+    if (i == a && len[i] == 0) ++a;
+  if (a >= kWinPerWave) return false;
+  int b = a, fill = 0;
+#pragma unroll
+  for (int i = 0; i < kWinPerWave; ++i)
+    if (i == b && i >= a && len[i] > 0 && fill + len[i] <= 16) {
+      fill += len[i];
+      b = i + 1;
+    }
+  int off = 0, idx = -1, wid = kPadWin;
+#pragma unroll
+  for (int i = 0; i < kWinPerWave; ++i) {
+    const int li = (i >= a && i < b) ? len[i] : 0;
+    if (c >= off && c < off + li) {
+      wid = i;
+      idx = start[i] + (c - off);
+    }
+    off += li;
+  }
+  ps.a = a;
+  ps.b = b;
+  ps.wid = wid;
+  ps.tok = idx >= 0 ? csr_tok[idx] : 0;
+  return true;
+}
 
 template <int DH>
 __global__ __launch_bounds__(256) void k_attn_t16_fwd(A16Args A) {
@@ -146,41 +189,46 @@ __global__ __launch_bounds__(256) void k_attn_t16_fwd(A16Args A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_t16[];
   const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
   const int c = lane & 15, g = lane >> 4;
-  unsigned short* tiles = reinterpret_cast<unsigned short*>(smem_t16 + wib * kWaveLds);
-  float* scal = reinterpret_cast<float*>(smem_t16 + wib * kWaveLds + 4 * 2 * kTile * 2);
+  unsigned short* tV = reinterpret_cast<unsigned short*>(smem_t16 + wib * kWaveLds);
+  float* sK = reinterpret_cast<float*>(tV + 2 * kTile);
+  int* sWid = reinterpret_cast<int*>(sK + 64);
+  // workgroup = (window quad, head quad): its 4 wavefronts take one head each (the quad's q / k / v pieces share cache lines)
   const int groups = A.H >> 2;
-  const long long item = (long long)blockIdx.x * 4 + wib;
-  if (item >= (long long)A.n_win * groups) return;
-  const int w = (int)(item / groups), hg = (int)(item % groups);
-  const int n = A.win_len[w], start = A.win_start[w];
-  const bool act = c < n;
-  const int tok = act ? A.csr_tok[start + c] : 0;
+  const int wq = blockIdx.x / groups, hd = 4 * (blockIdx.x % groups) + wib;
+  int len[kWinPerWave], start[kWinPerWave];
+#pragma unroll
+  for (int i = 0; i < kWinPerWave; ++i) {
+    const int w = kWinPerWave * wq + i;
+    len[i] = w < A.n_win ? A.win_len[w] : 0;
+    start[i] = w < A.n_win ? A.win_start[w] : 0;
+  }
   const float inv_tau = 1.f / fmaxf(*A.tau, A.tau_min);
   const int d = A.d;
-  Row<NP> q[4], k[4], v[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int col = (4 * hg + i) * DH + 4 * g;
-    q[i] = load_row<NP>(A.qk + (long long)tok * 2 * d + col, act);
-    k[i] = load_row<NP>(A.qk + (long long)tok * 2 * d + d + col, act);
-    v[i] = load_row<NP>(A.v + (long long)tok * d + col, act);
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    unsigned short* tV = tiles + i * 2 * kTile;
-    float* sK = scal + i * 64;
-    store_tile<NP>(tV, c, g, v[i]);
-    const float qa = inv_norm<NP>(q[i]) * inv_tau;
-    const float kin = inv_norm<NP>(k[i]);
-    if (g == 0) sK[c] = kin;
+  const int col = hd * DH + 4 * g;
+  Pass ps{0, 0, kPadWin, 0};
+  while (next_pass(ps, len, start, A.csr_tok, c)) {
+    const bool act = ps.wid != kPadWin;
+    const int tok = ps.tok;
+    const Row<NP> q = load_row<NP>(A.qk + (long long)tok * 2 * d + col, act);
+    const Row<NP> k = load_row<NP>(A.qk + (long long)tok * 2 * d + d + col, act);
+    const Row<NP> v = load_row<NP>(A.v + (long long)tok * d + col, act);
+    store_tile<NP>(tV, c, g, v);
+    const float qa = inv_norm<NP>(q) * inv_tau;
+    const float kin = inv_norm<NP>(k);
+    if (g == 0) {
+      sWid[c] = ps.wid;
+      sK[c] = kin;
+    }
     __builtin_amdgcn_wave_barrier();
+    const int4 kw4 = *reinterpret_cast<const int4*>(sWid + 4 * g);
     const float4 kk = *reinterpret_cast<const float4*>(sK + 4 * g);
-    f32x4 s = mma_rows<NP>(k[i], q[i]);                          // S^T[key 4 g + j][query c]
+    const int kw[4] = {kw4.x, kw4.y, kw4.z, kw4.w};
     const float kj[4] = {kk.x, kk.y, kk.z, kk.w};
+    f32x4 s = mma_rows<NP>(k, q);                                  // S^T[key 4 g + j][query c]
     float m = -1e30f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      s[j] = (4 * g + j < n) ? s[j] * qa * kj[j] : -1e30f;
+      s[j] = (kw[j] == ps.wid) ? s[j] * qa * kj[j] : -1e30f;       // keys of other windows and padding rows: masked
       m = fmaxf(m, s[j]);
     }
     m = grp_max(m);
@@ -191,15 +239,16 @@ __global__ __launch_bounds__(256) void k_attn_t16_fwd(A16Args A) {
       l += s[j];
     }
     l = grp_sum(l);
-    const float il = 1.f / l;
+    const float il = __builtin_amdgcn_rcpf(l);
     f32x4 o[NP];
 #pragma unroll
-    for (int p = 0; p < NP; ++p) o[p] = mma_tokens(tV, p, c, g, s);    // O^T[dh 16 p + 4 g + j][query c]
+    for (int p = 0; p < NP; ++p) o[p] = mma_tokens(tV, p, c, g, s);      // O^T[dh 16 p + 4 g + j][query c]
     if (act) {
-      unsigned short* dst = A.out + (long long)tok * d + (4 * hg + i) * DH + 4 * g;
+      unsigned short* dst = A.out + (long long)tok * d + col;
 #pragma unroll
       for (int p = 0; p < NP; ++p) store_piece(dst + 16 * p, o[p][0] * il, o[p][1] * il, o[p][2] * il, o[p][3] * il);
     }
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -209,89 +258,90 @@ __global__ __launch_bounds__(256) void k_attn_t16_bwd(A16BwdArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_t16[];
   const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
   const int c = lane & 15, g = lane >> 4;
-  unsigned short* tiles = reinterpret_cast<unsigned short*>(smem_t16 + wib * kWaveLds);
-  float* scal = reinterpret_cast<float*>(smem_t16 + wib * kWaveLds + 4 * 2 * kTile * 2);
+  unsigned short* tA = reinterpret_cast<unsigned short*>(smem_t16 + wib * kWaveLds);     // K (phase 1), then Q (phase 2)
+  unsigned short* tB = tA + kTile;                                                        // dO (phase 2)
+  float* sKin = reinterpret_cast<float*>(tB + kTile);
+  float* sQa = sKin + 16;
+  float* sLse = sKin + 32;
+  float* sD = sKin + 48;
+  int* sWid = reinterpret_cast<int*>(sKin + 64);
   const int groups = A.H >> 2;
-  const long long item = (long long)blockIdx.x * 4 + wib;
-  if (item >= (long long)A.n_win * groups) return;
-  const int w = (int)(item / groups), hg = (int)(item % groups);
-  const int n = A.win_len[w], start = A.win_start[w];
-  const bool act = c < n;
-  const int tok = act ? A.csr_tok[start + c] : 0;
+  const int wq = blockIdx.x / groups, hd = 4 * (blockIdx.x % groups) + wib;
+  int len[kWinPerWave], start[kWinPerWave];
+#pragma unroll
+  for (int i = 0; i < kWinPerWave; ++i) {
+    const int w = kWinPerWave * wq + i;
+    len[i] = w < A.n_win ? A.win_len[w] : 0;
+    start[i] = w < A.n_win ? A.win_start[w] : 0;
+  }
   const float inv_tau = 1.f / fmaxf(*A.tau, A.tau_min);
   const int d = A.d;
-  Row<NP> q[4], k[4], v[4], dO[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int col = (4 * hg + i) * DH + 4 * g;
-    q[i] = load_row<NP>(A.qk + (long long)tok * 2 * d + col, act);
-    k[i] = load_row<NP>(A.qk + (long long)tok * 2 * d + d + col, act);
-    v[i] = load_row<NP>(A.v + (long long)tok * d + col, act);
-    dO[i] = load_row<NP>(A.dout + (long long)tok * d + col, act);
-  }
+  const int col = hd * DH + 4 * g;
   float dtau = 0.f;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    unsigned short* tA = tiles + i * 2 * kTile;     // K (phase 1), then Q (phase 2)
-    unsigned short* tB = tA + kTile;                // dO (phase 2)
-    float* sKin = scal + i * 64;
-    float* sQa = sKin + 16;
-    float* sLse = sKin + 32;
-    float* sD = sKin + 48;
-    const int col = (4 * hg + i) * DH + 4 * g;
-    const float qin = inv_norm<NP>(q[i]);
-    const float kin = inv_norm<NP>(k[i]);
+  Pass ps{0, 0, kPadWin, 0};
+  while (next_pass(ps, len, start, A.csr_tok, c)) {
+    const bool act = ps.wid != kPadWin;
+    const int tok = ps.tok;
+    const Row<NP> q = load_row<NP>(A.qk + (long long)tok * 2 * d + col, act);
+    const Row<NP> k = load_row<NP>(A.qk + (long long)tok * 2 * d + d + col, act);
+    const Row<NP> v = load_row<NP>(A.v + (long long)tok * d + col, act);
+    const Row<NP> dO = load_row<NP>(A.dout + (long long)tok * d + col, act);
+    const float qin = inv_norm<NP>(q);
+    const float kin = inv_norm<NP>(k);
     const float qa = qin * inv_tau;
-    store_tile<NP>(tA, c, g, k[i]);
-    store_tile<NP>(tB, c, g, dO[i]);
+    store_tile<NP>(tA, c, g, k);
+    store_tile<NP>(tB, c, g, dO);
     if (g == 0) {
+      sWid[c] = ps.wid;
       sKin[c] = kin;
       sQa[c] = qa;
     }
     __builtin_amdgcn_wave_barrier();
+    const int4 kw4 = *reinterpret_cast<const int4*>(sWid + 4 * g);
     const float4 kk = *reinterpret_cast<const float4*>(sKin + 4 * g);
+    const int kw[4] = {kw4.x, kw4.y, kw4.z, kw4.w};               // window of rows 4 g + j (keys in phase 1, queries in phase 2)
     const float kj[4] = {kk.x, kk.y, kk.z, kk.w};
     // ---------------- phase 1: query on the lane -> dQ ----------------
     {
-      f32x4 s = mma_rows<NP>(k[i], q[i]);                        // S^T[key 4 g + j][query c] (raw dot products)
-      const f32x4 dP = mma_rows<NP>(v[i], dO[i]);                // dP^T[key][query]
+      f32x4 s = mma_rows<NP>(k, q);                                // S^T[key 4 g + j][query c] (raw dot products)
+      const f32x4 dP = mma_rows<NP>(v, dO);                        // dP^T[key][query]
       float m = -1e30f;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        s[j] = (4 * g + j < n) ? s[j] * qa * kj[j] : -1e30f;
+        s[j] = (kw[j] == ps.wid) ? s[j] * qa * kj[j] : -1e30f;     // other windows' keys and padding rows: masked
         m = fmaxf(m, s[j]);
       }
       m = grp_max(m);
       float e[4], l = 0.f, Dn = 0.f;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        e[j] = __expf(s[j] - m);                                 // exactly 0 for padded keys
+        e[j] = __expf(s[j] - m);                                   // exactly 0 for masked keys
         l += e[j];
         Dn = fmaf(e[j], dP[j], Dn);
       }
       l = grp_sum(l);
       Dn = grp_sum(Dn);
-      const float il = 1.f / l;
+      const float il = __builtin_amdgcn_rcpf(l);
       const float D = Dn * il;
       f32x4 dS;
       float dt = 0.f;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float ds = e[j] * il * (dP[j] - D);
-        dt = fmaf(ds, s[j], dt);                                 // padded key: 0 * -1e30 = -0
-        dS[j] = ds * kj[j];                                      // 1 / |k| of the key folded in: the A operand is the raw K row
+        dt = fmaf(ds, s[j], dt);                                   // masked key: 0 * -1e30 = -0
+        dS[j] = ds * kj[j];                                        // 1 / |k| of the key folded in: the A operand is the raw K row
       }
-      dtau = fmaf(-dt, inv_tau, dtau);                           // d a / d tau = -a / tau
+      if (act) dtau = fmaf(-dt, inv_tau, dtau);                    // d a / d tau = -a / tau
       if (g == 0) {
-        sLse[c] = act ? m + __logf(l) : 1e30f;                   // padded queries: exp(a - 1e30) = 0 in phase 2
+        sLse[c] = act ? m + __logf(l) : 1e30f;                     // padded queries: exp(a - 1e30) = 0 in phase 2
         sD[c] = D;
       }
       float qh[NP][4], pr = 0.f;
       f32x4 dq[NP];
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
-        dq[p] = mma_tokens(tA, p, c, g, dS);                     // dQ^^T[dh 16 p + 4 g + j][query c], without 1 / tau
-        piece_f32(q[i].p[p], qh[p]);
+        dq[p] = mma_tokens(tA, p, c, g, dS);                       // dQ^^T[dh 16 p + 4 g + j][query c], without 1 / tau
+        piece_f32(q.p[p], qh[p]);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           qh[p][j] *= qin;
@@ -309,29 +359,29 @@ __global__ __launch_bounds__(256) void k_attn_t16_bwd(A16BwdArgs A) {
     }
     // ---------------- phase 2: key on the lane -> dK, dV ----------------
     __builtin_amdgcn_wave_barrier();
-    store_tile<NP>(tA, c, g, q[i]);
+    store_tile<NP>(tA, c, g, q);
     __builtin_amdgcn_wave_barrier();
     {
       const float4 qq = *reinterpret_cast<const float4*>(sQa + 4 * g);
       const float4 ll = *reinterpret_cast<const float4*>(sLse + 4 * g);
       const float4 dd = *reinterpret_cast<const float4*>(sD + 4 * g);
       const float qj[4] = {qq.x, qq.y, qq.z, qq.w}, lj[4] = {ll.x, ll.y, ll.z, ll.w}, dj[4] = {dd.x, dd.y, dd.z, dd.w};
-      const f32x4 s = mma_rows<NP>(q[i], k[i]);                  // S[query 4 g + j][key c]
-      const f32x4 dP = mma_rows<NP>(dO[i], v[i]);                // dP[query][key]
+      const f32x4 s = mma_rows<NP>(q, k);                          // S[query 4 g + j][key c]
+      const f32x4 dP = mma_rows<NP>(dO, v);                        // dP[query][key]
       f32x4 P, dS;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float pj = act ? __expf(s[j] * qj[j] * kin - lj[j]) : 0.f;
+        const float pj = (kw[j] == ps.wid && act) ? __expf(s[j] * qj[j] * kin - lj[j]) : 0.f;    // same window only
         P[j] = pj;
-        dS[j] = pj * (dP[j] - dj[j]) * qj[j];                    // 1 / (|q| tau) of the query folded in
+        dS[j] = pj * (dP[j] - dj[j]) * qj[j];                      // 1 / (|q| tau) of the query folded in
       }
       float kh[NP][4], pr = 0.f;
       f32x4 dk[NP], dvv[NP];
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
-        dk[p] = mma_tokens(tA, p, c, g, dS);                     // dK^^T[dh][key c]
-        dvv[p] = mma_tokens(tB, p, c, g, P);                     // dV^T[dh][key c]
-        piece_f32(k[i].p[p], kh[p]);
+        dk[p] = mma_tokens(tA, p, c, g, dS);                       // dK^^T[dh][key c]
+        dvv[p] = mma_tokens(tB, p, c, g, P);                       // dV^T[dh][key c]
+        piece_f32(k.p[p], kh[p]);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           kh[p][j] *= kin;
@@ -350,11 +400,12 @@ __global__ __launch_bounds__(256) void k_attn_t16_bwd(A16BwdArgs A) {
         }
       }
     }
+    __builtin_amdgcn_wave_barrier();
   }
-  // every group of a column holds the same reduced statistics: the 4 groups counted each (query, key) pair once between
-  // them (dt sums this lane's 4 keys only), so the plain wave sum is the window total
+  // the 4 lane groups of a column hold the same reduced statistics and split the keys between them (dt sums this lane's 4
+  // keys), so the plain wave sum counts every (query, key) pair once; one partial per (window quad, head)
   dtau = gd_wave_sum(dtau);
-  if (lane == 0) A.dtau_part[item] = dtau;
+  if (lane == 0) A.dtau_part[(long long)blockIdx.x * 4 + wib] = dtau;
 }
 }  // namespace
 
@@ -362,8 +413,7 @@ __global__ __launch_bounds__(256) void k_attn_t16_bwd(A16BwdArgs A) {
 int gd_attn_t16_fwd(const void* qk, const void* v, void* out, const int* csr_tok, const int* win_start, const int* win_len, int n_win,
                     int d, int H, const float* tau, float tau_min, hipStream_t st) {
   A16Args A{(const unsigned short*)qk, (const unsigned short*)v, (unsigned short*)out, csr_tok, win_start, win_len, n_win, d, H, tau, tau_min};
-  const long long items = (long long)n_win * (H / 4);
-  const dim3 grid((unsigned)gd_div_up(items, 4));
+  const dim3 grid((unsigned)(gd_div_up(n_win, kWinPerWave) * (H / 4)));
   if (d / H == 16) hipLaunchKernelGGL((k_attn_t16_fwd<16>), grid, dim3(256), 4 * kWaveLds, st, A);
   else hipLaunchKernelGGL((k_attn_t16_fwd<32>), grid, dim3(256), 4 * kWaveLds, st, A);
   GD_LAUNCH_CHECK();
@@ -374,8 +424,7 @@ int gd_attn_t16_bwd(const void* qk, const void* v, const void* dout, void* dqk, 
                     const int* win_start, const int* win_len, int n_win, int d, int H, const float* tau, float tau_min, hipStream_t st) {
   A16BwdArgs A{(const unsigned short*)qk, (const unsigned short*)v, (const unsigned short*)dout, (unsigned short*)dqk, (unsigned short*)dv,
                dtau_part, csr_tok, win_start, win_len, n_win, d, H, tau, tau_min};
-  const long long items = (long long)n_win * (H / 4);
-  const dim3 grid((unsigned)gd_div_up(items, 4));
+  const dim3 grid((unsigned)(gd_div_up(n_win, kWinPerWave) * (H / 4)));
   if (d / H == 16) hipLaunchKernelGGL((k_attn_t16_bwd<16>), grid, dim3(256), 4 * kWaveLds, st, A);
   else hipLaunchKernelGGL((k_attn_t16_bwd<32>), grid, dim3(256), 4 * kWaveLds, st, A);
   GD_LAUNCH_CHECK();
