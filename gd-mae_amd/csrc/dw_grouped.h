@@ -1,0 +1,25 @@
+// Grouped weight-gradient launch (dw_grouped.hip): job table shared with the layer executor.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define GD_DW_MAX_JOBS 5
+
+struct GdDwJob {
+  const void* G;        // (rows, M) bf16 row-major: output gradient of the linear layer
+  const void* X;        // (rows, N) bf16 row-major: its input
+  int M, N;             // multiples of 128
+  float* part;          // (S, M, N) fp32 partial products
+  float* colpart;       // (S, M) fp32 column sums of G per slice, or null
+  int tile0;            // first 128 x 128 tile of this job in the layer's tile list (filled by gd_dw_grouped)
+};
+struct GdDwGroup {
+  GdDwJob job[GD_DW_MAX_JOBS];
+  int n_jobs;
+  int tiles_total;
+  int S;
+  long long rows_per_slice;
+};
+
+bool gd_dw_group_supported(long long n_pad, int d, int ff);
+int gd_dw_group_slices(long long n_pad, int tiles_total);
+int gd_dw_grouped(hipStream_t st, GdDwGroup& A, long long n_pad);

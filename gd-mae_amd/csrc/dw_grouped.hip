@@ -1,0 +1,260 @@
+// Weight gradients of one encoder layer as ONE launch (the backward of the nn.Linear layers of
+// sst_basic_block.py:57-84 and of the cosine_msa.py in- / out-projections):
+//
+//     dW_g (M_g, N_g) = G_g^T (M_g, rows) X_g (rows, N_g)        g = W2, W1, Wo, Wqk, Wv      rows = 20-50 k tokens
+//     db_g (M_g)      = column sums of G_g                        for the layers whose bias gradient is not a by-product
+//                                                                 of a LayerNorm backward (W1, Wqk, Wv)
+//
+// G / X are bf16 row-major, so the contraction runs over the slow axis of both operands: an MFMA fragment needs 8
+// consecutive rows of one column.  Chunks of 64 rows are staged row-major in LDS with 16-byte stores and the fragments are
+// read transposed (ds_read_b64_tr_b16); the 64-byte segments of a staged row are XOR-permuted with (row & 3), which makes
+// both the 16-byte stores and the transposed reads bank-conflict free at a 256-byte pitch.
+//
+// Work decomposition: the rows are cut into S slices; a workgroup (4 wavefronts = 2 x 2 blocks of 64 x 64) owns one
+// 128 x 128 output tile of one matrix for one slice, loops over the slice's chunks (next chunk prefetched into registers
+// behind the MFMAs) and writes its fp32 partial tile; partial tiles are summed in a fixed order by the caller's reduce
+// kernel (deterministic).  All tiles of a slice - every matrix of the layer - are placed on ONE XCD (blockIdx % 8), so
+// the 2-4x re-reads of a slice's activations by the tiles that share them are served by that XCD's L2.
+#include "common.h"
+#include "dw_grouped.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+constexpr int kTile = 128;
+constexpr int kChunk = 64;                       // rows per LDS stage
+constexpr int kRowBytes = kTile * 2;             // 256
+constexpr int kStage = kChunk * kRowBytes;       // one operand chunk: 16 KB
+
+// byte offset of the 16-byte unit `u16` (0 ... 15) of staged row `row`
+__device__ __forceinline__ int stage_off(int row, int u16) { return row * kRowBytes + (((u16 >> 2) ^ (row & 3)) << 6) + ((u16 & 3) << 4); }
+
+struct Chunk {          // this thread's four 16-byte pieces of a staged chunk (rows r, r + 16, r + 32, r + 48)
+  uint4 q0, q1, q2, q3;
+};
+__device__ __forceinline__ Chunk load_chunk(const unsigned short* __restrict__ base, int ld, long long row0, int col0, int tid) {
+  const int c = tid & 15, r = tid >> 4;
+  const unsigned short* p = base + (row0 + r) * ld + col0 + c * 8;
+  Chunk k;
+  k.q0 = *reinterpret_cast<const uint4*>(p);
+  k.q1 = *reinterpret_cast<const uint4*>(p + 16ll * ld);
+  k.q2 = *reinterpret_cast<const uint4*>(p + 32ll * ld);
+  k.q3 = *reinterpret_cast<const uint4*>(p + 48ll * ld);
+  return k;
+}
+__device__ __forceinline__ void store_chunk(unsigned char* __restrict__ lds, int tid, const Chunk& k) {
+  const int c = tid & 15, r = tid >> 4;
+  unsigned char* p = lds + stage_off(r, c);            // (row & 3) is the same for r, r + 16, ...
+  *reinterpret_cast<uint4*>(p) = k.q0;
+  *reinterpret_cast<uint4*>(p + 16 * kRowBytes) = k.q1;
+  *reinterpret_cast<uint4*>(p + 32 * kRowBytes) = k.q2;
+  *reinterpret_cast<uint4*>(p + 48 * kRowBytes) = k.q3;
+}
+__device__ __forceinline__ void add_bf16x8(const uint4& q, float (&cs)[8]) {
+  cs[0] += __uint_as_float(q.x << 16); cs[1] += __uint_as_float(q.x & 0xFFFF0000u);
+  cs[2] += __uint_as_float(q.y << 16); cs[3] += __uint_as_float(q.y & 0xFFFF0000u);
+  cs[4] += __uint_as_float(q.z << 16); cs[5] += __uint_as_float(q.z & 0xFFFF0000u);
+  cs[6] += __uint_as_float(q.w << 16); cs[7] += __uint_as_float(q.w & 0xFFFF0000u);
+}
+// operand fragment: column (col32 + (lane & 31)) of the staged chunk, rows k0 + 8 h + {0..7}
+__device__ __forceinline__ bf16x8 frag(const unsigned char* __restrict__ lds, int k0, int col32, int lane) {
+  const int i = lane & 15, grp = (lane >> 4) & 1, h = lane >> 5;
+  const int row = k0 + 8 * h + (i >> 2);
+  const int seg = col32 >> 5;                                      // 64-byte segment of the 32 columns
+  const unsigned char* p0 = lds + row * kRowBytes + ((seg ^ (row & 3)) << 6) + 32 * grp + 8 * (i & 3);
+  const int row1 = row + 4;
+  const unsigned char* p1 = lds + row1 * kRowBytes + ((seg ^ (row1 & 3)) << 6) + 32 * grp + 8 * (i & 3);
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)p0);
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)p1);
+  const uint2 a = __builtin_bit_cast(uint2, lo), b = __builtin_bit_cast(uint2, hi);
+  return __builtin_bit_cast(bf16x8, make_uint4(a.x, a.y, b.x, b.y));
+}
+
+__global__ __launch_bounds__(256, 2) void k_dw_grouped(GdDwGroup A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];        // [buffer][G | X][kStage]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  // slice s lives on XCD s % 8: blockIdx = xcd + 8 * (tile + tiles_total * (s / 8))
+  const int xcd = blockIdx.x & 7, pos = blockIdx.x >> 3;
+  const int sg = pos / A.tiles_total, t = pos - sg * A.tiles_total;
+  const int s = sg * 8 + xcd;
+  // uniform selects of the job fields (no dynamic indexing of the kernel argument, no struct temporaries)
+  const unsigned short* G = (const unsigned short*)A.job[0].G;
+  const unsigned short* X = (const unsigned short*)A.job[0].X;
+  float* part = A.job[0].part;
+  float* colpart = A.job[0].colpart;
+  int M = A.job[0].M, N = A.job[0].N, tile0 = 0;
+#pragma unroll
+  for (int j = 1; j < GD_DW_MAX_JOBS; ++j)
+    if (j < A.n_jobs && t >= A.job[j].tile0) {
+      G = (const unsigned short*)A.job[j].G;
+      X = (const unsigned short*)A.job[j].X;
+      part = A.job[j].part;
+      colpart = A.job[j].colpart;
+      M = A.job[j].M;
+      N = A.job[j].N;
+      tile0 = A.job[j].tile0;
+    }
+  const int tn_count = N / kTile;
+  const int tm = (t - tile0) / tn_count, tn = (t - tile0) - tm * tn_count;
+  const long long r0 = (long long)s * A.rows_per_slice;
+  const int nchunk = (int)(A.rows_per_slice / kChunk);
+  const int wm = wv >> 1, wn = wv & 1;                 // this wavefront's 64 x 64 block
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  float cs[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) cs[j] = 0.f;
+  const bool want_cs = colpart != nullptr && tn == 0;
+
+  // two chunks in flight in registers (the loads of chunk c + 2 are issued behind the barrier of chunk c: ~2 compute phases of
+  // latency cover per load), two LDS buffers
+  const int gcol = tm * kTile, xcol = tn * kTile;
+  Chunk g0 = load_chunk(G, M, r0, gcol, tid), x0 = load_chunk(X, N, r0, xcol, tid);
+  Chunk g1 = g0, x1 = x0;
+  if (nchunk > 1) {
+    g1 = load_chunk(G, M, r0 + kChunk, gcol, tid);
+    x1 = load_chunk(X, N, r0 + kChunk, xcol, tid);
+  }
+  auto compute = [&](const unsigned char* bg, const unsigned char* bx) {
+#pragma unroll
+    for (int ks = 0; ks < kChunk / 16; ++ks) {
+      const bf16x8 a0 = frag(bg, 16 * ks, wm * 64, lane), a1 = frag(bg, 16 * ks, wm * 64 + 32, lane);
+      const bf16x8 b0 = frag(bx, 16 * ks, wn * 64, lane), b1 = frag(bx, 16 * ks, wn * 64 + 32, lane);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+    }
+  };
+  unsigned char* bufg0 = lds;
+  unsigned char* bufx0 = lds + kStage;
+  unsigned char* bufg1 = lds + 2 * kStage;
+  unsigned char* bufx1 = lds + 3 * kStage;
+  for (int c = 0; c < nchunk; c += 2) {
+    store_chunk(bufg0, tid, g0);
+    store_chunk(bufx0, tid, x0);
+    if (want_cs) {
+      add_bf16x8(g0.q0, cs); add_bf16x8(g0.q1, cs); add_bf16x8(g0.q2, cs); add_bf16x8(g0.q3, cs);
+    }
+    __syncthreads();          // chunk c staged; buffer 0 was last read two phases ago, before the previous barrier
+    if (c + 2 < nchunk) {
+      g0 = load_chunk(G, M, r0 + (long long)(c + 2) * kChunk, gcol, tid);
+      x0 = load_chunk(X, N, r0 + (long long)(c + 2) * kChunk, xcol, tid);
+    }
+    compute(bufg0, bufx0);
+    if (c + 1 < nchunk) {
+      store_chunk(bufg1, tid, g1);
+      store_chunk(bufx1, tid, x1);
+      if (want_cs) {
+        add_bf16x8(g1.q0, cs); add_bf16x8(g1.q1, cs); add_bf16x8(g1.q2, cs); add_bf16x8(g1.q3, cs);
+      }
+      __syncthreads();
+      if (c + 3 < nchunk) {
+        g1 = load_chunk(G, M, r0 + (long long)(c + 3) * kChunk, gcol, tid);
+        x1 = load_chunk(X, N, r0 + (long long)(c + 3) * kChunk, xcol, tid);
+      }
+      compute(bufg1, bufx1);
+    }
+  }
+  // ---- partial tile: D[row = m by register, column = n by lane]
+  float* out = part + ((long long)s * M + tm * kTile + wm * 64) * N + tn * kTile + wn * 64;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        out[(long long)m * N + j * 32 + (lane & 31)] = acc[i][j][e];
+      }
+  if (want_cs) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(lds);       // (16 row groups, 128 columns)
+    const int c = tid & 15, r = tid >> 4;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[r * kTile + c * 8 + j] = cs[j];
+    __syncthreads();
+    if (tid < kTile) {
+      float tsum = 0.f;
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) tsum += red[rr * kTile + tid];
+      colpart[(long long)s * M + tm * kTile + tid] = tsum;
+    }
+  }
+}
+}  // namespace
+
+bool gd_dw_group_supported(long long n_pad, int d, int ff) {
+  return d % kTile == 0 && ff % kTile == 0 && d <= 512 && ff <= 1024 && n_pad > 0 && n_pad % (8 * kChunk) == 0;
+}
+// number of row slices: a multiple of 8 (one XCD per slice residue), tiles x slices ~ 2 workgroups per CU
+int gd_dw_group_slices(long long n_pad, int tiles_total) {
+  int S = 8;
+  while (S < 64 && (long long)tiles_total * S * 2 <= 512 && n_pad % ((long long)S * 2 * kChunk) == 0 && n_pad / (S * 2) >= 2 * kChunk) S *= 2;
+  return S;
+}
+
+// jobs: G (n_pad, M) / X (n_pad, N) bf16 row-major, M and N multiples of 128; part: (S, M, N) fp32, colpart: (S, M) fp32 or null.
+// Fills tile0 / tiles_total / S / rows_per_slice and launches.
+int gd_dw_grouped(hipStream_t st, GdDwGroup& A, long long n_pad) {
+  GD_REQUIRE(A.n_jobs >= 1 && A.n_jobs <= GD_DW_MAX_JOBS, "dw_grouped: job count");
+  int tiles = 0;
+  for (int j = 0; j < A.n_jobs; ++j) {
+    GD_REQUIRE(A.job[j].M % kTile == 0 && A.job[j].N % kTile == 0, "dw_grouped: M, N must be multiples of 128");
+    A.job[j].tile0 = tiles;
+    tiles += (A.job[j].M / kTile) * (A.job[j].N / kTile);
+  }
+  A.tiles_total = tiles;
+  GD_REQUIRE(n_pad % (8 * kChunk) == 0, "dw_grouped: rows must be a multiple of 512");
+  A.S = gd_dw_group_slices(n_pad, tiles);
+  A.rows_per_slice = n_pad / A.S;
+  hipLaunchKernelGGL(k_dw_grouped, dim3((unsigned)(tiles * A.S)), dim3(256), 4 * kStage, st, A);
+  GD_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// C ABI (tests, stand-alone use): one matrix.  dW (M, N) fp32 = G^T X, dbias (M) fp32 = column sums of G (optional)
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void k_dw_reduce(const float* __restrict__ part, int S, long long P, float* __restrict__ dst) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < P; i += (long long)gridDim.x * blockDim.x) {
+    float a = 0.f;
+    for (int s = 0; s < S; ++s) a += part[(long long)s * P + i];
+    dst[i] = a;
+  }
+}
+}  // namespace
+extern "C" size_t gdmae_dw_gemm_workspace_bytes(long long rows, int M, int N) {
+  const int S = gd_dw_group_slices(rows, (M / kTile) * (N / kTile));
+  return gd_align((size_t)S * M * N * sizeof(float)) + gd_align((size_t)S * M * sizeof(float));
+}
+extern "C" int gdmae_dw_gemm(const void* G, const void* X, long long rows, int M, int N, float* dW, float* dbias, void* workspace,
+                             void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  GD_REQUIRE(M % kTile == 0 && N % kTile == 0 && rows > 0 && rows % (8 * kChunk) == 0, "dw_gemm: M, N multiples of 128, rows a multiple of 512");
+  GdDwGroup A;
+  A.n_jobs = 1;
+  const int S = gd_dw_group_slices(rows, (M / kTile) * (N / kTile));
+  float* part = (float*)workspace;
+  float* colpart = (float*)((char*)workspace + gd_align((size_t)S * M * N * sizeof(float)));
+  A.job[0] = GdDwJob{G, X, M, N, part, dbias ? colpart : nullptr, 0};
+  {
+    const int rc = gd_dw_grouped(st, A, rows);
+    if (rc != 0) return rc;
+  }
+  hipLaunchKernelGGL(k_dw_reduce, dim3(256), dim3(256), 0, st, (const float*)part, A.S, (long long)M * N, dW);
+  GD_LAUNCH_CHECK();
+  if (dbias) {
+    hipLaunchKernelGGL(k_dw_reduce, dim3(4), dim3(256), 0, st, (const float*)colpart, A.S, (long long)M, dbias);
+    GD_LAUNCH_CHECK();
+  }
+  return 0;
+}

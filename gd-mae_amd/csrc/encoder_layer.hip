@@ -12,6 +12,7 @@
 // Parameter gradients are ACCUMULATED into the caller's fp32 buffers (flat optimizer buffer or zeroed temporaries).
 #include "../../include/gdmae_hip.h"
 #include "common.h"
+#include "dw_grouped.h"
 #include "gemm.h"
 #include <stdlib.h>
 
@@ -83,10 +84,10 @@ __global__ __launch_bounds__(256) void k_acc_vectors(AccJobs a) {
 // the split-K reduces of a layer's five weight gradients as ONE launch (blockIdx.y = job):
 // dst[i] += sum_{s < S} part[s * P + i], same slicing and association order as k_splitk_acc (gemm.hip)
 struct SplitkJobs {
-  const float* part[6];
-  float* dst[6];
-  int S[6];
-  long long P4[6];
+  const float* part[8];
+  float* dst[8];
+  int S[8];
+  long long P4[8];
   int count;
 };
 __global__ __launch_bounds__(256) void k_splitk_acc_jobs(SplitkJobs J) {
@@ -295,7 +296,7 @@ int linear_dw_deferred(const Ctx& c, const void* G, const void* X, float* dW, lo
   const long long kc = n_pad / S;
   GD_TRY(gd_gemm(c.st, false, true, k, m, (int)kc, X, k, G, m, part, k, c.ty, HIP_R_32F, nullptr, S, kc * k, kc * m, (long long)m * k,
                  c.lt_ws, kLtWorkspace));
-  GD_REQUIRE(J.count < 6 && ((long long)m * k) % 4 == 0, "splitk jobs");
+  GD_REQUIRE(J.count < 8 && ((long long)m * k) % 4 == 0, "splitk jobs");
   J.part[J.count] = part; J.dst[J.count] = dW; J.S[J.count] = S; J.P4[J.count] = (long long)m * k / 4;
   ++J.count;
   return 0;
@@ -398,8 +399,17 @@ Scratch scratch_layout(void* base, long long n_pad, int d, int ff, int es, int n
   s.ln_ws2 = take(gdmae_add_layernorm_workspace_bytes(d));
   {   // one split-K partial region per weight gradient of the backward (reduced together at the end of the layer)
     const int mk5[5][2] = {{d, ff}, {ff, d}, {d, d}, {2 * d, d}, {d, d}};
-    for (int i = 0; i < 5; ++i)
-      s.part_w[i] = take((size_t)splitk_for(n_pad, mk5[i][0], mk5[i][1]) * mk5[i][0] * mk5[i][1] * sizeof(float));
+    int Sg = 0;
+    if (gd_dw_group_supported(n_pad, d, ff)) {
+      int tiles = 0;
+      for (int i = 0; i < 5; ++i) tiles += (mk5[i][0] / 128) * (mk5[i][1] / 128);
+      Sg = gd_dw_group_slices(n_pad, tiles);
+    }
+    for (int i = 0; i < 5; ++i) {
+      int S = splitk_for(n_pad, mk5[i][0], mk5[i][1]);
+      if (Sg > S) S = Sg;
+      s.part_w[i] = take((size_t)S * mk5[i][0] * mk5[i][1] * sizeof(float));
+    }
   }
   {
     const int cm = ff > 2 * d ? ff : 2 * d;
@@ -450,6 +460,10 @@ bool use_fused(const gdmae_layer_args* a) {
   return !off && a->bf16 && a->packed != nullptr && a->d <= 256 && gd_tok_gemm_supported(a->d, a->ff) &&
          gd_tok_gemm_supported(a->ff, a->d) && gd_tok_gemm_supported(a->d, 2 * a->d) && gd_tok_gemm_supported(a->d, a->d) &&
          gd_tok_gemm_supported(2 * a->d, a->d);
+}
+bool use_grouped_dw(const gdmae_layer_args* a, long long n_pad) {
+  static const int off = getenv("GDMAE_DWGROUP") ? atoi(getenv("GDMAE_DWGROUP")) == 0 : 0;
+  return !off && a->bf16 && gd_dw_group_supported(n_pad, a->d, a->ff);
 }
 }  // namespace
 
@@ -606,7 +620,10 @@ static int layer_bwd(const gdmae_layer_args* a, bool upstream3, bool defer_add3,
                                    (float*)w.dx1_res, a->bf16 ? w.dfb : nullptr, nullptr, w.ln_ws2, c.st));
   SplitkJobs SJ;
   SJ.count = 0;
-  GD_TRY(linear_dw_deferred(c, w.dfb, s.gact, a->dW2, n_pad, d, ff, (float*)w.part_w[0], SJ));
+  // bf16 rows: the five weight gradients (and the three bias column sums that are not LayerNorm by-products) of the layer
+  // are ONE launch of the hand-written TN kernel at the end (dw_grouped.hip); fp32 rows / odd sizes: library split-K GEMMs
+  const bool grouped = use_grouped_dw(a, n_pad);
+  if (!grouped) GD_TRY(linear_dw_deferred(c, w.dfb, s.gact, a->dW2, n_pad, d, ff, (float*)w.part_w[0], SJ));
   const bool fused = use_fused(a);
   const Packed pk = packed_layout(a->packed, d, ff);
   if (fused) {
@@ -615,13 +632,13 @@ static int layer_bwd(const gdmae_layer_args* a, bool upstream3, bool defer_add3,
     GD_TRY(linear_dx(c, w.dfb, a->W2, w.dg, n_pad, d, ff));
     GD_TRY(gelu(c, false, w.dg, s.h, w.dh, n_pad * ff));
   }
-  GD_TRY(linear_dw_deferred(c, w.dh, s.x1b, a->dW1, n_pad, ff, d, (float*)w.part_w[1], SJ));
+  if (!grouped) GD_TRY(linear_dw_deferred(c, w.dh, s.x1b, a->dW1, n_pad, ff, d, (float*)w.part_w[1], SJ));
   if (fused) GD_TRY(gd_tok_gemm_plain(c.st, w.dh, pk.w1t, nullptr, n_pad, ff, d, w.dx1_b));
   else GD_TRY(linear_dx(c, w.dh, a->W1, w.dx1_b, n_pad, ff, d));
   // ---- LN1 (gradient = residual branch + FFN branch) and out-projection
   GD_TRY(gd_add_layernorm_bwd_ex(a->x, s.a, a->bf16, a->g1, (const float*)s.st1, (const float*)w.dx1_res, w.dx1_b, a->bf16, nullptr, 0,
                                  n, d, (float*)w.dx_res, a->bf16 ? w.dab : nullptr, nullptr, w.ln_ws, c.st));
-  GD_TRY(linear_dw_deferred(c, w.dab, s.o, a->dWo, n_pad, d, d, (float*)w.part_w[2], SJ));
+  if (!grouped) GD_TRY(linear_dw_deferred(c, w.dab, s.o, a->dWo, n_pad, d, d, (float*)w.part_w[2], SJ));
   if (fused) GD_TRY(gd_tok_gemm_plain(c.st, w.dab, pk.ot, nullptr, n_pad, d, d, w.d_o));
   else GD_TRY(linear_dx(c, w.dab, a->Wo, w.d_o, n_pad, d, d));
   // ---- attention
@@ -637,10 +654,38 @@ static int layer_bwd(const gdmae_layer_args* a, bool upstream3, bool defer_add3,
   }
   GD_TRY(gdmae_sum_partials_gated((const float*)w.apart, pbase, 1.f, (float*)w.dtau, a->tau, a->tau_min, stream));
   const char* Win = (const char*)a->Win;
-  GD_TRY(linear_dw_deferred(c, w.dqk, s.xpb, a->dWin, n_pad, 2 * d, d, (float*)w.part_w[3], SJ));
-  GD_TRY(linear_dw_deferred(c, w.dv, s.xb, a->dWin + (size_t)2 * d * d, n_pad, d, d, (float*)w.part_w[4], SJ));
-  GD_TRY(splitk_acc_jobs(c, SJ));                      // the five split-K reduces of the layer as one launch
-  {
+  if (grouped) {
+    GdDwGroup Gp;
+    Gp.n_jobs = 5;
+    float* cp = (float*)w.cs_part;                       // (3, S, cmax) column-sum partials
+    const int cmax = ff > 2 * d ? ff : 2 * d;
+    int tiles = 0;
+    const int mk5[5][2] = {{d, ff}, {ff, d}, {d, d}, {2 * d, d}, {d, d}};
+    for (int i = 0; i < 5; ++i) tiles += (mk5[i][0] / 128) * (mk5[i][1] / 128);
+    const int S = gd_dw_group_slices(n_pad, tiles);
+    Gp.job[0] = GdDwJob{w.dfb, s.gact, d, ff, (float*)w.part_w[0], nullptr, 0};
+    Gp.job[1] = GdDwJob{w.dh, s.x1b, ff, d, (float*)w.part_w[1], cp, 0};
+    Gp.job[2] = GdDwJob{w.dab, s.o, d, d, (float*)w.part_w[2], nullptr, 0};
+    Gp.job[3] = GdDwJob{w.dqk, s.xpb, 2 * d, d, (float*)w.part_w[3], cp + (size_t)S * cmax, 0};
+    Gp.job[4] = GdDwJob{w.dv, s.xb, d, d, (float*)w.part_w[4], cp + (size_t)2 * S * cmax, 0};
+    GD_TRY(gd_dw_grouped(c.st, Gp, n_pad));
+    GD_REQUIRE(Gp.S == S, "dw_grouped: slice count");
+    float* dW[5] = {a->dW2, a->dW1, a->dWo, a->dWin, a->dWin + (size_t)2 * d * d};
+    for (int i = 0; i < 5; ++i) {
+      SJ.part[i] = Gp.job[i].part; SJ.dst[i] = dW[i]; SJ.S[i] = S; SJ.P4[i] = (long long)mk5[i][0] * mk5[i][1] / 4;
+    }
+    // bias column sums: same reduce (partials (S, M) -> dst (M))
+    const int cj[3] = {1, 3, 4};
+    float* db[3] = {a->db1, a->dbin, a->dbin + 2 * d};
+    for (int i = 0; i < 3; ++i) {
+      SJ.part[5 + i] = Gp.job[cj[i]].colpart; SJ.dst[5 + i] = db[i]; SJ.S[5 + i] = S; SJ.P4[5 + i] = mk5[cj[i]][0] / 4;
+    }
+    SJ.count = 8;
+    GD_TRY(splitk_acc_jobs(c, SJ));
+  } else {
+    GD_TRY(linear_dw_deferred(c, w.dqk, s.xpb, a->dWin, n_pad, 2 * d, d, (float*)w.part_w[3], SJ));
+    GD_TRY(linear_dw_deferred(c, w.dv, s.xb, a->dWin + (size_t)2 * d * d, n_pad, d, d, (float*)w.part_w[4], SJ));
+    GD_TRY(splitk_acc_jobs(c, SJ));                      // the five split-K reduces of the layer as one launch
     ColsumJobs J;
     J.count = 3;
     J.x[0] = w.dh;  J.dst[0] = a->db1;           J.C[0] = ff;

@@ -92,6 +92,8 @@ SIGNATURES = {
     "gdmae_conv_block_fwd": (_I, [_P, _P]),
     "gdmae_conv_block_bwd": (_I, [_P, _P]),
     "gdmae_encoder_layer_bytes": (_I, [_L, _I, _I, _I, _I, _P, _P, _P]),
+    "gdmae_dw_gemm_workspace_bytes": (_Z, [_L, _I, _I]),
+    "gdmae_dw_gemm": (_I, [_P, _P, _L, _I, _I, _P, _P, _P, _P]),
     "gdmae_layer_packed_bytes": (_Z, [_I, _I]),
     "gdmae_layer_pack_jobs": (_I, [_P, _P, _P, _P, _I, _I, _P, _P]),
     "gdmae_tok_gemm_pack": (_I, [_P, _I, _P]),

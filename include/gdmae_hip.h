@@ -343,6 +343,15 @@ size_t gdmae_gemm_tn_splitk_workspace_bytes(long long K, int m, int n);
 int gdmae_gemm_tn_splitk(const void* A, const void* B, float* C, long long K, int m, int n, int ab_bf16, int accumulate,
                          void* workspace, void* stream);
 
+/* Hand-written bf16-MFMA "TN" product for the token-contracted weight gradients (dw_grouped.hip; backward of the nn.Linear
+ * layers of sst_basic_block.py:57-84 / cosine_msa.py): dW (M, N) fp32 = G^T X for G (rows, M), X (rows, N) bf16 row-major,
+ * dbias (M) fp32 = column sums of G (optional, may be NULL).  M, N multiples of 128, rows a multiple of 512 (callers
+ * zero-pad).  Deterministic (row slices summed in a fixed order).  The encoder-layer executor issues the five weight
+ * gradients of a layer through the same kernel as ONE launch. */
+size_t gdmae_dw_gemm_workspace_bytes(long long rows, int M, int N);
+int gdmae_dw_gemm(const void* G, const void* X, long long rows, int M, int N, float* dW, float* dbias, void* workspace,
+                  void* stream);
+
 /* ---- a6 as one call: sparse conv (k3) -> BatchNorm1d(train) -> ReLU block -------------------------- *
  * post_act_block (spconv_utils.py:37-56; conv_down / conv_out of SSTBlockV1, spt_backbone.py:206,217,256-263).
  * x (n_in, cin) rows in the compute dtype (bf16 != 0: bf16, else fp32) or fp32 with x_f32 (cast folded into the

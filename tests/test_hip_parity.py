@@ -1017,6 +1017,28 @@ def test_tile_conv_decoder_equals_dense_conv_decoder_bf16(name):
         assert torch.allclose(rt[k].float(), rd[k].float(), rtol=2e-3, atol=1e-5), k
 
 
+@pytest.mark.parametrize("rows,M,N", [(2048, 128, 128), (4096, 256, 128), (6144, 256, 512), (2048, 512, 256)])
+def test_dw_gemm_matches_fp32_product(rows, M, N):
+    """Hand-written TN product of the weight gradients (dw_grouped.hip): dW = G^T X and db = column sums of G for bf16 rows
+    against the fp32 product of the same bf16 values (fp32 accumulation in a different order: 1e-5 of the largest entry)."""
+    from gdmae_hip import lib as L
+    g = torch.Generator().manual_seed(rows + M + N)
+    G = (torch.randn(rows, M, generator=g) * 0.5).to(torch.bfloat16).to(dev())
+    X = torch.randn(rows, N, generator=g).to(torch.bfloat16).to(dev())
+    G[rows - 300:] = 0                                   # zero-padded tail rows, as the layer executor passes them
+    dW = torch.empty(M, N, dtype=torch.float32, device=dev())
+    db = torch.empty(M, dtype=torch.float32, device=dev())
+    ws = torch.empty(L.load().gdmae_dw_gemm_workspace_bytes(rows, M, N), dtype=torch.uint8, device=dev())
+    L.call("gdmae_dw_gemm", L.ptr(G), L.ptr(X), rows, M, N, L.ptr(dW), L.ptr(db), L.ptr(ws), L.stream())
+    ref = G.double().t() @ X.double()
+    assert (dW.double() - ref).abs().max() <= 1e-5 * ref.abs().max()
+    refb = G.double().sum(0)
+    assert (db.double() - refb).abs().max() <= 1e-5 * refb.abs().max() + 1e-6
+    dW2 = torch.empty_like(dW)
+    L.call("gdmae_dw_gemm", L.ptr(G), L.ptr(X), rows, M, N, L.ptr(dW2), None, L.ptr(ws), L.stream())
+    assert torch.equal(dW, dW2), "deterministic"
+
+
 def _pack_weight(w, transpose=False):
     """Packed (fragment-ordered) image of a 2-D fp32 weight through gdmae_tok_gemm_pack."""
     from gdmae_hip import lib as L
