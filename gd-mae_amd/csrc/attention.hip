@@ -385,7 +385,12 @@ __global__ __launch_bounds__(256) void k_win_attn_bwd(AttnBwdArgs A) {
     IO::template store<DH>(gdv + (long long)t * A.d + h * DH, dvv);
   }
   dtau = gd_wave_sum(dtau);
-  if (lane == 0) A.dtau_part[item] = dtau;
+  if (lane == 0) {
+    // the level owns n_win * H partial slots; the n_win * H / G items fill the first ones and zero the rest (no separate clear)
+    const long long used = (long long)A.n_win * groups, all = (long long)A.n_win * A.H;
+    A.dtau_part[item] = dtau;
+    for (long long i = used + item; i < all; i += used) A.dtau_part[i] = 0.f;
+  }
 }
 
 // sum of `n` values over one 1024-thread workgroup, fixed association order (every thread returns the total)

@@ -405,7 +405,13 @@ __global__ __launch_bounds__(256) void k_attn_t16_bwd(A16BwdArgs A) {
   // the 4 lane groups of a column hold the same reduced statistics and split the keys between them (dt sums this lane's 4
   // keys), so the plain wave sum counts every (query, key) pair once; one partial per (window quad, head)
   dtau = gd_wave_sum(dtau);
-  if (lane == 0) A.dtau_part[(long long)blockIdx.x * 4 + wib] = dtau;
+  if (lane == 0) {
+    // the level owns n_win * H partial slots (one per window and head); this grid fills gridDim * 4 <= n_win * H of them and
+    // zeroes the rest, so the consumer can sum the whole range without a separate clear
+    const long long mine = (long long)blockIdx.x * 4 + wib, used = (long long)gridDim.x * 4, all = (long long)A.n_win * A.H;
+    A.dtau_part[mine] = dtau;
+    for (long long i = used + mine; i < all; i += used) A.dtau_part[i] = 0.f;
+  }
 }
 }  // namespace
 

@@ -18,8 +18,9 @@ struct GdDwGroup {
   int tiles_total;
   int S;
   long long rows_per_slice;
+  long long n_valid;    // rows >= n_valid are treated as zero
 };
 
 bool gd_dw_group_supported(long long n_pad, int d, int ff);
 int gd_dw_group_slices(long long n_pad, int tiles_total);
-int gd_dw_grouped(hipStream_t st, GdDwGroup& A, long long n_pad);
+int gd_dw_grouped(hipStream_t st, GdDwGroup& A, long long n_pad, long long n_valid);

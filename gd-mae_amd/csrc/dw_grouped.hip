@@ -44,6 +44,17 @@ __device__ __forceinline__ Chunk load_chunk(const unsigned short* __restrict__ b
   k.q3 = *reinterpret_cast<const uint4*>(p + 48ll * ld);
   return k;
 }
+// rows >= n_valid (the padding of the row count to the slice grid) contribute nothing, whatever the buffers hold there:
+// the chunk(s) that reach past n_valid are cleared in registers before they are staged (uniform branch per chunk)
+__device__ __forceinline__ void mask_chunk(Chunk& k, long long row0, int tid, long long n_valid) {
+  if (row0 + kChunk <= n_valid) return;
+  const int r = tid >> 4;
+  const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+  if (row0 + r >= n_valid) k.q0 = z;
+  if (row0 + r + 16 >= n_valid) k.q1 = z;
+  if (row0 + r + 32 >= n_valid) k.q2 = z;
+  if (row0 + r + 48 >= n_valid) k.q3 = z;
+}
 __device__ __forceinline__ void store_chunk(unsigned char* __restrict__ lds, int tid, const Chunk& k) {
   const int c = tid & 15, r = tid >> 4;
   unsigned char* p = lds + stage_off(r, c);            // (row & 3) is the same for r, r + 16, ...
@@ -138,6 +149,8 @@ __global__ __launch_bounds__(256, 2) void k_dw_grouped(GdDwGroup A) {
   unsigned char* bufg1 = lds + 2 * kStage;
   unsigned char* bufx1 = lds + 3 * kStage;
   for (int c = 0; c < nchunk; c += 2) {
+    mask_chunk(g0, r0 + (long long)c * kChunk, tid, A.n_valid);
+    mask_chunk(x0, r0 + (long long)c * kChunk, tid, A.n_valid);
     store_chunk(bufg0, tid, g0);
     store_chunk(bufx0, tid, x0);
     if (want_cs) {
@@ -150,6 +163,8 @@ __global__ __launch_bounds__(256, 2) void k_dw_grouped(GdDwGroup A) {
     }
     compute(bufg0, bufx0);
     if (c + 1 < nchunk) {
+      mask_chunk(g1, r0 + (long long)(c + 1) * kChunk, tid, A.n_valid);
+      mask_chunk(x1, r0 + (long long)(c + 1) * kChunk, tid, A.n_valid);
       store_chunk(bufg1, tid, g1);
       store_chunk(bufx1, tid, x1);
       if (want_cs) {
@@ -201,9 +216,10 @@ int gd_dw_group_slices(long long n_pad, int tiles_total) {
   return S;
 }
 
-// jobs: G (n_pad, M) / X (n_pad, N) bf16 row-major, M and N multiples of 128; part: (S, M, N) fp32, colpart: (S, M) fp32 or null.
+// jobs: G (n_pad, M) / X (n_pad, N) bf16 row-major, M and N multiples of 128; part: (S, M, N) fp32, colpart: (S, M) fp32 or null;
+// rows >= n_valid are ignored (n_pad = the row count padded to the slice grid; the buffers must extend to n_pad rows).
 // Fills tile0 / tiles_total / S / rows_per_slice and launches.
-int gd_dw_grouped(hipStream_t st, GdDwGroup& A, long long n_pad) {
+int gd_dw_grouped(hipStream_t st, GdDwGroup& A, long long n_pad, long long n_valid) {
   GD_REQUIRE(A.n_jobs >= 1 && A.n_jobs <= GD_DW_MAX_JOBS, "dw_grouped: job count");
   int tiles = 0;
   for (int j = 0; j < A.n_jobs; ++j) {
@@ -215,6 +231,7 @@ int gd_dw_grouped(hipStream_t st, GdDwGroup& A, long long n_pad) {
   GD_REQUIRE(n_pad % (8 * kChunk) == 0, "dw_grouped: rows must be a multiple of 512");
   A.S = gd_dw_group_slices(n_pad, tiles);
   A.rows_per_slice = n_pad / A.S;
+  A.n_valid = n_valid;
   hipLaunchKernelGGL(k_dw_grouped, dim3((unsigned)(tiles * A.S)), dim3(256), 4 * kStage, st, A);
   GD_LAUNCH_CHECK();
   return 0;
@@ -247,7 +264,7 @@ extern "C" int gdmae_dw_gemm(const void* G, const void* X, long long rows, int M
   float* colpart = (float*)((char*)workspace + gd_align((size_t)S * M * N * sizeof(float)));
   A.job[0] = GdDwJob{G, X, M, N, part, dbias ? colpart : nullptr, 0};
   {
-    const int rc = gd_dw_grouped(st, A, rows);
+    const int rc = gd_dw_grouped(st, A, rows, rows);
     if (rc != 0) return rc;
   }
   hipLaunchKernelGGL(k_dw_reduce, dim3(256), dim3(256), 0, st, (const float*)part, A.S, (long long)M * N, dW);

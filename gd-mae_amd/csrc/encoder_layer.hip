@@ -120,6 +120,103 @@ __global__ __launch_bounds__(256) void k_splitk_acc_jobs(SplitkJobs J) {
   }
 }
 
+// The reductions that close a layer's backward as ONE launch (blockIdx.y = section):
+//   y <  J.count      split-K reduce of weight-gradient / bias-column-sum partials (as k_splitk_acc_jobs)
+//   y == J.count      vector accumulations (as k_acc_vectors: LayerNorm dgamma / dbeta / column-sum partial rows)
+//   y == J.count + 1  dtau += gate(tau) * sum of the attention partials (fixed order, one workgroup)
+struct TailJobs {
+  SplitkJobs J;
+  AccJobs a;
+  const float* tau_part;
+  long long n_part;
+  const float* tau;
+  float tau_min;
+  float* dtau;
+};
+__device__ inline void tail_splitk(const SplitkJobs& J, int job) {
+  __shared__ float4 sh[3][64];
+  const long long P4 = J.P4[job];
+  const int S = J.S[job];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const long long i = blockIdx.x * 64ll + tx;
+  if (blockIdx.x * 64ll >= P4) return;                 // uniform per workgroup
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < P4) {
+    const int s0 = (S * ty) / 4, s1 = (S * (ty + 1)) / 4;
+    const float4* p = (const float4*)J.part[job] + i;
+#pragma unroll 4
+    for (int s = s0; s < s1; ++s) {
+      const float4 v = p[(long long)s * P4];
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+  }
+  if (ty > 0) sh[ty - 1][tx] = acc;
+  __syncthreads();
+  if (ty == 0 && i < P4) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { const float4 v = sh[k][tx]; acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+    float4* d = (float4*)J.dst[job] + i;
+    const float4 o = *d;
+    acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+    *d = acc;
+  }
+}
+__device__ inline void tail_vectors(const AccJobs& a) {
+  __shared__ float sh[16][17];
+  const int cl = threadIdx.x & 15, ps = threadIdx.x >> 4;
+  int col = blockIdx.x * 16 + cl;
+  int j = 0;
+  while (j < a.count && col >= a.len[j]) col -= a.len[j++];
+  float acc = 0.f;
+  if (j < a.count) {
+    if (a.nblk[j] == 0) {
+      if (ps == 0) acc = a.src[j][col];
+    } else {
+      const float* p = a.src[j] + col;
+      const long long st = a.stride[j];
+#pragma unroll 8
+      for (int b = ps; b < a.nblk[j]; b += 16) acc += p[b * st];
+    }
+  }
+  sh[ps][cl] = acc;
+  __syncthreads();
+  if (ps == 0 && j < a.count) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += sh[k][cl];
+    a.dst[j][col] += s;
+  }
+}
+__global__ __launch_bounds__(256) void k_layer_tail(TailJobs T) {
+  const int y = blockIdx.y;
+  if (y < T.J.count) {
+    tail_splitk(T.J, y);
+  } else if (y == T.J.count) {
+    int cols = 0;
+    for (int j = 0; j < T.a.count; ++j) cols += T.a.len[j];
+    if (blockIdx.x * 16 < cols) tail_vectors(T.a);
+  } else if (blockIdx.x == 0) {
+    __shared__ float shw[4];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    long long i = threadIdx.x;
+    for (; i + 3 * 256 < T.n_part; i += 4 * 256) {
+      a0 += T.tau_part[i];
+      a1 += T.tau_part[i + 256];
+      a2 += T.tau_part[i + 512];
+      a3 += T.tau_part[i + 768];
+    }
+    for (; i < T.n_part; i += 256) a0 += T.tau_part[i];
+    const float w = gd_wave_sum((a0 + a1) + (a2 + a3));
+    if ((threadIdx.x & 63) == 0) shw[threadIdx.x >> 6] = w;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float t = (shw[0] + shw[1]) + (shw[2] + shw[3]);
+      if (!(T.tau[0] >= T.tau_min)) t = 0.f;            // d clamp(tau, min) / d tau
+      T.dtau[0] += t;
+    }
+  }
+}
+
 // exact (erf) GELU, 8 elements per thread
 template <bool BF>
 __global__ __launch_bounds__(256) void k_gelu_fwd(const void* __restrict__ h, void* __restrict__ out, long long total8) {
@@ -517,7 +614,8 @@ static int layer_fwd(const gdmae_layer_args* a, const gdmae_layer_args* next, bo
   add_zero(z, s.xpb, n, n_pad, (long long)d * es);
   add_zero(z, s.o, n, n_pad, (long long)d * es);
   add_zero(z, s.x1b, n, n_pad, (long long)d * es);   // fp32 mode: x1 itself
-  GD_TRY(zero_regions(c, z));
+  // (the grouped weight-gradient kernel does not read rows >= n, and every other consumer is row-wise)
+  if (!use_grouped_dw(a, n_pad)) GD_TRY(zero_regions(c, z));
   if (a->bf16) {
     if (!prepped) GD_TRY(gdmae_prep_tokens(a->x, a->pos_table, a->tok_pos, n, d, s.xb, s.xpb, 1, stream));
   } else {
@@ -610,7 +708,12 @@ static int layer_bwd(const gdmae_layer_args* a, bool upstream3, bool defer_add3,
   z.p[z.count] = w.apart;
   z.n16[z.count] = (unsigned long long)(gd_align((size_t)(items > 0 ? items : 1) * 4) / 16);
   ++z.count;
-  GD_TRY(zero_regions(c, z));
+  // bf16 rows: the five weight gradients (and the three bias column sums that are not LayerNorm by-products) of the layer
+  // are ONE launch of the hand-written TN kernel at the end (dw_grouped.hip), which ignores rows >= n, and the attention
+  // kernels fill every partial slot of their level: nothing to clear.  fp32 rows / odd sizes: library split-K GEMMs over
+  // zero-padded operands.
+  const bool grouped = use_grouped_dw(a, n_pad);
+  if (!grouped) GD_TRY(zero_regions(c, z));
   // ---- LN2 and FFN
   if (upstream3)   // dx_res / dx_qk / dx_v of the next layer are consumed here, before anything overwrites them
     GD_TRY(gd_add_layernorm_bwd_ex((const float*)s.x1, s.f, a->bf16, a->g2, (const float*)s.st2, (const float*)w.dx_res, w.dx_qk, a->bf16,
@@ -620,9 +723,6 @@ static int layer_bwd(const gdmae_layer_args* a, bool upstream3, bool defer_add3,
                                    (float*)w.dx1_res, a->bf16 ? w.dfb : nullptr, nullptr, w.ln_ws2, c.st));
   SplitkJobs SJ;
   SJ.count = 0;
-  // bf16 rows: the five weight gradients (and the three bias column sums that are not LayerNorm by-products) of the layer
-  // are ONE launch of the hand-written TN kernel at the end (dw_grouped.hip); fp32 rows / odd sizes: library split-K GEMMs
-  const bool grouped = use_grouped_dw(a, n_pad);
   if (!grouped) GD_TRY(linear_dw_deferred(c, w.dfb, s.gact, a->dW2, n_pad, d, ff, (float*)w.part_w[0], SJ));
   const bool fused = use_fused(a);
   const Packed pk = packed_layout(a->packed, d, ff);
@@ -652,7 +752,7 @@ static int layer_bwd(const gdmae_layer_args* a, bool upstream3, bool defer_add3,
     base += a->n_win[l];
     pbase += (long long)a->n_win[l] * a->nhead;
   }
-  GD_TRY(gdmae_sum_partials_gated((const float*)w.apart, pbase, 1.f, (float*)w.dtau, a->tau, a->tau_min, stream));
+  if (!grouped) GD_TRY(gdmae_sum_partials_gated((const float*)w.apart, pbase, 1.f, (float*)w.dtau, a->tau, a->tau_min, stream));
   const char* Win = (const char*)a->Win;
   if (grouped) {
     GdDwGroup Gp;
@@ -668,7 +768,7 @@ static int layer_bwd(const gdmae_layer_args* a, bool upstream3, bool defer_add3,
     Gp.job[2] = GdDwJob{w.dab, s.o, d, d, (float*)w.part_w[2], nullptr, 0};
     Gp.job[3] = GdDwJob{w.dqk, s.xpb, 2 * d, d, (float*)w.part_w[3], cp + (size_t)S * cmax, 0};
     Gp.job[4] = GdDwJob{w.dv, s.xb, d, d, (float*)w.part_w[4], cp + (size_t)2 * S * cmax, 0};
-    GD_TRY(gd_dw_grouped(c.st, Gp, n_pad));
+    GD_TRY(gd_dw_grouped(c.st, Gp, n_pad, n));
     GD_REQUIRE(Gp.S == S, "dw_grouped: slice count");
     float* dW[5] = {a->dW2, a->dW1, a->dWo, a->dWin, a->dWin + (size_t)2 * d * d};
     for (int i = 0; i < 5; ++i) {
@@ -680,8 +780,7 @@ static int layer_bwd(const gdmae_layer_args* a, bool upstream3, bool defer_add3,
     for (int i = 0; i < 3; ++i) {
       SJ.part[5 + i] = Gp.job[cj[i]].colpart; SJ.dst[5 + i] = db[i]; SJ.S[5 + i] = S; SJ.P4[5 + i] = mk5[cj[i]][0] / 4;
     }
-    SJ.count = 8;
-    GD_TRY(splitk_acc_jobs(c, SJ));
+    SJ.count = 8;                                        // reduced by the tail launch below
   } else {
     GD_TRY(linear_dw_deferred(c, w.dqk, s.xpb, a->dWin, n_pad, 2 * d, d, (float*)w.part_w[3], SJ));
     GD_TRY(linear_dw_deferred(c, w.dv, s.xb, a->dWin + (size_t)2 * d * d, n_pad, d, d, (float*)w.part_w[4], SJ));
@@ -715,6 +814,19 @@ static int layer_bwd(const gdmae_layer_args* a, bool upstream3, bool defer_add3,
     cols += j.len[i];
   }
   j.count = 7;
+  if (grouped) {
+    TailJobs T;
+    T.J = SJ;
+    j.count = 6;                                         // dtau comes straight from the attention partials
+    cols -= 1;
+    T.a = j;
+    T.tau_part = (const float*)w.apart; T.n_part = pbase; T.tau = a->tau; T.tau_min = a->tau_min; T.dtau = a->dtau;
+    long long gx = (cols + 15) / 16;
+    for (int q = 0; q < SJ.count; ++q) gx = (SJ.P4[q] + 63) / 64 > gx ? (SJ.P4[q] + 63) / 64 : gx;
+    hipLaunchKernelGGL(k_layer_tail, dim3((unsigned)gx, SJ.count + 2), dim3(256), 0, c.st, T);
+    GD_LAUNCH_CHECK();
+    return 0;
+  }
   hipLaunchKernelGGL(k_acc_vectors, dim3((cols + 15) / 16), dim3(256), 0, c.st, j);
   GD_LAUNCH_CHECK();
   return 0;
