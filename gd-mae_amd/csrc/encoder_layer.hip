@@ -492,8 +492,13 @@ Scratch scratch_layout(void* base, long long n_pad, int d, int ff, int es, int n
   size_t mk = (size_t)ff * d;
   if ((size_t)2 * d * d > mk) mk = (size_t)2 * d * d;
   s.part = take((size_t)256 * mk * 4);      // S * m * k <= 1024 tiles * 128 * 128 ... bounded by 256 * m * k
-  s.ln_ws = take(gdmae_add_layernorm_workspace_bytes(d));
-  s.ln_ws2 = take(gdmae_add_layernorm_workspace_bytes(d));
+  {   // LayerNorm-backward partial rows: the row kernel writes <= 1024 of them, the fused GEMM epilogue one per 32-row workgroup
+    size_t lnb = gdmae_add_layernorm_workspace_bytes(d);
+    const size_t fused_rows = (size_t)(n_pad / 32) * 3 * d * sizeof(float);
+    if (fused_rows > lnb) lnb = fused_rows;
+    s.ln_ws = take(lnb);
+    s.ln_ws2 = take(lnb);
+  }
   {   // one split-K partial region per weight gradient of the backward (reduced together at the end of the layer)
     const int mk5[5][2] = {{d, ff}, {ff, d}, {d, d}, {2 * d, d}, {d, d}};
     int Sg = 0;
@@ -532,6 +537,10 @@ bool gd_tok_gemm_supported(int K, int N);
 int gd_tok_gemm_plain(hipStream_t st, const void* X, const void* Wp, const void* bias, long long n_pad, int K, int N, void* out);
 int gd_tok_gemm_gelu(hipStream_t st, const void* X, const void* Wp, const void* bias, long long n_pad, int K, int N, void* h, void* gact);
 int gd_tok_gemm_gelu_bwd(hipStream_t st, const void* dY, const void* Wp, const void* h, long long n_pad, int K, int N, void* dh);
+int gd_tok_gemm_rows(int N);
+int gd_tok_gemm_ln_bwd(hipStream_t st, const void* X, const void* Wp, long long n, long long n_pad, int K, int N, const float* dy,
+                       const void* dy2_bf, const float* ln_a, const void* ln_b_bf, const float* stats, const float* gamma, float* dx,
+                       void* dx_bf, float* part);
 int gd_tok_gemm_res_ln(hipStream_t st, const void* X, const void* Wp, const void* bias, long long n, long long n_pad, int K, int N,
                        const float* res, const float* gamma, const float* beta, float eps, float* y, float* stats, void* y_bf,
                        const float* pos_table, const int* tok_pos, void* ypos_bf, void* f_out);
@@ -690,7 +699,10 @@ extern "C" int gdmae_encoder_stage_fwd(const gdmae_layer_args* layers, int n_lay
 // One layer backward.  `upstream3`: the upstream gradient is the sum of three tensors left in `scratch` by the
 // backward of the NEXT layer (its residual-stream gradient, dx_qk, dx_v - that layer skipped its add3 pass) instead of
 // a->dy; `defer_add3`: leave this layer's own three pieces in scratch for the previous layer the same way.
-static int layer_bwd(const gdmae_layer_args* a, bool upstream3, bool defer_add3, void* stream) {
+// prev: the layer below (processed next) whose LayerNorm-2 backward is fused behind this layer's last input-gradient GEMM, or
+// null; ln2_done: this layer's own LayerNorm-2 backward was already produced that way by the layer above
+static int layer_bwd(const gdmae_layer_args* a, bool upstream3, bool defer_add3, const gdmae_layer_args* prev, bool ln2_done,
+                     void* stream) {
   GD_REQUIRE(a->n > 0 && a->d % 8 == 0 && a->ff % 8 == 0, "encoder layer: bad sizes");
   const long long n = a->n, n_pad = pad_rows(n);
   const int d = a->d, ff = a->ff, es = a->bf16 ? 2 : 4;
@@ -715,7 +727,9 @@ static int layer_bwd(const gdmae_layer_args* a, bool upstream3, bool defer_add3,
   const bool grouped = use_grouped_dw(a, n_pad);
   if (!grouped) GD_TRY(zero_regions(c, z));
   // ---- LN2 and FFN
-  if (upstream3)   // dx_res / dx_qk / dx_v of the next layer are consumed here, before anything overwrites them
+  if (ln2_done) {
+    // dx1_res / dfb and the partial rows in ln_ws2 were written by the epilogue of the layer above's v-projection gradient
+  } else if (upstream3)   // dx_res / dx_qk / dx_v of the next layer are consumed here, before anything overwrites them
     GD_TRY(gd_add_layernorm_bwd_ex((const float*)s.x1, s.f, a->bf16, a->g2, (const float*)s.st2, (const float*)w.dx_res, w.dx_qk, a->bf16,
                                    w.dx_v, a->bf16, n, d, (float*)w.dx1_res, a->bf16 ? w.dfb : nullptr, nullptr, w.ln_ws2, c.st));
   else
@@ -733,11 +747,17 @@ static int layer_bwd(const gdmae_layer_args* a, bool upstream3, bool defer_add3,
     GD_TRY(gelu(c, false, w.dg, s.h, w.dh, n_pad * ff));
   }
   if (!grouped) GD_TRY(linear_dw_deferred(c, w.dh, s.x1b, a->dW1, n_pad, ff, d, (float*)w.part_w[1], SJ));
-  if (fused) GD_TRY(gd_tok_gemm_plain(c.st, w.dh, pk.w1t, nullptr, n_pad, ff, d, w.dx1_b));
-  else GD_TRY(linear_dx(c, w.dh, a->W1, w.dx1_b, n_pad, ff, d));
   // ---- LN1 (gradient = residual branch + FFN branch) and out-projection
-  GD_TRY(gd_add_layernorm_bwd_ex(a->x, s.a, a->bf16, a->g1, (const float*)s.st1, (const float*)w.dx1_res, w.dx1_b, a->bf16, nullptr, 0,
-                                 n, d, (float*)w.dx_res, a->bf16 ? w.dab : nullptr, nullptr, w.ln_ws, c.st));
+  const bool fuse_ln = fused && grouped;       // LayerNorm backward as the epilogue of the GEMM that produces its last gradient piece
+  if (fuse_ln) {
+    GD_TRY(gd_tok_gemm_ln_bwd(c.st, w.dh, pk.w1t, n, n_pad, ff, d, (const float*)w.dx1_res, nullptr, a->x, s.a, (const float*)s.st1, a->g1,
+                              (float*)w.dx_res, w.dab, (float*)w.ln_ws));
+  } else {
+    if (fused) GD_TRY(gd_tok_gemm_plain(c.st, w.dh, pk.w1t, nullptr, n_pad, ff, d, w.dx1_b));
+    else GD_TRY(linear_dx(c, w.dh, a->W1, w.dx1_b, n_pad, ff, d));
+    GD_TRY(gd_add_layernorm_bwd_ex(a->x, s.a, a->bf16, a->g1, (const float*)s.st1, (const float*)w.dx1_res, w.dx1_b, a->bf16, nullptr, 0,
+                                   n, d, (float*)w.dx_res, a->bf16 ? w.dab : nullptr, nullptr, w.ln_ws, c.st));
+  }
   if (!grouped) GD_TRY(linear_dw_deferred(c, w.dab, s.o, a->dWo, n_pad, d, d, (float*)w.part_w[2], SJ));
   if (fused) GD_TRY(gd_tok_gemm_plain(c.st, w.dab, pk.ot, nullptr, n_pad, d, d, w.d_o));
   else GD_TRY(linear_dx(c, w.dab, a->Wo, w.d_o, n_pad, d, d));
@@ -792,25 +812,18 @@ static int layer_bwd(const gdmae_layer_args* a, bool upstream3, bool defer_add3,
     J.x[2] = w.dv;  J.dst[2] = a->dbin + 2 * d;  J.C[2] = d;
     GD_TRY(colsum_jobs(c, J, n, ff > 2 * d ? ff : 2 * d, (float*)w.cs_part));
   }
-  if (fused) {
-    GD_TRY(gd_tok_gemm_plain(c.st, w.dqk, pk.qkt, nullptr, n_pad, 2 * d, d, w.dx_qk));
-    GD_TRY(gd_tok_gemm_plain(c.st, w.dv, pk.vt, nullptr, n_pad, d, d, w.dx_v));
-  } else {
-    GD_TRY(linear_dx(c, w.dqk, Win, w.dx_qk, n_pad, 2 * d, d));
-    GD_TRY(linear_dx(c, w.dv, Win + (size_t)2 * d * d * es, w.dx_v, n_pad, d, d));
-  }
-  if (!defer_add3) GD_TRY(gdmae_add3((const float*)w.dx_res, w.dx_qk, a->bf16, w.dx_v, a->bf16, n * d, a->dx, stream));
   // ---- LayerNorm / bias / temperature gradients
   // the LayerNorm backward partials (workgroup rows x {dgamma, dbeta, column sums of dx}) are reduced here, together with dtau
   AccJobs j;
-  const int nb = gd_ln_partial_rows(n, d);
+  const int nb_rows = gd_ln_partial_rows(n, d), nb_fused = (int)(n_pad / gd_tok_gemm_rows(d));
+  const int nb1 = fuse_ln ? nb_fused : nb_rows, nb2 = ln2_done ? nb_fused : nb_rows;
   const float* p1 = (const float*)w.ln_ws;    // LayerNorm 1: dg1, dbe1, bias gradient of the out-projection
   const float* p2 = (const float*)w.ln_ws2;   // LayerNorm 2: dg2, dbe2, bias gradient of the second FFN linear
   float* dst[7] = {a->dg1, a->dbe1, a->dbo, a->dg2, a->dbe2, a->db2, a->dtau};
   const float* src[7] = {p1, p1 + d, p1 + 2 * d, p2, p2 + d, p2 + 2 * d, (const float*)w.dtau};
   int cols = 0;
   for (int i = 0; i < 7; ++i) {
-    j.dst[i] = dst[i]; j.src[i] = src[i]; j.len[i] = i < 6 ? d : 1; j.nblk[i] = i < 6 ? nb : 0; j.stride[i] = 3 * d;
+    j.dst[i] = dst[i]; j.src[i] = src[i]; j.len[i] = i < 6 ? d : 1; j.nblk[i] = i < 3 ? nb1 : (i < 6 ? nb2 : 0); j.stride[i] = 3 * d;
     cols += j.len[i];
   }
   j.count = 7;
@@ -825,14 +838,33 @@ static int layer_bwd(const gdmae_layer_args* a, bool upstream3, bool defer_add3,
     for (int q = 0; q < SJ.count; ++q) gx = (SJ.P4[q] + 63) / 64 > gx ? (SJ.P4[q] + 63) / 64 : gx;
     hipLaunchKernelGGL(k_layer_tail, dim3((unsigned)gx, SJ.count + 2), dim3(256), 0, c.st, T);
     GD_LAUNCH_CHECK();
-    return 0;
+  } else {
+    hipLaunchKernelGGL(k_acc_vectors, dim3((cols + 15) / 16), dim3(256), 0, c.st, j);
+    GD_LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(k_acc_vectors, dim3((cols + 15) / 16), dim3(256), 0, c.st, j);
-  GD_LAUNCH_CHECK();
+
+  // ---- input gradient of the q/k and v projections (after the tail launch: the fused epilogue below re-uses ln_ws2)
+  if (fused) {
+    GD_TRY(gd_tok_gemm_plain(c.st, w.dqk, pk.qkt, nullptr, n_pad, 2 * d, d, w.dx_qk));
+    if (fuse_ln && prev) {
+      // ... and the LayerNorm-2 backward of the layer below: g = dx_res + dx_qk + bf16(dv Wv) is the gradient of its output
+      const Saved sp = saved_layout(prev->saved, n_pad, d, ff, es);
+      GD_TRY(gd_tok_gemm_ln_bwd(c.st, w.dv, pk.vt, n, n_pad, d, d, (const float*)w.dx_res, w.dx_qk, (const float*)sp.x1, sp.f,
+                                (const float*)sp.st2, prev->g2, (float*)w.dx1_res, w.dfb, (float*)w.ln_ws2));
+      return 0;
+    }
+    GD_TRY(gd_tok_gemm_plain(c.st, w.dv, pk.vt, nullptr, n_pad, d, d, w.dx_v));
+  } else {
+    GD_TRY(linear_dx(c, w.dqk, Win, w.dx_qk, n_pad, 2 * d, d));
+    GD_TRY(linear_dx(c, w.dv, Win + (size_t)2 * d * d * es, w.dx_v, n_pad, d, d));
+  }
+  if (!defer_add3) GD_TRY(gdmae_add3((const float*)w.dx_res, w.dx_qk, a->bf16, w.dx_v, a->bf16, n * d, a->dx, stream));
   return 0;
 }
 
-extern "C" int gdmae_encoder_layer_bwd(const gdmae_layer_args* a, void* stream) { return layer_bwd(a, false, false, stream); }
+extern "C" int gdmae_encoder_layer_bwd(const gdmae_layer_args* a, void* stream) {
+  return layer_bwd(a, false, false, nullptr, false, stream);
+}
 
 // Backward of gdmae_encoder_stage_fwd (layers in reverse); all layers MUST share one scratch buffer: the three pieces
 // of a layer's input gradient stay there and are summed on load by the previous layer's LayerNorm backward.
@@ -843,6 +875,11 @@ extern "C" int gdmae_encoder_stage_bwd(const gdmae_layer_args* layers, int n_lay
     GD_REQUIRE(layers[i].scratch == layers[0].scratch && layers[i].n == layers[0].n && layers[i].d == layers[0].d &&
                    layers[i].ff == layers[0].ff && layers[i].bf16 == layers[0].bf16,
                "encoder stage: layers must share scratch, n, d, ff, dtype");
-  for (int i = n_layers - 1; i >= 0; --i) GD_TRY(layer_bwd(&layers[i], i + 1 < n_layers, i > 0, stream));
+  // bf16 rows with packed weights: the LayerNorm-2 backward of layer i - 1 rides on layer i's last input-gradient GEMM
+  bool chain = true;
+  for (int i = 0; i < n_layers; ++i)
+    chain = chain && use_fused(&layers[i]) && use_grouped_dw(&layers[i], pad_rows(layers[i].n)) && layers[i].packed != nullptr;
+  for (int i = n_layers - 1; i >= 0; --i)
+    GD_TRY(layer_bwd(&layers[i], i + 1 < n_layers, i > 0, (chain && i > 0) ? &layers[i - 1] : nullptr, chain && i + 1 < n_layers, stream));
   return 0;
 }

@@ -13,6 +13,10 @@
 //   TG_GELU_BWD  dh = . * gelu'(h)                                              (input gradient of linear2 + activation)
 //   TG_RES_LN    y = LayerNorm(residual + bf16(. + bias)) in fp32, row statistics, optional bf16 copies y / y + pos
 //                (out-projection or linear2 + the post-norm of the layer, and the next layer's q/k/v operands)
+//   TG_LN_BWD    g = dy + [dy2] + bf16(.) is the gradient of a LayerNorm OUTPUT; dx = LayerNorm backward of g through
+//                LN(a + b) with the saved row statistics, in fp32 (+ bf16 copy), and one partial row of dgamma / dbeta /
+//                column sums of dx per workgroup (the input-gradient GEMM that feeds a post-norm's backward: linear1 of
+//                the FFN -> LayerNorm 1, the v projection of the next layer -> LayerNorm 2)
 // Numerics are those of the unfused sequence (GEMM output rounded to bf16, then the row kernels of layernorm.hip /
 // encoder_layer.hip on the rounded values): the fused path is bit-compatible with it up to the fp32 accumulation order
 // of the product.
@@ -35,7 +39,7 @@ union TgFrag {
 #define TG_WAVES 8
 #define TG_PF 4       // weight prefetch distance in k-steps
 
-enum { TG_PLAIN = 0, TG_GELU = 1, TG_GELU_BWD = 2, TG_RES_LN = 3 };
+enum { TG_PLAIN = 0, TG_GELU = 1, TG_GELU_BWD = 2, TG_RES_LN = 3, TG_LN_BWD = 4 };
 
 __device__ inline float tg_bf2f(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
 __device__ inline unsigned short tg_f2bf(float f) {
@@ -134,6 +138,10 @@ struct TgArgs {
   const int* tok_pos;
   unsigned short* ypos_bf;
   unsigned short* f_out;        // optional (n_pad, N): the rounded branch output bf16(. + bias) the LayerNorm backward re-reads
+  // LN_BWD: res = dy (n, N) fp32, aux = dy2 (n_pad, N) bf16 or null, stats (n, 2) READ, gamma; y = dx (n, N) fp32, y_bf = bf16 copy
+  const float* ln_a;            // (n, N) fp32: first addend of the LayerNorm input
+  const unsigned short* ln_b;   // (n_pad, N) bf16: second addend
+  float* part;                  // (gridDim.x, 3, N) fp32: dgamma, dbeta, column sums of dx of this workgroup's rows
 };
 
 template <int LPR>
@@ -188,6 +196,23 @@ __global__ __launch_bounds__(512, 4) void k_tok_gemm(TgArgs A) {
       const long long rr = row < A.n ? row : A.n - 1;
       res_pf[p] = *(const float4*)(A.res + rr * ND + c0);
       pos_pf[p] = A.ypos_bf ? A.tok_pos[rr] : 0;
+    }
+  }
+
+  float4 dy_pf[EPI == TG_LN_BWD ? LN_PASSES : 1], a_pf[EPI == TG_LN_BWD ? LN_PASSES : 1];
+  uint2 b_pf[EPI == TG_LN_BWD ? LN_PASSES : 1], d2_pf[EPI == TG_LN_BWD ? LN_PASSES : 1];
+  float2 st_pf[EPI == TG_LN_BWD ? LN_PASSES : 1];
+  if (EPI == TG_LN_BWD) {
+    const int c0 = 4 * (tid % LN_LPR), r = tid / LN_LPR;
+#pragma unroll
+    for (int p = 0; p < LN_PASSES; ++p) {
+      const long long row = row0 + p * LN_RPP + r;
+      const long long rr = row < A.n ? row : A.n - 1;
+      dy_pf[p] = *(const float4*)(A.res + rr * ND + c0);
+      a_pf[p] = *(const float4*)(A.ln_a + rr * ND + c0);
+      b_pf[p] = *(const uint2*)(A.ln_b + rr * ND + c0);
+      d2_pf[p] = A.aux ? *(const uint2*)(A.aux + rr * ND + c0) : make_uint2(0u, 0u);
+      st_pf[p] = *(const float2*)(A.stats + rr * 2);
     }
   }
 
@@ -308,6 +333,75 @@ __global__ __launch_bounds__(512, 4) void k_tok_gemm(TgArgs A) {
       }
       if (c0 == 0) *(float2*)(A.stats + row * 2) = make_float2(mean, rstd);
     }
+  } else if (EPI == TG_LN_BWD) {
+    // arithmetic and association order of k_add_ln_bwd (layernorm.hip) on g = (dy + dy2) + bf16(product)
+    constexpr int LPR = ND / 4;
+    constexpr int RPP = 512 / LPR;
+    const int c0 = 4 * (tid % LPR), r = tid / LPR;
+    const float4 g4 = *(const float4*)(A.gamma + c0);
+    const float g[4] = {g4.x, g4.y, g4.z, g4.w};
+    float dg[4] = {0.f, 0.f, 0.f, 0.f}, db[4] = {0.f, 0.f, 0.f, 0.f}, dsx[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int p = 0; p < (ROWS + RPP - 1) / RPP; ++p) {
+      const int rl = p * RPP + r;
+      const long long row = row0 + rl;
+      const bool live = row < A.n;
+      const long long e = (live ? row : A.n - 1) * ND + c0;
+      const uint2 fq = *(const uint2*)(lds + rl * SP + c0 * 2);
+      float d[4] = {dy_pf[p].x, dy_pf[p].y, dy_pf[p].z, dy_pf[p].w};
+      if (A.aux) {
+        d[0] += __uint_as_float(d2_pf[p].x << 16); d[1] += __uint_as_float(d2_pf[p].x & 0xFFFF0000u);
+        d[2] += __uint_as_float(d2_pf[p].y << 16); d[3] += __uint_as_float(d2_pf[p].y & 0xFFFF0000u);
+      }
+      d[0] += __uint_as_float(fq.x << 16); d[1] += __uint_as_float(fq.x & 0xFFFF0000u);
+      d[2] += __uint_as_float(fq.y << 16); d[3] += __uint_as_float(fq.y & 0xFFFF0000u);
+      const float sa[4] = {a_pf[p].x, a_pf[p].y, a_pf[p].z, a_pf[p].w};
+      const float sb[4] = {__uint_as_float(b_pf[p].x << 16), __uint_as_float(b_pf[p].x & 0xFFFF0000u), __uint_as_float(b_pf[p].y << 16),
+                           __uint_as_float(b_pf[p].y & 0xFFFF0000u)};
+      const float mean = st_pf[p].x, rstd = st_pf[p].y;
+      float gy[4], xh[4], m1 = 0.f, m2 = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (!live) d[k] = 0.f;
+        xh[k] = (sa[k] + sb[k] - mean) * rstd;
+        gy[k] = d[k] * g[k];
+        m1 += gy[k];
+        m2 = fmaf(gy[k], xh[k], m2);
+        dg[k] = fmaf(d[k], xh[k], dg[k]);
+        db[k] += d[k];
+      }
+      m1 = tg_group_sum<LPR>(m1) * (1.f / ND);
+      m2 = tg_group_sum<LPR>(m2) * (1.f / ND);
+      if (!live) continue;
+      float o[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        o[k] = rstd * (gy[k] - m1 - xh[k] * m2);
+        dsx[k] += o[k];
+      }
+      *(float4*)(A.y + e) = make_float4(o[0], o[1], o[2], o[3]);
+      if (A.y_bf) {
+        uint2 q;
+        q.x = tg_pack2(o[0], o[1]); q.y = tg_pack2(o[2], o[3]);
+        *(uint2*)(A.y_bf + e) = q;
+      }
+    }
+    // one partial row per workgroup: the RPP row slots of a column meet in LDS in a fixed order
+    __syncthreads();                                   // every thread is done with the staging tile
+    float* red = reinterpret_cast<float*>(lds);        // [RPP][3][ND]
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      red[(r * 3 + 0) * ND + c0 + k] = dg[k];
+      red[(r * 3 + 1) * ND + c0 + k] = db[k];
+      red[(r * 3 + 2) * ND + c0 + k] = dsx[k];
+    }
+    __syncthreads();
+    for (int c = tid; c < 3 * ND; c += 512) {
+      float acc1 = 0.f;
+#pragma unroll
+      for (int q = 0; q < RPP; ++q) acc1 += red[q * 3 * ND + c];
+      A.part[(long long)blockIdx.x * 3 * ND + c] = acc1;
+    }
   } else {
     constexpr int CPR = ND / 8;
     constexpr int RPP = 512 / CPR;
@@ -342,7 +436,9 @@ __global__ __launch_bounds__(512, 4) void k_tok_gemm(TgArgs A) {
 template <int KD, int ND, int EPI>
 static int tg_launch(const TgArgs& A, hipStream_t st) {
   constexpr int ROWS = TgRows<ND>::value;
-  constexpr int lds = ROWS * ((KD > ND ? KD : ND) * 2 + 16);
+  constexpr int lds_tile = ROWS * ((KD > ND ? KD : ND) * 2 + 16);
+  constexpr int lds_red = EPI == TG_LN_BWD ? (512 / (ND / 4)) * 3 * ND * 4 : 0;
+  constexpr int lds = lds_tile > lds_red ? lds_tile : lds_red;
   static bool once = false;
   if (!once) {
     GD_CHECK(hipFuncSetAttribute((const void*)k_tok_gemm<KD, ND, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -356,7 +452,7 @@ static int tg_launch(const TgArgs& A, hipStream_t st) {
 template <int EPI>
 static int tg_dispatch(int K, int N, const TgArgs& A, hipStream_t st) {
 #define TG_CASE(k_, n_)                                       \
-  if constexpr (!(EPI == TG_RES_LN && n_ > 256)) {            \
+  if constexpr (!((EPI == TG_RES_LN || EPI == TG_LN_BWD) && n_ > 256)) { \
     if (K == k_ && N == n_) return tg_launch<k_, n_, EPI>(A, st); \
   }
   TG_CASE(128, 128);
@@ -400,6 +496,27 @@ int gd_tok_gemm_res_ln(hipStream_t st, const void* X, const void* Wp, const void
   A.res = res; A.gamma = gamma; A.beta = beta; A.eps = eps; A.y = y; A.stats = stats; A.y_bf = (unsigned short*)y_bf;
   A.pos_table = pos_table; A.tok_pos = tok_pos; A.ypos_bf = (unsigned short*)ypos_bf;
   return tg_dispatch<TG_RES_LN>(K, N, A, st);
+}
+
+// dx (n, N) fp32 [+ dx_bf (n_pad, N) bf16] = LayerNorm backward of  g = dy + [dy2] + bf16(X Wp^T)  through LN(ln_a + ln_b) with the saved
+// (mean, rstd) rows; part: (n_pad / gd_tok_gemm_rows(N), 3, N) fp32 partial rows of dgamma / dbeta / column sums of dx
+int gd_tok_gemm_rows(int N) { return N >= 256 ? TgRows<256>::value : TgRows<128>::value; }
+int gd_tok_gemm_ln_bwd(hipStream_t st, const void* X, const void* Wp, long long n, long long n_pad, int K, int N, const float* dy,
+                       const void* dy2_bf, const float* ln_a, const void* ln_b_bf, const float* stats, const float* gamma, float* dx,
+                       void* dx_bf, float* part) {
+  TgArgs A = {};
+  A.X = (const unsigned short*)X; A.Wp = (const uint4*)Wp; A.n = n; A.n_pad = n_pad;
+  A.res = dy; A.aux = (const unsigned short*)dy2_bf; A.ln_a = ln_a; A.ln_b = (const unsigned short*)ln_b_bf;
+  A.stats = const_cast<float*>(stats); A.gamma = gamma; A.y = dx; A.y_bf = (unsigned short*)dx_bf; A.part = part;
+  return tg_dispatch<TG_LN_BWD>(K, N, A, st);
+}
+extern "C" int gdmae_tok_gemm_ln_bwd_rows(int N) { return gd_tok_gemm_rows(N); }
+extern "C" int gdmae_tok_gemm_ln_bwd(const void* X, const void* Wp, long long n, long long n_pad, int K, int N, const float* dy,
+                                     const void* dy2_bf16, const float* ln_a, const void* ln_b_bf16, const float* stats,
+                                     const float* gamma, float* dx, void* dx_bf16, float* part, void* stream) {
+  GD_REQUIRE(n_pad > 0 && n_pad % TG_ROWS == 0 && n <= n_pad && n >= 1, "tok_gemm: rows must be padded to a multiple of 64");
+  GD_REQUIRE(gd_tok_gemm_supported(K, N) && N <= 256, "tok_gemm_ln_bwd: unsupported (K, N)");
+  return gd_tok_gemm_ln_bwd((hipStream_t)stream, X, Wp, n, n_pad, K, N, dy, dy2_bf16, ln_a, ln_b_bf16, stats, gamma, dx, dx_bf16, part);
 }
 
 // ------------------------------------------------------------------------------------------------

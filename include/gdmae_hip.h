@@ -435,6 +435,16 @@ int gdmae_tok_gemm(const void* X, const void* Wp, const void* bias, long long n,
                    void* out0, void* out1, const void* aux, const float* res, const float* gamma, const float* beta, float eps,
                    float* y, float* stats, void* y_bf16, const float* pos_table, const int* tok_pos, void* ypos_bf16,
                    void* stream);
+
+/* Input-gradient token GEMM fused with the backward of the post-norm it feeds (tok_gemm.hip, epilogue LN_BWD; backward of
+ * sst_basic_block.py:57-84 `src = norm(src + dropout(src2))`):  g = dy + [dy2] + bf16(X Wp^T) is the gradient of
+ * LN(ln_a + ln_b); dx (n, N) fp32 and its optional bf16 copy dx_bf16 (n_pad, N) are the LayerNorm backward of g with the
+ * saved (mean, rstd) rows `stats`; part (n_pad / gdmae_tok_gemm_ln_bwd_rows(N), 3, N) fp32 receives one partial row of
+ * dgamma / dbeta / column sums of dx per workgroup (summed by the caller in a fixed order).  dy2 (bf16) may be NULL. */
+int gdmae_tok_gemm_ln_bwd_rows(int N);
+int gdmae_tok_gemm_ln_bwd(const void* X, const void* Wp, long long n, long long n_pad, int K, int N, const float* dy,
+                          const void* dy2_bf16, const float* ln_a, const void* ln_b_bf16, const float* stats,
+                          const float* gamma, float* dx, void* dx_bf16, float* part, void* stream);
 int gdmae_encoder_layer_bytes(long long n, int d, int ff, int nhead, int bf16, size_t* saved_bytes,
                               size_t* fwd_scratch_bytes, size_t* bwd_scratch_bytes);   /* depend on n only through ceil(n / 2048) */
 int gdmae_encoder_layer_fwd(const gdmae_layer_args* args /* host */, void* stream);

@@ -1122,3 +1122,34 @@ def test_tok_gemm_epilogues_match_torch(K, N):
         assert torch.allclose(stats[:, 0], s.mean(1), atol=1e-5) and torch.allclose(stats[:, 1], torch.rsqrt(s.var(1, unbiased=False) + 1e-5), rtol=1e-4)
         assert torch.equal(ybf[:n], y.bfloat16()) and float(ybf[n:].abs().max()) == 0
         assert torch.equal(ypos[:n], (y + pos[tp.long()]).bfloat16())
+        # LayerNorm backward fused behind the product: against the row kernel (gdmae_add_layernorm_bwd) fed with the rounded
+        # product as its 2nd / 3rd gradient piece - same arithmetic per row, so dx is bit-identical; the parameter-gradient
+        # partials are summed over different row groups
+        for with_dy2 in (False, True):
+            dy = torch.randn(n, N, generator=g).to(d_)
+            dy2 = torch.randn(n_pad, N, generator=g).bfloat16().to(d_) if with_dy2 else None
+            la = torch.randn(n, N, generator=g).to(d_)
+            lb = torch.randn(n_pad, N, generator=g).bfloat16().to(d_)
+            ssum = la + lb[:n].float()
+            st = torch.stack([ssum.mean(1), torch.rsqrt(ssum.var(1, unbiased=False) + 1e-5)], 1).contiguous()
+            rows = L.load().gdmae_tok_gemm_ln_bwd_rows(N)
+            part = torch.empty(n_pad // rows, 3, N, device=d_)
+            dx, dxb = torch.empty(n, N, device=d_), torch.zeros(n_pad, N, dtype=torch.bfloat16, device=d_)
+            L.call("gdmae_tok_gemm_ln_bwd", L.ptr(Xb), L.ptr(Wp), n, n_pad, K, N, L.ptr(dy), L.ptr(dy2), L.ptr(la), L.ptr(lb), L.ptr(st),
+                   L.ptr(gamma), L.ptr(dx), L.ptr(dxb), L.ptr(part), L.stream())
+            prod_b = torch.empty(n_pad, N, dtype=torch.bfloat16, device=d_)
+            call(0, out0=prod_b, b=None)
+            dx_r, sums = torch.empty(n, N, device=d_), torch.empty(3, N, device=d_)
+            ws = torch.empty(L.load().gdmae_add_layernorm_workspace_bytes(N), dtype=torch.uint8, device=d_)
+            if with_dy2:
+                dsum = torch.empty(n, N, device=d_)      # the row kernel's C ABI takes two pieces: fold dy + dy2 like the fused path
+                dsum.copy_(dy + dy2[:n].float())
+                L.call("gdmae_add_layernorm_bwd", L.ptr(la), L.ptr(lb), 1, L.ptr(gamma), L.ptr(st), L.ptr(dsum), L.ptr(prod_b), 1, n, N,
+                       L.ptr(dx_r), None, L.ptr(sums), L.ptr(ws), L.stream())
+            else:
+                L.call("gdmae_add_layernorm_bwd", L.ptr(la), L.ptr(lb), 1, L.ptr(gamma), L.ptr(st), L.ptr(dy), L.ptr(prod_b), 1, n, N,
+                       L.ptr(dx_r), None, L.ptr(sums), L.ptr(ws), L.stream())
+            assert torch.equal(dx, dx_r), float((dx - dx_r).abs().max())
+            assert torch.equal(dxb[:n], dx.bfloat16())
+            ps = part.double().sum(0)
+            assert float((ps - sums.double()).abs().max()) <= 1e-5 * float(sums.abs().max()) + 1e-5
