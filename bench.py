@@ -249,12 +249,13 @@ def main():
             bd["_gdmae_vox"], bd["_gdmae_plan"] = plan
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=mode["bf16"]):
             ret, tb, _ = net(bd)
-        ret["loss"].backward()
         pf = None
         if args.prefetch and nxt is not None:
-            # geometry plan of the NEXT batch: issued while the GPU is still busy with this backward (the host is ahead
-            # here), on a side stream that only waits for that batch's points to be resident
+            # geometry plan of the NEXT batch: issued between forward and backward, on a side stream that only waits for that
+            # batch's points to be resident - its ~100 small kernels run under this step's backward and are complete long
+            # before the host asks for them
             pf = net.backbone_3d.prefetch_plan(nxt, B, ready=nxt_ready)
+        ret["loss"].backward()
         opt.all_reduce_grads()
         opt.step(i)
         if pf is not None:
