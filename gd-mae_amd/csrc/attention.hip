@@ -521,6 +521,12 @@ int gd_attn_t32_bwd(const void* qk, const void* v, const void* dout, void* dqk, 
                     const int* win_start, const int* win_len, int n_win, int T, int d, int H, const float* tau, float tau_min,
                     hipStream_t st);
 
+int gd_attn_t3264_fwd(const void* qk, const void* v, void* out, const int* csr_tok, const int* ws32, const int* wl32, int n32, const int* ws64,
+                      const int* wl64, int n64, int d, int H, const float* tau, float tau_min, hipStream_t st);
+int gd_attn_t3264_bwd(const void* qk, const void* v, const void* dout, void* dqk, void* dv, const int* csr_tok, const int* ws32,
+                      const int* wl32, int n32, float* part32, const int* ws64, const int* wl64, int n64, float* part64, int d, int H,
+                      const float* tau, float tau_min, hipStream_t st);
+
 // bf16-MFMA variant of the T = 16 level for bf16 token I/O (attention_t16.hip)
 int gd_attn_t16_fwd(const void* qk, const void* v, void* out, const int* csr_tok, const int* win_start, const int* win_len, int n_win,
                     int d, int H, const float* tau, float tau_min, hipStream_t st);
@@ -579,4 +585,80 @@ extern "C" int gdmae_window_attention_bwd(const void* qk, const void* v, const v
                             tau_min, st);
   AttnBwdArgs A{qk, v, dout, dqk, dv, dtau_part, csr_tok, win_start, win_len, n_win, d, H, tau, tau_min};
   return io_bf16 ? dispatch_bwd<IoBF16>(A, T, DH, st) : dispatch_bwd<IoF32>(A, T, DH, st);
+}
+
+
+// All occupancy levels of one shift (the windows of level l are win_start / win_len [sum_{k<l} n_win[k], ...)), as the layer
+// executor issues them: bf16 rows on the matrix-core kernels go out as two launches (T = 16; T = 32 and T = 64 together),
+// everything else level by level.  Backward: dtau_part holds sum_l n_win[l] * H partial slots, level after level.
+static bool levels_fast_path(int io_bf16, int n_levels, const int* max_tokens, int H, int d) {
+  if (g_attn_impl != 0 || !io_bf16 || H % 4 != 0 || d % H != 0 || (d / H != 16 && d / H != 32)) return false;
+  for (int l = 0; l < n_levels; ++l)
+    if (max_tokens[l] != 16 && max_tokens[l] != 32 && max_tokens[l] != 64) return false;
+  return true;
+}
+extern "C" int gdmae_window_attention_levels_fwd(const void* qk, const void* v, void* out, int io_bf16, const int* csr_tok,
+                                                 const int* win_start, const int* win_len, int n_levels, const int* n_win,
+                                                 const int* max_tokens, int d, int H, const float* tau, float tau_min, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!levels_fast_path(io_bf16, n_levels, max_tokens, H, d)) {
+    int base = 0;
+    for (int l = 0; l < n_levels; ++l) {
+      const int rc = gdmae_window_attention_fwd(qk, v, out, io_bf16, csr_tok, win_start + base, win_len + base, n_win[l], max_tokens[l], d, H,
+                                                tau, tau_min, stream);
+      if (rc != 0) return rc;
+      base += n_win[l];
+    }
+    return 0;
+  }
+  const int* ws[3] = {nullptr, nullptr, nullptr};
+  const int* wl[3] = {nullptr, nullptr, nullptr};
+  int nw[3] = {0, 0, 0}, base = 0;
+  for (int l = 0; l < n_levels; ++l) {
+    const int k = max_tokens[l] == 16 ? 0 : (max_tokens[l] == 32 ? 1 : 2);
+    GD_REQUIRE(nw[k] == 0, "window attention: two levels with the same token capacity");
+    ws[k] = win_start + base; wl[k] = win_len + base; nw[k] = n_win[l];
+    base += n_win[l];
+  }
+  if (nw[0] > 0) {
+    const int rc = gd_attn_t16_fwd(qk, v, out, csr_tok, ws[0], wl[0], nw[0], d, H, tau, tau_min, st);
+    if (rc != 0) return rc;
+  }
+  return gd_attn_t3264_fwd(qk, v, out, csr_tok, ws[1], wl[1], nw[1], ws[2], wl[2], nw[2], d, H, tau, tau_min, st);
+}
+
+extern "C" int gdmae_window_attention_levels_bwd(const void* qk, const void* v, const void* dout, void* dqk, void* dv, int io_bf16,
+                                                 float* dtau_part, const int* csr_tok, const int* win_start, const int* win_len,
+                                                 int n_levels, const int* n_win, const int* max_tokens, int d, int H, const float* tau,
+                                                 float tau_min, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!levels_fast_path(io_bf16, n_levels, max_tokens, H, d)) {
+    int base = 0;
+    long long pbase = 0;
+    for (int l = 0; l < n_levels; ++l) {
+      const int rc = gdmae_window_attention_bwd(qk, v, dout, dqk, dv, io_bf16, dtau_part + pbase, csr_tok, win_start + base, win_len + base,
+                                                n_win[l], max_tokens[l], d, H, tau, tau_min, stream);
+      if (rc != 0) return rc;
+      base += n_win[l];
+      pbase += (long long)n_win[l] * H;
+    }
+    return 0;
+  }
+  const int* ws[3] = {nullptr, nullptr, nullptr};
+  const int* wl[3] = {nullptr, nullptr, nullptr};
+  float* part[3] = {nullptr, nullptr, nullptr};
+  int nw[3] = {0, 0, 0}, base = 0;
+  long long pbase = 0;
+  for (int l = 0; l < n_levels; ++l) {
+    const int k = max_tokens[l] == 16 ? 0 : (max_tokens[l] == 32 ? 1 : 2);
+    GD_REQUIRE(nw[k] == 0, "window attention: two levels with the same token capacity");
+    ws[k] = win_start + base; wl[k] = win_len + base; nw[k] = n_win[l]; part[k] = dtau_part + pbase;
+    base += n_win[l];
+    pbase += (long long)n_win[l] * H;
+  }
+  if (nw[0] > 0) {
+    const int rc = gd_attn_t16_bwd(qk, v, dout, dqk, dv, part[0], csr_tok, ws[0], wl[0], nw[0], d, H, tau, tau_min, st);
+    if (rc != 0) return rc;
+  }
+  return gd_attn_t3264_bwd(qk, v, dout, dqk, dv, csr_tok, ws[1], wl[1], nw[1], part[1], ws[2], wl[2], nw[2], part[2], d, H, tau, tau_min, st);
 }

@@ -168,14 +168,13 @@ template <int NT>
 constexpr int bwd_wave_lds() { return 2 * 32 * NT * kPitch * 2 + 4 * 32 * NT * 4; }    // 2 tiles + 4 scalar rows
 
 template <int NT, int DH>
-__global__ __launch_bounds__(256) void k_attn_t32_fwd(T32Args A) {
+__device__ __forceinline__ void t32_fwd_body(const T32Args& A, const unsigned blk, unsigned char* __restrict__ smem_t32) {
   constexpr int NPC = DH / 8;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_t32[];
   const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
   const int rho = lane & 31, h = lane >> 5;
   unsigned short* tV = reinterpret_cast<unsigned short*>(smem_t32 + wib * fwd_wave_lds<NT>());
   float* sKin = reinterpret_cast<float*>(tV + 32 * NT * kPitch);
-  const long long item = (long long)blockIdx.x * 4 + wib;
+  const long long item = (long long)blk * 4 + wib;
   if (item >= (long long)A.n_win * A.H) return;
   const int w = (int)(item / A.H), hd = (int)(item % A.H);
   const int n = A.win_len[w], start = A.win_start[w];
@@ -238,10 +237,9 @@ __global__ __launch_bounds__(256) void k_attn_t32_fwd(T32Args A) {
 }
 
 template <int NT, int DH>
-__global__ __launch_bounds__(256) void k_attn_t32_bwd(T32BwdArgs A) {
+__device__ __forceinline__ void t32_bwd_body(const T32BwdArgs& A, const unsigned blk, unsigned char* __restrict__ smem_t32) {
   constexpr int NPC = DH / 8;
   constexpr int TN = 32 * NT;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_t32[];
   const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
   const int rho = lane & 31, h = lane >> 5;
   unsigned short* tA = reinterpret_cast<unsigned short*>(smem_t32 + wib * bwd_wave_lds<NT>());    // K (phase 1), Q (phase 2)
@@ -250,7 +248,7 @@ __global__ __launch_bounds__(256) void k_attn_t32_bwd(T32BwdArgs A) {
   float* sQa = sKin + TN;
   float* sLse = sQa + TN;          // log2 units
   float* sD = sLse + TN;
-  const long long item = (long long)blockIdx.x * 4 + wib;
+  const long long item = (long long)blk * 4 + wib;
   if (item >= (long long)A.n_win * A.H) return;
   const int w = (int)(item / A.H), hd = (int)(item % A.H);
   const int n = A.win_len[w], start = A.win_start[w];
@@ -428,16 +426,15 @@ constexpr int kPairFwdLds = 2 * 64 * kPitch * 2 + 64 * 4;             // K, V ti
 constexpr int kPairBwdLds = 4 * 64 * kPitch * 2 + 4 * 64 * 4 + 16;    // K, V, Q, dO tiles + 4 scalar rows + the pair's dtau slot
 
 template <int DH>
-__global__ __launch_bounds__(256) void k_attn_t64_fwd(T32Args A) {
+__device__ __forceinline__ void t64_fwd_body(const T32Args& A, const unsigned blk, unsigned char* __restrict__ smem_t32) {
   constexpr int NPC = DH / 8;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_t32[];
   const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
   const int rho = lane & 31, h = lane >> 5, sub = wib & 1;
   unsigned short* tK = reinterpret_cast<unsigned short*>(smem_t32 + (wib >> 1) * kPairFwdLds);
   unsigned short* tV = tK + 64 * kPitch;
   float* sKin = reinterpret_cast<float*>(tV + 64 * kPitch);
   const long long n_items = (long long)A.n_win * A.H;
-  const long long item = min((long long)blockIdx.x * 2 + (wib >> 1), n_items - 1);      // odd tail: the pair recomputes the last item
+  const long long item = min((long long)blk * 2 + (wib >> 1), n_items - 1);      // odd tail: the pair recomputes the last item
   const int w = (int)(item / A.H), hd = (int)(item % A.H);
   const int n = A.win_len[w], start = A.win_start[w];
   const float inv_tau = 1.f / fmaxf(*A.tau, A.tau_min);
@@ -492,9 +489,8 @@ __global__ __launch_bounds__(256) void k_attn_t64_fwd(T32Args A) {
 }
 
 template <int DH>
-__global__ __launch_bounds__(256) void k_attn_t64_bwd(T32BwdArgs A) {
+__device__ __forceinline__ void t64_bwd_body(const T32BwdArgs& A, const unsigned blk, unsigned char* __restrict__ smem_t32) {
   constexpr int NPC = DH / 8;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_t32[];
   const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
   const int rho = lane & 31, h = lane >> 5, sub = wib & 1;
   unsigned short* tK = reinterpret_cast<unsigned short*>(smem_t32 + (wib >> 1) * kPairBwdLds);
@@ -506,7 +502,7 @@ __global__ __launch_bounds__(256) void k_attn_t64_bwd(T32BwdArgs A) {
   float* sLse = sQa + 64;
   float* sD = sLse + 64;
   const long long n_items = (long long)A.n_win * A.H;
-  const long long item_raw = (long long)blockIdx.x * 2 + (wib >> 1);
+  const long long item_raw = (long long)blk * 2 + (wib >> 1);
   const bool live = item_raw < n_items;                 // odd tail: the pair recomputes the last item, stores nothing
   const long long item = live ? item_raw : n_items - 1;
   const int w = (int)(item / A.H), hd = (int)(item % A.H);
@@ -654,45 +650,92 @@ __global__ __launch_bounds__(256) void k_attn_t64_bwd(T32BwdArgs A) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// kernels: one level alone, or the T = 64 and T = 32 levels of a layer in ONE launch (the T = 64 pairs first - they run
+// longest - then the T = 32 items fill in behind them; a level that is alone in its launch costs a full launch floor)
+// ---------------------------------------------------------------------------------------------------------------------
 template <int NT, int DH>
-int launch_fwd(const T32Args& A, hipStream_t st) {
-  const long long items = (long long)A.n_win * A.H;
-  hipLaunchKernelGGL((k_attn_t32_fwd<NT, DH>), dim3((unsigned)gd_div_up(items, 4)), dim3(256), 4 * fwd_wave_lds<NT>(), st, A);
-  GD_LAUNCH_CHECK();
-  return 0;
+__global__ __launch_bounds__(256) void k_attn_t32_fwd(T32Args A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_attn[];
+  t32_fwd_body<NT, DH>(A, blockIdx.x, smem_attn);
 }
 template <int NT, int DH>
-int launch_bwd(const T32BwdArgs& A, hipStream_t st) {
-  const long long items = (long long)A.n_win * A.H;
-  hipLaunchKernelGGL((k_attn_t32_bwd<NT, DH>), dim3((unsigned)gd_div_up(items, 4)), dim3(256), 4 * bwd_wave_lds<NT>(), st, A);
-  GD_LAUNCH_CHECK();
-  return 0;
+__global__ __launch_bounds__(256) void k_attn_t32_bwd(T32BwdArgs A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_attn[];
+  t32_bwd_body<NT, DH>(A, blockIdx.x, smem_attn);
 }
+template <int DH>
+__global__ __launch_bounds__(256) void k_attn_t64_fwd(T32Args A64, T32Args A32, unsigned nb64) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_attn[];
+  if (blockIdx.x < nb64) t64_fwd_body<DH>(A64, blockIdx.x, smem_attn);
+  else t32_fwd_body<1, DH>(A32, blockIdx.x - nb64, smem_attn);
+}
+template <int DH>
+__global__ __launch_bounds__(256) void k_attn_t64_bwd(T32BwdArgs A64, T32BwdArgs A32, unsigned nb64) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_attn[];
+  if (blockIdx.x < nb64) t64_bwd_body<DH>(A64, blockIdx.x, smem_attn);
+  else t32_bwd_body<1, DH>(A32, blockIdx.x - nb64, smem_attn);
+}
+
+constexpr int imax(int a, int b) { return a > b ? a : b; }
 }  // namespace
 
-// bf16 I/O only; called from attention.hip's entry points for T = 32 (NT = 1) and T = 64 (NT = 2)
-int gd_attn_t32_fwd(const void* qk, const void* v, void* out, const int* csr_tok, const int* win_start, const int* win_len, int n_win,
-                    int T, int d, int H, const float* tau, float tau_min, hipStream_t st) {
-  T32Args A{(const unsigned short*)qk, (const unsigned short*)v, (unsigned short*)out, csr_tok, win_start, win_len, n_win, d, H, tau, tau_min};
+// bf16 I/O only; called from attention.hip's entry points.  n32 / n64: windows of the T = 32 / T = 64 levels (either may be 0),
+// (win_start, win_len) of each level; both levels of a layer go out as one launch.
+int gd_attn_t3264_fwd(const void* qk, const void* v, void* out, const int* csr_tok, const int* ws32, const int* wl32, int n32, const int* ws64,
+                      const int* wl64, int n64, int d, int H, const float* tau, float tau_min, hipStream_t st) {
+  const T32Args A32{(const unsigned short*)qk, (const unsigned short*)v, (unsigned short*)out, csr_tok, ws32, wl32, n32, d, H, tau, tau_min};
+  const T32Args A64{(const unsigned short*)qk, (const unsigned short*)v, (unsigned short*)out, csr_tok, ws64, wl64, n64, d, H, tau, tau_min};
   const int DH = d / H;
-  if (T == 32) return DH == 16 ? launch_fwd<1, 16>(A, st) : launch_fwd<1, 32>(A, st);
-  const dim3 grid((unsigned)gd_div_up((long long)n_win * H, 2));
-  if (DH == 16) hipLaunchKernelGGL((k_attn_t64_fwd<16>), grid, dim3(256), 2 * kPairFwdLds, st, A);
-  else hipLaunchKernelGGL((k_attn_t64_fwd<32>), grid, dim3(256), 2 * kPairFwdLds, st, A);
+  const unsigned nb32 = (unsigned)gd_div_up((long long)n32 * H, 4), nb64 = (unsigned)gd_div_up((long long)n64 * H, 2);
+  if (nb32 + nb64 == 0) return 0;
+  if (nb64 == 0) {
+    if (DH == 16) hipLaunchKernelGGL((k_attn_t32_fwd<1, 16>), dim3(nb32), dim3(256), 4 * fwd_wave_lds<1>(), st, A32);
+    else hipLaunchKernelGGL((k_attn_t32_fwd<1, 32>), dim3(nb32), dim3(256), 4 * fwd_wave_lds<1>(), st, A32);
+  } else {
+    constexpr int lds = imax(2 * kPairFwdLds, 4 * fwd_wave_lds<1>());
+    if (DH == 16) hipLaunchKernelGGL((k_attn_t64_fwd<16>), dim3(nb64 + nb32), dim3(256), lds, st, A64, A32, nb64);
+    else hipLaunchKernelGGL((k_attn_t64_fwd<32>), dim3(nb64 + nb32), dim3(256), lds, st, A64, A32, nb64);
+  }
   GD_LAUNCH_CHECK();
   return 0;
 }
 
+// part32 / part64: n32 * H / n64 * H partial slots of d loss / d tau
+int gd_attn_t3264_bwd(const void* qk, const void* v, const void* dout, void* dqk, void* dv, const int* csr_tok, const int* ws32,
+                      const int* wl32, int n32, float* part32, const int* ws64, const int* wl64, int n64, float* part64, int d, int H,
+                      const float* tau, float tau_min, hipStream_t st) {
+  const T32BwdArgs A32{(const unsigned short*)qk, (const unsigned short*)v, (const unsigned short*)dout, (unsigned short*)dqk, (unsigned short*)dv,
+                       part32, csr_tok, ws32, wl32, n32, d, H, tau, tau_min};
+  const T32BwdArgs A64{(const unsigned short*)qk, (const unsigned short*)v, (const unsigned short*)dout, (unsigned short*)dqk, (unsigned short*)dv,
+                       part64, csr_tok, ws64, wl64, n64, d, H, tau, tau_min};
+  const int DH = d / H;
+  const unsigned nb32 = (unsigned)gd_div_up((long long)n32 * H, 4), nb64 = (unsigned)gd_div_up((long long)n64 * H, 2);
+  if (nb32 + nb64 == 0) return 0;
+  if (nb64 == 0) {
+    if (DH == 16) hipLaunchKernelGGL((k_attn_t32_bwd<1, 16>), dim3(nb32), dim3(256), 4 * bwd_wave_lds<1>(), st, A32);
+    else hipLaunchKernelGGL((k_attn_t32_bwd<1, 32>), dim3(nb32), dim3(256), 4 * bwd_wave_lds<1>(), st, A32);
+  } else {
+    constexpr int lds = imax(2 * kPairBwdLds, 4 * bwd_wave_lds<1>());
+    if (DH == 16) hipLaunchKernelGGL((k_attn_t64_bwd<16>), dim3(nb64 + nb32), dim3(256), lds, st, A64, A32, nb64);
+    else hipLaunchKernelGGL((k_attn_t64_bwd<32>), dim3(nb64 + nb32), dim3(256), lds, st, A64, A32, nb64);
+  }
+  GD_LAUNCH_CHECK();
+  return 0;
+}
+
+// one level (the per-level C entry points of attention.hip)
+int gd_attn_t32_fwd(const void* qk, const void* v, void* out, const int* csr_tok, const int* win_start, const int* win_len, int n_win,
+                    int T, int d, int H, const float* tau, float tau_min, hipStream_t st) {
+  if (T == 32) return gd_attn_t3264_fwd(qk, v, out, csr_tok, win_start, win_len, n_win, nullptr, nullptr, 0, d, H, tau, tau_min, st);
+  return gd_attn_t3264_fwd(qk, v, out, csr_tok, nullptr, nullptr, 0, win_start, win_len, n_win, d, H, tau, tau_min, st);
+}
 int gd_attn_t32_bwd(const void* qk, const void* v, const void* dout, void* dqk, void* dv, float* dtau_part, const int* csr_tok,
                     const int* win_start, const int* win_len, int n_win, int T, int d, int H, const float* tau, float tau_min,
                     hipStream_t st) {
-  T32BwdArgs A{(const unsigned short*)qk, (const unsigned short*)v, (const unsigned short*)dout, (unsigned short*)dqk, (unsigned short*)dv,
-               dtau_part, csr_tok, win_start, win_len, n_win, d, H, tau, tau_min};
-  const int DH = d / H;
-  if (T == 32) return DH == 16 ? launch_bwd<1, 16>(A, st) : launch_bwd<1, 32>(A, st);
-  const dim3 grid((unsigned)gd_div_up((long long)n_win * H, 2));
-  if (DH == 16) hipLaunchKernelGGL((k_attn_t64_bwd<16>), grid, dim3(256), 2 * kPairBwdLds, st, A);
-  else hipLaunchKernelGGL((k_attn_t64_bwd<32>), grid, dim3(256), 2 * kPairBwdLds, st, A);
-  GD_LAUNCH_CHECK();
-  return 0;
+  if (T == 32)
+    return gd_attn_t3264_bwd(qk, v, dout, dqk, dv, csr_tok, win_start, win_len, n_win, dtau_part, nullptr, nullptr, 0, nullptr, d, H, tau,
+                             tau_min, st);
+  return gd_attn_t3264_bwd(qk, v, dout, dqk, dv, csr_tok, nullptr, nullptr, 0, nullptr, win_start, win_len, n_win, dtau_part, d, H, tau,
+                           tau_min, st);
 }

@@ -642,13 +642,8 @@ static int layer_fwd(const gdmae_layer_args* a, const gdmae_layer_args* next, bo
     GD_TRY(linear_fwd(c, s.xpb, Win, bin, s.qk, n_pad, 2 * d, d));
     GD_TRY(linear_fwd(c, s.xb, Win + (size_t)2 * d * d * es, bin + (size_t)2 * d * es, s.v, n_pad, d, d));
   }
-  int base = 0;
-  for (int l = 0; l < a->n_levels; ++l) {
-    if (a->n_win[l] > 0)
-      GD_TRY(gdmae_window_attention_fwd(s.qk, s.v, s.o, a->bf16, a->csr_tok, a->win_start + base, a->win_len + base, a->n_win[l],
-                                        a->max_tokens[l], d, a->nhead, a->tau, a->tau_min, stream));
-    base += a->n_win[l];
-  }
+  GD_TRY(gdmae_window_attention_levels_fwd(s.qk, s.v, s.o, a->bf16, a->csr_tok, a->win_start, a->win_len, a->n_levels, a->n_win,
+                                           a->max_tokens, d, a->nhead, a->tau, a->tau_min, stream));
   if (fused) {
     // out-projection + residual + LayerNorm 1; linear1 + GELU; linear2 + residual + LayerNorm 2 (+ the next layer's
     // q/k/v operands): three launches for what is eight in the unfused sequence
@@ -762,16 +757,10 @@ static int layer_bwd(const gdmae_layer_args* a, bool upstream3, bool defer_add3,
   if (fused) GD_TRY(gd_tok_gemm_plain(c.st, w.dab, pk.ot, nullptr, n_pad, d, d, w.d_o));
   else GD_TRY(linear_dx(c, w.dab, a->Wo, w.d_o, n_pad, d, d));
   // ---- attention
-  int base = 0;
   long long pbase = 0;
-  for (int l = 0; l < a->n_levels; ++l) {
-    if (a->n_win[l] > 0)
-      GD_TRY(gdmae_window_attention_bwd(s.qk, s.v, w.d_o, w.dqk, w.dv, a->bf16, (float*)w.apart + pbase, a->csr_tok,
-                                        a->win_start + base, a->win_len + base, a->n_win[l], a->max_tokens[l], d, a->nhead, a->tau,
-                                        a->tau_min, stream));
-    base += a->n_win[l];
-    pbase += (long long)a->n_win[l] * a->nhead;
-  }
+  for (int l = 0; l < a->n_levels; ++l) pbase += (long long)a->n_win[l] * a->nhead;
+  GD_TRY(gdmae_window_attention_levels_bwd(s.qk, s.v, w.d_o, w.dqk, w.dv, a->bf16, (float*)w.apart, a->csr_tok, a->win_start, a->win_len,
+                                           a->n_levels, a->n_win, a->max_tokens, d, a->nhead, a->tau, a->tau_min, stream));
   if (!grouped) GD_TRY(gdmae_sum_partials_gated((const float*)w.apart, pbase, 1.f, (float*)w.dtau, a->tau, a->tau_min, stream));
   const char* Win = (const char*)a->Win;
   if (grouped) {

@@ -300,6 +300,17 @@ int gdmae_window_attention_fwd(const void* qk, const void* v, void* out, int io_
 int gdmae_window_attention_bwd(const void* qk, const void* v, const void* dout, void* dqk, void* dv, int io_bf16,
                                float* dtau_part, const int* csr_tok, const int* win_start, const int* win_len,
                                int n_win, int T, int d, int H, const float* tau, float tau_min, void* stream);
+/* All occupancy levels of one shift in one call (what the layer executor issues): the windows of level l are
+ * win_start / win_len [sum_{k<l} n_win[k], ...), max_tokens[l] its padded token count; dtau_part holds
+ * sum_l n_win[l] * H partial slots, level after level.  bf16 rows go out as two launches (T = 16; T = 32 and T = 64
+ * together), everything else level by level through the functions above. */
+int gdmae_window_attention_levels_fwd(const void* qk, const void* v, void* out, int io_bf16, const int* csr_tok,
+                                      const int* win_start, const int* win_len, int n_levels, const int* n_win,
+                                      const int* max_tokens, int d, int H, const float* tau, float tau_min, void* stream);
+int gdmae_window_attention_levels_bwd(const void* qk, const void* v, const void* dout, void* dqk, void* dv, int io_bf16,
+                                      float* dtau_part, const int* csr_tok, const int* win_start, const int* win_len,
+                                      int n_levels, const int* n_win, const int* max_tokens, int d, int H,
+                                      const float* tau, float tau_min, void* stream);
 /* out[0] = sum(term) / sum(weights), out[1] = 1 / sum(weights) (both 0 when no weight is positive): the weighted mean
  * that finishes pytorch3d.loss.chamfer_distance (spt_backbone_mae.py:83-89), one single-workgroup launch. */
 int gdmae_weighted_mean_finish(const float* term, const float* weights, long long n, float* out, void* stream);
