@@ -114,10 +114,10 @@ extern "C" int gdmae_conv_block_bwd(const gdmae_conv_block_args* a, void* stream
   Scratch s = layout(a->scratch, a->n_in, a->n_out, a->cin, a->cout, es);
   const int C = a->cout;
   // ---- BatchNorm1d + ReLU backward on the rows of y
-  CB_TRY(gdmae_rows_bwd_stats(a->y, a->bf16, nullptr, a->n_out, C, a->ab, a->ab + C, a->g, a->g_f32 ? 0 : a->bf16, C, 0, (double*)s.st,
+  CB_TRY(gdmae_rows_bwd_stats(a->y, a->bf16, nullptr, a->n_out, C, a->ab, a->ab + C, a->g, a->g_f32 ? 0 : a->bf16, C, 0, nullptr,
                               s.rs_ws, stream));
-  CB_TRY(gdmae_bn_bwd_coeffs((const double*)s.st, 3, a->stats, a->ab, a->gamma, C, (double)a->n_out, nullptr, a->dgamma, a->dbeta, 1,
-                             (float*)s.c01, stream));
+  CB_TRY(gdmae_bn_bwd_coeffs_rows((const float*)s.rs_ws, gdmae_rows_bwd_stats_rows(a->n_out), 3, a->stats, a->ab, a->gamma, C,
+                                  (double)a->n_out, nullptr, a->dgamma, a->dbeta, 1, (float*)s.c01, stream));
   CB_TRY(gdmae_rows_bwd(a->y, a->bf16, nullptr, a->n_out, C, a->ab, a->ab + C, (const float*)s.c01, (const float*)s.c01 + C, a->g,
                         a->g_f32 ? 0 : a->bf16, C, 0, s.dy, a->bf16, stream));
   // ---- weight gradient: dW (cout, 9 cin) += dy^T cols

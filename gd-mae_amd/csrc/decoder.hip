@@ -290,7 +290,11 @@ extern "C" int gdmae_rows_affine_relu_scatter(const void* P, int p_bf16, const i
 
 extern "C" size_t gdmae_rows_bwd_stats_workspace_bytes(int C) { return (size_t)512 * 3 * C * sizeof(float); }
 
-// out: double[3*C] = column sums of {dh, dh * P, dZ rows}
+// number of partial rows gdmae_rows_bwd_stats leaves in its workspace ((rows, 3, C) fp32)
+extern "C" int gdmae_rows_bwd_stats_rows(long long n) { return (int)(n / 32 > 512 ? 512 : (n / 32 > 0 ? n / 32 : 1)); }
+
+// out: double[3*C] = column sums of {dh, dh * P, dZ rows}; out == NULL: only the per-workgroup partial rows are produced
+// (workspace = (gdmae_rows_bwd_stats_rows(n), 3, C) fp32) for gdmae_bn_bwd_coeffs_rows to reduce
 extern "C" int gdmae_rows_bwd_stats(const void* P, int p_bf16, const int* site, long long n, int C, const float* a,
                                     const float* b, const void* dZ, int z_bf16, int z_row_elems, int col0, double* out,
                                     void* workspace, void* stream) {
@@ -312,8 +316,10 @@ extern "C" int gdmae_rows_bwd_stats(const void* P, int p_bf16, const int* site, 
   else { if (z_bf16) GD_LAUNCH(false, true); else GD_LAUNCH(false, false); }
 #undef GD_LAUNCH
   GD_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_partials_to_f64, dim3(gd_div_up(3 * C, 16)), dim3(256), 0, st, part, nblk, 3 * C, out);
-  GD_LAUNCH_CHECK();
+  if (out) {
+    hipLaunchKernelGGL(k_partials_to_f64, dim3(gd_div_up(3 * C, 16)), dim3(256), 0, st, part, nblk, 3 * C, out);
+    GD_LAUNCH_CHECK();
+  }
   return 0;
 }
 

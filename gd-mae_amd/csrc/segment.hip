@@ -451,6 +451,60 @@ __global__ __launch_bounds__(256) void k_bn_bwd_coeffs(const double* __restrict_
   else { dgamma[c] = dg; dbeta[c] = dbf; }
 }
 
+// the same from fp32 partial rows part (nblk, n_st, C) (gdmae_rows_bwd_stats with out == NULL): the fp64 column sums are formed
+// here - one workgroup per 8 channels, 32 slices of the rows per channel meeting in LDS in a fixed order
+__global__ __launch_bounds__(256) void k_bn_bwd_coeffs_rows(const float* __restrict__ part, int nblk, int n_st,
+                                                            const double* __restrict__ stats, const float* __restrict__ ab,
+                                                            const float* __restrict__ gamma, int C, double count,
+                                                            const double* __restrict__ tot, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, int accumulate, float* __restrict__ c01) {
+  __shared__ double sh[3][32][9];
+  const int cl = threadIdx.x & 7, ps = threadIdx.x >> 3;        // 8 channels x 32 row slices per workgroup
+  const int c = blockIdx.x * 8 + cl;
+  const long long stride = (long long)n_st * C;
+  for (int v = 0; v < n_st; ++v) {
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    if (c < C) {
+      const float* p = part + (long long)v * C + c;
+      int b = ps;
+      for (; b + 96 < nblk; b += 128) {                          // four independent loads in flight
+        a0 += (double)p[(long long)b * stride];
+        a1 += (double)p[(long long)(b + 32) * stride];
+        a2 += (double)p[(long long)(b + 64) * stride];
+        a3 += (double)p[(long long)(b + 96) * stride];
+      }
+      for (; b < nblk; b += 32) a0 += (double)p[(long long)b * stride];
+    }
+    sh[v][ps][cl] = (a0 + a1) + (a2 + a3);
+  }
+  __syncthreads();
+  if (ps != 0 || c >= C) return;
+  double s[3] = {0.0, 0.0, 0.0};
+  for (int v = 0; v < n_st; ++v)
+    for (int k = 0; k < 32; ++k) s[v] += sh[v][k][cl];
+  const double mean = stats[c], r = stats[C + c];
+  const double a = (double)ab[c], bb = (double)ab[C + c];
+  double db = s[0];
+  if (tot && n_st >= 3 && bb > 0.0) db += tot[c] - s[2];
+  const double da = s[1] - db * mean;
+  const double dv = -0.5 * (da * (double)gamma[c]) * r * r * r;
+  const double dmu = -db * a - 2.0 * mean * dv;
+  c01[c] = (float)(dmu / count);
+  c01[C + c] = (float)(2.0 * dv / count);
+  const float dg = (float)(da * r), dbf = (float)db;
+  if (accumulate) { dgamma[c] += dg; dbeta[c] += dbf; }
+  else { dgamma[c] = dg; dbeta[c] = dbf; }
+}
+extern "C" int gdmae_bn_bwd_coeffs_rows(const float* part, int nblk, int n_st, const double* stats, const float* ab, const float* gamma,
+                                        int C, double count, const double* tot, float* dgamma, float* dbeta, int accumulate, float* c01,
+                                        void* stream) {
+  GD_REQUIRE((n_st == 2 || n_st == 3) && nblk >= 1, "n_st must be 2 or 3");
+  hipLaunchKernelGGL(k_bn_bwd_coeffs_rows, dim3(gd_div_up(C, 8)), dim3(256), 0, (hipStream_t)stream, part, nblk, n_st, stats, ab, gamma, C,
+                     count, tot, dgamma, dbeta, accumulate, c01);
+  GD_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int gdmae_bn_bwd_coeffs(const double* st, int n_st, const double* stats, const float* ab, const float* gamma, int C,
                                    double count, const double* tot, float* dgamma, float* dbeta, int accumulate, float* c01,
                                    void* stream) {

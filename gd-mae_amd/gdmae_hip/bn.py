@@ -43,15 +43,20 @@ def bwd_coeffs(st: torch.Tensor, n_st: int, stats: torch.Tensor, ab: torch.Tenso
     """st f64[n_st*C] column sums {dh, dh*x, (g)} -> (dgamma, dbeta, c01 f32[2C]); with ``direct`` = flat-gradient
     views of (gamma, beta) the parameter gradients are accumulated there and (None, None, c01) is returned."""
     C = gamma.numel()
-    dev = st.device
+    dev = gamma.device
     c01 = torch.empty(2 * C, dtype=torch.float32, device=dev)
     dg, db = direct
     acc = int(dg is not None and db is not None)
     if not acc:
         dgb = torch.empty(2 * C, dtype=torch.float32, device=dev)
         dg, db = dgb[:C], dgb[C:]
-    L.call("gdmae_bn_bwd_coeffs", L.ptr(st), n_st, L.ptr(stats), L.ptr(ab), L.ptr(gamma), C, float(count),
-           L.ptr(tot) if tot is not None else None, L.ptr(dg), L.ptr(db), acc, L.ptr(c01), L.stream())
+    if isinstance(st, tuple):         # (workspace of gdmae_rows_bwd_stats called with out = NULL, its partial-row count)
+        part, nblk = st
+        L.call("gdmae_bn_bwd_coeffs_rows", L.ptr(part), nblk, n_st, L.ptr(stats), L.ptr(ab), L.ptr(gamma), C, float(count),
+               L.ptr(tot) if tot is not None else None, L.ptr(dg), L.ptr(db), acc, L.ptr(c01), L.stream())
+    else:
+        L.call("gdmae_bn_bwd_coeffs", L.ptr(st), n_st, L.ptr(stats), L.ptr(ab), L.ptr(gamma), C, float(count),
+               L.ptr(tot) if tot is not None else None, L.ptr(dg), L.ptr(db), acc, L.ptr(c01), L.stream())
     return (None, None, c01) if acc else (dg, db, c01)
 
 

@@ -281,11 +281,11 @@ class DecoderHead(torch.autograd.Function):
             Zd = Zrows - bgz[col:col + w]
             dW_rows.append(ops.splitk_tn(G, Zd))                          # (9*C2, w) fp32
             del G
-            st = torch.empty(3 * w, dtype=f64, device=dev)
             ws = torch.empty(L.load().gdmae_rows_bwd_stats_workspace_bytes(w), dtype=torch.uint8, device=dev)
             L.call("gdmae_rows_bwd_stats", L.ptr(P), _bf(P), None, n, w, L.ptr(ab), L.ptr(ab[w:]), L.ptr(dX), _bf(dX), w, 0,
-                   L.ptr(st), L.ptr(ws), L.stream())
-            dgamma, dbeta, c01 = gbn.bwd_coeffs(st, 3, stats_l[i], ab, gammas[i], R, tot[col:col + w], ctx.direct[i])
+                   None, L.ptr(ws), L.stream())
+            dgamma, dbeta, c01 = gbn.bwd_coeffs((ws, L.load().gdmae_rows_bwd_stats_rows(n)), 3, stats_l[i], ab, gammas[i], R,
+                                                tot[col:col + w], ctx.direct[i])
             dP = torch.empty_like(P)
             L.call("gdmae_rows_bwd", L.ptr(P), _bf(P), None, n, w, L.ptr(ab), L.ptr(ab[w:]), L.ptr(c01), L.ptr(c01[w:]), L.ptr(dX),
                    _bf(dX), w, 0, L.ptr(dP), _bf(dP), L.stream())

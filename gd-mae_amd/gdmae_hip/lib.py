@@ -58,6 +58,8 @@ SIGNATURES = {
     "gdmae_rows_bwd_stats": (_I, [_P, _I, _P, _L, _I, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
     "gdmae_bn_fold": (_I, [_P, _L, _I, _I, _D, _P, _P, _D, _D, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gdmae_bn_bwd_coeffs": (_I, [_P, _I, _P, _P, _P, _I, _D, _P, _P, _P, _I, _P, _P]),
+    "gdmae_rows_bwd_stats_rows": (_I, [_L]),
+    "gdmae_bn_bwd_coeffs_rows": (_I, [_P, _I, _I, _P, _P, _P, _I, _D, _P, _P, _P, _I, _P, _P]),
     "gdmae_border_sums_workspace_bytes": (_Z, [_I, _I]),
     "gdmae_border_sums": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
     "gdmae_conv3x3_grad_taps": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P, _P]),

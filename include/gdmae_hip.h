@@ -217,6 +217,12 @@ int gdmae_bn_fold(const void* x, long long R, int C, int is_bf16, double count, 
 int gdmae_bn_bwd_coeffs(const double* st, int n_st, const double* stats, const float* ab, const float* gamma, int C,
                         double count, const double* tot, float* dgamma, float* dbeta, int accumulate, float* c01,
                         void* stream);
+/* ... from the fp32 partial rows (nblk, n_st, C) that gdmae_rows_bwd_stats leaves in its workspace when called with out == NULL
+ * (nblk = gdmae_rows_bwd_stats_rows(n)): one launch instead of a reduce + a coefficient launch. */
+int gdmae_rows_bwd_stats_rows(long long n);
+int gdmae_bn_bwd_coeffs_rows(const float* part, int nblk, int n_st, const double* stats, const float* ab, const float* gamma, int C,
+                             double count, const double* tot, float* dgamma, float* dbeta, int accumulate, float* c01,
+                             void* stream);
 
 /* Backward of the decoder's dense 3x3 conv_out (spt_backbone_mae.py:46-52) restricted to the sites that need it:
  * out[t, k, :] = dY[site[t] - k] for the 9 taps k = (ky+1)*3 + (kx+1) (zero outside the H x W map), where the
