@@ -146,6 +146,40 @@ ROOFLINE_KERNELS = {
 }
 
 
+def _attention_product_timing(step, dev_batches, args, n_steps):
+    """{entry: summary} of the forward / backward all-levels attention entries over `n_steps` product-path steps: HIP events
+    recorded by the library around the calls (include/gdmae_hip.h gdmae_attention_timing), algorithmic bytes from the plans of
+    those steps (tokens x (4 | 7) x d x 2 B + CSR, per layer: every stage runs 2 layers on each of its 2 window shifts)."""
+    import ctypes as C
+    from gdmae_hip import lib as L
+    if not hasattr(L.load(), "gdmae_attention_timing"):
+        return None
+    L.call("gdmae_attention_timing", 1)
+    by = {"k_win_attn_fwd": 0.0, "k_win_attn_bwd": 0.0}
+    try:
+        for i in range(n_steps):
+            _, bd = step(args.warmup + args.steps, dev_batches[i % args.pool])
+            plan = bd["_gdmae_plan"]
+            for st, dm in zip(plan.stages, bd["_gdmae_dims"]):
+                for w in st.windows:
+                    for lvl, nw in enumerate(w.n_win):
+                        if nw > 0:
+                            by["k_win_attn_fwd"] += 2 * (w.n_tok[lvl] * (4 * dm * 2 + 4) + 8 * nw)
+                            by["k_win_attn_bwd"] += 2 * (w.n_tok[lvl] * (7 * dm * 2 + 4) + 8 * nw)
+        torch.cuda.synchronize()
+        out = {}
+        for which, name in ((0, "k_win_attn_fwd"), (1, "k_win_attn_bwd")):
+            ms, calls = C.c_double(0.0), C.c_longlong(0)
+            L.call("gdmae_attention_timing_read", which, C.byref(ms), C.byref(calls))
+            if calls.value:
+                out[name] = {"launches": calls.value, "total_ms": ms.value, "avg_us": 1e3 * ms.value / calls.value,
+                             "bytes_per_launch": by[name] / calls.value, "total_bytes": by[name], "flops_per_launch": 0.0,
+                             "total_flops": 0.0, "extra": {"timed": "product path: one call per layer = all occupancy levels"}}
+        return out
+    finally:
+        L.call("gdmae_attention_timing", 0)
+
+
 def measure_roofline(step, dev_batches, args, n_steps=4):
     """HIP-event timing (events on the launch stream) of the instrumented hand-written kernels over `n_steps` extra steps
     after the timed region; `roofline` describes the one with the LARGEST TOTAL TIME in this run, the others are listed
@@ -153,7 +187,8 @@ def measure_roofline(step, dev_batches, args, n_steps=4):
       k_conv3x3_tiles   executed MFMA flops = active tiles x 64 sites x 128 channels x (9 x Cin) x 2   (bound: bf16 MFMA);
                         the dense convolution of SURVEY section 8d would be B x H x W sites - reported as dense_equivalent
       k_conv_grad_taps  active sites x 9 taps x 128 channels x 2 B read + written
-      k_win_attn_*      tokens x (7 | 4) x d x elem + CSR bytes (q, k, v, dOut rows read, dq, dk, dv rows written, once each)
+      k_win_attn_*      tokens x (7 | 4) x d x elem + CSR bytes (q, k, v, dOut rows read, dq, dk, dv rows written, once each);
+                        one "launch" = one call of the all-levels entry (a layer's T = 16 launch + its T = 32 / 64 launch)
     `traffic` = HBM bytes per launch from this round's committed rocprofv3 PMC passes (profiles/, see _pmc_traffic)."""
     from gdmae_hip import timing
     with timing.collect() as T:
@@ -161,6 +196,11 @@ def measure_roofline(step, dev_batches, args, n_steps=4):
             step(args.warmup + args.steps, dev_batches[i % args.pool])
         summ = T.summary()
     summ = {k: v for k, v in summ.items() if k in ROOFLINE_KERNELS and v["total_ms"] > 0}
+    # the attention entry points are timed on the PRODUCT path (the per-operator path above launches every occupancy level on its
+    # own; the layer executor issues a layer's levels through gdmae_window_attention_levels_*, bracketed with HIP events there)
+    prod = _attention_product_timing(step, dev_batches, args, n_steps)
+    if prod:
+        summ.update(prod)
     if not summ:
         return None
 
@@ -240,10 +280,11 @@ def main():
     use_bf16 = mode["bf16"]
 
     pending = {}
+    stage_dims = [int(b.ENCODER.D_MODEL) for b in cfg.BACKBONE_3D.SST_BLOCK_LIST]
 
     def step(i, pts, nxt=None, nxt_ready=None):
         opt.zero_grad()
-        bd = {"points": pts, "batch_size": B, "_gdmae_grad_sync": opt.sync}
+        bd = {"points": pts, "batch_size": B, "_gdmae_grad_sync": opt.sync, "_gdmae_dims": stage_dims}
         if args.prefetch:
             plan = pending.pop(id(pts), None) or net.backbone_3d.prefetch_plan(pts, B).finish()
             bd["_gdmae_vox"], bd["_gdmae_plan"] = plan

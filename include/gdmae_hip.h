@@ -317,6 +317,11 @@ int gdmae_window_attention_levels_bwd(const void* qk, const void* v, const void*
                                       float* dtau_part, const int* csr_tok, const int* win_start, const int* win_len,
                                       int n_levels, const int* n_win, const int* max_tokens, int d, int H,
                                       const float* tau, float tau_min, void* stream);
+/* Measurement hook (bench.py roofline leg): HIP-event brackets around the two all-levels entries on the stream they launch on.
+ * gdmae_attention_timing(1) starts collecting (dropping earlier records), (0) stops; gdmae_attention_timing_read returns the
+ * summed milliseconds and the number of calls of the forward (which = 0) / backward (which = 1) entry. */
+int gdmae_attention_timing(int on);
+int gdmae_attention_timing_read(int which, double* total_ms, long long* calls);
 /* out[0] = sum(term) / sum(weights), out[1] = 1 / sum(weights) (both 0 when no weight is positive): the weighted mean
  * that finishes pytorch3d.loss.chamfer_distance (spt_backbone_mae.py:83-89), one single-workgroup launch. */
 int gdmae_weighted_mean_finish(const float* term, const float* weights, long long n, float* out, void* stream);
