@@ -65,7 +65,7 @@ template <bool PBF, bool ZBF>
 __global__ __launch_bounds__(256) void k_rows_affine_relu_scatter_v8(const void* __restrict__ P, const int* __restrict__ site,
                                                                      long long n, int C, const float* __restrict__ a,
                                                                      const float* __restrict__ b, void* __restrict__ Z,
-                                                                     int zrow, int col0) {
+                                                                     int zrow, int col0, const void* __restrict__ sub) {
   const int cv = C >> 3;
   const long long total = n * cv;
   for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
@@ -79,6 +79,12 @@ __global__ __launch_bounds__(256) void k_rows_affine_relu_scatter_v8(const void*
     for (int j = 0; j < 8; ++j) {
       const float h = fmaf(av[j], p[j], bv[j]);
       o[j] = h > 0.f ? h : 0.f;
+    }
+    if (sub) {      // Z = round(round(relu) - sub): the rows minus a per-channel constant, rounded like the two-step sequence
+      float sv[8];
+      dec_ld8<ZBF>(sub, c, sv);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (ZBF ? dec_bf2f(dec_f2bf(o[j])) : o[j]) - sv[j];
     }
     dec_st8<ZBF>(Z, (site ? (long long)site[r] : r) * zrow + col0 + c, o);
   }
@@ -269,8 +275,20 @@ extern "C" int gdmae_fill_rows(const void* v, long long R, int C, int elem_bytes
   return 0;
 }
 
+static int rows_affine_relu_scatter(const void* P, int p_bf16, const int* site, long long n, int C, const float* a, const float* b, void* Z,
+                                    int z_bf16, int z_row_elems, int col0, const void* sub, void* stream);
 extern "C" int gdmae_rows_affine_relu_scatter(const void* P, int p_bf16, const int* site, long long n, int C, const float* a,
                                               const float* b, void* Z, int z_bf16, int z_row_elems, int col0, void* stream) {
+  return rows_affine_relu_scatter(P, p_bf16, site, n, C, a, b, Z, z_bf16, z_row_elems, col0, nullptr, stream);
+}
+// Z[site[r] or r, col0 + c] = relu(a P + b) - sub[c]   (sub (C) in Z's dtype; C, the row pitch and col0 multiples of 8)
+extern "C" int gdmae_rows_affine_relu_sub(const void* P, int p_bf16, const int* site, long long n, int C, const float* a, const float* b,
+                                          const void* sub, void* Z, int z_bf16, int z_row_elems, int col0, void* stream) {
+  GD_REQUIRE(sub != nullptr && C % 8 == 0 && z_row_elems % 8 == 0 && col0 % 8 == 0, "rows_affine_relu_sub: 8-channel granularity");
+  return rows_affine_relu_scatter(P, p_bf16, site, n, C, a, b, Z, z_bf16, z_row_elems, col0, sub, stream);
+}
+static int rows_affine_relu_scatter(const void* P, int p_bf16, const int* site, long long n, int C, const float* a, const float* b, void* Z,
+                                    int z_bf16, int z_row_elems, int col0, const void* sub, void* stream) {
   if (n <= 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid(dec_grid(n * C)), block(256);
@@ -278,7 +296,7 @@ extern "C" int gdmae_rows_affine_relu_scatter(const void* P, int p_bf16, const i
   const dim3 grid8(dec_grid(n * C / 8));
 #define GD_LAUNCH(PB, ZB)                                                                                                         \
   do {                                                                                                                            \
-    if (v8) hipLaunchKernelGGL((k_rows_affine_relu_scatter_v8<PB, ZB>), grid8, block, 0, st, P, site, n, C, a, b, Z, z_row_elems, col0); \
+    if (v8) hipLaunchKernelGGL((k_rows_affine_relu_scatter_v8<PB, ZB>), grid8, block, 0, st, P, site, n, C, a, b, Z, z_row_elems, col0, sub); \
     else hipLaunchKernelGGL((k_rows_affine_relu_scatter<PB, ZB>), grid, block, 0, st, P, site, n, C, a, b, Z, z_row_elems, col0);  \
   } while (0)
   if (p_bf16) { if (z_bf16) GD_LAUNCH(true, true); else GD_LAUNCH(true, false); }

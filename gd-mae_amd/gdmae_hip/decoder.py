@@ -274,11 +274,17 @@ class DecoderHead(torch.autograd.Function):
             dX = ops.mm(G, Wd[:, :, col:col + w].reshape(9 * C2, w))      # dZ rows of this stage's active sites
             if Z is not None:
                 Zrows = _gather_slice(Z, sites[i], col, w)
+                Zd = Zrows - bgz[col:col + w]
             else:                                                         # the map was never built: redo BN + ReLU of the rows
-                Zrows = torch.empty(n, w, dtype=cdt, device=dev)
-                L.call("gdmae_rows_affine_relu_scatter", L.ptr(P), _bf(P), None, n, w, L.ptr(ab), L.ptr(ab[w:]), L.ptr(Zrows),
-                       _bf(Zrows), w, 0, L.stream())
-            Zd = Zrows - bgz[col:col + w]
+                Zd = torch.empty(n, w, dtype=cdt, device=dev)
+                bg = bgz[col:col + w]
+                if w % 8 == 0 and bg.dtype == cdt:
+                    L.call("gdmae_rows_affine_relu_sub", L.ptr(P), _bf(P), None, n, w, L.ptr(ab), L.ptr(ab[w:]), L.ptr(bg), L.ptr(Zd),
+                           _bf(Zd), w, 0, L.stream())
+                else:
+                    L.call("gdmae_rows_affine_relu_scatter", L.ptr(P), _bf(P), None, n, w, L.ptr(ab), L.ptr(ab[w:]), L.ptr(Zd),
+                           _bf(Zd), w, 0, L.stream())
+                    Zd = Zd - bg
             dW_rows.append(ops.splitk_tn(G, Zd))                          # (9*C2, w) fp32
             del G
             ws = torch.empty(L.load().gdmae_rows_bwd_stats_workspace_bytes(w), dtype=torch.uint8, device=dev)

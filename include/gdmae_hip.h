@@ -196,6 +196,10 @@ int gdmae_decoder_region_algebra(const double* stats2, const float* ab2, const d
 int gdmae_fill_rows(const void* v, long long R, int C, int elem_bytes, void* Z, void* stream);
 int gdmae_rows_affine_relu_scatter(const void* P, int p_bf16, const int* site, long long n, int C, const float* a,
                                    const float* b, void* Z, int z_bf16, int z_row_elems, int col0, void* stream);
+/* ... minus a per-channel constant sub (C) of Z's dtype, rounded like the two-step sequence (the decoder backward's Z - background
+ * rows); C, the row pitch and col0 must be multiples of 8. */
+int gdmae_rows_affine_relu_sub(const void* P, int p_bf16, const int* site, long long n, int C, const float* a, const float* b,
+                               const void* sub, void* Z, int z_bf16, int z_row_elems, int col0, void* stream);
 size_t gdmae_rows_bwd_stats_workspace_bytes(int C);
 int gdmae_rows_bwd_stats(const void* P, int p_bf16, const int* site, long long n, int C, const float* a, const float* b,
                          const void* dZ, int z_bf16, int z_row_elems, int col0, double* out, void* workspace, void* stream);
