@@ -197,15 +197,24 @@ __global__ __launch_bounds__(256) void k_layer_tail(TailJobs T) {
     if (blockIdx.x * 16 < cols) tail_vectors(T.a);
   } else if (blockIdx.x == 0) {
     __shared__ float shw[4];
+    // 16-byte loads, four of them in flight per thread: the ~50 k partials of a layer are one latency-bound chain per thread
+    // otherwise (this single workgroup was the longest-running part of the launch)
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    const long long n4 = T.n_part >> 2;
+    const float4* p4 = reinterpret_cast<const float4*>(T.tau_part);
     long long i = threadIdx.x;
-    for (; i + 3 * 256 < T.n_part; i += 4 * 256) {
-      a0 += T.tau_part[i];
-      a1 += T.tau_part[i + 256];
-      a2 += T.tau_part[i + 512];
-      a3 += T.tau_part[i + 768];
+    for (; i + 3 * 256 < n4; i += 4 * 256) {
+      const float4 v0 = p4[i], v1 = p4[i + 256], v2 = p4[i + 512], v3 = p4[i + 768];
+      a0 += (v0.x + v0.y) + (v0.z + v0.w);
+      a1 += (v1.x + v1.y) + (v1.z + v1.w);
+      a2 += (v2.x + v2.y) + (v2.z + v2.w);
+      a3 += (v3.x + v3.y) + (v3.z + v3.w);
     }
-    for (; i < T.n_part; i += 256) a0 += T.tau_part[i];
+    for (; i < n4; i += 256) {
+      const float4 v0 = p4[i];
+      a0 += (v0.x + v0.y) + (v0.z + v0.w);
+    }
+    for (long long j = (n4 << 2) + threadIdx.x; j < T.n_part; j += 256) a1 += T.tau_part[j];
     const float w = gd_wave_sum((a0 + a1) + (a2 + a3));
     if ((threadIdx.x & 63) == 0) shw[threadIdx.x >> 6] = w;
     __syncthreads();
