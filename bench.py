@@ -279,14 +279,14 @@ def main():
         if args.prefetch:
             plan = pending.pop(id(pts), None) or net.backbone_3d.prefetch_plan(pts, B).finish()
             bd["_gdmae_vox"], bd["_gdmae_plan"] = plan
-        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=mode["bf16"]):
-            ret, tb, _ = net(bd)
         pf = None
         if args.prefetch and nxt is not None:
-            # geometry plan of the NEXT batch: issued between forward and backward, on a side stream that only waits for that
-            # batch's points to be resident - its ~100 small kernels run under this step's backward and are complete long
-            # before the host asks for them
+            # geometry plan of the NEXT batch: issued at the start of the step on a side stream that is ordered after the work
+            # queued so far (the previous step) - its ~100 small kernels run under this step's forward and are complete long
+            # before the host asks for them at the end of the step
             pf = net.backbone_3d.prefetch_plan(nxt, B, ready=nxt_ready)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=mode["bf16"]):
+            ret, tb, _ = net(bd)
         ret["loss"].backward()
         opt.all_reduce_grads()
         opt.step(i)

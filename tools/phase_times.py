@@ -17,26 +17,90 @@ batches = [torch.from_numpy(synth.synth_batch(5 + i, 8, ds.point_cloud_range, **
 resident = torch.cuda.Event(); resident.record()
 pend = {}
 marks = []
+if "--plan-on-main" in sys.argv:           # geometry plan kernels on the training stream itself (serial) instead of the side stream
+    from gdmae_hip import plan as _plan
+    _plan.PlanPrefetch._side[dev.index] = torch.cuda.current_stream()
+SPIN = float(sys.argv[sys.argv.index("--spin-ms") + 1]) if "--spin-ms" in sys.argv else 0.0
+PFDROP = 1 if "--prefetch-drop" in sys.argv else (2 if "--prefetch-finish-drop" in sys.argv else 0)
+KEEP = []
+VOXONLY = "--vox-only" in sys.argv
+ENCONLY = "--enc-only" in sys.argv
+if ENCONLY:
+    from gdmae_hip import plan as _p0
+    VRAW = [_p0._voxelize_launch(b, net.backbone_3d.point_cloud_range, net.backbone_3d.voxel_size, net.backbone_3d.grid_size, 8) for b in batches]
+    torch.cuda.synchronize()
+DUMMY = int(sys.argv[sys.argv.index("--dummy") + 1]) if "--dummy" in sys.argv else 0
+SIDE = torch.cuda.Stream()
+TINY = torch.zeros(64, device=dev)
+REUSE = "--reuse-plans" in sys.argv      # geometry plans of the 4 pooled batches built once: the step without its plan kernels
+PLANS = [net.backbone_3d.prefetch_plan(b, 8).finish() for b in batches] if REUSE else None
 def ev():
     e = torch.cuda.Event(enable_timing=True); e.record(); return e
+HOST = {"finish": 0.0, "prefetch": 0.0, "forward": 0.0, "backward": 0.0, "opt": 0.0, "n": 0}
 def step(i, rec):
     pts, nxt = batches[i % 4], batches[(i + 1) % 4]
+    h0 = time.perf_counter()
     e0 = ev()
     opt.zero_grad()
-    pf = pend.pop(i, None) or net.backbone_3d.prefetch_plan(pts, 8)
+    if REUSE:
+        pf = PLANS[i % 4]
+    else:
+        pf = pend.pop(i, None) or net.backbone_3d.prefetch_plan(pts, 8)
     bd = {"points": pts, "batch_size": 8, "_gdmae_grad_sync": opt.sync}
     bd["_gdmae_vox"], bd["_gdmae_plan"] = pf.finish() if hasattr(pf, "finish") else pf
+    pfn = None if REUSE else net.backbone_3d.prefetch_plan(nxt, 8, ready=resident)
+    h1 = time.perf_counter()
     with torch.autocast("cuda", dtype=torch.bfloat16):
         ret, _, _ = net(bd)
     e1 = ev()
-    pfn = net.backbone_3d.prefetch_plan(nxt, 8, ready=resident)
+    h2 = time.perf_counter()
+    if PFDROP:                                   # the complete prefetch (launches, count copy, event) without finish(); result dropped
+        KEEP.append(net.backbone_3d.prefetch_plan(nxt, 8, ready=resident))
+        if len(KEEP) > 2:
+            old = KEEP.pop(0)
+            if PFDROP == 2:
+                old.finish()                     # ... or finished two steps later (host-side finalize + stream ordering), then dropped
+    if VOXONLY:                                  # only the voxelization kernels of the next batch on the side stream (result dropped)
+        from gdmae_hip import plan as _p
+        with torch.cuda.stream(SIDE):
+            _p._voxelize_launch(nxt, net.backbone_3d.point_cloud_range, net.backbone_3d.voxel_size, net.backbone_3d.grid_size, 8)
+    if ENCONLY:                                  # only the encoder-plan kernels (masking, token sets, rulebooks, windows, tiles)
+        from gdmae_hip import plan as _p
+        from pcdet.models.backbones_3d.spt_backbone import stage_plan_args
+        bb = net.backbone_3d
+        with torch.cuda.stream(SIDE):
+            vr = VRAW[(i + 1) % 4]
+            gx, gy, gz = vr["grid"]
+            _p._encoder_launch(vr, max(1, min(vr["n0"], 8 * gx * gy * gz)), *stage_plan_args(bb.model_cfg.SST_BLOCK_LIST),
+                               1 - bb.mask_ratio, None, bb._dec_sources())
+    if SPIN:                                     # host busy-wait: emulates host-side work without any GPU work
+        t_end = time.perf_counter() + SPIN * 1e-3
+        while time.perf_counter() < t_end:
+            pass
+    if DUMMY:                                    # N empty launches on a side stream: what do kernel boundaries on another queue cost?
+        with torch.cuda.stream(SIDE):
+            for _ in range(DUMMY):
+                TINY.add_(1.0)
+    h3 = time.perf_counter()
     ret["loss"].backward()
     e2 = ev()
+    h4 = time.perf_counter()
     opt.all_reduce_grads()
     opt.step(i)
     e3 = ev()
-    pend[i + 1] = pfn.finish()
-    if rec: marks.append((e0, e1, e2, e3))
+    h5 = time.perf_counter()
+    if not REUSE:
+        pend[i + 1] = pfn.finish()
+    h6 = time.perf_counter()
+    if rec:
+        marks.append((e0, e1, e2, e3))
+        HOST["finish"] += (h1 - h0) + (h6 - h5); HOST["forward"] += h2 - h1; HOST["prefetch"] += h3 - h2
+        HOST["backward"] += h4 - h3; HOST["opt"] += h5 - h4; HOST["n"] += 1
+print("stream priority range (least, greatest):", torch.cuda.Stream.priority_range())
+if "--high-priority" in sys.argv:          # training on a high-priority stream: the side-stream plan only fills what it leaves idle
+    hp = torch.cuda.Stream(priority=torch.cuda.Stream.priority_range()[1])
+    hp.wait_stream(torch.cuda.current_stream())
+    torch.cuda.set_stream(hp)
 for i in range(10): step(i, False)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
@@ -48,4 +112,5 @@ f = sum(a.elapsed_time(b) for a, b, _, _ in marks) / N
 b = sum(b_.elapsed_time(c) for _, b_, c, _ in marks) / N
 o = sum(c.elapsed_time(d) for _, _, c, d in marks) / N
 gap = sum(marks[k][3].elapsed_time(marks[k + 1][0]) for k in range(N - 1)) / (N - 1)
+print("host ms/step: " + ", ".join(f"{k} {1e3 * v / HOST['n']:.2f}" for k, v in HOST.items() if k != "n") + f" | total {1e3 * sum(v for k, v in HOST.items() if k != 'n') / HOST['n']:.2f}")
 print(f"wall/step {wall:.3f} ms | forward span {f:.3f} backward span {b:.3f} optimizer span {o:.3f} step-to-step gap {gap:.3f} | sum {f + b + o + gap:.3f}")
