@@ -295,6 +295,66 @@ def test_window_attention_fwd_bwd_matches_oracle(d, nhead, impl):
     L.call("gdmae_set_attention_impl", 0)
 
 
+@pytest.mark.parametrize("d,H", [(128, 8), (256, 8)])
+def test_packed_window_attention_edge_cases(d, H):
+    """The bf16 matrix-core attention kernels on hand-made window lists: full windows, single-token windows, groups whose tokens
+    sum to exactly 16 (one packed pass) or to 17 (two passes), a tail group of fewer than four windows, and for the T = 32 / 64
+    levels windows of exactly 17 / 32 / 33 / 64 tokens - against the lane-per-query VALU kernels (fp32 arithmetic) on the same bf16
+    rows, forward and backward, through the per-level and the all-levels entry points."""
+    from gdmae_hip import lib as L
+    dv = dev()
+    g = torch.Generator().manual_seed(d + H)
+    levels = {16: [16, 1, 1, 14, 8, 8, 5, 4, 4, 3, 16, 16, 2, 9, 1, 1, 1, 1, 7],            # 19 windows: tail group of 3
+              32: [17, 32, 20, 31, 25],
+              64: [33, 64, 40, 63, 50, 64, 35]}
+    lens = [n for T in (16, 32, 64) for n in levels[T]]
+    n_tok = sum(lens)
+    perm = torch.randperm(n_tok, generator=g).int()                       # tokens of a window are scattered rows
+    win_start = torch.tensor([sum(lens[:i]) for i in range(len(lens))], dtype=torch.int32)
+    win_len = torch.tensor(lens, dtype=torch.int32)
+    n_win = [len(levels[T]) for T in (16, 32, 64)]
+    qk = torch.randn(n_tok, 2 * d, generator=g).bfloat16().to(dv)
+    v = torch.randn(n_tok, d, generator=g).bfloat16().to(dv)
+    go = torch.randn(n_tok, d, generator=g).bfloat16().to(dv)
+    tau = torch.full((1,), 0.2, device=dv)
+    csr, ws, wl = perm.to(dv), win_start.to(dv), win_len.to(dv)
+    nw_h, T_h = L.host_i32(n_win), L.host_i32([16, 32, 64])
+
+    def run(impl, levels_entry):
+        L.call("gdmae_set_attention_impl", impl)
+        out = torch.zeros(n_tok, d, dtype=torch.bfloat16, device=dv)
+        dqk = torch.zeros(n_tok, 2 * d, dtype=torch.bfloat16, device=dv)
+        dvv = torch.zeros(n_tok, d, dtype=torch.bfloat16, device=dv)
+        part = torch.full((sum(n_win) * H,), 123.0, device=dv)             # every slot must be written
+        if levels_entry:
+            L.call("gdmae_window_attention_levels_fwd", L.ptr(qk), L.ptr(v), L.ptr(out), 1, L.ptr(csr), L.ptr(ws), L.ptr(wl), 3, nw_h, T_h, d, H,
+                   L.ptr(tau), 0.01, L.stream())
+            L.call("gdmae_window_attention_levels_bwd", L.ptr(qk), L.ptr(v), L.ptr(go), L.ptr(dqk), L.ptr(dvv), 1, L.ptr(part), L.ptr(csr),
+                   L.ptr(ws), L.ptr(wl), 3, nw_h, T_h, d, H, L.ptr(tau), 0.01, L.stream())
+        else:
+            base = pb = 0
+            for nw, T in zip(n_win, (16, 32, 64)):
+                L.call("gdmae_window_attention_fwd", L.ptr(qk), L.ptr(v), L.ptr(out), 1, L.ptr(csr), L.ptr(ws[base:]), L.ptr(wl[base:]), nw, T,
+                       d, H, L.ptr(tau), 0.01, L.stream())
+                L.call("gdmae_window_attention_bwd", L.ptr(qk), L.ptr(v), L.ptr(go), L.ptr(dqk), L.ptr(dvv), 1, L.ptr(part[pb:]), L.ptr(csr),
+                       L.ptr(ws[base:]), L.ptr(wl[base:]), nw, T, d, H, L.ptr(tau), 0.01, L.stream())
+                base += nw
+                pb += nw * H
+        return out.float(), dqk.float(), dvv.float(), float(part.sum())
+
+    try:
+        ref = run(1, False)
+        for entry in (False, True):
+            got = run(0, entry)
+            for a, b, nm in zip(got[:3], ref[:3], ("out", "dqk", "dv")):
+                rel = float((a - b).norm() / b.norm())
+                assert rel < 6e-3, (nm, entry, rel)                       # bf16 output rounding is 4e-3 per element
+                assert float((a - b).abs().max()) <= 0.06 * float(b.abs().max()), (nm, entry)
+            assert abs(got[3] - ref[3]) <= 2e-2 * abs(ref[3]) + 1e-4, (entry, got[3], ref[3])
+    finally:
+        L.call("gdmae_set_attention_impl", 0)
+
+
 @pytest.mark.parametrize("P1,P2", [(16, 64), (16, 40), (8, 64), (24, 33)])
 def test_chamfer_matches_oracle(P1, P2):
     """(16, *) is the NUM_PRD_POINTS = 16 fast path (transposed-butterfly minima), the others the generic kernel."""
