@@ -6,6 +6,8 @@ for p in (REPO, os.path.join(REPO, "gd-mae_amd")):
     sys.path.insert(0, p)
 import torch
 from gdmae_hip import lib as L
+if os.environ.get("GDMAE_LIB"):          # kernel experiments: a variant library built next to the product one
+    L.LIB_PATH = os.path.abspath(os.environ["GDMAE_LIB"])
 
 dev = torch.device("cuda:0")
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 40960
