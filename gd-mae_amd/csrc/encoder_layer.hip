@@ -544,6 +544,8 @@ int gd_ln_partial_rows(long long n, int d);
 // fused token GEMMs (tok_gemm.hip)
 bool gd_tok_gemm_supported(int K, int N);
 int gd_tok_gemm_plain(hipStream_t st, const void* X, const void* Wp, const void* bias, long long n_pad, int K, int N, void* out);
+int gd_tok_gemm_qkv(hipStream_t st, const void* Xpos, const void* X, const void* Wp_qk, const void* Wp_v, const void* bias3,
+                    long long n_pad, int d, void* qk, void* v);
 int gd_tok_gemm_gelu(hipStream_t st, const void* X, const void* Wp, const void* bias, long long n_pad, int K, int N, void* h, void* gact);
 int gd_tok_gemm_gelu_bwd(hipStream_t st, const void* dY, const void* Wp, const void* h, long long n_pad, int K, int N, void* dh);
 int gd_tok_gemm_rows(int N);
@@ -645,8 +647,7 @@ static int layer_fwd(const gdmae_layer_args* a, const gdmae_layer_args* next, bo
   const bool fused = use_fused(a);
   const Packed pk = packed_layout(a->packed, d, ff);
   if (fused) {
-    GD_TRY(gd_tok_gemm_plain(c.st, s.xpb, pk.qk, bin, n_pad, d, 2 * d, s.qk));
-    GD_TRY(gd_tok_gemm_plain(c.st, s.xb, pk.v, bin + (size_t)2 * d * es, n_pad, d, d, s.v));
+    GD_TRY(gd_tok_gemm_qkv(c.st, s.xpb, s.xb, pk.qk, pk.v, bin, n_pad, d, s.qk, s.v));
   } else {
     GD_TRY(linear_fwd(c, s.xpb, Win, bin, s.qk, n_pad, 2 * d, d));
     GD_TRY(linear_fwd(c, s.xb, Win + (size_t)2 * d * d * es, bin + (size_t)2 * d * es, s.v, n_pad, d, d));

@@ -159,8 +159,11 @@ struct TgRows {
   static constexpr int value = ND >= 256 ? 32 : 64;
 };
 
+// One row tile.  tile: index of the tile (rows tile * ROWS ..); mbs: 32-channel blocks per k-step of the packed weight image
+// A.Wp points into (MB for a whole image, more when the workgroup owns a channel slice of a wider one); ldo: row pitch of out0
+// in elements (plain epilogue only)
 template <int KD, int ND, int EPI>
-__global__ __launch_bounds__(512, 4) void k_tok_gemm(TgArgs A) {
+__device__ __forceinline__ void tg_tile(const TgArgs& A, const long long tile, const int mbs, const int ldo) {
   constexpr int ROWS = TgRows<ND>::value;   // 4 waves per SIMD = two workgroups per CU: <= 128 VGPRs
   constexpr int KS = KD / 16;                       // k-steps
   constexpr int MB = ND / 32;                       // 32-channel blocks of the output
@@ -170,7 +173,7 @@ __global__ __launch_bounds__(512, 4) void k_tok_gemm(TgArgs A) {
   constexpr int SP = ND * 2 + 16;                   // LDS row pitch of the staging tile
   extern __shared__ __align__(16) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const long long row0 = (long long)blockIdx.x * ROWS;
+  const long long row0 = tile * ROWS;
 
   // ---- weight fragments of the first TG_PF k-steps: in flight while the activation tile is loaded
   const int mb0 = MB >= TG_WAVES ? wv : (wv >> 1);          // first channel block of this wavefront (then + TG_WAVES)
@@ -180,7 +183,7 @@ __global__ __launch_bounds__(512, 4) void k_tok_gemm(TgArgs A) {
 #pragma unroll
   for (int ks = 0; ks < TG_PF; ++ks)
 #pragma unroll
-    for (int j = 0; j < MPW; ++j) wr[ks][j].q = wp[((size_t)ks * MB + j * TG_WAVES) * 64];
+    for (int j = 0; j < MPW; ++j) wr[ks][j].q = wp[((size_t)ks * mbs + j * TG_WAVES) * 64];
 
   // ---- row-epilogue operands that do not depend on the product (residual rows, positional-table rows, GELU-backward
   //      pre-activations) are requested NOW: their latency hides behind the tile load and the K loop instead of being paid
@@ -246,7 +249,7 @@ __global__ __launch_bounds__(512, 4) void k_tok_gemm(TgArgs A) {
     for (int ks = 0; ks < KS; ++ks) {
       if (ks + TG_PF < KS) {
 #pragma unroll
-        for (int j = 0; j < MPW; ++j) wr[(ks + TG_PF) % (TG_PF + 1)][j].q = wp[((size_t)(ks + TG_PF) * MB + j * TG_WAVES) * 64];
+        for (int j = 0; j < MPW; ++j) wr[(ks + TG_PF) % (TG_PF + 1)][j].q = wp[((size_t)(ks + TG_PF) * mbs + j * TG_WAVES) * 64];
       }
       if (ks + 1 < KS) {
 #pragma unroll
@@ -400,7 +403,7 @@ __global__ __launch_bounds__(512, 4) void k_tok_gemm(TgArgs A) {
       float acc1 = 0.f;
 #pragma unroll
       for (int q = 0; q < RPP; ++q) acc1 += red[q * 3 * ND + c];
-      A.part[(long long)blockIdx.x * 3 * ND + c] = acc1;
+      A.part[tile * 3 * ND + c] = acc1;
     }
   } else {
     constexpr int CPR = ND / 8;
@@ -412,7 +415,7 @@ __global__ __launch_bounds__(512, 4) void k_tok_gemm(TgArgs A) {
       const long long e = (row0 + rl) * ND + c * 8;
       const uint4 q = *(const uint4*)(lds + rl * SP + c * 16);
       if (EPI == TG_PLAIN) {
-        *(uint4*)(A.out0 + e) = q;
+        *(uint4*)(A.out0 + (row0 + rl) * ldo + c * 8) = q;
       } else if (EPI == TG_GELU) {
         *(uint4*)(A.out0 + e) = q;
         float v[8];
@@ -431,6 +434,61 @@ __global__ __launch_bounds__(512, 4) void k_tok_gemm(TgArgs A) {
       }
     }
   }
+}
+
+template <int KD, int ND, int EPI>
+__global__ __launch_bounds__(512, 4) void k_tok_gemm(TgArgs A) {
+  tg_tile<KD, ND, EPI>(A, blockIdx.x, ND / 32, ND);
+}
+
+// Up to three plain products over the same row tiles in ONE launch (the q, k and v projections of a layer: q and k read the
+// same operand rows).  The jobs of a row tile are adjacent workgroups of one XCD, so the shared operand tile is read from
+// HBM once and from that XCD's L2 afterwards.
+struct TgJob {
+  const unsigned short* X;
+  const uint4* Wp;              // first fragment of this job's channel slice
+  const unsigned short* bias;   // of the slice, or null
+  unsigned short* out;          // first column of the slice
+  int mbs, ldo;
+};
+struct TgMulti {
+  TgJob j0, j1, j2;
+  int n_jobs;
+  long long tiles, n_pad;
+};
+
+template <int KD, int ND>
+__global__ __launch_bounds__(512, 4) void k_tok_gemm_multi(TgMulti M) {
+  const int xcd = blockIdx.x & 7, g = blockIdx.x >> 3;
+  const int job = g % M.n_jobs;
+  const long long tile = (long long)(g / M.n_jobs) * 8 + xcd;
+  if (tile >= M.tiles) return;
+  TgArgs A = {};
+  A.X = job == 0 ? M.j0.X : (job == 1 ? M.j1.X : M.j2.X);
+  A.Wp = job == 0 ? M.j0.Wp : (job == 1 ? M.j1.Wp : M.j2.Wp);
+  A.bias = job == 0 ? M.j0.bias : (job == 1 ? M.j1.bias : M.j2.bias);
+  A.out0 = job == 0 ? M.j0.out : (job == 1 ? M.j1.out : M.j2.out);
+  A.n = A.n_pad = M.n_pad;
+  const int mbs = job == 0 ? M.j0.mbs : (job == 1 ? M.j1.mbs : M.j2.mbs);
+  const int ldo = job == 0 ? M.j0.ldo : (job == 1 ? M.j1.ldo : M.j2.ldo);
+  tg_tile<KD, ND, TG_PLAIN>(A, tile, mbs, ldo);
+}
+
+template <int KD, int ND>
+static int tg_launch_multi(const TgMulti& M, hipStream_t st) {
+  constexpr int ROWS = TgRows<ND>::value;
+  constexpr int lds = ROWS * ((KD > ND ? KD : ND) * 2 + 16);
+  static bool once = false;
+  if (!once) {
+    GD_CHECK(hipFuncSetAttribute((const void*)k_tok_gemm_multi<KD, ND>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    once = true;
+  }
+  TgMulti A = M;
+  A.tiles = M.n_pad / ROWS;
+  const long long groups = (A.tiles + 7) / 8 * A.n_jobs;
+  hipLaunchKernelGGL((k_tok_gemm_multi<KD, ND>), dim3((unsigned)(groups * 8)), dim3(512), lds, st, A);
+  GD_LAUNCH_CHECK();
+  return 0;
 }
 
 template <int KD, int ND, int EPI>
@@ -474,6 +532,21 @@ int gd_tok_gemm_plain(hipStream_t st, const void* X, const void* Wp, const void*
   A.X = (const unsigned short*)X; A.Wp = (const uint4*)Wp; A.bias = (const unsigned short*)bias; A.n = n_pad; A.n_pad = n_pad;
   A.out0 = (unsigned short*)out;
   return tg_dispatch<TG_PLAIN>(K, N, A, st);
+}
+// q | k = (X + pos) Wqk^T + b (n_pad, 2d) and v = X Wv^T + b (n_pad, d) in one launch; Wqk packed as one (2d, d) image
+int gd_tok_gemm_qkv(hipStream_t st, const void* Xpos, const void* X, const void* Wp_qk, const void* Wp_v, const void* bias3,
+                    long long n_pad, int d, void* qk, void* v) {
+  TgMulti M = {};
+  const unsigned short* b = (const unsigned short*)bias3;
+  M.j0 = TgJob{(const unsigned short*)Xpos, (const uint4*)Wp_qk, b, (unsigned short*)qk, 2 * d / 32, 2 * d};
+  M.j1 = TgJob{(const unsigned short*)Xpos, (const uint4*)Wp_qk + (size_t)(d / 32) * 64, b ? b + d : nullptr, (unsigned short*)qk + d,
+               2 * d / 32, 2 * d};
+  M.j2 = TgJob{(const unsigned short*)X, (const uint4*)Wp_v, b ? b + 2 * d : nullptr, (unsigned short*)v, d / 32, d};
+  M.n_jobs = 3;
+  M.n_pad = n_pad;
+  if (d == 128) return tg_launch_multi<128, 128>(M, st);
+  if (d == 256) return tg_launch_multi<256, 256>(M, st);
+  GD_REQUIRE(false, "tok_gemm_qkv: unsupported width");
 }
 int gd_tok_gemm_gelu(hipStream_t st, const void* X, const void* Wp, const void* bias, long long n_pad, int K, int N, void* h, void* gact) {
   TgArgs A = {};

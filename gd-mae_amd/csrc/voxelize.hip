@@ -39,7 +39,7 @@ __device__ inline bool vox_coord(float p, float lo, float vs, int g, int& c) {
 }
 
 __global__ __launch_bounds__(256) void k_point_keys(const float* __restrict__ pts, long long n0, VoxParams P,
-                                                    int* __restrict__ key, int* __restrict__ cell_cnt) {
+                                                    int* __restrict__ key, int* __restrict__ slot, int* __restrict__ cell_cnt) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n0;
        i += (long long)gridDim.x * blockDim.x) {
     const float* r = pts + i * P.ncols;
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void k_point_keys(const float* __restrict__ pt
     if (ok) {
       int b = (int)bf;
       k = ((b * P.gz + cz) * P.gy + cy) * P.gx + cx;
-      atomicAdd(&cell_cnt[k], 1);
+      slot[i] = atomicAdd(&cell_cnt[k], 1);   // arrival slot inside the pillar's CSR segment: the fill pass needs no second atomic
     }
     key[i] = k;
   }
@@ -135,7 +135,7 @@ __global__ void k_vox_finalize(const unsigned long long* total, const int* n_kee
 __global__ __launch_bounds__(256) void k_point_fill(const float* __restrict__ pts, long long n0, VoxParams P,
                                                     const int* __restrict__ key, const int* __restrict__ pos,
                                                     const int* __restrict__ cell2pillar, const int* __restrict__ pt_off,
-                                                    int* __restrict__ cell_cnt, float* __restrict__ pts_out,
+                                                    const int* __restrict__ slot, float* __restrict__ pts_out,
                                                     long long* __restrict__ point_coords, long long* __restrict__ inverse,
                                                     int* __restrict__ inverse32, int* __restrict__ csr_raw) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n0;
@@ -144,8 +144,7 @@ __global__ __launch_bounds__(256) void k_point_fill(const float* __restrict__ pt
     if (k < 0) continue;
     int dst = pos[i];
     int p = cell2pillar[k];
-    int slot = atomicSub(&cell_cnt[k], 1) - 1;  // leaves the table zeroed for the next call
-    csr_raw[pt_off[p] + slot] = dst;
+    csr_raw[pt_off[p] + slot[i]] = dst;
     inverse[dst] = p;
     inverse32[dst] = p;
     const float* r = pts + i * P.ncols;
@@ -271,9 +270,9 @@ __global__ __launch_bounds__(256) void k_big_mean(const int* __restrict__ big, i
 extern "C" size_t gdmae_voxelize_workspace_bytes(long long n_points, int batch_size, int gx, int gy, int gz) {
   long long cells = (long long)batch_size * gx * gy * gz;
   size_t b = 0;
-  b += gd_align(sizeof(int) * cells);                               // cell_cnt (must be zero on entry)
+  b += gd_align(sizeof(int) * cells);                               // cell_cnt (zeroed at entry)
   b += gd_align(sizeof(int) * cells);                               // cell2pillar
-  b += gd_align(sizeof(int) * n_points) * 3;                        // key, pos, csr_raw
+  b += gd_align(sizeof(int) * n_points) * 4;                        // key, pos, csr_raw, slot
   b += gd_align(sizeof(unsigned long long) * gd_scan_ws_elems(cells > n_points ? cells : n_points));
   b += gd_align(sizeof(unsigned long long) * 2) + gd_align(sizeof(int) * 2);
   b += gd_align(sizeof(int) * (2 + 3 * (n_points / 32 + 2)));          // big-pillar work items
@@ -310,6 +309,7 @@ extern "C" int gdmae_voxelize(const float* points, long long n_points, int n_col
   int* key = A.take<int>(n_points);
   int* pos = A.take<int>(n_points);
   int* csr_raw = A.take<int>(n_points);
+  int* slot = A.take<int>(n_points);
   unsigned long long* scan_ws = A.take<unsigned long long>(gd_scan_ws_elems(cells > n_points ? cells : n_points));
   unsigned long long* total = A.take<unsigned long long>(2);
   int* n_keep = A.take<int>(2);
@@ -320,7 +320,7 @@ extern "C" int gdmae_voxelize(const float* points, long long n_points, int n_col
   GD_CHECK(hipMemsetAsync(big, 0, sizeof(int) * 2, st));
   const int grid_pts = n_points > 0 ? (gd_div_up(n_points, 256) < 4096 ? gd_div_up(n_points, 256) : 4096) : 1;
   if (n_points > 0) {
-    hipLaunchKernelGGL(k_point_keys, dim3(grid_pts), dim3(256), 0, st, points, n_points, P, key, cell_cnt);
+    hipLaunchKernelGGL(k_point_keys, dim3(grid_pts), dim3(256), 0, st, points, n_points, P, key, slot, cell_cnt);
     GD_LAUNCH_CHECK();
   }
   {
@@ -337,7 +337,7 @@ extern "C" int gdmae_voxelize(const float* points, long long n_points, int n_col
   GD_LAUNCH_CHECK();
   if (n_points > 0) {
     hipLaunchKernelGGL(k_point_fill, dim3(grid_pts), dim3(256), 0, st, points, n_points, P, key, pos, cell2pillar,
-                       pillar_pt_off, cell_cnt, points_out, point_coords, inverse, inverse32, csr_raw);
+                       pillar_pt_off, slot, points_out, point_coords, inverse, inverse32, csr_raw);
     GD_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_pillar_sort_mean, dim3(4096), dim3(256), 0, st, counts, pillar_pt_off, csr_raw, pillar_pts,
                        point_rank, points_out, n_cols, pillar_mean);
