@@ -21,4 +21,5 @@ bash /root/repo/tools/pmc_kernels.sh $OUT/${TAG}_pmc_sq_mfma_kernels.csv "k_conv
   "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA" \
   "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS"
 python /root/repo/tools/class_shares.py $OUT/${TAG}_step_trace.csv $OUT/class_shares.json "profiles/${TAG}_step_trace.csv (rocprofv3 --kernel-trace of bench.py, one optimizer step incl. the side-stream geometry plan of the next batch)"
+python /root/repo/tools/step_traffic.py $OUT $TAG > $OUT/${TAG}_step_traffic.json
 ls -la $OUT
