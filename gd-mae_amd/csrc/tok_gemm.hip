@@ -583,6 +583,12 @@ int gd_tok_gemm_ln_bwd(hipStream_t st, const void* X, const void* Wp, long long 
   A.stats = const_cast<float*>(stats); A.gamma = gamma; A.y = dx; A.y_bf = (unsigned short*)dx_bf; A.part = part;
   return tg_dispatch<TG_LN_BWD>(K, N, A, st);
 }
+extern "C" int gdmae_tok_gemm_qkv(const void* Xpos, const void* X, const void* Wp_qk, const void* Wp_v, const void* bias3, long long n_pad,
+                                  int d, void* qk, void* v, void* stream) {
+  GD_REQUIRE(n_pad > 0 && n_pad % TG_ROWS == 0, "tok_gemm: rows must be padded to a multiple of 64");
+  GD_REQUIRE(d == 128 || d == 256, "tok_gemm_qkv: d must be 128 or 256");
+  return gd_tok_gemm_qkv((hipStream_t)stream, Xpos, X, Wp_qk, Wp_v, bias3, n_pad, d, qk, v);
+}
 extern "C" int gdmae_tok_gemm_ln_bwd_rows(int N) { return gd_tok_gemm_rows(N); }
 extern "C" int gdmae_tok_gemm_ln_bwd(const void* X, const void* Wp, long long n, long long n_pad, int K, int N, const float* dy,
                                      const void* dy2_bf16, const float* ln_a, const void* ln_b_bf16, const float* stats,

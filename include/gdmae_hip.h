@@ -462,6 +462,13 @@ int gdmae_tok_gemm(const void* X, const void* Wp, const void* bias, long long n,
                    float* y, float* stats, void* y_bf16, const float* pos_table, const int* tok_pos, void* ypos_bf16,
                    void* stream);
 
+/* The packed in-projection of cosine_msa.py / sst_basic_block.py:22-54 (q = k = x + pos, v = x) as ONE launch of three plain
+ * products over shared row tiles:  qk (n_pad, 2d) = Xpos Wqk^T + bias3[0:2d],  v (n_pad, d) = X Wv^T + bias3[2d:3d];
+ * Wp_qk = packed (2d, d) image of in_proj_weight[0:2d], Wp_v = packed (d, d) image of in_proj_weight[2d:3d], bias3 (3d) bf16
+ * or NULL, d in {128, 256}.  Bit-identical to two gdmae_tok_gemm calls with epilogue 0. */
+int gdmae_tok_gemm_qkv(const void* Xpos, const void* X, const void* Wp_qk, const void* Wp_v, const void* bias3, long long n_pad,
+                       int d, void* qk, void* v, void* stream);
+
 /* Input-gradient token GEMM fused with the backward of the post-norm it feeds (tok_gemm.hip, epilogue LN_BWD; backward of
  * sst_basic_block.py:57-84 `src = norm(src + dropout(src2))`):  g = dy + [dy2] + bf16(X Wp^T) is the gradient of
  * LN(ln_a + ln_b); dx (n, N) fp32 and its optional bf16 copy dx_bf16 (n_pad, N) are the LayerNorm backward of g with the

@@ -1110,6 +1110,33 @@ def _pack_weight(w, transpose=False):
     return dst
 
 
+@pytest.mark.parametrize("d,with_bias", [(128, True), (256, True), (256, False)])
+def test_tok_gemm_qkv_is_bit_identical_to_separate_products(d, with_bias):
+    """gdmae_tok_gemm_qkv (q, k and v projections of a layer as three jobs of one launch, the k half addressed inside the
+    packed (2d, d) image) against two gdmae_tok_gemm calls with the plain epilogue: same k order per output element ->
+    identical bits; row counts that are / are not a multiple of 8 tiles (the launch pads its grid to whole XCD groups)."""
+    from gdmae_hip import lib as L
+    d_ = dev()
+    g = torch.Generator().manual_seed(31 * d + int(with_bias))
+    for n_pad in (64, 1024, 1984):
+        X = torch.randn(n_pad, d, generator=g).bfloat16().to(d_)
+        Xp = (X.float().cpu() + torch.randn(n_pad, d, generator=g)).bfloat16().to(d_)
+        Win = (torch.randn(3 * d, d, generator=g) / d ** 0.5).to(d_)
+        b3 = torch.randn(3 * d, generator=g).bfloat16().to(d_) if with_bias else None
+        Wp_qk, Wp_v = _pack_weight(Win[:2 * d].contiguous()), _pack_weight(Win[2 * d:].contiguous())
+        qk, v = (torch.full((n_pad, 2 * d), 7.0, dtype=torch.bfloat16, device=d_), torch.full((n_pad, d), 7.0, dtype=torch.bfloat16, device=d_))
+        L.call("gdmae_tok_gemm_qkv", L.ptr(Xp), L.ptr(X), L.ptr(Wp_qk), L.ptr(Wp_v), L.ptr(b3), n_pad, d, L.ptr(qk), L.ptr(v), L.stream())
+        qk_ref, v_ref = torch.empty_like(qk), torch.empty_like(v)
+        for Xi, Wp, b, N, out in ((Xp, Wp_qk, b3[:2 * d] if with_bias else None, 2 * d, qk_ref), (X, Wp_v, b3[2 * d:] if with_bias else None, d, v_ref)):
+            L.call("gdmae_tok_gemm", L.ptr(Xi), L.ptr(Wp), L.ptr(b), n_pad, n_pad, d, N, 0, L.ptr(out), None, None, None, None, None, 1e-5,
+                   None, None, None, None, None, None, L.stream())
+        torch.cuda.synchronize()
+        assert torch.equal(qk.view(torch.int16), qk_ref.view(torch.int16)), (d, n_pad)
+        assert torch.equal(v.view(torch.int16), v_ref.view(torch.int16)), (d, n_pad)
+        ref = Xp.float() @ Win[:2 * d].bfloat16().float().t() + (b3[:2 * d].float() if with_bias else 0.0)
+        assert float((qk.float() - ref).abs().max()) < 0.05 * float(ref.abs().max())
+
+
 @pytest.mark.parametrize("K,N", [(128, 128), (128, 256), (256, 128), (256, 256), (256, 512), (512, 256)])
 def test_tok_gemm_epilogues_match_torch(K, N):
     """gdmae_tok_gemm (bf16 MFMA token GEMM with fused row epilogues) against torch on the same bf16-rounded operands:
