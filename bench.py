@@ -7,9 +7,16 @@ gradient all-reduce, global-norm clip, fused Adam) on synthetic Waymo-shape clou
         bench.py --gpus N --steps K --warmup W
 
 One process per GPU; frames are sharded across ranks (weak scaling: --batch-per-gpu frames each), the only
-collective is one all-reduce of the flat 32 MB gradient buffer per step (RCCL over xGMI).  Rank 0 prints
-ONE JSON line.  Inputs are resident in HBM when the timed region starts (the PCIe-inclusive rate is
-reported separately under "h2d_inclusive").
+collective is the bucketed all-reduce of the flat 32 MB gradient buffer, launched from inside backward (RCCL over
+xGMI).  Rank 0 prints ONE JSON line.
+
+Timed region: the batch of step t is resident in HBM when step t starts - its host-to-device copy
+was issued on a copy stream during step t - 1, the way a pin_memory data loader feeds the reference - so every
+batch consumed after the first one is copied INSIDE the timed region, overlapped with compute.  The same loop fed
+from batches that never leave HBM is reported under also.resident_inputs.
+
+Defaults: N = 1 -> BASELINE config B (8 frames per GPU, the reference yaml's BATCH_SIZE_PER_GPU); N > 1 -> BASELINE
+config C (global batch 32 on 8 GPUs = 4 frames per GPU, also used for its 2 / 4 GPU scaling points).
 """
 from __future__ import annotations
 
@@ -40,14 +47,16 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch-per-gpu", type=int, default=8, help="frames per GPU per step (gd_mae_ssl.yaml:184)")
-    ap.add_argument("--config", default="B", choices=["A", "B", "E"])
+    ap.add_argument("--batch-per-gpu", type=int, default=None,
+                    help="frames per GPU per step; default 8 at N = 1 (config B, gd_mae_ssl.yaml:184), 4 at N > 1 (config C)")
+    ap.add_argument("--config", default="B", choices=["A", "B", "D", "E"])
     ap.add_argument("--mask-ratio", type=float, default=0.75)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--pool", type=int, default=3, help="distinct pre-generated batches cycled through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--no-also", action="store_true", help="skip the extra fp32 / mask-0.85 / H2D-inclusive legs")
+    ap.add_argument("--no-also", action="store_true", help="skip the extra legs (resident inputs, fp32, mask 0.85, configs D / E, config-C batch)")
+    ap.add_argument("--feed", default="h2d", choices=["h2d", "resident"], help="h2d: every batch copied from pinned host memory inside the timed region")
     ap.add_argument("--prefetch", type=int, default=1, help="1: build the geometry plan of batch t+1 on a side stream")
     ap.add_argument("--miopen-find", type=int, default=1, help="1: torch.backends.cudnn.benchmark (MIOpen find mode)")
     return ap.parse_args()
@@ -128,70 +137,66 @@ def _pmc_traffic(kernels):
     return None, None
 
 
-# instrumented entry points (gdmae_hip.timing brackets): what bounds them and which device kernels they launch
+# instrumented kernel families: roofline that bounds them and the device kernels behind them.  Every family is timed with HIP
+# events on the launch stream ON THE PRODUCT PATH: the encoder families by brackets inside the native layer / stage executors
+# (include/gdmae_hip.h gdmae_kernel_timing), the decoder kernels by brackets around their single C-ABI call (gdmae_hip.timing)
 ROOFLINE_KERNELS = {
+    "k_tok_gemm": ("hbm", ("k_tok_gemm", "k_tok_gemm_multi", "k_ffn_fwd", "k_ffn_bwd")),
+    "k_dw_grouped": ("hbm", ("k_dw_grouped",)),
+    "k_layer_tail": ("hbm", ("k_layer_tail",)),
     "k_conv3x3_tiles": ("mfma", ("k_conv3x3_tiles",)),
     "k_conv_grad_taps": ("hbm", ("k_conv_grad_taps",)),
+    "k_dec_conv_bwd": ("hbm", ("k_dec_conv_bwd",)),
+    "k_spconv_fwd": ("hbm", ("k_spconv_fwd",)),
+    "k_spconv_bwd": ("hbm", ("k_spconv_bwd",)),
     "k_win_attn_bwd": ("hbm", ("k_win_attn_bwd", "k_attn_mfma_bwd", "k_attn_t16_bwd", "k_attn_t32_bwd", "k_attn_t64_bwd")),
     "k_win_attn_fwd": ("hbm", ("k_win_attn_fwd", "k_attn_mfma_fwd", "k_attn_t16_fwd", "k_attn_t32_fwd", "k_attn_t64_fwd")),
 }
 
 
-def _attention_product_timing(step, dev_batches, args, n_steps):
-    """{entry: summary} of the forward / backward all-levels attention entries over `n_steps` product-path steps: HIP events
-    recorded by the library around the calls (include/gdmae_hip.h gdmae_attention_timing), algorithmic bytes from the plans of
-    those steps (tokens x (4 | 7) x d x 2 B + CSR, per layer: every stage runs 2 layers on each of its 2 window shifts)."""
+def _library_slots():
+    """{family: summary} of the measurement slots of libgdmae_hip.so (brackets inside the native executors)."""
     import ctypes as C
     from gdmae_hip import lib as L
-    if not hasattr(L.load(), "gdmae_attention_timing"):
-        return None
-    L.call("gdmae_attention_timing", 1)
-    by = {"k_win_attn_fwd": 0.0, "k_win_attn_bwd": 0.0}
-    try:
-        for i in range(n_steps):
-            _, bd = step(args.warmup + args.steps, dev_batches[i % args.pool])
-            plan = bd["_gdmae_plan"]
-            for st, dm in zip(plan.stages, bd["_gdmae_dims"]):
-                for w in st.windows:
-                    for lvl, nw in enumerate(w.n_win):
-                        if nw > 0:
-                            by["k_win_attn_fwd"] += 2 * (w.n_tok[lvl] * (4 * dm * 2 + 4) + 8 * nw)
-                            by["k_win_attn_bwd"] += 2 * (w.n_tok[lvl] * (7 * dm * 2 + 4) + 8 * nw)
-        torch.cuda.synchronize()
-        out = {}
-        for which, name in ((0, "k_win_attn_fwd"), (1, "k_win_attn_bwd")):
-            ms, calls = C.c_double(0.0), C.c_longlong(0)
-            L.call("gdmae_attention_timing_read", which, C.byref(ms), C.byref(calls))
-            if calls.value:
-                out[name] = {"launches": calls.value, "total_ms": ms.value, "avg_us": 1e3 * ms.value / calls.value,
-                             "bytes_per_launch": by[name] / calls.value, "total_bytes": by[name], "flops_per_launch": 0.0,
-                             "total_flops": 0.0, "extra": {"timed": "product path: one call per layer = all occupancy levels"}}
-        return out
-    finally:
-        L.call("gdmae_attention_timing", 0)
+    lib = L.load()
+    out = {}
+    for slot in range(lib.gdmae_kernel_timing_slots()):
+        name = lib.gdmae_kernel_timing_name(slot).decode()
+        if not name:
+            continue
+        ms, calls, by, fl = C.c_double(0.0), C.c_longlong(0), C.c_double(0.0), C.c_double(0.0)
+        L.call("gdmae_kernel_timing_read", slot, C.byref(ms), C.byref(calls), C.byref(by), C.byref(fl))
+        if calls.value:
+            out[name] = {"launches": calls.value, "total_ms": ms.value, "avg_us": 1e3 * ms.value / calls.value,
+                         "bytes_per_launch": by.value / calls.value, "total_bytes": by.value,
+                         "flops_per_launch": fl.value / calls.value, "total_flops": fl.value, "extra": {}}
+    return out
 
 
-def measure_roofline(step, dev_batches, args, n_steps=4):
-    """HIP-event timing (events on the launch stream) of the instrumented hand-written kernels over `n_steps` extra steps
-    after the timed region; `roofline` describes the one with the LARGEST TOTAL TIME in this run, the others are listed
-    under "also".  Algorithmic work per launch:
+def measure_roofline(step, feed, n_steps=4):
+    """HIP-event timing (events on the launch stream) of the instrumented kernel families over `n_steps` extra steps of the
+    PRODUCT path after the timed region; `roofline` describes the family with the LARGEST TOTAL TIME in this run (the
+    dominant kernel), the others are listed under "also".  Algorithmic work per launch:
+      k_tok_gemm        every fused token-GEMM launch of the encoder (k_tok_gemm, k_tok_gemm_multi): operand rows read once,
+                        result rows written once, the packed weight image once - summed per launch inside the library
+      k_dw_grouped      rows x (M + N) x 2 B per weight gradient + the fp32 partial tiles
       k_conv3x3_tiles   executed MFMA flops = active tiles x 64 sites x 128 channels x (9 x Cin) x 2   (bound: bf16 MFMA);
                         the dense convolution of SURVEY section 8d would be B x H x W sites - reported as dense_equivalent
       k_conv_grad_taps  active sites x 9 taps x 128 channels x 2 B read + written
       k_win_attn_*      tokens x (7 | 4) x d x elem + CSR bytes (q, k, v, dOut rows read, dq, dk, dv rows written, once each);
                         one "launch" = one call of the all-levels entry (a layer's T = 16 launch + its T = 32 / 64 launch)
     `traffic` = HBM bytes per launch from this round's committed rocprofv3 PMC passes (profiles/, see _pmc_traffic)."""
+    from gdmae_hip import lib as L
     from gdmae_hip import timing
-    with timing.collect() as T:
-        for i in range(n_steps):
-            step(args.warmup + args.steps, dev_batches[i % args.pool])
-        summ = T.summary()
+    L.call("gdmae_kernel_timing", 1)
+    try:
+        with timing.collect() as T:
+            feed(n_steps)
+            summ = T.summary()
+        summ.update(_library_slots())
+    finally:
+        L.call("gdmae_kernel_timing", 0)
     summ = {k: v for k, v in summ.items() if k in ROOFLINE_KERNELS and v["total_ms"] > 0}
-    # the attention entry points are timed on the PRODUCT path (the per-operator path above launches every occupancy level on its
-    # own; the layer executor issues a layer's levels through gdmae_window_attention_levels_*, bracketed with HIP events there)
-    prod = _attention_product_timing(step, dev_batches, args, n_steps)
-    if prod:
-        summ.update(prod)
     if not summ:
         return None
 
@@ -215,10 +220,138 @@ def measure_roofline(step, dev_batches, args, n_steps=4):
 
     top = max(summ, key=lambda k: summ[k]["total_ms"])
     out, devk = describe(top, summ[top])
+    out["timed"] = "HIP events on the launch stream, product path (native stage executor), %d steps after the timed region" % n_steps
     out["traffic"], src = _pmc_traffic(devk)
     if src:
         out["traffic_source"] = src + " (2 x FETCH_SIZE + WRITE_SIZE per launch, committed rocprofv3 --pmc passes of this command)"
     out["also"] = {n: describe(n, v)[0] for n, v in summ.items() if n != top}
+    return out
+
+
+WORKLOADS = {
+    "A": "config A: synthetic KITTI-shape 20k-pt clouds, 0.32 m pillars, 2-layer SRA encoder d=128 + generative decoder",
+    "B": "config B: synthetic Waymo-shape clouds ~180k pts x5 feat, 0.32 m pillars (468x468), GD-MAE SRA encoder 128/256/256 x12 "
+         "layers + generative decoder",
+    "C": "config C: config B at global batch 32 on 8 GPUs = 4 frames per GPU (same per-GPU batch at 1/2/4 GPUs for the scaling "
+         "curve), DDP-style bucketed RCCL gradient all-reduce overlapped with backward",
+    "D": "config D: synthetic KITTI-shape 20k-pt clouds, 0.16 m pillars (432x496), fine-tune step SPTBackbone + SSTBEVBackbone + "
+         "CenterHead (CenterPoint), synthetic boxes",
+    "E": "config E: synthetic ONCE-shape 60k-pt clouds, 0.32 m pillars, 6-layer SRA d=256 + generative decoder",
+}
+
+
+class Workload:
+    """One model + optimizer + pool of pinned host batches, and the training step over them."""
+
+    def __init__(self, args, config, B, dev, rank, world, mask_ratio, total_steps, pool):
+        from gdmae_hip import configs, optim, synth
+        from pcdet.models import build_network
+        self.args, self.config, self.B, self.dev, self.world = args, config, B, dev, world
+        cfg, ds, skw = configs.named_config(config, mask_ratio=mask_ratio)
+        self.cfg, self.ds = cfg, ds
+        torch.manual_seed(1234)                       # identical initial weights on every rank
+        net = build_network(cfg, len(ds.class_names), ds, logging.getLogger("bench")).to(dev).train()
+        net.sync_loss_scalar = False                  # keep the loss on the device: no per-step host sync
+        self.mae = hasattr(net.backbone_3d, "prefetch_plan")
+        if self.mae:
+            net.backbone_3d.dense_spatial_features = False   # the step only consumes decoder rows at the pillar sites
+        self.net = net
+        self.opt = optim.FlatAdamOneCycle(net, configs.optimization_cfg(B), total_steps=total_steps)
+        # synthetic frames: frame f of rank r uses seed 100000 * r + 97 * k; pool of distinct batches in pinned host memory
+        self.pool = pool
+        host = [synth.synth_batch(100000 * rank + 97 * k, B, ds.point_cloud_range, **skw) for k in range(pool)]
+        self.pinned = [torch.from_numpy(b).pin_memory() for b in host]
+        self.gt = None
+        if not self.mae:                              # fine-tune step: synthetic ground-truth boxes (same recipe as the tests)
+            rng = np.random.default_rng(5 + rank)
+            self.gt = [torch.from_numpy(_synth_boxes(rng, B, 40, np.asarray(ds.point_cloud_range), len(ds.class_names))).to(dev)
+                       for _ in range(pool)]
+        self.resident = [p.to(dev, non_blocking=True) for p in self.pinned]
+        torch.cuda.synchronize()
+        self.mode = {"bf16": args.dtype == "bf16"}
+        self.pending = {}
+        self.copy_stream = torch.cuda.Stream(device=dev)
+        self.stage_dims = [int(b.ENCODER.D_MODEL) for b in cfg.BACKBONE_3D.SST_BLOCK_LIST]
+        self.last = None
+        self.advance = True           # False: every further step uses the same schedule position (extra legs after the timed region)
+
+    def step(self, i, pts, nxt=None, k=0, nxt_ready=None):
+        net, opt, B = self.net, self.opt, self.B
+        opt.zero_grad()
+        bd = {"points": pts, "batch_size": B, "_gdmae_grad_sync": opt.sync, "_gdmae_dims": self.stage_dims}
+        if self.gt is not None:
+            bd["gt_boxes"] = self.gt[k % self.pool]
+        pf = None
+        if self.mae and self.args.prefetch:
+            plan = self.pending.pop(id(pts), None) or net.backbone_3d.prefetch_plan(pts, B).finish()
+            bd["_gdmae_vox"], bd["_gdmae_plan"] = plan
+            if nxt is not None:
+                # geometry plan of the NEXT batch: issued at the start of the step on a side stream that is ordered after the
+                # work queued so far (incl. the wait for that batch's copy) - its ~100 small kernels run under this step's
+                # forward and are complete long before the host asks for them at the end of the step
+                pf = net.backbone_3d.prefetch_plan(nxt, B, ready=nxt_ready)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.mode["bf16"]):
+            ret, tb, _ = net(bd)
+        ret["loss"].backward()
+        opt.all_reduce_grads()
+        opt.step(i)
+        if pf is not None:
+            # ... and collected here, still behind the queued backward / optimizer kernels: the host-side part of the plan
+            # (counts to Python ints, ~300 tensor views) is off the next step's critical path, like a data-loader batch
+            # that is ready before it is asked for
+            self.pending[id(nxt)] = pf.finish()
+        self.last = (ret["loss"], bd)
+        return ret["loss"], bd
+
+    # ---- feeds: run n steps
+    def _fetch(self, j):
+        """H2D copy of pooled batch j on the copy stream (DMA next to the compute of the previous batch)."""
+        with torch.cuda.stream(self.copy_stream):
+            t = self.pinned[j % self.pool].to(self.dev, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.copy_stream)
+        return t, ev
+
+    def prime(self):
+        """Batch 0 of an h2d feed: copied BEFORE the timed region (inputs of the first step are resident when it starts)."""
+        self._primed = self._fetch(0)
+        self._primed[1].synchronize()
+
+    def feed_h2d(self, n, i0=0):
+        nxt, nev = getattr(self, "_primed", None) or self._fetch(0)
+        self._primed = None
+        main = torch.cuda.current_stream()
+        for i in range(n):
+            cur, cev = nxt, nev
+            main.wait_event(cev)
+            cur.record_stream(main)
+            # the next batch's copy: inside the timed region, overlapped with this step (the plan stream waits for its event)
+            nxt, nev = self._fetch(i + 1) if i + 1 < n else (None, None)
+            self.step(i0 + (i if self.advance else 0), cur, nxt, k=i, nxt_ready=nev)
+
+    def feed_resident(self, n, i0=0):
+        r = self.resident
+        for i in range(n):
+            self.step(i0 + (i if self.advance else 0), r[i % self.pool], r[(i + 1) % self.pool] if i + 1 < n else None, k=i)
+
+    def feed(self, n, i0=0):
+        (self.feed_h2d if self.args.feed == "h2d" else self.feed_resident)(n, i0)
+
+
+def _synth_boxes(rng, B, n_max, pcr, n_class):
+    """(B, n_max, 8) ground-truth boxes [x, y, z, dx, dy, dz, heading, class] with trailing zero rows (fine-tune legs)."""
+    out = np.zeros((B, n_max, 8), dtype=np.float32)
+    size = {1: (4.2, 1.8, 1.6), 2: (0.8, 0.7, 1.7), 3: (1.8, 0.7, 1.6)}
+    for b in range(B):
+        n = int(rng.integers(n_max // 2, n_max - 1))
+        out[b, :n, 0] = rng.uniform(pcr[0] + 1, pcr[3] - 1, n)
+        out[b, :n, 1] = rng.uniform(pcr[1] + 1, pcr[4] - 1, n)
+        out[b, :n, 2] = rng.uniform(-1.5, 0.5, n)
+        cls = rng.integers(1, n_class + 1, n)
+        for i in range(n):
+            out[b, i, 3:6] = np.array(size[min(int(cls[i]), 3)]) * rng.uniform(0.8, 1.3, 3)
+        out[b, :n, 6] = rng.uniform(-np.pi, np.pi, n)
+        out[b, :n, 7] = cls
     return out
 
 
@@ -245,57 +378,20 @@ def main():
         torch.cuda.synchronize()
         assert int(warm.item()) == world
 
-    from gdmae_hip import configs, optim, synth
-    from pcdet.models import build_network
-
-    cfg, ds, skw = configs.named_config(args.config, mask_ratio=args.mask_ratio)
-    torch.manual_seed(1234)                       # identical initial weights on every rank
-    net = build_network(cfg, len(ds.class_names), ds, logging.getLogger("bench")).to(dev).train()
-    net.sync_loss_scalar = False                  # keep the loss on the device: no per-step host sync
-    net.backbone_3d.dense_spatial_features = False   # the step only consumes decoder rows at the pillar sites
-    total_steps = args.warmup + args.steps + 1
-    opt = optim.FlatAdamOneCycle(net, configs.optimization_cfg(args.batch_per_gpu), total_steps=total_steps)
-    n_params = opt.n
-
-    # synthetic frames: frame f of rank r uses seed 1000 * r + f; pool of distinct batches, resident in HBM
+    # BASELINE config B at N = 1 (8 frames per GPU); config C (4 frames per GPU, global batch 32 at N = 8) at N > 1
+    explicit_batch = args.batch_per_gpu is not None
+    if args.batch_per_gpu is None:
+        args.batch_per_gpu = 8 if world == 1 else 4
     B = args.batch_per_gpu
+    named = args.config
+    if args.config == "B" and world > 1 and B == 4:
+        named = "C"
     # every pooled batch must pass through the untimed warmup once (first-use GEMM algorithm timing, MIOpen find)
     args.pool = max(1, min(args.pool, args.warmup))
-    host_batches = [synth.synth_batch(100000 * rank + 97 * k, B, ds.point_cloud_range, **skw) for k in range(args.pool)]
-    pinned = [torch.from_numpy(b).pin_memory() for b in host_batches]
-    dev_batches = [p.to(dev, non_blocking=True) for p in pinned]
-    resident = torch.cuda.Event()
-    resident.record()                              # every pooled batch is in HBM once this event has completed
-    torch.cuda.synchronize()
-    mode = {"bf16": args.dtype == "bf16"}
-    use_bf16 = mode["bf16"]
-
-    pending = {}
-    stage_dims = [int(b.ENCODER.D_MODEL) for b in cfg.BACKBONE_3D.SST_BLOCK_LIST]
-
-    def step(i, pts, nxt=None, nxt_ready=None):
-        opt.zero_grad()
-        bd = {"points": pts, "batch_size": B, "_gdmae_grad_sync": opt.sync, "_gdmae_dims": stage_dims}
-        if args.prefetch:
-            plan = pending.pop(id(pts), None) or net.backbone_3d.prefetch_plan(pts, B).finish()
-            bd["_gdmae_vox"], bd["_gdmae_plan"] = plan
-        pf = None
-        if args.prefetch and nxt is not None:
-            # geometry plan of the NEXT batch: issued at the start of the step on a side stream that is ordered after the work
-            # queued so far (the previous step) - its ~100 small kernels run under this step's forward and are complete long
-            # before the host asks for them at the end of the step
-            pf = net.backbone_3d.prefetch_plan(nxt, B, ready=nxt_ready)
-        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=mode["bf16"]):
-            ret, tb, _ = net(bd)
-        ret["loss"].backward()
-        opt.all_reduce_grads()
-        opt.step(i)
-        if pf is not None:
-            # ... and collected here, still behind the queued backward / optimizer kernels: the host-side part of the plan
-            # (counts to Python ints, ~300 tensor views) is off the next step's critical path, like a data-loader batch
-            # that is ready before it is asked for
-            pending[id(nxt)] = pf.finish()
-        return ret["loss"], bd
+    total_steps = args.warmup + args.steps + 1
+    wl = Workload(args, args.config, B, dev, rank, world, args.mask_ratio, total_steps, args.pool)
+    n_params = wl.opt.n
+    use_bf16 = wl.mode["bf16"]
 
     def sync_all():
         torch.cuda.synchronize()
@@ -303,13 +399,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        loss, bd = step(i, dev_batches[i % args.pool], dev_batches[(i + 1) % args.pool] if i + 1 < args.warmup else None, resident)
+    wl.feed(args.warmup, 0)
+    if args.feed == "h2d":
+        wl.prime()                                  # the first timed step's batch is resident when the clock starts
     sync_all()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        loss, bd = step(args.warmup + i, dev_batches[i % args.pool], dev_batches[(i + 1) % args.pool] if i + 1 < args.steps else None,
-                        resident)
+    wl.feed(args.steps, args.warmup)
     sync_all()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -318,93 +413,101 @@ def main():
     dt = float(tmax.item())
     frames = B * world * args.steps
     fps = frames / dt
+    wl.advance = False
+    loss, bd = wl.last
     final_loss = float(loss.detach())
     assert np.isfinite(final_loss), "training diverged"
 
-    out = {"metric": "MAE pre-train frames/sec (Waymo-shape, 180k pts, 75% mask)", "value": round(fps, 2),
+    pre = args.config in ("A", "B", "E")
+    out = {"metric": "MAE pre-train frames/sec (Waymo-shape, 180k pts, 75% mask)" if pre else "fine-tune frames/sec (KITTI-shape, CenterPoint head)",
+           "value": round(fps, 2),
            "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-           "config": {"workload": f"config {args.config}: synthetic Waymo-shape clouds ~180k pts x5 feat, 0.32 m pillars (468x468), "
-                                  f"GD-MAE SRA encoder 128/256/256 x12 layers + generative decoder, mask {args.mask_ratio}, "
-                                  f"full train step (fwd+bwd+grad all-reduce+clip+Adam)" if args.config == "B" else f"config {args.config}",
+           "config": {"workload": WORKLOADS[named] + (f", mask {args.mask_ratio}" if pre else "") +
+                                  ", full train step (H2D of the next batch + fwd + bwd + grad all-reduce + clip + Adam)",
                       "frames_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
-                      "params": n_params, "mask_ratio": args.mask_ratio, "loss_last": round(final_loss, 5)}}
+                      "params": n_params, "mask_ratio": args.mask_ratio if pre else None, "loss_last": round(final_loss, 5),
+                      "inputs": ("pinned host batches; batch t+1 copied on a copy stream during step t (inside the timed region), "
+                                 "batch 0 resident when the clock starts" if args.feed == "h2d" else "resident in HBM"),
+                      "outputs_skipped": ["batch_dict['spatial_features'] dense (B,128,Y,X) map - the pre-training step consumes the "
+                                          "decoder only at the pillar sites (SPTBackboneMAE.dense_spatial_features = False)"] if wl.mae else [],
+                      "parity_bound": ("bf16 throughput mode: voxel indices / token masks / window partition bit-exact vs the oracle; loss "
+                                       "within 1 %, per-parameter gradient norm within 10 % and cosine >= 0.97 of the fp32 parity mode "
+                                       "(tests/test_full_size_properties.py), which itself is held to loss 1e-4 rel of the reference "
+                                       "(also.fp32_parity_mode is that mode's throughput)") if use_bf16 else
+                                      "fp32 parity mode: bit-exact indices / masks, Chamfer loss within 1e-4 rel of the reference"}}
 
     # the roofline steps run on EVERY rank: they contain the gradient all-reduce, a collective the other ranks must join
-    roofline = measure_roofline(step, dev_batches, args) if not args.no_roofline else None
-    vox, ep = bd["_gdmae_vox"], bd["_gdmae_plan"]
+    roofline = measure_roofline(wl.step, lambda n: wl.feed(n, total_steps - 1), 4) if (not args.no_roofline and wl.mae) else None
+    loss, bd = wl.last
+    vox, ep = bd.get("_gdmae_vox"), bd.get("_gdmae_plan")
 
-    def timed_leg(n_warm, n_timed, feed=None):
+    def timed_leg(w, n_warm, n_timed, feed=None):
         """frames/s of `n_timed` more steps after `n_warm` untimed ones (single process; used for the extra legs)."""
-        pending.clear()
-        for i in range(n_warm):
-            step(args.warmup + args.steps, dev_batches[i % args.pool])
+        w.pending.clear()
+        f = feed or w.feed
+        f(n_warm, total_steps - 1)
+        if f == w.feed_h2d or (feed is None and w.args.feed == "h2d"):
+            w.prime()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        if feed is None:
-            for i in range(n_timed):
-                step(args.warmup + args.steps, dev_batches[i % args.pool],
-                     dev_batches[(i + 1) % args.pool] if i + 1 < n_timed else None, resident)
-        else:
-            feed(n_timed)
+        f(n_timed, total_steps - 1)
         torch.cuda.synchronize()
         dtl = time.perf_counter() - t1
-        return {"value": round(B * n_timed / dtl, 2), "unit": "frames/s", "ms_per_step": round(1e3 * dtl / n_timed, 3), "steps": n_timed}
+        return {"value": round(w.B * n_timed / dtl, 2), "unit": "frames/s", "ms_per_step": round(1e3 * dtl / n_timed, 3), "steps": n_timed,
+                "frames_per_gpu": w.B}
 
     also = {}
-    if world == 1 and not args.no_also:
-        # ---- SURVEY section 8d step incl. the H2D copy of the point batch: pinned host buffers handed over every step, the
-        #      copy of batch t+1 queued before the kernels of batch t (never the headline value: inputs there are resident)
-        copy_stream = torch.cuda.Stream(device=dev)
-
-        def fetch(j):
-            # the copy of batch j runs on its own stream (xGMI/PCIe DMA next to the compute of batch j - 1); the plan stream
-            # and the compute stream wait for its event only
-            with torch.cuda.stream(copy_stream):
-                t = pinned[j % args.pool].to(dev, non_blocking=True)
-                ev = torch.cuda.Event()
-                ev.record(copy_stream)
-            return t, ev
-
-        def h2d_feed(k):
-            nxt, nev = fetch(0)
-            for i in range(k):
-                cur, cev = nxt, nev
-                torch.cuda.current_stream().wait_event(cev)
-                cur.record_stream(torch.cuda.current_stream())
-                nxt, nev = fetch(i + 1) if i + 1 < k else (None, None)
-                step(args.warmup + args.steps, cur, nxt, nev)
-        also["h2d_inclusive"] = timed_leg(2, args.steps, h2d_feed)
-        also["h2d_inclusive"]["note"] = "same step with the 4.3 MB/frame H2D copy of every batch inside the timed region (SURVEY 8d), on a copy stream"
+    if world == 1 and not args.no_also and pre:
+        # ---- the same loop with batches that never leave HBM (what round 1 / 2 reported as the headline)
+        other_feed = wl.feed_resident if args.feed == "h2d" else wl.feed_h2d
+        also["resident_inputs" if args.feed == "h2d" else "h2d_inclusive"] = timed_leg(wl, 2, args.steps, other_feed)
         # ---- the reference yaml's own mask ratio (tools/cfgs/waymo_models/gd_mae_ssl.yaml:158)
         other = 0.85 if abs(args.mask_ratio - 0.85) > 1e-6 else 0.75
-        net.backbone_3d.mask_ratio = other
-        also[f"mask_{other}"] = timed_leg(3, max(5, args.steps // 2))
-        net.backbone_3d.mask_ratio = args.mask_ratio
+        wl.net.backbone_3d.mask_ratio = other
+        also[f"mask_{other}"] = timed_leg(wl, 3, max(5, args.steps // 2))
+        wl.net.backbone_3d.mask_ratio = args.mask_ratio
         # ---- fp32 parity mode (the mode whose loss is held to 1e-4 of the reference by tests/)
-        if mode["bf16"]:
-            mode["bf16"] = False
-            also["fp32_parity_mode"] = timed_leg(3, max(4, args.steps // 4))
+        if wl.mode["bf16"]:
+            wl.mode["bf16"] = False
+            also["fp32_parity_mode"] = timed_leg(wl, 3, max(4, args.steps // 4))
             also["fp32_parity_mode"]["note"] = "no autocast: fp32 rows / GEMMs, dense F.conv2d decoder convolution"
-            mode["bf16"] = True
-        pending.clear()
+            wl.mode["bf16"] = True
+        wl.pending.clear()
+        if args.config == "B" and not explicit_batch:
+            # ---- config C's per-GPU batch on this one GPU (the N = 1 point of the driver's scaling curve runs 8 frames per GPU;
+            #      this is the same step at the 4 frames per GPU that --gpus 2 / 4 / 8 use) and the other single-GPU configs
+            extra = [("config_C_batch_4_per_gpu", "B", 4), ("config_E", "E", 8), ("config_D_finetune", "D", 8)]
+            for key, cfg_name, b in extra:
+                try:
+                    w2 = Workload(args, cfg_name, b, dev, rank, world, args.mask_ratio, total_steps, 2)
+                    w2.advance = False
+                    also[key] = timed_leg(w2, 4, max(8, args.steps // 2))
+                    also[key]["workload"] = WORKLOADS["C" if key.startswith("config_C") else cfg_name]
+                    del w2
+                    torch.cuda.empty_cache()
+                except Exception as e:     # noqa: BLE001  (an extra leg must not take the headline line down)
+                    also[key] = {"error": repr(e)[:300]}
     if rank == 0:
-        # ---- sizes of the last timed batch (for the algorithmic byte model)
-        N, M = vox.N / B, vox.M / B
-        Ms = [s.n_tok / B for s in ep.stages]
-        dsz = [int(b.ENCODER.D_MODEL) for b in cfg.BACKBONE_3D.SST_BLOCK_LIST]
-        G = int(ds.grid_size[0]) * int(ds.grid_size[1])
-        a = 2 if use_bf16 else 4
-        bytes_train = 3 * algorithmic_bytes_per_frame(N, M, Ms, dsz, G, a)
-        out["config"].update({"points_per_frame": int(N), "pillars_per_frame": int(M), "tokens_per_frame": [int(m) for m in Ms]})
-        if ep.dec_tiles is not None:
-            nt = B * ((int(ds.grid_size[1]) + 7) // 8) * ((int(ds.grid_size[0]) + 7) // 8)
-            out["config"]["decoder_active_tiles"] = f"{ep.dec_tiles.n_act} of {nt}"
-        out["step_bytes_model"] = {"bytes_train_per_frame": int(bytes_train), "achieved_GBs": round(bytes_train * fps / world / 1e9, 1),
-                                   "frac_of_8TBs": round(bytes_train * fps / world / 1e9 / HBM_PEAK_GBS, 4),
-                                   "note": "SURVEY 8d whole-step algorithmic bytes (dense-decoder formula) x frames/s per GPU"}
+        if vox is not None and ep is not None and pre:
+            # ---- sizes of the last timed batch (for the algorithmic byte model)
+            N, M = vox.N / B, vox.M / B
+            Ms = [s.n_tok / B for s in ep.stages]
+            dsz = [int(b.ENCODER.D_MODEL) for b in wl.cfg.BACKBONE_3D.SST_BLOCK_LIST]
+            ds = wl.ds
+            G = int(ds.grid_size[0]) * int(ds.grid_size[1])
+            a = 2 if use_bf16 else 4
+            bytes_train = 3 * algorithmic_bytes_per_frame(N, M, Ms, dsz, G, a)
+            out["config"].update({"points_per_frame": int(N), "pillars_per_frame": int(M), "tokens_per_frame": [int(m) for m in Ms]})
+            if ep.dec_tiles is not None:
+                nt = B * ((int(ds.grid_size[1]) + 7) // 8) * ((int(ds.grid_size[0]) + 7) // 8)
+                out["config"]["decoder_active_tiles"] = f"{ep.dec_tiles.n_act} of {nt}"
+            out["step_bytes_model"] = {"bytes_train_per_frame": int(bytes_train), "achieved_GBs": round(bytes_train * fps / world / 1e9, 1),
+                                       "frac_of_8TBs": round(bytes_train * fps / world / 1e9 / HBM_PEAK_GBS, 4),
+                                       "note": "SURVEY 8d whole-step algorithmic bytes (dense-decoder formula) x frames/s per GPU"}
         if world > 1:
+            opt = wl.opt
             out["grad_sync"] = {"buckets": [[b, hi - lo] for b, lo, hi in opt.buckets], "last_step": opt.sync.log,
                                 "note": "one all-reduce per bucket; 'overlapped' = launched on the communication stream from inside "
                                         "backward(), 'tail' = after it"}
@@ -415,8 +518,7 @@ def main():
             out["kernel_time_shares"] = json.load(open(shares))
         if also:
             out["also"] = also
-            out["h2d_inclusive"] = also["h2d_inclusive"]
-        if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (rank 0's host cores)
+        if not args.no_cpu_baseline and world == 1 and pre:      # reported at N = 1 only (rank 0's host cores)
             out["cpu_baseline"] = measure_cpu_baseline(args.config, args.mask_ratio)
         print(json.dumps(out), flush=True)
     if world > 1:

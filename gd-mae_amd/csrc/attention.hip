@@ -591,58 +591,13 @@ extern "C" int gdmae_window_attention_bwd(const void* qk, const void* v, const v
 // All occupancy levels of one shift (the windows of level l are win_start / win_len [sum_{k<l} n_win[k], ...)), as the layer
 // executor issues them: bf16 rows on the matrix-core kernels go out as two launches (T = 16; T = 32 and T = 64 together),
 // everything else level by level.  Backward: dtau_part holds sum_l n_win[l] * H partial slots, level after level.
-// Optional HIP-event brackets around the all-levels entries (bench.py's roofline leg: the product path is what gets timed).
-#include <vector>
-namespace {
-struct TimedCall {
-  hipEvent_t a, b;
-};
-int g_attn_timing = 0;
-std::vector<TimedCall> g_timed[2];      // 0: forward, 1: backward
-struct TimedScope {
-  int which;
-  hipStream_t st;
-  TimedCall tc;
-  bool on;
-  TimedScope(int w, hipStream_t s) : which(w), st(s), on(g_attn_timing != 0) {
-    if (!on) return;
-    (void)hipEventCreate(&tc.a);
-    (void)hipEventCreate(&tc.b);
-    (void)hipEventRecord(tc.a, st);
-  }
-  ~TimedScope() {
-    if (!on) return;
-    (void)hipEventRecord(tc.b, st);
-    g_timed[which].push_back(tc);
-  }
-};
-}  // namespace
-// on != 0: start collecting (previous records dropped); on == 0: stop
-extern "C" int gdmae_attention_timing(int on) {
-  for (int w = 0; w < 2; ++w) {
-    for (auto& t : g_timed[w]) {
-      (void)hipEventDestroy(t.a);
-      (void)hipEventDestroy(t.b);
-    }
-    g_timed[w].clear();
-  }
-  g_attn_timing = on;
-  return 0;
-}
-// total milliseconds and number of bracketed calls of the forward (which = 0) / backward (1) entries since timing was switched on
-// (synchronises with the recorded events)
-extern "C" int gdmae_attention_timing_read(int which, double* total_ms, long long* calls) {
-  GD_REQUIRE(which == 0 || which == 1, "attention timing: which = 0 (forward) or 1 (backward)");
-  double tot = 0.0;
-  for (auto& t : g_timed[which]) {
-    GD_CHECK(hipEventSynchronize(t.b));
-    float ms = 0.f;
-    GD_CHECK(hipEventElapsedTime(&ms, t.a, t.b));
-    tot += ms;
-  }
-  *total_ms = tot;
-  *calls = (long long)g_timed[which].size();
-  return 0;
+// Both entries are measurement slots (common.h GdTimed: HIP-event brackets on the launch stream, bench.py's roofline leg).
+long long g_attn_tokens = 0;   // tokens of the layer whose attention entry is called next (set by the layer executor)
+void gd_attn_timing_tokens(long long n) { g_attn_tokens = n; }
+static double attn_alg_bytes(int n_levels, const int* n_win, const int* win_len_unused, long long n_tok, int d, int es, int rows_per_tok) {
+  long long nw = 0;
+  for (int l = 0; l < n_levels; ++l) nw += n_win[l];
+  return (double)n_tok * ((double)rows_per_tok * d * es + 4.0) + 8.0 * (double)nw;
 }
 
 static bool levels_fast_path(int io_bf16, int n_levels, const int* max_tokens, int H, int d) {
@@ -655,7 +610,9 @@ extern "C" int gdmae_window_attention_levels_fwd(const void* qk, const void* v, 
                                                  const int* win_start, const int* win_len, int n_levels, const int* n_win,
                                                  const int* max_tokens, int d, int H, const float* tau, float tau_min, void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  TimedScope timed(0, st);
+  // algorithmic bytes: q, k, v rows read + out row written per token (4 d elements) + CSR; the token count is not an argument
+  // of this entry - the caller (encoder_layer.hip) adds it through gd_attn_timing_tokens
+  GdTimed timed(GD_T_ATTN_FWD, st, attn_alg_bytes(n_levels, n_win, nullptr, g_attn_tokens, d, io_bf16 ? 2 : 4, 4));
   if (!levels_fast_path(io_bf16, n_levels, max_tokens, H, d)) {
     int base = 0;
     for (int l = 0; l < n_levels; ++l) {
@@ -687,7 +644,7 @@ extern "C" int gdmae_window_attention_levels_bwd(const void* qk, const void* v, 
                                                  int n_levels, const int* n_win, const int* max_tokens, int d, int H, const float* tau,
                                                  float tau_min, void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  TimedScope timed(1, st);
+  GdTimed timed(GD_T_ATTN_BWD, st, attn_alg_bytes(n_levels, n_win, nullptr, g_attn_tokens, d, io_bf16 ? 2 : 4, 7));
   if (!levels_fast_path(io_bf16, n_levels, max_tokens, H, d)) {
     int base = 0;
     long long pbase = 0;

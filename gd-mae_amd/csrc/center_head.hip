@@ -19,7 +19,7 @@ __global__ __launch_bounds__(64) void k_ch_prepare(const float* __restrict__ gt,
                                                    int n_class_total, float x0, float y0, float vsx, float vsy, float stride, int fw, int fh,
                                                    int num_max_objs, double overlap_d, int min_radius, ChBox* __restrict__ boxes,
                                                    float* __restrict__ ret_boxes, long long* __restrict__ inds, long long* __restrict__ mask,
-                                                   int ret_dim) {
+                                                   int ret_dim, float* __restrict__ iou_boxes) {
   const int b = blockIdx.x, lane = threadIdx.x;
   const float* g = gt + (long long)b * n_max * box_dim;
   int base = 0;
@@ -71,6 +71,10 @@ __global__ __launch_bounds__(64) void k_ch_prepare(const float* __restrict__ gt,
         rb[3] = logf(bx[3]); rb[4] = logf(bx[4]); rb[5] = logf(bx[5]);
         rb[6] = cosf(bx[6]); rb[7] = sinf(bx[6]);
         for (int e = 8; e < ret_dim; ++e) rb[e] = bx[e - 1];               // extra regression targets (velocity ...)
+        if (iou_boxes) {                                                   // IoU-aware head: the box itself (center_head.py:161)
+          float* ib = iou_boxes + ((long long)b * num_max_objs + k) * 7;
+          for (int e = 0; e < 7; ++e) ib[e] = bx[e];
+        }
       }
       boxes[(long long)b * num_max_objs + k] = rec;
     }
@@ -108,25 +112,108 @@ extern "C" size_t gdmae_center_head_targets_workspace_bytes(int B, int num_max_o
 // gt_boxes (B, n_max, box_dim) fp32 device [x, y, z, dx, dy, dz, heading, (extras,) class]; class_map device int
 // (n_class_total + 1): global class id -> 1-based id inside this head or 0.  Outputs (zero-filled here): heatmap
 // (B, n_cls, fh, fw) fp32, ret_boxes (B, num_max_objs, box_dim) fp32, inds / mask (B, num_max_objs) int64.
+extern "C" int gdmae_center_head_targets_iou(const float* gt_boxes, int B, int n_max, int box_dim, const int* class_map, int n_class_total,
+                                             int n_cls, const float* pc_range, const float* voxel_size, float feature_map_stride, int fw, int fh,
+                                             int num_max_objs, double gaussian_overlap, int min_radius, float* heatmap, float* ret_boxes,
+                                             float* iou_boxes, long long* inds, long long* mask, void* workspace, void* stream);
 extern "C" int gdmae_center_head_targets(const float* gt_boxes, int B, int n_max, int box_dim, const int* class_map, int n_class_total,
                                          int n_cls, const float* pc_range /* host [x0, y0] */, const float* voxel_size /* host [vx, vy] */,
                                          float feature_map_stride, int fw, int fh, int num_max_objs, double gaussian_overlap, int min_radius,
                                          float* heatmap, float* ret_boxes, long long* inds, long long* mask, void* workspace, void* stream) {
+  return gdmae_center_head_targets_iou(gt_boxes, B, n_max, box_dim, class_map, n_class_total, n_cls, pc_range, voxel_size, feature_map_stride,
+                                       fw, fh, num_max_objs, gaussian_overlap, min_radius, heatmap, ret_boxes, nullptr, inds, mask, workspace,
+                                       stream);
+}
+// the same + iou_boxes (B, num_max_objs, 7) fp32: the ground-truth box of every assigned slot (zero elsewhere), the regression
+// target of the IoU-aware head (center_head.py:118,161; null = not wanted)
+extern "C" int gdmae_center_head_targets_iou(const float* gt_boxes, int B, int n_max, int box_dim, const int* class_map, int n_class_total,
+                                             int n_cls, const float* pc_range, const float* voxel_size, float feature_map_stride, int fw, int fh,
+                                             int num_max_objs, double gaussian_overlap, int min_radius, float* heatmap, float* ret_boxes,
+                                             float* iou_boxes, long long* inds, long long* mask, void* workspace, void* stream) {
   GD_REQUIRE(B >= 1 && box_dim >= 8 && n_cls >= 1 && fw >= 1 && fh >= 1 && num_max_objs >= 1, "center_head_targets: bad sizes");
   hipStream_t st = (hipStream_t)stream;
   GD_CHECK(hipMemsetAsync(heatmap, 0, (size_t)B * n_cls * fh * fw * sizeof(float), st));
   GD_CHECK(hipMemsetAsync(ret_boxes, 0, (size_t)B * num_max_objs * box_dim * sizeof(float), st));
+  if (iou_boxes) GD_CHECK(hipMemsetAsync(iou_boxes, 0, (size_t)B * num_max_objs * 7 * sizeof(float), st));
   GD_CHECK(hipMemsetAsync(inds, 0, (size_t)B * num_max_objs * sizeof(long long), st));
   GD_CHECK(hipMemsetAsync(mask, 0, (size_t)B * num_max_objs * sizeof(long long), st));
   ChBox* boxes = (ChBox*)workspace;
   if (n_max > 0) {
     hipLaunchKernelGGL(k_ch_prepare, dim3(B), dim3(64), 0, st, gt_boxes, n_max, box_dim, class_map, n_class_total, pc_range[0], pc_range[1],
                        voxel_size[0], voxel_size[1], feature_map_stride, fw, fh, num_max_objs, gaussian_overlap, min_radius, boxes, ret_boxes,
-                       inds, mask, box_dim);
+                       inds, mask, box_dim, iou_boxes);
     GD_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_ch_draw, dim3(num_max_objs < n_max ? num_max_objs : n_max, B), dim3(256), 0, st, (const ChBox*)boxes, num_max_objs,
                        n_cls, fw, fh, heatmap);
     GD_LAUNCH_CHECK();
   }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Box decoding of a head's K best heat-map cells as ONE launch (evaluation / RoI path; reference
+// pcdet/models/model_utils/centernet_utils.py:163-260 `decode_bbox_from_heatmap` with its `_topk` / `_gather_feat` chain,
+// and the IoU normalisation of center_head.py:296-299).  The reference gathers every regression map separately through
+// (B, H*W, C) transposed copies of the maps; here one thread per candidate reads its 9-12 values straight from the
+// (B, C, H, W) maps.  cell: flat index over (class, y, x) of the head's heat map (the K best of ALL classes: the set and the
+// order the reference's per-class top-K followed by a top-K over classes x K produces).
+// ------------------------------------------------------------------------------------------------------------------
+struct ChDecode {
+  const long long* cell;     // (B, K)
+  const float* score;        // (B, K) sigmoid heat-map value
+  const float *center, *center_z, *dim, *rot, *vel, *iou;   // (B, 2 | 1 | 3 | 2 | 2 | 1, H, W); vel / iou optional
+  int B, K, H, W;
+  float x0, y0, vsx, vsy, stride;
+  float lim[6];
+  float score_thresh;
+  int use_thresh;
+  int box_dim;               // 7, or 9 with vel
+  float* boxes;              // (B, K, box_dim)
+  int* labels;               // (B, K) class index inside the head
+  float* ious;               // (B, K) clamp((iou + 1) / 2, 0, 1), or 1 without an iou map
+  unsigned char* valid;      // (B, K) inside the post-centre range and above the score threshold
+};
+__global__ __launch_bounds__(256) void k_ch_decode(ChDecode D) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i >= (long long)D.B * D.K) return;
+  const int b = (int)(i / D.K);
+  const long long hw = (long long)D.H * D.W;
+  const long long c = D.cell[i];
+  const int cls = (int)(c / hw);
+  const long long site = c % hw;
+  const int y = (int)(site / D.W), x = (int)(site % D.W);
+  auto at = [&](const float* m, int ch, int k) { return m[((long long)b * ch + k) * hw + site]; };
+  float box[9];
+  box[0] = (((float)x + at(D.center, 2, 0)) * D.stride) * D.vsx + D.x0;
+  box[1] = (((float)y + at(D.center, 2, 1)) * D.stride) * D.vsy + D.y0;
+  box[2] = at(D.center_z, 1, 0);
+  box[3] = expf(at(D.dim, 3, 0)); box[4] = expf(at(D.dim, 3, 1)); box[5] = expf(at(D.dim, 3, 2));
+  box[6] = atan2f(at(D.rot, 2, 1), at(D.rot, 2, 0));                 // rot = [cos, sin]
+  if (D.vel) { box[7] = at(D.vel, 2, 0); box[8] = at(D.vel, 2, 1); }
+  for (int e = 0; e < D.box_dim; ++e) D.boxes[i * D.box_dim + e] = box[e];
+  D.labels[i] = cls;
+  float q = 1.f;
+  if (D.iou) q = fminf(fmaxf((at(D.iou, 1, 0) + 1.f) * 0.5f, 0.f), 1.f);
+  D.ious[i] = q;
+  bool ok = true;
+  for (int e = 0; e < 3; ++e) ok = ok && box[e] >= D.lim[e] && box[e] <= D.lim[3 + e];
+  if (D.use_thresh) ok = ok && D.score[i] > D.score_thresh;
+  D.valid[i] = ok ? 1 : 0;
+}
+extern "C" int gdmae_center_head_decode(const long long* cell, const float* score, const float* center, const float* center_z,
+                                        const float* dim, const float* rot, const float* vel, const float* iou, int B, int K, int H, int W,
+                                        const float* pc_range /* host [x0, y0] */, const float* voxel_size /* host [vx, vy] */,
+                                        float feature_map_stride, const float* post_center_limit_range /* host [6] */, float score_thresh,
+                                        int use_score_thresh, float* boxes, int* labels, float* ious, unsigned char* valid, void* stream) {
+  GD_REQUIRE(B >= 1 && K >= 1 && H >= 1 && W >= 1, "center_head_decode: bad sizes");
+  ChDecode D;
+  D.cell = cell; D.score = score; D.center = center; D.center_z = center_z; D.dim = dim; D.rot = rot; D.vel = vel; D.iou = iou;
+  D.B = B; D.K = K; D.H = H; D.W = W;
+  D.x0 = pc_range[0]; D.y0 = pc_range[1]; D.vsx = voxel_size[0]; D.vsy = voxel_size[1]; D.stride = feature_map_stride;
+  for (int e = 0; e < 6; ++e) D.lim[e] = post_center_limit_range[e];
+  D.score_thresh = score_thresh; D.use_thresh = use_score_thresh; D.box_dim = vel ? 9 : 7;
+  D.boxes = boxes; D.labels = labels; D.ious = ious; D.valid = valid;
+  hipLaunchKernelGGL(k_ch_decode, dim3(gd_div_up((long long)B * K, 256)), dim3(256), 0, (hipStream_t)stream, D);
+  GD_LAUNCH_CHECK();
   return 0;
 }

@@ -26,6 +26,29 @@ extern "C" void gd_set_error(int code, const char* file, int line, const char* m
     }                                                      \
   } while (0)
 
+// ------------------------------------------------------------------------------------------
+// Measurement slots (bench.py roofline leg): HIP-event brackets around the launches of a kernel family ON THE PRODUCT PATH, on
+// the stream they are launched on, together with the algorithmic work of the bracketed launches.  Off by default (one load
+// of a flag per launch); gdmae_kernel_timing(1) starts collecting, gdmae_kernel_timing_read sums a slot (capi.hip).
+// ------------------------------------------------------------------------------------------
+enum {
+  GD_T_ATTN_FWD = 0, GD_T_ATTN_BWD = 1, GD_T_TOK_GEMM = 2, GD_T_DW_GROUPED = 3, GD_T_CONV_TILES = 4, GD_T_GRAD_TAPS = 5,
+  GD_T_SPCONV_FWD = 6, GD_T_SPCONV_BWD = 7, GD_T_DEC_CONV_BWD = 8, GD_T_VFE = 9, GD_T_PLAN = 10, GD_T_LAYER_TAIL = 11,
+  GD_T_FFN = 12, GD_T_SLOTS = 16
+};
+extern int g_gd_timing_on;
+void* gd_timing_begin(int slot, hipStream_t st);
+void gd_timing_end(void* handle, hipStream_t st, double bytes, double flops);
+struct GdTimed {
+  void* h;
+  hipStream_t st;
+  double bytes, flops;
+  GdTimed(int slot, hipStream_t s, double b, double f = 0.0) : h(g_gd_timing_on ? gd_timing_begin(slot, s) : nullptr), st(s), bytes(b), flops(f) {}
+  ~GdTimed() {
+    if (h) gd_timing_end(h, st, bytes, flops);
+  }
+};
+
 static inline int gd_div_up(long long a, long long b) { return (int)((a + b - 1) / b); }
 static inline size_t gd_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 

@@ -232,6 +232,12 @@ int gd_dw_grouped(hipStream_t st, GdDwGroup& A, long long n_pad, long long n_val
   A.S = gd_dw_group_slices(n_pad, tiles);
   A.rows_per_slice = n_pad / A.S;
   A.n_valid = n_valid;
+  double by = 0.0, fl = 0.0;   // operands read once (the re-reads by the tiles of a slice are L2 hits), fp32 partial tiles written
+  for (int j = 0; j < A.n_jobs; ++j) {
+    by += 2.0 * n_valid * (A.job[j].M + A.job[j].N) + 4.0 * A.S * (double)A.job[j].M * A.job[j].N;
+    fl += 2.0 * n_valid * (double)A.job[j].M * A.job[j].N;
+  }
+  GdTimed timed(GD_T_DW_GROUPED, st, by, fl);
   hipLaunchKernelGGL(k_dw_grouped, dim3((unsigned)(tiles * A.S)), dim3(256), 4 * kStage, st, A);
   GD_LAUNCH_CHECK();
   return 0;

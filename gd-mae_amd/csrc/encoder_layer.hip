@@ -542,6 +542,7 @@ int gd_add_layernorm_bwd_ex(const float* a, const void* b, int b_is_bf16, const 
 int gd_ln_partial_rows(long long n, int d);
 
 // fused token GEMMs (tok_gemm.hip)
+void gd_attn_timing_tokens(long long n);   // attention.hip: token count for the byte figure of the next attention entry
 bool gd_tok_gemm_supported(int K, int N);
 int gd_tok_gemm_plain(hipStream_t st, const void* X, const void* Wp, const void* bias, long long n_pad, int K, int N, void* out);
 int gd_tok_gemm_qkv(hipStream_t st, const void* Xpos, const void* X, const void* Wp_qk, const void* Wp_v, const void* bias3,
@@ -652,6 +653,7 @@ static int layer_fwd(const gdmae_layer_args* a, const gdmae_layer_args* next, bo
     GD_TRY(linear_fwd(c, s.xpb, Win, bin, s.qk, n_pad, 2 * d, d));
     GD_TRY(linear_fwd(c, s.xb, Win + (size_t)2 * d * d * es, bin + (size_t)2 * d * es, s.v, n_pad, d, d));
   }
+  gd_attn_timing_tokens(n);
   GD_TRY(gdmae_window_attention_levels_fwd(s.qk, s.v, s.o, a->bf16, a->csr_tok, a->win_start, a->win_len, a->n_levels, a->n_win,
                                            a->max_tokens, d, a->nhead, a->tau, a->tau_min, stream));
   if (fused) {
@@ -769,6 +771,7 @@ static int layer_bwd(const gdmae_layer_args* a, bool upstream3, bool defer_add3,
   // ---- attention
   long long pbase = 0;
   for (int l = 0; l < a->n_levels; ++l) pbase += (long long)a->n_win[l] * a->nhead;
+  gd_attn_timing_tokens(n);
   GD_TRY(gdmae_window_attention_levels_bwd(s.qk, s.v, w.d_o, w.dqk, w.dv, a->bf16, (float*)w.apart, a->csr_tok, a->win_start, a->win_len,
                                            a->n_levels, a->n_win, a->max_tokens, d, a->nhead, a->tau, a->tau_min, stream));
   if (!grouped) GD_TRY(gdmae_sum_partials_gated((const float*)w.apart, pbase, 1.f, (float*)w.dtau, a->tau, a->tau_min, stream));
@@ -835,6 +838,10 @@ static int layer_bwd(const gdmae_layer_args* a, bool upstream3, bool defer_add3,
     T.tau_part = (const float*)w.apart; T.n_part = pbase; T.tau = a->tau; T.tau_min = a->tau_min; T.dtau = a->dtau;
     long long gx = (cols + 15) / 16;
     for (int q = 0; q < SJ.count; ++q) gx = (SJ.P4[q] + 63) / 64 > gx ? (SJ.P4[q] + 63) / 64 : gx;
+    double tail_bytes = 4.0 * pbase;
+    for (int q = 0; q < SJ.count; ++q) tail_bytes += 16.0 * SJ.P4[q] * (SJ.S[q] + 2);
+    for (int q = 0; q < j.count; ++q) tail_bytes += 4.0 * j.len[q] * (j.nblk[q] + 2);
+    GdTimed timed(GD_T_LAYER_TAIL, c.st, tail_bytes);
     hipLaunchKernelGGL(k_layer_tail, dim3((unsigned)gx, SJ.count + 2), dim3(256), 0, c.st, T);
     GD_LAUNCH_CHECK();
   } else {

@@ -19,7 +19,7 @@ __global__ __launch_bounds__(256) void k_sq_partials(const float* __restrict__ g
   if (threadIdx.x == 0) part[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
 }
 
-#define GD_ADAM_MAX_SEG 16
+#define GD_ADAM_MAX_SEG 64
 struct AdamArgs {
   float lr, beta1, beta2, eps, wd, max_norm;
   float bc1, bc2_sqrt;  // 1 - beta1^t, sqrt(1 - beta2^t)
@@ -70,7 +70,7 @@ extern "C" int gdmae_adam_step(float* param, const float* grad, float* exp_avg, 
                                int n_segments, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                                float max_norm, float grad_scale, const float* sq_norm, void* stream) {
   GD_REQUIRE(step >= 1, "step counts from 1");
-  GD_REQUIRE(n_segments >= 0 && n_segments <= GD_ADAM_MAX_SEG, "adam_step: at most 16 segments");
+  GD_REQUIRE(n_segments >= 0 && n_segments <= GD_ADAM_MAX_SEG, "adam_step: at most 64 segments");
   AdamArgs A;
   A.lr = lr;
   A.beta1 = beta1;

@@ -531,6 +531,7 @@ int gd_tok_gemm_plain(hipStream_t st, const void* X, const void* Wp, const void*
   TgArgs A = {};
   A.X = (const unsigned short*)X; A.Wp = (const uint4*)Wp; A.bias = (const unsigned short*)bias; A.n = n_pad; A.n_pad = n_pad;
   A.out0 = (unsigned short*)out;
+  GdTimed timed(GD_T_TOK_GEMM, st, 2.0 * n_pad * (K + N) + 2.0 * K * N, 2.0 * n_pad * K * N);
   return tg_dispatch<TG_PLAIN>(K, N, A, st);
 }
 // q | k = (X + pos) Wqk^T + b (n_pad, 2d) and v = X Wv^T + b (n_pad, d) in one launch; Wqk packed as one (2d, d) image
@@ -544,6 +545,7 @@ int gd_tok_gemm_qkv(hipStream_t st, const void* Xpos, const void* X, const void*
   M.j2 = TgJob{(const unsigned short*)X, (const uint4*)Wp_v, b ? b + 2 * d : nullptr, (unsigned short*)v, d / 32, d};
   M.n_jobs = 3;
   M.n_pad = n_pad;
+  GdTimed timed(GD_T_TOK_GEMM, st, 2.0 * n_pad * (2 * d + 3 * d) + 2.0 * 3 * d * d, 2.0 * n_pad * d * 3 * d);
   if (d == 128) return tg_launch_multi<128, 128>(M, st);
   if (d == 256) return tg_launch_multi<256, 256>(M, st);
   GD_REQUIRE(false, "tok_gemm_qkv: unsupported width");
@@ -552,12 +554,14 @@ int gd_tok_gemm_gelu(hipStream_t st, const void* X, const void* Wp, const void* 
   TgArgs A = {};
   A.X = (const unsigned short*)X; A.Wp = (const uint4*)Wp; A.bias = (const unsigned short*)bias; A.n = n_pad; A.n_pad = n_pad;
   A.out0 = (unsigned short*)h; A.out1 = (unsigned short*)gact;
+  GdTimed timed(GD_T_TOK_GEMM, st, 2.0 * n_pad * (K + 2 * N) + 2.0 * K * N, 2.0 * n_pad * K * N);
   return tg_dispatch<TG_GELU>(K, N, A, st);
 }
 int gd_tok_gemm_gelu_bwd(hipStream_t st, const void* dY, const void* Wp, const void* h, long long n_pad, int K, int N, void* dh) {
   TgArgs A = {};
   A.X = (const unsigned short*)dY; A.Wp = (const uint4*)Wp; A.n = n_pad; A.n_pad = n_pad;
   A.out0 = (unsigned short*)dh; A.aux = (const unsigned short*)h;
+  GdTimed timed(GD_T_TOK_GEMM, st, 2.0 * n_pad * (K + 2 * N) + 2.0 * K * N, 2.0 * n_pad * K * N);
   return tg_dispatch<TG_GELU_BWD>(K, N, A, st);
 }
 int gd_tok_gemm_res_ln(hipStream_t st, const void* X, const void* Wp, const void* bias, long long n, long long n_pad, int K, int N,
@@ -568,6 +572,11 @@ int gd_tok_gemm_res_ln(hipStream_t st, const void* X, const void* Wp, const void
   A.X = (const unsigned short*)X; A.Wp = (const uint4*)Wp; A.bias = (const unsigned short*)bias; A.n = n; A.n_pad = n_pad;
   A.res = res; A.gamma = gamma; A.beta = beta; A.eps = eps; A.y = y; A.stats = stats; A.y_bf = (unsigned short*)y_bf;
   A.pos_table = pos_table; A.tok_pos = tok_pos; A.ypos_bf = (unsigned short*)ypos_bf;
+  // product operand + fp32 residual in, fp32 rows + statistics out, + the optional bf16 copies (y, y + pos, rounded branch)
+  GdTimed timed(GD_T_TOK_GEMM, st,
+                2.0 * n_pad * K + (double)n * N * (4 + 4 + (y_bf ? 2 : 0) + (ypos_bf ? 2 : 0) + (f_out ? 2 : 0)) + 8.0 * n +
+                    (ypos_bf ? 4.0 * n : 0.0) + 2.0 * K * N,
+                2.0 * n_pad * K * N);
   return tg_dispatch<TG_RES_LN>(K, N, A, st);
 }
 
@@ -581,6 +590,12 @@ int gd_tok_gemm_ln_bwd(hipStream_t st, const void* X, const void* Wp, long long 
   A.X = (const unsigned short*)X; A.Wp = (const uint4*)Wp; A.n = n; A.n_pad = n_pad;
   A.res = dy; A.aux = (const unsigned short*)dy2_bf; A.ln_a = ln_a; A.ln_b = (const unsigned short*)ln_b_bf;
   A.stats = const_cast<float*>(stats); A.gamma = gamma; A.y = dx; A.y_bf = (unsigned short*)dx_bf; A.part = part;
+  // product operand, dy (fp32) [+ dy2 (bf16)], both LayerNorm addends (fp32 + bf16), statistics in; dx (fp32) [+ bf16 copy] and the
+  // per-workgroup partial rows out
+  GdTimed timed(GD_T_TOK_GEMM, st,
+                2.0 * n_pad * K + (double)n * N * (4 + (dy2_bf ? 2 : 0) + 4 + 2 + 4 + (dx_bf ? 2 : 0)) + 8.0 * n +
+                    12.0 * N * (double)(n_pad / gd_tok_gemm_rows(N)) + 2.0 * K * N,
+                2.0 * n_pad * K * N);
   return tg_dispatch<TG_LN_BWD>(K, N, A, st);
 }
 extern "C" int gdmae_tok_gemm_qkv(const void* Xpos, const void* X, const void* Wp_qk, const void* Wp_v, const void* bias3, long long n_pad,

@@ -78,6 +78,18 @@ def center_head_cfg(class_names=('Vehicle', 'Pedestrian', 'Cyclist'), post_range
     })
 
 
+def center_head_iou_cfg(class_names=('Vehicle', 'Pedestrian', 'Cyclist'), post_range=(-75.2, -75.2, -2, 75.2, 75.2, 4)):
+    """DENSE_HEAD section of tools/cfgs/waymo_models/gd_mae_iou.yaml:215-254: CenterHead with the extra ``iou`` regression map,
+    ``iou_weight`` and the IoU-rectified per-class NMS."""
+    c = center_head_cfg(class_names, post_range)
+    c.SEPARATE_HEAD_CFG.HEAD_DICT['iou'] = AttrDict({'out_channels': 1, 'num_conv': 2})
+    c.LOSS_CONFIG.LOSS_WEIGHTS['iou_weight'] = 1.0
+    c.POST_PROCESSING.NMS_CONFIG = AttrDict({'NMS_TYPE': 'multi_class_nms', 'NMS_THRESH': [0.8, 0.55, 0.55],
+                                             'NMS_PRE_MAXSIZE': [2048, 1024, 1024], 'NMS_POST_MAXSIZE': [200, 150, 150],
+                                             'IOU_RECTIFIER': [0.5, 0.71, 0.65]})
+    return c
+
+
 def optimization_cfg(batch_size_per_gpu=8, num_epochs=30):
     """OPTIMIZATION section of the ssl yamls (gd_mae_ssl.yaml:183-203)."""
     return AttrDict({'BATCH_SIZE_PER_GPU': batch_size_per_gpu, 'NUM_EPOCHS': num_epochs, 'OPTIMIZER': 'adam_onecycle',

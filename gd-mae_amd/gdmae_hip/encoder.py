@@ -412,7 +412,7 @@ def encoder_stage(blocks, x, pos_table, wplans):
     """``blocks``: the stage's BasicShiftBlockV2 modules (layer k of a block uses window partition k % len(wplans))."""
     pairs = [(layer, wplans[k % len(wplans)]) for block in blocks for k, layer in enumerate(block.encoder_list)]
     layers = [p[0] for p in pairs]
-    if (STAGE and IMPL == "native" and not timing.enabled() and x.is_cuda and
+    if (STAGE and IMPL == "native" and x.is_cuda and
             all(getattr(l, "fused", False) and l.activation_name == "gelu" for l in layers)):
         plists = [_plist(l) for l in layers]
         directs = [[_direct(p) for p in pl] for pl in plists]
@@ -426,7 +426,7 @@ def encoder_stage(blocks, x, pos_table, wplans):
 def encoder_layer(layer, x, wplan, pos_table):
     """``layer``: pcdet EncoderLayer module (parameter container); returns LN(x1 + FFN(x1)), x1 = LN(x + attn(x))."""
     sa = layer.win_attn.self_attn
-    fn = EncoderLayerNativeFn if (IMPL == "native" and not timing.enabled()) else EncoderLayerFn
+    fn = EncoderLayerNativeFn if (IMPL == "native") else EncoderLayerFn
     return fn.apply(x, sa.in_proj_weight, sa.in_proj_bias, sa.tau, sa.out_proj.weight, sa.out_proj.bias,
                     layer.linear1.weight, layer.linear1.bias, layer.linear2.weight, layer.linear2.bias,
                     layer.norm1.weight, layer.norm1.bias, layer.norm2.weight, layer.norm2.bias,

@@ -83,6 +83,10 @@ SIGNATURES = {
     "gdmae_window_attention_levels_bwd": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P, _P, _I, _I, _P, _F, _P]),
     "gdmae_attention_timing": (_I, [_I]),
     "gdmae_attention_timing_read": (_I, [_I, _P, _P]),
+    "gdmae_kernel_timing": (_I, [_I]),
+    "gdmae_kernel_timing_slots": (_I, []),
+    "gdmae_kernel_timing_name": (C.c_char_p, [_I]),
+    "gdmae_kernel_timing_read": (_I, [_I, _P, _P, _P, _P]),
     "gdmae_add_layernorm_workspace_bytes": (_Z, [_I]),
     "gdmae_add_layernorm_fwd": (_I, [_P, _P, _I, _P, _P, _L, _I, _F, _P, _P, _P, _P]),
     "gdmae_add_layernorm_bwd": (_I, [_P, _P, _I, _P, _P, _P, _P, _I, _L, _I, _P, _P, _P, _P, _P]),
@@ -121,6 +125,8 @@ SIGNATURES = {
     "gdmae_group_inner_inds": (_I, [_P, _L, _L, _I, _P, _P, _Z, _P]),
     "gdmae_center_head_targets_workspace_bytes": (_Z, [_I, _I]),
     "gdmae_center_head_targets": (_I, [_P, _I, _I, _I, _P, _I, _I, _P, _P, _F, _I, _I, _I, _D, _I, _P, _P, _P, _P, _P, _P]),
+    "gdmae_center_head_targets_iou": (_I, [_P, _I, _I, _I, _P, _I, _I, _P, _P, _F, _I, _I, _I, _D, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "gdmae_center_head_decode": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _F, _P, _F, _I, _P, _P, _P, _P, _P]),
     "gdmae_boxes_bev_pairs": (_I, [_P, _I, _P, _I, _I, _P, _P]),
     "gdmae_nms_workspace_bytes": (_Z, [_I]),
     "gdmae_nms_bev": (_I, [_P, _I, _F, _I, _P, _P, _P, _P]),

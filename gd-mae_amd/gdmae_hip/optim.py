@@ -92,7 +92,20 @@ class FlatAdamOneCycle:
             params += opt_p + frz_p
             frozen += frz_p
             off += n_all
-        assert len(self.buckets) <= 16, "at most 16 gradient buckets (gdmae_adam_step segments)"
+        # adjacent optimised ranges (a bucket without frozen parameters followed by the next bucket) are one Adam segment;
+        # gdmae_adam_step takes up to 64 of them
+        merged = []
+        for lo, hi in zip(self.segments[0::2], self.segments[1::2]):
+            if hi == lo:
+                continue
+            if merged and merged[-1][1] == lo:
+                merged[-1][1] = hi
+            else:
+                merged.append([lo, hi])
+        self.segments = [v for seg in merged for v in seg]
+        if len(merged) > 64:
+            raise ValueError(f"{len(merged)} disjoint optimised ranges: gdmae_adam_step takes at most 64 segments - pass a coarser "
+                             "bucket_of (e.g. one bucket per top-level module)")
         self.frozen = frozen
         self.model = model
         dev = params[0].device
@@ -161,6 +174,16 @@ class FlatAdamOneCycle:
         self.sync.finish()
         self._grad_scale = 1.0 / self.world_size()
 
+    def broadcast_buffers(self, src: int = 0):
+        """DDP's ``broadcast_buffers`` (reference tools/train.py:146 wraps the model with the default True: BatchNorm running
+        statistics and ``global_step`` of every rank are overwritten with rank ``src``'s before each forward).  The training
+        arithmetic never reads those buffers and rank 0 - the rank that writes checkpoints - only ever sees its own, so the
+        step itself skips the per-step broadcast; call this before evaluating / saving on a rank other than ``src``."""
+        if self.world_size() <= 1:
+            return
+        for b in self.model.buffers():
+            dist.broadcast(b, src=src, group=self.pg)
+
     def step(self, accumulated_iter: int | None = None):
         self._check_views()
         it = self.t if accumulated_iter is None else accumulated_iter
@@ -217,11 +240,11 @@ class FlatAdamOneCycle:
         return {"state": state, "param_groups": pgs}
 
     def load_state_dict(self, sd):
-        if "param_groups" not in sd:                     # flat layout written by earlier versions of this class
-            self.t = int(sd["t"])
-            self.exp_avg.copy_(sd["exp_avg"])
-            self.exp_avg_sq.copy_(sd["exp_avg_sq"])
-            return
+        if "param_groups" not in sd:
+            # flat buffers written by early versions of this class: the buffer layout has changed since (bucket order,
+            # optimised parameters first), so the moments would land on the wrong parameters without any size mismatch
+            raise ValueError("optimizer state in the retired flat layout ('t' / 'exp_avg' / 'exp_avg_sq'): not loadable - "
+                             "save with FlatAdamOneCycle.state_dict() (torch.optim.Adam wire format, keyed by parameter order)")
         groups = self._reference_groups()
         table = self._offsets()
         assert [len(g["params"]) for g in sd["param_groups"]] == [len(g) for g in groups], "optimizer state: group sizes differ"
@@ -258,12 +281,22 @@ class GradSync:
         self.works = []
         self._comm = None
         self.log = []            # (bucket name, 'overlapped' | 'tail') of the last step: what the tests look at
+        # mode: 'overlap' (default) - buckets reduced from the tensor hooks inside backward();
+        #       'tail'    - every bucket reduced in finish(), after backward() (the A/B reference of the tests);
+        #       'check'   - hooks only SNAPSHOT what they would have handed to the collective; finish() compares every
+        #                   snapshot with the final local gradient (a bucket that was marked complete too early raises)
+        #                   and then reduces at the tail.  GDMAE_SYNC_MODE selects it without code changes;
+        #       'off'     - no collective at all (local gradients; single-rank reference inside multi-rank tests)
+        import os
+        self.mode = os.environ.get("GDMAE_SYNC_MODE", "overlap")
+        self._snap = {}
 
     def _active(self):
-        return self.opt.world_size() > 1
+        return self.mode != "off" and self.opt.world_size() > 1
 
     def begin_step(self):
-        self.launched, self.works, self.log = set(), [], []
+        assert self.mode in ("overlap", "tail", "check", "off"), self.mode
+        self.launched, self.works, self.log, self._snap = set(), [], [], {}
 
     def bucket_names(self):
         return [b for b, _, _ in self.opt.buckets]
@@ -275,7 +308,12 @@ class GradSync:
         names = list(done_buckets)
 
         def hook(_g):
-            self.reduce(names, "overlapped")
+            if self.mode == "overlap":
+                self.reduce(names, "overlapped")
+            elif self.mode == "check":
+                for b, lo, hi in self.opt.buckets:
+                    if b in names and b not in self._snap:
+                        self._snap[b] = self.opt.flat_grad[lo:hi].clone()
             return None
         tensor.register_hook(hook)
 
@@ -303,6 +341,13 @@ class GradSync:
     def finish(self):
         if not self._active():
             return
+        if self.mode == "check":
+            for b, lo, hi in self.opt.buckets:
+                snap = self._snap.get(b)
+                if snap is not None and not torch.equal(snap, self.opt.flat_grad[lo:hi]):
+                    raise RuntimeError(f"GradSync: bucket '{b}' changed after the hook that marks it complete fired - a parameter "
+                                       "of this bucket is used before the marked tensor (its all-reduce would have been launched "
+                                       "on an unfinished gradient)")
         self.reduce(self.bucket_names(), "tail")
         for w in self.works:
             w.wait()                                      # NCCL/RCCL: orders the CURRENT stream behind the collective

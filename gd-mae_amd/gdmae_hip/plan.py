@@ -362,9 +362,10 @@ class PlanPrefetch:
 
     def __init__(self, points, point_cloud_range, voxel_size, grid_size, batch_size, strides, window_shapes, drop_infos,
                  keep_frac=None, noise=None, ready=None, dec_sources=None):
-        """``ready``: event recorded after ``points`` (and ``noise``) were produced; the plan stream then waits for that
-        event only and the plan can be built while the main stream is still busy with the previous batch's backward.
-        Without it the plan stream is ordered after everything queued on the main stream so far."""
+        """The plan stream is always ordered after everything queued on the calling stream so far (see the comment below for
+        why that ordering is what keeps the plan tensors safe without ``record_stream``).  ``ready``: an ADDITIONAL event the
+        plan stream waits for - the H2D copy of ``points`` when it was issued on a copy stream the calling stream has not
+        waited for yet."""
         dev = points.device
         main = torch.cuda.current_stream(dev)
         side = PlanPrefetch._side.setdefault(dev.index, torch.cuda.Stream(device=dev))
@@ -373,8 +374,10 @@ class PlanPrefetch:
         # from the plan stream's pool and read by the main stream; once their last reference dies the allocator hands the blocks
         # to LATER plan-stream allocations only, i.e. to a prefetch whose kernels wait here for all main-stream work that could
         # still read them.  (With `record_stream` every freed block cost an event record on the training stream: 130 marker
-        # packets and ~0.5 ms of queue time per step.)  `ready` is accepted for API compatibility.
+        # packets and ~0.5 ms of queue time per step.)  `ready` adds a wait, it never replaces this one.
         side.wait_stream(main)
+        if ready is not None:
+            side.wait_event(ready)
         points.record_stream(side)
         if noise is not None:
             noise.record_stream(side)
@@ -392,6 +395,9 @@ class PlanPrefetch:
 
     def finish(self):
         """-> (VoxelPlan, EncoderPlan); the current (main) stream is ordered after the plan stream."""
+        # invariant behind the missing record_stream calls (see __init__): plan tensors are only ever ALLOCATED on the plan
+        # stream inside __init__ and only ever CONSUMED on the stream that issues the prefetches
+        assert torch.cuda.current_stream() != self.side, "plan tensors must not be consumed on the plan stream"
         self.event.synchronize()
         torch.cuda.current_stream().wait_event(self.event)
         c = self.host.tolist()

@@ -97,10 +97,10 @@ def cfg_from_list(cfg_list, config):
     for dotted, text in zip(cfg_list[0::2], cfg_list[1::2]):
         *parents, leaf = dotted.split('.')
         node = config
-        for name in parents + [leaf]:
-            assert name in node, 'NotFoundKey: %s' % name
-            if name is not leaf:
-                node = node[name]
+        for name in parents:
+            assert isinstance(node, dict) and name in node, 'NotFoundKey: %s' % name
+            node = node[name]
+        assert isinstance(node, dict) and leaf in node, 'NotFoundKey: %s' % leaf
         node[leaf] = _coerce(_parse_scalar(text), node[leaf], dotted, text)
 
 

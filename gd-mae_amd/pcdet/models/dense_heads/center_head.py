@@ -7,8 +7,15 @@ regression maps).  What differs is where the work happens: the reference assigns
 the CPU (numpy Gaussian patches, a D2H + H2D round trip per sample); here ``assign_targets`` is two launches of
 libgdmae_hip.so per head (``gdmae_center_head_targets``), no host transfer.
 
-Evaluation: ``generate_predicted_boxes`` (center_head.py:279-342) decodes the K best heat-map cells
-(model_utils/centernet_utils.py) and runs the rotated NMS of csrc/iou3d_nms.hip through ``model_nms_utils``."""
+IoU-aware variant (``iou`` entry in HEAD_DICT, tools/cfgs/waymo_models/gd_mae_iou.yaml:228-254): an extra regression map
+trained with L1 against 2 * IoU3D(decoded box, ground truth) - 1 at the object cells (loss_utils.py:398-419,
+center_head.py:258-275); at evaluation the scores are rectified as score^(1-a) * iou^a per class before a per-class rotated
+NMS (``multi_class_nms``; model_nms_utils.py:28-46).
+
+Evaluation / RoI path: ``generate_predicted_boxes`` (center_head.py:279-342) takes the K best cells of the flattened
+(class, y, x) heat map, decodes them in ONE launch (``gdmae_center_head_decode``: the reference's
+``decode_bbox_from_heatmap`` gathers every map through transposed copies) and runs the on-device rotated NMS of
+csrc/iou3d_nms.hip."""
 import copy
 
 import torch
@@ -16,7 +23,7 @@ import torch.nn as nn
 from torch.nn.init import kaiming_normal_
 
 from gdmae_hip import lib as L
-from ..model_utils import centernet_utils, model_nms_utils
+from ...ops.iou3d_nms import iou3d_nms_utils
 
 
 class SeparateHead(nn.Module):
@@ -90,8 +97,6 @@ class CenterHead(nn.Module):
             hd['hm'] = dict(out_channels=len(names), num_conv=model_cfg.NUM_HM_CONV)
             self.heads_list.append(SeparateHead(c, hd, init_bias=-2.19, use_bias=use_bias))
         self.with_iou = 'iou' in self.separate_head_cfg.HEAD_DICT
-        if self.with_iou:
-            raise NotImplementedError("IoU-aware head (IoULossCenterNet) is not part of the shipped GD-MAE configs")
         self.predict_boxes_when_training = predict_boxes_when_training
         self.forward_ret_dict = {}
 
@@ -106,7 +111,7 @@ class CenterHead(nn.Module):
         B, n_max, box_dim = gt.shape
         dev = gt.device
         K = int(cfg.NUM_MAX_OBJS)
-        ret = {'heatmaps': [], 'target_boxes': [], 'inds': [], 'masks': []}
+        ret = {'heatmaps': [], 'target_boxes': [], 'iou_boxes': [], 'inds': [], 'masks': []}
         ws = torch.empty(L.load().gdmae_center_head_targets_workspace_bytes(B, K), dtype=torch.uint8, device=dev)
         for h, names in enumerate(self.class_names_each_head):
             key = (h, dev.index)
@@ -116,11 +121,14 @@ class CenterHead(nn.Module):
             tb = torch.empty(B, K, box_dim, dtype=torch.float32, device=dev)
             inds = torch.empty(B, K, dtype=torch.int64, device=dev)
             mask = torch.empty(B, K, dtype=torch.int64, device=dev)
-            L.call("gdmae_center_head_targets", L.ptr(gt), B, n_max, box_dim, L.ptr(self._class_map_dev[key]), len(self.class_names),
+            ib = torch.empty(B, K, 7, dtype=torch.float32, device=dev)
+            L.call("gdmae_center_head_targets_iou", L.ptr(gt), B, n_max, box_dim, L.ptr(self._class_map_dev[key]), len(self.class_names),
                    len(names), L.host_f32([self.point_cloud_range[0], self.point_cloud_range[1]]),
                    L.host_f32([self.voxel_size[0], self.voxel_size[1]]), float(cfg.FEATURE_MAP_STRIDE), fw, fh, K,
-                   float(cfg.GAUSSIAN_OVERLAP), int(cfg.MIN_RADIUS), L.ptr(hm), L.ptr(tb), L.ptr(inds), L.ptr(mask), L.ptr(ws), L.stream())
+                   float(cfg.GAUSSIAN_OVERLAP), int(cfg.MIN_RADIUS), L.ptr(hm), L.ptr(tb), L.ptr(ib), L.ptr(inds), L.ptr(mask), L.ptr(ws),
+                   L.stream())
             ret['heatmaps'].append(hm), ret['target_boxes'].append(tb), ret['inds'].append(inds), ret['masks'].append(mask)
+            ret['iou_boxes'].append(ib)
         return ret
 
     @staticmethod
@@ -140,37 +148,104 @@ class CenterHead(nn.Module):
             loss = loss + hm_loss + loc_loss
             tb_dict['hm_loss_head_%d' % idx] = hm_loss.detach()
             tb_dict['loc_loss_head_%d' % idx] = loc_loss.detach()
+            if self.with_iou:
+                iou_loss = self.iou_loss(pd, targets['masks'][idx], targets['inds'][idx], targets['iou_boxes'][idx]) * w['iou_weight']
+                loss = loss + iou_loss
+                tb_dict['iou_loss_head_%d' % idx] = iou_loss.detach()
         return loss, tb_dict
+
+    def iou_loss(self, pd, mask, ind, box_gt):
+        """L1 between the ``iou`` map at the object cells and 2 * IoU3D(decoded box there, its ground truth) - 1, summed and
+        divided by (number of objects + 1e-4) (loss_utils.py:398-419 on the boxes of center_head.py:258-272).  Only the
+        object cells are decoded (the reference decodes the full (B, 7, H, W) map first); the IoU target carries no gradient."""
+        B, _, H, W = pd['dim'].shape
+        sel = mask.bool()
+        b_idx = torch.arange(B, device=ind.device).view(B, 1).expand_as(ind)[sel]
+        cell = ind[sel]
+
+        def at(name):
+            m = pd[name].float()
+            return m.permute(0, 2, 3, 1).reshape(B, H * W, m.shape[1])[b_idx, cell]
+        pred = at('iou')
+        with torch.no_grad():
+            ctr, cz, dim, rot = at('center'), at('center_z'), at('dim').exp(), at('rot')
+            xs = ((cell % W).to(ctr.dtype) + ctr[:, 0]) * self.feature_map_stride * self.voxel_size[0] + self.point_cloud_range[0]
+            ys = (torch.div(cell, W, rounding_mode='floor').to(ctr.dtype) + ctr[:, 1]) * self.feature_map_stride * self.voxel_size[1] \
+                + self.point_cloud_range[1]
+            boxes = torch.cat([xs[:, None], ys[:, None], cz, dim, torch.atan2(rot[:, 1:2], rot[:, 0:1])], dim=1)
+            gt = box_gt[sel]
+            # IoU of the i-th decoded box with the i-th ground-truth box: the diagonal of the pair matrix
+            target = torch.diagonal(iou3d_nms_utils.boxes_iou3d_gpu(boxes, gt)).unsqueeze(-1) if boxes.shape[0] else pred.detach()
+            target = 2 * target - 1
+        return torch.abs(pred - target).sum() / (sel.sum() + 1e-4)
 
     def generate_predicted_boxes(self, batch_size, pred_dicts):
         cfg = self.model_cfg.POST_PROCESSING
-        dev = pred_dicts[0]['hm'].device
-        limit = torch.tensor(cfg.POST_CENTER_LIMIT_RANGE, dtype=torch.float32, device=dev)
-        ret = [{'pred_boxes': [], 'pred_scores': [], 'pred_labels': []} for _ in range(batch_size)]
+        nms = cfg.NMS_CONFIG
+        if nms.NMS_TYPE not in ('nms_gpu', 'multi_class_nms'):
+            raise NotImplementedError(f"NMS_TYPE {nms.NMS_TYPE} (the reference asserts circle_nms out as 'not checked yet')")
+        K = int(cfg.MAX_OBJ_PER_SAMPLE)
+        per_sample = [([], [], []) for _ in range(batch_size)]
         for idx, pd in enumerate(pred_dicts):
             hm = pd['hm'].float().sigmoid()
-            vel = pd['vel'].float() if 'vel' in self.separate_head_cfg.HEAD_ORDER else None
-            finals = centernet_utils.decode_bbox_from_heatmap(
-                heatmap=hm, rot_cos=pd['rot'][:, 0:1].float(), rot_sin=pd['rot'][:, 1:2].float(), center=pd['center'].float(),
-                center_z=pd['center_z'].float(), dim=pd['dim'].float().exp(), vel=vel, iou=torch.ones_like(hm[:, 0:1]),
-                point_cloud_range=self.point_cloud_range, voxel_size=self.voxel_size, feature_map_stride=self.feature_map_stride,
-                K=cfg.MAX_OBJ_PER_SAMPLE, circle_nms=(cfg.NMS_CONFIG.NMS_TYPE == 'circle_nms'), score_thresh=cfg.SCORE_THRESH,
-                post_center_limit_range=limit)
-            cmap = torch.tensor([self.class_names.index(c) for c in self.class_names_each_head[idx]], dtype=torch.int64, device=dev)
-            for k, fd in enumerate(finals):
-                labels = cmap[fd['pred_labels'].long()]
-                if cfg.NMS_CONFIG.NMS_TYPE != 'nms_gpu':
-                    raise NotImplementedError(cfg.NMS_CONFIG.NMS_TYPE)
-                selected, selected_scores = model_nms_utils.class_agnostic_nms(box_scores=fd['pred_scores'], box_preds=fd['pred_boxes'],
-                                                                               nms_config=cfg.NMS_CONFIG, score_thresh=None)
-                ret[k]['pred_boxes'].append(fd['pred_boxes'][selected])
-                ret[k]['pred_scores'].append(selected_scores)
-                ret[k]['pred_labels'].append(labels[selected])
-        for k in range(batch_size):
-            ret[k]['pred_boxes'] = torch.cat(ret[k]['pred_boxes'], dim=0)
-            ret[k]['pred_scores'] = torch.cat(ret[k]['pred_scores'], dim=0)
-            ret[k]['pred_labels'] = torch.cat(ret[k]['pred_labels'], dim=0) + 1
-        return ret
+            B, C, H, W = hm.shape
+            dev = hm.device
+            f = lambda name: pd[name].float().contiguous()   # noqa: E731
+            vel = f('vel') if 'vel' in self.separate_head_cfg.HEAD_ORDER else None
+            iou = f('iou') if 'iou' in pd else None
+            k = min(K, C * H * W)
+            score, cell = torch.topk(hm.reshape(B, -1), k)             # best cells over all classes, descending
+            boxes = torch.empty(B, k, 9 if vel is not None else 7, dtype=torch.float32, device=dev)
+            labels = torch.empty(B, k, dtype=torch.int32, device=dev)
+            ious = torch.empty(B, k, dtype=torch.float32, device=dev)
+            valid = torch.empty(B, k, dtype=torch.uint8, device=dev)
+            L.call("gdmae_center_head_decode", L.ptr(cell.contiguous()), L.ptr(score.contiguous()), L.ptr(f('center')), L.ptr(f('center_z')),
+                   L.ptr(f('dim')), L.ptr(f('rot')), L.ptr(vel), L.ptr(iou), B, k, H, W,
+                   L.host_f32([self.point_cloud_range[0], self.point_cloud_range[1]]), L.host_f32([self.voxel_size[0], self.voxel_size[1]]),
+                   float(self.feature_map_stride), L.host_f32(list(cfg.POST_CENTER_LIMIT_RANGE)),
+                   float(cfg.SCORE_THRESH if cfg.SCORE_THRESH is not None else 0.0), int(cfg.SCORE_THRESH is not None),
+                   L.ptr(boxes), L.ptr(labels), L.ptr(ious), L.ptr(valid), L.stream())
+            to_global = torch.tensor([self.class_names.index(c) for c in self.class_names_each_head[idx]], dtype=torch.int64, device=dev)
+            for b in range(batch_size):
+                ok = valid[b].bool()
+                bx, sc, lab, q = boxes[b][ok], score[b][ok], to_global[labels[b][ok].long()], ious[b][ok]
+                if nms.NMS_TYPE == 'nms_gpu':
+                    keep = self._nms_one(bx, sc, nms.NMS_THRESH, nms.NMS_PRE_MAXSIZE, nms.NMS_POST_MAXSIZE)
+                else:
+                    # IoU-rectified scores, then one rotated NMS per class (model_nms_utils.py:28-46)
+                    a = sc.new_tensor(list(nms.IOU_RECTIFIER))[lab]
+                    sc = torch.pow(sc, 1 - a) * torch.pow(q, a)
+                    keeps = []
+                    for c in range(len(nms.NMS_THRESH)):
+                        own = (lab == c).nonzero(as_tuple=True)[0]
+                        if own.numel():
+                            keeps.append(own[self._nms_one(bx[own], sc[own], nms.NMS_THRESH[c], nms.NMS_PRE_MAXSIZE[c],
+                                                           nms.NMS_POST_MAXSIZE[c])])
+                    keep = torch.cat(keeps) if keeps else torch.zeros(0, dtype=torch.int64, device=dev)
+                per_sample[b][0].append(bx[keep]), per_sample[b][1].append(sc[keep]), per_sample[b][2].append(lab[keep] + 1)
+        return [{'pred_boxes': torch.cat(p[0]), 'pred_scores': torch.cat(p[1]), 'pred_labels': torch.cat(p[2])} for p in per_sample]
+
+    @staticmethod
+    def _nms_one(boxes, scores, thresh, pre_max, post_max):
+        """Indices (descending score) surviving the rotated NMS of the ``pre_max`` best boxes, at most ``post_max`` of them."""
+        if boxes.shape[0] == 0:
+            return torch.zeros(0, dtype=torch.int64, device=boxes.device)
+        keep, _ = iou3d_nms_utils.nms_gpu(boxes[:, :7], scores, thresh, pre_maxsize=int(pre_max))
+        return keep[:int(post_max)]
+
+    @staticmethod
+    def reorder_rois_for_refining(batch_size, pred_dicts):
+        """Per-sample predictions -> zero-padded (B, n_max, .) RoI tensors for a second stage (center_head.py:344-360; at least
+        one padded row so an empty batch keeps its shape)."""
+        n = max(1, max(int(d['pred_boxes'].shape[0]) for d in pred_dicts))
+        ref = pred_dicts[0]['pred_boxes']
+        rois = ref.new_zeros(batch_size, n, ref.shape[-1])
+        scores = ref.new_zeros(batch_size, n)
+        labels = torch.zeros(batch_size, n, dtype=torch.int64, device=ref.device)
+        for b, d in enumerate(pred_dicts[:batch_size]):
+            m = d['pred_boxes'].shape[0]
+            rois[b, :m], scores[b, :m], labels[b, :m] = d['pred_boxes'], d['pred_scores'], d['pred_labels']
+        return rois, scores, labels
 
     def forward(self, data_dict):
         x = self.shared_conv(data_dict['spatial_features_2d'])
@@ -179,5 +254,12 @@ class CenterHead(nn.Module):
             self.forward_ret_dict['target_dicts'] = self.assign_targets(data_dict['gt_boxes'], feature_map_size=x.shape[2:])
         self.forward_ret_dict['pred_dicts'] = pred_dicts
         if not self.training or self.predict_boxes_when_training:
-            data_dict['final_box_dicts'] = self.generate_predicted_boxes(data_dict['batch_size'], pred_dicts)
+            boxes = self.generate_predicted_boxes(data_dict['batch_size'], pred_dicts)
+            data_dict['cls_preds_normalized'] = True
+            if self.predict_boxes_when_training:      # a RoI head follows (two-stage configs): padded RoI tensors
+                data_dict['rois'], data_dict['roi_scores'], data_dict['roi_labels'] = self.reorder_rois_for_refining(
+                    data_dict['batch_size'], boxes)
+                data_dict['has_class_labels'] = True
+            else:
+                data_dict['final_box_dicts'] = boxes
         return data_dict

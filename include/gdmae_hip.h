@@ -326,6 +326,16 @@ int gdmae_window_attention_levels_bwd(const void* qk, const void* v, const void*
  * summed milliseconds and the number of calls of the forward (which = 0) / backward (which = 1) entry. */
 int gdmae_attention_timing(int on);
 int gdmae_attention_timing_read(int which, double* total_ms, long long* calls);
+/* Generalisation (round 3): measurement slots for every instrumented kernel family of the PRODUCT path - the brackets sit
+ * inside the native layer / stage executors, so what is timed is exactly what the training step launches.  Slots
+ * (gdmae_kernel_timing_name): 0 k_win_attn_fwd, 1 k_win_attn_bwd (all-levels entries), 2 k_tok_gemm (every fused token GEMM
+ * launch incl. k_tok_gemm_multi), 3 k_dw_grouped, 11 k_layer_tail, ...  gdmae_kernel_timing(1) starts collecting (dropping
+ * earlier records), (0) stops; gdmae_kernel_timing_read returns summed milliseconds, call count and the summed ALGORITHMIC
+ * bytes / flops of the bracketed launches (operands read once + results written once, stated next to each bracket). */
+int gdmae_kernel_timing(int on);
+int gdmae_kernel_timing_slots(void);
+const char* gdmae_kernel_timing_name(int slot);
+int gdmae_kernel_timing_read(int slot, double* total_ms, long long* calls, double* bytes, double* flops);
 /* out[0] = sum(term) / sum(weights), out[1] = 1 / sum(weights) (both 0 when no weight is positive): the weighted mean
  * that finishes pytorch3d.loss.chamfer_distance (spt_backbone_mae.py:83-89), one single-workgroup launch. */
 int gdmae_weighted_mean_finish(const float* term, const float* weights, long long n, float* out, void* stream);
@@ -545,6 +555,22 @@ int gdmae_center_head_targets(const float* gt_boxes, int B, int n_max, int box_d
                               int n_cls, const float* pc_range /* host [x0, y0] */, const float* voxel_size /* host [vx, vy] */,
                               float feature_map_stride, int fw, int fh, int num_max_objs, double gaussian_overlap, int min_radius,
                               float* heatmap, float* ret_boxes, long long* inds, long long* mask, void* workspace, void* stream);
+/* The same + iou_boxes (B, num_max_objs, 7) fp32 = the ground-truth box of every assigned slot (zero elsewhere): the target of the
+ * IoU-aware head (center_head.py:118,161; tools/cfgs/waymo_models/gd_mae_iou.yaml:228); null = not wanted. */
+int gdmae_center_head_targets_iou(const float* gt_boxes, int B, int n_max, int box_dim, const int* class_map, int n_class_total,
+                                  int n_cls, const float* pc_range, const float* voxel_size, float feature_map_stride, int fw, int fh,
+                                  int num_max_objs, double gaussian_overlap, int min_radius, float* heatmap, float* ret_boxes,
+                                  float* iou_boxes, long long* inds, long long* mask, void* workspace, void* stream);
+/* Box decoding of a head's K best heat-map cells, one launch (replaces centernet_utils.py:163-260 decode_bbox_from_heatmap and
+ * its _topk / _transpose_and_gather_feat chain; IoU normalisation of center_head.py:296-299).  cell (B, K) int64: flat index
+ * over (class, y, x) of the head's heat map; score (B, K); maps (B, c, H, W) fp32, dim = LOG sizes, rot = [cos, sin], vel / iou
+ * optional (null).  boxes (B, K, 7 | 9) [x, y, z, dx, dy, dz, heading (, vx, vy)], labels (B, K) class inside the head, ious
+ * (B, K) = clamp((iou + 1) / 2, 0, 1) or 1, valid (B, K) = inside post_center_limit_range [and score > score_thresh]. */
+int gdmae_center_head_decode(const long long* cell, const float* score, const float* center, const float* center_z,
+                             const float* dim, const float* rot, const float* vel, const float* iou, int B, int K, int H, int W,
+                             const float* pc_range /* host [x0, y0] */, const float* voxel_size /* host [vx, vy] */,
+                             float feature_map_stride, const float* post_center_limit_range /* host [6] */, float score_thresh,
+                             int use_score_thresh, float* boxes, int* labels, float* ious, unsigned char* valid, void* stream);
 
 /* ---- f4 (next row): rotated BEV IoU and NMS for evaluation ------------------------------------------ *
  * Replace the iou3d_nms CUDA extension (pcdet/ops/iou3d_nms/src/iou3d_nms_kernel.cu:236-414; iou3d_nms.cpp): boxes

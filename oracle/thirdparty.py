@@ -15,7 +15,8 @@ anchored on the reference's call sites only:
 * ``pytorch3d`` (README.md:21)       call site ``pcdet/models/backbones_3d/spt_backbone_mae.py:88``
 
 They are cross-checked in ``tests/test_oracle_thirdparty.py`` against independent formulations
-(dense ``F.conv2d`` on a zero-filled map, ``scatter_reduce``, brute-force ``cdist``).
+(per-site neighbour loops over a coordinate dictionary for the sparse convolutions, per-segment python
+loops for the scatters, brute-force ``cdist`` for the Chamfer distance).
 """
 from __future__ import annotations
 

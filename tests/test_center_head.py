@@ -141,3 +141,109 @@ def test_config_d_training_step(autocast):
         assert torch.isfinite(opt.flat_param).all() and not torch.equal(before, opt.flat_param)
         res.append((float(ret.loss), opt.flat_grad.clone()))
     assert res[0][0] == res[1][0] or autocast            # fp32: deterministic kernels -> identical loss
+
+
+def _iou_head(dev, pcr, vs):
+    from pcdet.models.dense_heads import CenterHead
+    grid = np.round((np.array(pcr[3:6]) - np.array(pcr[0:3])) / np.array(vs)).astype(np.int64)
+    torch.manual_seed(5)
+    head = CenterHead(model_cfg=configs.center_head_iou_cfg(post_range=(pcr[0], pcr[1], -4, pcr[3], pcr[4], 3)), input_channels=32,
+                      num_class=3, class_names=['Vehicle', 'Pedestrian', 'Cyclist'], grid_size=grid,
+                      point_cloud_range=np.array(pcr, dtype=np.float32), voxel_size=list(vs), predict_boxes_when_training=False)
+    return head.to(dev), grid
+
+
+@pytest.mark.gpu
+def test_iou_aware_head_loss_matches_restatement():
+    """IoU-aware CenterHead (tools/cfgs/waymo_models/gd_mae_iou.yaml:228-254; center_head.py:95-104,258-275;
+    loss_utils.py:398-419): the head builds with the extra ``iou`` map, ``iou_boxes`` targets are the ground-truth boxes of the
+    assigned slots, and ``iou_loss_head_0`` equals the reference formula evaluated step by step - full (B, 7, H, W) box map,
+    gather at the object cells, L1 against 2 * IoU3D - 1 with the IoU from the CPU oracle (oracle/iou3d_oracle.py), divided by
+    (number of objects + 1e-4).  The iou branch receives a gradient, the box maps do not get one from this term."""
+    from oracle import iou3d_oracle as orc
+    from tests_golden_boxes import synth_boxes
+    dev = torch.device("cuda:0")
+    pcr, vs = [0, -10.24, -3, 20.48, 10.24, 1], [0.16, 0.16, 4]
+    head, grid = _iou_head(dev, pcr, vs)
+    head.train()
+    assert head.with_iou and 'iou' in dict(head.heads_list[0].named_children())
+    B, H, W = 2, int(grid[1]), int(grid[0])
+    gt = torch.from_numpy(synth_boxes(np.random.default_rng(11), B, 16, np.asarray(pcr, dtype=np.float32), 3)).to(dev)
+    x = torch.randn(B, 32, H, W, device=dev, generator=torch.Generator(device=dev).manual_seed(3)) * 0.5
+    dd = head({"spatial_features_2d": x, "gt_boxes": gt, "batch_size": B})
+    td, pd = head.forward_ret_dict["target_dicts"], head.forward_ret_dict["pred_dicts"][0]
+    mask, ind, ib = td["masks"][0], td["inds"][0], td["iou_boxes"][0]
+    n_obj = int(mask.sum())
+    assert n_obj >= 10
+    # iou_boxes: the k-th box of the head's classes of each sample (all three classes belong to the one head here)
+    for b in range(B):
+        real = gt[b][gt[b, :, 7] > 0]
+        assert torch.equal(ib[b, :real.shape[0]], real[:, :7]) and float(ib[b, real.shape[0]:].abs().sum()) == 0
+    loss, tb = head.get_loss()
+    # ---- the reference's formula, step by step
+    with torch.no_grad():
+        ys, xs = torch.meshgrid(torch.arange(H, device=dev), torch.arange(W, device=dev), indexing="ij")
+        xs = (xs[None, None].float() + pd["center"][:, 0:1].float()) * head.feature_map_stride * vs[0] + pcr[0]
+        ys = (ys[None, None].float() + pd["center"][:, 1:2].float()) * head.feature_map_stride * vs[1] + pcr[1]
+        rot = torch.atan2(pd["rot"][:, 1:2].float(), pd["rot"][:, 0:1].float())
+        box_map = torch.cat([xs, ys, pd["center_z"].float(), pd["dim"].float().exp(), rot], dim=1)          # (B, 7, H, W)
+        flat = box_map.permute(0, 2, 3, 1).reshape(B, H * W, 7)
+        pb = flat.gather(1, ind.unsqueeze(2).expand(B, ind.shape[1], 7))[mask.bool()].cpu().numpy()
+        gb = ib[mask.bool()].cpu().numpy()
+        pred = pd["iou"].float().permute(0, 2, 3, 1).reshape(B, H * W, 1).gather(1, ind.unsqueeze(2))[mask.bool()].cpu().numpy()[:, 0]
+    tgt = np.zeros(n_obj, dtype=np.float64)
+    for i in range(n_obj):
+        a, g = pb[i], gb[i]
+        ov = float(orc.overlap(a, g))
+        h = max(min(a[2] + a[5] / 2, g[2] + g[5] / 2) - max(a[2] - a[5] / 2, g[2] - g[5] / 2), 0.0)
+        o3 = ov * h
+        tgt[i] = 2 * o3 / max(a[3] * a[4] * a[5] + g[3] * g[4] * g[5] - o3, 1e-6) - 1
+    want = np.abs(pred.astype(np.float64) - tgt).sum() / (n_obj + 1e-4)
+    got = float(tb["iou_loss_head_0"])
+    assert abs(got - want) <= 1e-4 * max(want, 1e-6), (got, want)
+    assert abs(float(loss) - float(tb["hm_loss_head_0"] + tb["loc_loss_head_0"] + tb["iou_loss_head_0"])) < 1e-4 * float(loss)
+    loss.backward()
+    g_iou = [p.grad for n, p in head.heads_list[0].iou.named_parameters()]
+    assert all(g is not None and torch.isfinite(g).all() for g in g_iou) and any(float(g.abs().max()) > 0 for g in g_iou)
+
+
+@pytest.mark.gpu
+def test_iou_rectified_multi_class_nms_decode():
+    """Evaluation of the IoU-aware head (center_head.py:296-299,318-322; model_nms_utils.py:28-46): scores are rectified as
+    score^(1 - a_c) * iou^a_c with iou = clamp((map + 1) / 2, 0, 1), NMS runs per class with the class's threshold - an
+    overlapping pair of the SAME class loses its weaker box, an overlapping pair of DIFFERENT classes keeps both - and
+    ``reorder_rois_for_refining`` pads the per-sample results."""
+    dev = torch.device("cuda:0")
+    pcr, vs = [0, -10.24, -3, 20.48, 10.24, 1], [0.16, 0.16, 4]
+    head, grid = _iou_head(dev, pcr, vs)
+    head.eval()
+    B, H, W = 2, int(grid[1]), int(grid[0])
+    pd = {"hm": torch.full((B, 3, H, W), -9.0, device=dev), "center": torch.full((B, 2, H, W), 0.5, device=dev),
+          "center_z": torch.zeros(B, 1, H, W, device=dev), "dim": torch.zeros(B, 3, H, W, device=dev),
+          "rot": torch.zeros(B, 2, H, W, device=dev), "iou": torch.zeros(B, 1, H, W, device=dev)}
+    pd["rot"][:, 0] = 1.0
+    pd["dim"][:, 0], pd["dim"][:, 1], pd["dim"][:, 2] = np.log(4.0), np.log(2.0), np.log(1.5)
+    # sample 0: same-class overlapping pair at (40, 40) / (40, 42): 0.32 m apart, 4 x 2 m boxes -> IoU ~0.85 > 0.8
+    pd["hm"][0, 0, 40, 40], pd["hm"][0, 0, 40, 42] = 3.0, 2.0
+    # different classes on the same spot (60, 60) / (60, 61): both survive
+    pd["hm"][0, 1, 60, 60], pd["hm"][0, 2, 60, 61] = 2.5, 2.4
+    pd["iou"][0, 0, 40, 40], pd["iou"][0, 0, 60, 60], pd["iou"][0, 0, 60, 61] = 0.6, 3.0, -3.0       # -> 0.8, 1 (clamped), 0 (clamped)
+    # sample 1: one isolated box
+    pd["hm"][1, 2, 20, 90] = 1.0
+    pd["iou"][1, 0, 20, 90] = 0.0                                                                      # -> 0.5
+    out = head.generate_predicted_boxes(B, [pd])
+    s = lambda v: 1 / (1 + np.exp(-v))   # noqa: E731
+    a = [0.5, 0.71, 0.65]
+    b0 = {int(l): (float(sc), bx.cpu().numpy()) for l, sc, bx in zip(out[0]["pred_labels"], out[0]["pred_scores"], out[0]["pred_boxes"])}
+    # three survivors: the weaker Vehicle box is suppressed; the Cyclist box keeps its place with a rectified score of 0 (its iou
+    # clamps to 0; neither the reference nor this head re-thresholds after the rectification)
+    assert out[0]["pred_boxes"].shape == (3, 7), out[0]
+    assert b0[3][0] == 0.0
+    assert abs(b0[1][0] - s(3.0) ** (1 - a[0]) * 0.8 ** a[0]) < 1e-5       # the stronger Vehicle box, rectified
+    assert abs(b0[2][0] - s(2.5) ** (1 - a[1]) * 1.0 ** a[1]) < 1e-5       # Pedestrian: iou clamped to 1
+    assert abs(b0[1][1][0] - (40 + 0.5) * 0.16) < 1e-4 and abs(b0[1][1][1] - ((40 + 0.5) * 0.16 - 10.24)) < 1e-4
+    assert out[1]["pred_boxes"].shape == (1, 7) and int(out[1]["pred_labels"][0]) == 3
+    assert abs(float(out[1]["pred_scores"][0]) - s(1.0) ** (1 - a[2]) * 0.5 ** a[2]) < 1e-5
+    rois, scores, labels = head.reorder_rois_for_refining(B, out)
+    assert rois.shape == (B, 2, 7) and float(rois[1, 1].abs().sum()) == 0 and labels.dtype == torch.int64 and int(labels[1, 1]) == 0
+    assert torch.equal(rois[0], out[0]["pred_boxes"]) and torch.equal(scores[1, :1], out[1]["pred_scores"])

@@ -33,3 +33,11 @@ def test_yaml_merge_base_include_and_overrides(tmp_path):
     log.info = lambda m, *a: lines.append(m % a if a else m)
     log_config_to_file(cfg, logger=log)
     assert "cfg.OPT.LR: 0.01" in lines and "\ncfg.DATA.AUG = edict()" in lines and "cfg.DATA.AUG.FLIP: True" in lines
+
+
+def test_cfg_from_list_descends_by_position_not_identity():
+    """'A.A' (CPython interns one-character strings: both parts are the SAME object) must set config['A']['A']."""
+    from pcdet.config import AttrDict, cfg_from_list
+    cfg = AttrDict({'A': AttrDict({'A': 1, 'B': 2}), 'B': 3})
+    cfg_from_list(['A.A', '5', 'B', '7'], cfg)
+    assert cfg.A.A == 5 and cfg.A.B == 2 and cfg.B == 7
