@@ -245,5 +245,5 @@ def test_iou_rectified_multi_class_nms_decode():
     assert out[1]["pred_boxes"].shape == (1, 7) and int(out[1]["pred_labels"][0]) == 3
     assert abs(float(out[1]["pred_scores"][0]) - s(1.0) ** (1 - a[2]) * 0.5 ** a[2]) < 1e-5
     rois, scores, labels = head.reorder_rois_for_refining(B, out)
-    assert rois.shape == (B, 2, 7) and float(rois[1, 1].abs().sum()) == 0 and labels.dtype == torch.int64 and int(labels[1, 1]) == 0
+    assert rois.shape == (B, 3, 7) and float(rois[1, 1:].abs().sum()) == 0 and labels.dtype == torch.int64 and int(labels[1, 1]) == 0
     assert torch.equal(rois[0], out[0]["pred_boxes"]) and torch.equal(scores[1, :1], out[1]["pred_scores"])
