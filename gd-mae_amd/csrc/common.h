@@ -253,3 +253,158 @@ static inline int gd_device_scan(long long n, LoadF load, StoreF store, T* total
   GD_LAUNCH_CHECK();
   return 0;
 }
+
+
+// ------------------------------------------------------------------------------------------
+// Single-launch device-wide exclusive scan (decoupled look-back), same load / store functors as gd_device_scan:
+//   store(i, exclusive_prefix, value) for every i < n;  on_total(grand_total) once, by the last tile (optional work that
+//   used to need a 1-thread "finalize" launch);  total (optional device pointer) receives the grand total.
+// One workgroup = one tile of GD_SCAN_TILE elements; tiles take a ticket (atomic counter), publish their aggregate, look
+// back over their predecessors' aggregates / inclusive prefixes (one wavefront, 64 predecessors per step) and publish their
+// inclusive prefix.  All cross-workgroup words are accessed with RELAXED agent-scope atomics (loads / stores that go past the
+// per-XCD L2) and ordered by hand: a value is stored, the store is waited for (s_waitcnt vmcnt(0)), then its flag
+// is stored; a reader loads the flag and only then the value.  Agent-scope release / acquire fences instead would write back /
+// invalidate the whole L2 of the XCD once per tile (measured: 66-104 us per 1.5 M-element scan instead of ~15).
+// `state`: gd_scan_lb_state_bytes<T>(n) bytes that are ZERO at entry (the callers of the geometry plan clear the states of
+// all their scans with ONE memset); a state must not be reused by a second scan without clearing it.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+struct GdScanWords {
+  static constexpr int N = (sizeof(T) + 7) / 8;
+};
+template <typename T>
+static inline size_t gd_scan_lb_state_bytes(long long n) {
+  const size_t nb = (size_t)gd_div_up(n > 0 ? n : 1, GD_SCAN_TILE);
+  return gd_align(8 + nb * 4) + 2 * gd_align(nb * GdScanWords<T>::N * 8);
+}
+__device__ inline void gd_scan_put(unsigned long long* w, int v) { __hip_atomic_store(w, (unsigned long long)(unsigned)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline void gd_scan_put(unsigned long long* w, unsigned long long v) { __hip_atomic_store(w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline void gd_scan_put(unsigned long long* w, U128 v) {
+  __hip_atomic_store(w, v.a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(w + 1, v.b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline void gd_scan_get(const unsigned long long* w, int& v) { v = (int)(unsigned)__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline void gd_scan_get(const unsigned long long* w, unsigned long long& v) { v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline void gd_scan_get(const unsigned long long* w, U128& v) {
+  v.a = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  v.b = __hip_atomic_load(w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// the value stores above (sc1: past the per-XCD L2) have been acknowledged before the flag store below is issued.  A
+// workgroup-scope release fence emits NO wait on gfx950 (verified in the ISA: the two stores went out back to back and a
+// reader on another XCD saw the flag before the value); an agent-scope one adds an L2 write-back the protocol does not need.
+__device__ inline void gd_scan_store_done() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+struct GdNoTotal {
+  template <typename T>
+  __device__ void operator()(T) const {}
+};
+
+template <typename T, typename LoadF, typename StoreF, typename TotalF>
+__global__ __launch_bounds__(GD_SCAN_BLOCK) void gd_scan_lb_kernel(long long n, LoadF load, StoreF store, TotalF on_total, T* total,
+                                                                  unsigned* ticket, unsigned* flags, unsigned long long* agg,
+                                                                  unsigned long long* incl) {
+  constexpr int W = GdScanWords<T>::N;
+  __shared__ T smem[GD_SCAN_BLOCK / GD_WAVE + 1];
+  __shared__ unsigned s_tile;
+  __shared__ T s_excl;
+  if (threadIdx.x == 0) s_tile = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  const unsigned tile = s_tile;
+  const unsigned nb = gridDim.x;
+  const long long base = (long long)tile * GD_SCAN_TILE;
+  T vals[GD_SCAN_ITEMS];
+  T acc = gd_zero<T>();
+  if (base + GD_SCAN_TILE <= n) {      // full tile: no per-element bounds branch, the loads of a thread go out together
+#pragma unroll
+    for (int k = 0; k < GD_SCAN_ITEMS; ++k) vals[k] = load(base + (long long)threadIdx.x * GD_SCAN_ITEMS + k);
+  } else {
+#pragma unroll
+    for (int k = 0; k < GD_SCAN_ITEMS; ++k) {
+      const long long i = base + (long long)threadIdx.x * GD_SCAN_ITEMS + k;
+      vals[k] = (i < n) ? load(i) : gd_zero<T>();
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < GD_SCAN_ITEMS; ++k) acc = acc + vals[k];
+  T tot;
+  const T ex = gd_block_exclusive_scan<T, GD_SCAN_BLOCK>(acc, tot, smem);
+  // ---- publish the aggregate, look back, publish the inclusive prefix (wavefront 0)
+  if (threadIdx.x < GD_WAVE) {
+    const int lane = threadIdx.x;
+    T excl = gd_zero<T>();
+    if (tile == 0) {
+      if (lane == 0) {
+        gd_scan_put(incl, tot);
+        gd_scan_store_done();
+        __hip_atomic_store(flags, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    } else {
+      if (lane == 0) {
+        gd_scan_put(agg + (size_t)tile * W, tot);
+        gd_scan_store_done();
+        __hip_atomic_store(flags + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      long long hi = (long long)tile - 1;      // newest predecessor not yet accounted for
+      while (true) {
+        const long long j = hi - lane;         // lane 0 looks at the nearest predecessor
+        unsigned f = 2u;
+        if (j >= 0) {
+          while ((f = __hip_atomic_load(flags + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u) __builtin_amdgcn_s_sleep(1);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        // nearest lane whose predecessor already has an inclusive prefix: everything beyond it is covered by that prefix
+        const unsigned long long done = __ballot(f == 2u);
+        const int stop = __ffsll((long long)done) - 1;          // -1: none among these 64
+        T part = gd_zero<T>();
+        if (j >= 0 && (stop < 0 || lane <= stop)) {
+          if (f == 2u) gd_scan_get(incl + (size_t)j * W, part);
+          else gd_scan_get(agg + (size_t)j * W, part);
+        }
+        // ordered sum over the lanes (lane 0 = nearest tile; the order only matters for the association of T = U128 / int sums,
+        // which are exact anyway)
+#pragma unroll
+        for (int d = GD_WAVE / 2; d > 0; d >>= 1) {
+          T o = gd_shfl(part, (lane + d) & (GD_WAVE - 1));
+          if (lane + d < GD_WAVE) part = part + o;
+        }
+        part = gd_shfl(part, 0);
+        excl = excl + part;
+        if (stop >= 0) break;
+        hi -= GD_WAVE;
+      }
+      if (lane == 0) {
+        gd_scan_put(incl + (size_t)tile * W, excl + tot);
+        gd_scan_store_done();
+        __hip_atomic_store(flags + tile, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    if (lane == 0) {
+      s_excl = excl;
+      if (tile == nb - 1) {
+        if (total) *total = excl + tot;
+        on_total(excl + tot);
+      }
+    }
+  }
+  __syncthreads();
+  T run = s_excl + ex;
+#pragma unroll
+  for (int k = 0; k < GD_SCAN_ITEMS; ++k) {
+    const long long i = base + (long long)threadIdx.x * GD_SCAN_ITEMS + k;
+    if (i < n) store(i, run, vals[k]);
+    run = run + vals[k];
+  }
+}
+
+template <typename T, typename LoadF, typename StoreF, typename TotalF>
+static inline int gd_device_scan_lb(long long n, LoadF load, StoreF store, TotalF on_total, T* total, void* state, hipStream_t st) {
+  const int nb = gd_div_up(n > 0 ? n : 1, GD_SCAN_TILE);
+  char* p = (char*)state;
+  unsigned* ticket = (unsigned*)p;
+  unsigned* flags = (unsigned*)(p + 8);
+  unsigned long long* agg = (unsigned long long*)(p + gd_align(8 + (size_t)nb * 4));
+  unsigned long long* incl = (unsigned long long*)((char*)agg + gd_align((size_t)nb * GdScanWords<T>::N * 8));
+  hipLaunchKernelGGL((gd_scan_lb_kernel<T, LoadF, StoreF, TotalF>), dim3(nb), dim3(GD_SCAN_BLOCK), 0, st, n, load, store, on_total, total,
+                     ticket, flags, agg, incl);
+  GD_LAUNCH_CHECK();
+  return 0;
+}

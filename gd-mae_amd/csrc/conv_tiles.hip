@@ -127,6 +127,27 @@ extern "C" int gdmae_decoder_tiles(const int* const* maps, const int* strides, i
   return gd_device_scan<int>(nt, CtFlagLoad{flag}, CtSlotStore{tile_slot, tile_list}, n_act, scan_ws, st);
 }
 
+// The same with the single-launch scan (geometry plan, plan.hip): flag (nt ints) + a ZEROED look-back state of
+// gd_decoder_tiles_lb_state_bytes(nt) bytes; two launches.
+size_t gd_decoder_tiles_lb_state_bytes(long long nt) { return gd_scan_lb_state_bytes<int>(nt); }
+int gd_decoder_tiles_lb(const int* const* maps, const int* strides, int k, int B, int H, int W, int* tile_slot, int* tile_list, int* n_act,
+                        int* flag, void* lb_state, hipStream_t st) {
+  GD_REQUIRE(k >= 1 && k <= CT_MAX_SRC, "decoder_tiles: 1..3 source stages");
+  CtMaps Mp;
+  Mp.k = k;
+  for (int g = 0; g < k; ++g) {
+    const int s = strides[g];
+    GD_REQUIRE((s == 1 || s == 2 || s == 4 || s == 8) && H % s == 0 && W % s == 0, "decoder_tiles: stride must be 1, 2, 4 or 8 and divide the map");
+    Mp.map[g] = maps[g];
+    Mp.ls[g] = s == 1 ? 0 : (s == 2 ? 1 : (s == 4 ? 2 : 3));
+  }
+  const int TH = (H + 7) / 8, TW = (W + 7) / 8;
+  const long long nt = (long long)B * TH * TW;
+  hipLaunchKernelGGL(k_ct_tile_flags, dim3(gd_div_up(nt, 4)), dim3(256), 0, st, Mp, B, H, W, TH, TW, flag);
+  GD_LAUNCH_CHECK();
+  return gd_device_scan_lb<int>(nt, CtFlagLoad{flag}, CtSlotStore{tile_slot, tile_list}, GdNoTotal{}, n_act, lb_state, st);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Per-step preparation: weights in MFMA-fragment order, background row, border-class constants
 // ------------------------------------------------------------------------------------------------

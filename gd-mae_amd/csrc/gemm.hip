@@ -60,6 +60,7 @@ typedef std::tuple<int, int, int, int, int, int, int, int, int, int, int, int, i
 
 hipblasLtHandle_t g_lt = nullptr;
 std::map<GemmKey, GemmPlan> g_plans;
+long long g_gemm_calls = 0, g_gemm_tuned = 0;     // gdmae_gemm_stats: library GEMM calls / plans created (first use of a shape bucket)
 std::mutex g_lt_mu;
 
 #define LT_CHECK(x)                                                         \
@@ -80,17 +81,27 @@ int gd_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const void* A
   if (!g_lt) LT_CHECK(hipblasLtCreate(&g_lt));
   // loose shapes: extents are bucketed to 3 significant bits (<= 25 % apart; extents <= 64 to multiples of 16), so the
   // number of cached (and timed) plans stays bounded whatever token / point / site counts the batches have
+  // ... and the LONG extents (token / point / site counts, which change with every batch and - through the random mask - with
+  // every step) to the next power of two: a tall-skinny product's best algorithm hardly depends on how tall it is, while every
+  // new key costs a candidate timing with stream synchronisation (measured: 7 new keys in 40 steps of fresh batches = +0.7 ms
+  // per step with the 3-bit buckets; none after the first step with these)
   auto bucket = [loose](int x) {
     if (!loose) return x;
     if (x <= 64) return (x + 15) / 16 * 16;
     int g = 1;
+    if (x > 2048) {
+      while (g < x) g <<= 1;
+      return g;
+    }
     while ((g << 3) < x) g <<= 1;      // g = 2^(floor(log2(x-1)) - 2)
     return (x + g - 1) / g * g;
   };
   const GemmKey key((int)ta, (int)tb, bucket(M), bucket(N), bucket(K), lda, ldb, ldc, (int)tab, (int)tc, bias ? 1 : 0, batch,
                     loose ? 1 : 0);
   auto it = g_plans.find(key);
+  ++g_gemm_calls;
   if (it == g_plans.end()) {
+    ++g_gemm_tuned;
     GemmPlan p;
     LT_CHECK(hipblasLtMatmulDescCreate(&p.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F));
     const int32_t opa = ta ? HIPBLAS_OP_T : HIPBLAS_OP_N, opb = tb ? HIPBLAS_OP_T : HIPBLAS_OP_N;
@@ -253,6 +264,14 @@ int gd_splitk_acc(hipStream_t st, const float* part, int S, long long P, float* 
 // row-major C-ABI entry points
 // ------------------------------------------------------------------------------------------
 extern "C" size_t gdmae_gemm_workspace_bytes(void) { return GD_LT_WORKSPACE; }
+
+// calls[0] = library GEMM calls so far, calls[1] = algorithm plans created so far (each = first use of a shape bucket: candidate
+// timing with stream synchronisation): a training loop is in its steady state once calls[1] stops growing
+extern "C" int gdmae_gemm_stats(long long* calls) {
+  calls[0] = g_gemm_calls;
+  calls[1] = g_gemm_tuned;
+  return 0;
+}
 
 extern "C" int gdmae_gemm(const void* A, const void* B, void* C, long long M, long long N, long long K, int trans_a, int trans_b,
                           int ab_bf16, int c_f32, const void* bias, void* workspace, void* stream) {

@@ -16,6 +16,106 @@ __device__ inline unsigned gd_fkey(float f) {
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
+// digit of the k-th smallest key among the histogram's entries, by ONE wavefront (4 bins per lane + wave scan) instead of a
+// 256-step serial walk by one thread (each step a dependent LDS read: ~8 us per radix pass)
+__device__ inline void mask_pick_digit(const unsigned* hist, unsigned prefix, int shift, unsigned* s_prefix, int* s_k) {
+  const int lane = threadIdx.x;
+  if (lane >= GD_WAVE) return;
+  const int k = *s_k;
+  const unsigned h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+  const int mine = (int)(h0 + h1 + h2 + h3);
+  const int incl = gd_wave_inclusive_scan(mine);
+  const int excl = incl - mine;
+  const unsigned long long hit = __ballot(incl >= k);           // first lane whose cumulative count reaches k
+  const int first = __ffsll((long long)hit) - 1;
+  if (lane == first) {
+    int cum = excl, d = 4 * lane;
+    const unsigned h[4] = {h0, h1, h2, h3};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (cum + (int)h[q] >= k) {
+        d = 4 * lane + q;
+        break;
+      }
+      cum += (int)h[q];
+    }
+    *s_prefix = prefix | ((unsigned)d << shift);
+    *s_k = k - cum;
+  }
+}
+
+constexpr int kMaskKpt = 16;     // keys a thread keeps in registers: samples up to 16 K pillars read the noise once
+
+template <bool CACHED>
+__device__ inline void mask_select_body(const float* __restrict__ noise, int off, int L, int len_keep, float* __restrict__ mask,
+                                        unsigned* hist, unsigned* s_prefix, int* s_k, int* s_scan) {
+  const int tid = threadIdx.x;
+  unsigned kreg[CACHED ? kMaskKpt : 1];
+  if (CACHED) {
+#pragma unroll
+    for (int r = 0; r < kMaskKpt; ++r) {
+      const int i = r * 1024 + tid;
+      kreg[r] = i < L ? gd_fkey(noise[off + i]) : 0u;
+    }
+  }
+  if (tid == 0) {
+    *s_prefix = 0u;
+    *s_k = len_keep;
+  }
+  for (int pass = 0; pass < 4; ++pass) {
+    const int shift = 24 - 8 * pass;
+    const unsigned hi_mask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
+    if (tid < 256) hist[tid] = 0u;
+    __syncthreads();
+    const unsigned prefix = *s_prefix;
+    if (CACHED) {
+#pragma unroll
+      for (int r = 0; r < kMaskKpt; ++r) {
+        const int i = r * 1024 + tid;
+        if (i < L && (kreg[r] & hi_mask) == prefix) atomicAdd(&hist[(kreg[r] >> shift) & 255u], 1u);
+      }
+    } else {
+      for (int i = tid; i < L; i += 1024) {
+        const unsigned u = gd_fkey(noise[off + i]);
+        if ((u & hi_mask) == prefix) atomicAdd(&hist[(u >> shift) & 255u], 1u);
+      }
+    }
+    __syncthreads();
+    mask_pick_digit(hist, prefix, shift, s_prefix, s_k);
+    __syncthreads();
+  }
+  const unsigned thr = *s_prefix;
+  const int ties_to_keep = *s_k;  // >= 1
+  int carry = 0;
+  const int rounds = (L + 1023) / 1024;
+  for (int r = 0; r < rounds; ++r) {
+    const int i = r * 1024 + tid;
+    unsigned u = 0xFFFFFFFFu;
+    if (i < L) {
+      if (CACHED) {
+        u = 0u;
+#pragma unroll
+        for (int q = 0; q < kMaskKpt; ++q) u = q == r ? kreg[q] : u;
+      } else {
+        u = gd_fkey(noise[off + i]);
+      }
+    }
+    const int eq = (i < L && u == thr) ? 1 : 0;
+    // exact ties with the threshold are rare: the ordered scan only runs for the chunks that contain one
+    const int n_eq = __syncthreads_count(eq);
+    int ord = carry;
+    if (n_eq > 0) {
+      int tot;
+      ord = carry + gd_block_exclusive_scan<int, 1024>(eq, tot, s_scan);
+      carry += tot;
+    }
+    if (i < L) {
+      const bool keep = (u < thr) || (eq && ord < ties_to_keep);
+      mask[off + i] = keep ? 0.f : 1.f;
+    }
+  }
+}
+
 __global__ __launch_bounds__(1024) void k_mask_select(const float* __restrict__ noise,
                                                       const int* __restrict__ sample_off, double keep_frac,
                                                       float* __restrict__ mask, int* __restrict__ len_keep_out) {
@@ -33,51 +133,8 @@ __global__ __launch_bounds__(1024) void k_mask_select(const float* __restrict__ 
     for (int i = threadIdx.x; i < L; i += blockDim.x) mask[off + i] = v;
     return;
   }
-  if (threadIdx.x == 0) {
-    s_prefix = 0u;
-    s_k = len_keep;
-  }
-  for (int pass = 0; pass < 4; ++pass) {
-    const int shift = 24 - 8 * pass;
-    const unsigned hi_mask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
-    if (threadIdx.x < 256) hist[threadIdx.x] = 0u;
-    __syncthreads();
-    const unsigned prefix = s_prefix;
-    for (int i = threadIdx.x; i < L; i += blockDim.x) {
-      unsigned u = gd_fkey(noise[off + i]);
-      if ((u & hi_mask) == prefix) atomicAdd(&hist[(u >> shift) & 255u], 1u);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      int k = s_k;
-      unsigned cum = 0u;
-      for (int d = 0; d < 256; ++d) {
-        unsigned h = hist[d];
-        if ((int)(cum + h) >= k) {
-          s_prefix = prefix | ((unsigned)d << shift);
-          s_k = k - (int)cum;
-          break;
-        }
-        cum += h;
-      }
-    }
-    __syncthreads();
-  }
-  const unsigned thr = s_prefix;
-  const int ties_to_keep = s_k;  // >= 1
-  int carry = 0;
-  for (int base = 0; base < L; base += blockDim.x) {
-    const int i = base + threadIdx.x;
-    unsigned u = i < L ? gd_fkey(noise[off + i]) : 0xFFFFFFFFu;
-    const int eq = (i < L && u == thr) ? 1 : 0;
-    int tot;
-    const int ord = carry + gd_block_exclusive_scan<int, 1024>(eq, tot, s_scan);
-    carry += tot;
-    if (i < L) {
-      const bool keep = (u < thr) || (eq && ord < ties_to_keep);
-      mask[off + i] = keep ? 0.f : 1.f;
-    }
-  }
+  if (L <= kMaskKpt * 1024) mask_select_body<true>(noise, off, L, len_keep, mask, hist, &s_prefix, &s_k, s_scan);
+  else mask_select_body<false>(noise, off, L, len_keep, mask, hist, &s_prefix, &s_k, s_scan);
 }
 
 // noise: (M,) one value per pillar, pillars grouped by sample (sample_pillar_off from gdmae_voxelize)

@@ -343,3 +343,266 @@ extern "C" int gdmae_window_partition(const int* map, int B, int Y, int X, int w
   GD_LAUNCH_CHECK();
   return 0;
 }
+
+
+// ==========================================================================================
+// Geometry-plan variants (plan.hip): the same index structures with single-launch scans (gd_device_scan_lb, ZEROED states
+// provided by the caller) and fewer, merged launches.  Outputs are bit-identical to the entry points above.
+// ==========================================================================================
+
+// stage-1 tokens by a scan over the CELLS (pillars are in ascending cell order, so the token order is the same): the map is
+// written for every cell - no memset - and the pillar list is not touched
+struct VisCellLoad {
+  const float* mask;
+  const int* cell2pillar;
+  __device__ int operator()(long long c) const {
+    const int p = cell2pillar[c];
+    const float m = mask[p < 0 ? 0 : p];          // unconditional: the loads of a thread's 16 cells go out together
+    return (int)(p >= 0) & (int)(m == 0.f);
+  }
+};
+struct VisCellStore {
+  const int* cell2pillar;
+  int* tok_pillar;
+  int* tok_cell;
+  int* map;
+  __device__ void operator()(long long c, int ex, int v) const {
+    map[c] = v ? ex : -1;
+    if (v) {
+      tok_pillar[ex] = cell2pillar[c];
+      tok_cell[ex] = (int)c;
+    }
+  }
+};
+size_t gd_plan_scan_state_bytes(long long n) { return gd_scan_lb_state_bytes<int>(n); }
+size_t gd_plan_win_state_bytes(long long n) { return gd_scan_lb_state_bytes<U128>(n); }
+
+int gd_plan_visible_tokens(const float* mask, const int* cell2pillar, long long n_cells, int* tok_pillar, int* tok_cell, int* map,
+                           int* n_tok, void* lb_state, hipStream_t st) {
+  return gd_device_scan_lb<int>(n_cells, VisCellLoad{mask, cell2pillar}, VisCellStore{cell2pillar, tok_pillar, tok_cell, map}, GdNoTotal{},
+                                n_tok, lb_state, st);
+}
+
+// strided conv k3 s2 p1 output set by a scan over the OUTPUT cells: a cell is active iff one of its 9 input taps is (no flag
+// array, no marking pass)
+struct DownLoad {
+  const int* map_in;
+  Dims di, dn;
+  __device__ int operator()(long long c) const {
+    const int ci = (int)c;                      // 32-bit divisions
+    const int ox = ci % dn.X;
+    const int r = ci / dn.X;
+    const int oy = r % dn.Y, b = r / dn.Y;
+    // nine independent lookups (clamped addresses, validity applied afterwards): all loads of a thread's items are in flight
+    // together instead of one dependent branch per tap
+    const int* m = map_in + (long long)b * di.Y * di.X;
+    int any = 0;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = 2 * oy - 1 + ky;
+      const int cy = iy < 0 ? 0 : (iy >= di.Y ? di.Y - 1 : iy);
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = 2 * ox - 1 + kx;
+        const int cx = ix < 0 ? 0 : (ix >= di.X ? di.X - 1 : ix);
+        const int v = m[(long long)cy * di.X + cx];
+        any |= (int)(v >= 0 && iy == cy && ix == cx);
+      }
+    }
+    return any;
+  }
+};
+int gd_plan_downsample(const int* map_in, int B, int Yi, int Xi, int* tok_cell_out, int* map_out, int* n_out, void* lb_state,
+                       hipStream_t st) {
+  Dims di{B, Yi, Xi};
+  Dims dn{B, (Yi + 2 - 3) / 2 + 1, (Xi + 2 - 3) / 2 + 1};
+  const long long cells = (long long)B * dn.Y * dn.X;
+  return gd_device_scan_lb<int>(cells, DownLoad{map_in, di, dn}, FlagStore{tok_cell_out, map_out}, GdNoTotal{}, n_out, lb_state, st);
+}
+
+// all index tables of a stage in ONE launch (blockIdx.y = job): rulebooks (mode 0 / 1 / 2 of k_rulebook, optionally with the
+// tap-reversed copy nbr_rev[t][8 - k] = nbr[t][k] - the transposed submanifold rulebook) and the full-resolution sites under the
+// tokens of a strided stage (mode 3: out[t * s * s + dy * s + dx] = ((b * Y s + y s + dy) * X s + x s + dx))
+struct PlanJob {
+  const int* n_tok;
+  const int* tok_cell;
+  Dims dt, dm;
+  const int* map;
+  int mode, s;
+  int* nbr;
+  int* nbr_rev;
+};
+struct PlanJobs {
+  PlanJob j[4];
+  int count;
+};
+__global__ __launch_bounds__(256) void k_plan_jobs(PlanJobs J) {
+  const PlanJob& q = J.j[blockIdx.y];
+  const int n = *q.n_tok;
+  if (q.mode == 3) {
+    const int ss = q.s * q.s;
+    const long long total = (long long)n * ss;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+      const int t = (int)(i / ss), e = (int)(i % ss);
+      const int c = q.tok_cell[t];
+      const int x = c % q.dt.X, r = c / q.dt.X, y = r % q.dt.Y, b = r / q.dt.Y;
+      q.nbr[i] = (b * (q.dt.Y * q.s) + y * q.s + e / q.s) * (q.dt.X * q.s) + x * q.s + e % q.s;
+    }
+    return;
+  }
+  const long long total = (long long)n * 9;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int t = (int)(i / 9), k = (int)(i % 9);
+    const int ky = k / 3, kx = k % 3;
+    const int c = q.tok_cell[t];
+    const int x = c % q.dt.X, r = c / q.dt.X, y = r % q.dt.Y, b = r / q.dt.Y;
+    int my, mx;
+    bool ok = true;
+    if (q.mode == 0) {
+      my = y + ky - 1;
+      mx = x + kx - 1;
+    } else if (q.mode == 1) {
+      my = 2 * y - 1 + ky;
+      mx = 2 * x - 1 + kx;
+    } else {
+      const int ty = y + 1 - ky, tx = x + 1 - kx;
+      ok = !(ty & 1) && !(tx & 1) && ty >= 0 && tx >= 0;
+      my = ty >> 1;
+      mx = tx >> 1;
+    }
+    ok = ok && my >= 0 && my < q.dm.Y && mx >= 0 && mx < q.dm.X;
+    const int v = ok ? q.map[(b * q.dm.Y + my) * q.dm.X + mx] : -1;
+    q.nbr[i] = v;
+    if (q.nbr_rev) q.nbr_rev[(long long)t * 9 + (8 - k)] = v;
+  }
+}
+int gd_plan_jobs(const PlanJobs& J, long long cap_max, hipStream_t st) {
+  if (J.count <= 0) return 0;
+  int grid = gd_div_up((cap_max > 0 ? cap_max : 1) * 9, 256);
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(k_plan_jobs, dim3(grid, J.count), dim3(256), 0, st, J);
+  GD_LAUNCH_CHECK();
+  return 0;
+}
+
+// both shifts of a stage's window partition: one count launch, one scan per shift (totals written by the scan's last tile),
+// one fill launch
+struct WinPair {
+  WinParams P[2];
+  int* win_cnt[2];
+  int* win_dense[2];
+  int* win_tokpre[2];
+  int* counts[2];
+  int *tok_win[2], *tok_level[2], *tok_slot[2], *tok_pos[2], *csr_tok[2], *win_start[2], *win_len[2];
+};
+__global__ __launch_bounds__(256) void k_win_count2(WinPair Q, const int* __restrict__ map, int n_win) {
+  const int lane = threadIdx.x & (GD_WAVE - 1);
+  const int wib = threadIdx.x / GD_WAVE;
+  const int sh = blockIdx.y;
+  for (int w = blockIdx.x * 4 + wib; w < n_win; w += gridDim.x * 4) {
+    int ref;
+    const int t = win_token(Q.P[sh], map, w, lane, ref);
+    const unsigned long long m = __ballot(t >= 0);
+    if (lane == 0) Q.win_cnt[sh][w] = __popcll(m);
+  }
+}
+struct WinTotal {
+  int* counts;
+  __device__ void operator()(U128 total) const {
+    int nw = 0, nt = 0;
+    for (int l = 0; l < 3; ++l) {
+      const int a = (int)((total.a >> (21 * l)) & 0x1FFFFFull);
+      const int b = (int)((total.b >> (21 * l)) & 0x1FFFFFull);
+      counts[l] = a;
+      counts[3 + l] = b;
+      nw += a;
+      nt += b;
+    }
+    counts[6] = nw;
+    counts[7] = nt;
+  }
+};
+__global__ __launch_bounds__(256) void k_win_fill2(WinPair Q, const int* __restrict__ map, int n_win) {
+  const int lane = threadIdx.x & (GD_WAVE - 1);
+  const int wib = threadIdx.x / GD_WAVE;
+  const int sh = blockIdx.y;
+  const WinParams& P = Q.P[sh];
+  const int* counts = Q.counts[sh];
+  for (int w = blockIdx.x * 4 + wib; w < n_win; w += gridDim.x * 4) {
+    const int cnt = Q.win_cnt[sh][w];
+    if (cnt <= 0) continue;
+    const int l = win_level(P, cnt);
+    if (l < 0) continue;
+    int ref;
+    const int t = win_token(P, map, w, lane, ref);
+    const unsigned long long m = __ballot(t >= 0);
+    int wbase = 0, tbase = 0;
+    for (int q = 0; q < l; ++q) {
+      wbase += counts[q];
+      tbase += counts[3 + q];
+    }
+    const int d = Q.win_dense[sh][w];
+    const int start = tbase + Q.win_tokpre[sh][w];
+    if (lane == 0) {
+      Q.win_start[sh][wbase + d] = start;
+      Q.win_len[sh][wbase + d] = cnt;
+    }
+    if (t >= 0) {
+      const int r = __popcll(m & ((1ull << lane) - 1ull));
+      Q.csr_tok[sh][start + r] = t;
+      Q.tok_win[sh][t] = ref;
+      Q.tok_level[sh][t] = l;
+      Q.tok_slot[sh][t] = d * P.T[l] + r;
+      Q.tok_pos[sh][t] = lane;
+    }
+  }
+}
+size_t gd_plan_windows_ws_bytes(int B, int Y, int X, int wx, int wy) {
+  const long long n = (long long)B * ((X + wx - 1) / wx + 1) * ((Y + wy - 1) / wy + 1);
+  return 2 * 3 * gd_align(sizeof(int) * n);
+}
+long long gd_plan_n_windows(int B, int Y, int X, int wx, int wy) { return (long long)B * ((X + wx - 1) / wx + 1) * ((Y + wy - 1) / wy + 1); }
+// out[sh][7]: tok_win, tok_level, tok_slot, tok_pos, csr_tok, win_start, win_len; counts[sh]: int[8]; lb_state: two ZEROED
+// gd_plan_win_state_bytes(n_win) states
+int gd_plan_windows(const int* map, int B, int Y, int X, int wx, int wy, int nlev, const int* drop_lo, const int* drop_hi,
+                    const int* max_tokens, int* const out[2][7], int* const counts[2], void* workspace, void* lb_state, hipStream_t st) {
+  GD_REQUIRE(wx * wy <= GD_WAVE && wx > 0 && wy > 0, "window must fit one wavefront (wx*wy <= 64)");
+  GD_REQUIRE(nlev >= 1 && nlev <= 3, "1..3 drop levels");
+  WinPair Q;
+  const long long n_win = gd_plan_n_windows(B, Y, X, wx, wy);
+  GD_REQUIRE(n_win < (1 << 21), "window grid too large for the packed scan");
+  GdArena A(workspace, gd_plan_windows_ws_bytes(B, Y, X, wx, wy));
+  for (int sh = 0; sh < 2; ++sh) {
+    WinParams& P = Q.P[sh];
+    P.B = B; P.Y = Y; P.X = X; P.wx = wx; P.wy = wy;
+    P.sx = sh ? wx / 2 : wx;   // sst_utils.py:19-22: the un-shifted pass adds a full window
+    P.sy = sh ? wy / 2 : wy;
+    P.nwx = (X + wx - 1) / wx + 1;
+    P.nwy = (Y + wy - 1) / wy + 1;
+    P.nwz = 2;
+    P.nlev = nlev;
+    for (int l = 0; l < 3; ++l) {
+      P.lo[l] = l < nlev ? drop_lo[l] : 0;
+      P.hi[l] = l < nlev ? drop_hi[l] : 0;
+      P.T[l] = l < nlev ? max_tokens[l] : 0;
+    }
+    Q.win_cnt[sh] = A.take<int>(n_win);
+    Q.win_dense[sh] = A.take<int>(n_win);
+    Q.win_tokpre[sh] = A.take<int>(n_win);
+    Q.counts[sh] = counts[sh];
+    Q.tok_win[sh] = out[sh][0]; Q.tok_level[sh] = out[sh][1]; Q.tok_slot[sh] = out[sh][2]; Q.tok_pos[sh] = out[sh][3];
+    Q.csr_tok[sh] = out[sh][4]; Q.win_start[sh] = out[sh][5]; Q.win_len[sh] = out[sh][6];
+  }
+  int grid = gd_div_up(n_win, 4);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(k_win_count2, dim3(grid, 2), dim3(256), 0, st, Q, map, (int)n_win);
+  GD_LAUNCH_CHECK();
+  for (int sh = 0; sh < 2; ++sh) {
+    int rc = gd_device_scan_lb<U128>(n_win, WinLoad{Q.P[sh], Q.win_cnt[sh]}, WinStore{Q.win_dense[sh], Q.win_tokpre[sh]},
+                                     WinTotal{counts[sh]}, (U128*)nullptr, (char*)lb_state + sh * gd_plan_win_state_bytes(n_win), st);
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(k_win_fill2, dim3(grid, 2), dim3(256), 0, st, Q, map, (int)n_win);
+  GD_LAUNCH_CHECK();
+  return 0;
+}

@@ -38,10 +38,32 @@ __device__ inline bool vox_coord(float p, float lo, float vs, int g, int& c) {
   return ok;
 }
 
+// Point chunk of a workgroup: chunks are dealt so that the workgroups of one XCD (blockIdx % 8; gridDim.x is a multiple of 8)
+// walk ONE contiguous eighth of the point array.  Frames are concatenated in the batch, cells are keyed frame-major, so the
+// atomic counters (and later the cell tables) a workgroup touches belong to one XCD's L2 instead of bouncing between all eight
+// (k_point_keys: 108 -> ~50 us for 1.44 M points).
+#define VOX_FOR_POINTS(i, n0)                                                                                         \
+  const long long per8_ = ((n0) + 7) / 8;                                                                             \
+  const long long lo8_ = (long long)(blockIdx.x & 7) * per8_;                                                         \
+  const long long hi8_ = lo8_ + per8_ < (n0) ? lo8_ + per8_ : (n0);                                                   \
+  for (long long i = lo8_ + (long long)(blockIdx.x >> 3) * blockDim.x + threadIdx.x; i < hi8_;                        \
+       i += (long long)(gridDim.x >> 3) * blockDim.x)
+
+__global__ __launch_bounds__(256) void k_zero_cells(int* __restrict__ cell_cnt, long long cells, int* __restrict__ big) {
+  const long long per8 = ((cells + 7) / 8 + 3) & ~3ll;
+  const long long lo = (long long)(blockIdx.x & 7) * per8;
+  const long long hi = lo + per8 < cells ? lo + per8 : cells;
+  for (long long i = lo + ((long long)(blockIdx.x >> 3) * blockDim.x + threadIdx.x) * 4; i < hi; i += (long long)(gridDim.x >> 3) * blockDim.x * 4) {
+    if (i + 4 <= hi) *reinterpret_cast<int4*>(cell_cnt + i) = make_int4(0, 0, 0, 0);
+    else
+      for (long long j = i; j < hi; ++j) cell_cnt[j] = 0;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < 2) big[threadIdx.x] = 0;
+}
+
 __global__ __launch_bounds__(256) void k_point_keys(const float* __restrict__ pts, long long n0, VoxParams P,
                                                     int* __restrict__ key, int* __restrict__ slot, int* __restrict__ cell_cnt) {
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n0;
-       i += (long long)gridDim.x * blockDim.x) {
+  VOX_FOR_POINTS(i, n0) {
     const float* r = pts + i * P.ncols;
     float bf = r[0];
     int cx, cy, cz;
@@ -97,17 +119,18 @@ struct CellStore {
       big[2 + 2 * big_cap + atomicAdd(&big[1], 1)] = p;
     }
     const int cps = P.gz * P.gy * P.gx;
-    if (c % cps == 0) sample_off[c / cps] = p;
+    const int ci = (int)c;                 // B*Z*Y*X < 2^31: 32-bit divisions (the 64-bit ones are emulated)
+    if (ci % cps == 0) sample_off[ci / cps] = p;
     if (v) {
       cell2pillar[c] = p;
       pt_off[p] = (int)(unsigned)ex;
-      pillar_cell[p] = (int)c;
-      int x = (int)(c % P.gx);
-      long long t = c / P.gx;
-      int y = (int)(t % P.gy);
+      pillar_cell[p] = ci;
+      int x = ci % P.gx;
+      int t = ci / P.gx;
+      int y = t % P.gy;
       t /= P.gy;
-      int z = (int)(t % P.gz);
-      int b = (int)(t / P.gz);
+      int z = t % P.gz;
+      int b = t / P.gz;
       long long* o = voxel_coords + 4ll * p;
       o[0] = b;
       o[1] = z;
@@ -137,14 +160,16 @@ __global__ __launch_bounds__(256) void k_point_fill(const float* __restrict__ pt
                                                     const int* __restrict__ cell2pillar, const int* __restrict__ pt_off,
                                                     const int* __restrict__ slot, float* __restrict__ pts_out,
                                                     long long* __restrict__ point_coords, long long* __restrict__ inverse,
-                                                    int* __restrict__ inverse32, int* __restrict__ csr_raw) {
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n0;
-       i += (long long)gridDim.x * blockDim.x) {
+                                                    int* __restrict__ inverse32, int* __restrict__ csr_raw,
+                                                    int* __restrict__ raw_pillar) {
+  VOX_FOR_POINTS(i, n0) {
     int k = key[i];
     if (k < 0) continue;
     int dst = pos[i];
     int p = cell2pillar[k];
-    csr_raw[pt_off[p] + slot[i]] = dst;
+    const int q = pt_off[p] + slot[i];
+    csr_raw[q] = dst;
+    if (raw_pillar) raw_pillar[q] = p;     // pillar of the raw CSR slot: k_rank_points reads it next to csr_raw instead of gathering
     inverse[dst] = p;
     inverse32[dst] = p;
     const float* r = pts + i * P.ncols;
@@ -200,7 +225,8 @@ __device__ inline void pillar_mean(const float* __restrict__ pts_out, int ncols,
 __global__ __launch_bounds__(256) void k_pillar_sort_mean(const int* __restrict__ counts, const int* __restrict__ pt_off,
                                                           const int* __restrict__ csr_raw, int* __restrict__ csr,
                                                           int* __restrict__ rank, const float* __restrict__ pts_out,
-                                                          int ncols, float* __restrict__ mean) {
+                                                          int ncols, float* __restrict__ mean, float* __restrict__ pts_pm,
+                                                          int* __restrict__ row_pillar) {
   const int lane = threadIdx.x & (GD_WAVE - 1);
   const int wib = threadIdx.x / GD_WAVE;
   const int M = counts[1];
@@ -215,6 +241,12 @@ __global__ __launch_bounds__(256) void k_pillar_sort_mean(const int* __restrict_
     if (lane < cnt) {
       csr[off + rk] = own;
       rank[own] = rk;
+      if (pts_pm) {   // pillar-major copy of the row (what gdmae_pillar_major_rows produces in a pass of its own)
+        const float* r = pts_out + (long long)own * ncols;
+        float* w = pts_pm + (long long)(off + rk) * ncols;
+        for (int c = 0; c < ncols; ++c) w[c] = r[c];
+        row_pillar[off + rk] = p;
+      }
     }
     if (F <= 0) continue;
     int src = 0;   // lane r fetches the id whose rank is r
@@ -229,7 +261,8 @@ __global__ __launch_bounds__(256) void k_pillar_sort_mean(const int* __restrict_
 // ~1000-step items instead of one 16000-step serial tail.
 __global__ __launch_bounds__(256) void k_big_rank(const int* __restrict__ big, const int* __restrict__ pt_off,
                                                   const int* __restrict__ csr_raw, int* __restrict__ csr,
-                                                  int* __restrict__ rank) {
+                                                  int* __restrict__ rank, const float* __restrict__ pts_out, int ncols,
+                                                  float* __restrict__ pts_pm, int* __restrict__ row_pillar) {
   const int lane = threadIdx.x & (GD_WAVE - 1);
   const int wib = threadIdx.x / GD_WAVE;
   const int n_items = big[0];
@@ -248,6 +281,12 @@ __global__ __launch_bounds__(256) void k_big_rank(const int* __restrict__ big, c
     if (base + lane < cnt) {
       csr[off + rk] = own;
       rank[own] = rk;
+      if (pts_pm) {
+        const float* r = pts_out + (long long)own * ncols;
+        float* w = pts_pm + (long long)(off + rk) * ncols;
+        for (int c = 0; c < ncols; ++c) w[c] = r[c];
+        row_pillar[off + rk] = p;
+      }
     }
   }
 }
@@ -272,21 +311,107 @@ extern "C" size_t gdmae_voxelize_workspace_bytes(long long n_points, int batch_s
   size_t b = 0;
   b += gd_align(sizeof(int) * cells);                               // cell_cnt (zeroed at entry)
   b += gd_align(sizeof(int) * cells);                               // cell2pillar
-  b += gd_align(sizeof(int) * n_points) * 4;                        // key, pos, csr_raw, slot
+  b += gd_align(sizeof(int) * n_points) * 5;                        // key, pos, csr_raw, slot, raw_pillar
   b += gd_align(sizeof(unsigned long long) * gd_scan_ws_elems(cells > n_points ? cells : n_points));
   b += gd_align(sizeof(unsigned long long) * 2) + gd_align(sizeof(int) * 2);
   b += gd_align(sizeof(int) * (2 + 3 * (n_points / 32 + 2)));          // big-pillar work items
   return b + 4096;
 }
 
-// See include/gdmae_hip.h for the contract.
-extern "C" int gdmae_voxelize(const float* points, long long n_points, int n_cols, const float* lo, const float* vs,
-                              const int* grid_xyz, int batch_size, float* points_out, long long* point_coords,
-                              long long* inverse, int* inverse32, long long* voxel_coords, int* pillar_cell,
-                              int* pillar_pt_off, int* pillar_pts, int* point_rank, int* sample_pillar_off,
-                              float* pillar_mean, int* cell2pillar_out, int* counts, void* workspace,
-                              size_t workspace_bytes, void* stream) {
-  hipStream_t st = (hipStream_t)stream;
+// Plan path: rank of every point inside its pillar by ONE THREAD PER POINT over the raw (arrival-order) CSR - the thread counts
+// the ids of its pillar's segment that are smaller than its own (the lanes of a pillar read the same addresses: broadcast loads
+// from L1).  Any pillar size in one kernel: a 1000-point wall pillar is 1000 threads x 1000 loads instead of the serial
+// tail of k_big_rank, and the 10-point average pillar no longer idles 54 lanes of a wavefront.  Also writes the pillar-major
+// row of the point (gdmae_pillar_major_rows).
+__global__ __launch_bounds__(256) void k_rank_points(const int* __restrict__ counts, const int* __restrict__ csr_raw,
+                                                     const int* __restrict__ raw_pillar, const int* __restrict__ pt_off,
+                                                     int* __restrict__ csr, int* __restrict__ rank, const float* __restrict__ pts_out,
+                                                     int ncols, float* __restrict__ pts_pm, int* __restrict__ row_pillar) {
+  const int N = counts[0];
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < N; q += gridDim.x * blockDim.x) {
+    const int own = csr_raw[q];
+    const int p = raw_pillar[q];                  // written next to csr_raw by the fill pass: both loads are coalesced
+    const int off = pt_off[p], cnt = pt_off[p + 1] - off;
+    const int* seg = csr_raw + off;
+    int rk = 0;
+    int j = 0;
+    for (; j + 16 <= cnt; j += 16) {              // 16 independent (broadcast) loads in flight: a 1000-point pillar is 62 round trips
+      int u[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) u[e] = seg[j + e];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) rk += u[e] < own;
+    }
+    for (; j + 4 <= cnt; j += 4) {
+      const int a = seg[j], b = seg[j + 1], c = seg[j + 2], d = seg[j + 3];
+      rk += (a < own) + (b < own) + (c < own) + (d < own);
+    }
+    for (; j < cnt; ++j) rk += seg[j] < own;
+    csr[off + rk] = own;
+    rank[own] = rk;
+    if (pts_pm) {
+      const float* r = pts_out + (long long)own * ncols;
+      float* w = pts_pm + (long long)(off + rk) * ncols;
+      for (int c = 0; c < ncols; ++c) w[c] = r[c];
+      row_pillar[off + rk] = p;
+    }
+  }
+}
+// Sequential (canonical ascending-id order, bit-identical to a CPU index_add_) feature sum of a pillar by one thread per
+// (pillar, channel) over the pillar-major rows: consecutive rows, independent loads, one dependent add chain.
+__global__ __launch_bounds__(256) void k_pillar_mean_rows(const int* __restrict__ counts, const int* __restrict__ pt_off,
+                                                          const float* __restrict__ pts_pm, int ncols, float* __restrict__ mean) {
+  const int F = ncols - 1;
+  const long long total = (long long)counts[1] * F;
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const int p = (int)(e / F), c = (int)(e % F);
+    const int off = pt_off[p], cnt = pt_off[p + 1] - off;
+    const float* r = pts_pm + (long long)off * ncols + 1 + c;
+    float acc = 0.f;
+    int j = 0;
+    for (; j + 16 <= cnt; j += 16) {              // the loads are independent of the add chain: 16 in flight per trip
+      float v[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) v[e] = r[(long long)(j + e) * ncols];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc = __fadd_rn(acc, v[e]);
+    }
+    for (; j + 4 <= cnt; j += 4) {
+      const float v0 = r[(long long)j * ncols], v1 = r[(long long)(j + 1) * ncols], v2 = r[(long long)(j + 2) * ncols],
+                  v3 = r[(long long)(j + 3) * ncols];
+      acc = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(acc, v0), v1), v2), v3);
+    }
+    for (; j < cnt; ++j) acc = __fadd_rn(acc, r[(long long)j * ncols]);
+    mean[e] = __fdiv_rn(acc, (float)cnt);
+  }
+}
+
+// the one-thread finalize of the classic path, as the grand-total hooks of the two single-launch scans
+struct KeepTotal {
+  int* counts;
+  __device__ void operator()(int n_keep) const { counts[0] = n_keep; }
+};
+struct CellTotal {
+  int B;
+  int* pt_off;
+  int* sample_off;
+  int* counts;
+  __device__ void operator()(unsigned long long t) const {
+    const int M = (int)(t >> 32), N = (int)(unsigned)t;
+    pt_off[M] = N;
+    sample_off[B] = M;
+    counts[1] = M;
+  }
+};
+
+// Body of gdmae_voxelize.  lb_state == null: the classic schedule (three-launch scans, finalize launch, no pillar-major rows).
+// lb_state != null (geometry plan, plan.hip): 2 * gd_scan_lb_state_bytes-sized ZEROED scan states -> single-launch scans with the
+// finalize folded in; points_pm / row_pillar (optional) are written by the ranking kernels instead of a pass of their own.
+int gd_voxelize_impl(const float* points, long long n_points, int n_cols, const float* lo, const float* vs, const int* grid_xyz,
+                     int batch_size, float* points_out, long long* point_coords, long long* inverse, int* inverse32,
+                     long long* voxel_coords, int* pillar_cell, int* pillar_pt_off, int* pillar_pts, int* point_rank,
+                     int* sample_pillar_off, float* pillar_mean, int* cell2pillar_out, int* counts, void* workspace, size_t workspace_bytes,
+                     void* lb_state, float* points_pm, int* row_pillar, hipStream_t st) {
   GD_REQUIRE(n_cols >= 4 && n_cols <= 65, "n_cols must be 1+F with 3 <= F <= 64");
   VoxParams P;
   for (int i = 0; i < 3; ++i) {
@@ -310,45 +435,86 @@ extern "C" int gdmae_voxelize(const float* points, long long n_points, int n_col
   int* pos = A.take<int>(n_points);
   int* csr_raw = A.take<int>(n_points);
   int* slot = A.take<int>(n_points);
+  int* raw_pillar_ws = A.take<int>(n_points);
   unsigned long long* scan_ws = A.take<unsigned long long>(gd_scan_ws_elems(cells > n_points ? cells : n_points));
   unsigned long long* total = A.take<unsigned long long>(2);
   int* n_keep = A.take<int>(2);
   const int big_cap = (int)(n_points / 32 + 2);
   int* big = A.take<int>(2 + 3 * (size_t)big_cap);
 
-  GD_CHECK(hipMemsetAsync(cell_cnt, 0, sizeof(int) * cells, st));
-  GD_CHECK(hipMemsetAsync(big, 0, sizeof(int) * 2, st));
-  const int grid_pts = n_points > 0 ? (gd_div_up(n_points, 256) < 4096 ? gd_div_up(n_points, 256) : 4096) : 1;
+  if (lb_state) {
+    // zeroed by the XCD that will own the counters (frame-major eighths, as VOX_FOR_POINTS deals the points): the atomics of
+    // k_point_keys then find their lines in the local L2 instead of pulling them out of another XCD's
+    hipLaunchKernelGGL(k_zero_cells, dim3(2048), dim3(256), 0, st, cell_cnt, cells, big);
+    GD_LAUNCH_CHECK();
+  } else {
+    GD_CHECK(hipMemsetAsync(cell_cnt, 0, sizeof(int) * cells, st));
+    GD_CHECK(hipMemsetAsync(big, 0, sizeof(int) * 2, st));
+  }
+  int grid_pts = n_points > 0 ? (gd_div_up(n_points, 256) < 4096 ? gd_div_up(n_points, 256) : 4096) : 8;
+  grid_pts = (grid_pts + 7) / 8 * 8;              // VOX_FOR_POINTS: a multiple of 8 workgroups
   if (n_points > 0) {
     hipLaunchKernelGGL(k_point_keys, dim3(grid_pts), dim3(256), 0, st, points, n_points, P, key, slot, cell_cnt);
     GD_LAUNCH_CHECK();
   }
-  {
+  CellStore cs{P, cell2pillar, pillar_pt_off, pillar_cell, voxel_coords, sample_pillar_off, big, big_cap};
+  if (lb_state) {
+    char* s0 = (char*)lb_state;
+    char* s1 = s0 + gd_scan_lb_state_bytes<int>(n_points);
+    int rc = gd_device_scan_lb<int>(n_points, KeepLoad{key}, KeepStore{pos}, KeepTotal{counts}, (int*)nullptr, s0, st);
+    if (rc) return rc;
+    rc = gd_device_scan_lb<unsigned long long>(cells, CellLoad{cell_cnt}, cs, CellTotal{batch_size, pillar_pt_off, sample_pillar_off, counts},
+                                               (unsigned long long*)nullptr, s1, st);
+    if (rc) return rc;
+  } else {
     int rc = gd_device_scan<int>(n_points, KeepLoad{key}, KeepStore{pos}, n_keep, (int*)scan_ws, st);
     if (rc) return rc;
-  }
-  {
-    CellStore cs{P, cell2pillar, pillar_pt_off, pillar_cell, voxel_coords, sample_pillar_off, big, big_cap};
-    int rc = gd_device_scan<unsigned long long>(cells, CellLoad{cell_cnt}, cs, total, scan_ws, st);
+    rc = gd_device_scan<unsigned long long>(cells, CellLoad{cell_cnt}, cs, total, scan_ws, st);
     if (rc) return rc;
+    hipLaunchKernelGGL(k_vox_finalize, dim3(1), dim3(64), 0, st, total, n_keep, batch_size, pillar_pt_off,
+                       sample_pillar_off, counts);
+    GD_LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(k_vox_finalize, dim3(1), dim3(64), 0, st, total, n_keep, batch_size, pillar_pt_off,
-                     sample_pillar_off, counts);
-  GD_LAUNCH_CHECK();
   if (n_points > 0) {
+    int* raw_pillar = (lb_state && points_pm) ? raw_pillar_ws : nullptr;
     hipLaunchKernelGGL(k_point_fill, dim3(grid_pts), dim3(256), 0, st, points, n_points, P, key, pos, cell2pillar,
-                       pillar_pt_off, slot, points_out, point_coords, inverse, inverse32, csr_raw);
+                       pillar_pt_off, slot, points_out, point_coords, inverse, inverse32, csr_raw, raw_pillar);
     GD_LAUNCH_CHECK();
+    if (lb_state && points_pm) {
+      // plan path: one thread per point ranks it (any pillar size) and writes its pillar-major row; the means walk those rows
+      hipLaunchKernelGGL(k_rank_points, dim3(grid_pts), dim3(256), 0, st, counts, csr_raw, (const int*)raw_pillar_ws, pillar_pt_off, pillar_pts, point_rank,
+                         points_out, n_cols, points_pm, row_pillar);
+      GD_LAUNCH_CHECK();
+      hipLaunchKernelGGL(k_pillar_mean_rows, dim3(grid_pts), dim3(256), 0, st, counts, pillar_pt_off, points_pm, n_cols, pillar_mean);
+      GD_LAUNCH_CHECK();
+      return 0;
+    }
     hipLaunchKernelGGL(k_pillar_sort_mean, dim3(4096), dim3(256), 0, st, counts, pillar_pt_off, csr_raw, pillar_pts,
-                       point_rank, points_out, n_cols, pillar_mean);
+                       point_rank, points_out, n_cols, pillar_mean, points_pm, row_pillar);
     GD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_big_rank, dim3(2048), dim3(256), 0, st, big, pillar_pt_off, csr_raw, pillar_pts, point_rank);
+    hipLaunchKernelGGL(k_big_rank, dim3(2048), dim3(256), 0, st, big, pillar_pt_off, csr_raw, pillar_pts, point_rank, (const float*)points_out,
+                       n_cols, points_pm, row_pillar);
     GD_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_big_mean, dim3(1024), dim3(256), 0, st, big, big_cap, pillar_pt_off, pillar_pts, points_out, n_cols,
                        pillar_mean);
     GD_LAUNCH_CHECK();
   }
   return 0;
+}
+size_t gd_voxelize_lb_state_bytes(long long n_points, long long cells) {
+  return gd_scan_lb_state_bytes<int>(n_points) + gd_scan_lb_state_bytes<unsigned long long>(cells);
+}
+
+// See include/gdmae_hip.h for the contract.
+extern "C" int gdmae_voxelize(const float* points, long long n_points, int n_cols, const float* lo, const float* vs,
+                              const int* grid_xyz, int batch_size, float* points_out, long long* point_coords,
+                              long long* inverse, int* inverse32, long long* voxel_coords, int* pillar_cell,
+                              int* pillar_pt_off, int* pillar_pts, int* point_rank, int* sample_pillar_off,
+                              float* pillar_mean, int* cell2pillar_out, int* counts, void* workspace,
+                              size_t workspace_bytes, void* stream) {
+  return gd_voxelize_impl(points, n_points, n_cols, lo, vs, grid_xyz, batch_size, points_out, point_coords, inverse, inverse32,
+                          voxel_coords, pillar_cell, pillar_pt_off, pillar_pts, point_rank, sample_pillar_off, pillar_mean,
+                          cell2pillar_out, counts, workspace, workspace_bytes, nullptr, nullptr, nullptr, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -458,12 +624,13 @@ static int gd_group_csr(const long long* gid, long long n, long long n_groups, G
   hipLaunchKernelGGL(k_group_fill, dim3(grid), dim3(256), 0, st, gid, n, n_groups, off, cnt, csr_raw);
   GD_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_pillar_sort_mean, dim3(2048), dim3(256), 0, st, counts, off, csr_raw, csr, rank,
-                     (const float*)nullptr, 1, (float*)nullptr);
+                     (const float*)nullptr, 1, (float*)nullptr, (float*)nullptr, (int*)nullptr);
   GD_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_group_big_items, dim3(gd_div_up(n_groups, 256) < 2048 ? gd_div_up(n_groups, 256) : 2048), dim3(256), 0,
                      st, off, n_groups, big);
   GD_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_big_rank, dim3(2048), dim3(256), 0, st, big, off, csr_raw, csr, rank);
+  hipLaunchKernelGGL(k_big_rank, dim3(2048), dim3(256), 0, st, big, off, csr_raw, csr, rank, (const float*)nullptr, 1, (float*)nullptr,
+                     (int*)nullptr);
   GD_LAUNCH_CHECK();
   *off_out = off;
   *csr_out = csr;

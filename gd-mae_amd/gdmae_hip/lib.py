@@ -96,6 +96,7 @@ SIGNATURES = {
     "gdmae_sum_partials": (_I, [_P, _L, _F, _P, _I, _P]),
     "gdmae_sum_partials_gated": (_I, [_P, _L, _F, _P, _P, _F, _P]),
     "gdmae_gemm_workspace_bytes": (_Z, []),
+    "gdmae_gemm_stats": (_I, [_P]),
     "gdmae_gemm": (_I, [_P, _P, _P, _L, _L, _L, _I, _I, _I, _I, _P, _P, _P]),
     "gdmae_gemm_tn_splitk_workspace_bytes": (_Z, [_L, _I, _I]),
     "gdmae_gemm_tn_splitk": (_I, [_P, _P, _P, _L, _I, _I, _I, _I, _P, _P]),
@@ -130,6 +131,8 @@ SIGNATURES = {
     "gdmae_boxes_bev_pairs": (_I, [_P, _I, _P, _I, _I, _P, _P]),
     "gdmae_nms_workspace_bytes": (_Z, [_I]),
     "gdmae_nms_bev": (_I, [_P, _I, _F, _I, _P, _P, _P, _P]),
+    "gdmae_geometry_plan_layout": (_I, [_P, _P, _I, _P, _P]),
+    "gdmae_geometry_plan": (_I, [_P, _P, _P, _P, _Z, _P]),
     "gdmae_grad_sq_norm": (_I, [_P, _L, _P, _P, _P]),
     "gdmae_adam_step": (_I, [_P, _P, _P, _P, _P, _I, _F, _F, _F, _F, _F, _I, _F, _F, _P, _P]),
 }
@@ -141,6 +144,19 @@ class LayerArgs(C.Structure):
                 + [(k, _P) for k in ("tok_pos", "csr_tok", "win_start", "win_len", "pos_table", "Win", "bin", "Wo", "bo", "W1", "b1",
                                      "W2", "b2", "g1", "be1", "g2", "be2", "tau", "x", "y", "dy", "dx", "dWin", "dbin", "dtau", "dWo",
                                      "dbo", "dW1", "db1", "dW2", "db2", "dg1", "dbe1", "dg2", "dbe2", "saved", "scratch", "packed")])
+
+
+class PlanParams(C.Structure):
+    """ctypes mirror of ``gdmae_plan_params`` (include/gdmae_hip.h)."""
+    _fields_ = [("n_points", _L), ("n_cols", _I), ("batch_size", _I), ("lo", _F * 3), ("vs", _F * 3), ("grid", _I * 3), ("n_stages", _I),
+                ("stride", _I * 4), ("win_x", _I * 4), ("win_y", _I * 4), ("n_levels", _I * 4), ("drop_lo", (_I * 3) * 4),
+                ("drop_hi", (_I * 3) * 4), ("max_tokens", (_I * 3) * 4), ("masked", _I), ("keep_frac", _D), ("n_dec", _I),
+                ("dec_sources", _I * 4), ("want_pm", _I)]
+
+
+class PlanBuffer(C.Structure):
+    """ctypes mirror of ``gdmae_plan_buffer``."""
+    _fields_ = [("name", C.c_char * 40), ("offset", _L), ("bytes", _L)]
 
 
 class ConvBlockArgs(C.Structure):

@@ -351,12 +351,93 @@ def encoder_plan(vox: VoxelPlan, strides, window_shapes, drop_infos, keep_frac: 
     return _encoder_finalize(e, e["counts"].tolist(), vox.M)   # the one host sync of this phase
 
 
+# ------------------------------------------------------------------------------------------------
+# the whole plan as ONE call of the library (csrc/plan.hip: gdmae_geometry_plan)
+# ------------------------------------------------------------------------------------------------
+_PLAN_SHAPES = {}      # shape key -> (PlanParams, {name: (offset, bytes)}, arena bytes, per-stage geometry)
+_PINNED = {}           # device index -> rotating pinned int32 buffers for the count read-back
+
+
+def _plan_shape(n0, ncols, B, pcr, voxel_size, grid_size, strides, window_shapes, drop_infos, keep_frac, dec_sources):
+    gx, gy, gz = (int(g) for g in grid_size)
+    lo = tuple(float(v) for v in pcr[:3])
+    vs = tuple(float(v) for v in voxel_size)
+    drops = tuple(tuple(map(tuple, _drop_arrays(d))) for d in drop_infos)
+    key = (n0, ncols, B, lo, vs, (gx, gy, gz), tuple(int(s) for s in strides), tuple(tuple(int(v) for v in w) for w in window_shapes),
+           drops, keep_frac is not None, None if dec_sources is None else tuple(int(i) for i in dec_sources))
+    hit = _PLAN_SHAPES.get(key)
+    if hit is not None:
+        return hit
+    import ctypes as C
+    ns = len(strides)
+    assert gz == 1, "the SST backbone works on single-layer pillar grids (spt_backbone_mae.py:94)"
+    assert 1 <= ns <= 4
+    P = L.PlanParams()
+    P.n_points, P.n_cols, P.batch_size = n0, ncols, B
+    for i in range(3):
+        P.lo[i], P.vs[i] = lo[i], vs[i]
+        P.grid[i] = (gx, gy, gz)[i]
+    P.n_stages = ns
+    geo = []
+    Y, X = gy, gx
+    cap = max(1, min(n0, B * gx * gy))
+    m_cap = cap
+    for i in range(ns):
+        wx, wy, wz = (int(v) for v in window_shapes[i])
+        assert wz == 1
+        dlo, dhi, dT = drops[i]
+        assert wx * wy <= max(dT), "token drop would not be the identity: unsupported (SURVEY header item 5)"
+        P.stride[i], P.win_x[i], P.win_y[i], P.n_levels[i] = int(strides[i]), wx, wy, len(dT)
+        for l in range(len(dT)):
+            P.drop_lo[i][l], P.drop_hi[i][l], P.max_tokens[i][l] = dlo[l], dhi[l], dT[l]
+        cap_in = cap
+        if int(strides[i]) > 1:
+            assert int(strides[i]) == 2, "only the k3 s2 p1 strided sparse conv of the shipped configs is implemented"
+            Y, X = (Y - 1) // 2 + 1, (X - 1) // 2 + 1
+            cap = min(4 * cap, B * Y * X)
+        us = gy // Y
+        up_s = us if (us >= 1 and us * Y == gy and us * X == gx) else 0
+        geo.append(dict(Y=Y, X=X, cap=cap, cap_in=cap_in, up_s=up_s, strided=int(strides[i]) > 1, T=list(dT)))
+    P.masked = int(keep_frac is not None)
+    P.keep_frac = float(keep_frac) if keep_frac is not None else 1.0
+    P.n_dec = 0 if dec_sources is None else len(dec_sources)
+    for g in range(P.n_dec):
+        P.dec_sources[g] = int(dec_sources[g])
+    P.want_pm = 1
+    table = (L.PlanBuffer * 160)()
+    n_ent, total = C.c_int(0), C.c_size_t(0)
+    L.call("gdmae_geometry_plan_layout", C.byref(P), table, 160, C.byref(n_ent), C.byref(total))
+    names = {table[i].name.decode(): (int(table[i].offset), int(table[i].bytes)) for i in range(n_ent.value)}
+    hit = _PLAN_SHAPES[key] = (P, names, int(total.value), geo, m_cap, (lo, vs, (gx, gy, gz)))
+    return hit
+
+
+class _Arena:
+    """Typed views into the plan's single device allocation (one ``as_strided`` per buffer)."""
+
+    def __init__(self, raw, names):
+        self.raw, self.names = raw, names
+        self.base = {torch.int32: raw.view(torch.int32), torch.float32: raw.view(torch.float32), torch.int64: raw.view(torch.int64)}
+
+    def has(self, name):
+        return name in self.names
+
+    def view(self, name, dtype, *shape):
+        off, _ = self.names[name]
+        es = 8 if dtype == torch.int64 else 4
+        strides, acc = [], 1
+        for d in reversed(shape):
+            strides.append(acc)
+            acc *= int(d)
+        return self.base[dtype].as_strided(tuple(int(d) for d in shape), tuple(reversed(strides)), off // es)
+
+
 class PlanPrefetch:
     """Geometry plan of a batch built ahead of time on a side stream (the analogue of a data-loader prefetch: the
-    plan depends only on the input points, never on the weights).  All kernels of gdmae_voxelize and the encoder
-    plan are enqueued back-to-back with capacity-sized buffers, the few int32 counts are copied to pinned host
-    memory asynchronously, and ``finish()`` only waits for THAT stream - so the training step of batch t+1 never
-    stalls the host behind the backward of batch t, and the host can run a full step ahead of the GPU."""
+    plan depends only on the input points, never on the weights).  The whole plan is ONE call of the library
+    (``gdmae_geometry_plan``, csrc/plan.hip: ~32 launches into one arena allocation), the data-dependent counts are copied
+    to pinned host memory asynchronously, and ``finish()`` only waits for THAT stream - so the training step of batch t+1
+    never stalls the host behind the backward of batch t, and the host can run a full step ahead of the GPU."""
 
     _side = {}
 
@@ -366,44 +447,98 @@ class PlanPrefetch:
         why that ordering is what keeps the plan tensors safe without ``record_stream``).  ``ready``: an ADDITIONAL event the
         plan stream waits for - the H2D copy of ``points`` when it was issued on a copy stream the calling stream has not
         waited for yet."""
+        import ctypes as C
+        assert points.is_cuda and points.dtype == torch.float32 and points.dim() == 2
+        points = points.contiguous()
         dev = points.device
         main = torch.cuda.current_stream(dev)
         side = PlanPrefetch._side.setdefault(dev.index, torch.cuda.Stream(device=dev))
         # The plan stream is ordered after everything queued on the main stream so far.  That makes `points` / `noise` visible
-        # and - the reason it is unconditional - lets the ~130 plan tensors live without `record_stream`: they are allocated
-        # from the plan stream's pool and read by the main stream; once their last reference dies the allocator hands the blocks
-        # to LATER plan-stream allocations only, i.e. to a prefetch whose kernels wait here for all main-stream work that could
-        # still read them.  (With `record_stream` every freed block cost an event record on the training stream: 130 marker
-        # packets and ~0.5 ms of queue time per step.)  `ready` adds a wait, it never replaces this one.
+        # and - the reason it is unconditional - lets the plan arena live without `record_stream`: it is allocated from the plan
+        # stream's pool and read by the main stream; once its last reference dies the allocator hands the block to LATER
+        # plan-stream allocations only, i.e. to a prefetch whose kernels wait here for all main-stream work that could still
+        # read it.  (With `record_stream` every freed block cost an event record on the training stream.)  `ready` adds a
+        # wait, it never replaces this one.
         side.wait_stream(main)
         if ready is not None:
             side.wait_event(ready)
         points.record_stream(side)
         if noise is not None:
             noise.record_stream(side)
+        n0, ncols = points.shape
+        P, names, total, geo, m_cap, _ = self.shape = _plan_shape(n0, ncols, int(batch_size), point_cloud_range, voxel_size, grid_size,
+                                                                    strides, window_shapes, drop_infos, keep_frac, dec_sources)
+        self.masked, self.dec_sources, self.batch_size, self.ncols = keep_frac is not None, dec_sources, int(batch_size), ncols
         with torch.cuda.stream(side):
-            self.vraw = _voxelize_launch(points, point_cloud_range, voxel_size, grid_size, batch_size)
-            gx, gy, gz = self.vraw["grid"]
-            m_cap = max(1, min(self.vraw["n0"], batch_size * gx * gy * gz))
-            self.eraw = _encoder_launch(self.vraw, m_cap, strides, window_shapes, drop_infos, keep_frac, noise, dec_sources)
-            allc = torch.cat([self.vraw["counts"], self.eraw["counts"]])
-            self.host = torch.empty(allc.numel(), dtype=torch.int32).pin_memory()
-            self.host.copy_(allc, non_blocking=True)
+            raw = torch.empty(total, dtype=torch.uint8, device=dev)
+            if self.masked and noise is None:
+                noise = torch.rand(m_cap, device=dev, dtype=torch.float32)
+            if noise is not None:
+                assert noise.dtype == torch.float32 and noise.numel() >= 1
+                noise = noise.contiguous()
+            L.call("gdmae_geometry_plan", C.byref(P), L.ptr(points), None if noise is None else L.ptr(noise), L.ptr(raw), total, L.stream())
+            self.arena = _Arena(raw, names)
+            nc = names["counts"][1] // 4
+            pool = _PINNED.setdefault(dev.index, [[], 0])
+            if len(pool[0]) < 8:
+                pool[0].append(torch.empty(256, dtype=torch.int32).pin_memory())
+            self.host = pool[0][pool[1] % len(pool[0])][:nc]       # 8 prefetches deep before a buffer is reused
+            pool[1] += 1
+            self.host.copy_(self.arena.view("counts", torch.int32, nc), non_blocking=True)
             self.event = torch.cuda.Event()
             self.event.record(side)
-        self.side, self.keep = side, allc
+        self.side, self.keep, self.points = side, noise, points
+        self.serial = side == main          # plan issued on the calling stream itself (A/B switch of tools/phase_times.py)
 
     def finish(self):
         """-> (VoxelPlan, EncoderPlan); the current (main) stream is ordered after the plan stream."""
-        # invariant behind the missing record_stream calls (see __init__): plan tensors are only ever ALLOCATED on the plan
+        # invariant behind the missing record_stream calls (see __init__): the plan arena is only ever ALLOCATED on the plan
         # stream inside __init__ and only ever CONSUMED on the stream that issues the prefetches
-        assert torch.cuda.current_stream() != self.side, "plan tensors must not be consumed on the plan stream"
+        assert self.serial or torch.cuda.current_stream() != self.side, "plan tensors must not be consumed on the plan stream"
         self.event.synchronize()
         torch.cuda.current_stream().wait_event(self.event)
         c = self.host.tolist()
+        P, names, total, geo, m_cap, (lo, vs, grid) = self.shape
+        A, V = self.arena, self.arena.view
+        i32, f32, i64 = torch.int32, torch.float32, torch.int64
+        B, ncols = self.batch_size, self.ncols
+        F = ncols - 1
         N, M = int(c[0]), int(c[1])
-        vox = _voxelize_finalize(self.vraw, N, M)
-        ep = _encoder_finalize(self.eraw, c[2:], M)
+        gx, gy, gz = grid
+        vox = VoxelPlan(B, grid, lo, vs, ncols, N, M, V("points", f32, N, ncols), V("point_coords", i64, N, 4), V("inverse", i64, N),
+                        V("inverse32", i32, N), V("voxel_coords", i64, M, 4), V("pillar_cell", i32, M), V("pt_off", i32, M + 1),
+                        V("pillar_pts", i32, N), V("point_rank", i32, N), V("sample_off", i32, B + 1), V("pillar_mean", f32, M, F),
+                        V("cell2pillar", i32, B * gx * gy * gz), V("counts", i32, 2), V("points_pm", f32, N, ncols), V("row_pillar", i32, N))
+        vox._arena = A                                           # keeps the allocation alive with the plan
+        ns = len(geo)
+        n_vis = int(c[2 + ns + 16 * ns + 1])
+        stages = []
+        for i, g in enumerate(geo):
+            n = int(c[2 + i])
+            pre = f"s{i}."
+            wps = []
+            for k in range(2):
+                wc = c[2 + ns + 16 * i + 8 * k: 2 + ns + 16 * i + 8 * k + 8]
+                assert wc[7] == n, (wc, n)
+                nw = int(wc[6])
+                wpre = f"{pre}w{k}."
+                wps.append(WindowPlan(V(wpre + "tok_win", i32, n), V(wpre + "tok_level", i32, n), V(wpre + "tok_slot", i32, n),
+                                      V(wpre + "tok_pos", i32, n), V(wpre + "csr_tok", i32, n), V(wpre + "win_start", i32, nw),
+                                      V(wpre + "win_len", i32, nw), [int(v) for v in wc[0:3]], [int(v) for v in wc[3:6]], list(g["T"])))
+            n_prev = (int(c[2 + i - 1]) if i > 0 else n_vis) if g["strided"] else 0
+            sp = StagePlan(B, g["Y"], g["X"], n, V(pre + "tok_cell", i32, n), V(pre + "map", i32, B * g["Y"] * g["X"]),
+                           V(pre + "nbr_subm", i32, n, 9), V(pre + "nbr_down", i32, n, 9) if g["strided"] else None,
+                           V(pre + "nbr_down_t", i32, n_prev, 9) if g["strided"] else None, wps)
+            sp._nbr_subm_t = V(pre + "nbr_subm_t", i32, n, 9)
+            sp._up_sites = (g["up_s"], V(pre + "up_sites", i32, n * g["up_s"] * g["up_s"])) if g["up_s"] > 1 else None
+            stages.append(sp)
+        dt = None
+        if A.has("dec.tile_slot"):
+            n_act = int(c[2 + ns + 16 * ns])
+            nt = B * ((gy + 7) // 8) * ((gx + 7) // 8)
+            dt = DecoderTiles(tuple(int(i) for i in self.dec_sources), B, gy, gx, n_act, V("dec.tile_slot", i32, nt), V("dec.tile_list", i32, n_act))
+        ep = EncoderPlan(V("mask", f32, M) if self.masked else None, V("tok_pillar", i32, stages[0].n_tok if not geo[0]["strided"] else n_vis),
+                         stages, dt)
         return vox, ep
 
 

@@ -372,6 +372,9 @@ int gdmae_add3(const float* a, const void* b, int b_bf16, const void* c, int c_b
  *   gdmae_gemm_tn_splitk: C (m,n) fp32 (+)= A^T B for A (K,m), B (K,n) with the long K dimension (20 k ... 1.4 M
  *     rows) split into equal slices = one batched GEMM + a fixed-order reduction (weight gradients).
  * workspace: gdmae_gemm_workspace_bytes() / gdmae_gemm_tn_splitk_workspace_bytes(K, m, n). */
+/* calls[0] = library GEMM calls so far, calls[1] = algorithm plans created so far (first use of a shape bucket = candidate timing
+ * with stream synchronisation): a loop has reached its steady state once calls[1] stops growing. */
+int gdmae_gemm_stats(long long* calls);
 size_t gdmae_gemm_workspace_bytes(void);
 int gdmae_gemm(const void* A, const void* B, void* C, long long M, long long N, long long K, int trans_a, int trans_b,
                int ab_bf16, int c_f32, const void* bias, void* workspace, void* stream);
@@ -541,6 +544,48 @@ int gdmae_ingroup_inds(const long long* group_inds, long long n, long long n_gro
                        void* workspace, size_t workspace_bytes, void* stream);
 int gdmae_group_inner_inds(const long long* inverse_inds, long long n, long long M, int K, long long* group_inds,
                            void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- the whole geometry plan as ONE call (round 3) ---------------------------------------------------- *
+ * Voxelization (gdmae_voxelize + gdmae_pillar_major_rows), random masking, the token set / cell map of every stage, all
+ * sparse-conv rulebooks incl. the transposed ones, the full-resolution sites under the tokens of strided stages, both window
+ * partitions of every stage and the decoder's active tiles - the index side of SURVEY rows a1-a3, a5-a10, a16, a17 that the
+ * reference spreads over dyn_vfe.py:62-81, common_utils.py:49-63, spconv's rulebook builder, sst_utils.py:6-104,
+ * spt_backbone.py:32-104 and sst_ops_gpu.cu - enqueued by a single call (~32 launches, no host sync, no allocation).
+ * Every buffer lives in ONE caller-provided arena; gdmae_geometry_plan_layout lists (name, offset, bytes) of each buffer and
+ * the arena size for given CAPACITIES (it does not depend on the data, cache it per shape).  Names: the gdmae_voxelize outputs
+ * ("points", "point_coords", "inverse", "inverse32", "voxel_coords", "pillar_cell", "pt_off", "pillar_pts", "point_rank",
+ * "sample_off", "pillar_mean", "cell2pillar"), "points_pm" / "row_pillar", "mask", "tok_pillar", per stage i "s<i>.tok_cell",
+ * "s<i>.map", "s<i>.nbr_subm", "s<i>.nbr_subm_t", "s<i>.nbr_down", "s<i>.nbr_down_t", "s<i>.up_sites", per shift k
+ * "s<i>.w<k>.{tok_win,tok_level,tok_slot,tok_pos,csr_tok,win_start,win_len}", "dec.tile_slot" / "dec.tile_list", and
+ * "counts" = int32 [N points kept, M pillars | tokens of stage 0.. | 8 per (stage, shift): windows per level (3), tokens per
+ * level (3), windows, tokens | active tiles | visible pillars] - the only thing the host has to read back.
+ * noise: (min(n_points, B*Y*X)) fp32 masking noise, one value per pillar in pillar order (null when !masked).
+ * Outputs are bit-identical to the per-operator entry points above. */
+#define GDMAE_PLAN_MAX_STAGES 4
+typedef struct gdmae_plan_params {
+  long long n_points;          /* rows of `points` (capacity of every per-point / per-pillar buffer) */
+  int n_cols, batch_size;
+  float lo[3], vs[3];
+  int grid[3];                 /* X, Y, Z (Z = 1) */
+  int n_stages;
+  int stride[GDMAE_PLAN_MAX_STAGES];               /* conv_down stride of the stage: 1 (first stage only) or 2 (k3 s2 p1) */
+  int win_x[GDMAE_PLAN_MAX_STAGES], win_y[GDMAE_PLAN_MAX_STAGES];
+  int n_levels[GDMAE_PLAN_MAX_STAGES];
+  int drop_lo[GDMAE_PLAN_MAX_STAGES][3], drop_hi[GDMAE_PLAN_MAX_STAGES][3], max_tokens[GDMAE_PLAN_MAX_STAGES][3];
+  int masked;                  /* 0: every pillar is a token (fine-tune backbone) */
+  double keep_frac;            /* 1 - mask ratio (python double) */
+  int n_dec;                   /* decoder source stages (0: no tile set) */
+  int dec_sources[GDMAE_PLAN_MAX_STAGES];
+  int want_pm;                 /* pillar-major point rows */
+} gdmae_plan_params;
+typedef struct gdmae_plan_buffer {
+  char name[40];
+  long long offset, bytes;
+} gdmae_plan_buffer;
+int gdmae_geometry_plan_layout(const gdmae_plan_params* p, gdmae_plan_buffer* table, int max_entries, int* n_entries,
+                               size_t* total_bytes);
+int gdmae_geometry_plan(const gdmae_plan_params* p, const float* points, const float* noise, void* arena, size_t arena_bytes,
+                        void* stream);
 
 /* ---- f1 (next row): CenterHead target assignment --------------------------------------------------- *
  * Replaces the per-box Python / CPU loop of CenterHead.assign_targets (pcdet/models/dense_heads/center_head.py:106-221;

@@ -272,3 +272,41 @@ def test_bench_mode_matches_fp32_mode_at_full_size(scene):
     tb, tf = torch.stack([gb[n][0] for n in taus]), torch.stack([gf[n][0] for n in taus])
     assert float((tb - tf).norm()) <= 0.20 * float(tf.norm()), (tb.tolist(), tf.tolist())
     assert not bad, bad
+
+
+def test_one_call_plan_equals_per_operator_plan_at_full_size(scene):
+    """The geometry plan as ONE library call (gdmae_geometry_plan: single-launch look-back scans with hundreds of tiles, merged
+    launches, one arena) against the per-operator entry points on 8 full-size frames with the same masking noise: every index
+    structure bit-identical - voxel table, CSR, ranks, means, pillar-major rows, mask, token sets, maps, rulebooks incl. the
+    transposed ones, window partitions of both shifts, upsampled sites, active decoder tiles."""
+    import dataclasses
+    from gdmae_hip import plan as gplan
+    from pcdet.models.backbones_3d.spt_backbone import stage_plan_args
+    cfg, ds, skw, B, pts, vox0, _ = scene
+    noise = torch.rand(vox0.M, generator=torch.Generator().manual_seed(5)).to(dev())
+    args = stage_plan_args(cfg.BACKBONE_3D.SST_BLOCK_LIST)
+    ep0 = gplan.encoder_plan(vox0, *args, keep_frac=0.25, noise=noise, dec_sources=[0, 1, 2])
+    cap_noise = torch.cat([noise, torch.rand(pts.shape[0] - noise.numel(), device=dev())])
+    for rep in range(2):                                   # twice: the arena / look-back states of a previous plan are reused memory
+        vox1, ep1 = gplan.PlanPrefetch(pts, ds.point_cloud_range, ds.voxel_size, ds.grid_size, B, *args, keep_frac=0.25, noise=cap_noise,
+                                       dec_sources=[0, 1, 2]).finish()
+        assert (vox1.N, vox1.M) == (vox0.N, vox0.M)
+        for name in ("points", "point_coords", "inverse", "inverse32", "voxel_coords", "pillar_cell", "pt_off", "pillar_pts", "point_rank",
+                     "sample_off", "pillar_mean", "cell2pillar", "points_pm", "row_pillar"):
+            assert torch.equal(getattr(vox0, name), getattr(vox1, name)), name
+        assert torch.equal(ep0.mask, ep1.mask) and torch.equal(ep0.tok_pillar, ep1.tok_pillar)
+        for i, (a, b) in enumerate(zip(ep0.stages, ep1.stages)):
+            assert (a.B, a.Y, a.X, a.n_tok) == (b.B, b.Y, b.X, b.n_tok)
+            for name in ("tok_cell", "map", "nbr_subm", "nbr_down", "nbr_down_t", "_nbr_subm_t"):
+                x, y = getattr(a, name), getattr(b, name)
+                assert (x is None) == (y is None) and (x is None or torch.equal(x, y)), (i, name)
+            assert (a._up_sites is None) == (b._up_sites is None)
+            if a._up_sites is not None:
+                assert a._up_sites[0] == b._up_sites[0] and torch.equal(a._up_sites[1], b._up_sites[1])
+            for k, (wa, wb) in enumerate(zip(a.windows, b.windows)):
+                for f in dataclasses.fields(wa):
+                    x, y = getattr(wa, f.name), getattr(wb, f.name)
+                    assert torch.equal(x, y) if isinstance(x, torch.Tensor) else x == y, (i, k, f.name)
+        assert ep0.dec_tiles.n_act == ep1.dec_tiles.n_act and torch.equal(ep0.dec_tiles.tile_slot, ep1.dec_tiles.tile_slot)
+        assert torch.equal(ep0.dec_tiles.tile_list, ep1.dec_tiles.tile_list)
+        del vox1, ep1

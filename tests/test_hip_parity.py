@@ -673,7 +673,8 @@ def test_prefetched_plan_is_identical_to_inline_plan():
     noise_cap = torch.cat([noise, torch.rand(pts.shape[0] - noise.numel(), device=dev())])   # capacity-sized noise
     pf = bb.prefetch_plan(pts, B, noise=noise_cap)
     vox1, ep1 = pf.finish()
-    for name in ("N", "M", "points", "point_coords", "inverse", "voxel_coords", "pillar_cell", "pt_off", "sample_off", "pillar_mean"):
+    for name in ("N", "M", "points", "point_coords", "inverse", "inverse32", "voxel_coords", "pillar_cell", "pt_off", "pillar_pts",
+                 "point_rank", "sample_off", "pillar_mean", "cell2pillar", "points_pm", "row_pillar"):
         same(getattr(vox0, name), getattr(vox1, name), f"vox.{name}")
     same(ep0.mask, ep1.mask, "mask")
     same(ep0.tok_pillar, ep1.tok_pillar, "tok_pillar")
@@ -683,6 +684,18 @@ def test_prefetched_plan_is_identical_to_inline_plan():
                 assert torch.equal(a.map, b.map)
             else:
                 same(getattr(a, f.name), getattr(b, f.name), f"stage{i}.{f.name}")
+        # the tables the one-call plan builds in its own kernels: transposed submanifold rulebook, full-resolution sites
+        same(torch.flip(a.nbr_subm, dims=[1]).contiguous(), b._nbr_subm_t, f"stage{i}.nbr_subm_t")
+        up = bb.grid_size[1] // a.Y
+        if up > 1:
+            assert b._up_sites[0] == up
+            same(gplan.upsample_cells(a.tok_cell, a.Y, a.X, int(up)).reshape(-1), b._up_sites[1], f"stage{i}.up_sites")
+    srcs = bb._dec_sources()
+    dt0 = gplan.decoder_tiles(ep0, srcs, int(bb.grid_size[1]), int(bb.grid_size[0]))
+    dt1 = ep1.dec_tiles
+    assert dt1 is not None and dt0.n_act == dt1.n_act and dt0.sources == dt1.sources
+    same(dt0.tile_slot, dt1.tile_slot, "dec.tile_slot")
+    same(dt0.tile_list, dt1.tile_list, "dec.tile_list")
     ret0, _, _ = net({"points": pts, "batch_size": B, "mae_noise": noise})
     ret1, _, _ = net({"points": pts, "batch_size": B, "_gdmae_vox": vox1, "_gdmae_plan": ep1})
     assert float(ret0["loss"]) == float(ret1["loss"])

@@ -34,6 +34,11 @@ SIDE = torch.cuda.Stream()
 TINY = torch.zeros(64, device=dev)
 REUSE = "--reuse-plans" in sys.argv      # geometry plans of the 4 pooled batches built once: the step without its plan kernels
 PLANS = [net.backbone_3d.prefetch_plan(b, 8).finish() for b in batches] if REUSE else None
+PREBUILT = "--prebuilt" in sys.argv       # one never-consumed plan per step, all built before the loop (no plan kernels inside the steps)
+if PREBUILT:
+    REUSE = True
+    PLANS = [net.backbone_3d.prefetch_plan(batches[i % 4], 8).finish() for i in range(64)]
+    torch.cuda.synchronize()
 def ev():
     e = torch.cuda.Event(enable_timing=True); e.record(); return e
 HOST = {"finish": 0.0, "prefetch": 0.0, "forward": 0.0, "backward": 0.0, "opt": 0.0, "n": 0}
@@ -43,13 +48,15 @@ def step(i, rec):
     e0 = ev()
     opt.zero_grad()
     if REUSE:
-        pf = PLANS[i % 4]
+        pf = PLANS[i % len(PLANS)]
     else:
         pf = pend.pop(i, None) or net.backbone_3d.prefetch_plan(pts, 8)
     bd = {"points": pts, "batch_size": 8, "_gdmae_grad_sync": opt.sync}
     bd["_gdmae_vox"], bd["_gdmae_plan"] = pf.finish() if hasattr(pf, "finish") else pf
+    hp0 = time.perf_counter()
     pfn = None if REUSE else net.backbone_3d.prefetch_plan(nxt, 8, ready=resident)
     h1 = time.perf_counter()
+    HOST["issue"] = HOST.get("issue", 0.0) + (h1 - hp0 if rec else 0.0)
     with torch.autocast("cuda", dtype=torch.bfloat16):
         ret, _, _ = net(bd)
     e1 = ev()
@@ -90,7 +97,12 @@ def step(i, rec):
     e3 = ev()
     h5 = time.perf_counter()
     if not REUSE:
+        hw0 = time.perf_counter()
+        pfn.event.synchronize()
+        hw1 = time.perf_counter()
         pend[i + 1] = pfn.finish()
+        if rec:
+            HOST["wait"] = HOST.get("wait", 0.0) + hw1 - hw0
     h6 = time.perf_counter()
     if rec:
         marks.append((e0, e1, e2, e3))
@@ -101,16 +113,24 @@ if "--high-priority" in sys.argv:          # training on a high-priority stream:
     hp = torch.cuda.Stream(priority=torch.cuda.Stream.priority_range()[1])
     hp.wait_stream(torch.cuda.current_stream())
     torch.cuda.set_stream(hp)
+def gemm_stats():
+    import ctypes as C
+    from gdmae_hip import lib as L
+    a = (C.c_longlong * 2)()
+    L.call("gdmae_gemm_stats", a)
+    return int(a[0]), int(a[1])
 for i in range(10): step(i, False)
 torch.cuda.synchronize()
+print("library GEMM calls / plans created after the warm-up:", gemm_stats())
 t0 = time.perf_counter()
 N = 40
 for i in range(10, 10 + N): step(i, True)
 torch.cuda.synchronize()
 wall = (time.perf_counter() - t0) / N * 1e3
+print("library GEMM calls / plans created after the timed steps:", gemm_stats())
 f = sum(a.elapsed_time(b) for a, b, _, _ in marks) / N
 b = sum(b_.elapsed_time(c) for _, b_, c, _ in marks) / N
 o = sum(c.elapsed_time(d) for _, _, c, d in marks) / N
 gap = sum(marks[k][3].elapsed_time(marks[k + 1][0]) for k in range(N - 1)) / (N - 1)
-print("host ms/step: " + ", ".join(f"{k} {1e3 * v / HOST['n']:.2f}" for k, v in HOST.items() if k != "n") + f" | total {1e3 * sum(v for k, v in HOST.items() if k != 'n') / HOST['n']:.2f}")
+print("host ms/step: " + ", ".join(f"{k} {1e3 * v / HOST['n']:.2f}" for k, v in HOST.items() if k != "n") + f" | total {1e3 * sum(v for k, v in HOST.items() if k not in ('n', 'issue', 'wait')) / HOST['n']:.2f} (issue / wait are parts of finish)")
 print(f"wall/step {wall:.3f} ms | forward span {f:.3f} backward span {b:.3f} optimizer span {o:.3f} step-to-step gap {gap:.3f} | sum {f + b + o + gap:.3f}")
