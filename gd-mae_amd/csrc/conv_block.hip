@@ -7,7 +7,13 @@
 // rulebook gather + GEMM for the input gradient.  Parameter gradients are ACCUMULATED into the caller's fp32 buffers.
 #include "../../include/gdmae_hip.h"
 #include "common.h"
+#include "dw_grouped.h"
 #include "gemm.h"
+#include <stdlib.h>
+
+// spconv.hip: implicit-GEMM sparse convolution over the rulebook (bf16, 128 / 256 channels)
+bool gd_spconv_supported(int cin, int cout);
+int gd_spconv(hipStream_t st, const void* X, int x_f32, const int* nbr, const void* Wp, long long n, int cin, int cout, void* Y, int slot);
 
 namespace {
 
@@ -50,24 +56,63 @@ __global__ __launch_bounds__(256) void k_permute_w(const T* __restrict__ W, int 
 }
 
 struct Scratch {
-  char *gemm_ws, *cs_ws, *st, *rs_ws, *c01, *dy, *gcols, *wt, *sk_ws;
+  char *gemm_ws, *cs_ws, *st, *rs_ws, *c01, *dy, *gcols, *wt, *sk_ws, *dw_part;
   size_t bytes;
 };
-Scratch layout(void* base, long long n_in, long long n_out, int cin, int cout, int es) {
+long long pad512(long long n) { return (n + 1023) / 1024 * 1024; }       // rows of dy: a multiple of 16 slices x 64-row chunks
+// row slices of the gathered weight-gradient launch: ~2 workgroups per CU (GDMAE_SPCONV_DW_WGS overrides the bound)
+int conv_dw_slices(long long n_pad, int tiles) {
+  static const int wgs = getenv("GDMAE_SPCONV_DW_WGS") ? atoi(getenv("GDMAE_SPCONV_DW_WGS")) : 1200;
+  return gd_dw_group_slices_for(n_pad, tiles, wgs);
+}
+// implicit: the im2col-free path (spconv.hip + the gathered grouped weight gradient): no gathered matrices, no library workspaces;
+// dy is padded to the slice grid of the weight-gradient kernel, which also gets its partial tiles here
+Scratch layout(void* base, long long n_in, long long n_out, int cin, int cout, int es, bool implicit) {
   Scratch s;
   size_t off = 0;
   auto take = [&](size_t b) { char* p = (char*)base + off; off += gd_align(b); return p; };
-  s.gemm_ws = take(GD_LT_WORKSPACE);
+  s.gemm_ws = take(implicit ? 0 : GD_LT_WORKSPACE);
   s.cs_ws = take(gdmae_colstats_workspace_bytes(cout));
   s.st = take((size_t)3 * cout * sizeof(double));
   s.rs_ws = take(gdmae_rows_bwd_stats_workspace_bytes(cout));
   s.c01 = take((size_t)2 * cout * sizeof(float));
-  s.dy = take((size_t)n_out * cout * es);
-  s.gcols = take((size_t)n_in * 9 * cout * es);
-  s.wt = take((size_t)9 * cout * cin * es);
-  s.sk_ws = take(gdmae_gemm_tn_splitk_workspace_bytes(n_out, cout, 9 * cin));
+  s.dy = take((size_t)(implicit ? pad512(n_out) : n_out) * cout * es);
+  s.gcols = take(implicit ? 0 : (size_t)n_in * 9 * cout * es);
+  s.wt = take(implicit ? 0 : (size_t)9 * cout * cin * es);
+  s.sk_ws = take(implicit ? 0 : gdmae_gemm_tn_splitk_workspace_bytes(n_out, cout, 9 * cin));
+  s.dw_part = nullptr;
+  if (implicit) {
+    const int tiles = 9 * (cout / 128) * (cin / 128);
+    s.dw_part = take((size_t)conv_dw_slices(pad512(n_out), tiles) * 9 * cout * cin * sizeof(float));
+  }
   s.bytes = off;
   return s;
+}
+bool use_implicit(const gdmae_conv_block_args* a) {
+  static const int off = getenv("GDMAE_SPCONV") ? atoi(getenv("GDMAE_SPCONV")) == 0 : 0;
+  return !off && a->bf16 && a->packed_fwd != nullptr && a->packed_bwd != nullptr && gd_spconv_supported(a->cin, a->cout) &&
+         gd_spconv_supported(a->cout, a->cin);
+}
+
+// dW[(o * 9 + k) * cin + i] += sum_s part[k][s][o][i]: the 9 per-tap partial products of the grouped weight-gradient launch into
+// the (cout, 3, 3, cin) layout, fixed order
+__global__ __launch_bounds__(256) void k_spconv_dw_reduce(const float* __restrict__ part, int S, int cout, int cin, float* __restrict__ dW) {
+  const long long per_tap = (long long)S * cout * cin, mn4 = (long long)cout * cin / 4;
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < 9 * mn4; e += (long long)gridDim.x * blockDim.x) {
+    const int k = (int)(e / mn4);
+    const long long r = e % mn4;
+    const float4* p = reinterpret_cast<const float4*>(part + k * per_tap) + r;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < S; ++s) {
+      const float4 v = p[(long long)s * mn4];
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    const long long o = (r * 4) / cin, i = (r * 4) % cin;
+    float4* d = reinterpret_cast<float4*>(dW + (o * 9 + k) * cin + i);
+    float4 w = *d;
+    w.x += acc.x; w.y += acc.y; w.z += acc.z; w.w += acc.w;
+    *d = w;
+  }
 }
 
 #define CB_TRY(x)             \
@@ -79,7 +124,12 @@ Scratch layout(void* base, long long n_in, long long n_out, int cin, int cout, i
 }  // namespace
 
 extern "C" size_t gdmae_conv_block_scratch_bytes(long long n_in, long long n_out, int cin, int cout, int bf16) {
-  return layout(nullptr, n_in, n_out, cin, cout, bf16 ? 2 : 4).bytes;
+  size_t b = layout(nullptr, n_in, n_out, cin, cout, bf16 ? 2 : 4, false).bytes;
+  if (bf16 && gd_spconv_supported(cin, cout) && gd_spconv_supported(cout, cin)) {
+    const size_t bi = layout(nullptr, n_in, n_out, cin, cout, 2, true).bytes;
+    b = bi > b ? bi : b;
+  }
+  return b;
 }
 
 extern "C" int gdmae_conv_block_fwd(const gdmae_conv_block_args* a, void* stream) {
@@ -87,9 +137,13 @@ extern "C" int gdmae_conv_block_fwd(const gdmae_conv_block_args* a, void* stream
   if (a->n_out <= 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   const int es = a->bf16 ? 2 : 4;
-  Scratch s = layout(a->scratch, a->n_in, a->n_out, a->cin, a->cout, es);
+  const bool implicit = use_implicit(a);
+  Scratch s = layout(a->scratch, a->n_in, a->n_out, a->cin, a->cout, es, implicit);
   const long long slots = a->n_out * 9;
-  if (a->bf16 && a->x_f32) {
+  if (implicit) {
+    // the gathered rows go straight into the MFMA operand tile: no im2col matrix, no library GEMM
+    CB_TRY(gd_spconv(st, a->x, a->x_f32, a->nbr, a->packed_fwd, a->n_out, a->cin, a->cout, a->y, GD_T_SPCONV_FWD));
+  } else if (a->bf16 && a->x_f32) {
     long long g = (slots * (a->cin / 8) + 255) / 256;
     if (g > 16384) g = 16384;
     hipLaunchKernelGGL(k_gather_rows_f32_bf16, dim3((int)g), dim3(256), 0, st, (const float*)a->x, a->nbr, slots, a->cin,
@@ -98,7 +152,8 @@ extern "C" int gdmae_conv_block_fwd(const gdmae_conv_block_args* a, void* stream
   } else {
     CB_TRY(gdmae_gather_rows(a->x, a->nbr, slots, a->cin * es, a->cols, stream));
   }
-  CB_TRY(gdmae_gemm(a->cols, a->W, a->y, a->n_out, a->cout, 9ll * a->cin, 0, 1, a->bf16, 0, nullptr, s.gemm_ws, stream));
+  if (!implicit)
+    CB_TRY(gdmae_gemm(a->cols, a->W, a->y, a->n_out, a->cout, 9ll * a->cin, 0, 1, a->bf16, 0, nullptr, s.gemm_ws, stream));
   CB_TRY(gdmae_bn_fold(a->y, a->n_out, a->cout, a->bf16, (double)a->n_out, a->gamma, a->beta, a->eps, a->momentum, a->running_mean,
                        a->running_var, a->num_batches, a->stats, a->ab, a->mv, s.cs_ws, stream));
   CB_TRY(gdmae_rows_affine_relu_scatter(a->y, a->bf16, nullptr, a->n_out, a->cout, a->ab, a->ab + a->cout, a->out, a->bf16, a->cout, 0,
@@ -111,7 +166,8 @@ extern "C" int gdmae_conv_block_bwd(const gdmae_conv_block_args* a, void* stream
   if (a->n_out <= 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   const int es = a->bf16 ? 2 : 4;
-  Scratch s = layout(a->scratch, a->n_in, a->n_out, a->cin, a->cout, es);
+  const bool implicit = use_implicit(a);
+  Scratch s = layout(a->scratch, a->n_in, a->n_out, a->cin, a->cout, es, implicit);
   const int C = a->cout;
   // ---- BatchNorm1d + ReLU backward on the rows of y
   CB_TRY(gdmae_rows_bwd_stats(a->y, a->bf16, nullptr, a->n_out, C, a->ab, a->ab + C, a->g, a->g_f32 ? 0 : a->bf16, C, 0, nullptr,
@@ -120,6 +176,29 @@ extern "C" int gdmae_conv_block_bwd(const gdmae_conv_block_args* a, void* stream
                                   (double)a->n_out, nullptr, a->dgamma, a->dbeta, 1, (float*)s.c01, stream));
   CB_TRY(gdmae_rows_bwd(a->y, a->bf16, nullptr, a->n_out, C, a->ab, a->ab + C, (const float*)s.c01, (const float*)s.c01 + C, a->g,
                         a->g_f32 ? 0 : a->bf16, C, 0, s.dy, a->bf16, stream));
+  if (implicit) {
+    // ---- weight gradient: the nine per-tap products dW_k (cout, cin) = dy^T X[nbr[:, k]] as ONE grouped TN launch (the X rows
+    //      are gathered through the rulebook column on load; all tiles of a row slice on one XCD), reduced into (cout, 9, cin)
+    GdDwGroup Gp;
+    Gp.n_jobs = 9;
+    const long long n_pad = pad512(a->n_out);
+    const int S = conv_dw_slices(n_pad, 9 * (C / 128) * (a->cin / 128));
+    for (int k = 0; k < 9; ++k) {
+      Gp.job[k] = GdDwJob{s.dy, a->x, C, a->cin, (float*)s.dw_part + (size_t)k * S * C * a->cin, nullptr, 0, a->nbr + k, 9, a->x_f32};
+    }
+    {
+      GdTimed timed(GD_T_SPCONV_BWD, st, (double)a->n_out * (2.0 * C + 9.0 * a->cin * (a->x_f32 ? 4 : 2) + 36.0) + 36.0 * S * C * a->cin,
+                    2.0 * a->n_out * 9.0 * C * a->cin);
+      CB_TRY(gd_dw_grouped_s(st, Gp, n_pad, a->n_out, S));
+    }
+    GD_REQUIRE(Gp.S == S, "conv block: slice count");
+    hipLaunchKernelGGL(k_spconv_dw_reduce, dim3(gd_div_up(9ll * C * a->cin / 4, 256)), dim3(256), 0, st, (const float*)s.dw_part, S, C, a->cin,
+                       a->dW);
+    GD_LAUNCH_CHECK();
+    // ---- input gradient: the same implicit GEMM over the transposed rulebook with the per-tap transposed weights
+    if (a->dx) CB_TRY(gd_spconv(st, s.dy, 0, a->nbr_t, a->packed_bwd, a->n_in, C, a->cin, a->dx, GD_T_SPCONV_BWD));
+    return 0;
+  }
   // ---- weight gradient: dW (cout, 9 cin) += dy^T cols
   CB_TRY(gdmae_gemm_tn_splitk(s.dy, a->cols, a->dW, a->n_out, C, 9 * a->cin, a->bf16, 1, s.sk_ws, stream));
   // ---- input gradient: dx (n_in, cin) = gather(dy, nbr_t) (n_in, 9 cout) @ Wt (9 cout, cin)

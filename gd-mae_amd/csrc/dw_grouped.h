@@ -2,7 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-#define GD_DW_MAX_JOBS 5
+#define GD_DW_MAX_JOBS 9
 
 struct GdDwJob {
   const void* G;        // (rows, M) bf16 row-major: output gradient of the linear layer
@@ -11,6 +11,11 @@ struct GdDwJob {
   float* part;          // (S, M, N) fp32 partial products
   float* colpart;       // (S, M) fp32 column sums of G per slice, or null
   int tile0;            // first 128 x 128 tile of this job in the layer's tile list (filled by gd_dw_grouped)
+  // optional gather of the X rows (sparse-convolution weight gradients: X row of operand row r = X[xidx[r * xidx_stride]], a
+  // negative index = a zero row); x_f32: the X rows are fp32 (N columns) and rounded to bf16 on load
+  const int* xidx;
+  int xidx_stride;
+  int x_f32;
 };
 struct GdDwGroup {
   GdDwJob job[GD_DW_MAX_JOBS];
@@ -23,4 +28,6 @@ struct GdDwGroup {
 
 bool gd_dw_group_supported(long long n_pad, int d, int ff);
 int gd_dw_group_slices(long long n_pad, int tiles_total);
+int gd_dw_group_slices_for(long long n_pad, int tiles_total, int max_wgs);
 int gd_dw_grouped(hipStream_t st, GdDwGroup& A, long long n_pad, long long n_valid);
+int gd_dw_grouped_s(hipStream_t st, GdDwGroup& A, long long n_pad, long long n_valid, int S);

@@ -44,6 +44,59 @@ __device__ __forceinline__ Chunk load_chunk(const unsigned short* __restrict__ b
   k.q3 = *reinterpret_cast<const uint4*>(p + 48ll * ld);
   return k;
 }
+// X rows through an index (rulebook column of a sparse convolution); rows >= n_valid are not looked up.  Branch-free: the four
+// indices of a thread's pieces are loaded first, then the four rows (row 0 for a missing tap, cleared afterwards), so a chunk costs
+// two round trips instead of eight serialised ones.
+__device__ __forceinline__ uint4 cvt_f32x8(const float4& a, const float4& b) {
+  auto f2bf = [](float f) -> unsigned {
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7F800000u) == 0x7F800000u) return u >> 16;
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+  };
+  uint4 q;
+  q.x = f2bf(a.x) | (f2bf(a.y) << 16); q.y = f2bf(a.z) | (f2bf(a.w) << 16);
+  q.z = f2bf(b.x) | (f2bf(b.y) << 16); q.w = f2bf(b.z) | (f2bf(b.w) << 16);
+  return q;
+}
+struct ChunkIdx {
+  int j0, j1, j2, j3;
+};
+__device__ __forceinline__ ChunkIdx load_chunk_idx(const int* __restrict__ xidx, int stride, long long row0, long long n_valid, int tid) {
+  const long long r = row0 + (tid >> 4);
+  ChunkIdx k;
+  k.j0 = r < n_valid ? xidx[r * stride] : -1;
+  k.j1 = r + 16 < n_valid ? xidx[(r + 16) * stride] : -1;
+  k.j2 = r + 32 < n_valid ? xidx[(r + 32) * stride] : -1;
+  k.j3 = r + 48 < n_valid ? xidx[(r + 48) * stride] : -1;
+  return k;
+}
+template <bool F32>
+__device__ __forceinline__ Chunk load_chunk_rows(const void* __restrict__ base, int ld, const ChunkIdx& I, int col0, int tid) {
+  const int col = col0 + (tid & 15) * 8;
+  const long long o0 = (long long)(I.j0 < 0 ? 0 : I.j0) * ld + col, o1 = (long long)(I.j1 < 0 ? 0 : I.j1) * ld + col;
+  const long long o2 = (long long)(I.j2 < 0 ? 0 : I.j2) * ld + col, o3 = (long long)(I.j3 < 0 ? 0 : I.j3) * ld + col;
+  Chunk k;
+  if (F32) {
+    const float* f = (const float*)base;
+    const float4 a0 = *reinterpret_cast<const float4*>(f + o0), b0 = *reinterpret_cast<const float4*>(f + o0 + 4);
+    const float4 a1 = *reinterpret_cast<const float4*>(f + o1), b1 = *reinterpret_cast<const float4*>(f + o1 + 4);
+    const float4 a2 = *reinterpret_cast<const float4*>(f + o2), b2 = *reinterpret_cast<const float4*>(f + o2 + 4);
+    const float4 a3 = *reinterpret_cast<const float4*>(f + o3), b3 = *reinterpret_cast<const float4*>(f + o3 + 4);
+    k.q0 = cvt_f32x8(a0, b0); k.q1 = cvt_f32x8(a1, b1); k.q2 = cvt_f32x8(a2, b2); k.q3 = cvt_f32x8(a3, b3);
+  } else {
+    const unsigned short* h = (const unsigned short*)base;
+    k.q0 = *reinterpret_cast<const uint4*>(h + o0);
+    k.q1 = *reinterpret_cast<const uint4*>(h + o1);
+    k.q2 = *reinterpret_cast<const uint4*>(h + o2);
+    k.q3 = *reinterpret_cast<const uint4*>(h + o3);
+  }
+  const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+  if (I.j0 < 0) k.q0 = z;
+  if (I.j1 < 0) k.q1 = z;
+  if (I.j2 < 0) k.q2 = z;
+  if (I.j3 < 0) k.q3 = z;
+  return k;
+}
 // rows >= n_valid (the padding of the row count to the slice grid) contribute nothing, whatever the buffers hold there:
 // the chunk(s) that reach past n_valid are cleared in registers before they are staged (uniform branch per chunk)
 __device__ __forceinline__ void mask_chunk(Chunk& k, long long row0, int tid, long long n_valid) {
@@ -96,6 +149,8 @@ __global__ __launch_bounds__(256, 2) void k_dw_grouped(GdDwGroup A) {
   float* part = A.job[0].part;
   float* colpart = A.job[0].colpart;
   int M = A.job[0].M, N = A.job[0].N, tile0 = 0;
+  const int* xidx = A.job[0].xidx;
+  int xstride = A.job[0].xidx_stride, x_f32 = A.job[0].x_f32;
 #pragma unroll
   for (int j = 1; j < GD_DW_MAX_JOBS; ++j)
     if (j < A.n_jobs && t >= A.job[j].tile0) {
@@ -106,6 +161,9 @@ __global__ __launch_bounds__(256, 2) void k_dw_grouped(GdDwGroup A) {
       M = A.job[j].M;
       N = A.job[j].N;
       tile0 = A.job[j].tile0;
+      xidx = A.job[j].xidx;
+      xstride = A.job[j].xidx_stride;
+      x_f32 = A.job[j].x_f32;
     }
   const int tn_count = N / kTile;
   const int tm = (t - tile0) / tn_count, tn = (t - tile0) - tm * tn_count;
@@ -127,11 +185,24 @@ __global__ __launch_bounds__(256, 2) void k_dw_grouped(GdDwGroup A) {
   // two chunks in flight in registers (the loads of chunk c + 2 are issued behind the barrier of chunk c: ~2 compute phases of
   // latency cover per load), two LDS buffers
   const int gcol = tm * kTile, xcol = tn * kTile;
-  Chunk g0 = load_chunk(G, M, r0, gcol, tid), x0 = load_chunk(X, N, r0, xcol, tid);
+  // gathered X: the indices of chunk c + 4 are requested when the rows of chunk c + 2 are (one more stage of look-ahead for the
+  // dependent load); i0 / i1 hold the indices of the next even / odd chunk to fetch
+  ChunkIdx i0 = {-1, -1, -1, -1}, i1 = {-1, -1, -1, -1};
+  auto load_x = [&](long long row0, ChunkIdx& I) {
+    if (!xidx) return load_chunk(X, N, row0, xcol, tid);
+    const Chunk k = x_f32 ? load_chunk_rows<true>(X, N, I, xcol, tid) : load_chunk_rows<false>(X, N, I, xcol, tid);
+    I = load_chunk_idx(xidx, xstride, row0 + 2 * kChunk, A.n_valid, tid);      // for this buffer's next chunk
+    return k;
+  };
+  if (xidx) {
+    i0 = load_chunk_idx(xidx, xstride, r0, A.n_valid, tid);
+    i1 = load_chunk_idx(xidx, xstride, r0 + kChunk, A.n_valid, tid);
+  }
+  Chunk g0 = load_chunk(G, M, r0, gcol, tid), x0 = load_x(r0, i0);
   Chunk g1 = g0, x1 = x0;
   if (nchunk > 1) {
     g1 = load_chunk(G, M, r0 + kChunk, gcol, tid);
-    x1 = load_chunk(X, N, r0 + kChunk, xcol, tid);
+    x1 = load_x(r0 + kChunk, i1);
   }
   auto compute = [&](const unsigned char* bg, const unsigned char* bx) {
 #pragma unroll
@@ -159,7 +230,7 @@ __global__ __launch_bounds__(256, 2) void k_dw_grouped(GdDwGroup A) {
     __syncthreads();          // chunk c staged; buffer 0 was last read two phases ago, before the previous barrier
     if (c + 2 < nchunk) {
       g0 = load_chunk(G, M, r0 + (long long)(c + 2) * kChunk, gcol, tid);
-      x0 = load_chunk(X, N, r0 + (long long)(c + 2) * kChunk, xcol, tid);
+      x0 = load_x(r0 + (long long)(c + 2) * kChunk, i0);
     }
     compute(bufg0, bufx0);
     if (c + 1 < nchunk) {
@@ -173,7 +244,7 @@ __global__ __launch_bounds__(256, 2) void k_dw_grouped(GdDwGroup A) {
       __syncthreads();
       if (c + 3 < nchunk) {
         g1 = load_chunk(G, M, r0 + (long long)(c + 3) * kChunk, gcol, tid);
-        x1 = load_chunk(X, N, r0 + (long long)(c + 3) * kChunk, xcol, tid);
+        x1 = load_x(r0 + (long long)(c + 3) * kChunk, i1);
       }
       compute(bufg1, bufx1);
     }
@@ -210,16 +281,21 @@ bool gd_dw_group_supported(long long n_pad, int d, int ff) {
   return d % kTile == 0 && ff % kTile == 0 && d <= 512 && ff <= 1024 && n_pad > 0 && n_pad % (8 * kChunk) == 0;
 }
 // number of row slices: a multiple of 8 (one XCD per slice residue), tiles x slices ~ 2 workgroups per CU
-int gd_dw_group_slices(long long n_pad, int tiles_total) {
+int gd_dw_group_slices(long long n_pad, int tiles_total) { return gd_dw_group_slices_for(n_pad, tiles_total, 512); }
+// ... with the number of workgroups the launch should not exceed after doubling (the layer launch wants ~1 workgroup per CU:
+// its tiles re-read few operands; the gathered sparse-convolution launch is latency-bound and wants both resident slots filled)
+int gd_dw_group_slices_for(long long n_pad, int tiles_total, int max_wgs) {
   int S = 8;
-  while (S < 64 && (long long)tiles_total * S * 2 <= 512 && n_pad % ((long long)S * 2 * kChunk) == 0 && n_pad / (S * 2) >= 2 * kChunk) S *= 2;
+  while (S < 64 && (long long)tiles_total * S * 2 <= max_wgs && n_pad % ((long long)S * 2 * kChunk) == 0 && n_pad / (S * 2) >= 2 * kChunk) S *= 2;
   return S;
 }
 
 // jobs: G (n_pad, M) / X (n_pad, N) bf16 row-major, M and N multiples of 128; part: (S, M, N) fp32, colpart: (S, M) fp32 or null;
 // rows >= n_valid are ignored (n_pad = the row count padded to the slice grid; the buffers must extend to n_pad rows).
 // Fills tile0 / tiles_total / S / rows_per_slice and launches.
-int gd_dw_grouped(hipStream_t st, GdDwGroup& A, long long n_pad, long long n_valid) {
+int gd_dw_grouped(hipStream_t st, GdDwGroup& A, long long n_pad, long long n_valid) { return gd_dw_grouped_s(st, A, n_pad, n_valid, 0); }
+// S > 0: that many row slices (a multiple of 8 that divides n_pad / 64) instead of the default choice
+int gd_dw_grouped_s(hipStream_t st, GdDwGroup& A, long long n_pad, long long n_valid, int S) {
   GD_REQUIRE(A.n_jobs >= 1 && A.n_jobs <= GD_DW_MAX_JOBS, "dw_grouped: job count");
   int tiles = 0;
   for (int j = 0; j < A.n_jobs; ++j) {
@@ -229,7 +305,8 @@ int gd_dw_grouped(hipStream_t st, GdDwGroup& A, long long n_pad, long long n_val
   }
   A.tiles_total = tiles;
   GD_REQUIRE(n_pad % (8 * kChunk) == 0, "dw_grouped: rows must be a multiple of 512");
-  A.S = gd_dw_group_slices(n_pad, tiles);
+  A.S = S > 0 ? S : gd_dw_group_slices(n_pad, tiles);
+  GD_REQUIRE(A.S % 8 == 0 && n_pad % ((long long)A.S * kChunk) == 0, "dw_grouped: slices must be a multiple of 8 that divides the row chunks");
   A.rows_per_slice = n_pad / A.S;
   A.n_valid = n_valid;
   double by = 0.0, fl = 0.0;   // operands read once (the re-reads by the tiles of a slice are L2 hits), fp32 partial tiles written

@@ -1,0 +1,240 @@
+// 2-D sparse convolution (k3: submanifold, strided s2 p1, and their input gradients) as an IMPLICIT GEMM over the rulebook
+// (reference call sites pcdet/utils/spconv_utils.py:37-56, spt_backbone.py:206,217 - spconv's
+// gather-GEMM-scatter there, un-vendored):
+//
+//     Y[r, :] = sum_{tap = 0..8}  W_tap (COUT, CIN)  X[nbr[r, tap], :]          (nbr < 0: the tap has no active input)
+//
+// Round 2 materialised the im2col matrix (n x 9 CIN bf16: 207 MB for the 256 -> 256 block of stage 2), ran a library GEMM
+// over it and kept it for the weight gradient; the input gradient did the same over the transposed rulebook.  Here the
+// gathered rows never leave the CU: a workgroup (8 wavefronts) owns 32 or 64 output rows and the FULL output width; per tap
+// it gathers its rows' CIN-vectors through the rulebook straight into an LDS tile (the next tap's rows are in flight in
+// registers while the current tap is multiplied), and accumulates Y^T = W X^T with v_mfma_f32_32x32x16_bf16 exactly as
+// the token GEMMs do (A = weights streamed in fragment order from a packed image - 9 per-tap images back to back, refreshed
+// once per optimizer step -, B = the LDS tile).  The same kernel is the input gradient: X = dY rows, nbr = the transposed
+// rulebook, W = the per-tap transposed weights.  fp32 source rows (the first convolution after an fp32 stage output) are
+// rounded to bf16 on their way into LDS.
+//
+// Bytes per output row: 9 gathered rows x CIN x 2 B (L2 hits: every input row is read by up to 9 outputs) + COUT x 2 B
+// written, against 9 CIN x 2 B written + read for the im2col matrix before.
+#include "../../include/gdmae_hip.h"
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+union SpFrag {
+  uint4 q;
+  bf16x8 v;
+};
+__device__ inline unsigned short sp_f2bf(float f) {
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7F800000u) == 0x7F800000u) return (unsigned short)(u >> 16);
+  return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+__device__ inline unsigned sp_pack2(float lo, float hi) { return sp_f2bf(lo) | ((unsigned)sp_f2bf(hi) << 16); }
+
+struct SpArgs {
+  const void* X;          // (n_src, CIN) bf16 or fp32 rows
+  const int* nbr;         // (n, 9) source row of every (output row, tap), < 0: none
+  const uint4* Wp;        // 9 packed (COUT, CIN) images
+  unsigned short* Y;      // (n, COUT) bf16
+  long long n;
+};
+
+constexpr int kWaves = 8;
+constexpr int kRing = 8;      // weight fragments in flight (ring), prefetch distance 4 k-steps
+constexpr int kPf = 4;
+
+template <int COUT>
+struct SpRows {
+  static constexpr int value = COUT >= 256 ? 32 : 64;
+};
+
+template <int CIN, int COUT, bool SRC_F32>
+__global__ __launch_bounds__(512, 2) void k_spconv(SpArgs A) {
+  constexpr int ROWS = SpRows<COUT>::value;
+  constexpr int KS = CIN / 16;                     // k-steps per tap
+  constexpr int MB = COUT / 32;                    // 32-channel blocks
+  constexpr int MPW = MB >= kWaves ? MB / kWaves : 1;
+  constexpr int NPW = MB >= kWaves ? ROWS / 32 : 1;
+  constexpr int XP = CIN * 2 + 16;                 // LDS row pitch of a gathered tile (conflict-free ds_read_b128)
+  constexpr int SP = COUT * 2 + 16;                // ... of the output staging tile
+  constexpr int CPR = CIN / 8;                     // 16-byte chunks per gathered row
+  constexpr int RPP = 512 / CPR;                   // rows per pass of the 512 threads
+  constexpr int P = ROWS / RPP;                    // passes per tap
+  static_assert(KS % kRing == 0 && P >= 1 && ROWS % RPP == 0, "unsupported shape");
+  extern __shared__ __align__(16) unsigned char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const long long row0 = (long long)blockIdx.x * ROWS;
+  const int mb0 = MB >= kWaves ? wv : (wv >> 1);
+  const int nb0 = MB >= kWaves ? 0 : (wv & 1);
+  const uint4* __restrict__ wp = A.Wp + (size_t)mb0 * 64 + lane;        // + (gstep * MB + j * kWaves) * 64
+
+  // ---- weight fragments of the first k-steps
+  SpFrag wr[kRing][MPW];
+#pragma unroll
+  for (int ks = 0; ks < kPf; ++ks)
+#pragma unroll
+    for (int j = 0; j < MPW; ++j) wr[ks][j].q = wp[((size_t)ks * MB + j * kWaves) * 64];
+
+  // ---- gather machinery: this thread's chunk c of rows gr[p]
+  const int gc = tid % CPR;
+  int idx_cur[P], idx_nxt[P];
+  long long grow[P];
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    grow[p] = row0 + p * RPP + tid / CPR;
+    idx_cur[p] = grow[p] < A.n ? A.nbr[grow[p] * 9] : -1;
+    idx_nxt[p] = grow[p] < A.n ? A.nbr[grow[p] * 9 + 1] : -1;
+  }
+  uint4 rq[P];
+  auto fetch = [&](const int (&idx)[P]) {
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      uint4 q = make_uint4(0u, 0u, 0u, 0u);
+      if (idx[p] >= 0) {
+        if (SRC_F32) {
+          const float* s = (const float*)A.X + (long long)idx[p] * CIN + gc * 8;
+          const float4 a = *reinterpret_cast<const float4*>(s), b = *reinterpret_cast<const float4*>(s + 4);
+          q.x = sp_pack2(a.x, a.y); q.y = sp_pack2(a.z, a.w); q.z = sp_pack2(b.x, b.y); q.w = sp_pack2(b.z, b.w);
+        } else {
+          q = *reinterpret_cast<const uint4*>((const unsigned short*)A.X + (long long)idx[p] * CIN + gc * 8);
+        }
+      }
+      rq[p] = q;
+    }
+  };
+  auto stage = [&](unsigned char* b) {
+#pragma unroll
+    for (int p = 0; p < P; ++p) *reinterpret_cast<uint4*>(b + (p * RPP + tid / CPR) * XP + gc * 16) = rq[p];
+  };
+  fetch(idx_cur);
+  stage(lds);
+  __syncthreads();
+
+  f32x16 acc[MPW][NPW];
+#pragma unroll
+  for (int j = 0; j < MPW; ++j)
+#pragma unroll
+    for (int b = 0; b < NPW; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[j][b][i] = 0.f;
+
+  for (int tap = 0; tap < 9; ++tap) {
+    if (tap < 8) fetch(idx_nxt);                                   // next tap's rows: in flight behind this tap's MFMAs
+    if (tap < 7) {
+#pragma unroll
+      for (int p = 0; p < P; ++p) idx_nxt[p] = grow[p] < A.n ? A.nbr[grow[p] * 9 + tap + 2] : -1;
+    }
+    const unsigned char* lb = lds + (tap & 1) * (ROWS * XP) + ((nb0 * 32) + (lane & 31)) * XP + (lane >> 5) * 16;
+    const size_t g0 = (size_t)tap * KS;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      if (tap < 8 || ks + kPf < KS) {
+#pragma unroll
+        for (int j = 0; j < MPW; ++j) wr[(ks + kPf) % kRing][j].q = wp[((g0 + ks + kPf) * MB + j * kWaves) * 64];
+      }
+      SpFrag sf[NPW];
+#pragma unroll
+      for (int b = 0; b < NPW; ++b) sf[b].q = *reinterpret_cast<const uint4*>(lb + b * 32 * XP + ks * 32);
+#pragma unroll
+      for (int j = 0; j < MPW; ++j)
+#pragma unroll
+        for (int b = 0; b < NPW; ++b) acc[j][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[ks % kRing][j].v, sf[b].v, acc[j][b], 0, 0, 0);
+    }
+    if (tap < 8) stage(lds + ((tap + 1) & 1) * (ROWS * XP));
+    __syncthreads();
+  }
+
+  // ---- accumulators -> bf16 -> staging tile [row][channel] -> 16-byte row stores
+#pragma unroll
+  for (int j = 0; j < MPW; ++j) {
+    const int cb = (mb0 + j * kWaves) * 32 + 4 * (lane >> 5);
+#pragma unroll
+    for (int b = 0; b < NPW; ++b) {
+      const int row = (nb0 + b) * 32 + (lane & 31);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        uint2 o;
+        o.x = sp_pack2(acc[j][b][4 * q], acc[j][b][4 * q + 1]);
+        o.y = sp_pack2(acc[j][b][4 * q + 2], acc[j][b][4 * q + 3]);
+        *reinterpret_cast<uint2*>(lds + row * SP + (cb + 8 * q) * 2) = o;
+      }
+    }
+  }
+  __syncthreads();
+  {
+    constexpr int OCPR = COUT / 8;
+    constexpr int ORPP = 512 / OCPR;
+    const int c = tid % OCPR, r = tid / OCPR;
+#pragma unroll
+    for (int p = 0; p < (ROWS + ORPP - 1) / ORPP; ++p) {
+      const int rl = p * ORPP + r;
+      if (rl < ROWS && row0 + rl < A.n)
+        *reinterpret_cast<uint4*>(A.Y + (row0 + rl) * COUT + c * 8) = *reinterpret_cast<const uint4*>(lds + rl * SP + c * 16);
+    }
+  }
+}
+
+template <int CIN, int COUT, bool SRC_F32>
+int sp_launch(const SpArgs& A, hipStream_t st) {
+  constexpr int ROWS = SpRows<COUT>::value;
+  constexpr int tile = ROWS * (CIN * 2 + 16), stg = ROWS * (COUT * 2 + 16);
+  constexpr int lds = 2 * tile > stg ? 2 * tile : stg;
+  static bool once = false;
+  if (!once) {
+    GD_CHECK(hipFuncSetAttribute((const void*)k_spconv<CIN, COUT, SRC_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    once = true;
+  }
+  hipLaunchKernelGGL((k_spconv<CIN, COUT, SRC_F32>), dim3((unsigned)gd_div_up(A.n, ROWS)), dim3(512), lds, st, A);
+  GD_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace
+
+bool gd_spconv_supported(int cin, int cout) { return (cin == 128 || cin == 256) && (cout == 128 || cout == 256); }
+size_t gd_spconv_packed_bytes(int cin, int cout) { return (size_t)9 * cin * cout * 2; }
+
+// Y (n, cout) bf16 = sum_tap Wp_tap X[nbr[:, tap]]; X bf16 or fp32 (x_f32) rows; Wp = 9 packed (cout, cin) images
+int gd_spconv(hipStream_t st, const void* X, int x_f32, const int* nbr, const void* Wp, long long n, int cin, int cout, void* Y, int slot) {
+  if (n <= 0) return 0;
+  GD_REQUIRE(gd_spconv_supported(cin, cout), "spconv: channels must be 128 or 256");
+  SpArgs A{X, nbr, (const uint4*)Wp, (unsigned short*)Y, n};
+  // gathered rows (L2) + the output rows + the weight image, per launch
+  GdTimed timed(slot, st, (double)n * (9.0 * cin * (x_f32 ? 4 : 2) + 2.0 * cout + 36.0) + 18.0 * cin * cout, 2.0 * n * 9.0 * cin * cout);
+#define SP_CASE(ci, co)                                                    \
+  if (cin == ci && cout == co) return x_f32 ? sp_launch<ci, co, true>(A, st) : sp_launch<ci, co, false>(A, st);
+  SP_CASE(128, 128);
+  SP_CASE(128, 256);
+  SP_CASE(256, 128);
+  SP_CASE(256, 256);
+#undef SP_CASE
+  return -1;
+}
+
+// C ABI: see include/gdmae_hip.h
+extern "C" size_t gdmae_spconv_packed_bytes(int cin, int cout) { return gd_spconv_packed_bytes(cin, cout); }
+
+// pack-job table (gdmae_tok_gemm_pack format: {src, dst, M, K, ld, transpose} x 9) of a (cout, 3, 3, cin) fp32 weight:
+// transposed = 0: the forward images (cout, cin) per tap; 1: the input-gradient images (cin, cout) per tap
+extern "C" int gdmae_spconv_pack_jobs(const float* W, int cin, int cout, int transposed, void* packed, long long* jobs) {
+  GD_REQUIRE(gd_spconv_supported(cin, cout), "spconv_pack_jobs: channels must be 128 or 256");
+  for (int t = 0; t < 9; ++t) {
+    long long* J = jobs + 6 * t;
+    J[0] = (long long)(W + (size_t)t * cin);
+    J[1] = (long long)((char*)packed + (size_t)t * cin * cout * 2);
+    J[2] = transposed ? cin : cout;      // rows of the packed (M, K) matrix
+    J[3] = transposed ? cout : cin;
+    J[4] = 9ll * cin;                    // A[r][c] = transposed ? src[c * ld + r] : src[r * ld + c]
+    J[5] = transposed;
+  }
+  return 0;
+}
+
+extern "C" int gdmae_spconv(const void* X, int x_f32, const int* nbr, const void* packed, long long n, int cin, int cout, void* Y,
+                            void* stream) {
+  return gd_spconv((hipStream_t)stream, X, x_f32, nbr, packed, n, cin, cout, Y, GD_T_SPCONV_FWD);
+}

@@ -11,7 +11,12 @@ import ctypes as C
 import torch
 
 from . import lib as L
-from . import ops
+from . import ops, packing
+
+
+import os
+
+IMPLICIT = os.environ.get("GDMAE_SPCONV", "1") != "0"    # False: im2col gather + library GEMMs (round-2 schedule, A/B reference)
 
 
 class ConvBNReLUFn(torch.autograd.Function):
@@ -34,18 +39,26 @@ class ConvBNReLUFn(torch.autograd.Function):
         if bn.training and bn.running_mean is not None:
             a.momentum = float(bn.momentum)
             a.running_mean, a.running_var, a.num_batches = L.ptr(bn.running_mean), L.ptr(bn.running_var), L.ptr(bn.num_batches_tracked)
-        cols = torch.empty(n_out, 9 * cin, dtype=cdt, device=dev)
+        # bf16 with 128 / 256 channels: implicit GEMM over the rulebook (csrc/spconv.hip) on packed weight images that the
+        # optimizer refreshes once per step - no im2col matrix is built or kept
+        packed = None
+        if cdt == torch.bfloat16 and IMPLICIT and packing.conv_supported(weight):
+            packed = packing.conv_registered(weight)
+            a.packed_fwd, a.packed_bwd = L.ptr(packed[0]), L.ptr(packed[1])
+        cols = torch.empty(n_out, 9 * cin, dtype=cdt, device=dev) if packed is None else torch.empty(0, dtype=cdt, device=dev)
         y = torch.empty(n_out, cout, dtype=cdt, device=dev)
         out = torch.empty(n_out, cout, dtype=cdt, device=dev)
         stats = torch.empty(2 * cout, dtype=torch.float64, device=dev)
         abmv = torch.empty(4 * cout, dtype=torch.float32, device=dev)
         nb = L.load().gdmae_conv_block_scratch_bytes(n_in, n_out, cin, cout, a.bf16)
         scratch = torch.empty(nb, dtype=torch.uint8, device=dev)
-        a.cols, a.y, a.out, a.stats, a.ab, a.mv = L.ptr(cols), L.ptr(y), L.ptr(out), L.ptr(stats), L.ptr(abmv), L.ptr(abmv[2 * cout:])
+        a.cols, a.y, a.out, a.stats, a.ab, a.mv = (L.ptr(cols) if packed is None else None, L.ptr(y), L.ptr(out), L.ptr(stats),
+                                                   L.ptr(abmv), L.ptr(abmv[2 * cout:]))
         a.scratch = L.ptr(scratch)
         L.call("gdmae_conv_block_fwd", C.byref(a), L.stream())
         ctx.save_for_backward(x, cols, y, stats, abmv, wc, nbr, nbr_t, bn.weight.detach())
         ctx.meta = (a, nb, direct, x.dtype)
+        ctx.packed = packed
         return out
 
     @staticmethod

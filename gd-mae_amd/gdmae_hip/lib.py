@@ -92,6 +92,7 @@ SIGNATURES = {
     "gdmae_add_layernorm_bwd": (_I, [_P, _P, _I, _P, _P, _P, _P, _I, _L, _I, _P, _P, _P, _P, _P]),
     "gdmae_prep_tokens": (_I, [_P, _P, _P, _L, _I, _P, _P, _I, _P]),
     "gdmae_add3": (_I, [_P, _P, _I, _P, _I, _L, _P, _P]),
+    "gdmae_add3_to": (_I, [_P, _P, _I, _P, _I, _L, _P, _I, _P]),
     "gdmae_set_attention_impl": (_I, [_I]),
     "gdmae_sum_partials": (_I, [_P, _L, _F, _P, _I, _P]),
     "gdmae_sum_partials_gated": (_I, [_P, _L, _F, _P, _P, _F, _P]),
@@ -101,6 +102,9 @@ SIGNATURES = {
     "gdmae_gemm_tn_splitk_workspace_bytes": (_Z, [_L, _I, _I]),
     "gdmae_gemm_tn_splitk": (_I, [_P, _P, _P, _L, _I, _I, _I, _I, _P, _P]),
     "gdmae_conv_block_scratch_bytes": (_Z, [_L, _L, _I, _I, _I]),
+    "gdmae_spconv_packed_bytes": (_Z, [_I, _I]),
+    "gdmae_spconv_pack_jobs": (_I, [_P, _I, _I, _I, _P, _P]),
+    "gdmae_spconv": (_I, [_P, _I, _P, _P, _L, _I, _I, _P, _P]),
     "gdmae_conv_block_fwd": (_I, [_P, _P]),
     "gdmae_conv_block_bwd": (_I, [_P, _P]),
     "gdmae_encoder_layer_bytes": (_I, [_L, _I, _I, _I, _I, _P, _P, _P]),
@@ -164,7 +168,7 @@ class ConvBlockArgs(C.Structure):
     _fields_ = ([("n_in", _L), ("n_out", _L), ("cin", _I), ("cout", _I), ("bf16", _I), ("x_f32", _I), ("g_f32", _I),
                  ("eps", _F), ("momentum", _F)]
                 + [(k, _P) for k in ("x", "nbr", "nbr_t", "W", "gamma", "beta", "running_mean", "running_var", "num_batches", "cols",
-                                     "y", "stats", "ab", "mv", "out", "g", "dx", "dW", "dgamma", "dbeta", "scratch")])
+                                     "y", "stats", "ab", "mv", "out", "g", "dx", "dW", "dgamma", "dbeta", "scratch", "packed_fwd", "packed_bwd")])
 
 
 _lib = None

@@ -236,22 +236,25 @@ class LinearSplitK(torch.autograd.Function):
 
 
 class ResidualAdd(torch.autograd.Function):
-    """a (fp32) + b (fp32 or bf16) -> fp32 as one gdmae_add3 launch: the block residual ``feat + out`` of SSTBlockV1
-    (spt_backbone.py:158), where ``feat`` is the bf16 output of the sparse-conv block under autocast (torch's
-    mixed-dtype add kernel takes 55-70 us for these 10 M elements, this one ~15)."""
+    """a (fp32) + b (fp32 or bf16) as one gdmae_add3_to launch: the block residual ``feat + out`` of SSTBlockV1
+    (spt_backbone.py:158), where ``feat`` is the bf16 output of the sparse-conv block under autocast.  Under autocast the sum is
+    written in bf16: its only consumer is the next sparse convolution, which rounds its input rows to bf16 anyway (same
+    arithmetic), and each of those rows is gathered up to nine times there - and nine times more by the weight gradient."""
 
     @staticmethod
     def forward(ctx, a, b):
         assert a.dtype == torch.float32 and b.dtype in (torch.float32, torch.bfloat16) and a.shape == b.shape
         ctx.b_dtype = b.dtype
         a, b = a.contiguous(), b.contiguous()
-        out = torch.empty_like(a)
-        L.call("gdmae_add3", L.ptr(a), L.ptr(b), int(b.dtype == torch.bfloat16), None, 0, a.numel(), L.ptr(out), L.stream())
+        odt = torch.bfloat16 if (torch.is_autocast_enabled() and b.dtype == torch.bfloat16) else torch.float32
+        out = torch.empty_like(a, dtype=odt)
+        L.call("gdmae_add3_to", L.ptr(a), L.ptr(b), int(b.dtype == torch.bfloat16), None, 0, a.numel(), L.ptr(out),
+               int(odt == torch.bfloat16), L.stream())
         return out
 
     @staticmethod
     def backward(ctx, g):
-        return g, (g if g.dtype == ctx.b_dtype else g.to(ctx.b_dtype))
+        return (g if g.dtype == torch.float32 else g.float()), (g if g.dtype == ctx.b_dtype else g.to(ctx.b_dtype))
 
 
 def linear(x, weight, bias=None):

@@ -56,6 +56,46 @@ def registered(Win, Wo, W1, W2):
     return packed
 
 
+# ---- sparse-convolution weights (csrc/spconv.hip): per-tap images of W (cout, 3, 3, cin) and of its per-tap transposes
+def _conv_jobs(W, fwd, bwd):
+    cout, _, _, cin = W.shape
+    jobs = (C.c_longlong * 54)()
+    L.call("gdmae_spconv_pack_jobs", L.ptr(W), cin, cout, 0, L.ptr(fwd), jobs)
+    out = list(jobs)
+    L.call("gdmae_spconv_pack_jobs", L.ptr(W), cin, cout, 1, L.ptr(bwd), jobs)
+    return out + list(jobs)
+
+
+def conv_supported(W):
+    return (W.is_cuda and W.dtype == torch.float32 and W.is_contiguous() and W.dim() == 4 and W.shape[1] == 3 and W.shape[2] == 3
+            and W.shape[0] in (128, 256) and W.shape[3] in (128, 256))
+
+
+def conv_pack_now(W):
+    """(forward images, input-gradient images) of a sparse-conv weight, packed now (one launch)."""
+    cout, _, _, cin = W.shape
+    nb = L.load().gdmae_spconv_packed_bytes(cin, cout)
+    fwd = torch.empty(nb, dtype=torch.uint8, device=W.device)
+    bwd = torch.empty(nb, dtype=torch.uint8, device=W.device)
+    jobs = torch.tensor(_conv_jobs(W.detach(), fwd, bwd), dtype=torch.int64).to(W.device)
+    L.call("gdmae_tok_gemm_pack", L.ptr(jobs), 18, L.stream())
+    fwd._gd_jobs = jobs
+    return fwd, bwd
+
+
+def conv_registered(W):
+    """The same for a weight owned by a flat optimizer: packed now, then refreshed with the encoder layers' images by the ONE
+    pack launch per optimizer step."""
+    key = id(W)
+    ent = _REG.get(key)
+    if ent is not None and ent["ref"]() is W and ent["ptrs"] == (W.data_ptr(),):
+        return ent["packed"], ent["packed2"]
+    fwd, bwd = conv_pack_now(W)
+    _REG[key] = dict(ref=weakref.ref(W), packed=fwd, packed2=bwd, ptrs=(W.data_ptr(),), jobs=_conv_jobs(W.detach(), fwd, bwd))
+    _TABLE.clear()
+    return fwd, bwd
+
+
 def repack_registered():
     """Refresh every registered image with ONE launch per device (called after the optimizer step)."""
     dead = [k for k, e in _REG.items() if e["ref"]() is None]

@@ -363,6 +363,11 @@ int gdmae_add_layernorm_bwd(const float* a, const void* b, int b_is_bf16, const 
 int gdmae_prep_tokens(const float* x, const float* pos_table, const int* tok_pos, long long n, int d, void* x_out,
                       void* xpos_out, int out_bf16, void* stream);
 int gdmae_add3(const float* a, const void* b, int b_bf16, const void* c, int c_bf16, long long total, float* out, void* stream);
+/* the same with the result in fp32 (out_bf16 = 0) or bf16 (1): the block residual feat + out of SSTBlockV1 (spt_backbone.py:158)
+ * goes to the next sparse convolution, which rounds its input rows to bf16 anyway - written in bf16 the 9 gathers of every row
+ * move half the bytes */
+int gdmae_add3_to(const float* a, const void* b, int b_bf16, const void* c, int c_bf16, long long total, void* out, int out_bf16,
+                  void* stream);
 
 /* ---- library GEMMs (hipBLASLt, one cached algorithm per shape bucket) ------------------------------ *
  * The token / point / site GEMMs of the path outside the encoder-layer executor (nn.Linear of DynVFE, the
@@ -419,8 +424,21 @@ typedef struct gdmae_conv_block_args {
   void* dx;        /* (n_in, cin) compute dtype                    [backward] */
   float *dW, *dgamma, *dbeta;
   void* scratch;   /* gdmae_conv_block_scratch_bytes */
+  /* round 3, bf16 with 128 / 256 channels: packed weight images (gdmae_spconv_pack_jobs + gdmae_tok_gemm_pack) select the
+   * im2col-free path - the convolution and its input gradient are implicit GEMMs over the rulebook (gdmae_spconv), the weight
+   * gradient one grouped TN launch that gathers the input rows on load; `cols` is then neither written nor read (may be NULL) */
+  const void* packed_fwd;   /* 9 x (cout, cin) images */
+  const void* packed_bwd;   /* 9 x (cin, cout) images (per-tap transposed weights) */
 } gdmae_conv_block_args;
 size_t gdmae_conv_block_scratch_bytes(long long n_in, long long n_out, int cin, int cout, int bf16);
+/* Sparse convolution as an implicit GEMM over a rulebook (csrc/spconv.hip): Y (n, cout) bf16 = sum_tap W_tap X[nbr[:, tap]], X bf16
+ * or fp32 (x_f32) rows, nbr (n, 9) with negative entries for missing taps; cin, cout in {128, 256}.  packed: 9 per-tap
+ * (cout, cin) bf16 images in MFMA-fragment order (gdmae_spconv_packed_bytes), produced by gdmae_tok_gemm_pack from the job table
+ * gdmae_spconv_pack_jobs writes (9 x 6 int64; transposed = 1: the (cin, cout) images of the input-gradient convolution, to be
+ * used with the transposed rulebook and cin / cout swapped).  Replaces spconv's gather-GEMM-scatter (spconv_utils.py:37-56). */
+size_t gdmae_spconv_packed_bytes(int cin, int cout);
+int gdmae_spconv_pack_jobs(const float* W /* (cout, 3, 3, cin) fp32 */, int cin, int cout, int transposed, void* packed, long long* jobs);
+int gdmae_spconv(const void* X, int x_f32, const int* nbr, const void* packed, long long n, int cin, int cout, void* Y, void* stream);
 int gdmae_conv_block_fwd(const gdmae_conv_block_args* args /* host */, void* stream);
 int gdmae_conv_block_bwd(const gdmae_conv_block_args* args /* host */, void* stream);
 

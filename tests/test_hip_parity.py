@@ -1253,3 +1253,43 @@ def test_tok_gemm_epilogues_match_torch(K, N):
             assert torch.equal(dxb[:n], dx.bfloat16())
             ps = part.double().sum(0)
             assert float((ps - sums.double()).abs().max()) <= 1e-5 * float(sums.abs().max()) + 1e-5
+
+
+@pytest.mark.parametrize("cin,cout,src_f32", [(128, 128, False), (128, 256, True), (256, 128, False), (256, 256, True), (256, 256, False)])
+def test_spconv_implicit_gemm_matches_gathered_product(cin, cout, src_f32):
+    """gdmae_spconv (implicit GEMM over a rulebook, packed per-tap weight images) against the explicit formulation it replaces:
+    gather the 9 neighbour rows (zeros where the rulebook says -1), round them to bf16, multiply by the bf16 weights with fp32
+    accumulation, round to bf16.  Ragged row count (not a multiple of the 32 / 64-row tile), missing taps, repeated sources;
+    forward images and the transposed (input-gradient) images."""
+    import ctypes as C
+    from gdmae_hip import lib as L
+    g = torch.Generator().manual_seed(cin + cout)
+    n_src, n = 1500, 1237
+    X = torch.randn(n_src, cin, generator=g).to(dev())
+    nbr = torch.randint(-1, n_src, (n, 9), generator=g).int()
+    nbr[::7] = -1                                              # rows without any active tap
+    nbr[5] = 3                                                 # all taps read the same source row
+    nbr = nbr.to(dev())
+    W = (torch.randn(cout, 3, 3, cin, generator=g) * 0.05).to(dev())
+    lib = L.load()
+    for transposed in (0, 1):
+        ci, co = (cin, cout) if not transposed else (cout, cin)      # the input-gradient convolution swaps the roles
+        Xs = X if not transposed else torch.randn(n_src, ci, generator=g).to(dev())
+        src = Xs if src_f32 else Xs.bfloat16()
+        packed = torch.empty(lib.gdmae_spconv_packed_bytes(cin, cout), dtype=torch.uint8, device=dev())
+        jobs = (C.c_longlong * 54)()
+        L.call("gdmae_spconv_pack_jobs", L.ptr(W), cin, cout, transposed, L.ptr(packed), jobs)
+        jd = torch.tensor(list(jobs), dtype=torch.int64).to(dev())
+        L.call("gdmae_tok_gemm_pack", L.ptr(jd), 9, L.stream())
+        Y = torch.empty(n, co, dtype=torch.bfloat16, device=dev())
+        L.call("gdmae_spconv", L.ptr(src.contiguous()), int(src_f32), L.ptr(nbr), L.ptr(packed), n, ci, co, L.ptr(Y), L.stream())
+        xb = Xs.bfloat16().float()
+        Wb = W.bfloat16().float()
+        ref = torch.zeros(n, co, device=dev())
+        for k in range(9):
+            rows = torch.where(nbr[:, k:k + 1] >= 0, xb[nbr[:, k].clamp(min=0).long()], torch.zeros(1, device=dev()))
+            Wk = Wb[:, k // 3, k % 3, :]                       # (cout, cin)
+            ref += rows @ (Wk.t() if not transposed else Wk)
+        err = float((Y.float() - ref).abs().max())
+        assert err <= 2 ** -7 * float(ref.abs().max()), (transposed, err, float(ref.abs().max()))     # one bf16 rounding of the result
+        assert float(Y[::7].abs().max()) == 0.0
