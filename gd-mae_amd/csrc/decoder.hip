@@ -920,3 +920,102 @@ extern "C" int gdmae_decoder_region_algebra(const double* stats2, const float* a
   GD_LAUNCH_CHECK();
   return 0;
 }
+
+
+// ------------------------------------------------------------------------------------------
+// Round 3: the 3x3 conv_out backward WITHOUT the tap matrix.  Round 2 wrote the 9 shifted output-gradient rows of every active
+// site (k_conv_grad_taps: 1.4 GB at config B) and read them back twice (two library GEMMs).  Now
+//   gdmae_decoder_dy             dYc = bf16(k0 + k1 * Yc + rows[pillar]) on the active tiles, ONCE, in Yc's tile-compact layout
+//   gdmae_decoder_site_rulebook  nbr[t, k] = row of dYc holding site[t] - offset(k), -1 outside the map (geometry: built with the plan)
+// and the input-gradient rows / the weight gradient are the implicit-GEMM sparse convolution (spconv.hip) and the grouped TN
+// launch with gathered rows (dw_grouped.hip) over that rulebook: every dY row is read through L2, nothing is materialised
+// nine-fold.  Same values as the taps (one bf16 rounding of dY), same tap convention k = (ky + 1) * 3 + (kx + 1).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_decoder_dy(const unsigned short* __restrict__ Yc, const int* __restrict__ tile_list, int n_act,
+                                                    const float* __restrict__ k0, const float* __restrict__ k1,
+                                                    const float* __restrict__ rows, const int* __restrict__ cell2pillar, int H, int W,
+                                                    int TH, int TW, int C, unsigned short* __restrict__ dYc) {
+  const int cv = C >> 3;
+  const long long total = (long long)n_act * GD_TILE_SITES * cv;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int v = (int)(i % cv);
+    const long long row = i / cv;
+    const int slot = (int)(row >> 6), loc = (int)(row & 63);
+    const int tile = tile_list[slot];
+    const int tx = tile % TW, r = tile / TW, ty = r % TH, b = r / TH;
+    const int y = ty * GD_TILE + (loc >> 3), x = tx * GD_TILE + (loc & 7);
+    uint4 q = make_uint4(0u, 0u, 0u, 0u);
+    if (y < H && x < W) {
+      const int c0 = v * 8;
+      const uint4 yq = reinterpret_cast<const uint4*>(Yc + row * C)[v];
+      const unsigned w4[4] = {yq.x, yq.y, yq.z, yq.w};
+      float yv[8], o[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        yv[2 * j] = __uint_as_float(w4[j] << 16);
+        yv[2 * j + 1] = __uint_as_float(w4[j] & 0xFFFF0000u);
+      }
+      const float4 ka = ((const float4*)k0)[c0 >> 2], kb = ((const float4*)k0)[(c0 >> 2) + 1];
+      const float4 la = ((const float4*)k1)[c0 >> 2], lb = ((const float4*)k1)[(c0 >> 2) + 1];
+      const float kk0[8] = {ka.x, ka.y, ka.z, ka.w, kb.x, kb.y, kb.z, kb.w};
+      const float kk1[8] = {la.x, la.y, la.z, la.w, lb.x, lb.y, lb.z, lb.w};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = fmaf(kk1[j], yv[j], kk0[j]);
+      const int p = cell2pillar[((long long)b * H + y) * W + x];
+      if (p >= 0) {
+        const float4 r0 = ((const float4*)rows)[((long long)p * C + c0) >> 2], r1 = ((const float4*)rows)[(((long long)p * C + c0) >> 2) + 1];
+        o[0] += r0.x; o[1] += r0.y; o[2] += r0.z; o[3] += r0.w; o[4] += r1.x; o[5] += r1.y; o[6] += r1.z; o[7] += r1.w;
+      }
+      q.x = dec_f2bf(o[0]) | ((unsigned)dec_f2bf(o[1]) << 16);
+      q.y = dec_f2bf(o[2]) | ((unsigned)dec_f2bf(o[3]) << 16);
+      q.z = dec_f2bf(o[4]) | ((unsigned)dec_f2bf(o[5]) << 16);
+      q.w = dec_f2bf(o[6]) | ((unsigned)dec_f2bf(o[7]) << 16);
+    }
+    reinterpret_cast<uint4*>(dYc + row * C)[v] = q;
+  }
+}
+extern "C" int gdmae_decoder_dy(const void* Yc, const int* tile_list, int n_act, const float* k0, const float* k1, const float* rows,
+                                const int* cell2pillar, int H, int W, int C, void* dYc, void* stream) {
+  GD_REQUIRE(C % 8 == 0, "decoder_dy: C must be a multiple of 8");
+  if (n_act <= 0) return 0;
+  long long g = ((long long)n_act * GD_TILE_SITES * (C / 8) + 255) / 256;
+  if (g > 65536) g = 65536;
+  hipLaunchKernelGGL(k_decoder_dy, dim3((int)g), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)Yc, tile_list, n_act, k0, k1, rows,
+                     cell2pillar, H, W, (H + 7) / 8, (W + 7) / 8, C, (unsigned short*)dYc);
+  GD_LAUNCH_CHECK();
+  return 0;
+}
+
+// nbr[t * 9 + k] = tile-compact row of site[t] - (ky - 1, kx - 1), -1 outside the map (or in a tile that is not active: cannot
+// happen for the sites the active-tile set was built from).  n_dev: device count of sites (capacity `cap` bounds the grid).
+__global__ __launch_bounds__(256) void k_decoder_site_rulebook(const int* __restrict__ site, const int* __restrict__ n_dev, int sites_per_tok,
+                                                               const int* __restrict__ tile_slot, int H, int W, int TH, int TW,
+                                                               int* __restrict__ nbr) {
+  const long long total = (long long)(*n_dev) * sites_per_tok * 9;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int k = (int)(i % 9);
+    const int s = site[i / 9];
+    const int x = s % W, r = s / W, y = r % H, b = r / H;
+    const int uy = y - (k / 3 - 1), ux = x - (k % 3 - 1);
+    int v = -1;
+    if (uy >= 0 && uy < H && ux >= 0 && ux < W) {
+      const int sl = tile_slot[(b * TH + (uy >> 3)) * TW + (ux >> 3)];
+      if (sl >= 0) v = sl * GD_TILE_SITES + (uy & 7) * GD_TILE + (ux & 7);
+    }
+    nbr[i] = v;
+  }
+}
+int gd_decoder_site_rulebook(const int* site, const int* n_dev, int sites_per_tok, long long cap_sites, const int* tile_slot, int H, int W,
+                             int* nbr, hipStream_t st) {
+  long long g = (cap_sites * 9 + 255) / 256;
+  if (g > 4096) g = 4096;
+  if (g < 1) g = 1;
+  hipLaunchKernelGGL(k_decoder_site_rulebook, dim3((int)g), dim3(256), 0, st, site, n_dev, sites_per_tok, tile_slot, H, W, (H + 7) / 8,
+                     (W + 7) / 8, nbr);
+  GD_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int gdmae_decoder_site_rulebook(const int* site, const int* n_dev, int sites_per_tok, long long cap_sites, const int* tile_slot,
+                                           int H, int W, int* nbr, void* stream) {
+  return gd_decoder_site_rulebook(site, n_dev, sites_per_tok, cap_sites, tile_slot, H, W, nbr, (hipStream_t)stream);
+}

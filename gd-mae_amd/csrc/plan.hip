@@ -53,6 +53,8 @@ int gd_plan_windows(const int* map, int B, int Y, int X, int wx, int wy, int nle
 size_t gd_decoder_tiles_lb_state_bytes(long long nt);
 int gd_decoder_tiles_lb(const int* const* maps, const int* strides, int k, int B, int H, int W, int* tile_slot, int* tile_list, int* n_act,
                         int* flag, void* lb_state, hipStream_t st);
+int gd_decoder_site_rulebook(const int* site, const int* n_dev, int sites_per_tok, long long cap_sites, const int* tile_slot, int H, int W,
+                             int* nbr, hipStream_t st);
 
 namespace {
 
@@ -95,7 +97,7 @@ struct Offsets {
     long long tok_cell, map, nbr_subm, nbr_subm_t, nbr_down, nbr_down_t, up_sites, win_ws;
     long long w[2][7];
   } s[GDMAE_PLAN_MAX_STAGES];
-  long long dec_slot, dec_list, dec_flag;
+  long long dec_slot, dec_list, dec_flag, dec_nbr[3];
   size_t lb_bytes, vox_ws_bytes;
   int n_counts;
   bool dec;
@@ -221,6 +223,12 @@ int layout(const gdmae_plan_params* p, gdmae_plan_buffer* table, int max_entries
     O.dec_slot = L.add("dec.tile_slot", sizeof(int) * nt);
     O.dec_list = L.add("dec.tile_list", sizeof(int) * nt);
     O.dec_flag = L.add("dec.flag", sizeof(int) * nt);
+    // rulebooks of the conv_out backward: tile-compact row of every (active site, tap) per source stage
+    for (int g = 0; g < p->n_dec; ++g) {
+      const StageGeo& sg = O.geo[p->dec_sources[g]];
+      snprintf(nm, sizeof(nm), "dec.nbr%d", g);
+      O.dec_nbr[g] = L.add(nm, sizeof(int) * sg.cap * sg.up_s * sg.up_s * 9);
+    }
   }
   GD_REQUIRE(L.ok, "geometry plan: buffer table too small");
   if (total) *total = L.off;
@@ -333,6 +341,13 @@ extern "C" int gdmae_geometry_plan(const gdmae_plan_params* p, const float* poin
     }
     int rc = gd_decoder_tiles_lb(maps, ups, p->n_dec, B, gy, gx, I(O.dec_slot), I(O.dec_list), n_act, I(O.dec_flag), lb, st);
     if (rc) return rc;
+    for (int g = 0; g < p->n_dec; ++g) {
+      const int si = p->dec_sources[g];
+      const StageGeo& sg = O.geo[si];
+      const int* sites = sg.up_s > 1 ? I(O.s[si].up_sites) : I(O.s[si].tok_cell);
+      rc = gd_decoder_site_rulebook(sites, n_tok + si, sg.up_s * sg.up_s, sg.cap * sg.up_s * sg.up_s, I(O.dec_slot), gy, gx, I(O.dec_nbr[g]), st);
+      if (rc) return rc;
+    }
   }
   return 0;
 }

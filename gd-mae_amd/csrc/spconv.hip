@@ -18,6 +18,8 @@
 // written, against 9 CIN x 2 B written + read for the im2col matrix before.
 #include "../../include/gdmae_hip.h"
 #include "common.h"
+#include "dw_grouped.h"
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -235,6 +237,57 @@ extern "C" int gdmae_spconv_pack_jobs(const float* W, int cin, int cout, int tra
 }
 
 extern "C" int gdmae_spconv(const void* X, int x_f32, const int* nbr, const void* packed, long long n, int cin, int cout, void* Y,
-                            void* stream) {
-  return gd_spconv((hipStream_t)stream, X, x_f32, nbr, packed, n, cin, cout, Y, GD_T_SPCONV_FWD);
+                            int timing_slot, void* stream) {
+  return gd_spconv((hipStream_t)stream, X, x_f32, nbr, packed, n, cin, cout, Y, timing_slot > 0 ? timing_slot : GD_T_SPCONV_FWD);
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Nine per-tap TN products over a rulebook as ONE grouped launch + a fixed-order reduce:
+//     out[k][n][m_off + m] (+)= sum_t  G[t][m] * X[nbr[t][k]][n]         k = 0..8,  G (n_pad rows, M) bf16, X (.., N) bf16
+// (the weight gradient of the decoder's 3x3 conv_out per source stage: G = the stage's BatchNorm/ReLU rows minus background, X =
+// the tile-compact output gradient, out = dWk (9, C2, Cin) at the stage's column offset - spt_backbone_mae.py:46-52 backward).
+// ------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void k_tap_dw_reduce(const float* __restrict__ part, int S, int M, int N, float* __restrict__ out, int ld_out,
+                                                       int m_off) {
+  // part: [k][s][m][n] -> out[(k * N + n) * ld_out + m_off + m]
+  const long long per_tap = (long long)S * M * N;
+  const long long total = 9ll * N * M;
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const int n = (int)(e % N);                    // n fastest: the S partial reads of a thread group are coalesced
+    const long long km = e / N;
+    const int m = (int)(km % M), k = (int)(km / M);
+    const float* p = part + k * per_tap + (long long)m * N + n;
+    float acc = 0.f;
+    for (int s = 0; s < S; ++s) acc += p[(long long)s * M * N];
+    out[((long long)k * N + n) * ld_out + m_off + m] += acc;
+  }
+}
+int tap_dw_slices(long long n_pad, int tiles) {
+  static const int wgs = getenv("GDMAE_SPCONV_DW_WGS") ? atoi(getenv("GDMAE_SPCONV_DW_WGS")) : 1200;
+  return gd_dw_group_slices_for(n_pad, tiles, wgs);
+}
+}  // namespace
+
+extern "C" size_t gdmae_tap_dw_workspace_bytes(long long n_pad, int M, int N) {
+  return gd_align((size_t)tap_dw_slices(n_pad, 9 * (M / 128) * (N / 128)) * 9 * M * N * sizeof(float));
+}
+extern "C" int gdmae_tap_dw(const void* G, long long n, long long n_pad, int M, const void* X, const int* nbr, int N, float* out, int ld_out,
+                            int m_off, void* workspace, void* stream) {
+  GD_REQUIRE(M % 128 == 0 && N % 128 == 0 && n_pad % 1024 == 0 && n <= n_pad && n >= 0, "tap_dw: M, N multiples of 128, rows padded to 1024");
+  if (n == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  GdDwGroup Gp;
+  Gp.n_jobs = 9;
+  const int S = tap_dw_slices(n_pad, 9 * (M / 128) * (N / 128));
+  for (int k = 0; k < 9; ++k) Gp.job[k] = GdDwJob{G, X, M, N, (float*)workspace + (size_t)k * S * M * N, nullptr, 0, nbr + k, 9, 0};
+  {
+    GdTimed timed(GD_T_DEC_CONV_BWD, st, (double)n * (2.0 * M + 9.0 * 2.0 * N + 36.0) + 36.0 * S * M * N, 2.0 * n * 9.0 * M * N);
+    int rc = gd_dw_grouped_s(st, Gp, n_pad, n, S);
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(k_tap_dw_reduce, dim3(gd_div_up(9ll * M * N, 256)), dim3(256), 0, st, (const float*)workspace, S, M, N, out, ld_out, m_off);
+  GD_LAUNCH_CHECK();
+  return 0;
 }

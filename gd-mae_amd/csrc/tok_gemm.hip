@@ -92,20 +92,23 @@ __device__ inline float tg_gelu_grad(float h) {
 // ------------------------------------------------------------------------------------------------
 // weight packing: dst[(ks * MB + mb) * 64 + lane] = 8 bf16 of row mb * 32 + (lane & 31), columns ks * 16 + (lane >> 5) * 8 ..
 // of the (M, K) matrix  A[r][c] = transpose ? src[c * M + r] : src[r * ld + c]   (fp32 master weights, rounded here)
-// jobs: device table of n_jobs x 6 int64 {src, dst, M, K, ld, transpose}; blockIdx.y = job
+// jobs: device table of n_jobs x 6 int64 {src, dst, M, K, ld, transpose | (es << 2)}; blockIdx.y = job.  es (default 0 = 1): element
+// stride of the unit dimension, A[r][c] = transpose ? src[c * ld + r * es] : src[r * ld + c * es]  (a (Cout, Cin, 3, 3) convolution
+// weight read per tap has es = 9)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_tg_pack(const long long* __restrict__ jobs) {
   const long long* J = jobs + (long long)blockIdx.y * 6;
   const float* src = (const float*)J[0];
   uint4* dst = (uint4*)J[1];
-  const int M = (int)J[2], K = (int)J[3], ld = (int)J[4], tr = (int)J[5];
+  const int M = (int)J[2], K = (int)J[3], ld = (int)J[4], tr = (int)(J[5] & 1);
+  const int es = (int)(J[5] >> 2) > 0 ? (int)(J[5] >> 2) : 1;
   const int MB = M / 32, total = (K / 16) * MB * 64;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
     const int lane = i & 63, mb = (i >> 6) % MB, ks = (i >> 6) / MB;
     const int r = mb * 32 + (lane & 31), c = ks * 16 + (lane >> 5) * 8;
     float f[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) f[j] = tr ? src[(long long)(c + j) * ld + r] : src[(long long)r * ld + c + j];
+    for (int j = 0; j < 8; ++j) f[j] = tr ? src[(long long)(c + j) * ld + (long long)r * es] : src[(long long)r * ld + (long long)(c + j) * es];
     dst[i] = tg_pack8(f);
   }
 }

@@ -33,11 +33,17 @@ from __future__ import annotations
 import torch
 import torch.nn.functional as F
 
+import os
+
 from . import bn as gbn
 from . import lib as L
-from . import ops
+from . import ops, packing
 from . import plan as gplan
 from . import timing
+
+# conv_out backward of the tile path: "implicit" = tile-compact output gradient + implicit-GEMM input gradient + gathered grouped
+# weight gradient (no tap matrix, no library GEMM); "taps" = the round-2 schedule (gdmae_conv3x3_grad_taps + two library GEMMs)
+CONV_BWD = os.environ.get("GDMAE_DEC_BWD", "implicit")
 
 BN_EPS, BN_MOM = 1e-3, 0.01
 
@@ -203,6 +209,7 @@ class DecoderHead(torch.autograd.Function):
         ctx.k, ctx.widths, ctx.geom = k, widths, geom
         ctx.direct = [gbn.direct_pair(g, be) for g, be in zip(gammas, betas)] + [gbn.direct_pair(gamma2, beta2)]
         ctx.direct_w = ops.direct_grad(conv_w)
+        ctx.conv_param = conv_w        # the parameter object itself: the packed images of the backward are registered on its identity
         mean2, var2 = mv2[:C2], mv2[C2:]
         ctx.mark_non_differentiable(y2, mean2, var2, *mv_out)
         ctx.set_materialize_grads(False)      # no zero tensors for the unused gradients of those outputs
@@ -263,30 +270,59 @@ class DecoderHead(torch.autograd.Function):
         grads = [None] * 7
         dW_rows = []
         col = 0
+        # ---- tile path: the output gradient ONCE in Yc's tile-compact layout, rulebooks of the (active site, tap) rows
+        implicit = None
+        if (CONV_BWD == "implicit" and tile_slot is not None and y2.dtype == torch.bfloat16 and use_native and C2 == 128
+                and all(w == 128 for w in ctx.widths) and len(ctx.geom) > 6 and ctx.geom[6] is not None):
+            dt = ctx.geom[6][0]
+            packed = packing.decoder_conv_packed(ctx.conv_param, ctx.widths, ctx.direct_w is not None)
+            if packed is not None:
+                if dt.nbr is None:
+                    dt.nbr = gplan.decoder_site_rulebooks(dt, sites, ctx.geom[6][2])
+                dYc = torch.empty_like(y2)
+                L.call("gdmae_decoder_dy", L.ptr(y2), L.ptr(dt.tile_list), dt.n_act, L.ptr(k01), L.ptr(k01[C2:]), L.ptr(rows),
+                       L.ptr(cell2pillar), H, W, C2, L.ptr(dYc), L.stream())
+                implicit = (dt, packed, dYc)
         for i, w in enumerate(ctx.widths):
             P = Ps[i]
             n = P.shape[0]
             ab = ab_l[i]
-            G = torch.empty(n, 9 * C2, dtype=cdt, device=dev)
-            with timing.kernel("k_conv_grad_taps", 2.0 * n * 9 * C2 * G.element_size()):
-                L.call("gdmae_conv3x3_grad_taps", L.ptr(y2), _bf(y2), L.ptr(tile_slot), L.ptr(ybg), L.ptr(k01), L.ptr(k01[C2:]),
-                       L.ptr(rows), L.ptr(cell2pillar), L.ptr(sites[i]), n, H, W, C2, L.ptr(G), L.stream())
-            dX = ops.mm(G, Wd[:, :, col:col + w].reshape(9 * C2, w))      # dZ rows of this stage's active sites
-            if Z is not None:
-                Zrows = _gather_slice(Z, sites[i], col, w)
-                Zd = Zrows - bgz[col:col + w]
-            else:                                                         # the map was never built: redo BN + ReLU of the rows
-                Zd = torch.empty(n, w, dtype=cdt, device=dev)
+            if implicit is not None:
+                dt, packed, dYc = implicit
+                nbr = dt.nbr[i]
+                assert nbr.shape[0] == n, (nbr.shape, n)
+                # dZ rows of the stage's active sites: implicit GEMM over the rulebook (9 gathered dY rows per site)
+                dX = torch.empty(n, w, dtype=cdt, device=dev)
+                L.call("gdmae_spconv", L.ptr(dYc), 0, L.ptr(nbr), packed.data_ptr() + i * 9 * w * C2 * 2, n, C2, w, L.ptr(dX), 8, L.stream())
+                n_pad = (n + 1023) // 1024 * 1024
+                Zd = torch.empty(n_pad, w, dtype=cdt, device=dev)
                 bg = bgz[col:col + w]
-                if w % 8 == 0 and bg.dtype == cdt:
-                    L.call("gdmae_rows_affine_relu_sub", L.ptr(P), _bf(P), None, n, w, L.ptr(ab), L.ptr(ab[w:]), L.ptr(bg), L.ptr(Zd),
-                           _bf(Zd), w, 0, L.stream())
-                else:
-                    L.call("gdmae_rows_affine_relu_scatter", L.ptr(P), _bf(P), None, n, w, L.ptr(ab), L.ptr(ab[w:]), L.ptr(Zd),
-                           _bf(Zd), w, 0, L.stream())
-                    Zd = Zd - bg
-            dW_rows.append(ops.splitk_tn(G, Zd))                          # (9*C2, w) fp32
-            del G
+                L.call("gdmae_rows_affine_relu_sub", L.ptr(P), _bf(P), None, n, w, L.ptr(ab), L.ptr(ab[w:]), L.ptr(bg), L.ptr(Zd),
+                       _bf(Zd), w, 0, L.stream())
+                # weight gradient: dWk[k][co][col + ci] += sum_t dY[site_t - k][co] * Zd[t][ci], nine taps in one grouped launch
+                ws = torch.empty(L.load().gdmae_tap_dw_workspace_bytes(n_pad, w, C2), dtype=torch.uint8, device=dev)
+                L.call("gdmae_tap_dw", L.ptr(Zd), n, n_pad, w, L.ptr(dYc), L.ptr(nbr), C2, L.ptr(dWk), Cin, col, L.ptr(ws), L.stream())
+            else:
+                G = torch.empty(n, 9 * C2, dtype=cdt, device=dev)
+                with timing.kernel("k_conv_grad_taps", 2.0 * n * 9 * C2 * G.element_size()):
+                    L.call("gdmae_conv3x3_grad_taps", L.ptr(y2), _bf(y2), L.ptr(tile_slot), L.ptr(ybg), L.ptr(k01), L.ptr(k01[C2:]),
+                           L.ptr(rows), L.ptr(cell2pillar), L.ptr(sites[i]), n, H, W, C2, L.ptr(G), L.stream())
+                dX = ops.mm(G, Wd[:, :, col:col + w].reshape(9 * C2, w))      # dZ rows of this stage's active sites
+                if Z is not None:
+                    Zrows = _gather_slice(Z, sites[i], col, w)
+                    Zd = Zrows - bgz[col:col + w]
+                else:                                                         # the map was never built: redo BN + ReLU of the rows
+                    Zd = torch.empty(n, w, dtype=cdt, device=dev)
+                    bg = bgz[col:col + w]
+                    if w % 8 == 0 and bg.dtype == cdt:
+                        L.call("gdmae_rows_affine_relu_sub", L.ptr(P), _bf(P), None, n, w, L.ptr(ab), L.ptr(ab[w:]), L.ptr(bg), L.ptr(Zd),
+                               _bf(Zd), w, 0, L.stream())
+                    else:
+                        L.call("gdmae_rows_affine_relu_scatter", L.ptr(P), _bf(P), None, n, w, L.ptr(ab), L.ptr(ab[w:]), L.ptr(Zd),
+                               _bf(Zd), w, 0, L.stream())
+                        Zd = Zd - bg
+                dW_rows.append(ops.splitk_tn(G, Zd))                          # (9*C2, w) fp32
+                del G
             ws = torch.empty(L.load().gdmae_rows_bwd_stats_workspace_bytes(w), dtype=torch.uint8, device=dev)
             L.call("gdmae_rows_bwd_stats", L.ptr(P), _bf(P), None, n, w, L.ptr(ab), L.ptr(ab[w:]), L.ptr(dX), _bf(dX), w, 0,
                    None, L.ptr(ws), L.stream())
@@ -297,7 +333,8 @@ class DecoderHead(torch.autograd.Function):
                    _bf(dX), w, 0, L.ptr(dP), _bf(dP), L.stream())
             grads += [None, dP, dgamma, dbeta]
             col += w
-        dWk = dWk + torch.cat(dW_rows, dim=1).view(9, C2, Cin)
+        if dW_rows:
+            dWk = dWk + torch.cat(dW_rows, dim=1).view(9, C2, Cin)
         dW = dWk.permute(1, 2, 0).reshape(C2, Cin, 3, 3)
         if ctx.direct_w is not None:
             ctx.direct_w.add_(dW)

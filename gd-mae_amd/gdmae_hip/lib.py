@@ -104,7 +104,11 @@ SIGNATURES = {
     "gdmae_conv_block_scratch_bytes": (_Z, [_L, _L, _I, _I, _I]),
     "gdmae_spconv_packed_bytes": (_Z, [_I, _I]),
     "gdmae_spconv_pack_jobs": (_I, [_P, _I, _I, _I, _P, _P]),
-    "gdmae_spconv": (_I, [_P, _I, _P, _P, _L, _I, _I, _P, _P]),
+    "gdmae_spconv": (_I, [_P, _I, _P, _P, _L, _I, _I, _P, _I, _P]),
+    "gdmae_decoder_dy": (_I, [_P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _P, _P]),
+    "gdmae_decoder_site_rulebook": (_I, [_P, _P, _I, _L, _P, _I, _I, _P, _P]),
+    "gdmae_tap_dw_workspace_bytes": (_Z, [_L, _I, _I]),
+    "gdmae_tap_dw": (_I, [_P, _L, _L, _I, _P, _P, _I, _P, _I, _I, _P, _P]),
     "gdmae_conv_block_fwd": (_I, [_P, _P]),
     "gdmae_conv_block_bwd": (_I, [_P, _P]),
     "gdmae_encoder_layer_bytes": (_I, [_L, _I, _I, _I, _I, _P, _P, _P]),

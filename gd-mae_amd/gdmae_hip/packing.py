@@ -96,6 +96,40 @@ def conv_registered(W):
     return fwd, bwd
 
 
+# ---- decoder conv_out (Conv2d 3x3, weight (C2, Cin, 3, 3)): per (source stage, tap) the (w, C2) image A[ci][co] = W[co][col + ci][tap]
+#      of the input-gradient convolution over the tile-compact output gradient (gdmae_hip/decoder.py backward)
+def _dec_jobs(W, widths, packed):
+    C2, Cin = W.shape[0], W.shape[1]
+    jobs, col, off = [], 0, 0
+    for w in widths:
+        for k in range(9):
+            jobs += [W.data_ptr() + 4 * (col * 9 + k), packed.data_ptr() + off, w, C2, Cin * 9, 1 | (9 << 2)]
+            off += w * C2 * 2
+        col += w
+    return jobs
+
+
+def decoder_conv_packed(W, widths, registered_ok):
+    """Packed images (one buffer, stage-major then tap) of the decoder's conv_out weight; registered for the per-step refresh when
+    the weight is owned by a flat optimizer, packed on the spot otherwise.  None when the shapes are not served."""
+    if not (W.is_cuda and W.dtype == torch.float32 and W.is_contiguous() and W.dim() == 4 and W.shape[0] == 128
+            and all(w == 128 for w in widths) and sum(widths) == W.shape[1]):
+        return None
+    key = ("dec", id(W))
+    ent = _REG.get(key)
+    if registered_ok and ent is not None and ent["ref"]() is W and ent["ptrs"] == (W.data_ptr(),):
+        return ent["packed"]
+    packed = torch.empty(sum(widths) * W.shape[0] * 9 * 2, dtype=torch.uint8, device=W.device)
+    jobs = _dec_jobs(W, widths, packed)
+    jd = torch.tensor(jobs, dtype=torch.int64).to(W.device)
+    L.call("gdmae_tok_gemm_pack", L.ptr(jd), len(jobs) // 6, L.stream())
+    packed._gd_jobs = jd
+    if registered_ok:
+        _REG[key] = dict(ref=weakref.ref(W), packed=packed, ptrs=(W.data_ptr(),), jobs=jobs)
+        _TABLE.clear()
+    return packed
+
+
 def repack_registered():
     """Refresh every registered image with ONE launch per device (called after the optimizer step)."""
     dead = [k for k, e in _REG.items() if e["ref"]() is None]

@@ -144,6 +144,7 @@ class DecoderTiles:
     n_act: int
     tile_slot: torch.Tensor            # (B * ceil(H/8) * ceil(W/8),) int32 tile -> slot / -1
     tile_list: torch.Tensor            # (n_act,) int32 ascending tile ids
+    nbr: Optional[list] = None         # per source stage (n_sites, 9) int32: tile-compact row of (site, tap) / -1 (conv_out backward)
 
 
 @dataclass
@@ -200,8 +201,35 @@ def decoder_tiles(ep: "EncoderPlan", sources, H: int, W: int) -> DecoderTiles:
     assert all(sp.Y * u == H and sp.X * u == W for sp, u in zip(st, ups))
     r = _decoder_tiles_launch([sp.map for sp in st], ups, B, H, W, st[0].map.device)
     n = int(r["n_act"].item())
-    ep.dec_tiles = DecoderTiles(sources, B, H, W, n, r["tile_slot"], r["tile_list"][:n])
+    ep.dec_tiles = DecoderTiles(sources, B, H, W, n, r["tile_slot"], r["tile_list"][:n], _site_rulebooks(st, ups, r["tile_slot"], H, W))
     return ep.dec_tiles
+
+
+def decoder_site_rulebooks(dt: "DecoderTiles", sites, ups):
+    """Rulebooks of the conv_out backward for a tile set that came without them (inline plans): ``sites[g]`` = full-resolution
+    cells of source stage g's active sites, ``ups[g]`` its upsampling stride."""
+    out = []
+    for st, u in zip(sites, ups):
+        n_dev = torch.tensor([st.numel() // (u * u)], dtype=I32, device=st.device)
+        nbr = _empty(st.numel() * 9, I32, st.device)
+        L.call("gdmae_decoder_site_rulebook", L.ptr(st.contiguous()), L.ptr(n_dev), u * u, st.numel(), L.ptr(dt.tile_slot), dt.H, dt.W,
+               L.ptr(nbr), L.stream())
+        out.append(nbr.view(-1, 9))
+    return out
+
+
+def _site_rulebooks(stages, ups, tile_slot, H, W):
+    """Per source stage the (n_sites, 9) rulebook of the conv_out backward (gdmae_decoder_site_rulebook)."""
+    out = []
+    for sp, u in zip(stages, ups):
+        sites = sp.tok_cell if u == 1 else (sp._up_sites[1] if getattr(sp, "_up_sites", None) is not None and sp._up_sites[0] == u
+                                            else upsample_cells(sp.tok_cell, sp.Y, sp.X, u).reshape(-1).contiguous())
+        n_dev = torch.tensor([sp.n_tok], dtype=I32, device=tile_slot.device)
+        nbr = _empty(sites.numel() * 9, I32, tile_slot.device)
+        L.call("gdmae_decoder_site_rulebook", L.ptr(sites.contiguous()), L.ptr(n_dev), u * u, sites.numel(), L.ptr(tile_slot), H, W, L.ptr(nbr),
+               L.stream())
+        out.append(nbr.view(-1, 9))
+    return out
 
 
 def _encoder_launch(vox, m_cap: int, strides, window_shapes, drop_infos, keep_frac, noise, dec_sources=None) -> dict:
@@ -536,7 +564,9 @@ class PlanPrefetch:
         if A.has("dec.tile_slot"):
             n_act = int(c[2 + ns + 16 * ns])
             nt = B * ((gy + 7) // 8) * ((gx + 7) // 8)
-            dt = DecoderTiles(tuple(int(i) for i in self.dec_sources), B, gy, gx, n_act, V("dec.tile_slot", i32, nt), V("dec.tile_list", i32, n_act))
+            nbrs = [V(f"dec.nbr{g}", i32, stages[int(si)].n_tok * geo[int(si)]["up_s"] ** 2, 9) for g, si in enumerate(self.dec_sources)]
+            dt = DecoderTiles(tuple(int(i) for i in self.dec_sources), B, gy, gx, n_act, V("dec.tile_slot", i32, nt), V("dec.tile_list", i32, n_act),
+                              nbrs)
         ep = EncoderPlan(V("mask", f32, M) if self.masked else None, V("tok_pillar", i32, stages[0].n_tok if not geo[0]["strided"] else n_vis),
                          stages, dt)
         return vox, ep

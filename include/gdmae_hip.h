@@ -438,7 +438,25 @@ size_t gdmae_conv_block_scratch_bytes(long long n_in, long long n_out, int cin, 
  * used with the transposed rulebook and cin / cout swapped).  Replaces spconv's gather-GEMM-scatter (spconv_utils.py:37-56). */
 size_t gdmae_spconv_packed_bytes(int cin, int cout);
 int gdmae_spconv_pack_jobs(const float* W /* (cout, 3, 3, cin) fp32 */, int cin, int cout, int transposed, void* packed, long long* jobs);
-int gdmae_spconv(const void* X, int x_f32, const int* nbr, const void* packed, long long n, int cin, int cout, void* Y, void* stream);
+int gdmae_spconv(const void* X, int x_f32, const int* nbr, const void* packed, long long n, int cin, int cout, void* Y,
+                 int timing_slot /* 0: the sparse-conv forward slot of gdmae_kernel_timing */, void* stream);
+/* ---- 3x3 conv_out backward of the generative decoder without the tap matrix (round 3; spt_backbone_mae.py:46-52 backward) ---- *
+ * gdmae_decoder_dy: dYc (n_act * 64, C) bf16 = k0 + k1 * Yc + rows[pillar of the site] on the active tiles (Yc / tile_list of
+ *   gdmae_conv3x3_tiles_fwd / gdmae_decoder_tiles; rows (M, C) fp32 = the sparse part of the output gradient; zero at the
+ *   out-of-map sites of edge tiles) - the conv output gradient, materialised ONCE instead of nine-fold (gdmae_conv3x3_grad_taps).
+ * gdmae_decoder_site_rulebook: nbr[t, k] = row of dYc holding site[t] - (ky - 1, kx - 1), k = 3 ky + kx, -1 outside the map;
+ *   site = full-resolution cells ((b H + y) W + x) of a source stage's active sites, sites_per_tok of them per token, token count on
+ *   the device (n_dev).  Geometry only: gdmae_geometry_plan builds it as "dec.nbr<g>".
+ * gdmae_tap_dw: out[k][n][m_off + m] += sum_t G[t][m] X[nbr[t][k]][n] for the 9 taps as ONE grouped TN launch + a fixed-order
+ *   reduce (G (n_pad >= n rows, M) bf16 contiguous, n_pad a multiple of 1024; X rows (.., N) bf16 gathered through nbr (n, 9));
+ *   with gdmae_spconv over the same rulebook for the input gradient this replaces the taps + two library GEMMs per stage. */
+int gdmae_decoder_dy(const void* Yc, const int* tile_list, int n_act, const float* k0, const float* k1, const float* rows,
+                     const int* cell2pillar, int H, int W, int C, void* dYc, void* stream);
+int gdmae_decoder_site_rulebook(const int* site, const int* n_dev, int sites_per_tok, long long cap_sites, const int* tile_slot,
+                                int H, int W, int* nbr, void* stream);
+size_t gdmae_tap_dw_workspace_bytes(long long n_pad, int M, int N);
+int gdmae_tap_dw(const void* G, long long n, long long n_pad, int M, const void* X, const int* nbr, int N, float* out, int ld_out,
+                 int m_off, void* workspace, void* stream);
 int gdmae_conv_block_fwd(const gdmae_conv_block_args* args /* host */, void* stream);
 int gdmae_conv_block_bwd(const gdmae_conv_block_args* args /* host */, void* stream);
 

@@ -1282,7 +1282,7 @@ def test_spconv_implicit_gemm_matches_gathered_product(cin, cout, src_f32):
         jd = torch.tensor(list(jobs), dtype=torch.int64).to(dev())
         L.call("gdmae_tok_gemm_pack", L.ptr(jd), 9, L.stream())
         Y = torch.empty(n, co, dtype=torch.bfloat16, device=dev())
-        L.call("gdmae_spconv", L.ptr(src.contiguous()), int(src_f32), L.ptr(nbr), L.ptr(packed), n, ci, co, L.ptr(Y), L.stream())
+        L.call("gdmae_spconv", L.ptr(src.contiguous()), int(src_f32), L.ptr(nbr), L.ptr(packed), n, ci, co, L.ptr(Y), 0, L.stream())
         xb = Xs.bfloat16().float()
         Wb = W.bfloat16().float()
         ref = torch.zeros(n, co, device=dev())
