@@ -59,11 +59,11 @@ struct Scratch {
   char *gemm_ws, *cs_ws, *st, *rs_ws, *c01, *dy, *gcols, *wt, *sk_ws, *dw_part;
   size_t bytes;
 };
-long long pad512(long long n) { return (n + 1023) / 1024 * 1024; }       // rows of dy: a multiple of 16 slices x 64-row chunks
-// row slices of the gathered weight-gradient launch: ~2 workgroups per CU (GDMAE_SPCONV_DW_WGS overrides the bound)
-int conv_dw_slices(long long n_pad, int tiles) {
+// row slices of the gathered weight-gradient launch (~2+ workgroups per CU; GDMAE_SPCONV_DW_WGS overrides the bound) and the
+// padded row count of dy that goes with them
+int conv_dw_pick(long long n_out, int tiles, long long* n_pad) {
   static const int wgs = getenv("GDMAE_SPCONV_DW_WGS") ? atoi(getenv("GDMAE_SPCONV_DW_WGS")) : 1200;
-  return gd_dw_group_slices_for(n_pad, tiles, wgs);
+  return gd_dw_pick(n_out, tiles, wgs, n_pad);
 }
 // implicit: the im2col-free path (spconv.hip + the gathered grouped weight gradient): no gathered matrices, no library workspaces;
 // dy is padded to the slice grid of the weight-gradient kernel, which also gets its partial tiles here
@@ -76,14 +76,15 @@ Scratch layout(void* base, long long n_in, long long n_out, int cin, int cout, i
   s.st = take((size_t)3 * cout * sizeof(double));
   s.rs_ws = take(gdmae_rows_bwd_stats_workspace_bytes(cout));
   s.c01 = take((size_t)2 * cout * sizeof(float));
-  s.dy = take((size_t)(implicit ? pad512(n_out) : n_out) * cout * es);
+  long long n_pad = n_out;
+  const int S_dw = implicit ? conv_dw_pick(n_out, 9 * (cout / 128) * (cin / 128), &n_pad) : 0;
+  s.dy = take((size_t)n_pad * cout * es);
   s.gcols = take(implicit ? 0 : (size_t)n_in * 9 * cout * es);
   s.wt = take(implicit ? 0 : (size_t)9 * cout * cin * es);
   s.sk_ws = take(implicit ? 0 : gdmae_gemm_tn_splitk_workspace_bytes(n_out, cout, 9 * cin));
   s.dw_part = nullptr;
   if (implicit) {
-    const int tiles = 9 * (cout / 128) * (cin / 128);
-    s.dw_part = take((size_t)conv_dw_slices(pad512(n_out), tiles) * 9 * cout * cin * sizeof(float));
+    s.dw_part = take((size_t)S_dw * 9 * cout * cin * sizeof(float));
   }
   s.bytes = off;
   return s;
@@ -181,8 +182,8 @@ extern "C" int gdmae_conv_block_bwd(const gdmae_conv_block_args* a, void* stream
     //      are gathered through the rulebook column on load; all tiles of a row slice on one XCD), reduced into (cout, 9, cin)
     GdDwGroup Gp;
     Gp.n_jobs = 9;
-    const long long n_pad = pad512(a->n_out);
-    const int S = conv_dw_slices(n_pad, 9 * (C / 128) * (a->cin / 128));
+    long long n_pad = 0;
+    const int S = conv_dw_pick(a->n_out, 9 * (C / 128) * (a->cin / 128), &n_pad);
     for (int k = 0; k < 9; ++k) {
       Gp.job[k] = GdDwJob{s.dy, a->x, C, a->cin, (float*)s.dw_part + (size_t)k * S * C * a->cin, nullptr, 0, a->nbr + k, 9, a->x_f32};
     }

@@ -29,5 +29,6 @@ struct GdDwGroup {
 bool gd_dw_group_supported(long long n_pad, int d, int ff);
 int gd_dw_group_slices(long long n_pad, int tiles_total);
 int gd_dw_group_slices_for(long long n_pad, int tiles_total, int max_wgs);
+int gd_dw_pick(long long n, int tiles_total, int max_wgs, long long* n_pad);
 int gd_dw_grouped(hipStream_t st, GdDwGroup& A, long long n_pad, long long n_valid);
 int gd_dw_grouped_s(hipStream_t st, GdDwGroup& A, long long n_pad, long long n_valid, int S);

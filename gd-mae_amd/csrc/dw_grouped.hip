@@ -282,6 +282,17 @@ bool gd_dw_group_supported(long long n_pad, int d, int ff) {
 }
 // number of row slices: a multiple of 8 (one XCD per slice residue), tiles x slices ~ 2 workgroups per CU
 int gd_dw_group_slices(long long n_pad, int tiles_total) { return gd_dw_group_slices_for(n_pad, tiles_total, 512); }
+// Slice count FIRST, then the row padding that makes it fit (gathered launches: the row count is data dependent, and a padding
+// granule of 1024 rows capped the slices at 16 - 288 workgroups for the 384 k decoder sites): S doubles while tiles x S stays within
+// max_wgs and a slice keeps >= 4 chunks; *n_pad = rows padded to S x 64.
+int gd_dw_pick(long long n, int tiles_total, int max_wgs, long long* n_pad) {
+  int S = 8;
+  while (S < 64 && (long long)tiles_total * S * 2 <= max_wgs && n / (S * 2) >= 4 * kChunk) S *= 2;
+  const long long g = (long long)S * kChunk;
+  *n_pad = (n + g - 1) / g * g;
+  if (*n_pad < g) *n_pad = g;
+  return S;
+}
 // ... with the number of workgroups the launch should not exceed after doubling (the layer launch wants ~1 workgroup per CU:
 // its tiles re-read few operands; the gathered sparse-convolution launch is latency-bound and wants both resident slots filled)
 int gd_dw_group_slices_for(long long n_pad, int tiles_total, int max_wgs) {

@@ -264,23 +264,32 @@ __global__ __launch_bounds__(256) void k_tap_dw_reduce(const float* __restrict__
     out[((long long)k * N + n) * ld_out + m_off + m] += acc;
   }
 }
-int tap_dw_slices(long long n_pad, int tiles) {
+int tap_dw_pick(long long n, int tiles, long long* n_pad) {
   static const int wgs = getenv("GDMAE_SPCONV_DW_WGS") ? atoi(getenv("GDMAE_SPCONV_DW_WGS")) : 1200;
-  return gd_dw_group_slices_for(n_pad, tiles, wgs);
+  return gd_dw_pick(n, tiles, wgs, n_pad);
 }
 }  // namespace
 
-extern "C" size_t gdmae_tap_dw_workspace_bytes(long long n_pad, int M, int N) {
-  return gd_align((size_t)tap_dw_slices(n_pad, 9 * (M / 128) * (N / 128)) * 9 * M * N * sizeof(float));
+// rows the G operand must be allocated for (>= n: the row count padded to the slice grid the launch will use)
+extern "C" long long gdmae_tap_dw_rows(long long n, int M, int N) {
+  long long n_pad = 0;
+  tap_dw_pick(n, 9 * (M / 128) * (N / 128), &n_pad);
+  return n_pad;
+}
+extern "C" size_t gdmae_tap_dw_workspace_bytes(long long n, int M, int N) {
+  long long n_pad = 0;
+  return gd_align((size_t)tap_dw_pick(n, 9 * (M / 128) * (N / 128), &n_pad) * 9 * M * N * sizeof(float));
 }
 extern "C" int gdmae_tap_dw(const void* G, long long n, long long n_pad, int M, const void* X, const int* nbr, int N, float* out, int ld_out,
                             int m_off, void* workspace, void* stream) {
-  GD_REQUIRE(M % 128 == 0 && N % 128 == 0 && n_pad % 1024 == 0 && n <= n_pad && n >= 0, "tap_dw: M, N multiples of 128, rows padded to 1024");
+  GD_REQUIRE(M % 128 == 0 && N % 128 == 0 && n >= 0, "tap_dw: M, N multiples of 128");
   if (n == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   GdDwGroup Gp;
   Gp.n_jobs = 9;
-  const int S = tap_dw_slices(n_pad, 9 * (M / 128) * (N / 128));
+  long long want = 0;
+  const int S = tap_dw_pick(n, 9 * (M / 128) * (N / 128), &want);
+  GD_REQUIRE(n_pad == want, "tap_dw: G must be allocated for gdmae_tap_dw_rows(n, M, N) rows");
   for (int k = 0; k < 9; ++k) Gp.job[k] = GdDwJob{G, X, M, N, (float*)workspace + (size_t)k * S * M * N, nullptr, 0, nbr + k, 9, 0};
   {
     GdTimed timed(GD_T_DEC_CONV_BWD, st, (double)n * (2.0 * M + 9.0 * 2.0 * N + 36.0) + 36.0 * S * M * N, 2.0 * n * 9.0 * M * N);

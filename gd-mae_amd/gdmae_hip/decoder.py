@@ -294,13 +294,13 @@ class DecoderHead(torch.autograd.Function):
                 # dZ rows of the stage's active sites: implicit GEMM over the rulebook (9 gathered dY rows per site)
                 dX = torch.empty(n, w, dtype=cdt, device=dev)
                 L.call("gdmae_spconv", L.ptr(dYc), 0, L.ptr(nbr), packed.data_ptr() + i * 9 * w * C2 * 2, n, C2, w, L.ptr(dX), 8, L.stream())
-                n_pad = (n + 1023) // 1024 * 1024
+                n_pad = int(L.load().gdmae_tap_dw_rows(n, w, C2))
                 Zd = torch.empty(n_pad, w, dtype=cdt, device=dev)
                 bg = bgz[col:col + w]
                 L.call("gdmae_rows_affine_relu_sub", L.ptr(P), _bf(P), None, n, w, L.ptr(ab), L.ptr(ab[w:]), L.ptr(bg), L.ptr(Zd),
                        _bf(Zd), w, 0, L.stream())
                 # weight gradient: dWk[k][co][col + ci] += sum_t dY[site_t - k][co] * Zd[t][ci], nine taps in one grouped launch
-                ws = torch.empty(L.load().gdmae_tap_dw_workspace_bytes(n_pad, w, C2), dtype=torch.uint8, device=dev)
+                ws = torch.empty(L.load().gdmae_tap_dw_workspace_bytes(n, w, C2), dtype=torch.uint8, device=dev)
                 L.call("gdmae_tap_dw", L.ptr(Zd), n, n_pad, w, L.ptr(dYc), L.ptr(nbr), C2, L.ptr(dWk), Cin, col, L.ptr(ws), L.stream())
             else:
                 G = torch.empty(n, 9 * C2, dtype=cdt, device=dev)

@@ -107,6 +107,7 @@ SIGNATURES = {
     "gdmae_spconv": (_I, [_P, _I, _P, _P, _L, _I, _I, _P, _I, _P]),
     "gdmae_decoder_dy": (_I, [_P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _P, _P]),
     "gdmae_decoder_site_rulebook": (_I, [_P, _P, _I, _L, _P, _I, _I, _P, _P]),
+    "gdmae_tap_dw_rows": (_L, [_L, _I, _I]),
     "gdmae_tap_dw_workspace_bytes": (_Z, [_L, _I, _I]),
     "gdmae_tap_dw": (_I, [_P, _L, _L, _I, _P, _P, _I, _P, _I, _I, _P, _P]),
     "gdmae_conv_block_fwd": (_I, [_P, _P]),

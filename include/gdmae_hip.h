@@ -448,13 +448,14 @@ int gdmae_spconv(const void* X, int x_f32, const int* nbr, const void* packed, l
  *   site = full-resolution cells ((b H + y) W + x) of a source stage's active sites, sites_per_tok of them per token, token count on
  *   the device (n_dev).  Geometry only: gdmae_geometry_plan builds it as "dec.nbr<g>".
  * gdmae_tap_dw: out[k][n][m_off + m] += sum_t G[t][m] X[nbr[t][k]][n] for the 9 taps as ONE grouped TN launch + a fixed-order
- *   reduce (G (n_pad >= n rows, M) bf16 contiguous, n_pad a multiple of 1024; X rows (.., N) bf16 gathered through nbr (n, 9));
+ *   reduce (G (n_pad = gdmae_tap_dw_rows(n, M, N) >= n rows, M) bf16 contiguous; X rows (.., N) bf16 gathered through nbr (n, 9));
  *   with gdmae_spconv over the same rulebook for the input gradient this replaces the taps + two library GEMMs per stage. */
 int gdmae_decoder_dy(const void* Yc, const int* tile_list, int n_act, const float* k0, const float* k1, const float* rows,
                      const int* cell2pillar, int H, int W, int C, void* dYc, void* stream);
 int gdmae_decoder_site_rulebook(const int* site, const int* n_dev, int sites_per_tok, long long cap_sites, const int* tile_slot,
                                 int H, int W, int* nbr, void* stream);
-size_t gdmae_tap_dw_workspace_bytes(long long n_pad, int M, int N);
+long long gdmae_tap_dw_rows(long long n, int M, int N);      /* n_pad: rows G must be allocated for */
+size_t gdmae_tap_dw_workspace_bytes(long long n, int M, int N);
 int gdmae_tap_dw(const void* G, long long n, long long n_pad, int M, const void* X, const int* nbr, int N, float* out, int ld_out,
                  int m_off, void* workspace, void* stream);
 int gdmae_conv_block_fwd(const gdmae_conv_block_args* args /* host */, void* stream);
