@@ -466,7 +466,7 @@ def main():
         # ---- the reference yaml's own mask ratio (tools/cfgs/waymo_models/gd_mae_ssl.yaml:158)
         other = 0.85 if abs(args.mask_ratio - 0.85) > 1e-6 else 0.75
         wl.net.backbone_3d.mask_ratio = other
-        also[f"mask_{other}"] = timed_leg(wl, 3, max(5, args.steps // 2))
+        also[f"mask_{other}"] = timed_leg(wl, 6, max(5, args.steps // 2))      # (new token counts: every pooled batch twice through the warm-up)
         wl.net.backbone_3d.mask_ratio = args.mask_ratio
         # ---- fp32 parity mode (the mode whose loss is held to 1e-4 of the reference by tests/)
         if wl.mode["bf16"]:

@@ -62,7 +62,7 @@ struct Scratch {
 // row slices of the gathered weight-gradient launch (~2+ workgroups per CU; GDMAE_SPCONV_DW_WGS overrides the bound) and the
 // padded row count of dy that goes with them
 int conv_dw_pick(long long n_out, int tiles, long long* n_pad) {
-  static const int wgs = getenv("GDMAE_SPCONV_DW_WGS") ? atoi(getenv("GDMAE_SPCONV_DW_WGS")) : 1200;
+  static const int wgs = getenv("GDMAE_SPCONV_DW_WGS") ? atoi(getenv("GDMAE_SPCONV_DW_WGS")) : 640;
   return gd_dw_pick(n_out, tiles, wgs, n_pad);
 }
 // implicit: the im2col-free path (spconv.hip + the gathered grouped weight gradient): no gathered matrices, no library workspaces;
@@ -157,8 +157,8 @@ extern "C" int gdmae_conv_block_fwd(const gdmae_conv_block_args* a, void* stream
     CB_TRY(gdmae_gemm(a->cols, a->W, a->y, a->n_out, a->cout, 9ll * a->cin, 0, 1, a->bf16, 0, nullptr, s.gemm_ws, stream));
   CB_TRY(gdmae_bn_fold(a->y, a->n_out, a->cout, a->bf16, (double)a->n_out, a->gamma, a->beta, a->eps, a->momentum, a->running_mean,
                        a->running_var, a->num_batches, a->stats, a->ab, a->mv, s.cs_ws, stream));
-  CB_TRY(gdmae_rows_affine_relu_scatter(a->y, a->bf16, nullptr, a->n_out, a->cout, a->ab, a->ab + a->cout, a->out, a->bf16, a->cout, 0,
-                                        stream));
+  CB_TRY(gdmae_rows_affine_relu_scatter(a->y, a->bf16, nullptr, a->n_out, a->cout, a->ab, a->ab + a->cout, a->out,
+                                        a->out_f32 ? 0 : a->bf16, a->cout, 0, stream));
   return 0;
 }
 

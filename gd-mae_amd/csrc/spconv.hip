@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256) void k_tap_dw_reduce(const float* __restrict__
   }
 }
 int tap_dw_pick(long long n, int tiles, long long* n_pad) {
-  static const int wgs = getenv("GDMAE_SPCONV_DW_WGS") ? atoi(getenv("GDMAE_SPCONV_DW_WGS")) : 1200;
+  static const int wgs = getenv("GDMAE_SPCONV_DW_WGS") ? atoi(getenv("GDMAE_SPCONV_DW_WGS")) : 640;
   return gd_dw_pick(n, tiles, wgs, n_pad);
 }
 }  // namespace

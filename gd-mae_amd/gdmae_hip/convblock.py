@@ -22,7 +22,7 @@ IMPLICIT = os.environ.get("GDMAE_SPCONV", "1") != "0"    # False: im2col gather 
 class ConvBNReLUFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, info):
-        weight, bn, nbr, nbr_t, direct = info
+        weight, bn, nbr, nbr_t, direct, out_f32 = info
         cout, _, _, cin = weight.shape
         n_in, n_out = x.shape[0], nbr.shape[0]
         dev = x.device
@@ -47,7 +47,8 @@ class ConvBNReLUFn(torch.autograd.Function):
             a.packed_fwd, a.packed_bwd = L.ptr(packed[0]), L.ptr(packed[1])
         cols = torch.empty(n_out, 9 * cin, dtype=cdt, device=dev) if packed is None else torch.empty(0, dtype=cdt, device=dev)
         y = torch.empty(n_out, cout, dtype=cdt, device=dev)
-        out = torch.empty(n_out, cout, dtype=cdt, device=dev)
+        out = torch.empty(n_out, cout, dtype=torch.float32 if out_f32 else cdt, device=dev)
+        a.out_f32 = int(out_f32 and cdt != torch.float32)
         stats = torch.empty(2 * cout, dtype=torch.float64, device=dev)
         abmv = torch.empty(4 * cout, dtype=torch.float32, device=dev)
         nb = L.load().gdmae_conv_block_scratch_bytes(n_in, n_out, cin, cout, a.bf16)
@@ -78,9 +79,10 @@ class ConvBNReLUFn(torch.autograd.Function):
         return dx, None
 
 
-def conv_bn_relu(x, conv, bn, nbr, nbr_t):
-    """-> features (n_out, cout) or None if the block's parameters are not owned by a flat optimizer (caller falls back)."""
+def conv_bn_relu(x, conv, bn, nbr, nbr_t, out_f32=False):
+    """-> features (n_out, cout) or None if the block's parameters are not owned by a flat optimizer (caller falls back).
+    ``out_f32``: write the block output in fp32 also in bf16 mode (it feeds the fp32 residual stream of an encoder stage)."""
     direct = [ops.direct_grad(p) for p in (conv.weight, bn.weight, bn.bias)]
     if any(t is None for t in direct) or not x.is_cuda:
         return None
-    return ConvBNReLUFn.apply(x, (conv.weight, bn, nbr, nbr_t, direct))
+    return ConvBNReLUFn.apply(x, (conv.weight, bn, nbr, nbr_t, direct, out_f32))

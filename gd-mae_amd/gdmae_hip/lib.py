@@ -83,6 +83,7 @@ SIGNATURES = {
     "gdmae_window_attention_levels_bwd": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P, _P, _I, _I, _P, _F, _P]),
     "gdmae_attention_timing": (_I, [_I]),
     "gdmae_attention_timing_read": (_I, [_I, _P, _P]),
+    "gdmae_create_masked_stream": (_I, [_P, _I, _P]),
     "gdmae_kernel_timing": (_I, [_I]),
     "gdmae_kernel_timing_slots": (_I, []),
     "gdmae_kernel_timing_name": (C.c_char_p, [_I]),
@@ -173,7 +174,8 @@ class ConvBlockArgs(C.Structure):
     _fields_ = ([("n_in", _L), ("n_out", _L), ("cin", _I), ("cout", _I), ("bf16", _I), ("x_f32", _I), ("g_f32", _I),
                  ("eps", _F), ("momentum", _F)]
                 + [(k, _P) for k in ("x", "nbr", "nbr_t", "W", "gamma", "beta", "running_mean", "running_var", "num_batches", "cols",
-                                     "y", "stats", "ab", "mv", "out", "g", "dx", "dW", "dgamma", "dbeta", "scratch", "packed_fwd", "packed_bwd")])
+                                     "y", "stats", "ab", "mv", "out", "g", "dx", "dW", "dgamma", "dbeta", "scratch", "packed_fwd", "packed_bwd")]
+                + [("out_f32", _I)])
 
 
 _lib = None

@@ -246,7 +246,7 @@ class ResidualAdd(torch.autograd.Function):
         assert a.dtype == torch.float32 and b.dtype in (torch.float32, torch.bfloat16) and a.shape == b.shape
         ctx.b_dtype = b.dtype
         a, b = a.contiguous(), b.contiguous()
-        odt = torch.bfloat16 if (torch.is_autocast_enabled() and b.dtype == torch.bfloat16) else torch.float32
+        odt = torch.bfloat16 if torch.is_autocast_enabled() else torch.float32
         out = torch.empty_like(a, dtype=odt)
         L.call("gdmae_add3_to", L.ptr(a), L.ptr(b), int(b.dtype == torch.bfloat16), None, 0, a.numel(), L.ptr(out),
                int(odt == torch.bfloat16), L.stream())
@@ -254,7 +254,8 @@ class ResidualAdd(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        return (g if g.dtype == torch.float32 else g.float()), (g if g.dtype == ctx.b_dtype else g.to(ctx.b_dtype))
+        ga = g if g.dtype == torch.float32 else g.float()
+        return ga, (ga if ctx.b_dtype == torch.float32 else (g if g.dtype == ctx.b_dtype else g.to(ctx.b_dtype)))
 
 
 def linear(x, weight, bias=None):

@@ -96,6 +96,7 @@ class SparseConv2d(SparseConvolution):
 class SparseSequential(SparseModule):
     fused_bn_relu = True     # conv -> BatchNorm1d(train) -> ReLU as one statistics pass + one fused row pass
     native_block = os.environ.get("GDMAE_CONV_BLOCK", "1") != "0"   # whole block as one native call when a flat optimizer owns it
+    out_fp32 = False         # native block: fp32 output also under autocast (set for conv_down: it feeds an encoder stage's fp32 stream)
 
     def __init__(self, *mods):
         super().__init__()
@@ -110,7 +111,7 @@ class SparseSequential(SparseModule):
             conv, bn = mods[0], mods[1]
             if self.native_block and isinstance(conv, SparseConvolution):
                 nbr, nbr_t, stage = conv.rulebooks(x)
-                f = convblock.conv_bn_relu(x.features, conv, bn, nbr, nbr_t)     # one native call per direction
+                f = convblock.conv_bn_relu(x.features, conv, bn, nbr, nbr_t, self.out_fp32)     # one native call per direction
                 if f is not None:
                     return x.replace_feature(f) if stage == x._stage else SparseConvTensor(f, x._plan, stage)
             x = conv(x)

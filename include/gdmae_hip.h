@@ -332,6 +332,9 @@ int gdmae_attention_timing_read(int which, double* total_ms, long long* calls);
  * launch incl. k_tok_gemm_multi), 3 k_dw_grouped, 11 k_layer_tail, ...  gdmae_kernel_timing(1) starts collecting (dropping
  * earlier records), (0) stops; gdmae_kernel_timing_read returns summed milliseconds, call count and the summed ALGORITHMIC
  * bytes / flops of the bracketed launches (operands read once + results written once, stated next to each bracket). */
+/* A HIP stream restricted to the compute units whose bit is set in mask (hipExtStreamCreateWithCUMask; `words` 32-bit words):
+ * side-stream work (the geometry plan of the next batch) confined to a few CUs per XCD. */
+int gdmae_create_masked_stream(const unsigned* mask, int words, void** stream_out);
 int gdmae_kernel_timing(int on);
 int gdmae_kernel_timing_slots(void);
 const char* gdmae_kernel_timing_name(int slot);
@@ -429,6 +432,8 @@ typedef struct gdmae_conv_block_args {
    * gradient one grouped TN launch that gathers the input rows on load; `cols` is then neither written nor read (may be NULL) */
   const void* packed_fwd;   /* 9 x (cout, cin) images */
   const void* packed_bwd;   /* 9 x (cin, cout) images (per-tap transposed weights) */
+  int out_f32;              /* forward: write `out` in fp32 although the block computes in bf16 (the consumer is the fp32 residual
+                               stream of an encoder stage: saves its cast pass) */
 } gdmae_conv_block_args;
 size_t gdmae_conv_block_scratch_bytes(long long n_in, long long n_out, int cin, int cout, int bf16);
 /* Sparse convolution as an implicit GEMM over a rulebook (csrc/spconv.hip): Y (n, cout) bf16 = sum_tap W_tap X[nbr[:, tap]], X bf16
