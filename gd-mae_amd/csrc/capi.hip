@@ -93,13 +93,3 @@ extern "C" int gdmae_attention_timing_read(int which, double* total_ms, long lon
   return gdmae_kernel_timing_read(which == 0 ? GD_T_ATTN_FWD : GD_T_ATTN_BWD, total_ms, calls, nullptr, nullptr);
 }
 
-// A HIP stream restricted to a subset of the compute units (hipExtStreamCreateWithCUMask): the geometry plan of the NEXT batch
-// runs beside the training stream; confined to a few CUs per XCD its latency-bound kernels stop displacing the training kernels'
-// workgroups everywhere (GDMAE_PLAN_CU_MASK in gdmae_hip/plan.py).  mask: `words` 32-bit words, bit i = CU i enabled.
-extern "C" int gdmae_create_masked_stream(const unsigned* mask, int words, void** stream_out) {
-  GD_REQUIRE(mask != nullptr && words >= 1 && stream_out != nullptr, "create_masked_stream: bad arguments");
-  hipStream_t st = nullptr;
-  GD_CHECK(hipExtStreamCreateWithCUMask(&st, (uint32_t)words, mask));
-  *stream_out = (void*)st;
-  return 0;
-}

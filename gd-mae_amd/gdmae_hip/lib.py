@@ -83,7 +83,6 @@ SIGNATURES = {
     "gdmae_window_attention_levels_bwd": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P, _P, _I, _I, _P, _F, _P]),
     "gdmae_attention_timing": (_I, [_I]),
     "gdmae_attention_timing_read": (_I, [_I, _P, _P]),
-    "gdmae_create_masked_stream": (_I, [_P, _I, _P]),
     "gdmae_kernel_timing": (_I, [_I]),
     "gdmae_kernel_timing_slots": (_I, []),
     "gdmae_kernel_timing_name": (C.c_char_p, [_I]),

@@ -460,22 +460,6 @@ class _Arena:
         return self.base[dtype].as_strided(tuple(int(d) for d in shape), tuple(reversed(strides)), off // es)
 
 
-def _plan_stream(dev):
-    """The stream the plans are built on.  GDMAE_PLAN_CU_MASK=<hex words, comma separated, least significant first> restricts it to
-    those compute units (bit i = CU i; e.g. 0x11111111 x 8 = every fourth CU)."""
-    import os
-    spec = os.environ.get("GDMAE_PLAN_CU_MASK", "")
-    if not spec:
-        return torch.cuda.Stream(device=dev)
-    import ctypes as C
-    words = [int(w, 16) for w in spec.split(",")]
-    arr = (C.c_uint * len(words))(*words)
-    out = C.c_void_p()
-    with torch.cuda.device(dev):
-        L.call("gdmae_create_masked_stream", arr, len(words), C.byref(out))
-    return torch.cuda.ExternalStream(out.value, device=dev)
-
-
 class PlanPrefetch:
     """Geometry plan of a batch built ahead of time on a side stream (the analogue of a data-loader prefetch: the
     plan depends only on the input points, never on the weights).  The whole plan is ONE call of the library
@@ -496,9 +480,7 @@ class PlanPrefetch:
         points = points.contiguous()
         dev = points.device
         main = torch.cuda.current_stream(dev)
-        side = PlanPrefetch._side.get(dev.index)
-        if side is None:
-            side = PlanPrefetch._side[dev.index] = _plan_stream(dev)
+        side = PlanPrefetch._side.setdefault(dev.index, torch.cuda.Stream(device=dev))
         # The plan stream is ordered after everything queued on the main stream so far.  That makes `points` / `noise` visible
         # and - the reason it is unconditional - lets the plan arena live without `record_stream`: it is allocated from the plan
         # stream's pool and read by the main stream; once its last reference dies the allocator hands the block to LATER

@@ -68,8 +68,6 @@ class SSTBlockV1(nn.Module):
         norm_fn = partial(nn.BatchNorm1d, eps=1e-3, momentum=0.01)
         self.conv_down = post_act_block(input_channels, d_model, 3, norm_fn=norm_fn, stride=stride, padding=1,
                                         indice_key=f'{indice_key}_spconv', conv_type='spconv', dim=2) if stride > 1 else None
-        if self.conv_down is not None:
-            self.conv_down.out_fp32 = True          # its output is the fp32 residual stream of the encoder stage
         self.sst_input_layer = SSTInputLayer(model_cfg.PREPROCESS)
         self.encoder_blocks = nn.ModuleList([
             BasicShiftBlockV2(d_model, enc.NHEAD, enc.DIM_FEEDFORWARD, enc.DROPOUT, enc.ACTIVATION, batch_first=False,

@@ -96,7 +96,8 @@ class SparseConv2d(SparseConvolution):
 class SparseSequential(SparseModule):
     fused_bn_relu = True     # conv -> BatchNorm1d(train) -> ReLU as one statistics pass + one fused row pass
     native_block = os.environ.get("GDMAE_CONV_BLOCK", "1") != "0"   # whole block as one native call when a flat optimizer owns it
-    out_fp32 = False         # native block: fp32 output also under autocast (set for conv_down: it feeds an encoder stage's fp32 stream)
+    out_fp32 = False         # native block: fp32 output also under autocast (skips one bf16 rounding + the consumer's cast pass; off:
+                             # the block then rounds exactly where the op-by-op path does, which the A/B test pins to 1e-6)
 
     def __init__(self, *mods):
         super().__init__()

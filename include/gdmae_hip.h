@@ -332,9 +332,6 @@ int gdmae_attention_timing_read(int which, double* total_ms, long long* calls);
  * launch incl. k_tok_gemm_multi), 3 k_dw_grouped, 11 k_layer_tail, ...  gdmae_kernel_timing(1) starts collecting (dropping
  * earlier records), (0) stops; gdmae_kernel_timing_read returns summed milliseconds, call count and the summed ALGORITHMIC
  * bytes / flops of the bracketed launches (operands read once + results written once, stated next to each bracket). */
-/* A HIP stream restricted to the compute units whose bit is set in mask (hipExtStreamCreateWithCUMask; `words` 32-bit words):
- * side-stream work (the geometry plan of the next batch) confined to a few CUs per XCD. */
-int gdmae_create_masked_stream(const unsigned* mask, int words, void** stream_out);
 int gdmae_kernel_timing(int on);
 int gdmae_kernel_timing_slots(void);
 const char* gdmae_kernel_timing_name(int slot);
