@@ -548,7 +548,11 @@ int gd_tok_gemm_plain(hipStream_t st, const void* X, const void* Wp, const void*
 int gd_tok_gemm_qkv(hipStream_t st, const void* Xpos, const void* X, const void* Wp_qk, const void* Wp_v, const void* bias3,
                     long long n_pad, int d, void* qk, void* v);
 int gd_tok_gemm_gelu(hipStream_t st, const void* X, const void* Wp, const void* bias, long long n_pad, int K, int N, void* h, void* gact);
-int gd_tok_gemm_gelu_bwd(hipStream_t st, const void* dY, const void* Wp, const void* h, long long n_pad, int K, int N, void* dh);
+int gd_tok_gemm_gelu_bwd(hipStream_t st, const void* dY, const void* Wp, const void* h, long long n_pad, int K, int N, void* dh, void* gact);
+bool gd_tok_gemm_ffn_supported(int d, int ff);
+int gd_tok_gemm_ffn(hipStream_t st, const void* X, const void* W1p, const void* b1, const void* W2p, const void* b2, long long n,
+                    long long n_pad, int d, void* h, const float* res, const float* gamma, const float* beta, float eps, float* y,
+                    float* stats, void* y_bf, const float* pos_table, const int* tok_pos, void* ypos_bf, void* f_out);
 int gd_tok_gemm_rows(int N);
 int gd_tok_gemm_ln_bwd(hipStream_t st, const void* X, const void* Wp, long long n, long long n_pad, int K, int N, const float* dy,
                        const void* dy2_bf, const float* ln_a, const void* ln_b_bf, const float* stats, const float* gamma, float* dx,
@@ -582,6 +586,12 @@ bool use_fused(const gdmae_layer_args* a) {
 bool use_grouped_dw(const gdmae_layer_args* a, long long n_pad) {
   static const int off = getenv("GDMAE_DWGROUP") ? atoi(getenv("GDMAE_DWGROUP")) == 0 : 0;
   return !off && a->bf16 && gd_dw_group_supported(n_pad, a->d, a->ff);
+}
+// feed-forward block as one forward launch (gelu(h) is then produced by the BACKWARD's GELU kernel, which runs before the grouped
+// weight-gradient launch - not before the per-matrix one)
+bool use_ffn(const gdmae_layer_args* a, long long n_pad) {
+  static const int off = getenv("GDMAE_FFN") ? atoi(getenv("GDMAE_FFN")) == 0 : 0;
+  return !off && use_fused(a) && use_grouped_dw(a, n_pad) && gd_tok_gemm_ffn_supported(a->d, a->ff);
 }
 }  // namespace
 
@@ -661,15 +671,23 @@ static int layer_fwd(const gdmae_layer_args* a, const gdmae_layer_args* next, bo
     // q/k/v operands): three launches for what is eight in the unfused sequence
     GD_TRY(gd_tok_gemm_res_ln(c.st, s.o, pk.o, a->bo, n, n_pad, d, d, a->x, a->g1, a->be1, a->eps, (float*)s.x1, (float*)s.st1, s.x1b,
                               nullptr, nullptr, nullptr, s.a));
-    GD_TRY(gd_tok_gemm_gelu(c.st, s.x1b, pk.w1, a->b1, n_pad, d, ff, s.h, s.gact));
+    // linear1 + GELU + linear2 + residual + LayerNorm 2 in one launch when the widths allow it: gelu(h) never leaves the CU (the
+    // backward's GELU kernel writes it into s.gact for the weight gradient of linear2)
+    const bool ffn1 = use_ffn(a, n_pad);
+    if (!ffn1) GD_TRY(gd_tok_gemm_gelu(c.st, s.x1b, pk.w1, a->b1, n_pad, d, ff, s.h, s.gact));
+    void *y_bf = nullptr, *ypos_bf = nullptr;
+    const float* ptab = nullptr;
+    const int* tpos = nullptr;
     if (next) {
       Saved sn = saved_layout(next->saved, n_pad, d, ff, es);
-      GD_TRY(gd_tok_gemm_res_ln(c.st, s.gact, pk.w2, a->b2, n, n_pad, ff, d, (const float*)s.x1, a->g2, a->be2, a->eps, a->y,
-                                (float*)s.st2, sn.xb, next->pos_table, next->tok_pos, sn.xpb, s.f));
-    } else {
-      GD_TRY(gd_tok_gemm_res_ln(c.st, s.gact, pk.w2, a->b2, n, n_pad, ff, d, (const float*)s.x1, a->g2, a->be2, a->eps, a->y,
-                                (float*)s.st2, nullptr, nullptr, nullptr, nullptr, s.f));
+      y_bf = sn.xb; ypos_bf = sn.xpb; ptab = next->pos_table; tpos = next->tok_pos;
     }
+    if (ffn1)
+      GD_TRY(gd_tok_gemm_ffn(c.st, s.x1b, pk.w1, a->b1, pk.w2, a->b2, n, n_pad, d, s.h, (const float*)s.x1, a->g2, a->be2, a->eps, a->y,
+                             (float*)s.st2, y_bf, ptab, tpos, ypos_bf, s.f));
+    else
+      GD_TRY(gd_tok_gemm_res_ln(c.st, s.gact, pk.w2, a->b2, n, n_pad, ff, d, (const float*)s.x1, a->g2, a->be2, a->eps, a->y,
+                                (float*)s.st2, y_bf, ptab, tpos, ypos_bf, s.f));
     return 0;
   }
   GD_TRY(linear_fwd(c, s.o, a->Wo, a->bo, s.a, n_pad, d, d));
@@ -748,7 +766,8 @@ static int layer_bwd(const gdmae_layer_args* a, bool upstream3, bool defer_add3,
   const bool fused = use_fused(a);
   const Packed pk = packed_layout(a->packed, d, ff);
   if (fused) {
-    GD_TRY(gd_tok_gemm_gelu_bwd(c.st, w.dfb, pk.w2t, s.h, n_pad, d, ff, w.dh));     // dh = (dfb W2) * gelu'(h)
+    // dh = (dfb W2) * gelu'(h); after the one-launch forward also gelu(h), the operand of linear2's weight gradient
+    GD_TRY(gd_tok_gemm_gelu_bwd(c.st, w.dfb, pk.w2t, s.h, n_pad, d, ff, w.dh, use_ffn(a, n_pad) ? s.gact : nullptr));
   } else {
     GD_TRY(linear_dx(c, w.dfb, a->W2, w.dg, n_pad, d, ff));
     GD_TRY(gelu(c, false, w.dg, s.h, w.dh, n_pad * ff));

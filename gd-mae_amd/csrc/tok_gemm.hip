@@ -426,7 +426,8 @@ __device__ __forceinline__ void tg_tile(const TgArgs& A, const long long tile, c
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = tg_gelu(v[j]);
         *(uint4*)(A.out1 + e) = tg_pack8(v);
-      } else {   // TG_GELU_BWD: dh = dg * (Phi(h) + h * phi(h))
+      } else {   // TG_GELU_BWD: dh = dg * (Phi(h) + h * phi(h));  optionally gelu(h) next to it (the operand of the weight
+                 // gradient of the linear layer behind the GELU, when the forward kept it in LDS only: k_tok_ffn)
         const uint4 hq = *(const uint4*)(A.aux + e);
         float g[8], v[8];
         tg_unpack8(q, g);
@@ -434,6 +435,11 @@ __device__ __forceinline__ void tg_tile(const TgArgs& A, const long long tile, c
 #pragma unroll
         for (int j = 0; j < 8; ++j) g[j] = g[j] * tg_gelu_grad(v[j]);
         *(uint4*)(A.out0 + e) = tg_pack8(g);
+        if (A.out1) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = tg_gelu(v[j]);
+          *(uint4*)(A.out1 + e) = tg_pack8(v);
+        }
       }
     }
   }
@@ -526,6 +532,243 @@ static int tg_dispatch(int K, int N, const TgArgs& A, hipStream_t st) {
   GD_REQUIRE(false, "tok_gemm: unsupported (K, N)");
 }
 
+// ------------------------------------------------------------------------------------------------
+// The feed-forward block of a layer as ONE launch (sst_basic_block.py:79-84: linear1 -> GELU -> linear2 -> residual +
+// LayerNorm 2):  h = X W1^T + b1 (bf16, stored: the backward differentiates the GELU at it),  g = gelu(h) lives in LDS only
+// (32 rows x FF bf16 per workgroup: the second product reads its operand tile from there, the (n, FF) activation is neither
+// written nor read back - the backward's GELU kernel re-creates it next to dh for the weight gradient),  then the RES_LN
+// epilogue of the kernel above on  g W2^T + b2.  Same fragments, k order, rounding points and row arithmetic as
+// k_tok_gemm<D, FF, TG_GELU> followed by k_tok_gemm<FF, D, TG_RES_LN>: bit-identical outputs.
+// ------------------------------------------------------------------------------------------------
+struct TgFfnArgs {
+  const unsigned short* X;      // (n_pad, D) bf16
+  const uint4* W1p;             // packed (FF, D)
+  const unsigned short* b1;     // (FF) bf16 or null
+  const uint4* W2p;             // packed (D, FF)
+  const unsigned short* b2;     // (D) bf16 or null
+  unsigned short* h;            // (n_pad, FF) bf16
+  TgArgs L;                     // the RES_LN operands / outputs (X, Wp, bias, out* unused)
+};
+
+template <int D>
+__global__ __launch_bounds__(512, 4) void k_tok_ffn(TgFfnArgs F) {
+  constexpr int FF = 2 * D;
+  constexpr int ROWS = D >= 256 ? 32 : 64;
+  constexpr int XP = D * 2 + 16, HP = FF * 2 + 16, SP = D * 2 + 16;
+  constexpr int KS1 = D / 16, MB1 = FF / 32, MPW1 = MB1 / TG_WAVES, NPW1 = ROWS / 32;     // product 1: every wavefront MPW1 channel blocks x all rows
+  constexpr int KS2 = FF / 16, MB2 = D / 32;                                                // product 2: one block per wavefront
+  static_assert(MPW1 * NPW1 == 2 && (MB2 == 8 || MB2 == 4), "tile shapes");
+  extern __shared__ __align__(16) unsigned char lds[];
+  unsigned char* const xl = lds;                     // activation tile, later the staging tile of product 2
+  unsigned char* const hl = lds + ROWS * XP;         // h, then gelu(h): the operand tile of product 2
+  const TgArgs& A = F.L;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const long long row0 = (long long)blockIdx.x * ROWS;
+
+  // ---- weight fragments of product 1, first TG_PF k-steps
+  const uint4* __restrict__ wp1 = F.W1p + (size_t)wv * 64 + lane;
+  TgFrag wr[TG_PF + 1][MPW1];
+#pragma unroll
+  for (int ks = 0; ks < TG_PF; ++ks)
+#pragma unroll
+    for (int j = 0; j < MPW1; ++j) wr[ks][j].q = wp1[((size_t)ks * MB1 + j * TG_WAVES) * 64];
+  // ---- LayerNorm operands (as tg_tile)
+  constexpr int LPR = D / 4, LRPP = 512 / LPR, LPASS = ROWS / LRPP;
+  const int lc0 = 4 * (tid % LPR), lr = tid / LPR;
+  float4 res_pf[LPASS];
+  int pos_pf[LPASS];
+#pragma unroll
+  for (int p = 0; p < LPASS; ++p) {
+    const long long row = row0 + p * LRPP + lr;
+    const long long rr = row < A.n ? row : A.n - 1;
+    res_pf[p] = *(const float4*)(A.res + rr * D + lc0);
+    pos_pf[p] = A.ypos_bf ? A.tok_pos[rr] : 0;
+  }
+  // ---- activation tile
+  {
+    constexpr int CPR = D / 8, RPP = 512 / CPR;
+    const int c = tid % CPR, r = tid / CPR;
+#pragma unroll
+    for (int p = 0; p < ROWS / RPP; ++p) {
+      const int row = p * RPP + r;
+      *(uint4*)(xl + row * XP + c * 16) = *(const uint4*)(F.X + (row0 + row) * D + c * 8);
+    }
+  }
+  __syncthreads();
+  // ---- product 1
+  f32x16 acc1[MPW1][NPW1];
+#pragma unroll
+  for (int j = 0; j < MPW1; ++j)
+#pragma unroll
+    for (int b = 0; b < NPW1; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc1[j][b][i] = 0.f;
+  {
+    const unsigned char* lb = xl + (lane & 31) * XP + (lane >> 5) * 16;
+    TgFrag sf[2][NPW1];
+#pragma unroll
+    for (int b = 0; b < NPW1; ++b) sf[0][b].q = *(const uint4*)(lb + b * 32 * XP);
+#pragma unroll
+    for (int ks = 0; ks < KS1; ++ks) {
+      if (ks + TG_PF < KS1) {
+#pragma unroll
+        for (int j = 0; j < MPW1; ++j) wr[(ks + TG_PF) % (TG_PF + 1)][j].q = wp1[((size_t)(ks + TG_PF) * MB1 + j * TG_WAVES) * 64];
+      }
+      if (ks + 1 < KS1) {
+#pragma unroll
+        for (int b = 0; b < NPW1; ++b) sf[(ks + 1) & 1][b].q = *(const uint4*)(lb + b * 32 * XP + (ks + 1) * 32);
+      }
+#pragma unroll
+      for (int j = 0; j < MPW1; ++j)
+#pragma unroll
+        for (int b = 0; b < NPW1; ++b)
+          acc1[j][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[ks % (TG_PF + 1)][j].v, sf[ks & 1][b].v, acc1[j][b], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // ---- weight fragments of product 2 (in flight behind the GELU pass)
+  const int mb2 = MB2 >= TG_WAVES ? wv : (wv >> 1), nb2 = MB2 >= TG_WAVES ? 0 : (wv & 1);
+  const uint4* __restrict__ wp2 = F.W2p + (size_t)mb2 * 64 + lane;
+  TgFrag w2[TG_PF + 1];
+#pragma unroll
+  for (int ks = 0; ks < TG_PF; ++ks) w2[ks].q = wp2[(size_t)ks * MB2 * 64];
+  // ---- h = bf16(acc + b1) -> LDS [row][channel]
+#pragma unroll
+  for (int j = 0; j < MPW1; ++j) {
+    const int cb = (wv + j * TG_WAVES) * 32 + 4 * (lane >> 5);
+#pragma unroll
+    for (int b = 0; b < NPW1; ++b) {
+      const int row = b * 32 + (lane & 31);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc1[j][b][4 * q + e];
+        if (F.b1) {
+          const uint2 bq = *(const uint2*)(F.b1 + cb + 8 * q);
+          v[0] += __uint_as_float(bq.x << 16); v[1] += __uint_as_float(bq.x & 0xFFFF0000u);
+          v[2] += __uint_as_float(bq.y << 16); v[3] += __uint_as_float(bq.y & 0xFFFF0000u);
+        }
+        uint2 o;
+        o.x = tg_pack2(v[0], v[1]);
+        o.y = tg_pack2(v[2], v[3]);
+        *(uint2*)(hl + row * HP + (cb + 8 * q) * 2) = o;
+      }
+    }
+  }
+  __syncthreads();
+  // ---- row pass: h leaves for HBM, gelu(h) replaces it in LDS
+  {
+    constexpr int CPR = FF / 8, RPP = 512 / CPR;
+    const int c = tid % CPR, r = tid / CPR;
+#pragma unroll
+    for (int p = 0; p < ROWS / RPP; ++p) {
+      const int rl = p * RPP + r;
+      const uint4 q = *(const uint4*)(hl + rl * HP + c * 16);
+      *(uint4*)(F.h + (row0 + rl) * FF + c * 8) = q;
+      float v[8];
+      tg_unpack8(q, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = tg_gelu(v[j]);
+      *(uint4*)(hl + rl * HP + c * 16) = tg_pack8(v);
+    }
+  }
+  __syncthreads();
+  // ---- product 2: operand tile = gelu(h) in LDS
+  f32x16 acc2;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc2[i] = 0.f;
+  {
+    const unsigned char* lb = hl + ((nb2 * 32) + (lane & 31)) * HP + (lane >> 5) * 16;
+    TgFrag sf[2];
+    sf[0].q = *(const uint4*)lb;
+#pragma unroll
+    for (int ks = 0; ks < KS2; ++ks) {
+      if (ks + TG_PF < KS2) w2[(ks + TG_PF) % (TG_PF + 1)].q = wp2[(size_t)(ks + TG_PF) * MB2 * 64];
+      if (ks + 1 < KS2) sf[(ks + 1) & 1].q = *(const uint4*)(lb + (ks + 1) * 32);
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2[ks % (TG_PF + 1)].v, sf[ks & 1].v, acc2, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // ---- bf16(acc + b2) -> staging tile (the activation tile's region: nobody reads it any more)
+  {
+    const int cb = mb2 * 32 + 4 * (lane >> 5), row = nb2 * 32 + (lane & 31);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = acc2[4 * q + e];
+      if (F.b2) {
+        const uint2 bq = *(const uint2*)(F.b2 + cb + 8 * q);
+        v[0] += __uint_as_float(bq.x << 16); v[1] += __uint_as_float(bq.x & 0xFFFF0000u);
+        v[2] += __uint_as_float(bq.y << 16); v[3] += __uint_as_float(bq.y & 0xFFFF0000u);
+      }
+      uint2 o;
+      o.x = tg_pack2(v[0], v[1]);
+      o.y = tg_pack2(v[2], v[3]);
+      *(uint2*)(xl + row * SP + (cb + 8 * q) * 2) = o;
+    }
+  }
+  __syncthreads();
+  // ---- residual + LayerNorm rows (the RES_LN epilogue of tg_tile)
+  {
+    const float4 g4 = *(const float4*)(A.gamma + lc0), b4 = *(const float4*)(A.beta + lc0);
+    const float g[4] = {g4.x, g4.y, g4.z, g4.w}, bt[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+    for (int p = 0; p < LPASS; ++p) {
+      const int rl = p * LRPP + lr;
+      const long long row = row0 + rl;
+      const bool live = row < A.n;
+      const long long e = (live ? row : A.n - 1) * D + lc0;
+      const float4 a4 = res_pf[p];
+      const uint2 fq = *(const uint2*)(xl + rl * SP + lc0 * 2);
+      if (A.f_out) *(uint2*)(A.f_out + (row0 + rl) * D + lc0) = fq;
+      float sv[4] = {a4.x, a4.y, a4.z, a4.w};
+      sv[0] += __uint_as_float(fq.x << 16); sv[1] += __uint_as_float(fq.x & 0xFFFF0000u);
+      sv[2] += __uint_as_float(fq.y << 16); sv[3] += __uint_as_float(fq.y & 0xFFFF0000u);
+      const float mean = tg_group_sum<LPR>((sv[0] + sv[1]) + (sv[2] + sv[3])) * (1.f / D);
+      float sq = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float dlt = sv[k] - mean;
+        sq = fmaf(dlt, dlt, sq);
+      }
+      const float rstd = rsqrtf(tg_group_sum<LPR>(sq) * (1.f / D) + A.eps);
+      if (!live) continue;
+      float o[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[k] = (sv[k] - mean) * rstd * g[k] + bt[k];
+      *(float4*)(A.y + e) = make_float4(o[0], o[1], o[2], o[3]);
+      if (A.y_bf) {
+        uint2 q;
+        q.x = tg_pack2(o[0], o[1]); q.y = tg_pack2(o[2], o[3]);
+        *(uint2*)(A.y_bf + e) = q;
+      }
+      if (A.ypos_bf) {
+        const float4 p4 = *(const float4*)(A.pos_table + (long long)pos_pf[p] * D + lc0);
+        uint2 q;
+        q.x = tg_pack2(o[0] + p4.x, o[1] + p4.y); q.y = tg_pack2(o[2] + p4.z, o[3] + p4.w);
+        *(uint2*)(A.ypos_bf + e) = q;
+      }
+      if (lc0 == 0) *(float2*)(A.stats + row * 2) = make_float2(mean, rstd);
+    }
+  }
+}
+
+template <int D>
+static int tg_launch_ffn(const TgFfnArgs& F, long long n_pad, hipStream_t st) {
+  constexpr int ROWS = D >= 256 ? 32 : 64;
+  constexpr int lds = ROWS * (D * 2 + 16) + ROWS * (4 * D + 16);
+  static bool once = false;
+  if (!once) {
+    GD_CHECK(hipFuncSetAttribute((const void*)k_tok_ffn<D>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    once = true;
+  }
+  hipLaunchKernelGGL((k_tok_ffn<D>), dim3((unsigned)(n_pad / ROWS)), dim3(512), lds, st, F);
+  GD_LAUNCH_CHECK();
+  return 0;
+}
+
 // internal front end (encoder_layer.hip)
 bool gd_tok_gemm_supported(int K, int N) {
   return (K == 128 && (N == 128 || N == 256)) || (K == 256 && (N == 128 || N == 256 || N == 512)) || (K == 512 && N == 256);
@@ -560,11 +803,11 @@ int gd_tok_gemm_gelu(hipStream_t st, const void* X, const void* Wp, const void* 
   GdTimed timed(GD_T_TOK_GEMM, st, 2.0 * n_pad * (K + 2 * N) + 2.0 * K * N, 2.0 * n_pad * K * N);
   return tg_dispatch<TG_GELU>(K, N, A, st);
 }
-int gd_tok_gemm_gelu_bwd(hipStream_t st, const void* dY, const void* Wp, const void* h, long long n_pad, int K, int N, void* dh) {
+int gd_tok_gemm_gelu_bwd(hipStream_t st, const void* dY, const void* Wp, const void* h, long long n_pad, int K, int N, void* dh, void* gact) {
   TgArgs A = {};
   A.X = (const unsigned short*)dY; A.Wp = (const uint4*)Wp; A.n = n_pad; A.n_pad = n_pad;
-  A.out0 = (unsigned short*)dh; A.aux = (const unsigned short*)h;
-  GdTimed timed(GD_T_TOK_GEMM, st, 2.0 * n_pad * (K + 2 * N) + 2.0 * K * N, 2.0 * n_pad * K * N);
+  A.out0 = (unsigned short*)dh; A.aux = (const unsigned short*)h; A.out1 = (unsigned short*)gact;
+  GdTimed timed(GD_T_TOK_GEMM, st, 2.0 * n_pad * (K + (gact ? 3 : 2) * N) + 2.0 * K * N, 2.0 * n_pad * K * N);
   return tg_dispatch<TG_GELU_BWD>(K, N, A, st);
 }
 int gd_tok_gemm_res_ln(hipStream_t st, const void* X, const void* Wp, const void* bias, long long n, long long n_pad, int K, int N,
@@ -581,6 +824,30 @@ int gd_tok_gemm_res_ln(hipStream_t st, const void* X, const void* Wp, const void
                     (ypos_bf ? 4.0 * n : 0.0) + 2.0 * K * N,
                 2.0 * n_pad * K * N);
   return tg_dispatch<TG_RES_LN>(K, N, A, st);
+}
+
+// y = LayerNorm(res + bf16(gelu(bf16(X W1^T + b1)) W2^T + b2)) with every output of gd_tok_gemm_res_ln; h (n_pad, 2 d) bf16 is the
+// only trace of the hidden activation in HBM (gd_tok_gemm_gelu_bwd re-creates gelu(h) for the weight gradient)
+bool gd_tok_gemm_ffn_supported(int d, int ff) { return (d == 128 || d == 256) && ff == 2 * d; }
+int gd_tok_gemm_ffn(hipStream_t st, const void* X, const void* W1p, const void* b1, const void* W2p, const void* b2, long long n,
+                    long long n_pad, int d, void* h, const float* res, const float* gamma, const float* beta, float eps, float* y,
+                    float* stats, void* y_bf, const float* pos_table, const int* tok_pos, void* ypos_bf, void* f_out) {
+  TgFfnArgs F = {};
+  F.X = (const unsigned short*)X; F.W1p = (const uint4*)W1p; F.b1 = (const unsigned short*)b1; F.W2p = (const uint4*)W2p;
+  F.b2 = (const unsigned short*)b2; F.h = (unsigned short*)h;
+  TgArgs& A = F.L;
+  A.n = n; A.n_pad = n_pad; A.res = res; A.gamma = gamma; A.beta = beta; A.eps = eps; A.y = y; A.stats = stats;
+  A.y_bf = (unsigned short*)y_bf; A.pos_table = pos_table; A.tok_pos = tok_pos; A.ypos_bf = (unsigned short*)ypos_bf;
+  A.f_out = (unsigned short*)f_out;
+  const int ff = 2 * d;
+  // operand + residual in, h + LayerNorm rows (+ copies) out, both weight images
+  GdTimed timed(GD_T_TOK_GEMM, st,
+                2.0 * n_pad * d + 2.0 * n_pad * ff + (double)n * d * (4 + 4 + (y_bf ? 2 : 0) + (ypos_bf ? 2 : 0) + (f_out ? 2 : 0)) + 8.0 * n +
+                    (ypos_bf ? 4.0 * n : 0.0) + 4.0 * d * ff,
+                4.0 * n_pad * d * ff);
+  if (d == 128) return tg_launch_ffn<128>(F, n_pad, st);
+  if (d == 256) return tg_launch_ffn<256>(F, n_pad, st);
+  GD_REQUIRE(false, "tok_gemm_ffn: d must be 128 or 256");
 }
 
 // dx (n, N) fp32 [+ dx_bf (n_pad, N) bf16] = LayerNorm backward of  g = dy + [dy2] + bf16(X Wp^T)  through LN(ln_a + ln_b) with the saved
@@ -607,6 +874,14 @@ extern "C" int gdmae_tok_gemm_qkv(const void* Xpos, const void* X, const void* W
   GD_REQUIRE(d == 128 || d == 256, "tok_gemm_qkv: d must be 128 or 256");
   return gd_tok_gemm_qkv((hipStream_t)stream, Xpos, X, Wp_qk, Wp_v, bias3, n_pad, d, qk, v);
 }
+extern "C" int gdmae_tok_gemm_ffn(const void* X, const void* W1p, const void* b1, const void* W2p, const void* b2, long long n, long long n_pad,
+                                  int d, void* h, const float* res, const float* gamma, const float* beta, float eps, float* y, float* stats,
+                                  void* y_bf16, const float* pos_table, const int* tok_pos, void* ypos_bf16, void* f_out, void* stream) {
+  GD_REQUIRE(n_pad > 0 && n_pad % TG_ROWS == 0 && n <= n_pad && n >= 1, "tok_gemm: rows must be padded to a multiple of 64");
+  GD_REQUIRE(d == 128 || d == 256, "tok_gemm_ffn: d must be 128 or 256");
+  return gd_tok_gemm_ffn((hipStream_t)stream, X, W1p, b1, W2p, b2, n, n_pad, d, h, res, gamma, beta, eps, y, stats, y_bf16, pos_table, tok_pos,
+                         ypos_bf16, f_out);
+}
 extern "C" int gdmae_tok_gemm_ln_bwd_rows(int N) { return gd_tok_gemm_rows(N); }
 extern "C" int gdmae_tok_gemm_ln_bwd(const void* X, const void* Wp, long long n, long long n_pad, int K, int N, const float* dy,
                                      const void* dy2_bf16, const float* ln_a, const void* ln_b_bf16, const float* stats,
@@ -618,7 +893,8 @@ extern "C" int gdmae_tok_gemm_ln_bwd(const void* X, const void* Wp, long long n,
 
 // ------------------------------------------------------------------------------------------------
 // C ABI (tests and stand-alone use): Y = epilogue(X Wp^T + bias), see the table at the top.  epilogue: 0 plain, 1 GELU
-// (out0 = h, out1 = gelu(h)), 2 GELU backward (aux = h), 3 residual + LayerNorm (out0 optional: the rounded product).
+// (out0 = h, out1 = gelu(h)), 2 GELU backward (aux = h; out1 optional: gelu(h)), 3 residual + LayerNorm (out0 optional: the
+// rounded product).
 // ------------------------------------------------------------------------------------------------
 extern "C" int gdmae_tok_gemm(const void* X, const void* Wp, const void* bias, long long n, long long n_pad, int K, int N,
                               int epilogue, void* out0, void* out1, const void* aux, const float* res, const float* gamma,
@@ -630,7 +906,7 @@ extern "C" int gdmae_tok_gemm(const void* X, const void* Wp, const void* bias, l
   switch (epilogue) {
     case TG_PLAIN: return gd_tok_gemm_plain(st, X, Wp, bias, n_pad, K, N, out0);
     case TG_GELU: return gd_tok_gemm_gelu(st, X, Wp, bias, n_pad, K, N, out0, out1);
-    case TG_GELU_BWD: return gd_tok_gemm_gelu_bwd(st, X, Wp, aux, n_pad, K, N, out0);
+    case TG_GELU_BWD: return gd_tok_gemm_gelu_bwd(st, X, Wp, aux, n_pad, K, N, out0, out1);
     case TG_RES_LN:
       return gd_tok_gemm_res_ln(st, X, Wp, bias, n, n_pad, K, N, res, gamma, beta, eps, y, stats, y_bf16, pos_table, tok_pos, ypos_bf16,
                                 out0);

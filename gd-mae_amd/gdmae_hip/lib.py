@@ -120,6 +120,7 @@ SIGNATURES = {
     "gdmae_tok_gemm_pack": (_I, [_P, _I, _P]),
     "gdmae_tok_gemm": (_I, [_P, _P, _P, _L, _L, _I, _I, _I, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P]),
     "gdmae_tok_gemm_qkv": (_I, [_P, _P, _P, _P, _P, _L, _I, _P, _P, _P]),
+    "gdmae_tok_gemm_ffn": (_I, [_P, _P, _P, _P, _P, _L, _L, _I, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gdmae_tok_gemm_ln_bwd_rows": (_I, [_I]),
     "gdmae_tok_gemm_ln_bwd": (_I, [_P, _P, _L, _L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gdmae_encoder_layer_fwd": (_I, [_P, _P]),

@@ -507,7 +507,7 @@ int gdmae_layer_pack_jobs(const float* Win, const float* Wo, const float* W1, co
 int gdmae_tok_gemm_pack(const long long* jobs_dev, int n_jobs, void* stream);
 /* Y = epilogue(X Wp^T + bias): X (n_pad, K) bf16 rows (n_pad % 64 == 0), Wp = packed (N, K) weights, bias (N) bf16 or
  * NULL; (K, N) in {128, 256} x {128, 256}, (256, 512), (512, 256).  epilogue 0: out0 = . (bf16); 1: out0 = h = . and
- * out1 = gelu_erf(h); 2: out0 = . * gelu'(aux) (aux = h); 3: y = LayerNorm(res + bf16(.)) fp32 (first n rows), stats
+ * out1 = gelu_erf(h); 2: out0 = . * gelu'(aux) (aux = h), and out1 = gelu_erf(aux) when out1 is given; 3: y = LayerNorm(res + bf16(.)) fp32 (first n rows), stats
  * (n, 2) = mean | rstd, optional bf16 copies y_bf16 = y and ypos_bf16 = y + pos_table[tok_pos[row]]. */
 int gdmae_tok_gemm(const void* X, const void* Wp, const void* bias, long long n, long long n_pad, int K, int N, int epilogue,
                    void* out0, void* out1, const void* aux, const float* res, const float* gamma, const float* beta, float eps,
@@ -520,6 +520,15 @@ int gdmae_tok_gemm(const void* X, const void* Wp, const void* bias, long long n,
  * or NULL, d in {128, 256}.  Bit-identical to two gdmae_tok_gemm calls with epilogue 0. */
 int gdmae_tok_gemm_qkv(const void* Xpos, const void* X, const void* Wp_qk, const void* Wp_v, const void* bias3, long long n_pad,
                        int d, void* qk, void* v, void* stream);
+
+/* The feed-forward block of a layer as ONE launch (tok_gemm.hip k_tok_ffn; sst_basic_block.py:79-84 linear1 -> GELU -> linear2 ->
+ * residual + LayerNorm 2):  h (n_pad, 2 d) bf16 = X W1^T + b1 is stored (the backward differentiates the GELU at it), gelu(h)
+ * stays in LDS as the operand tile of the second product (gdmae_tok_gemm epilogue 2 re-creates it through out1 for the weight
+ * gradient), then every output of epilogue 3: y, stats, y_bf16 / ypos_bf16 / f_out (optional).  W1p = packed (2 d, d) image,
+ * W2p = packed (d, 2 d) image, d in {128, 256}.  Bit-identical to epilogue 1 followed by epilogue 3. */
+int gdmae_tok_gemm_ffn(const void* X, const void* W1p, const void* b1, const void* W2p, const void* b2, long long n, long long n_pad,
+                       int d, void* h, const float* res, const float* gamma, const float* beta, float eps, float* y, float* stats,
+                       void* y_bf16, const float* pos_table, const int* tok_pos, void* ypos_bf16, void* f_out, void* stream);
 
 /* Input-gradient token GEMM fused with the backward of the post-norm it feeds (tok_gemm.hip, epilogue LN_BWD; backward of
  * sst_basic_block.py:57-84 `src = norm(src + dropout(src2))`):  g = dy + [dy2] + bf16(X Wp^T) is the gradient of

@@ -1255,6 +1255,60 @@ def test_tok_gemm_epilogues_match_torch(K, N):
             assert float((ps - sums.double()).abs().max()) <= 1e-5 * float(sums.abs().max()) + 1e-5
 
 
+@pytest.mark.parametrize("d", [128, 256])
+def test_one_launch_ffn_equals_two_token_gemms(d):
+    """gdmae_tok_gemm_ffn (linear1 + GELU + linear2 + residual + LayerNorm 2 in one launch, gelu(h) in LDS only) against the two
+    launches it replaces (gdmae_tok_gemm epilogue 1, then epilogue 3): every output bit for bit, ragged row count, with and
+    without the optional copies; the GELU-backward epilogue re-creates gelu(h) bit for bit."""
+    from gdmae_hip import lib as L
+    g = torch.Generator().manual_seed(d)
+    ff, n, n_pad = 2 * d, 1237, 1280
+    d_ = dev()
+
+    def pack(w):
+        M, K = w.shape
+        dst = torch.empty(M * K, dtype=torch.bfloat16, device=d_)
+        jobs = torch.tensor([w.data_ptr(), dst.data_ptr(), M, K, K, 0], dtype=torch.int64).to(d_)
+        L.call("gdmae_tok_gemm_pack", L.ptr(jobs), 1, L.stream())
+        return dst
+
+    X = torch.randn(n_pad, d, generator=g).bfloat16().to(d_)
+    W1, W2 = (torch.randn(ff, d, generator=g) / d ** 0.5).to(d_), (torch.randn(d, ff, generator=g) / ff ** 0.5).to(d_)
+    W1p, W2p = pack(W1), pack(W2)
+    b1, b2 = torch.randn(ff, generator=g).bfloat16().to(d_), torch.randn(d, generator=g).bfloat16().to(d_)
+    res = torch.randn(n, d, generator=g).to(d_)
+    gamma, beta = (torch.rand(d, generator=g) + 0.5).to(d_), torch.randn(d, generator=g).to(d_)
+    pos = torch.randn(64, d, generator=g).to(d_)
+    tp = torch.randint(0, 64, (n,), generator=g).int().to(d_)
+
+    def outs():
+        return dict(y=torch.zeros(n, d, device=d_), st=torch.zeros(n, 2, device=d_), ybf=torch.zeros(n_pad, d, dtype=torch.bfloat16, device=d_),
+                    ypos=torch.zeros(n_pad, d, dtype=torch.bfloat16, device=d_), f=torch.zeros(n_pad, d, dtype=torch.bfloat16, device=d_),
+                    h=torch.zeros(n_pad, ff, dtype=torch.bfloat16, device=d_))
+    for full in (True, False):
+        a, b = outs(), outs()
+        gact = torch.empty(n_pad, ff, dtype=torch.bfloat16, device=d_)
+        L.call("gdmae_tok_gemm", L.ptr(X), L.ptr(W1p), L.ptr(b1), n_pad, n_pad, d, ff, 1, L.ptr(a["h"]), L.ptr(gact), None, None, None, None,
+               1e-5, None, None, None, None, None, None, L.stream())
+        L.call("gdmae_tok_gemm", L.ptr(gact), L.ptr(W2p), L.ptr(b2), n, n_pad, ff, d, 3, L.ptr(a["f"]), None, None, L.ptr(res), L.ptr(gamma),
+               L.ptr(beta), 1e-5, L.ptr(a["y"]), L.ptr(a["st"]), L.ptr(a["ybf"]) if full else None, L.ptr(pos) if full else None,
+               L.ptr(tp) if full else None, L.ptr(a["ypos"]) if full else None, L.stream())
+        L.call("gdmae_tok_gemm_ffn", L.ptr(X), L.ptr(W1p), L.ptr(b1), L.ptr(W2p), L.ptr(b2), n, n_pad, d, L.ptr(b["h"]), L.ptr(res), L.ptr(gamma),
+               L.ptr(beta), 1e-5, L.ptr(b["y"]), L.ptr(b["st"]), L.ptr(b["ybf"]) if full else None, L.ptr(pos) if full else None,
+               L.ptr(tp) if full else None, L.ptr(b["ypos"]) if full else None, L.ptr(b["f"]), L.stream())
+        for k in a:
+            assert torch.equal(a[k], b[k]), (k, full)
+        assert float(a["y"].abs().max()) > 0.5
+        # backward side: dh and gelu(h) from the GELU-backward epilogue
+        dY = torch.randn(n_pad, d, generator=g).bfloat16().to(d_)
+        W2t = pack(W2.t().contiguous())
+        dh0, dh1, g1 = (torch.empty(n_pad, ff, dtype=torch.bfloat16, device=d_) for _ in range(3))
+        for o1, dh in ((None, dh0), (g1, dh1)):
+            L.call("gdmae_tok_gemm", L.ptr(dY), L.ptr(W2t), None, n_pad, n_pad, d, ff, 2, L.ptr(dh), L.ptr(o1), L.ptr(b["h"]), None, None, None,
+                   1e-5, None, None, None, None, None, None, L.stream())
+        assert torch.equal(dh0, dh1) and torch.equal(g1, gact)
+
+
 @pytest.mark.parametrize("cin,cout,src_f32", [(128, 128, False), (128, 256, True), (256, 128, False), (256, 256, True), (256, 256, False)])
 def test_spconv_implicit_gemm_matches_gathered_product(cin, cout, src_f32):
     """gdmae_spconv (implicit GEMM over a rulebook, packed per-tap weight images) against the explicit formulation it replaces:
