@@ -365,12 +365,18 @@ def main():
     torch.cuda.set_device(local)
     torch.backends.cudnn.benchmark = bool(args.miopen_find)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # GDMAE_BENCH_FORCE_DIST=1: rehearsal of the N > 1 code path on ONE GPU over RCCL (a one-rank nccl group; the gradient
+    # exchange is forced on - sum over one rank = identity): every collective, stream hand-over and barrier of the multi-GPU
+    # run executes against the real library.  The printed line is the N = 1 line plus "grad_sync".
+    force_dist = world == 1 and os.environ.get("GDMAE_BENCH_FORCE_DIST", "0") == "1"
+    distd = world > 1 or force_dist
+    if distd:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         # nccl == RCCL on ROCm; GDMAE_DIST_BACKEND=gloo only for the control-flow smoke run of two ranks on one GPU
         dist.init_process_group(os.environ.get("GDMAE_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
-    if world > 1:
+    if distd:
         # create the communicator HERE, on the main thread and the current stream: the bucketed gradient exchange issues its
         # first collectives from tensor hooks inside backward() (autograd thread, communication stream)
         warm = torch.ones(1, device=dev)
@@ -390,12 +396,14 @@ def main():
     args.pool = max(1, min(args.pool, args.warmup))
     total_steps = args.warmup + args.steps + 1
     wl = Workload(args, args.config, B, dev, rank, world, args.mask_ratio, total_steps, args.pool)
+    if force_dist:
+        wl.opt.sync.force = True
     n_params = wl.opt.n
     use_bf16 = wl.mode["bf16"]
 
     def sync_all():
         torch.cuda.synchronize()
-        if world > 1:
+        if distd:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -408,7 +416,7 @@ def main():
     sync_all()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
+    if distd:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     frames = B * world * args.steps
@@ -506,7 +514,7 @@ def main():
             out["step_bytes_model"] = {"bytes_train_per_frame": int(bytes_train), "achieved_GBs": round(bytes_train * fps / world / 1e9, 1),
                                        "frac_of_8TBs": round(bytes_train * fps / world / 1e9 / HBM_PEAK_GBS, 4),
                                        "note": "SURVEY 8d whole-step algorithmic bytes (dense-decoder formula) x frames/s per GPU"}
-        if world > 1:
+        if distd:
             opt = wl.opt
             out["grad_sync"] = {"buckets": [[b, hi - lo] for b, lo, hi in opt.buckets], "last_step": opt.sync.log,
                                 "note": "one all-reduce per bucket; 'overlapped' = launched on the communication stream from inside "
@@ -521,7 +529,7 @@ def main():
         if not args.no_cpu_baseline and world == 1 and pre:      # reported at N = 1 only (rank 0's host cores)
             out["cpu_baseline"] = measure_cpu_baseline(args.config, args.mask_ratio)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if distd:
         dist.barrier()
         dist.destroy_process_group()
 

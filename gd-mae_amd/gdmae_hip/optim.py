@@ -290,9 +290,13 @@ class GradSync:
         import os
         self.mode = os.environ.get("GDMAE_SYNC_MODE", "overlap")
         self._snap = {}
+        # force: run the exchange even in a one-rank group (the sum over one rank is the identity): how the RCCL call pattern -
+        # collectives issued from tensor hooks on the autograd thread, on the communication stream - is exercised on a box
+        # with a single GPU (RCCL refuses two ranks per device)
+        self.force = os.environ.get("GDMAE_SYNC_FORCE", "0") == "1"
 
     def _active(self):
-        return self.mode != "off" and self.opt.world_size() > 1
+        return self.mode != "off" and (self.opt.world_size() > 1 or (self.force and dist.is_initialized()))
 
     def begin_step(self):
         assert self.mode in ("overlap", "tail", "check", "off"), self.mode

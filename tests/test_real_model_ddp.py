@@ -144,6 +144,68 @@ def test_overlapped_bucketed_allreduce_on_the_real_model_two_ranks(config, B):
         assert ok["log_off"] == []
 
 
+def _rccl_worker(port, q):
+    _guard(_rccl_worker_body)(port, q)
+
+
+def _rccl_worker_body(port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)          # nccl == RCCL on ROCm
+    warm = torch.ones(1, device="cuda:0")
+    dist.all_reduce(warm)                                             # communicator created on the main thread, as bench.py does
+    from gdmae_hip import configs, optim
+    cfg, ds, net, pts = _build("A", 2, 0)
+    opt = optim.FlatAdamOneCycle(net, configs.optimization_cfg(2), total_steps=10)
+    opt.sync.force = True
+    grads, logs = {}, {}
+    for mode in ("off", "overlap", "tail", "check", "overlap"):
+        opt.sync.mode = mode
+        opt.zero_grad()
+        torch.manual_seed(99)
+        bd = {"points": pts, "batch_size": 2, "_gdmae_grad_sync": opt.sync}
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            ret, _, _ = net(bd)
+        ret["loss"].backward()
+        opt.all_reduce_grads()
+        torch.cuda.synchronize()
+        grads[mode] = opt.flat_grad.detach().clone()
+        logs[mode] = list(opt.sync.log)
+    opt.step(0)
+    # the bench's timing protocol over RCCL: barrier + MAX all-reduce of the elapsed time
+    dist.barrier()
+    t = torch.tensor([1.25], device="cuda:0")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    torch.cuda.synchronize()
+    q.put({"eq_overlap": bool(torch.equal(grads["overlap"], grads["off"])), "eq_tail": bool(torch.equal(grads["tail"], grads["off"])),
+           "eq_check": bool(torch.equal(grads["check"], grads["off"])), "log_overlap": logs["overlap"], "log_tail": logs["tail"],
+           "buckets": [b for b, _, _ in opt.buckets], "tmax": float(t.item()), "scale": opt._grad_scale,
+           "nonzero": float((grads["off"] != 0).float().mean())})
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_bucketed_exchange_over_rccl_one_rank():
+    """The RCCL call pattern of the overlapped exchange on real hardware: a one-rank nccl group (RCCL refuses two ranks on one
+    device), GradSync forced on - collectives issued from the tensor hooks on the autograd thread and the communication stream,
+    work.wait() ordering, barrier + MAX reduce of bench.py.  The sum over one rank is the identity: every mode must return the
+    local gradient bit for bit, with the overlapped launch order of the two-rank gloo test."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+    p.start()
+    out = q.get(timeout=900)
+    p.join(timeout=120)
+    assert not (isinstance(out, tuple) and out[0] == "error"), out[1]
+    assert p.exitcode == 0
+    assert out["eq_overlap"] and out["eq_tail"] and out["eq_check"] and out["nonzero"] > 0.9, out
+    names = out["buckets"]
+    want = [[names[-1], "overlapped"]] + [[b, "overlapped"] for b in reversed(names[1:-1])] + [["vfe", "tail"]]
+    assert [list(x) for x in out["log_overlap"]] == want, out["log_overlap"]
+    assert all(h == "tail" for _, h in out["log_tail"]) and len(out["log_tail"]) == len(names)
+    assert out["tmax"] == 1.25
+
+
 def _ddp_worker(port, q):
     _guard(_ddp_worker_body)(port, q)
 
