@@ -141,7 +141,7 @@ def _pmc_traffic(kernels):
 # events on the launch stream ON THE PRODUCT PATH: the encoder families by brackets inside the native layer / stage executors
 # (include/gdmae_hip.h gdmae_kernel_timing), the decoder kernels by brackets around their single C-ABI call (gdmae_hip.timing)
 ROOFLINE_KERNELS = {
-    "k_tok_gemm": ("hbm", ("k_tok_gemm", "k_tok_gemm_multi", "k_ffn_fwd", "k_ffn_bwd")),
+    "k_tok_gemm": ("hbm", ("k_tok_gemm", "k_tok_gemm_multi", "k_tok_ffn")),
     "k_dw_grouped": ("hbm", ("k_dw_grouped",)),
     "k_layer_tail": ("hbm", ("k_layer_tail",)),
     "k_conv3x3_tiles": ("mfma", ("k_conv3x3_tiles",)),
