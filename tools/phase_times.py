@@ -7,13 +7,14 @@ import torch
 from gdmae_hip import configs, optim, synth
 from pcdet.models import build_network
 dev = torch.device("cuda:0")
+NB = int(sys.argv[sys.argv.index("--frames") + 1]) if "--frames" in sys.argv else 8     # frames per step (4 = config C's share per GPU)
 cfg, ds, skw = configs.named_config("B", mask_ratio=0.75)
 torch.manual_seed(1234)
 net = build_network(cfg, 3, ds, logging.getLogger("p")).to(dev).train()
 net.sync_loss_scalar = False
 net.backbone_3d.dense_spatial_features = False
-opt = optim.FlatAdamOneCycle(net, configs.optimization_cfg(8), total_steps=200)
-batches = [torch.from_numpy(synth.synth_batch(5 + i, 8, ds.point_cloud_range, **skw)).to(dev) for i in range(4)]
+opt = optim.FlatAdamOneCycle(net, configs.optimization_cfg(NB), total_steps=200)
+batches = [torch.from_numpy(synth.synth_batch(5 + i, NB, ds.point_cloud_range, **skw)).to(dev) for i in range(4)]
 resident = torch.cuda.Event(); resident.record()
 pend = {}
 marks = []
@@ -27,17 +28,17 @@ VOXONLY = "--vox-only" in sys.argv
 ENCONLY = "--enc-only" in sys.argv
 if ENCONLY:
     from gdmae_hip import plan as _p0
-    VRAW = [_p0._voxelize_launch(b, net.backbone_3d.point_cloud_range, net.backbone_3d.voxel_size, net.backbone_3d.grid_size, 8) for b in batches]
+    VRAW = [_p0._voxelize_launch(b, net.backbone_3d.point_cloud_range, net.backbone_3d.voxel_size, net.backbone_3d.grid_size, NB) for b in batches]
     torch.cuda.synchronize()
 DUMMY = int(sys.argv[sys.argv.index("--dummy") + 1]) if "--dummy" in sys.argv else 0
 SIDE = torch.cuda.Stream()
 TINY = torch.zeros(64, device=dev)
 REUSE = "--reuse-plans" in sys.argv      # geometry plans of the 4 pooled batches built once: the step without its plan kernels
-PLANS = [net.backbone_3d.prefetch_plan(b, 8).finish() for b in batches] if REUSE else None
+PLANS = [net.backbone_3d.prefetch_plan(b, NB).finish() for b in batches] if REUSE else None
 PREBUILT = "--prebuilt" in sys.argv       # one never-consumed plan per step, all built before the loop (no plan kernels inside the steps)
 if PREBUILT:
     REUSE = True
-    PLANS = [net.backbone_3d.prefetch_plan(batches[i % 4], 8).finish() for i in range(64)]
+    PLANS = [net.backbone_3d.prefetch_plan(batches[i % 4], NB).finish() for i in range(64)]
     torch.cuda.synchronize()
 def ev():
     e = torch.cuda.Event(enable_timing=True); e.record(); return e
@@ -50,8 +51,8 @@ def step(i, rec):
     if REUSE:
         pf = PLANS[i % len(PLANS)]
     else:
-        pf = pend.pop(i, None) or net.backbone_3d.prefetch_plan(pts, 8)
-    bd = {"points": pts, "batch_size": 8, "_gdmae_grad_sync": opt.sync}
+        pf = pend.pop(i, None) or net.backbone_3d.prefetch_plan(pts, NB)
+    bd = {"points": pts, "batch_size": NB, "_gdmae_grad_sync": opt.sync}
     bd["_gdmae_vox"], bd["_gdmae_plan"] = pf.finish() if hasattr(pf, "finish") else pf
     hp0 = time.perf_counter()
     pfn = None if REUSE else net.backbone_3d.prefetch_plan(nxt, 8, ready=resident)
@@ -70,7 +71,7 @@ def step(i, rec):
     if VOXONLY:                                  # only the voxelization kernels of the next batch on the side stream (result dropped)
         from gdmae_hip import plan as _p
         with torch.cuda.stream(SIDE):
-            _p._voxelize_launch(nxt, net.backbone_3d.point_cloud_range, net.backbone_3d.voxel_size, net.backbone_3d.grid_size, 8)
+            _p._voxelize_launch(nxt, net.backbone_3d.point_cloud_range, net.backbone_3d.voxel_size, net.backbone_3d.grid_size, NB)
     if ENCONLY:                                  # only the encoder-plan kernels (masking, token sets, rulebooks, windows, tiles)
         from gdmae_hip import plan as _p
         from pcdet.models.backbones_3d.spt_backbone import stage_plan_args
