@@ -12,6 +12,8 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.abspath(os.path.join(_HERE, "..", "csrc", "libgdmae_hip.so"))
+if os.environ.get("GDMAE_LIB"):          # kernel experiments: a variant library built next to the product one (tools/build_variant.sh)
+    LIB_PATH = os.path.abspath(os.environ["GDMAE_LIB"])
 
 
 class GdmaeHipError(RuntimeError):
