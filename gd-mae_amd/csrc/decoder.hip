@@ -65,7 +65,8 @@ template <bool PBF, bool ZBF>
 __global__ __launch_bounds__(256) void k_rows_affine_relu_scatter_v8(const void* __restrict__ P, const int* __restrict__ site,
                                                                      long long n, int C, const float* __restrict__ a,
                                                                      const float* __restrict__ b, void* __restrict__ Z,
-                                                                     int zrow, int col0, const void* __restrict__ sub) {
+                                                                     int zrow, int col0, const void* __restrict__ sub,
+                                                                     const void* __restrict__ add) {
   const int cv = C >> 3;
   const long long total = n * cv;
   for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
@@ -85,6 +86,12 @@ __global__ __launch_bounds__(256) void k_rows_affine_relu_scatter_v8(const void*
       dec_ld8<ZBF>(sub, c, sv);
 #pragma unroll
       for (int j = 0; j < 8; ++j) o[j] = (ZBF ? dec_bf2f(dec_f2bf(o[j])) : o[j]) - sv[j];
+    }
+    if (add) {      // Z = round(round(relu) + add[r]): identity shortcut of a dense block (rows of Z's dtype), rounded like y + x
+      float rv[8];
+      dec_ld8<ZBF>(add, r * C + c, rv);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (ZBF ? dec_bf2f(dec_f2bf(o[j])) : o[j]) + rv[j];
     }
     dec_st8<ZBF>(Z, (site ? (long long)site[r] : r) * zrow + col0 + c, o);
   }
@@ -276,7 +283,7 @@ extern "C" int gdmae_fill_rows(const void* v, long long R, int C, int elem_bytes
 }
 
 static int rows_affine_relu_scatter(const void* P, int p_bf16, const int* site, long long n, int C, const float* a, const float* b, void* Z,
-                                    int z_bf16, int z_row_elems, int col0, const void* sub, void* stream);
+                                    int z_bf16, int z_row_elems, int col0, const void* sub, void* stream, const void* add = nullptr);
 extern "C" int gdmae_rows_affine_relu_scatter(const void* P, int p_bf16, const int* site, long long n, int C, const float* a,
                                               const float* b, void* Z, int z_bf16, int z_row_elems, int col0, void* stream) {
   return rows_affine_relu_scatter(P, p_bf16, site, n, C, a, b, Z, z_bf16, z_row_elems, col0, nullptr, stream);
@@ -288,7 +295,7 @@ extern "C" int gdmae_rows_affine_relu_sub(const void* P, int p_bf16, const int* 
   return rows_affine_relu_scatter(P, p_bf16, site, n, C, a, b, Z, z_bf16, z_row_elems, col0, sub, stream);
 }
 static int rows_affine_relu_scatter(const void* P, int p_bf16, const int* site, long long n, int C, const float* a, const float* b, void* Z,
-                                    int z_bf16, int z_row_elems, int col0, const void* sub, void* stream) {
+                                    int z_bf16, int z_row_elems, int col0, const void* sub, void* stream, const void* add) {
   if (n <= 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid(dec_grid(n * C)), block(256);
@@ -296,7 +303,7 @@ static int rows_affine_relu_scatter(const void* P, int p_bf16, const int* site, 
   const dim3 grid8(dec_grid(n * C / 8));
 #define GD_LAUNCH(PB, ZB)                                                                                                         \
   do {                                                                                                                            \
-    if (v8) hipLaunchKernelGGL((k_rows_affine_relu_scatter_v8<PB, ZB>), grid8, block, 0, st, P, site, n, C, a, b, Z, z_row_elems, col0, sub); \
+    if (v8) hipLaunchKernelGGL((k_rows_affine_relu_scatter_v8<PB, ZB>), grid8, block, 0, st, P, site, n, C, a, b, Z, z_row_elems, col0, sub, add); \
     else hipLaunchKernelGGL((k_rows_affine_relu_scatter<PB, ZB>), grid, block, 0, st, P, site, n, C, a, b, Z, z_row_elems, col0);  \
   } while (0)
   if (p_bf16) { if (z_bf16) GD_LAUNCH(true, true); else GD_LAUNCH(true, false); }
@@ -304,6 +311,13 @@ static int rows_affine_relu_scatter(const void* P, int p_bf16, const int* site, 
 #undef GD_LAUNCH
   GD_LAUNCH_CHECK();
   return 0;
+}
+// Z[r] = relu(a P[r] + b) + R[r]  (R, Z (n, C) rows of the same dtype; C % 8 == 0): BatchNorm + ReLU + identity shortcut of a dense
+// Conv-BN-ReLU block (sst_bev_backbone.py:36-40), rounded like the two-step sequence
+extern "C" int gdmae_rows_affine_relu_add(const void* P, int p_bf16, long long n, int C, const float* a, const float* b, const void* R,
+                                          void* Z, int z_bf16, void* stream) {
+  GD_REQUIRE(R != nullptr && C % 8 == 0, "rows_affine_relu_add: 8-channel granularity");
+  return rows_affine_relu_scatter(P, p_bf16, nullptr, n, C, a, b, Z, z_bf16, C, 0, nullptr, stream, R);
 }
 
 extern "C" size_t gdmae_rows_bwd_stats_workspace_bytes(int C) { return (size_t)512 * 3 * C * sizeof(float); }

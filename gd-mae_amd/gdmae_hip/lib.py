@@ -57,6 +57,7 @@ SIGNATURES = {
     "gdmae_colstats": (_I, [_P, _L, _I, _I, _P, _P, _P]),
     "gdmae_rows_affine_relu_scatter": (_I, [_P, _I, _P, _L, _I, _P, _P, _P, _I, _I, _I, _P]),
     "gdmae_rows_affine_relu_sub": (_I, [_P, _I, _P, _L, _I, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "gdmae_rows_affine_relu_add": (_I, [_P, _I, _L, _I, _P, _P, _P, _P, _I, _P]),
     "gdmae_rows_bwd_stats_workspace_bytes": (_Z, [_I]),
     "gdmae_rows_bwd_stats": (_I, [_P, _I, _P, _L, _I, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
     "gdmae_bn_fold": (_I, [_P, _L, _I, _I, _D, _P, _P, _D, _D, _P, _P, _P, _P, _P, _P, _P, _P]),

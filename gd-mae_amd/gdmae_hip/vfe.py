@@ -23,17 +23,24 @@ def _bf(t):
 
 
 class BNReLURows(torch.autograd.Function):
-    """relu(BatchNorm1d_train(x)) for x (N, C) fp32/bf16; returns (out [x.dtype], mean, biased var).
-    ``bn``: the nn.BatchNorm1d module (running statistics updated in the statistics launch) or None."""
+    """relu(BatchNorm1d_train(x)) [+ residual] for x (N, C) fp32/bf16; returns (out [x.dtype], mean, biased var).
+    ``bn``: the nn.BatchNorm1d / 2d module (running statistics updated in the statistics launch) or None; ``residual``: (N, C) rows
+    of x's dtype added AFTER the ReLU in the same pass (identity shortcut of a dense block; its gradient is the output gradient)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, bn=None):
+    def forward(ctx, x, gamma, beta, eps, bn=None, residual=None):
         x = x.contiguous()
         n, C = x.shape
         stats, ab, mv = gbn.fold(x, n, gamma, beta, eps, bn)
         out = torch.empty_like(x)
-        L.call("gdmae_rows_affine_relu_scatter", L.ptr(x), _bf(x), None, n, C, L.ptr(ab), L.ptr(ab[C:]), L.ptr(out), _bf(out), C, 0,
-               L.stream())
+        if residual is not None:
+            assert residual.shape == x.shape and residual.dtype == x.dtype and residual.is_contiguous() and C % 8 == 0
+            L.call("gdmae_rows_affine_relu_add", L.ptr(x), _bf(x), n, C, L.ptr(ab), L.ptr(ab[C:]), L.ptr(residual), L.ptr(out), _bf(out),
+                   L.stream())
+        else:
+            L.call("gdmae_rows_affine_relu_scatter", L.ptr(x), _bf(x), None, n, C, L.ptr(ab), L.ptr(ab[C:]), L.ptr(out), _bf(out), C, 0,
+                   L.stream())
+        ctx.has_res = residual is not None
         ctx.save_for_backward(x, ab, stats, gamma.detach())
         ctx.direct = gbn.direct_pair(gamma, beta)
         mf, vf = mv[:C], mv[C:]
@@ -44,7 +51,7 @@ class BNReLURows(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g, _m, _v):
         if g is None:
-            return None, None, None, None, None
+            return None, None, None, None, None, None
         x, ab, stats, gamma = ctx.saved_tensors
         n, C = x.shape
         g = g.contiguous()
@@ -56,7 +63,7 @@ class BNReLURows(torch.autograd.Function):
         dx = torch.empty_like(x)
         L.call("gdmae_rows_bwd", L.ptr(x), _bf(x), None, n, C, L.ptr(ab), L.ptr(ab[C:]), L.ptr(c01), L.ptr(c01[C:]), L.ptr(g),
                _bf(g), C, 0, L.ptr(dx), _bf(dx), L.stream())
-        return dx, dgamma, dbeta, None, None
+        return dx, dgamma, dbeta, None, None, (g if ctx.has_res else None)
 
 
 class BNReLUSegmentMax(torch.autograd.Function):

@@ -2,8 +2,11 @@
 momentum 0.01) + ReLU blocks with identity shortcuts where shapes allow.  Parameter names / shapes and the
 ``spatial_features -> spatial_features_2d`` contract follow the reference ``SSTBEVBackbone``
 (pcdet/models/backbones_2d/sst_bev_backbone.py:6-42) so fine-tune checkpoints load by key.  The maps here are dense (every
-pillar is a token in the fine-tune path), so the convolutions are plain dense contractions issued through PyTorch-ROCm."""
+pillar is a token in the fine-tune path), so the convolutions are plain dense contractions issued through PyTorch-ROCm; BatchNorm +
+ReLU of their channels-last outputs run through the row kernels of the hot path (gdmae_hip.dense)."""
 import torch.nn as nn
+
+from gdmae_hip import dense as gdense
 
 
 class SSTBEVBackbone(nn.Module):
@@ -23,7 +26,9 @@ class SSTBEVBackbone(nn.Module):
     def forward(self, data_dict):
         x = data_dict['spatial_features']
         for i, block in enumerate(self.conv_layer):
-            y = block(x)
-            x = y + x if (y.shape == x.shape and i in self.conv_shortcut) else y
+            conv = block[0]
+            same = (conv.out_channels == x.shape[1] and tuple(conv.stride) == (1, 1) and
+                    all(2 * p == d * (k - 1) for p, d, k in zip(conv.padding, conv.dilation, conv.kernel_size)))
+            x = gdense.conv_bn_relu(block, x, shortcut=x if (same and i in self.conv_shortcut) else None)
         data_dict['spatial_features_2d'] = x
         return data_dict

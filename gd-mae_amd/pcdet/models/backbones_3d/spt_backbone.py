@@ -15,6 +15,7 @@ import torch.nn as nn
 
 from ..model_utils.sst_basic_block import BasicShiftBlockV2
 from ...utils.spconv_utils import post_act_block, replace_feature, SparseConvTensor
+from gdmae_hip import dense as gdense
 from gdmae_hip import encoder as genc
 from gdmae_hip import ops, plan as gplan
 
@@ -113,8 +114,8 @@ def run_decoder(model_cfg, deblocks, conv_out, hidden):
     feats, strides = [], []
     for i, src in enumerate(model_cfg.FEATURES_SOURCE):
         x = hidden[int(src[-1]) - 1]
-        feats.append(deblocks[i](x.dense()))
-    y = conv_out(torch.cat(feats, dim=1))
+        feats.append(gdense.conv_bn_relu(deblocks[i], x.dense()))
+    y = gdense.conv_bn_relu(conv_out, torch.cat(feats, dim=1))
     return y
 
 

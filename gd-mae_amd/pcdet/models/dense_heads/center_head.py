@@ -22,6 +22,7 @@ import torch
 import torch.nn as nn
 from torch.nn.init import kaiming_normal_
 
+from gdmae_hip import dense as gdense
 from gdmae_hip import lib as L
 from ...ops.iou3d_nms import iou3d_nms_utils
 
@@ -48,7 +49,13 @@ class SeparateHead(nn.Module):
             setattr(self, name, fc)
 
     def forward(self, x):
-        return {name: getattr(self, name)(x) for name in self.sep_head_dict}
+        out = {}
+        for name in self.sep_head_dict:
+            y = x
+            for layer in getattr(self, name):
+                y = gdense.conv_bn_relu(layer, y) if isinstance(layer, nn.Sequential) else layer(y)
+            out[name] = y
+        return out
 
 
 def focal_loss_centernet(pred, gt):
@@ -248,7 +255,7 @@ class CenterHead(nn.Module):
         return rois, scores, labels
 
     def forward(self, data_dict):
-        x = self.shared_conv(data_dict['spatial_features_2d'])
+        x = gdense.conv_bn_relu(self.shared_conv, data_dict['spatial_features_2d'])
         pred_dicts = [head(x) for head in self.heads_list]
         if self.training:
             self.forward_ret_dict['target_dicts'] = self.assign_targets(data_dict['gt_boxes'], feature_map_size=x.shape[2:])

@@ -200,6 +200,11 @@ int gdmae_rows_affine_relu_scatter(const void* P, int p_bf16, const int* site, l
  * rows); C, the row pitch and col0 must be multiples of 8. */
 int gdmae_rows_affine_relu_sub(const void* P, int p_bf16, const int* site, long long n, int C, const float* a, const float* b,
                                const void* sub, void* Z, int z_bf16, int z_row_elems, int col0, void* stream);
+/* ... plus an identity shortcut: Z[r] = relu(a P[r] + b) + R[r] for rows R, Z (n, C) of the same dtype, rounded like the two-step
+ * sequence - BatchNorm2d + ReLU + `y + x` of a dense channels-last Conv-BN-ReLU block (sst_bev_backbone.py:36-40, fine-tune row
+ * f1; a channels-last (B, C, Y, X) map is the row-major (B Y X, C) matrix). */
+int gdmae_rows_affine_relu_add(const void* P, int p_bf16, long long n, int C, const float* a, const float* b, const void* R, void* Z,
+                               int z_bf16, void* stream);
 size_t gdmae_rows_bwd_stats_workspace_bytes(int C);
 int gdmae_rows_bwd_stats(const void* P, int p_bf16, const int* site, long long n, int C, const float* a, const float* b,
                          const void* dZ, int z_bf16, int z_row_elems, int col0, double* out, void* workspace, void* stream);

@@ -1255,6 +1255,55 @@ def test_tok_gemm_epilogues_match_torch(K, N):
             assert float((ps - sums.double()).abs().max()) <= 1e-5 * float(sums.abs().max()) + 1e-5
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("with_shortcut", [False, True])
+def test_dense_bn_relu_through_row_kernels_matches_torch(dtype, with_shortcut):
+    """gdmae_hip.dense.conv_bn_relu (fine-tune row f1: BatchNorm2d(train) + ReLU [+ identity shortcut] of a dense channels-last map
+    through gdmae_bn_fold / gdmae_rows_affine_relu[_add] / gdmae_rows_bwd_stats / gdmae_rows_bwd) against the module sequence it
+    replaces: output, running statistics, and the gradients of the input, the shortcut, gamma and beta."""
+    import copy
+    import torch.nn as nn
+    from gdmae_hip import dense as gdense
+    torch.manual_seed(3)
+    B, C, Y, X = 2, 64, 37, 29
+    block = nn.Sequential(nn.Conv2d(C, C, 3, padding=1, bias=False), nn.BatchNorm2d(C, eps=1e-3, momentum=0.01), nn.ReLU()).to(dev())
+    with torch.no_grad():
+        block[1].weight.uniform_(0.5, 1.5)
+        block[1].bias.normal_()
+    ref = copy.deepcopy(block)
+    x0 = torch.randn(B, C, Y, X, device=dev()).to(memory_format=torch.channels_last)
+    g0 = torch.randn(B, C, Y, X, device=dev()).to(memory_format=torch.channels_last)
+    outs = []
+    for mod, fused in ((block, True), (ref, False)):
+        x = x0.clone().requires_grad_()
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dtype == torch.bfloat16):
+            if fused:
+                y = gdense.conv_bn_relu(mod, x, shortcut=x if with_shortcut else None)
+                rm, rv = mod[1].running_mean, mod[1].running_var
+            else:
+                # the module sequence written out (training-mode BatchNorm2d in fp32 on the convolution's output, rounded back to its
+                # dtype; MIOpen's own NHWC batch norm is not used as the reference: it crashes on this map size in bf16)
+                bn = mod[1]
+                c = mod[0](x)
+                cf = c.float()
+                mean, var = cf.mean((0, 2, 3)), cf.var((0, 2, 3), unbiased=False)
+                z = (cf - mean[None, :, None, None]) * torch.rsqrt(var + bn.eps)[None, :, None, None]
+                z = (z * bn.weight[None, :, None, None] + bn.bias[None, :, None, None]).to(c.dtype)
+                y = torch.relu(z)
+                y = y + x.to(y.dtype) if with_shortcut else y
+                cnt = cf.numel() / C
+                rm = bn.momentum * mean.detach()
+                rv = (1 - bn.momentum) * torch.ones_like(var) + bn.momentum * var.detach() * cnt / (cnt - 1)
+        (y.float() * g0).sum().backward()
+        outs.append((y.float(), x.grad.float(), mod[1].weight.grad, mod[1].bias.grad, mod[0].weight.grad, rm, rv))
+    tol = 2e-5 if dtype == torch.float32 else 3e-2
+    names = ["out", "dx", "dgamma", "dbeta", "dW", "running_mean", "running_var"]
+    for nm, a, b in zip(names, outs[0], outs[1]):
+        scale = float(b.abs().max()) + 1e-6
+        assert float((a - b).abs().max()) <= tol * scale, (nm, float((a - b).abs().max()), scale)
+    assert int(block[1].num_batches_tracked) == 1
+
+
 @pytest.mark.parametrize("d", [128, 256])
 def test_one_launch_ffn_equals_two_token_gemms(d):
     """gdmae_tok_gemm_ffn (linear1 + GELU + linear2 + residual + LayerNorm 2 in one launch, gelu(h) in LDS only) against the two
