@@ -12,7 +12,7 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
-from .vfe import BNReLURows
+from .vfe import BNReLURows, BNReLURowsCat
 
 
 def rows_supported(y: torch.Tensor, bn: nn.BatchNorm2d) -> bool:
@@ -45,3 +45,21 @@ def conv_bn_relu(block: nn.Sequential, x: torch.Tensor, shortcut: torch.Tensor |
         return y if shortcut is None else y + shortcut
     y = block(x)
     return y if shortcut is None else y + shortcut
+
+
+def conv_bn_relu_cat(blocks, xs) -> torch.Tensor:
+    """cat([block_i(x_i)], dim=1) for Sequential(conv | deconv, BatchNorm2d, ReLU) blocks on maps of one spatial size (the decoder's
+    three deblocks, spt_backbone.py:296-303 / spt_backbone_mae.py:125-132): BatchNorm + ReLU of every branch write their column
+    slice of the channels-last result directly - no cat pass, and the backward reads its slice of the gradient in place."""
+    ys = [b[0](x) for b, x in zip(blocks, xs)]
+    ok = all(len(b) == 3 and isinstance(b[1], nn.BatchNorm2d) and isinstance(b[2], nn.ReLU) and rows_supported(y, b[1])
+             for b, y in zip(blocks, ys))
+    ok = ok and len({(y.shape[0],) + tuple(y.shape[2:]) + (y.dtype,) for y in ys}) == 1 and len({float(b[1].eps) for b in blocks}) == 1
+    if not ok:
+        return torch.cat([b[2](b[1](y)) for b, y in zip(blocks, ys)], dim=1)
+    B, _, Y, X = ys[0].shape
+    args = []
+    for b, y in zip(blocks, ys):
+        args += [y.permute(0, 2, 3, 1).reshape(B * Y * X, y.shape[1]), b[1].weight, b[1].bias]
+    out = BNReLURowsCat.apply(tuple(b[1] for b in blocks), float(blocks[0][1].eps), *args)
+    return out.view(B, Y, X, -1).permute(0, 3, 1, 2)

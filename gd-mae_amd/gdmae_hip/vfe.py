@@ -66,6 +66,52 @@ class BNReLURows(torch.autograd.Function):
         return dx, dgamma, dbeta, None, None, (g if ctx.has_res else None)
 
 
+class BNReLURowsCat(torch.autograd.Function):
+    """cat([relu(BatchNorm_train(x_i)) for i], dim=1) for row matrices x_i (N, C_i) of one dtype, written straight into the column
+    slices of the (N, sum C_i) result (the row kernels take a row pitch and a first column); the backward reads its slice of the
+    output gradient in place.  apply(bns, eps, x_0, gamma_0, beta_0, x_1, ...) -> (N, sum C_i)."""
+
+    @staticmethod
+    def forward(ctx, bns, eps, *args):
+        xs = [a.contiguous() for a in args[0::3]]
+        gammas, betas = args[1::3], args[2::3]
+        n, Ct = xs[0].shape[0], sum(x.shape[1] for x in xs)
+        assert all(x.shape[0] == n and x.dtype == xs[0].dtype and x.shape[1] % 8 == 0 for x in xs)
+        out = torch.empty(n, Ct, dtype=xs[0].dtype, device=xs[0].device)
+        saved, col = [], 0
+        for x, g_, b_, bn in zip(xs, gammas, betas, bns):
+            C = x.shape[1]
+            stats, ab, _ = gbn.fold(x, n, g_, b_, eps, bn)
+            L.call("gdmae_rows_affine_relu_scatter", L.ptr(x), _bf(x), None, n, C, L.ptr(ab), L.ptr(ab[C:]), L.ptr(out), _bf(out), Ct, col,
+                   L.stream())
+            saved += [x, ab, stats, g_.detach()]
+            col += C
+        ctx.save_for_backward(*saved)
+        ctx.direct = [gbn.direct_pair(g_, b_) for g_, b_ in zip(gammas, betas)]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        sv = ctx.saved_tensors
+        g = g.contiguous()
+        n, Ct = g.shape
+        grads, col = [None, None], 0
+        for i in range(len(sv) // 4):
+            x, ab, stats, gamma = sv[4 * i:4 * i + 4]
+            C = x.shape[1]
+            st = torch.empty(3 * C, dtype=torch.float64, device=x.device)
+            ws = torch.empty(L.load().gdmae_rows_bwd_stats_workspace_bytes(C), dtype=torch.uint8, device=x.device)
+            L.call("gdmae_rows_bwd_stats", L.ptr(x), _bf(x), None, n, C, L.ptr(ab), L.ptr(ab[C:]), L.ptr(g), _bf(g), Ct, col, L.ptr(st),
+                   L.ptr(ws), L.stream())
+            dgamma, dbeta, c01 = gbn.bwd_coeffs(st, 3, stats, ab, gamma, n, None, ctx.direct[i])
+            dx = torch.empty_like(x)
+            L.call("gdmae_rows_bwd", L.ptr(x), _bf(x), None, n, C, L.ptr(ab), L.ptr(ab[C:]), L.ptr(c01), L.ptr(c01[C:]), L.ptr(g), _bf(g),
+                   Ct, col, L.ptr(dx), _bf(dx), L.stream())
+            grads += [dx, dgamma, dbeta]
+            col += C
+        return tuple(grads)
+
+
 class BNReLUSegmentMax(torch.autograd.Function):
     """max over each pillar's points of relu(BatchNorm1d_train(x)); returns (out (M, C) fp32, mean, biased var)."""
 

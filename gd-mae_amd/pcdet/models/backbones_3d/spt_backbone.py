@@ -111,11 +111,8 @@ def build_decoder(model_cfg):
 def run_decoder(model_cfg, deblocks, conv_out, hidden):
     """Densify each source stage -> ConvTranspose2d(k=s)+BN+ReLU -> cat -> Conv2d 3x3+BN+ReLU
     (spt_backbone_mae.py:125-133).  Dense maps are channels-last in memory."""
-    feats, strides = [], []
-    for i, src in enumerate(model_cfg.FEATURES_SOURCE):
-        x = hidden[int(src[-1]) - 1]
-        feats.append(gdense.conv_bn_relu(deblocks[i], x.dense()))
-    y = gdense.conv_bn_relu(conv_out, torch.cat(feats, dim=1))
+    xs = [hidden[int(src[-1]) - 1].dense() for src in model_cfg.FEATURES_SOURCE]
+    y = gdense.conv_bn_relu(conv_out, gdense.conv_bn_relu_cat(list(deblocks), xs))
     return y
 
 

@@ -1304,6 +1304,40 @@ def test_dense_bn_relu_through_row_kernels_matches_torch(dtype, with_shortcut):
     assert int(block[1].num_batches_tracked) == 1
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_dense_bn_relu_cat_equals_separate_blocks(dtype):
+    """gdmae_hip.dense.conv_bn_relu_cat (the decoder's three deblocks writing BatchNorm + ReLU straight into the column slices of the
+    concatenated channels-last map) against torch.cat of the single-block path: output, running statistics and every gradient."""
+    import copy
+    import torch.nn as nn
+    from gdmae_hip import dense as gdense
+    torch.manual_seed(5)
+    B, Y, X = 2, 24, 40
+    spec = [(64, 128, 1), (128, 128, 2), (256, 128, 4)]
+    blocks = [nn.Sequential(nn.ConvTranspose2d(ci, co, s, stride=s, bias=False), nn.BatchNorm2d(co, eps=1e-3, momentum=0.01), nn.ReLU())
+              .to(dev()) for ci, co, s in spec]
+    with torch.no_grad():
+        for b in blocks:
+            b[1].weight.uniform_(0.5, 1.5)
+            b[1].bias.normal_()
+    ref = copy.deepcopy(blocks)
+    xs0 = [torch.randn(B, ci, Y // s, X // s, device=dev()).to(memory_format=torch.channels_last) for ci, _, s in spec]
+    g0 = torch.randn(B, 384, Y, X, device=dev()).to(memory_format=torch.channels_last)
+    res = []
+    for mods, fused in ((blocks, True), (ref, False)):
+        xs = [x.clone().requires_grad_() for x in xs0]
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dtype == torch.bfloat16):
+            y = gdense.conv_bn_relu_cat(mods, xs) if fused else torch.cat([gdense.conv_bn_relu(m, x) for m, x in zip(mods, xs)], dim=1)
+        assert y.shape == (B, 384, Y, X)
+        (y.float() * g0).sum().backward()
+        res.append([y.float()] + [x.grad for x in xs] + [m[1].weight.grad for m in mods] + [m[1].bias.grad for m in mods] +
+                   [m[0].weight.grad for m in mods] + [m[1].running_mean for m in mods] + [m[1].running_var for m in mods])
+    names = ["out"] + [f"{k}{i}" for k in ("dx", "dgamma", "dbeta", "dW", "running_mean", "running_var") for i in range(3)]
+    for nm, a, b in zip(names, *res):         # (the library's transposed convolutions are not bit-reproducible call to call)
+        tol = (1e-5 if dtype == torch.float32 else 2e-2) * (float(b.float().abs().max()) + 1e-6)
+        assert float((a.float() - b.float()).abs().max()) <= tol, (nm, float((a.float() - b.float()).abs().max()), tol)
+
+
 @pytest.mark.parametrize("d", [128, 256])
 def test_one_launch_ffn_equals_two_token_gemms(d):
     """gdmae_tok_gemm_ffn (linear1 + GELU + linear2 + residual + LayerNorm 2 in one launch, gelu(h) in LDS only) against the two
