@@ -55,7 +55,10 @@ def parse():
     ap.add_argument("--pool", type=int, default=3, help="distinct pre-generated batches cycled through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--no-also", action="store_true", help="skip the extra legs (resident inputs, fp32, mask 0.85, configs D / E, config-C batch)")
+    ap.add_argument("--no-also", action="store_true", help="skip the extra legs (resident inputs, fp32, mask 0.85, config E, config-C batch)")
+    ap.add_argument("--legs", choices=("default", "full"), default="default",
+                    help="full: also the config D (fine-tune) leg - its dense convolutions go through MIOpen, which compiles / searches "
+                         "kernels at first use: 5 - 7 minutes on a fresh box, so it is not part of the default run")
     ap.add_argument("--feed", default="h2d", choices=["h2d", "resident"], help="h2d: every batch copied from pinned host memory inside the timed region")
     ap.add_argument("--prefetch", type=int, default=1, help="1: build the geometry plan of batch t+1 on a side stream")
     ap.add_argument("--miopen-find", type=int, default=1, help="1: torch.backends.cudnn.benchmark (MIOpen find mode)")
@@ -453,6 +456,7 @@ def main():
 
     def timed_leg(w, n_warm, n_timed, feed=None):
         """frames/s of `n_timed` more steps after `n_warm` untimed ones (single process; used for the extra legs)."""
+        t_leg0 = time.perf_counter()
         w.pending.clear()
         f = feed or w.feed
         f(n_warm, total_steps - 1)
@@ -464,7 +468,7 @@ def main():
         torch.cuda.synchronize()
         dtl = time.perf_counter() - t1
         return {"value": round(w.B * n_timed / dtl, 2), "unit": "frames/s", "ms_per_step": round(1e3 * dtl / n_timed, 3), "steps": n_timed,
-                "frames_per_gpu": w.B}
+                "frames_per_gpu": w.B, "leg_wall_s": round(time.perf_counter() - t_leg0, 1)}
 
     also = {}
     if world == 1 and not args.no_also and pre:
@@ -486,12 +490,20 @@ def main():
         if args.config == "B" and not explicit_batch:
             # ---- config C's per-GPU batch on this one GPU (the N = 1 point of the driver's scaling curve runs 8 frames per GPU;
             #      this is the same step at the 4 frames per GPU that --gpus 2 / 4 / 8 use) and the other single-GPU configs
-            extra = [("config_C_batch_4_per_gpu", "B", 4), ("config_E", "E", 8), ("config_D_finetune", "D", 8)]
+            extra = [("config_C_batch_4_per_gpu", "B", 4), ("config_E", "E", 8)]
+            if args.legs == "full":
+                extra.append(("config_D_finetune", "D", 8))
+            else:
+                also["config_D_finetune"] = {"skipped": "MIOpen compiles / searches the dense fine-tune convolutions at first use (5 - 7 minutes on a "
+                                                        "fresh box): run `python bench.py --legs full` or `python bench.py --config D`; the last "
+                                                        "full run is committed as profiles/r03_bench_n1.json"}
             for key, cfg_name, b in extra:
                 try:
+                    t_build = time.perf_counter()
                     w2 = Workload(args, cfg_name, b, dev, rank, world, args.mask_ratio, total_steps, 2)
                     w2.advance = False
                     also[key] = timed_leg(w2, 4, max(8, args.steps // 2))
+                    also[key]["leg_wall_s"] = round(time.perf_counter() - t_build, 1)
                     also[key]["workload"] = WORKLOADS["C" if key.startswith("config_C") else cfg_name]
                     del w2
                     torch.cuda.empty_cache()

@@ -5,7 +5,7 @@ set -u
 TAG=${1:-r02}
 OUT=$PWD/gpurun_out/profiles_$TAG
 mkdir -p $OUT
-python bench.py > $OUT/bench_full.log 2>&1
+python bench.py --legs full > $OUT/bench_full.log 2>&1
 tail -1 $OUT/bench_full.log > $OUT/${TAG}_bench_n1.json
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_kt
