@@ -30,6 +30,31 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+// streaming (nontemporal) stores for outputs whose next reader is far away - the fp32 rows of the residual stream, the branch
+// output and the pre-activation kept for the backward: 2 - 6 % on the LayerNorm-epilogue launches (35.6 vs 37.8 us for 128 -> 256,
+// 39.0 vs 40.8 for 256 -> 256 at 43 k rows), -0.085 ms per step in a same-box A/B (TG_NT_STORES=0 builds the plain stores)
+#ifndef TG_NT_STORES
+#define TG_NT_STORES 1
+#endif
+#if TG_NT_STORES
+#define TG_ST_U2(ptr, val) __builtin_nontemporal_store(*(const unsigned long long*)&(val), (unsigned long long*)(ptr))
+#define TG_ST_U4(ptr, val)                                                              \
+  do {                                                                                  \
+    typedef unsigned int tg_u4v __attribute__((ext_vector_type(4)));                    \
+    const tg_u4v v_ = {(val).x, (val).y, (val).z, (val).w};                             \
+    __builtin_nontemporal_store(v_, (tg_u4v*)(ptr));                                    \
+  } while (0)
+#define TG_ST_F4(ptr, a, b, c, d)                                                       \
+  do {                                                                                  \
+    typedef float tg_f4v __attribute__((ext_vector_type(4)));                           \
+    const tg_f4v v_ = {a, b, c, d};                                                     \
+    __builtin_nontemporal_store(v_, (tg_f4v*)(ptr));                                    \
+  } while (0)
+#else
+#define TG_ST_U2(ptr, val) (*(uint2*)(ptr) = (val))
+#define TG_ST_U4(ptr, val) (*(uint4*)(ptr) = (val))
+#define TG_ST_F4(ptr, a, b, c, d) (*(float4*)(ptr) = make_float4(a, b, c, d))
+#endif
 union TgFrag {
   uint4 q;
   bf16x8 v;
@@ -309,7 +334,7 @@ __device__ __forceinline__ void tg_tile(const TgArgs& A, const long long tile, c
       const long long e = (live ? row : A.n - 1) * ND + c0;
       const float4 a4 = res_pf[p];
       const uint2 fq = *(const uint2*)(lds + rl * SP + c0 * 2);
-      if (A.f_out) *(uint2*)(A.f_out + (row0 + rl) * ND + c0) = fq;
+      if (A.f_out) TG_ST_U2(A.f_out + (row0 + rl) * ND + c0, fq);
       float s[4] = {a4.x, a4.y, a4.z, a4.w};
       s[0] += __uint_as_float(fq.x << 16); s[1] += __uint_as_float(fq.x & 0xFFFF0000u);
       s[2] += __uint_as_float(fq.y << 16); s[3] += __uint_as_float(fq.y & 0xFFFF0000u);
@@ -325,7 +350,7 @@ __device__ __forceinline__ void tg_tile(const TgArgs& A, const long long tile, c
       float o[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) o[k] = (s[k] - mean) * rstd * g[k] + bt[k];
-      *(float4*)(A.y + e) = make_float4(o[0], o[1], o[2], o[3]);
+      TG_ST_F4(A.y + e, o[0], o[1], o[2], o[3]);
       if (A.y_bf) {
         uint2 q;
         q.x = tg_pack2(o[0], o[1]); q.y = tg_pack2(o[2], o[3]);
@@ -385,7 +410,7 @@ __device__ __forceinline__ void tg_tile(const TgArgs& A, const long long tile, c
         o[k] = rstd * (gy[k] - m1 - xh[k] * m2);
         dsx[k] += o[k];
       }
-      *(float4*)(A.y + e) = make_float4(o[0], o[1], o[2], o[3]);
+      TG_ST_F4(A.y + e, o[0], o[1], o[2], o[3]);
       if (A.y_bf) {
         uint2 q;
         q.x = tg_pack2(o[0], o[1]); q.y = tg_pack2(o[2], o[3]);
@@ -665,7 +690,7 @@ __global__ __launch_bounds__(512, 4) void k_tok_ffn(TgFfnArgs F) {
     for (int p = 0; p < ROWS / RPP; ++p) {
       const int rl = p * RPP + r;
       const uint4 q = *(const uint4*)(hl + rl * HP + c * 16);
-      *(uint4*)(F.h + (row0 + rl) * FF + c * 8) = q;
+      TG_ST_U4(F.h + (row0 + rl) * FF + c * 8, q);
       float v[8];
       tg_unpack8(q, v);
 #pragma unroll
@@ -722,7 +747,7 @@ __global__ __launch_bounds__(512, 4) void k_tok_ffn(TgFfnArgs F) {
       const long long e = (live ? row : A.n - 1) * D + lc0;
       const float4 a4 = res_pf[p];
       const uint2 fq = *(const uint2*)(xl + rl * SP + lc0 * 2);
-      if (A.f_out) *(uint2*)(A.f_out + (row0 + rl) * D + lc0) = fq;
+      if (A.f_out) TG_ST_U2(A.f_out + (row0 + rl) * D + lc0, fq);
       float sv[4] = {a4.x, a4.y, a4.z, a4.w};
       sv[0] += __uint_as_float(fq.x << 16); sv[1] += __uint_as_float(fq.x & 0xFFFF0000u);
       sv[2] += __uint_as_float(fq.y << 16); sv[3] += __uint_as_float(fq.y & 0xFFFF0000u);
@@ -738,7 +763,7 @@ __global__ __launch_bounds__(512, 4) void k_tok_ffn(TgFfnArgs F) {
       float o[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) o[k] = (sv[k] - mean) * rstd * g[k] + bt[k];
-      *(float4*)(A.y + e) = make_float4(o[0], o[1], o[2], o[3]);
+      TG_ST_F4(A.y + e, o[0], o[1], o[2], o[3]);
       if (A.y_bf) {
         uint2 q;
         q.x = tg_pack2(o[0], o[1]); q.y = tg_pack2(o[2], o[3]);
