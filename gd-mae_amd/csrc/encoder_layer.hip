@@ -559,7 +559,7 @@ int gd_tok_gemm_ln_bwd(hipStream_t st, const void* X, const void* Wp, long long 
                        void* dx_bf, float* part);
 int gd_tok_gemm_res_ln(hipStream_t st, const void* X, const void* Wp, const void* bias, long long n, long long n_pad, int K, int N,
                        const float* res, const float* gamma, const float* beta, float eps, float* y, float* stats, void* y_bf,
-                       const float* pos_table, const int* tok_pos, void* ypos_bf, void* f_out);
+                       const float* pos_table, const int* tok_pos, void* ypos_bf, void* f_out, int y_cached);
 
 namespace {
 // packed weight image of a layer: element offsets (in bf16 elements) of the ten operands
@@ -670,7 +670,7 @@ static int layer_fwd(const gdmae_layer_args* a, const gdmae_layer_args* next, bo
     // out-projection + residual + LayerNorm 1; linear1 + GELU; linear2 + residual + LayerNorm 2 (+ the next layer's
     // q/k/v operands): three launches for what is eight in the unfused sequence
     GD_TRY(gd_tok_gemm_res_ln(c.st, s.o, pk.o, a->bo, n, n_pad, d, d, a->x, a->g1, a->be1, a->eps, (float*)s.x1, (float*)s.st1, s.x1b,
-                              nullptr, nullptr, nullptr, s.a));
+                              nullptr, nullptr, nullptr, s.a, 1));      // x1 is the residual operand of the very next launch
     // linear1 + GELU + linear2 + residual + LayerNorm 2 in one launch when the widths allow it: gelu(h) never leaves the CU (the
     // backward's GELU kernel writes it into s.gact for the weight gradient of linear2)
     const bool ffn1 = use_ffn(a, n_pad);
@@ -687,7 +687,7 @@ static int layer_fwd(const gdmae_layer_args* a, const gdmae_layer_args* next, bo
                              (float*)s.st2, y_bf, ptab, tpos, ypos_bf, s.f));
     else
       GD_TRY(gd_tok_gemm_res_ln(c.st, s.gact, pk.w2, a->b2, n, n_pad, ff, d, (const float*)s.x1, a->g2, a->be2, a->eps, a->y,
-                                (float*)s.st2, y_bf, ptab, tpos, ypos_bf, s.f));
+                                (float*)s.st2, y_bf, ptab, tpos, ypos_bf, s.f, 0));
     return 0;
   }
   GD_TRY(linear_fwd(c, s.o, a->Wo, a->bo, s.a, n_pad, d, d));

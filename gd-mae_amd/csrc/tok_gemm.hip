@@ -160,6 +160,7 @@ struct TgArgs {
   const float* beta;
   float eps;
   float* y;                     // (n, N) fp32
+  int y_cached;                 // RES_LN: the next launch reads y again (LayerNorm 1 -> feed-forward block): plain store instead of streaming
   float* stats;                 // (n, 2) mean, rstd
   unsigned short* y_bf;         // optional (n_pad, N) bf16 copy of y
   const float* pos_table;       // optional: ypos_bf = bf16(y + pos_table[tok_pos[row]])
@@ -350,7 +351,8 @@ __device__ __forceinline__ void tg_tile(const TgArgs& A, const long long tile, c
       float o[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) o[k] = (s[k] - mean) * rstd * g[k] + bt[k];
-      TG_ST_F4(A.y + e, o[0], o[1], o[2], o[3]);
+      if (A.y_cached) *(float4*)(A.y + e) = make_float4(o[0], o[1], o[2], o[3]);
+      else TG_ST_F4(A.y + e, o[0], o[1], o[2], o[3]);
       if (A.y_bf) {
         uint2 q;
         q.x = tg_pack2(o[0], o[1]); q.y = tg_pack2(o[2], o[3]);
@@ -837,9 +839,10 @@ int gd_tok_gemm_gelu_bwd(hipStream_t st, const void* dY, const void* Wp, const v
 }
 int gd_tok_gemm_res_ln(hipStream_t st, const void* X, const void* Wp, const void* bias, long long n, long long n_pad, int K, int N,
                        const float* res, const float* gamma, const float* beta, float eps, float* y, float* stats, void* y_bf,
-                       const float* pos_table, const int* tok_pos, void* ypos_bf, void* f_out) {
+                       const float* pos_table, const int* tok_pos, void* ypos_bf, void* f_out, int y_cached) {
   TgArgs A = {};
   A.f_out = (unsigned short*)f_out;
+  A.y_cached = y_cached;
   A.X = (const unsigned short*)X; A.Wp = (const uint4*)Wp; A.bias = (const unsigned short*)bias; A.n = n; A.n_pad = n_pad;
   A.res = res; A.gamma = gamma; A.beta = beta; A.eps = eps; A.y = y; A.stats = stats; A.y_bf = (unsigned short*)y_bf;
   A.pos_table = pos_table; A.tok_pos = tok_pos; A.ypos_bf = (unsigned short*)ypos_bf;
@@ -934,7 +937,7 @@ extern "C" int gdmae_tok_gemm(const void* X, const void* Wp, const void* bias, l
     case TG_GELU_BWD: return gd_tok_gemm_gelu_bwd(st, X, Wp, aux, n_pad, K, N, out0, out1);
     case TG_RES_LN:
       return gd_tok_gemm_res_ln(st, X, Wp, bias, n, n_pad, K, N, res, gamma, beta, eps, y, stats, y_bf16, pos_table, tok_pos, ypos_bf16,
-                                out0);
+                                out0, 0);
   }
   GD_REQUIRE(false, "tok_gemm: unknown epilogue");
 }
