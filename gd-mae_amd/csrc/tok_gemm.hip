@@ -55,6 +55,38 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define TG_ST_U4(ptr, val) (*(uint4*)(ptr) = (val))
 #define TG_ST_F4(ptr, a, b, c, d) (*(float4*)(ptr) = make_float4(a, b, c, d))
 #endif
+// streaming (nontemporal) loads for operands that were written a whole forward pass ago and are read exactly once (the LayerNorm
+// addends and the GELU pre-activation saved for the backward): they do not displace the gradients the neighbouring launches pass
+// to each other through L2 / MALL
+#ifndef TG_NT_LOADS
+#define TG_NT_LOADS 1
+#endif
+__device__ inline float4 tg_ld_f4_once(const float* p) {
+#if TG_NT_LOADS
+  typedef float v4 __attribute__((ext_vector_type(4)));
+  const v4 v = __builtin_nontemporal_load((const v4*)p);
+  return make_float4(v.x, v.y, v.z, v.w);
+#else
+  return *(const float4*)p;
+#endif
+}
+__device__ inline uint2 tg_ld_u2_once(const void* p) {
+#if TG_NT_LOADS
+  const unsigned long long v = __builtin_nontemporal_load((const unsigned long long*)p);
+  return make_uint2((unsigned)v, (unsigned)(v >> 32));
+#else
+  return *(const uint2*)p;
+#endif
+}
+__device__ inline uint4 tg_ld_u4_once(const void* p) {
+#if TG_NT_LOADS
+  typedef unsigned int v4 __attribute__((ext_vector_type(4)));
+  const v4 v = __builtin_nontemporal_load((const v4*)p);
+  return make_uint4(v.x, v.y, v.z, v.w);
+#else
+  return *(const uint4*)p;
+#endif
+}
 union TgFrag {
   uint4 q;
   bf16x8 v;
@@ -241,8 +273,8 @@ __device__ __forceinline__ void tg_tile(const TgArgs& A, const long long tile, c
       const long long row = row0 + p * LN_RPP + r;
       const long long rr = row < A.n ? row : A.n - 1;
       dy_pf[p] = *(const float4*)(A.res + rr * ND + c0);
-      a_pf[p] = *(const float4*)(A.ln_a + rr * ND + c0);
-      b_pf[p] = *(const uint2*)(A.ln_b + rr * ND + c0);
+      a_pf[p] = tg_ld_f4_once(A.ln_a + rr * ND + c0);
+      b_pf[p] = tg_ld_u2_once(A.ln_b + rr * ND + c0);
       d2_pf[p] = A.aux ? *(const uint2*)(A.aux + rr * ND + c0) : make_uint2(0u, 0u);
       st_pf[p] = *(const float2*)(A.stats + rr * 2);
     }
@@ -455,7 +487,7 @@ __device__ __forceinline__ void tg_tile(const TgArgs& A, const long long tile, c
         *(uint4*)(A.out1 + e) = tg_pack8(v);
       } else {   // TG_GELU_BWD: dh = dg * (Phi(h) + h * phi(h));  optionally gelu(h) next to it (the operand of the weight
                  // gradient of the linear layer behind the GELU, when the forward kept it in LDS only: k_tok_ffn)
-        const uint4 hq = *(const uint4*)(A.aux + e);
+        const uint4 hq = tg_ld_u4_once(A.aux + e);
         float g[8], v[8];
         tg_unpack8(q, g);
         tg_unpack8(hq, v);
