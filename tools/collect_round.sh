@@ -5,8 +5,8 @@ set -u
 TAG=${1:-r02}
 OUT=$PWD/gpurun_out/profiles_$TAG
 mkdir -p $OUT
-python bench.py --legs full > $OUT/bench_full.log 2>&1
-tail -1 $OUT/bench_full.log > $OUT/${TAG}_bench_n1.json
+if [ -z "${SKIP_BENCH:-}" ]; then python bench.py --legs full > $OUT/bench_full.log 2>&1; fi
+if [ -z "${SKIP_BENCH:-}" ]; then tail -1 $OUT/bench_full.log > $OUT/${TAG}_bench_n1.json; fi
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_kt
 rocprofv3 --kernel-trace --stats -f csv -T -d /tmp/prof_kt -- python /root/repo/bench.py --steps 12 --warmup 6 --no-cpu-baseline --no-roofline --no-also > /tmp/kt.log 2>&1
