@@ -561,6 +561,22 @@ int gd_tok_gemm_res_ln(hipStream_t st, const void* X, const void* Wp, const void
                        const float* res, const float* gamma, const float* beta, float eps, float* y, float* stats, void* y_bf,
                        const float* pos_table, const int* tok_pos, void* ypos_bf, void* f_out, int y_cached);
 
+// layer around its bytes (layer_fused.hip)
+bool gd_layer_fused_supported(int d, int ff);
+int gd_layer_fused_rows(int d);
+int gd_layer_fused_fwd(hipStream_t st, int d, const void* o, const void* x, const void* Wo, const void* W1, const void* W2, const void* bo,
+                       const void* b1, const void* b2, const float* g1, const float* be1, const float* g2, const float* be2, float eps,
+                       long long n, long long n_pad, void* a, void* x1, void* h, void* f, float* st1, float* st2, float* y, void* y_bf,
+                       void* ypos_bf, const float* pos_table, const int* tok_pos);
+int gd_layer_fused_bwd_ffn(hipStream_t st, int d, const void* df, const void* h, const void* x, const void* a, const float* st1, const float* g1,
+                           const void* W2t, const void* W1t, const void* Wot, long long n, long long n_pad, void* dh, void* gact, void* da,
+                           void* d_o, float* part);
+int gd_layer_fused_bwd_in(hipStream_t st, int d, const void* dqk, const void* dv, const void* Wqkt, const void* Wvt, const void* dres, long long n,
+                          long long n_pad, const void* ln_a, const void* ln_b, const float* stats, const float* gamma, void* dout, float* part,
+                          float* dx);
+int gd_layer_fused_ln2_top(hipStream_t st, int d, const float* dy, const void* ln_a, const void* ln_b, const float* stats, const float* gamma,
+                           long long n, long long n_pad, void* dout, float* part);
+
 namespace {
 // packed weight image of a layer: element offsets (in bf16 elements) of the ten operands
 struct Packed {
@@ -593,7 +609,23 @@ bool use_ffn(const gdmae_layer_args* a, long long n_pad) {
   static const int off = getenv("GDMAE_FFN") ? atoi(getenv("GDMAE_FFN")) == 0 : 0;
   return !off && use_fused(a) && use_grouped_dw(a, n_pad) && gd_tok_gemm_ffn_supported(a->d, a->ff);
 }
+// the stage as three fused launches per layer and direction around the attention, bf16 residual stream (layer_fused.hip);
+// GDMAE_LAYER_V2=0: the launch-per-product sequence with the fp32 stream (A/B reference)
+int g_layer_path = -1;      // -1: GDMAE_LAYER_V2 (default on), 0: launch-per-product, 1: fused (gdmae_encoder_set_layer_path)
+bool stage_v2(const gdmae_layer_args* layers, int n_layers) {
+  static const int env_off = getenv("GDMAE_LAYER_V2") ? atoi(getenv("GDMAE_LAYER_V2")) == 0 : 0;
+  if (g_layer_path == 0 || (g_layer_path < 0 && env_off)) return false;
+  for (int i = 0; i < n_layers; ++i)
+    if (!(use_ffn(&layers[i], pad_rows(layers[i].n)) && gd_layer_fused_supported(layers[i].d, layers[i].ff))) return false;
+  return true;
+}
 }  // namespace
+
+extern "C" int gdmae_encoder_set_layer_path(int path) {
+  GD_REQUIRE(path >= -1 && path <= 1, "encoder_set_layer_path: -1 (environment default), 0 or 1");
+  g_layer_path = path;
+  return 0;
+}
 
 extern "C" size_t gdmae_layer_packed_bytes(int d, int ff) { return packed_layout(nullptr, d, ff).bytes; }
 
@@ -710,8 +742,43 @@ extern "C" int gdmae_encoder_layer_fwd(const gdmae_layer_args* a, void* stream) 
 
 // L consecutive layers of one stage (same n, d, ff; layer i + 1 reads layer i's y): one call, and in bf16 mode the
 // prep_tokens pass of layers 1.. is folded into the previous layer's second LayerNorm.
+// The stage with the fused layer launches (layer_fused.hip): per layer q/k/v projections, attention, ONE launch for everything
+// behind it.  The residual stream between the layers is the bf16 row the next layer's v projection reads anyway (xb of its saved
+// block); only the last layer writes the fp32 rows the caller sees.
+static int stage_fwd_v2(const gdmae_layer_args* layers, int n_layers, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  for (int i = 0; i < n_layers; ++i) {
+    const gdmae_layer_args* a = &layers[i];
+    GD_REQUIRE(a->n > 0 && a->n_levels >= 1 && a->n_levels <= 4, "encoder layer: bad sizes");
+    const long long n = a->n, n_pad = pad_rows(n);
+    const int d = a->d, ff = a->ff;
+    Saved s = saved_layout(a->saved, n_pad, d, ff, 2);
+    const Packed pk = packed_layout(a->packed, d, ff);
+    if (i == 0) GD_TRY(gdmae_prep_tokens(a->x, a->pos_table, a->tok_pos, n, d, s.xb, s.xpb, 1, stream));
+    GD_TRY(gd_tok_gemm_qkv(st, s.xpb, s.xb, pk.qk, pk.v, a->bin, n_pad, d, s.qk, s.v));
+    gd_attn_timing_tokens(n);
+    GD_TRY(gdmae_window_attention_levels_fwd(s.qk, s.v, s.o, 1, a->csr_tok, a->win_start, a->win_len, a->n_levels, a->n_win, a->max_tokens, d,
+                                             a->nhead, a->tau, a->tau_min, stream));
+    const gdmae_layer_args* next = i + 1 < n_layers ? &layers[i + 1] : nullptr;
+    void *y_bf = nullptr, *ypos_bf = nullptr;
+    if (next) {
+      Saved sn = saved_layout(next->saved, n_pad, d, ff, 2);
+      y_bf = sn.xb; ypos_bf = sn.xpb;
+    }
+    GD_TRY(gd_layer_fused_fwd(st, d, s.o, s.xb, pk.o, pk.w1, pk.w2, a->bo, a->b1, a->b2, a->g1, a->be1, a->g2, a->be2, a->eps, n, n_pad, s.a,
+                              s.x1b, s.h, s.f, (float*)s.st1, (float*)s.st2, next ? nullptr : a->y, y_bf, ypos_bf,
+                              next ? next->pos_table : nullptr, next ? next->tok_pos : nullptr));
+  }
+  return 0;
+}
+
 extern "C" int gdmae_encoder_stage_fwd(const gdmae_layer_args* layers, int n_layers, void* stream) {
   GD_REQUIRE(n_layers >= 1, "encoder stage: no layers");
+  for (int i = 0; i < n_layers; ++i)
+    GD_REQUIRE(i == 0 || (layers[i].x == layers[i - 1].y && layers[i].n == layers[0].n && layers[i].d == layers[0].d &&
+                          layers[i].ff == layers[0].ff && layers[i].bf16 == layers[0].bf16),
+               "encoder stage: layers must chain (x[i] = y[i-1]) and share n, d, ff, dtype");
+  if (stage_v2(layers, n_layers)) return stage_fwd_v2(layers, n_layers, stream);
   for (int i = 0; i < n_layers; ++i) {
     GD_REQUIRE(i == 0 || (layers[i].x == layers[i - 1].y && layers[i].n == layers[0].n && layers[i].d == layers[0].d &&
                           layers[i].ff == layers[0].ff && layers[i].bf16 == layers[0].bf16),
@@ -720,6 +787,69 @@ extern "C" int gdmae_encoder_stage_fwd(const gdmae_layer_args* layers, int n_lay
   }
   return 0;
 }
+
+
+namespace {
+// The five weight gradients + three bias column sums of a layer as ONE grouped launch, then the tail launch that reduces their
+// split-K partials together with the LayerNorm partial rows (nb1 / nb2 rows of LayerNorm 1 / 2) and the attention's dtau partials.
+int grouped_dw_and_tail(const gdmae_layer_args* a, const Saved& s, const Scratch& w, const Ctx& c, long long n, long long n_pad, int nb1,
+                        int nb2, long long pbase) {
+  const int d = a->d, ff = a->ff;
+  SplitkJobs SJ;
+  SJ.count = 0;
+  GdDwGroup Gp;
+  Gp.n_jobs = 5;
+  float* cp = (float*)w.cs_part;                       // (3, S, cmax) column-sum partials
+  const int cmax = ff > 2 * d ? ff : 2 * d;
+  int tiles = 0;
+  const int mk5[5][2] = {{d, ff}, {ff, d}, {d, d}, {2 * d, d}, {d, d}};
+  for (int i = 0; i < 5; ++i) tiles += (mk5[i][0] / 128) * (mk5[i][1] / 128);
+  const int S = gd_dw_group_slices(n_pad, tiles);
+  Gp.job[0] = GdDwJob{w.dfb, s.gact, d, ff, (float*)w.part_w[0], nullptr, 0};
+  Gp.job[1] = GdDwJob{w.dh, s.x1b, ff, d, (float*)w.part_w[1], cp, 0};
+  Gp.job[2] = GdDwJob{w.dab, s.o, d, d, (float*)w.part_w[2], nullptr, 0};
+  Gp.job[3] = GdDwJob{w.dqk, s.xpb, 2 * d, d, (float*)w.part_w[3], cp + (size_t)S * cmax, 0};
+  Gp.job[4] = GdDwJob{w.dv, s.xb, d, d, (float*)w.part_w[4], cp + (size_t)2 * S * cmax, 0};
+  GD_TRY(gd_dw_grouped(c.st, Gp, n_pad, n));
+  GD_REQUIRE(Gp.S == S, "dw_grouped: slice count");
+  float* dW[5] = {a->dW2, a->dW1, a->dWo, a->dWin, a->dWin + (size_t)2 * d * d};
+  for (int i = 0; i < 5; ++i) {
+    SJ.part[i] = Gp.job[i].part; SJ.dst[i] = dW[i]; SJ.S[i] = S; SJ.P4[i] = (long long)mk5[i][0] * mk5[i][1] / 4;
+  }
+  // bias column sums: same reduce (partials (S, M) -> dst (M))
+  const int cj[3] = {1, 3, 4};
+  float* db[3] = {a->db1, a->dbin, a->dbin + 2 * d};
+  for (int i = 0; i < 3; ++i) {
+    SJ.part[5 + i] = Gp.job[cj[i]].colpart; SJ.dst[5 + i] = db[i]; SJ.S[5 + i] = S; SJ.P4[5 + i] = mk5[cj[i]][0] / 4;
+  }
+  SJ.count = 8;
+  // LayerNorm / bias gradients from the per-workgroup partial rows {dgamma, dbeta, column sums of dx}; dtau from the attention partials
+  AccJobs j;
+  const float* p1 = (const float*)w.ln_ws;    // LayerNorm 1: dg1, dbe1, bias gradient of the out-projection
+  const float* p2 = (const float*)w.ln_ws2;   // LayerNorm 2: dg2, dbe2, bias gradient of the second FFN linear
+  float* dst[6] = {a->dg1, a->dbe1, a->dbo, a->dg2, a->dbe2, a->db2};
+  const float* src[6] = {p1, p1 + d, p1 + 2 * d, p2, p2 + d, p2 + 2 * d};
+  int cols = 0;
+  for (int i = 0; i < 6; ++i) {
+    j.dst[i] = dst[i]; j.src[i] = src[i]; j.len[i] = d; j.nblk[i] = i < 3 ? nb1 : nb2; j.stride[i] = 3 * d;
+    cols += d;
+  }
+  j.count = 6;
+  TailJobs T;
+  T.J = SJ;
+  T.a = j;
+  T.tau_part = (const float*)w.apart; T.n_part = pbase; T.tau = a->tau; T.tau_min = a->tau_min; T.dtau = a->dtau;
+  long long gx = (cols + 15) / 16;
+  for (int q = 0; q < SJ.count; ++q) gx = (SJ.P4[q] + 63) / 64 > gx ? (SJ.P4[q] + 63) / 64 : gx;
+  double tail_bytes = 4.0 * pbase;
+  for (int q = 0; q < SJ.count; ++q) tail_bytes += 16.0 * SJ.P4[q] * (SJ.S[q] + 2);
+  for (int q = 0; q < j.count; ++q) tail_bytes += 4.0 * j.len[q] * (j.nblk[q] + 2);
+  GdTimed timed(GD_T_LAYER_TAIL, c.st, tail_bytes);
+  hipLaunchKernelGGL(k_layer_tail, dim3((unsigned)gx, SJ.count + 2), dim3(256), 0, c.st, T);
+  GD_LAUNCH_CHECK();
+  return 0;
+}
+}  // namespace
 
 // One layer backward.  `upstream3`: the upstream gradient is the sum of three tensors left in `scratch` by the
 // backward of the NEXT layer (its residual-stream gradient, dx_qk, dx_v - that layer skipped its add3 pass) instead of
@@ -795,33 +925,10 @@ static int layer_bwd(const gdmae_layer_args* a, bool upstream3, bool defer_add3,
                                            a->n_levels, a->n_win, a->max_tokens, d, a->nhead, a->tau, a->tau_min, stream));
   if (!grouped) GD_TRY(gdmae_sum_partials_gated((const float*)w.apart, pbase, 1.f, (float*)w.dtau, a->tau, a->tau_min, stream));
   const char* Win = (const char*)a->Win;
+  const int nb_rows = gd_ln_partial_rows(n, d), nb_fused = (int)(n_pad / gd_tok_gemm_rows(d));
+  const int nb1 = fuse_ln ? nb_fused : nb_rows, nb2 = ln2_done ? nb_fused : nb_rows;
   if (grouped) {
-    GdDwGroup Gp;
-    Gp.n_jobs = 5;
-    float* cp = (float*)w.cs_part;                       // (3, S, cmax) column-sum partials
-    const int cmax = ff > 2 * d ? ff : 2 * d;
-    int tiles = 0;
-    const int mk5[5][2] = {{d, ff}, {ff, d}, {d, d}, {2 * d, d}, {d, d}};
-    for (int i = 0; i < 5; ++i) tiles += (mk5[i][0] / 128) * (mk5[i][1] / 128);
-    const int S = gd_dw_group_slices(n_pad, tiles);
-    Gp.job[0] = GdDwJob{w.dfb, s.gact, d, ff, (float*)w.part_w[0], nullptr, 0};
-    Gp.job[1] = GdDwJob{w.dh, s.x1b, ff, d, (float*)w.part_w[1], cp, 0};
-    Gp.job[2] = GdDwJob{w.dab, s.o, d, d, (float*)w.part_w[2], nullptr, 0};
-    Gp.job[3] = GdDwJob{w.dqk, s.xpb, 2 * d, d, (float*)w.part_w[3], cp + (size_t)S * cmax, 0};
-    Gp.job[4] = GdDwJob{w.dv, s.xb, d, d, (float*)w.part_w[4], cp + (size_t)2 * S * cmax, 0};
-    GD_TRY(gd_dw_grouped(c.st, Gp, n_pad, n));
-    GD_REQUIRE(Gp.S == S, "dw_grouped: slice count");
-    float* dW[5] = {a->dW2, a->dW1, a->dWo, a->dWin, a->dWin + (size_t)2 * d * d};
-    for (int i = 0; i < 5; ++i) {
-      SJ.part[i] = Gp.job[i].part; SJ.dst[i] = dW[i]; SJ.S[i] = S; SJ.P4[i] = (long long)mk5[i][0] * mk5[i][1] / 4;
-    }
-    // bias column sums: same reduce (partials (S, M) -> dst (M))
-    const int cj[3] = {1, 3, 4};
-    float* db[3] = {a->db1, a->dbin, a->dbin + 2 * d};
-    for (int i = 0; i < 3; ++i) {
-      SJ.part[5 + i] = Gp.job[cj[i]].colpart; SJ.dst[5 + i] = db[i]; SJ.S[5 + i] = S; SJ.P4[5 + i] = mk5[cj[i]][0] / 4;
-    }
-    SJ.count = 8;                                        // reduced by the tail launch below
+    GD_TRY(grouped_dw_and_tail(a, s, w, c, n, n_pad, nb1, nb2, pbase));
   } else {
     GD_TRY(linear_dw_deferred(c, w.dqk, s.xpb, a->dWin, n_pad, 2 * d, d, (float*)w.part_w[3], SJ));
     GD_TRY(linear_dw_deferred(c, w.dv, s.xb, a->dWin + (size_t)2 * d * d, n_pad, d, d, (float*)w.part_w[4], SJ));
@@ -832,38 +939,18 @@ static int layer_bwd(const gdmae_layer_args* a, bool upstream3, bool defer_add3,
     J.x[1] = w.dqk; J.dst[1] = a->dbin;          J.C[1] = 2 * d;
     J.x[2] = w.dv;  J.dst[2] = a->dbin + 2 * d;  J.C[2] = d;
     GD_TRY(colsum_jobs(c, J, n, ff > 2 * d ? ff : 2 * d, (float*)w.cs_part));
-  }
-  // ---- LayerNorm / bias / temperature gradients
-  // the LayerNorm backward partials (workgroup rows x {dgamma, dbeta, column sums of dx}) are reduced here, together with dtau
-  AccJobs j;
-  const int nb_rows = gd_ln_partial_rows(n, d), nb_fused = (int)(n_pad / gd_tok_gemm_rows(d));
-  const int nb1 = fuse_ln ? nb_fused : nb_rows, nb2 = ln2_done ? nb_fused : nb_rows;
-  const float* p1 = (const float*)w.ln_ws;    // LayerNorm 1: dg1, dbe1, bias gradient of the out-projection
-  const float* p2 = (const float*)w.ln_ws2;   // LayerNorm 2: dg2, dbe2, bias gradient of the second FFN linear
-  float* dst[7] = {a->dg1, a->dbe1, a->dbo, a->dg2, a->dbe2, a->db2, a->dtau};
-  const float* src[7] = {p1, p1 + d, p1 + 2 * d, p2, p2 + d, p2 + 2 * d, (const float*)w.dtau};
-  int cols = 0;
-  for (int i = 0; i < 7; ++i) {
-    j.dst[i] = dst[i]; j.src[i] = src[i]; j.len[i] = i < 6 ? d : 1; j.nblk[i] = i < 3 ? nb1 : (i < 6 ? nb2 : 0); j.stride[i] = 3 * d;
-    cols += j.len[i];
-  }
-  j.count = 7;
-  if (grouped) {
-    TailJobs T;
-    T.J = SJ;
-    j.count = 6;                                         // dtau comes straight from the attention partials
-    cols -= 1;
-    T.a = j;
-    T.tau_part = (const float*)w.apart; T.n_part = pbase; T.tau = a->tau; T.tau_min = a->tau_min; T.dtau = a->dtau;
-    long long gx = (cols + 15) / 16;
-    for (int q = 0; q < SJ.count; ++q) gx = (SJ.P4[q] + 63) / 64 > gx ? (SJ.P4[q] + 63) / 64 : gx;
-    double tail_bytes = 4.0 * pbase;
-    for (int q = 0; q < SJ.count; ++q) tail_bytes += 16.0 * SJ.P4[q] * (SJ.S[q] + 2);
-    for (int q = 0; q < j.count; ++q) tail_bytes += 4.0 * j.len[q] * (j.nblk[q] + 2);
-    GdTimed timed(GD_T_LAYER_TAIL, c.st, tail_bytes);
-    hipLaunchKernelGGL(k_layer_tail, dim3((unsigned)gx, SJ.count + 2), dim3(256), 0, c.st, T);
-    GD_LAUNCH_CHECK();
-  } else {
+    // ---- LayerNorm / bias / temperature gradients from the LayerNorm backward partial rows
+    AccJobs j;
+    const float* p1 = (const float*)w.ln_ws;
+    const float* p2 = (const float*)w.ln_ws2;
+    float* dst[7] = {a->dg1, a->dbe1, a->dbo, a->dg2, a->dbe2, a->db2, a->dtau};
+    const float* src[7] = {p1, p1 + d, p1 + 2 * d, p2, p2 + d, p2 + 2 * d, (const float*)w.dtau};
+    int cols = 0;
+    for (int i = 0; i < 7; ++i) {
+      j.dst[i] = dst[i]; j.src[i] = src[i]; j.len[i] = i < 6 ? d : 1; j.nblk[i] = i < 3 ? nb1 : (i < 6 ? nb2 : 0); j.stride[i] = 3 * d;
+      cols += j.len[i];
+    }
+    j.count = 7;
     hipLaunchKernelGGL(k_acc_vectors, dim3((cols + 15) / 16), dim3(256), 0, c.st, j);
     GD_LAUNCH_CHECK();
   }
@@ -887,6 +974,42 @@ static int layer_bwd(const gdmae_layer_args* a, bool upstream3, bool defer_add3,
   return 0;
 }
 
+// Backward of stage_fwd_v2: per layer the feed-forward / LayerNorm-1 / out-projection launch, the attention backward, the grouped
+// weight gradients + tail, and the in-projection launch that also runs the LayerNorm-2 backward of the layer below (df of that
+// layer and its partial rows land in the shared scratch: dfb, ln_ws2).
+static int stage_bwd_v2(const gdmae_layer_args* layers, int n_layers, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  for (int i = n_layers - 1; i >= 0; --i) {
+    const gdmae_layer_args* a = &layers[i];
+    const long long n = a->n, n_pad = pad_rows(n);
+    const int d = a->d, ff = a->ff;
+    Saved s = saved_layout(a->saved, n_pad, d, ff, 2);
+    Scratch w = scratch_layout(a->scratch, n_pad, d, ff, 2, a->nhead);
+    Ctx c{st, HIP_R_16BF, 2, w.lt_ws};
+    const Packed pk = packed_layout(a->packed, d, ff);
+    if (i == n_layers - 1)
+      GD_TRY(gd_layer_fused_ln2_top(st, d, a->dy, s.x1b, s.f, (const float*)s.st2, a->g2, n, n_pad, w.dfb, (float*)w.ln_ws2));
+    GD_TRY(gd_layer_fused_bwd_ffn(st, d, w.dfb, s.h, s.xb, s.a, (const float*)s.st1, a->g1, pk.w2t, pk.w1t, pk.ot, n, n_pad, w.dh, s.gact,
+                                  w.dab, w.d_o, (float*)w.ln_ws));
+    long long pbase = 0;
+    for (int l = 0; l < a->n_levels; ++l) pbase += (long long)a->n_win[l] * a->nhead;
+    gd_attn_timing_tokens(n);
+    GD_TRY(gdmae_window_attention_levels_bwd(s.qk, s.v, w.d_o, w.dqk, w.dv, 1, (float*)w.apart, a->csr_tok, a->win_start, a->win_len,
+                                             a->n_levels, a->n_win, a->max_tokens, d, a->nhead, a->tau, a->tau_min, stream));
+    const int nb = (int)(n_pad / gd_layer_fused_rows(d));
+    GD_TRY(grouped_dw_and_tail(a, s, w, c, n, n_pad, nb, nb, pbase));
+    if (i > 0) {
+      const Saved sp = saved_layout(layers[i - 1].saved, n_pad, d, ff, 2);
+      GD_TRY(gd_layer_fused_bwd_in(st, d, w.dqk, w.dv, pk.qkt, pk.vt, w.dab, n, n_pad, sp.x1b, sp.f, (const float*)sp.st2, layers[i - 1].g2,
+                                   w.dfb, (float*)w.ln_ws2, nullptr));
+    } else {
+      GD_TRY(gd_layer_fused_bwd_in(st, d, w.dqk, w.dv, pk.qkt, pk.vt, w.dab, n, n_pad, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                   a->dx));
+    }
+  }
+  return 0;
+}
+
 extern "C" int gdmae_encoder_layer_bwd(const gdmae_layer_args* a, void* stream) {
   return layer_bwd(a, false, false, nullptr, false, stream);
 }
@@ -900,6 +1023,7 @@ extern "C" int gdmae_encoder_stage_bwd(const gdmae_layer_args* layers, int n_lay
     GD_REQUIRE(layers[i].scratch == layers[0].scratch && layers[i].n == layers[0].n && layers[i].d == layers[0].d &&
                    layers[i].ff == layers[0].ff && layers[i].bf16 == layers[0].bf16,
                "encoder stage: layers must share scratch, n, d, ff, dtype");
+  if (stage_v2(layers, n_layers)) return stage_bwd_v2(layers, n_layers, stream);
   // bf16 rows with packed weights: the LayerNorm-2 backward of layer i - 1 rides on layer i's last input-gradient GEMM
   bool chain = true;
   for (int i = 0; i < n_layers; ++i)

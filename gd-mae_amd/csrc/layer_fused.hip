@@ -1,0 +1,759 @@
+// Encoder layer around its bytes (reference pcdet/models/model_utils/sst_basic_block.py:57-84 EncoderLayer,
+// cosine_msa.py:56-62 packed in-projection): everything of a post-norm layer that is not the windowed attention itself is THREE
+// launches, and the residual stream between them is bf16 - a token row crosses HBM once per tensor the backward really needs.
+//
+//   forward   k_layer_fwd      a = o Wo^T + bo;  x1 = LN1(x + a);  h = x1 W1^T + b1;  f = gelu(h) W2^T + b2;  y = LN2(x1 + f)
+//                              in : o, x (bf16)                         out: a, x1, h, f (bf16, kept for the backward), row statistics,
+//                                                                            y (bf16) and y + pos (bf16) = the next layer's operands
+//   backward  k_layer_bwd_ffn  dh = (df W2) * gelu'(h);  g1 = df + dh W1;  da = LN1'(g1);  do = da Wo
+//                              in : df, h, x, a (bf16), statistics      out: dh, gelu(h) (operands of the weight gradients), da, do
+//             k_layer_bwd_in   gx = da + [dqk | dv] Win;  df' = LN2'(gx) of the layer BELOW (or dx, fp32, at the bottom of a stage)
+//                              in : dqk, dv, da, x1', f' (bf16)         out: df' (bf16) + its dgamma / dbeta / column-sum partial rows
+//             k_ln2_bwd_top    df = LN2'(dy) for the top layer of a stage (dy arrives in fp32 from the sparse-conv block above)
+//
+// Against the launch-per-product sequence of tok_gemm.hip (out-projection + LN1, feed-forward block, GELU backward, two LayerNorm
+// backward epilogues, two plain input-gradient products) a layer moves 60 d bytes per token instead of 106 d: the fp32 copies of
+// the residual stream and of its gradient are gone (LayerNorm re-normalises every half layer, so the stream is O(1) and its bf16
+// rounding is the rounding every GEMM operand already had), LN1's output lives in LDS between the out-projection and the
+// feed-forward block, and the gradient of the residual branch is the SAME tensor as the gradient of the branch (df is read once
+// as GEMM operand and once as addend from the tile in LDS).  Fused phases share one row tile per workgroup: 32 rows for d = 256,
+// 64 for d = 128, 8 wavefronts, weights streamed as MFMA A operands from the fragment-ordered images of tok_gemm_pack.
+#include "tok_tiles.h"
+
+namespace {
+
+// ---- one product of a row tile:  acc[j][b] (32 channels x 32 rows, fp32) += W (ND, KD) X^T, X = bf16 rows in LDS ---------------
+template <int KD, int ND, int ROWS>
+struct TlShape {
+  static constexpr int KS = KD / 16;                                    // k-steps
+  static constexpr int MB = ND / 32;                                    // 32-channel blocks of the output
+  static constexpr int MPW = MB >= TG_WAVES ? MB / TG_WAVES : 1;        // channel blocks per wavefront
+  static constexpr int NPW = MB >= TG_WAVES ? ROWS / 32 : 1;            // 32-row blocks per wavefront
+  static_assert(MB >= TG_WAVES || (MB * (ROWS / 32) == TG_WAVES), "every wavefront needs an output block");
+  __device__ static int mb0(int wv) { return MB >= TG_WAVES ? wv : (wv / (ROWS / 32)); }
+  __device__ static int nb0(int wv) { return MB >= TG_WAVES ? 0 : (wv % (ROWS / 32)); }
+};
+
+// fragment (ks, j) of a wavefront; the image of a second matrix continues the K dimension after KSPLIT k-steps (the q/k and v
+// halves of the packed in-projection are two images)
+template <int KD, int ND, int ROWS, int KSPLIT>
+__device__ __forceinline__ uint4 tl_wfrag(const uint4* __restrict__ w0, const uint4* __restrict__ w1, int ks, int j) {
+  using S = TlShape<KD, ND, ROWS>;
+  return ks < KSPLIT ? w0[((size_t)ks * S::MB + j * TG_WAVES) * 64] : w1[((size_t)(ks - KSPLIT) * S::MB + j * TG_WAVES) * 64];
+}
+
+template <int KD, int ND, int ROWS, int KSPLIT = KD / 16>
+struct TlProd {
+  using S = TlShape<KD, ND, ROWS>;
+  TgFrag wr[TG_PF + 1][S::MPW];
+  const uint4* __restrict__ w0;
+  const uint4* __restrict__ w1;
+  // first TG_PF k-steps of the weights: issued early (before a row pass or a tile load) so that their latency is hidden
+  __device__ __forceinline__ void prefetch(const uint4* W0, const uint4* W1, int wv, int lane) {
+    w0 = W0 + (size_t)S::mb0(wv) * 64 + lane;
+    w1 = W1 ? W1 + (size_t)S::mb0(wv) * 64 + lane : w0;
+#pragma unroll
+    for (int ks = 0; ks < TG_PF; ++ks)
+#pragma unroll
+      for (int j = 0; j < S::MPW; ++j) wr[ks][j].q = tl_wfrag<KD, ND, ROWS, KSPLIT>(w0, w1, ks, j);
+  }
+  __device__ __forceinline__ void run(const unsigned char* xs, int XP, int wv, int lane, f32x16 (&acc)[S::MPW][S::NPW]) {
+    const unsigned char* lb = xs + ((S::nb0(wv) * 32) + (lane & 31)) * XP + (lane >> 5) * 16;
+    TgFrag sf[2][S::NPW];
+#pragma unroll
+    for (int b = 0; b < S::NPW; ++b) sf[0][b].q = *(const uint4*)(lb + b * 32 * XP);
+#pragma unroll
+    for (int ks = 0; ks < S::KS; ++ks) {
+      if (ks + TG_PF < S::KS) {
+#pragma unroll
+        for (int j = 0; j < S::MPW; ++j) wr[(ks + TG_PF) % (TG_PF + 1)][j].q = tl_wfrag<KD, ND, ROWS, KSPLIT>(w0, w1, ks + TG_PF, j);
+      }
+      if (ks + 1 < S::KS) {
+#pragma unroll
+        for (int b = 0; b < S::NPW; ++b) sf[(ks + 1) & 1][b].q = *(const uint4*)(lb + b * 32 * XP + (ks + 1) * 32);
+      }
+#pragma unroll
+      for (int j = 0; j < S::MPW; ++j)
+#pragma unroll
+        for (int b = 0; b < S::NPW; ++b)
+          acc[j][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[ks % (TG_PF + 1)][j].v, sf[ks & 1][b].v, acc[j][b], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+};
+
+template <int MPW, int NPW>
+__device__ __forceinline__ void tl_zero(f32x16 (&acc)[MPW][NPW]) {
+#pragma unroll
+  for (int j = 0; j < MPW; ++j)
+#pragma unroll
+    for (int b = 0; b < NPW; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[j][b][i] = 0.f;
+}
+
+// accumulators (+ bias) -> bf16 -> LDS tile [row][channel] with row pitch SP
+template <int KD, int ND, int ROWS>
+__device__ __forceinline__ void tl_stage(const f32x16 (&acc)[TlShape<KD, ND, ROWS>::MPW][TlShape<KD, ND, ROWS>::NPW], const unsigned short* bias,
+                                         unsigned char* out, int SP, int wv, int lane) {
+  using S = TlShape<KD, ND, ROWS>;
+#pragma unroll
+  for (int j = 0; j < S::MPW; ++j) {
+    const int cb = (S::mb0(wv) + j * TG_WAVES) * 32 + 4 * (lane >> 5);
+#pragma unroll
+    for (int b = 0; b < S::NPW; ++b) {
+      const int row = (S::nb0(wv) + b) * 32 + (lane & 31);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[j][b][4 * q + e];
+        if (bias) {
+          const uint2 bq = *(const uint2*)(bias + cb + 8 * q);
+          v[0] += __uint_as_float(bq.x << 16); v[1] += __uint_as_float(bq.x & 0xFFFF0000u);
+          v[2] += __uint_as_float(bq.y << 16); v[3] += __uint_as_float(bq.y & 0xFFFF0000u);
+        }
+        uint2 o;
+        o.x = tg_pack2(v[0], v[1]);
+        o.y = tg_pack2(v[2], v[3]);
+        *(uint2*)(out + row * SP + (cb + 8 * q) * 2) = o;
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ void tl_unpack4(const uint2& q, float (&f)[4]) {
+  f[0] = __uint_as_float(q.x << 16); f[1] = __uint_as_float(q.x & 0xFFFF0000u);
+  f[2] = __uint_as_float(q.y << 16); f[3] = __uint_as_float(q.y & 0xFFFF0000u);
+}
+__device__ __forceinline__ uint2 tl_pack4(const float (&f)[4]) {
+  uint2 q;
+  q.x = tg_pack2(f[0], f[1]); q.y = tg_pack2(f[2], f[3]);
+  return q;
+}
+
+template <int D>
+struct TlRows {
+  static constexpr int ROWS = D >= 256 ? 32 : 64;
+  static constexpr int LPR = D / 4;                 // lanes per row in the LayerNorm passes (4 consecutive columns per lane)
+  static constexpr int LRPP = 512 / LPR;            // rows per pass
+  static constexpr int LPASS = ROWS / LRPP;
+};
+
+// LayerNorm forward of one row piece: s[4] -> o[4]; returns (mean, rstd)
+template <int D>
+__device__ __forceinline__ float2 tl_ln_fwd(const float (&s)[4], const float (&g)[4], const float (&bt)[4], float eps, float (&o)[4]) {
+  constexpr int LPR = TlRows<D>::LPR;
+  const float mean = tg_group_sum<LPR>((s[0] + s[1]) + (s[2] + s[3])) * (1.f / D);
+  float sq = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float dlt = s[k] - mean;
+    sq = fmaf(dlt, dlt, sq);
+  }
+  const float rstd = rsqrtf(tg_group_sum<LPR>(sq) * (1.f / D) + eps);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) o[k] = (s[k] - mean) * rstd * g[k] + bt[k];
+  return make_float2(mean, rstd);
+}
+
+// LayerNorm backward over the rows of a tile: per-thread accumulators of dgamma / dbeta / column sums of dx, one partial row
+// per workgroup (arithmetic and association order of k_add_ln_bwd, layernorm.hip)
+template <int D>
+struct TlLnBwd {
+  float dg[4], db[4], dsx[4];
+  __device__ __forceinline__ void init() {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dg[k] = db[k] = dsx[k] = 0.f;
+  }
+  // d: gradient of the LayerNorm output (zeroed here when the row is padding); xa + xb: the LayerNorm input
+  __device__ __forceinline__ void row(float (&d)[4], bool live, const uint2& xa, const uint2& xb, const float2& st, const float (&g)[4],
+                                      float (&o)[4]) {
+    constexpr int LPR = TlRows<D>::LPR;
+    float sa[4], sb[4];
+    tl_unpack4(xa, sa);
+    tl_unpack4(xb, sb);
+    const float mean = st.x, rstd = st.y;
+    float gy[4], xh[4], m1 = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (!live) d[k] = 0.f;
+      xh[k] = (sa[k] + sb[k] - mean) * rstd;
+      gy[k] = d[k] * g[k];
+      m1 += gy[k];
+      m2 = fmaf(gy[k], xh[k], m2);
+      dg[k] = fmaf(d[k], xh[k], dg[k]);
+      db[k] += d[k];
+    }
+    m1 = tg_group_sum<LPR>(m1) * (1.f / D);
+    m2 = tg_group_sum<LPR>(m2) * (1.f / D);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      o[k] = live ? rstd * (gy[k] - m1 - xh[k] * m2) : 0.f;
+      dsx[k] += o[k];
+    }
+  }
+  // red: LDS, LRPP x 3 x D floats, free for use by every thread once the caller's barrier has passed; contains two barriers
+  __device__ __forceinline__ void finish(float* red, float* part_row, int tid) {
+    constexpr int LPR = TlRows<D>::LPR, LRPP = TlRows<D>::LRPP;
+    const int c0 = 4 * (tid % LPR), r = tid / LPR;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      red[(r * 3 + 0) * D + c0 + k] = dg[k];
+      red[(r * 3 + 1) * D + c0 + k] = db[k];
+      red[(r * 3 + 2) * D + c0 + k] = dsx[k];
+    }
+    __syncthreads();
+    for (int c = tid; c < 3 * D; c += 512) {
+      float a = 0.f;
+#pragma unroll
+      for (int q = 0; q < LRPP; ++q) a += red[q * 3 * D + c];
+      part_row[c] = a;
+    }
+  }
+};
+
+// rows of a bf16 (n_pad, W) matrix -> LDS tile, 16 bytes per thread and access; c_off: first column of the tile (bytes)
+template <int W, int ROWS>
+__device__ __forceinline__ void tl_load_tile(const unsigned short* __restrict__ src, long long row0, unsigned char* dst, int P, int c_off, int tid) {
+  constexpr int CPR = W / 8, RPP = 512 / CPR;
+  static_assert(ROWS % RPP == 0 || RPP > ROWS, "tile load");
+  const int c = tid % CPR, r = tid / CPR;
+#pragma unroll
+  for (int p = 0; p < (ROWS + RPP - 1) / RPP; ++p) {
+    const int row = p * RPP + r;
+    if (RPP > ROWS && row >= ROWS) break;
+    *(uint4*)(dst + row * P + c_off + c * 16) = *(const uint4*)(src + (row0 + row) * W + c * 8);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+struct LfArgs {
+  const unsigned short* o;       // (n_pad, D) attention output
+  const unsigned short* x;       // (n_pad, D) layer input = residual of LayerNorm 1
+  const uint4 *Wo, *W1, *W2;     // packed (D, D), (FF, D), (D, FF)
+  const unsigned short *bo, *b1, *b2;
+  const float *g1, *be1, *g2, *be2;
+  float eps;
+  long long n, n_pad;
+  unsigned short *a, *x1, *h, *f;   // kept for the backward: branch outputs (the LayerNorm addends), LN1 output, pre-activation
+  float *st1, *st2;                 // (n, 2) mean, rstd
+  float* y;                         // optional (n, D) fp32: output of the stage's last layer
+  unsigned short* y_bf;             // optional (n_pad, D): the next layer's v / residual operand
+  unsigned short* ypos_bf;          // optional (n_pad, D): the next layer's q / k operand, bf16(y + pos_table[tok_pos[row]])
+  const float* pos_table;
+  const int* tok_pos;
+};
+
+template <int D>
+__global__ __launch_bounds__(512, 4) void k_layer_fwd(LfArgs A) {
+  constexpr int FF = 2 * D;
+  using R = TlRows<D>;
+  constexpr int ROWS = R::ROWS, LPR = R::LPR, LRPP = R::LRPP, LPASS = R::LPASS;
+  constexpr int XP = D * 2 + 16, HP = FF * 2 + 16;
+  extern __shared__ __align__(16) unsigned char lds[];
+  unsigned char* const xl = lds;                     // o tile -> a (staging) -> x1 tile -> f (staging)
+  unsigned char* const hl = lds + ROWS * XP;         // h (staging) -> gelu(h) tile
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const long long row0 = (long long)blockIdx.x * ROWS;
+  const int lc0 = 4 * (tid % LPR), lr = tid / LPR;
+
+  TlProd<D, D, ROWS> pa;
+  pa.prefetch(A.Wo, nullptr, wv, lane);
+  uint2 res_pf[LPASS];
+  int pos_pf[LPASS];
+#pragma unroll
+  for (int p = 0; p < LPASS; ++p) {
+    const long long row = row0 + p * LRPP + lr;
+    const long long rr = row < A.n ? row : A.n - 1;
+    res_pf[p] = *(const uint2*)(A.x + rr * D + lc0);
+    pos_pf[p] = A.ypos_bf ? A.tok_pos[rr] : 0;
+  }
+  tl_load_tile<D, ROWS>(A.o, row0, xl, XP, 0, tid);
+  __syncthreads();
+  // ---- a = o Wo^T + bo
+  {
+    f32x16 acc[1][TlShape<D, D, ROWS>::NPW];
+    tl_zero(acc);
+    pa.run(xl, XP, wv, lane, acc);
+    __syncthreads();                                 // every wavefront is done with the o tile
+    tl_stage<D, D, ROWS>(acc, A.bo, xl, XP, wv, lane);
+  }
+  TlProd<D, FF, ROWS> pb;
+  pb.prefetch(A.W1, nullptr, wv, lane);
+  __syncthreads();
+  // ---- x1 = LN1(x + a): a leaves for HBM, x1 replaces it in LDS (operand tile of linear1) and is the residual of LN2
+  uint2 x1_keep[LPASS];
+  {
+    const float4 g4 = *(const float4*)(A.g1 + lc0), b4 = *(const float4*)(A.be1 + lc0);
+    const float g[4] = {g4.x, g4.y, g4.z, g4.w}, bt[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+    for (int p = 0; p < LPASS; ++p) {
+      const int rl = p * LRPP + lr;
+      const long long row = row0 + rl;
+      const bool live = row < A.n;
+      const uint2 fq = *(const uint2*)(xl + rl * XP + lc0 * 2);
+      float s[4], r4[4], o[4];
+      tl_unpack4(fq, s);
+      tl_unpack4(res_pf[p], r4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) s[k] += r4[k];
+      const float2 st = tl_ln_fwd<D>(s, g, bt, A.eps, o);
+      uint2 q = tl_pack4(o);
+      if (!live) q = make_uint2(0u, 0u);             // pad rows: zero operand rows (garbage attention rows stay out of the tile)
+      *(uint2*)(xl + rl * XP + lc0 * 2) = q;
+      x1_keep[p] = q;
+      if (live) {
+        TG_ST_U2(A.a + row * D + lc0, fq);
+        TG_ST_U2(A.x1 + row * D + lc0, q);
+        if (lc0 == 0) *(float2*)(A.st1 + row * 2) = st;
+      }
+    }
+  }
+  __syncthreads();
+  // ---- h = x1 W1^T + b1
+  {
+    f32x16 acc[TlShape<D, FF, ROWS>::MPW][TlShape<D, FF, ROWS>::NPW];
+    tl_zero(acc);
+    pb.run(xl, XP, wv, lane, acc);
+    tl_stage<D, FF, ROWS>(acc, A.b1, hl, HP, wv, lane);
+  }
+  TlProd<FF, D, ROWS> pc;
+  pc.prefetch(A.W2, nullptr, wv, lane);
+  __syncthreads();
+  // ---- h leaves for HBM (the backward differentiates the GELU at it), gelu(h) replaces it in LDS
+  {
+    constexpr int CPR = FF / 8, RPP = 512 / CPR;
+    const int c = tid % CPR, r = tid / CPR;
+#pragma unroll
+    for (int p = 0; p < ROWS / RPP; ++p) {
+      const int rl = p * RPP + r;
+      const uint4 q = *(const uint4*)(hl + rl * HP + c * 16);
+      TG_ST_U4(A.h + (row0 + rl) * FF + c * 8, q);
+      float v[8];
+      tg_unpack8(q, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = tg_gelu(v[j]);
+      *(uint4*)(hl + rl * HP + c * 16) = tg_pack8(v);
+    }
+  }
+  __syncthreads();
+  // ---- f = gelu(h) W2^T + b2  (staged over the x1 tile: nobody reads it any more)
+  {
+    f32x16 acc[1][TlShape<FF, D, ROWS>::NPW];
+    tl_zero(acc);
+    pc.run(hl, HP, wv, lane, acc);
+    tl_stage<FF, D, ROWS>(acc, A.b2, xl, XP, wv, lane);
+  }
+  __syncthreads();
+  // ---- y = LN2(x1 + f)
+  {
+    const float4 g4 = *(const float4*)(A.g2 + lc0), b4 = *(const float4*)(A.be2 + lc0);
+    const float g[4] = {g4.x, g4.y, g4.z, g4.w}, bt[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+    for (int p = 0; p < LPASS; ++p) {
+      const int rl = p * LRPP + lr;
+      const long long row = row0 + rl;
+      const bool live = row < A.n;
+      const uint2 fq = *(const uint2*)(xl + rl * XP + lc0 * 2);
+      float s[4], r4[4], o[4];
+      tl_unpack4(fq, s);
+      tl_unpack4(x1_keep[p], r4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) s[k] += r4[k];
+      const float2 st = tl_ln_fwd<D>(s, g, bt, A.eps, o);
+      if (!live) continue;
+      const long long e = row * D + lc0;
+      TG_ST_U2(A.f + e, fq);
+      if (A.y) TG_ST_F4(A.y + e, o[0], o[1], o[2], o[3]);
+      if (A.y_bf) *(uint2*)(A.y_bf + e) = tl_pack4(o);
+      if (A.ypos_bf) {
+        const float4 p4 = *(const float4*)(A.pos_table + (long long)pos_pf[p] * D + lc0);
+        const float op[4] = {o[0] + p4.x, o[1] + p4.y, o[2] + p4.z, o[3] + p4.w};
+        *(uint2*)(A.ypos_bf + e) = tl_pack4(op);
+      }
+      if (lc0 == 0) *(float2*)(A.st2 + row * 2) = st;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward, feed-forward block + LayerNorm 1 + out-projection
+// ------------------------------------------------------------------------------------------------
+struct LbArgs {
+  const unsigned short* df;      // (n_pad, D) gradient of the LayerNorm-2 input: of f AND of the residual x1
+  const unsigned short* h;       // (n_pad, FF)
+  const unsigned short *x, *a;   // LayerNorm-1 addends
+  const float* st1;
+  const float* g1;
+  const uint4 *W2t, *W1t, *Wot;  // packed (FF, D), (D, FF), (D, D): transposes of W2, W1, Wo
+  long long n, n_pad;
+  unsigned short *dh, *gact;     // (n_pad, FF): operands of the weight gradients of linear1 / linear2
+  unsigned short *da, *d_o;      // (n_pad, D): gradient of the LayerNorm-1 input (of a and of the residual x), and of the attention output
+  float* part;                   // (n_pad / ROWS, 3, D) partial rows of dgamma1 / dbeta1 / column sums of da
+};
+
+template <int D>
+__global__ __launch_bounds__(512, 4) void k_layer_bwd_ffn(LbArgs A) {
+  constexpr int FF = 2 * D;
+  using R = TlRows<D>;
+  constexpr int ROWS = R::ROWS, LPR = R::LPR, LRPP = R::LRPP, LPASS = R::LPASS;
+  constexpr int XP = D * 2 + 16, HP = FF * 2 + 16;
+  static_assert(LRPP * 3 * D * 4 <= ROWS * HP, "partial-row reduction fits the hidden tile");
+  extern __shared__ __align__(16) unsigned char lds[];
+  unsigned char* const gl = lds;                     // df tile -> dx1 (staging) -> da tile -> do (staging)
+  unsigned char* const hl = lds + ROWS * XP;         // dg (staging) -> dh tile -> reduction scratch
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const long long row0 = (long long)blockIdx.x * ROWS;
+  const int lc0 = 4 * (tid % LPR), lr = tid / LPR;
+
+  TlProd<D, FF, ROWS> pa;
+  pa.prefetch(A.W2t, nullptr, wv, lane);
+  // operands of the row passes that do not depend on the products: requested now
+  constexpr int HCPR = FF / 8, HRPP = 512 / HCPR, HPASS = ROWS / HRPP;
+  const int hc = tid % HCPR, hr = tid / HCPR;
+  uint4 h_pf[HPASS];
+#pragma unroll
+  for (int p = 0; p < HPASS; ++p) h_pf[p] = tg_ld_u4_once(A.h + (row0 + p * HRPP + hr) * FF + hc * 8);
+  tl_load_tile<D, ROWS>(A.df, row0, gl, XP, 0, tid);
+  __syncthreads();
+  // ---- dg = df W2
+  {
+    f32x16 acc[TlShape<D, FF, ROWS>::MPW][TlShape<D, FF, ROWS>::NPW];
+    tl_zero(acc);
+    pa.run(gl, XP, wv, lane, acc);
+    tl_stage<D, FF, ROWS>(acc, nullptr, hl, HP, wv, lane);
+  }
+  TlProd<FF, D, ROWS> pb;
+  pb.prefetch(A.W1t, nullptr, wv, lane);
+  // operands of the LayerNorm pass: in flight behind the GELU pass and the second product (requested here, not at the top,
+  // to stay inside 128 registers during the first product)
+  uint2 dy_pf[LPASS], xa_pf[LPASS], xb_pf[LPASS];
+  float2 st_pf[LPASS];
+#pragma unroll
+  for (int p = 0; p < LPASS; ++p) {
+    const long long row = row0 + p * LRPP + lr;
+    const long long rr = row < A.n ? row : A.n - 1;
+    dy_pf[p] = *(const uint2*)(A.df + rr * D + lc0);
+    xa_pf[p] = tg_ld_u2_once(A.x + rr * D + lc0);
+    xb_pf[p] = tg_ld_u2_once(A.a + rr * D + lc0);
+    st_pf[p] = *(const float2*)(A.st1 + rr * 2);
+  }
+  __syncthreads();
+  // ---- dh = dg * gelu'(h) (operand tile of the next product, and of linear1's weight gradient); gelu(h) for linear2's
+#pragma unroll
+  for (int p = 0; p < HPASS; ++p) {
+    const int rl = p * HRPP + hr;
+    const long long e = (row0 + rl) * FF + hc * 8;
+    const uint4 q = *(const uint4*)(hl + rl * HP + hc * 16);
+    float g[8], v[8];
+    tg_unpack8(q, g);
+    tg_unpack8(h_pf[p], v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) g[j] = g[j] * tg_gelu_grad(v[j]);
+    const uint4 dq = tg_pack8(g);
+    *(uint4*)(hl + rl * HP + hc * 16) = dq;
+    *(uint4*)(A.dh + e) = dq;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = tg_gelu(v[j]);
+    *(uint4*)(A.gact + e) = tg_pack8(v);
+  }
+  __syncthreads();
+  // ---- dx1 = dh W1 (staged over the df tile: its rows are in registers)
+  {
+    f32x16 acc[1][TlShape<FF, D, ROWS>::NPW];
+    tl_zero(acc);
+    pb.run(hl, HP, wv, lane, acc);
+    tl_stage<FF, D, ROWS>(acc, nullptr, gl, XP, wv, lane);
+  }
+  TlProd<D, D, ROWS> pc;
+  pc.prefetch(A.Wot, nullptr, wv, lane);
+  __syncthreads();                                   // staging complete; every wavefront is done with the dh tile
+  // ---- da = LN1'(df + dx1)
+  {
+    const float4 g4 = *(const float4*)(A.g1 + lc0);
+    const float g[4] = {g4.x, g4.y, g4.z, g4.w};
+    TlLnBwd<D> L;
+    L.init();
+#pragma unroll
+    for (int p = 0; p < LPASS; ++p) {
+      const int rl = p * LRPP + lr;
+      const long long row = row0 + rl;
+      const bool live = row < A.n;
+      const uint2 fq = *(const uint2*)(gl + rl * XP + lc0 * 2);
+      float d[4], d2[4], o[4];
+      tl_unpack4(dy_pf[p], d);
+      tl_unpack4(fq, d2);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) d[k] += d2[k];
+      L.row(d, live, xa_pf[p], xb_pf[p], st_pf[p], g, o);
+      const uint2 q = tl_pack4(o);
+      *(uint2*)(gl + rl * XP + lc0 * 2) = q;
+      if (live) *(uint2*)(A.da + row * D + lc0) = q;
+    }
+    L.finish(reinterpret_cast<float*>(hl), A.part + (long long)blockIdx.x * 3 * D, tid);   // its barrier also publishes the da tile
+  }
+  // ---- do = da Wo
+  {
+    f32x16 acc[1][TlShape<D, D, ROWS>::NPW];
+    tl_zero(acc);
+    pc.run(gl, XP, wv, lane, acc);
+    __syncthreads();                                 // every wavefront is done with the da tile
+    tl_stage<D, D, ROWS>(acc, nullptr, gl, XP, wv, lane);
+  }
+  __syncthreads();
+  {
+    constexpr int CPR = D / 8, RPP = 512 / CPR;
+    const int c = tid % CPR, r = tid / CPR;
+#pragma unroll
+    for (int p = 0; p < (ROWS + RPP - 1) / RPP; ++p) {
+      const int rl = p * RPP + r;
+      if (RPP > ROWS && rl >= ROWS) break;
+      *(uint4*)(A.d_o + (row0 + rl) * D + c * 8) = *(const uint4*)(gl + rl * XP + c * 16);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward, in-projection + the LayerNorm-2 backward of the layer below (or the fp32 input gradient of the stage)
+// ------------------------------------------------------------------------------------------------
+struct LiArgs {
+  const unsigned short *dqk, *dv;   // (n_pad, 2 D), (n_pad, D)
+  const uint4 *Wqkt, *Wvt;          // packed (D, 2 D), (D, D): transposes of Win[:2d], Win[2d:]
+  const unsigned short* dres;       // (n_pad, D) gradient through the residual branch (da of this layer)
+  long long n, n_pad;
+  // LN = true: LayerNorm 2 of the layer below
+  const unsigned short *ln_a, *ln_b;
+  const float* st;
+  const float* gamma;
+  unsigned short* dout;             // (n_pad, D) gradient of that LayerNorm's input
+  float* part;
+  // LN = false
+  float* dx;                        // (n, D) fp32
+};
+
+template <int D, bool LN>
+__global__ __launch_bounds__(512, 4) void k_layer_bwd_in(LiArgs A) {
+  using R = TlRows<D>;
+  constexpr int ROWS = R::ROWS, LPR = R::LPR, LRPP = R::LRPP, LPASS = R::LPASS;
+  constexpr int KD = 3 * D, XP = KD * 2 + 16, SP = D * 2 + 16;
+  static_assert(LRPP * 3 * D * 4 + ROWS * SP <= ROWS * XP, "staging tile + reduction scratch fit the operand tile");
+  extern __shared__ __align__(16) unsigned char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const long long row0 = (long long)blockIdx.x * ROWS;
+  const int lc0 = 4 * (tid % LPR), lr = tid / LPR;
+
+  TlProd<KD, D, ROWS, 2 * D / 16> pa;
+  pa.prefetch(A.Wqkt, A.Wvt, wv, lane);
+  uint2 dy_pf[LPASS], xa_pf[LN ? LPASS : 1], xb_pf[LN ? LPASS : 1];
+  float2 st_pf[LN ? LPASS : 1];
+#pragma unroll
+  for (int p = 0; p < LPASS; ++p) {
+    const long long row = row0 + p * LRPP + lr;
+    const long long rr = row < A.n ? row : A.n - 1;
+    dy_pf[p] = *(const uint2*)(A.dres + rr * D + lc0);
+    if (LN) {
+      xa_pf[p] = tg_ld_u2_once(A.ln_a + rr * D + lc0);
+      xb_pf[p] = tg_ld_u2_once(A.ln_b + rr * D + lc0);
+      st_pf[p] = *(const float2*)(A.st + rr * 2);
+    }
+  }
+  tl_load_tile<2 * D, ROWS>(A.dqk, row0, lds, XP, 0, tid);
+  tl_load_tile<D, ROWS>(A.dv, row0, lds, XP, 4 * D, tid);
+  __syncthreads();
+  {
+    f32x16 acc[1][TlShape<KD, D, ROWS>::NPW];
+    tl_zero(acc);
+    pa.run(lds, XP, wv, lane, acc);
+    __syncthreads();
+    tl_stage<KD, D, ROWS>(acc, nullptr, lds, SP, wv, lane);
+  }
+  __syncthreads();
+  if (LN) {
+    const float4 g4 = *(const float4*)(A.gamma + lc0);
+    const float g[4] = {g4.x, g4.y, g4.z, g4.w};
+    TlLnBwd<D> L;
+    L.init();
+#pragma unroll
+    for (int p = 0; p < LPASS; ++p) {
+      const int rl = p * LRPP + lr;
+      const long long row = row0 + rl;
+      const bool live = row < A.n;
+      const uint2 fq = *(const uint2*)(lds + rl * SP + lc0 * 2);
+      float d[4], d2[4], o[4];
+      tl_unpack4(dy_pf[p], d);
+      tl_unpack4(fq, d2);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) d[k] += d2[k];
+      L.row(d, live, xa_pf[p], xb_pf[p], st_pf[p], g, o);
+      if (live) *(uint2*)(A.dout + row * D + lc0) = tl_pack4(o);
+    }
+    L.finish(reinterpret_cast<float*>(lds + ROWS * SP), A.part + (long long)blockIdx.x * 3 * D, tid);
+  } else {
+#pragma unroll
+    for (int p = 0; p < LPASS; ++p) {
+      const int rl = p * LRPP + lr;
+      const long long row = row0 + rl;
+      if (row >= A.n) continue;
+      const uint2 fq = *(const uint2*)(lds + rl * SP + lc0 * 2);
+      float d[4], d2[4];
+      tl_unpack4(dy_pf[p], d);
+      tl_unpack4(fq, d2);
+      TG_ST_F4(A.dx + row * D + lc0, d[0] + d2[0], d[1] + d2[1], d[2] + d2[2], d[3] + d2[3]);
+    }
+  }
+}
+
+// df = LN2'(dy) for the top layer of a stage: dy (n, D) fp32, LayerNorm input = x1 + f (bf16), same row tiles / partial rows
+struct LtArgs {
+  const float* dy;
+  const unsigned short *ln_a, *ln_b;
+  const float* st;
+  const float* gamma;
+  long long n;
+  unsigned short* dout;
+  float* part;
+};
+template <int D>
+__global__ __launch_bounds__(512) void k_ln2_bwd_top(LtArgs A) {
+  using R = TlRows<D>;
+  constexpr int ROWS = R::ROWS, LPR = R::LPR, LRPP = R::LRPP, LPASS = R::LPASS;
+  __shared__ float red[LRPP * 3 * D];
+  const int tid = threadIdx.x;
+  const long long row0 = (long long)blockIdx.x * ROWS;
+  const int lc0 = 4 * (tid % LPR), lr = tid / LPR;
+  const float4 g4 = *(const float4*)(A.gamma + lc0);
+  const float g[4] = {g4.x, g4.y, g4.z, g4.w};
+  TlLnBwd<D> L;
+  L.init();
+#pragma unroll
+  for (int p = 0; p < LPASS; ++p) {
+    const long long row = row0 + p * LRPP + lr;
+    const bool live = row < A.n;
+    const long long rr = live ? row : A.n - 1;
+    const float4 d4 = *(const float4*)(A.dy + rr * D + lc0);
+    float d[4] = {d4.x, d4.y, d4.z, d4.w}, o[4];
+    L.row(d, live, tg_ld_u2_once(A.ln_a + rr * D + lc0), tg_ld_u2_once(A.ln_b + rr * D + lc0), *(const float2*)(A.st + rr * 2), g, o);
+    if (live) *(uint2*)(A.dout + row * D + lc0) = tl_pack4(o);
+  }
+  L.finish(red, A.part + (long long)blockIdx.x * 3 * D, tid);
+}
+
+template <typename K>
+int set_lds(K kernel, int bytes) {
+  GD_CHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  return 0;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// internal front end (encoder_layer.hip)
+// ------------------------------------------------------------------------------------------------
+bool gd_layer_fused_supported(int d, int ff) { return (d == 128 || d == 256) && ff == 2 * d; }
+int gd_layer_fused_rows(int d) { return d >= 256 ? 32 : 64; }
+
+int gd_layer_fused_fwd(hipStream_t st, int d, const void* o, const void* x, const void* Wo, const void* W1, const void* W2, const void* bo,
+                       const void* b1, const void* b2, const float* g1, const float* be1, const float* g2, const float* be2, float eps,
+                       long long n, long long n_pad, void* a, void* x1, void* h, void* f, float* st1, float* st2, float* y, void* y_bf,
+                       void* ypos_bf, const float* pos_table, const int* tok_pos) {
+  LfArgs A = {};
+  A.o = (const unsigned short*)o; A.x = (const unsigned short*)x;
+  A.Wo = (const uint4*)Wo; A.W1 = (const uint4*)W1; A.W2 = (const uint4*)W2;
+  A.bo = (const unsigned short*)bo; A.b1 = (const unsigned short*)b1; A.b2 = (const unsigned short*)b2;
+  A.g1 = g1; A.be1 = be1; A.g2 = g2; A.be2 = be2; A.eps = eps; A.n = n; A.n_pad = n_pad;
+  A.a = (unsigned short*)a; A.x1 = (unsigned short*)x1; A.h = (unsigned short*)h; A.f = (unsigned short*)f; A.st1 = st1; A.st2 = st2;
+  A.y = y; A.y_bf = (unsigned short*)y_bf; A.ypos_bf = (unsigned short*)ypos_bf; A.pos_table = pos_table; A.tok_pos = tok_pos;
+  const int rows = gd_layer_fused_rows(d), ff = 2 * d;
+  const int lds = rows * (d * 2 + 16) + rows * (ff * 2 + 16);
+  // o, x in; a, x1, h, f, (y | y_bf + ypos_bf) out; three weight images
+  GdTimed timed(GD_T_TOK_GEMM, st,
+                2.0 * n_pad * d + (double)n * d * (2 + 2 + 2 + 2 + (y ? 4 : 0) + (y_bf ? 2 : 0) + (ypos_bf ? 2 : 0)) + 2.0 * n_pad * ff + 16.0 * n +
+                    (ypos_bf ? 4.0 * n : 0.0) + 2.0 * (d * d + 2.0 * d * ff),
+                2.0 * n_pad * (d * d + 2.0 * d * ff));
+  static bool once[2] = {false, false};
+  if (d == 128) {
+    if (!once[0]) { if (int rc = set_lds(k_layer_fwd<128>, lds)) return rc; once[0] = true; }
+    hipLaunchKernelGGL(k_layer_fwd<128>, dim3((unsigned)(n_pad / rows)), dim3(512), lds, st, A);
+  } else if (d == 256) {
+    if (!once[1]) { if (int rc = set_lds(k_layer_fwd<256>, lds)) return rc; once[1] = true; }
+    hipLaunchKernelGGL(k_layer_fwd<256>, dim3((unsigned)(n_pad / rows)), dim3(512), lds, st, A);
+  } else {
+    GD_REQUIRE(false, "layer_fused_fwd: d must be 128 or 256");
+  }
+  GD_LAUNCH_CHECK();
+  return 0;
+}
+
+int gd_layer_fused_bwd_ffn(hipStream_t st, int d, const void* df, const void* h, const void* x, const void* a, const float* st1, const float* g1,
+                           const void* W2t, const void* W1t, const void* Wot, long long n, long long n_pad, void* dh, void* gact, void* da,
+                           void* d_o, float* part) {
+  LbArgs A = {};
+  A.df = (const unsigned short*)df; A.h = (const unsigned short*)h; A.x = (const unsigned short*)x; A.a = (const unsigned short*)a;
+  A.st1 = st1; A.g1 = g1; A.W2t = (const uint4*)W2t; A.W1t = (const uint4*)W1t; A.Wot = (const uint4*)Wot; A.n = n; A.n_pad = n_pad;
+  A.dh = (unsigned short*)dh; A.gact = (unsigned short*)gact; A.da = (unsigned short*)da; A.d_o = (unsigned short*)d_o; A.part = part;
+  const int rows = gd_layer_fused_rows(d), ff = 2 * d;
+  const int lds = rows * (d * 2 + 16) + rows * (ff * 2 + 16);
+  // df, h, x, a in; dh, gelu(h), da, do out; partial rows; three weight images
+  GdTimed timed(GD_T_TOK_GEMM, st,
+                2.0 * n_pad * d + 2.0 * n_pad * ff + (double)n * d * (2 + 2 + 2) + 2.0 * n_pad * d + 4.0 * n_pad * ff + 8.0 * n +
+                    12.0 * d * (double)(n_pad / rows) + 2.0 * (d * d + 2.0 * d * ff),
+                2.0 * n_pad * (d * d + 2.0 * d * ff));
+  static bool once[2] = {false, false};
+  if (d == 128) {
+    if (!once[0]) { if (int rc = set_lds(k_layer_bwd_ffn<128>, lds)) return rc; once[0] = true; }
+    hipLaunchKernelGGL(k_layer_bwd_ffn<128>, dim3((unsigned)(n_pad / rows)), dim3(512), lds, st, A);
+  } else if (d == 256) {
+    if (!once[1]) { if (int rc = set_lds(k_layer_bwd_ffn<256>, lds)) return rc; once[1] = true; }
+    hipLaunchKernelGGL(k_layer_bwd_ffn<256>, dim3((unsigned)(n_pad / rows)), dim3(512), lds, st, A);
+  } else {
+    GD_REQUIRE(false, "layer_fused_bwd_ffn: d must be 128 or 256");
+  }
+  GD_LAUNCH_CHECK();
+  return 0;
+}
+
+// LN: dout (n_pad, d) bf16 + part; otherwise dx (n, d) fp32
+int gd_layer_fused_bwd_in(hipStream_t st, int d, const void* dqk, const void* dv, const void* Wqkt, const void* Wvt, const void* dres, long long n,
+                          long long n_pad, const void* ln_a, const void* ln_b, const float* stats, const float* gamma, void* dout, float* part,
+                          float* dx) {
+  LiArgs A = {};
+  A.dqk = (const unsigned short*)dqk; A.dv = (const unsigned short*)dv; A.Wqkt = (const uint4*)Wqkt; A.Wvt = (const uint4*)Wvt;
+  A.dres = (const unsigned short*)dres; A.n = n; A.n_pad = n_pad; A.ln_a = (const unsigned short*)ln_a; A.ln_b = (const unsigned short*)ln_b;
+  A.st = stats; A.gamma = gamma; A.dout = (unsigned short*)dout; A.part = part; A.dx = dx;
+  const bool ln = dx == nullptr;
+  const int rows = gd_layer_fused_rows(d);
+  const int lds = rows * (3 * d * 2 + 16);
+  GdTimed timed(GD_T_TOK_GEMM, st,
+                2.0 * n_pad * 3 * d + (double)n * d * (2 + (ln ? 2 + 2 + 2 : 4)) + (ln ? 8.0 * n + 12.0 * d * (double)(n_pad / rows) : 0.0) +
+                    2.0 * 3 * d * d,
+                2.0 * n_pad * 3 * d * d);
+  static bool once[4] = {false, false, false, false};
+#define LI_CASE(D_, LN_, idx)                                                                                   \
+  {                                                                                                             \
+    if (!once[idx]) { if (int rc = set_lds(k_layer_bwd_in<D_, LN_>, lds)) return rc; once[idx] = true; }        \
+    hipLaunchKernelGGL((k_layer_bwd_in<D_, LN_>), dim3((unsigned)(n_pad / rows)), dim3(512), lds, st, A);       \
+  }
+  if (d == 128 && ln) LI_CASE(128, true, 0)
+  else if (d == 128) LI_CASE(128, false, 1)
+  else if (d == 256 && ln) LI_CASE(256, true, 2)
+  else if (d == 256) LI_CASE(256, false, 3)
+  else GD_REQUIRE(false, "layer_fused_bwd_in: d must be 128 or 256");
+#undef LI_CASE
+  GD_LAUNCH_CHECK();
+  return 0;
+}
+
+int gd_layer_fused_ln2_top(hipStream_t st, int d, const float* dy, const void* ln_a, const void* ln_b, const float* stats, const float* gamma,
+                           long long n, long long n_pad, void* dout, float* part) {
+  LtArgs A = {dy, (const unsigned short*)ln_a, (const unsigned short*)ln_b, stats, gamma, n, (unsigned short*)dout, part};
+  const int rows = gd_layer_fused_rows(d);
+  GdTimed timed(GD_T_TOK_GEMM, st, (double)n * d * (4 + 2 + 2 + 2) + 8.0 * n + 12.0 * d * (double)(n_pad / rows));
+  if (d == 128) hipLaunchKernelGGL(k_ln2_bwd_top<128>, dim3((unsigned)(n_pad / rows)), dim3(512), 0, st, A);
+  else if (d == 256) hipLaunchKernelGGL(k_ln2_bwd_top<256>, dim3((unsigned)(n_pad / rows)), dim3(512), 0, st, A);
+  else GD_REQUIRE(false, "layer_fused_ln2_top: d must be 128 or 256");
+  GD_LAUNCH_CHECK();
+  return 0;
+}

@@ -127,7 +127,7 @@ int layout(const gdmae_plan_params* p, gdmae_plan_buffer* table, int max_entries
   if (int rc = check(p)) return rc;
   Layout L{table, max_entries, 0, 0, true};
   const int B = p->batch_size, gx = p->grid[0], gy = p->grid[1], F = p->n_cols - 1;
-  const long long n0 = p->n_points;
+  const long long n0 = p->cap_points > p->n_points ? p->cap_points : p->n_points;   // capacities, not data
   O.cells = (long long)B * gx * gy;
   GD_REQUIRE(O.cells < (1ll << 31), "geometry plan: B*Y*X must fit int32");
   O.cap_pts = n0 > 0 ? n0 : 1;

@@ -147,7 +147,11 @@ class FlatAdamOneCycle:
         off = 0
         for p in self.params:
             k = p.numel()
-            p._gd_shadow = (self.flat_param_bf16[off:off + k].view(p.shape), p._version)
+            sh = getattr(p, "_gd_shadow", None)
+            # the view is persistent; only a torch-side in-place change of the parameter (version bump) needs a new stamp - the
+            # optimizer kernels write the flat buffer through raw pointers (190 slice + view constructions per step were 0.7 ms)
+            if sh is None or sh[1] != p._version or sh[0].data_ptr() != self.flat_param_bf16.data_ptr() + 2 * off:
+                p._gd_shadow = (self.flat_param_bf16[off:off + k].view(p.shape), p._version)
             off += k
         if self.flat_param.is_cuda:
             from . import packing

@@ -14,8 +14,27 @@ import torch
 
 from . import lib as L
 
-_REG = {}          # id(Win) -> dict(ref, packed, jobs)
+_REG = {}          # id(Win) -> dict(ref, refs, vers, packed, jobs)
 _TABLE = {}        # device index -> (signature, device job table, n_jobs)
+
+
+def _vers(ts):
+    return tuple(t._version for t in ts)
+
+
+def _current(ent, ts):
+    """A registered image is valid only for the weight VALUES it was packed from: the optimizer's kernels update the flat buffer
+    behind torch's back (no version bump) and refresh every image right after (repack_registered), whereas any in-place change
+    through torch between two optimizer steps (load_state_dict after a first forward, a mid-training resume, an EMA swap,
+    p.data.copy_) bumps ``_version`` and keeps ``data_ptr`` - the image is then re-packed on the spot, INTO THE SAME BUFFER
+    (native argument structs cache its address)."""
+    v = _vers(ts)
+    if ent["vers"] != v:
+        jobs = torch.tensor(ent["jobs"], dtype=torch.int64).to(ent["packed"].device)
+        L.call("gdmae_tok_gemm_pack", L.ptr(jobs), len(ent["jobs"]) // 6, L.stream())
+        ent["packed"]._gd_jobs = jobs
+        ent["vers"] = v
+    return ent
 
 
 def _jobs_for(Win, Wo, W1, W2, packed):
@@ -47,10 +66,12 @@ def registered(Win, Wo, W1, W2):
         return None
     key = id(Win)
     ent = _REG.get(key)
-    if ent is not None and ent["ref"]() is Win and ent["ptrs"] == tuple(t.data_ptr() for t in (Win, Wo, W1, W2)):
-        return ent["packed"]
+    ws = (Win, Wo, W1, W2)
+    if ent is not None and ent["ref"]() is Win and ent["ptrs"] == tuple(t.data_ptr() for t in ws):
+        return _current(ent, ws)["packed"]
     packed = pack_now(Win, Wo, W1, W2)
-    _REG[key] = dict(ref=weakref.ref(Win), packed=packed, ptrs=tuple(t.data_ptr() for t in (Win, Wo, W1, W2)),
+    _REG[key] = dict(ref=weakref.ref(Win), refs=[weakref.ref(t) for t in ws], vers=_vers(ws), packed=packed,
+                     ptrs=tuple(t.data_ptr() for t in ws),
                      jobs=_jobs_for(Win.detach(), Wo.detach(), W1.detach(), W2.detach(), packed))
     _TABLE.clear()
     return packed
@@ -89,9 +110,11 @@ def conv_registered(W):
     key = id(W)
     ent = _REG.get(key)
     if ent is not None and ent["ref"]() is W and ent["ptrs"] == (W.data_ptr(),):
+        _current(ent, (W,))
         return ent["packed"], ent["packed2"]
     fwd, bwd = conv_pack_now(W)
-    _REG[key] = dict(ref=weakref.ref(W), packed=fwd, packed2=bwd, ptrs=(W.data_ptr(),), jobs=_conv_jobs(W.detach(), fwd, bwd))
+    _REG[key] = dict(ref=weakref.ref(W), refs=[weakref.ref(W)], vers=_vers((W,)), packed=fwd, packed2=bwd, ptrs=(W.data_ptr(),),
+                     jobs=_conv_jobs(W.detach(), fwd, bwd))
     _TABLE.clear()
     return fwd, bwd
 
@@ -118,14 +141,14 @@ def decoder_conv_packed(W, widths, registered_ok):
     key = ("dec", id(W))
     ent = _REG.get(key)
     if registered_ok and ent is not None and ent["ref"]() is W and ent["ptrs"] == (W.data_ptr(),):
-        return ent["packed"]
+        return _current(ent, (W,))["packed"]
     packed = torch.empty(sum(widths) * W.shape[0] * 9 * 2, dtype=torch.uint8, device=W.device)
     jobs = _dec_jobs(W, widths, packed)
     jd = torch.tensor(jobs, dtype=torch.int64).to(W.device)
     L.call("gdmae_tok_gemm_pack", L.ptr(jd), len(jobs) // 6, L.stream())
     packed._gd_jobs = jd
     if registered_ok:
-        _REG[key] = dict(ref=weakref.ref(W), packed=packed, ptrs=(W.data_ptr(),), jobs=jobs)
+        _REG[key] = dict(ref=weakref.ref(W), refs=[weakref.ref(W)], vers=_vers((W,)), packed=packed, ptrs=(W.data_ptr(),), jobs=jobs)
         _TABLE.clear()
     return packed
 
@@ -151,3 +174,7 @@ def repack_registered():
             _TABLE[dev.index] = tab
         with torch.cuda.device(dev):
             L.call("gdmae_tok_gemm_pack", L.ptr(tab[1]), tab[2], L.stream())
+        for e in ents:
+            ts = [r() for r in e["refs"]]
+            if all(t is not None for t in ts):
+                e["vers"] = _vers(ts)

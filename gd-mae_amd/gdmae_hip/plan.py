@@ -382,26 +382,37 @@ def encoder_plan(vox: VoxelPlan, strides, window_shapes, drop_infos, keep_frac: 
 # ------------------------------------------------------------------------------------------------
 # the whole plan as ONE call of the library (csrc/plan.hip: gdmae_geometry_plan)
 # ------------------------------------------------------------------------------------------------
-_PLAN_SHAPES = {}      # shape key -> (PlanParams, {name: (offset, bytes)}, arena bytes, per-stage geometry)
-_PINNED = {}           # device index -> rotating pinned int32 buffers for the count read-back
+import collections
+
+_PLAN_SHAPES = collections.OrderedDict()   # shape key -> (PlanParams, {name: (offset, bytes)}, arena bytes, per-stage geometry): LRU
+_PLAN_SHAPES_MAX = 32
+_PLAN_GRANULE = 16384  # point capacity of a layout: the batch's point count rounded up to this (real batches differ in n0 every step)
+_PINNED = {}           # device index -> free pinned int32 buffers for the count read-back (a prefetch owns one until finish())
 
 
 def _plan_shape(n0, ncols, B, pcr, voxel_size, grid_size, strides, window_shapes, drop_infos, keep_frac, dec_sources):
+    """Layout of the plan arena for the CAPACITY bucket of ``n0`` points (the layout is a pure function of capacities; the exact
+    point count travels with each call).  Bounded LRU: a layout is ~30 KB of host memory and real data produces a new point
+    count with almost every batch."""
     gx, gy, gz = (int(g) for g in grid_size)
     lo = tuple(float(v) for v in pcr[:3])
     vs = tuple(float(v) for v in voxel_size)
     drops = tuple(tuple(map(tuple, _drop_arrays(d))) for d in drop_infos)
+    n_exact = n0
+    n0 = max(1, (n0 + _PLAN_GRANULE - 1) // _PLAN_GRANULE) * _PLAN_GRANULE
     key = (n0, ncols, B, lo, vs, (gx, gy, gz), tuple(int(s) for s in strides), tuple(tuple(int(v) for v in w) for w in window_shapes),
-           drops, keep_frac is not None, None if dec_sources is None else tuple(int(i) for i in dec_sources))
+           drops, None if keep_frac is None else float(keep_frac), None if dec_sources is None else tuple(int(i) for i in dec_sources))
     hit = _PLAN_SHAPES.get(key)
     if hit is not None:
+        _PLAN_SHAPES.move_to_end(key)
         return hit
+    del n_exact
     import ctypes as C
     ns = len(strides)
     assert gz == 1, "the SST backbone works on single-layer pillar grids (spt_backbone_mae.py:94)"
     assert 1 <= ns <= 4
     P = L.PlanParams()
-    P.n_points, P.n_cols, P.batch_size = n0, ncols, B
+    P.n_points, P.cap_points, P.n_cols, P.batch_size = n0, n0, ncols, B      # n_points is set per call (PlanPrefetch)
     for i in range(3):
         P.lo[i], P.vs[i] = lo[i], vs[i]
         P.grid[i] = (gx, gy, gz)[i]
@@ -437,6 +448,8 @@ def _plan_shape(n0, ncols, B, pcr, voxel_size, grid_size, strides, window_shapes
     L.call("gdmae_geometry_plan_layout", C.byref(P), table, 160, C.byref(n_ent), C.byref(total))
     names = {table[i].name.decode(): (int(table[i].offset), int(table[i].bytes)) for i in range(n_ent.value)}
     hit = _PLAN_SHAPES[key] = (P, names, int(total.value), geo, m_cap, (lo, vs, (gx, gy, gz)))
+    while len(_PLAN_SHAPES) > _PLAN_SHAPES_MAX:
+        _PLAN_SHAPES.popitem(last=False)
     return hit
 
 
@@ -504,14 +517,16 @@ class PlanPrefetch:
             if noise is not None:
                 assert noise.dtype == torch.float32 and noise.numel() >= 1
                 noise = noise.contiguous()
-            L.call("gdmae_geometry_plan", C.byref(P), L.ptr(points), None if noise is None else L.ptr(noise), L.ptr(raw), total, L.stream())
+            Pc = L.PlanParams.from_buffer_copy(P)                  # the cached struct describes the capacity bucket
+            Pc.n_points = n0
+            L.call("gdmae_geometry_plan", C.byref(Pc), L.ptr(points), None if noise is None else L.ptr(noise), L.ptr(raw), total, L.stream())
             self.arena = _Arena(raw, names)
             nc = names["counts"][1] // 4
-            pool = _PINNED.setdefault(dev.index, [[], 0])
-            if len(pool[0]) < 8:
-                pool[0].append(torch.empty(256, dtype=torch.int32).pin_memory())
-            self.host = pool[0][pool[1] % len(pool[0])][:nc]       # 8 prefetches deep before a buffer is reused
-            pool[1] += 1
+            assert nc <= 256
+            free = _PINNED.setdefault(dev.index, [])
+            # this prefetch OWNS its pinned buffer until finish() hands it back: any number of prefetches may be in flight
+            self._pinned = free.pop() if free else torch.empty(256, dtype=torch.int32).pin_memory()
+            self.host = self._pinned[:nc]
             self.host.copy_(self.arena.view("counts", torch.int32, nc), non_blocking=True)
             self.event = torch.cuda.Event()
             self.event.record(side)
@@ -526,6 +541,9 @@ class PlanPrefetch:
         self.event.synchronize()
         torch.cuda.current_stream().wait_event(self.event)
         c = self.host.tolist()
+        if self._pinned is not None:                               # read: the buffer may serve the next prefetch
+            _PINNED.setdefault(self.points.device.index, []).append(self._pinned)
+            self._pinned = None
         P, names, total, geo, m_cap, (lo, vs, grid) = self.shape
         A, V = self.arena, self.arena.view
         i32, f32, i64 = torch.int32, torch.float32, torch.int64

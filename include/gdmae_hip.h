@@ -555,6 +555,14 @@ int gdmae_encoder_layer_bwd(const gdmae_layer_args* args /* host */, void* strea
  * Backward: layers[n_layers-1].dy = upstream gradient, layers[0].dx = gradient of the stage input. */
 int gdmae_encoder_stage_fwd(const gdmae_layer_args* layers /* host array */, int n_layers, void* stream);
 int gdmae_encoder_stage_bwd(const gdmae_layer_args* layers /* host array */, int n_layers, void* stream);
+/* Which launch sequence the stage entry points use for bf16 rows with packed weights (d in {128, 256}, ff = 2 d):
+ *   1  "layer around its bytes" (csrc/layer_fused.hip): per layer and direction THREE launches around the attention
+ *      (forward: out-projection + LayerNorm 1 + feed-forward block + LayerNorm 2; backward: feed-forward block + LayerNorm 1 +
+ *      out-projection, and in-projection + LayerNorm 2 of the layer below), bf16 residual stream inside the stage: 60 d bytes per
+ *      token and layer instead of 106 d.  Only layers[n_layers-1].y (fp32) is written; the y of the other layers is not.
+ *   0  one launch per product with fused row epilogues and an fp32 residual stream (csrc/tok_gemm.hip), every layers[i].y written.
+ *  -1  the default: 1 unless the environment variable GDMAE_LAYER_V2 is 0. */
+int gdmae_encoder_set_layer_path(int path);
 
 /* ---- a17-a19: reconstruction targets and Chamfer loss ----------------------------------------- *
  * gdmae_group_gt_points replaces sst_ops_cuda.group_inner_inds_wrapper (sst_ops_api.cpp:8;
@@ -630,6 +638,9 @@ typedef struct gdmae_plan_params {
   int n_dec;                   /* decoder source stages (0: no tile set) */
   int dec_sources[GDMAE_PLAN_MAX_STAGES];
   int want_pm;                 /* pillar-major point rows */
+  long long cap_points;        /* capacity the LAYOUT is sized for (0: n_points).  A caller whose batches differ in point count from
+                                  step to step asks for the layout of a rounded-up capacity once and then passes the exact n_points
+                                  (<= cap_points) with every gdmae_geometry_plan call on that layout */
 } gdmae_plan_params;
 typedef struct gdmae_plan_buffer {
   char name[40];
