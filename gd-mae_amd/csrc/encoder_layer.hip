@@ -567,15 +567,16 @@ int gd_layer_fused_rows(int d);
 int gd_layer_fused_fwd(hipStream_t st, int d, const void* o, const void* x, const void* Wo, const void* W1, const void* W2, const void* bo,
                        const void* b1, const void* b2, const float* g1, const float* be1, const float* g2, const float* be2, float eps,
                        long long n, long long n_pad, void* a, void* x1, void* h, void* f, float* st1, float* st2, float* y, void* y_bf,
-                       void* ypos_bf, const float* pos_table, const int* tok_pos);
+                       void* ypos_bf, const float* pos_table, const int* tok_pos, const void* res0, void* res_out);
 int gd_layer_fused_bwd_ffn(hipStream_t st, int d, const void* df, const void* h, const void* x, const void* a, const float* st1, const float* g1,
                            const void* W2t, const void* W1t, const void* Wot, long long n, long long n_pad, void* dh, void* gact, void* da,
                            void* d_o, float* part);
 int gd_layer_fused_bwd_in(hipStream_t st, int d, const void* dqk, const void* dv, const void* Wqkt, const void* Wvt, const void* dres, long long n,
                           long long n_pad, const void* ln_a, const void* ln_b, const float* stats, const float* gamma, void* dout, float* part,
-                          float* dx);
-int gd_layer_fused_ln2_top(hipStream_t st, int d, const float* dy, const void* ln_a, const void* ln_b, const float* stats, const float* gamma,
-                           long long n, long long n_pad, void* dout, float* part);
+                          float* dx, const void* dtop, void* dx_bf);
+int gd_layer_fused_ln2_top(hipStream_t st, int d, const float* dy, const void* dy_bf, const void* ln_a, const void* ln_b, const float* stats,
+                           const float* gamma, long long n, long long n_pad, void* dout, float* part);
+int gd_layer_fused_prep_bf(hipStream_t st, const void* x, const float* pos_table, const int* tok_pos, long long n, int d, void* xb, void* xpb);
 
 namespace {
 // packed weight image of a layer: element offsets (in bf16 elements) of the ten operands
@@ -625,6 +626,10 @@ extern "C" int gdmae_encoder_set_layer_path(int path) {
   GD_REQUIRE(path >= -1 && path <= 1, "encoder_set_layer_path: -1 (environment default), 0 or 1");
   g_layer_path = path;
   return 0;
+}
+
+extern "C" int gdmae_encoder_stage_fused(const gdmae_layer_args* layers, int n_layers) {
+  return (layers != nullptr && n_layers >= 1 && stage_v2(layers, n_layers)) ? 1 : 0;
 }
 
 extern "C" size_t gdmae_layer_packed_bytes(int d, int ff) { return packed_layout(nullptr, d, ff).bytes; }
@@ -754,7 +759,10 @@ static int stage_fwd_v2(const gdmae_layer_args* layers, int n_layers, void* stre
     const int d = a->d, ff = a->ff;
     Saved s = saved_layout(a->saved, n_pad, d, ff, 2);
     const Packed pk = packed_layout(a->packed, d, ff);
-    if (i == 0) GD_TRY(gdmae_prep_tokens(a->x, a->pos_table, a->tok_pos, n, d, s.xb, s.xpb, 1, stream));
+    if (i == 0) {
+      if (a->x_bf16) GD_TRY(gd_layer_fused_prep_bf(st, a->x, a->pos_table, a->tok_pos, n, d, s.xb, s.xpb));
+      else GD_TRY(gdmae_prep_tokens(a->x, a->pos_table, a->tok_pos, n, d, s.xb, s.xpb, 1, stream));
+    }
     GD_TRY(gd_tok_gemm_qkv(st, s.xpb, s.xb, pk.qk, pk.v, a->bin, n_pad, d, s.qk, s.v));
     gd_attn_timing_tokens(n);
     GD_TRY(gdmae_window_attention_levels_fwd(s.qk, s.v, s.o, 1, a->csr_tok, a->win_start, a->win_len, a->n_levels, a->n_win, a->max_tokens, d,
@@ -766,8 +774,9 @@ static int stage_fwd_v2(const gdmae_layer_args* layers, int n_layers, void* stre
       y_bf = sn.xb; ypos_bf = sn.xpb;
     }
     GD_TRY(gd_layer_fused_fwd(st, d, s.o, s.xb, pk.o, pk.w1, pk.w2, a->bo, a->b1, a->b2, a->g1, a->be1, a->g2, a->be2, a->eps, n, n_pad, s.a,
-                              s.x1b, s.h, s.f, (float*)s.st1, (float*)s.st2, next ? nullptr : a->y, y_bf, ypos_bf,
-                              next ? next->pos_table : nullptr, next ? next->tok_pos : nullptr));
+                              s.x1b, s.h, s.f, (float*)s.st1, (float*)s.st2, (next || a->res_out) ? nullptr : a->y, y_bf, ypos_bf,
+                              next ? next->pos_table : nullptr, next ? next->tok_pos : nullptr,
+                              (!next && a->res_out) ? saved_layout(layers[0].saved, n_pad, d, ff, 2).xb : nullptr, next ? nullptr : a->res_out));
   }
   return 0;
 }
@@ -779,6 +788,7 @@ extern "C" int gdmae_encoder_stage_fwd(const gdmae_layer_args* layers, int n_lay
                           layers[i].ff == layers[0].ff && layers[i].bf16 == layers[0].bf16),
                "encoder stage: layers must chain (x[i] = y[i-1]) and share n, d, ff, dtype");
   if (stage_v2(layers, n_layers)) return stage_fwd_v2(layers, n_layers, stream);
+  GD_REQUIRE(!layers[0].x_bf16 && !layers[n_layers - 1].res_out, "encoder stage: bf16 input rows / the folded block residual need the fused path");
   for (int i = 0; i < n_layers; ++i) {
     GD_REQUIRE(i == 0 || (layers[i].x == layers[i - 1].y && layers[i].n == layers[0].n && layers[i].d == layers[0].d &&
                           layers[i].ff == layers[0].ff && layers[i].bf16 == layers[0].bf16),
@@ -987,8 +997,11 @@ static int stage_bwd_v2(const gdmae_layer_args* layers, int n_layers, void* stre
     Scratch w = scratch_layout(a->scratch, n_pad, d, ff, 2, a->nhead);
     Ctx c{st, HIP_R_16BF, 2, w.lt_ws};
     const Packed pk = packed_layout(a->packed, d, ff);
+    const gdmae_layer_args* top = &layers[n_layers - 1];
+    const bool res_mode = top->dres != nullptr && layers[0].dx_bf16 != nullptr;      // block residual folded into the stage
     if (i == n_layers - 1)
-      GD_TRY(gd_layer_fused_ln2_top(st, d, a->dy, s.x1b, s.f, (const float*)s.st2, a->g2, n, n_pad, w.dfb, (float*)w.ln_ws2));
+      GD_TRY(gd_layer_fused_ln2_top(st, d, res_mode ? nullptr : a->dy, res_mode ? a->dres : nullptr, s.x1b, s.f, (const float*)s.st2, a->g2, n,
+                                    n_pad, w.dfb, (float*)w.ln_ws2));
     GD_TRY(gd_layer_fused_bwd_ffn(st, d, w.dfb, s.h, s.xb, s.a, (const float*)s.st1, a->g1, pk.w2t, pk.w1t, pk.ot, n, n_pad, w.dh, s.gact,
                                   w.dab, w.d_o, (float*)w.ln_ws));
     long long pbase = 0;
@@ -1001,10 +1014,10 @@ static int stage_bwd_v2(const gdmae_layer_args* layers, int n_layers, void* stre
     if (i > 0) {
       const Saved sp = saved_layout(layers[i - 1].saved, n_pad, d, ff, 2);
       GD_TRY(gd_layer_fused_bwd_in(st, d, w.dqk, w.dv, pk.qkt, pk.vt, w.dab, n, n_pad, sp.x1b, sp.f, (const float*)sp.st2, layers[i - 1].g2,
-                                   w.dfb, (float*)w.ln_ws2, nullptr));
+                                   w.dfb, (float*)w.ln_ws2, nullptr, nullptr, nullptr));
     } else {
       GD_TRY(gd_layer_fused_bwd_in(st, d, w.dqk, w.dv, pk.qkt, pk.vt, w.dab, n, n_pad, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-                                   a->dx));
+                                   res_mode ? nullptr : a->dx, res_mode ? top->dres : nullptr, res_mode ? a->dx_bf16 : nullptr));
     }
   }
   return 0;
@@ -1024,6 +1037,7 @@ extern "C" int gdmae_encoder_stage_bwd(const gdmae_layer_args* layers, int n_lay
                    layers[i].ff == layers[0].ff && layers[i].bf16 == layers[0].bf16,
                "encoder stage: layers must share scratch, n, d, ff, dtype");
   if (stage_v2(layers, n_layers)) return stage_bwd_v2(layers, n_layers, stream);
+  GD_REQUIRE(!layers[n_layers - 1].dres && !layers[0].dx_bf16, "encoder stage: the folded block residual needs the fused path");
   // bf16 rows with packed weights: the LayerNorm-2 backward of layer i - 1 rides on layer i's last input-gradient GEMM
   bool chain = true;
   for (int i = 0; i < n_layers; ++i)

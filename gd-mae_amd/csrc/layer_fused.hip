@@ -20,6 +20,17 @@
 // 64 for d = 128, 8 wavefronts, weights streamed as MFMA A operands from the fragment-ordered images of tok_gemm_pack.
 #include "tok_tiles.h"
 
+// experiment switches (tools/build_variant.sh): weight prefetch distance, row tile of the d = 256 stages, resident workgroups
+#ifndef TL_PF
+#define TL_PF TG_PF
+#endif
+#ifndef TL_ROWS256
+#define TL_ROWS256 32
+#endif
+#ifndef TL_MINW
+#define TL_MINW 4
+#endif
+
 namespace {
 
 // ---- one product of a row tile:  acc[j][b] (32 channels x 32 rows, fp32) += W (ND, KD) X^T, X = bf16 rows in LDS ---------------
@@ -45,15 +56,15 @@ __device__ __forceinline__ uint4 tl_wfrag(const uint4* __restrict__ w0, const ui
 template <int KD, int ND, int ROWS, int KSPLIT = KD / 16>
 struct TlProd {
   using S = TlShape<KD, ND, ROWS>;
-  TgFrag wr[TG_PF + 1][S::MPW];
+  TgFrag wr[TL_PF + 1][S::MPW];
   const uint4* __restrict__ w0;
   const uint4* __restrict__ w1;
-  // first TG_PF k-steps of the weights: issued early (before a row pass or a tile load) so that their latency is hidden
+  // first TL_PF k-steps of the weights: issued early (before a row pass or a tile load) so that their latency is hidden
   __device__ __forceinline__ void prefetch(const uint4* W0, const uint4* W1, int wv, int lane) {
     w0 = W0 + (size_t)S::mb0(wv) * 64 + lane;
     w1 = W1 ? W1 + (size_t)S::mb0(wv) * 64 + lane : w0;
 #pragma unroll
-    for (int ks = 0; ks < TG_PF; ++ks)
+    for (int ks = 0; ks < TL_PF; ++ks)
 #pragma unroll
       for (int j = 0; j < S::MPW; ++j) wr[ks][j].q = tl_wfrag<KD, ND, ROWS, KSPLIT>(w0, w1, ks, j);
   }
@@ -64,9 +75,9 @@ struct TlProd {
     for (int b = 0; b < S::NPW; ++b) sf[0][b].q = *(const uint4*)(lb + b * 32 * XP);
 #pragma unroll
     for (int ks = 0; ks < S::KS; ++ks) {
-      if (ks + TG_PF < S::KS) {
+      if (ks + TL_PF < S::KS) {
 #pragma unroll
-        for (int j = 0; j < S::MPW; ++j) wr[(ks + TG_PF) % (TG_PF + 1)][j].q = tl_wfrag<KD, ND, ROWS, KSPLIT>(w0, w1, ks + TG_PF, j);
+        for (int j = 0; j < S::MPW; ++j) wr[(ks + TL_PF) % (TL_PF + 1)][j].q = tl_wfrag<KD, ND, ROWS, KSPLIT>(w0, w1, ks + TL_PF, j);
       }
       if (ks + 1 < S::KS) {
 #pragma unroll
@@ -76,7 +87,7 @@ struct TlProd {
       for (int j = 0; j < S::MPW; ++j)
 #pragma unroll
         for (int b = 0; b < S::NPW; ++b)
-          acc[j][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[ks % (TG_PF + 1)][j].v, sf[ks & 1][b].v, acc[j][b], 0, 0, 0);
+          acc[j][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[ks % (TL_PF + 1)][j].v, sf[ks & 1][b].v, acc[j][b], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -134,7 +145,7 @@ __device__ __forceinline__ uint2 tl_pack4(const float (&f)[4]) {
 
 template <int D>
 struct TlRows {
-  static constexpr int ROWS = D >= 256 ? 32 : 64;
+  static constexpr int ROWS = D >= 256 ? TL_ROWS256 : 64;
   static constexpr int LPR = D / 4;                 // lanes per row in the LayerNorm passes (4 consecutive columns per lane)
   static constexpr int LRPP = 512 / LPR;            // rows per pass
   static constexpr int LPASS = ROWS / LRPP;
@@ -245,10 +256,12 @@ struct LfArgs {
   unsigned short* ypos_bf;          // optional (n_pad, D): the next layer's q / k operand, bf16(y + pos_table[tok_pos[row]])
   const float* pos_table;
   const int* tok_pos;
+  const unsigned short* res0;       // optional (n_pad, D): input rows of the STAGE; res_out = bf16(res0 + y), the block residual
+  unsigned short* res_out;          // optional (n, D)
 };
 
 template <int D>
-__global__ __launch_bounds__(512, 4) void k_layer_fwd(LfArgs A) {
+__global__ __launch_bounds__(512, TL_MINW) void k_layer_fwd(LfArgs A) {
   constexpr int FF = 2 * D;
   using R = TlRows<D>;
   constexpr int ROWS = R::ROWS, LPR = R::LPR, LRPP = R::LRPP, LPASS = R::LPASS;
@@ -368,6 +381,12 @@ __global__ __launch_bounds__(512, 4) void k_layer_fwd(LfArgs A) {
       const long long e = row * D + lc0;
       TG_ST_U2(A.f + e, fq);
       if (A.y) TG_ST_F4(A.y + e, o[0], o[1], o[2], o[3]);
+      if (A.res_out) {
+        float r0[4];
+        tl_unpack4(*(const uint2*)(A.res0 + e), r0);
+        const float rs[4] = {r0[0] + o[0], r0[1] + o[1], r0[2] + o[2], r0[3] + o[3]};
+        *(uint2*)(A.res_out + e) = tl_pack4(rs);
+      }
       if (A.y_bf) *(uint2*)(A.y_bf + e) = tl_pack4(o);
       if (A.ypos_bf) {
         const float4 p4 = *(const float4*)(A.pos_table + (long long)pos_pf[p] * D + lc0);
@@ -396,7 +415,7 @@ struct LbArgs {
 };
 
 template <int D>
-__global__ __launch_bounds__(512, 4) void k_layer_bwd_ffn(LbArgs A) {
+__global__ __launch_bounds__(512, TL_MINW) void k_layer_bwd_ffn(LbArgs A) {
   constexpr int FF = 2 * D;
   using R = TlRows<D>;
   constexpr int ROWS = R::ROWS, LPR = R::LPR, LRPP = R::LRPP, LPASS = R::LPASS;
@@ -530,12 +549,14 @@ struct LiArgs {
   const float* gamma;
   unsigned short* dout;             // (n_pad, D) gradient of that LayerNorm's input
   float* part;
-  // LN = false
+  // LN = false: gradient of the stage input, fp32 (dx) or - block-residual mode - bf16 with the gradient of the skip path added
   float* dx;                        // (n, D) fp32
+  const unsigned short* dtop;       // (n, D) bf16 gradient of the block residual
+  unsigned short* dx_bf;            // (n, D) bf16 = dtop + dres + product
 };
 
 template <int D, bool LN>
-__global__ __launch_bounds__(512, 4) void k_layer_bwd_in(LiArgs A) {
+__global__ __launch_bounds__(512, TL_MINW) void k_layer_bwd_in(LiArgs A) {
   using R = TlRows<D>;
   constexpr int ROWS = R::ROWS, LPR = R::LPR, LRPP = R::LRPP, LPASS = R::LPASS;
   constexpr int KD = 3 * D, XP = KD * 2 + 16, SP = D * 2 + 16;
@@ -601,14 +622,22 @@ __global__ __launch_bounds__(512, 4) void k_layer_bwd_in(LiArgs A) {
       float d[4], d2[4];
       tl_unpack4(dy_pf[p], d);
       tl_unpack4(fq, d2);
-      TG_ST_F4(A.dx + row * D + lc0, d[0] + d2[0], d[1] + d2[1], d[2] + d2[2], d[3] + d2[3]);
+      if (A.dx_bf) {
+        float d3[4];
+        tl_unpack4(*(const uint2*)(A.dtop + row * D + lc0), d3);
+        const float o[4] = {d3[0] + (d[0] + d2[0]), d3[1] + (d[1] + d2[1]), d3[2] + (d[2] + d2[2]), d3[3] + (d[3] + d2[3])};
+        *(uint2*)(A.dx_bf + row * D + lc0) = tl_pack4(o);
+      } else {
+        TG_ST_F4(A.dx + row * D + lc0, d[0] + d2[0], d[1] + d2[1], d[2] + d2[2], d[3] + d2[3]);
+      }
     }
   }
 }
 
 // df = LN2'(dy) for the top layer of a stage: dy (n, D) fp32, LayerNorm input = x1 + f (bf16), same row tiles / partial rows
 struct LtArgs {
-  const float* dy;
+  const float* dy;                  // (n, D) fp32, or
+  const unsigned short* dy_bf;      // (n, D) bf16 when dy is null
   const unsigned short *ln_a, *ln_b;
   const float* st;
   const float* gamma;
@@ -633,12 +662,37 @@ __global__ __launch_bounds__(512) void k_ln2_bwd_top(LtArgs A) {
     const long long row = row0 + p * LRPP + lr;
     const bool live = row < A.n;
     const long long rr = live ? row : A.n - 1;
-    const float4 d4 = *(const float4*)(A.dy + rr * D + lc0);
-    float d[4] = {d4.x, d4.y, d4.z, d4.w}, o[4];
+    float d[4], o[4];
+    if (A.dy) {
+      const float4 d4 = *(const float4*)(A.dy + rr * D + lc0);
+      d[0] = d4.x; d[1] = d4.y; d[2] = d4.z; d[3] = d4.w;
+    } else {
+      tl_unpack4(*(const uint2*)(A.dy_bf + rr * D + lc0), d);
+    }
     L.row(d, live, tg_ld_u2_once(A.ln_a + rr * D + lc0), tg_ld_u2_once(A.ln_b + rr * D + lc0), *(const float2*)(A.st + rr * 2), g, o);
     if (live) *(uint2*)(A.dout + row * D + lc0) = tl_pack4(o);
   }
   L.finish(red, A.part + (long long)blockIdx.x * 3 * D, tid);
+}
+
+// operands of the first layer of a stage whose input rows are bf16: xb = x (padded buffer), xpb = bf16(x + pos_table[tok_pos[row]])
+__global__ __launch_bounds__(256) void k_prep_tokens_bf(const unsigned short* __restrict__ x, const float* __restrict__ pos_table,
+                                                        const int* __restrict__ tok_pos, long long n, int d, unsigned short* __restrict__ xb,
+                                                        unsigned short* __restrict__ xpb) {
+  const int cpr = d >> 3;
+  const long long total = n * cpr;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long row = i / cpr;
+    const int c = (int)(i - row * cpr) << 3;
+    const uint4 q = *(const uint4*)(x + row * d + c);
+    *(uint4*)(xb + row * d + c) = q;
+    float v[8];
+    tg_unpack8(q, v);
+    const float* pr = pos_table + (long long)tok_pos[row] * d + c;
+    const float4 p0 = *(const float4*)pr, p1 = *(const float4*)(pr + 4);
+    v[0] += p0.x; v[1] += p0.y; v[2] += p0.z; v[3] += p0.w; v[4] += p1.x; v[5] += p1.y; v[6] += p1.z; v[7] += p1.w;
+    *(uint4*)(xpb + row * d + c) = tg_pack8(v);
+  }
 }
 
 template <typename K>
@@ -653,13 +707,14 @@ int set_lds(K kernel, int bytes) {
 // internal front end (encoder_layer.hip)
 // ------------------------------------------------------------------------------------------------
 bool gd_layer_fused_supported(int d, int ff) { return (d == 128 || d == 256) && ff == 2 * d; }
-int gd_layer_fused_rows(int d) { return d >= 256 ? 32 : 64; }
+int gd_layer_fused_rows(int d) { return d >= 256 ? TL_ROWS256 : 64; }
 
 int gd_layer_fused_fwd(hipStream_t st, int d, const void* o, const void* x, const void* Wo, const void* W1, const void* W2, const void* bo,
                        const void* b1, const void* b2, const float* g1, const float* be1, const float* g2, const float* be2, float eps,
                        long long n, long long n_pad, void* a, void* x1, void* h, void* f, float* st1, float* st2, float* y, void* y_bf,
-                       void* ypos_bf, const float* pos_table, const int* tok_pos) {
+                       void* ypos_bf, const float* pos_table, const int* tok_pos, const void* res0, void* res_out) {
   LfArgs A = {};
+  A.res0 = (const unsigned short*)res0; A.res_out = (unsigned short*)res_out;
   A.o = (const unsigned short*)o; A.x = (const unsigned short*)x;
   A.Wo = (const uint4*)Wo; A.W1 = (const uint4*)W1; A.W2 = (const uint4*)W2;
   A.bo = (const unsigned short*)bo; A.b1 = (const unsigned short*)b1; A.b2 = (const unsigned short*)b2;
@@ -670,7 +725,7 @@ int gd_layer_fused_fwd(hipStream_t st, int d, const void* o, const void* x, cons
   const int lds = rows * (d * 2 + 16) + rows * (ff * 2 + 16);
   // o, x in; a, x1, h, f, (y | y_bf + ypos_bf) out; three weight images
   GdTimed timed(GD_T_TOK_GEMM, st,
-                2.0 * n_pad * d + (double)n * d * (2 + 2 + 2 + 2 + (y ? 4 : 0) + (y_bf ? 2 : 0) + (ypos_bf ? 2 : 0)) + 2.0 * n_pad * ff + 16.0 * n +
+                2.0 * n_pad * d + (double)n * d * (2 + 2 + 2 + 2 + (y ? 4 : 0) + (y_bf ? 2 : 0) + (ypos_bf ? 2 : 0) + (res_out ? 4 : 0)) + 2.0 * n_pad * ff + 16.0 * n +
                     (ypos_bf ? 4.0 * n : 0.0) + 2.0 * (d * d + 2.0 * d * ff),
                 2.0 * n_pad * (d * d + 2.0 * d * ff));
   static bool once[2] = {false, false};
@@ -718,12 +773,13 @@ int gd_layer_fused_bwd_ffn(hipStream_t st, int d, const void* df, const void* h,
 // LN: dout (n_pad, d) bf16 + part; otherwise dx (n, d) fp32
 int gd_layer_fused_bwd_in(hipStream_t st, int d, const void* dqk, const void* dv, const void* Wqkt, const void* Wvt, const void* dres, long long n,
                           long long n_pad, const void* ln_a, const void* ln_b, const float* stats, const float* gamma, void* dout, float* part,
-                          float* dx) {
+                          float* dx, const void* dtop, void* dx_bf) {
   LiArgs A = {};
+  A.dtop = (const unsigned short*)dtop; A.dx_bf = (unsigned short*)dx_bf;
   A.dqk = (const unsigned short*)dqk; A.dv = (const unsigned short*)dv; A.Wqkt = (const uint4*)Wqkt; A.Wvt = (const uint4*)Wvt;
   A.dres = (const unsigned short*)dres; A.n = n; A.n_pad = n_pad; A.ln_a = (const unsigned short*)ln_a; A.ln_b = (const unsigned short*)ln_b;
   A.st = stats; A.gamma = gamma; A.dout = (unsigned short*)dout; A.part = part; A.dx = dx;
-  const bool ln = dx == nullptr;
+  const bool ln = dx == nullptr && dx_bf == nullptr;
   const int rows = gd_layer_fused_rows(d);
   const int lds = rows * (3 * d * 2 + 16);
   GdTimed timed(GD_T_TOK_GEMM, st,
@@ -746,11 +802,22 @@ int gd_layer_fused_bwd_in(hipStream_t st, int d, const void* dqk, const void* dv
   return 0;
 }
 
-int gd_layer_fused_ln2_top(hipStream_t st, int d, const float* dy, const void* ln_a, const void* ln_b, const float* stats, const float* gamma,
-                           long long n, long long n_pad, void* dout, float* part) {
-  LtArgs A = {dy, (const unsigned short*)ln_a, (const unsigned short*)ln_b, stats, gamma, n, (unsigned short*)dout, part};
+int gd_layer_fused_prep_bf(hipStream_t st, const void* x, const float* pos_table, const int* tok_pos, long long n, int d, void* xb, void* xpb) {
+  if (n <= 0) return 0;
+  long long g = (n * (d / 8) + 255) / 256;
+  if (g > 8192) g = 8192;
+  hipLaunchKernelGGL(k_prep_tokens_bf, dim3((unsigned)g), dim3(256), 0, st, (const unsigned short*)x, pos_table, tok_pos, n, d, (unsigned short*)xb,
+                     (unsigned short*)xpb);
+  GD_LAUNCH_CHECK();
+  return 0;
+}
+
+// dy: (n, d) fp32, or null and dy_bf: (n, d) bf16
+int gd_layer_fused_ln2_top(hipStream_t st, int d, const float* dy, const void* dy_bf, const void* ln_a, const void* ln_b, const float* stats,
+                           const float* gamma, long long n, long long n_pad, void* dout, float* part) {
+  LtArgs A = {dy, (const unsigned short*)dy_bf, (const unsigned short*)ln_a, (const unsigned short*)ln_b, stats, gamma, n, (unsigned short*)dout, part};
   const int rows = gd_layer_fused_rows(d);
-  GdTimed timed(GD_T_TOK_GEMM, st, (double)n * d * (4 + 2 + 2 + 2) + 8.0 * n + 12.0 * d * (double)(n_pad / rows));
+  GdTimed timed(GD_T_TOK_GEMM, st, (double)n * d * ((dy ? 4 : 2) + 2 + 2 + 2) + 8.0 * n + 12.0 * d * (double)(n_pad / rows));
   if (d == 128) hipLaunchKernelGGL(k_ln2_bwd_top<128>, dim3((unsigned)(n_pad / rows)), dim3(512), 0, st, A);
   else if (d == 256) hipLaunchKernelGGL(k_ln2_bwd_top<256>, dim3((unsigned)(n_pad / rows)), dim3(512), 0, st, A);
   else GD_REQUIRE(false, "layer_fused_ln2_top: d must be 128 or 256");

@@ -345,6 +345,7 @@ class EncoderLayerNativeFn(torch.autograd.Function):
 # stage executor: all layers of a stage (NUM_BLOCKS x 2) as ONE call per direction
 # ------------------------------------------------------------------------------------------------
 TOKGEMM = os.environ.get("GDMAE_TOKGEMM", "1") != "0"   # False: token GEMMs through hipBLASLt + separate row kernels (A/B)
+FOLD_RESIDUAL = os.environ.get("GDMAE_FOLD_RES", "1") != "0"   # False: the block residual as its own add pass behind the stage (A/B)
 STAGE = os.environ.get("GDMAE_STAGE", "1") != "0"     # False / GDMAE_STAGE=0: one call per layer (A/B reference)
 
 
@@ -357,12 +358,15 @@ def _plist(layer):
 
 class EncoderStageFn(torch.autograd.Function):
     """x -> layer_L(... layer_1(x)) through gdmae_encoder_stage_fwd / _bwd.  Only used when every parameter lives in a
-    flat optimizer buffer (gradients are accumulated there directly, so the parameters are not autograd inputs)."""
+    flat optimizer buffer (gradients are accumulated there directly, so the parameters are not autograd inputs).
+
+    ``residual``: return x + stage(x) - the block residual of SSTBlockV1 (spt_backbone.py:219-264).  On the fused path
+    (csrc/layer_fused.hip) with bf16 rows the sum is written by the last layer's launch and the skip-path gradient is added by the
+    first layer's backward launch (no cast / add passes around the stage); otherwise it is one ``ResidualAdd`` behind the stage."""
 
     @staticmethod
-    def forward(ctx, x, info):
+    def forward(ctx, x, info, residual):
         layers, wplans, pos_table, plists, directs = info
-        x = x.float().contiguous()
         n, d = x.shape
         dev = x.device
         nl = len(layers)
@@ -371,45 +375,90 @@ class EncoderStageFn(torch.autograd.Function):
         nhead, tau_min, eps, ff = sa.num_heads, sa.tau_min, l0.norm1.eps, l0.linear1.weight.shape[0]
         cdt = torch.bfloat16 if torch.is_autocast_enabled() else torch.float32
         sb, fb, bb = _layer_bytes(n, d, ff, nhead, int(cdt == torch.bfloat16))
-        ys = torch.empty(nl, n, d, dtype=torch.float32, device=dev)
-        saved = torch.empty(nl, sb, dtype=torch.uint8, device=dev)
-        scratch = torch.empty(fb, dtype=torch.uint8, device=dev)
         arr = (L.LayerArgs * nl)()
         bases = []
         for i in range(nl):
             base, keep = _param_args(plists[i], cdt, directs[i])
             bases.append((base, keep))
-            a = _call_args(base, x if i == 0 else ys[i - 1], wplans[i], pos_table, nhead, tau_min, eps, cdt, ff)
-            a.y, a.saved, a.scratch = ys[i].data_ptr(), saved[i].data_ptr(), scratch.data_ptr()
-            arr[i] = a
+            arr[i] = _call_args(base, x, wplans[i], pos_table, nhead, tau_min, eps, cdt, ff)
+        saved = torch.empty(nl, sb, dtype=torch.uint8, device=dev)
+        scratch = torch.empty(fb, dtype=torch.uint8, device=dev)
+        for i in range(nl):
+            arr[i].saved, arr[i].scratch = saved[i].data_ptr(), scratch.data_ptr()
+        fused = bool(L.load().gdmae_encoder_stage_fused(arr, nl))
+        folded = fused and residual and x.dtype == torch.bfloat16 and FOLD_RESIDUAL
+        if fused:
+            # only the last layer's output leaves the stage; x[i] == y[i-1] is the chaining contract of the entry point, the
+            # intermediate rows live in the layers' saved blocks
+            xin = x.contiguous() if folded else x.float().contiguous()
+            out = torch.empty(n, d, dtype=torch.bfloat16 if folded else torch.float32, device=dev)
+            for i in range(nl):
+                arr[i].x = xin.data_ptr() if i == 0 else 1 + i     # never dereferenced for i > 0; distinct tokens keep the chain check
+                arr[i].y = (2 + i) if i + 1 < nl else out.data_ptr()
+            if folded:
+                arr[0].x_bf16 = 1
+                arr[nl - 1].res_out = out.data_ptr()
+                arr[nl - 1].y = 0
+            ys = None
+        else:
+            xin = x.float().contiguous()
+            ys = torch.empty(nl, n, d, dtype=torch.float32, device=dev)
+            for i in range(nl):
+                arr[i].x = (xin if i == 0 else ys[i - 1]).data_ptr()
+                arr[i].y = ys[i].data_ptr()
+            out = ys[nl - 1]
         L.call("gdmae_encoder_stage_fwd", arr, nl, L.stream())
-        ctx.save_for_backward(x, ys, saved, pos_table)
-        ctx.meta = (wplans, nhead, tau_min, eps, cdt, ff, bb, bases)
-        return ys[nl - 1]
+        ctx.save_for_backward(xin, saved, pos_table, *([] if ys is None else [ys]))
+        ctx.meta = (wplans, nhead, tau_min, eps, cdt, ff, bb, bases, fused, folded, residual, x.dtype)
+        if residual and not folded:
+            odt = torch.bfloat16 if cdt == torch.bfloat16 else torch.float32
+            res = torch.empty(n, d, dtype=odt, device=dev)
+            xc = x.contiguous()
+            L.call("gdmae_add3_to", L.ptr(out), L.ptr(xc), _bf(xc), None, 0, out.numel(), L.ptr(res), int(odt == torch.bfloat16), L.stream())
+            return res
+        return out
 
     @staticmethod
     def backward(ctx, dy):
-        x, ys, saved, pos_table = ctx.saved_tensors
-        wplans, nhead, tau_min, eps, cdt, ff, bb, bases = ctx.meta
-        nl = ys.shape[0]
-        dy = dy.float().contiguous()
-        dx = torch.empty_like(x)
-        scratch = torch.empty(bb, dtype=torch.uint8, device=x.device)
+        xin, saved, pos_table = ctx.saved_tensors[:3]
+        ys = ctx.saved_tensors[3] if len(ctx.saved_tensors) > 3 else None
+        wplans, nhead, tau_min, eps, cdt, ff, bb, bases, fused, folded, residual, x_dtype = ctx.meta
+        nl = saved.shape[0]
+        n, d = xin.shape
+        scratch = torch.empty(bb, dtype=torch.uint8, device=xin.device)
         arr = (L.LayerArgs * nl)()
         for i in range(nl):
-            a = _call_args(bases[i][0], x if i == 0 else ys[i - 1], wplans[i], pos_table, nhead, tau_min, eps, cdt, ff)
+            a = _call_args(bases[i][0], xin, wplans[i], pos_table, nhead, tau_min, eps, cdt, ff)
             a.saved, a.scratch = saved[i].data_ptr(), scratch.data_ptr()
-            if i == nl - 1:
-                a.dy = dy.data_ptr()
-            if i == 0:
-                a.dx = dx.data_ptr()
+            if fused:
+                a.x = xin.data_ptr() if i == 0 else 1 + i
+                a.y = 2 + i
+            else:
+                a.x = (xin if i == 0 else ys[i - 1]).data_ptr()
+                a.y = ys[i].data_ptr()
             arr[i] = a
+        if folded:
+            g = dy.contiguous() if dy.dtype == torch.bfloat16 else dy.to(torch.bfloat16).contiguous()
+            dx = torch.empty(n, d, dtype=torch.bfloat16, device=xin.device)
+            arr[0].x_bf16 = 1
+            arr[nl - 1].dres, arr[0].dx_bf16 = g.data_ptr(), dx.data_ptr()
+            L.call("gdmae_encoder_stage_bwd", arr, nl, L.stream())
+            return dx, None, None
+        g = dy.float().contiguous()
+        dx = torch.empty(n, d, dtype=torch.float32, device=xin.device)
+        arr[nl - 1].dy, arr[0].dx = g.data_ptr(), dx.data_ptr()
         L.call("gdmae_encoder_stage_bwd", arr, nl, L.stream())
-        return dx, None
+        if residual:                 # the skip path carries dy unchanged
+            if x_dtype == torch.float32:
+                dx.add_(g)
+            else:                    # same roundings as autograd's accumulation of the two branches in the input's dtype
+                dx = dx.to(x_dtype) + (dy if dy.dtype == x_dtype else dy.to(x_dtype))
+        return dx, None, None
 
 
-def encoder_stage(blocks, x, pos_table, wplans):
-    """``blocks``: the stage's BasicShiftBlockV2 modules (layer k of a block uses window partition k % len(wplans))."""
+def encoder_stage(blocks, x, pos_table, wplans, residual=False):
+    """``blocks``: the stage's BasicShiftBlockV2 modules (layer k of a block uses window partition k % len(wplans)).
+    ``residual``: return x + stage(x) (the block residual of SSTBlockV1), fp32 -> fp32, bf16 under autocast."""
     pairs = [(layer, wplans[k % len(wplans)]) for block in blocks for k, layer in enumerate(block.encoder_list)]
     layers = [p[0] for p in pairs]
     if (STAGE and IMPL == "native" and x.is_cuda and
@@ -417,9 +466,12 @@ def encoder_stage(blocks, x, pos_table, wplans):
         plists = [_plist(l) for l in layers]
         directs = [[_direct(p) for p in pl] for pl in plists]
         if all(t is not None for dl in directs for t in dl):
-            return EncoderStageFn.apply(x, (layers, [p[1] for p in pairs], pos_table, plists, directs))
+            return EncoderStageFn.apply(x, (layers, [p[1] for p in pairs], pos_table, plists, directs), residual)
+    feat = x
     for layer, wp in pairs:
         x = layer(x, pos_table, wp)
+    if residual:
+        return ops.ResidualAdd.apply(x, feat) if (x.is_cuda and x.dtype == torch.float32) else feat + x
     return x
 
 

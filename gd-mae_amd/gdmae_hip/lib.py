@@ -131,6 +131,7 @@ SIGNATURES = {
     "gdmae_encoder_stage_fwd": (_I, [_P, _I, _P]),
     "gdmae_encoder_stage_bwd": (_I, [_P, _I, _P]),
     "gdmae_encoder_set_layer_path": (_I, [_I]),
+    "gdmae_encoder_stage_fused": (_I, [_P, _I]),
     "gdmae_group_gt_points": (_I, [_P, _I, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
     "gdmae_chamfer": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P]),
     "gdmae_augment_collate_workspace_bytes": (_Z, [_L]),
@@ -157,7 +158,8 @@ class LayerArgs(C.Structure):
                  ("n_win", _I * 4), ("max_tokens", _I * 4)]
                 + [(k, _P) for k in ("tok_pos", "csr_tok", "win_start", "win_len", "pos_table", "Win", "bin", "Wo", "bo", "W1", "b1",
                                      "W2", "b2", "g1", "be1", "g2", "be2", "tau", "x", "y", "dy", "dx", "dWin", "dbin", "dtau", "dWo",
-                                     "dbo", "dW1", "db1", "dW2", "db2", "dg1", "dbe1", "dg2", "dbe2", "saved", "scratch", "packed")])
+                                     "dbo", "dW1", "db1", "dW2", "db2", "dg1", "dbe1", "dg2", "dbe2", "saved", "scratch", "packed")]
+                + [("x_bf16", _I), ("res_out", _P), ("dres", _P), ("dx_bf16", _P)])
 
 
 class PlanParams(C.Structure):

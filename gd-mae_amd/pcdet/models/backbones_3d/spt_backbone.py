@@ -81,8 +81,8 @@ class SSTBlockV1(nn.Module):
         feat = sp_tensor.features
         wplans = sp_tensor.stage_plan.windows
         table = self.sst_input_layer.pos_table(feat.shape[1], feat.device)
-        out = genc.encoder_stage(self.encoder_blocks, feat, table, wplans)   # = block_k(... block_1(feat)), one call per stage
-        res = ops.ResidualAdd.apply(out, feat) if (out.is_cuda and out.dtype == torch.float32) else feat + out
+        # feat + block_k(... block_1(feat)): one call per stage, the block residual folded into it where the fused layer path runs
+        res = genc.encoder_stage(self.encoder_blocks, feat, table, wplans, residual=True)
         sp_tensor = replace_feature(sp_tensor, res)             # token drop is the identity (no un-shuffle)
         return self.conv_out(sp_tensor)
 

@@ -501,6 +501,15 @@ typedef struct gdmae_layer_args {
    * the library's own fused kernels (gdmae_tok_gemm: bias + GELU, residual + LayerNorm, GELU backward in the epilogue)
    * instead of hipBLASLt + separate row kernels. */
   const void* packed;
+  /* Fused stage path only (gdmae_encoder_stage_fused() == 1), optional: the block residual around the stage (SSTBlockV1.forward,
+   * spt_backbone.py:219-264: the stage output is added to the stage input before conv_out) folded into the stage's own launches,
+   * all rows bf16.  Forward: layers[0].x_bf16 = 1 (x holds bf16 rows) and layers[n_layers-1].res_out = (n, d) bf16 receives
+   * x + y instead of y.  Backward: layers[n_layers-1].dres = (n, d) bf16 gradient of res_out (read instead of dy; it is also the
+   * gradient of the skip path) and layers[0].dx_bf16 = (n, d) bf16 receives dres + the gradient through the stage instead of dx. */
+  int x_bf16;
+  void* res_out;
+  const void* dres;
+  void* dx_bf16;
 } gdmae_layer_args;
 /* Packed weight image of one layer (bf16 mode): forward operands [Win(q,k rows) | Win(v rows) | Wo | W1 | W2] followed by
  * the transposed operands of the input-gradient products [W2^T | W1^T | Wo^T | Win(q,k)^T | Win(v)^T].
@@ -563,6 +572,8 @@ int gdmae_encoder_stage_bwd(const gdmae_layer_args* layers /* host array */, int
  *   0  one launch per product with fused row epilogues and an fp32 residual stream (csrc/tok_gemm.hip), every layers[i].y written.
  *  -1  the default: 1 unless the environment variable GDMAE_LAYER_V2 is 0. */
 int gdmae_encoder_set_layer_path(int path);
+/* 1 when gdmae_encoder_stage_fwd / _bwd would take the fused path (1 above) for these layers, else 0 */
+int gdmae_encoder_stage_fused(const gdmae_layer_args* layers /* host array */, int n_layers);
 
 /* ---- a17-a19: reconstruction targets and Chamfer loss ----------------------------------------- *
  * gdmae_group_gt_points replaces sst_ops_cuda.group_inner_inds_wrapper (sst_ops_api.cpp:8;
