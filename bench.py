@@ -66,7 +66,8 @@ def parse():
 
 
 def algorithmic_bytes_per_frame(N, M, Ms, ds, G, a):
-    """BYTES_FWD of SURVEY.md §8(d) (S1..S5); BYTES_TRAIN = 3 x BYTES_FWD."""
+    """BYTES_FWD of SURVEY.md §8(d) (S1..S5); BYTES_TRAIN = 3 x BYTES_FWD.  G = decoder sites per frame: every BEV cell for the
+    reference's dense decoder, the sites of the active 8 x 8 tiles for the sparse-aware decoder this build runs."""
     F = 5
     s1 = N * (1 + F) * 4 + N * 4 + M * (16 + 4 * F)
     s2 = 3 * (N * (1 + F) * 4 + N * 4) + M * 128 * a
@@ -109,7 +110,15 @@ def measure_cpu_baseline(config: str, mask_ratio: float):
         if it:
             times.append(time.perf_counter() - t0)
     dt = sorted(times)[1]
-    return {"value": round(1.0 / dt, 4), "unit": "frames/s", "cores": cores, "kind": "port",
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": round(1.0 / dt, 4), "unit": "frames/s", "cores": cores, "cpu_model": model, "kind": "port",
             "sample": f"1 frame of config {config} ({pts.shape[0]} pts), full train step fwd+bwd+Adam in fp32; median of 3 after one "
                       f"warm-up step ({', '.join('%.1f' % t for t in times)} s), {cores} threads (best of 16 / 32 / 64 / 128 measured "
                       f"on the MI355X host; {avail} logical CPUs available)"}
@@ -144,7 +153,7 @@ def _pmc_traffic(kernels):
 # events on the launch stream ON THE PRODUCT PATH: the encoder families by brackets inside the native layer / stage executors
 # (include/gdmae_hip.h gdmae_kernel_timing), the decoder kernels by brackets around their single C-ABI call (gdmae_hip.timing)
 ROOFLINE_KERNELS = {
-    "k_tok_gemm": ("hbm", ("k_tok_gemm", "k_tok_gemm_multi", "k_tok_ffn")),
+    "k_tok_gemm": ("hbm", ("k_tok_gemm", "k_tok_gemm_multi", "k_tok_ffn", "k_layer_fwd", "k_layer_bwd_ffn", "k_layer_bwd_in", "k_ln2_bwd_top")),
     "k_dw_grouped": ("hbm", ("k_dw_grouped",)),
     "k_layer_tail": ("hbm", ("k_layer_tail",)),
     "k_conv3x3_tiles": ("mfma", ("k_conv3x3_tiles",)),
@@ -170,8 +179,10 @@ def _library_slots():
         ms, calls, by, fl = C.c_double(0.0), C.c_longlong(0), C.c_double(0.0), C.c_double(0.0)
         L.call("gdmae_kernel_timing_read", slot, C.byref(ms), C.byref(calls), C.byref(by), C.byref(fl))
         if calls.value:
+            side = C.c_double(0.0)
+            L.call("gdmae_kernel_timing_read_side", slot, C.byref(side))
             out[name] = {"launches": calls.value, "total_ms": ms.value, "avg_us": 1e3 * ms.value / calls.value,
-                         "bytes_per_launch": by.value / calls.value, "total_bytes": by.value,
+                         "bytes_per_launch": by.value / calls.value, "total_bytes": by.value, "side_bytes": side.value,
                          "flops_per_launch": fl.value / calls.value, "total_flops": fl.value, "extra": {}}
     return out
 
@@ -217,6 +228,17 @@ def measure_roofline(step, feed, n_steps=4):
             d["algorithmic_flops_per_launch"] = int(v["flops_per_launch"])
         else:
             d["algorithmic_bytes_per_launch"] = int(v["bytes_per_launch"])
+            if name == "k_tok_gemm":
+                # what the family's launches move BESIDES the bf16 operand / result rows and weight images the fraction is computed
+                # from: fp32 statistics rows, per-workgroup partial rows, fp32 rows at the stage boundary, the y + pos copies
+                sb = v.get("side_bytes", 0.0)
+                d["side_stream_bytes_per_launch"] = int(sb / max(v["launches"], 1))
+                d["algorithmic_GB_per_step"] = round(v["total_bytes"] / n_steps / 1e9, 3)
+                d["side_stream_GB_per_step"] = round(sb / n_steps / 1e9, 3)
+                d["achieved_incl_side_streams"] = round((v["total_bytes"] + sb) / sec / 1e9, 1)
+                d["kernels"] = ("k_layer_fwd / k_layer_bwd_ffn / k_layer_bwd_in / k_ln2_bwd_top (csrc/layer_fused.hip: three fused launches per "
+                                "encoder layer and direction around the attention, bf16 residual stream) + k_tok_gemm_multi (q / k / v "
+                                "projections)")
         for k2, val in v.get("extra", {}).items():
             d[k2] = val
         return d, devk
@@ -277,8 +299,16 @@ class Workload:
         self.stage_dims = [int(b.ENCODER.D_MODEL) for b in cfg.BACKBONE_3D.SST_BLOCK_LIST]
         self.last = None
         self.advance = True           # False: every further step uses the same schedule position (extra legs after the timed region)
+        self.host_s = 0.0
 
     def step(self, i, pts, nxt=None, k=0, nxt_ready=None):
+        t_host = time.perf_counter()
+        try:
+            return self._step(i, pts, nxt, k, nxt_ready)
+        finally:
+            self.host_s += time.perf_counter() - t_host       # host time inside the step call (issue + any wait on the plan event)
+
+    def _step(self, i, pts, nxt=None, k=0, nxt_ready=None):
         net, opt, B = self.net, self.opt, self.B
         opt.zero_grad()
         bd = {"points": pts, "batch_size": B, "_gdmae_grad_sync": opt.sync, "_gdmae_dims": self.stage_dims}
@@ -358,6 +388,45 @@ def _synth_boxes(rng, B, n_max, pcr, n_class):
     return out
 
 
+def pin_rank_to_numa(local, world):
+    """One rank per GPU on one host: bind the process to cores of the NUMA node its GPU hangs off (sysfs numa_node of the PCI
+    function; the node's cpu list is split evenly between the ranks that land on it), so that eight ranks' interpreters,
+    autograd threads and pinned staging buffers do not migrate across sockets.  Best effort: returns a description or None."""
+    try:
+        if not hasattr(os, "sched_setaffinity"):
+            return None
+        prop = torch.cuda.get_device_properties(local)
+        bdf = "%04x:%02x:%02x.0" % (getattr(prop, "pci_domain_id", 0), prop.pci_bus_id, prop.pci_device_id)
+        node = int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read())
+        if node < 0:
+            return None
+        cpus = []
+        for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+            lo, _, hi = part.partition("-")
+            cpus += list(range(int(lo), int(hi or lo) + 1))
+        allowed = sorted(set(cpus) & set(os.sched_getaffinity(0)))
+        # ranks sharing the node: GPUs whose numa_node is the same, in device order
+        same = []
+        for dv in range(torch.cuda.device_count()):
+            pr = torch.cuda.get_device_properties(dv)
+            b2 = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+            try:
+                if int(open(f"/sys/bus/pci/devices/{b2}/numa_node").read()) == node:
+                    same.append(dv)
+            except OSError:
+                pass
+        if world > 1 and local in same and len(allowed) >= 4 * len(same):
+            per = len(allowed) // len(same)
+            k = same.index(local)
+            allowed = allowed[k * per:(k + 1) * per]
+        if not allowed:
+            return None
+        os.sched_setaffinity(0, allowed)
+        return {"numa_node": node, "cpus": f"{allowed[0]}-{allowed[-1]} ({len(allowed)})", "pci": bdf}
+    except Exception:      # noqa: BLE001  (placement is an optimisation, never a reason to fail the run)
+        return None
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -368,6 +437,7 @@ def main():
     torch.cuda.set_device(local)
     torch.backends.cudnn.benchmark = bool(args.miopen_find)
     dev = torch.device("cuda", local)
+    affinity = pin_rank_to_numa(local, world) if (world > 1 or os.environ.get("GDMAE_BENCH_PIN", "0") == "1") else None
     # GDMAE_BENCH_FORCE_DIST=1: rehearsal of the N > 1 code path on ONE GPU over RCCL (a one-rank nccl group; the gradient
     # exchange is forced on - sum over one rank = identity): every collective, stream hand-over and barrier of the multi-GPU
     # run executes against the real library.  The printed line is the N = 1 line plus "grad_sync".
@@ -414,14 +484,26 @@ def main():
     if args.feed == "h2d":
         wl.prime()                                  # the first timed step's batch is resident when the clock starts
     sync_all()
+    from gdmae_hip import plan as gplan
+    wl.host_s = 0.0
+    wait0 = gplan.EVENT_WAIT_S
+    wl.opt.sync.measure = distd
     t0 = time.perf_counter()
     wl.feed(args.steps, args.warmup)
     sync_all()
     dt = time.perf_counter() - t0
+    host_wait_ms = 1e3 * (gplan.EVENT_WAIT_S - wait0) / args.steps
+    host_ms = 1e3 * wl.host_s / args.steps - host_wait_ms      # issue time: what the host needs per step when it never has to wait
+    wl.opt.sync.measure = False
+    exposed_ms = wl.opt.sync.exposed_ms() if distd else None
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if distd:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
+    if distd:                                       # slowest rank's host time / exposed exchange time
+        hx = torch.tensor([host_ms, exposed_ms or 0.0, -host_wait_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(hx, op=dist.ReduceOp.MAX)
+        host_ms, exposed_ms, host_wait_ms = float(hx[0].item()), float(hx[1].item()), -float(hx[2].item())
     frames = B * world * args.steps
     fps = frames / dt
     wl.advance = False
@@ -433,7 +515,7 @@ def main():
     out = {"metric": "MAE pre-train frames/sec (Waymo-shape, 180k pts, 75% mask)" if pre else "fine-tune frames/sec (KITTI-shape, CenterPoint head)",
            "value": round(fps, 2),
            "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-           "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+           "ms_per_step": round(1e3 * dt / args.steps, 3), "host_ms_per_step": round(host_ms, 3), "host_wait_ms_per_step": round(host_wait_ms, 3), "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
            "config": {"workload": WORKLOADS[named] + (f", mask {args.mask_ratio}" if pre else "") +
                                   ", full train step (H2D of the next batch + fwd + bwd + grad all-reduce + clip + Adam)",
@@ -475,6 +557,14 @@ def main():
         # ---- the same loop with batches that never leave HBM (what round 1 / 2 reported as the headline)
         other_feed = wl.feed_resident if args.feed == "h2d" else wl.feed_h2d
         also["resident_inputs" if args.feed == "h2d" else "h2d_inclusive"] = timed_leg(wl, 2, args.steps, other_feed)
+        # ---- the drop-in default: batch_dict['spatial_features'] materialised dense as the reference module does
+        #      (spt_backbone_mae.py:130-138; SPTBackboneMAE.dense_spatial_features = True is the class default, the headline turns it
+        #      off because the pre-training step never reads the map - INTEGRATION.md section A)
+        if wl.mae:
+            wl.net.backbone_3d.dense_spatial_features = True
+            also["drop_in_default"] = timed_leg(wl, 3, max(5, args.steps // 2))
+            also["drop_in_default"]["note"] = "dense_spatial_features = True: the (B,128,Y,X) map of the reference is written every step"
+            wl.net.backbone_3d.dense_spatial_features = False
         # ---- the reference yaml's own mask ratio (tools/cfgs/waymo_models/gd_mae_ssl.yaml:158)
         other = 0.85 if abs(args.mask_ratio - 0.85) > 1e-6 else 0.75
         wl.net.backbone_3d.mask_ratio = other
@@ -525,10 +615,23 @@ def main():
                 out["config"]["decoder_active_tiles"] = f"{ep.dec_tiles.n_act} of {nt}"
             out["step_bytes_model"] = {"bytes_train_per_frame": int(bytes_train), "achieved_GBs": round(bytes_train * fps / world / 1e9, 1),
                                        "frac_of_8TBs": round(bytes_train * fps / world / 1e9 / HBM_PEAK_GBS, 4),
-                                       "note": "SURVEY 8d whole-step algorithmic bytes (dense-decoder formula) x frames/s per GPU"}
+                                       "note": "SURVEY 8d whole-step algorithmic bytes with the DENSE-decoder term (2208 x all BEV cells x a: bytes "
+                                               "this build does not move - it flatters the step) x frames/s per GPU; the sparse_decoder entry "
+                                               "counts the decoder term over the sites of the active 8 x 8 tiles only, which is what runs"}
+            if ep.dec_tiles is not None:
+                g_act = 64.0 * ep.dec_tiles.n_act / B
+                bt_sp = 3 * algorithmic_bytes_per_frame(N, M, Ms, dsz, g_act, a)
+                out["step_bytes_model"]["sparse_decoder"] = {
+                    "bytes_train_per_frame": int(bt_sp), "achieved_GBs": round(bt_sp * fps / world / 1e9, 1),
+                    "frac_of_8TBs": round(bt_sp * fps / world / 1e9 / HBM_PEAK_GBS, 4), "decoder_sites_per_frame": int(g_act)}
         if distd:
             opt = wl.opt
             out["grad_sync"] = {"buckets": [[b, hi - lo] for b, lo, hi in opt.buckets], "last_step": opt.sync.log,
+                                "exposed_ms": None if exposed_ms is None else round(exposed_ms, 4),
+                                "exposed_ms_note": "time per step the compute stream waited for the last collective after its own backward work "
+                                                   "(HIP events on both streams, max over ranks); 0 = the exchange hid under the backward",
+                                "checked_steps": opt.sync.checked_steps,
+                                "cpu_affinity": affinity,
                                 "note": "one all-reduce per bucket; 'overlapped' = launched on the communication stream from inside "
                                         "backward(), 'tail' = after it"}
         if roofline is not None:

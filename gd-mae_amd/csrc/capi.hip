@@ -22,7 +22,7 @@ int g_gd_timing_on = 0;
 namespace {
 struct TimedCall {
   hipEvent_t a, b;
-  double bytes, flops;
+  double bytes, flops, side;
 };
 std::vector<TimedCall> g_timed[GD_T_SLOTS];
 const char* const kSlotNames[GD_T_SLOTS] = {"k_win_attn_fwd", "k_win_attn_bwd", "k_tok_gemm", "k_dw_grouped", "k_conv3x3_tiles",
@@ -44,11 +44,12 @@ void* gd_timing_begin(int slot, hipStream_t st) {
   (void)hipEventRecord(p->tc.a, st);
   return p;
 }
-void gd_timing_end(void* handle, hipStream_t st, double bytes, double flops) {
+void gd_timing_end(void* handle, hipStream_t st, double bytes, double flops, double side) {
   Pending* p = (Pending*)handle;
   (void)hipEventRecord(p->tc.b, st);
   p->tc.bytes = bytes;
   p->tc.flops = flops;
+  p->tc.side = side;
   g_timed[p->slot].push_back(p->tc);
   delete p;
 }
@@ -84,6 +85,14 @@ extern "C" int gdmae_kernel_timing_read(int slot, double* total_ms, long long* c
   *calls = (long long)g_timed[slot].size();
   if (bytes) *bytes = by;
   if (flops) *flops = fl;
+  return 0;
+}
+// summed side-stream bytes of a slot (what its launches move besides the operand / result rows and weights counted in `bytes`)
+extern "C" int gdmae_kernel_timing_read_side(int slot, double* side_bytes) {
+  GD_REQUIRE(slot >= 0 && slot < GD_T_SLOTS && side_bytes != nullptr, "kernel timing: no such slot");
+  double sd = 0.0;
+  for (auto& t : g_timed[slot]) sd += t.side;
+  *side_bytes = sd;
   return 0;
 }
 // round-2 names of the two attention slots

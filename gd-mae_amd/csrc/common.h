@@ -38,14 +38,18 @@ enum {
 };
 extern int g_gd_timing_on;
 void* gd_timing_begin(int slot, hipStream_t st);
-void gd_timing_end(void* handle, hipStream_t st, double bytes, double flops);
+void gd_timing_end(void* handle, hipStream_t st, double bytes, double flops, double side);
+// bytes: operand / result rows in the compute dtype + weight images, each counted once (the figure the roofline fraction is
+// computed from); side: what the launch moves besides by design (fp32 statistics rows, per-workgroup partial rows, fp32 rows at a
+// stage boundary, duplicate copies such as y + pos)
 struct GdTimed {
   void* h;
   hipStream_t st;
-  double bytes, flops;
-  GdTimed(int slot, hipStream_t s, double b, double f = 0.0) : h(g_gd_timing_on ? gd_timing_begin(slot, s) : nullptr), st(s), bytes(b), flops(f) {}
+  double bytes, flops, side;
+  GdTimed(int slot, hipStream_t s, double b, double f = 0.0, double sd = 0.0)
+      : h(g_gd_timing_on ? gd_timing_begin(slot, s) : nullptr), st(s), bytes(b), flops(f), side(sd) {}
   ~GdTimed() {
-    if (h) gd_timing_end(h, st, bytes, flops);
+    if (h) gd_timing_end(h, st, bytes, flops, side);
   }
 };
 

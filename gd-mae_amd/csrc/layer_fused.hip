@@ -723,11 +723,12 @@ int gd_layer_fused_fwd(hipStream_t st, int d, const void* o, const void* x, cons
   A.y = y; A.y_bf = (unsigned short*)y_bf; A.ypos_bf = (unsigned short*)ypos_bf; A.pos_table = pos_table; A.tok_pos = tok_pos;
   const int rows = gd_layer_fused_rows(d), ff = 2 * d;
   const int lds = rows * (d * 2 + 16) + rows * (ff * 2 + 16);
-  // o, x in; a, x1, h, f, (y | y_bf + ypos_bf) out; three weight images
+  // bf16 rows: o, x in; a, x1, h, f, y (or x + y) out; three weight images.  Side: fp32 y at the stage boundary, the y + pos copy,
+  // the stage input re-read for the block residual, statistics rows, position ids
   GdTimed timed(GD_T_TOK_GEMM, st,
-                2.0 * n_pad * d + (double)n * d * (2 + 2 + 2 + 2 + (y ? 4 : 0) + (y_bf ? 2 : 0) + (ypos_bf ? 2 : 0) + (res_out ? 4 : 0)) + 2.0 * n_pad * ff + 16.0 * n +
-                    (ypos_bf ? 4.0 * n : 0.0) + 2.0 * (d * d + 2.0 * d * ff),
-                2.0 * n_pad * (d * d + 2.0 * d * ff));
+                2.0 * n_pad * d + (double)n * d * (2 + 2 + 2 + 2 + ((y_bf || res_out) ? 2 : 0)) + 2.0 * n_pad * ff + 2.0 * (d * d + 2.0 * d * ff),
+                2.0 * n_pad * (d * d + 2.0 * d * ff),
+                (double)n * d * ((y ? 4 : 0) + (ypos_bf ? 2 : 0) + (res_out ? 2 : 0)) + 16.0 * n + (ypos_bf ? 4.0 * n : 0.0));
   static bool once[2] = {false, false};
   if (d == 128) {
     if (!once[0]) { if (int rc = set_lds(k_layer_fwd<128>, lds)) return rc; once[0] = true; }
@@ -751,11 +752,10 @@ int gd_layer_fused_bwd_ffn(hipStream_t st, int d, const void* df, const void* h,
   A.dh = (unsigned short*)dh; A.gact = (unsigned short*)gact; A.da = (unsigned short*)da; A.d_o = (unsigned short*)d_o; A.part = part;
   const int rows = gd_layer_fused_rows(d), ff = 2 * d;
   const int lds = rows * (d * 2 + 16) + rows * (ff * 2 + 16);
-  // df, h, x, a in; dh, gelu(h), da, do out; partial rows; three weight images
+  // bf16 rows: df, h, x, a in; dh, gelu(h), da, do out; three weight images.  Side: statistics rows, partial rows
   GdTimed timed(GD_T_TOK_GEMM, st,
-                2.0 * n_pad * d + 2.0 * n_pad * ff + (double)n * d * (2 + 2 + 2) + 2.0 * n_pad * d + 4.0 * n_pad * ff + 8.0 * n +
-                    12.0 * d * (double)(n_pad / rows) + 2.0 * (d * d + 2.0 * d * ff),
-                2.0 * n_pad * (d * d + 2.0 * d * ff));
+                2.0 * n_pad * d + 2.0 * n_pad * ff + (double)n * d * (2 + 2 + 2) + 2.0 * n_pad * d + 4.0 * n_pad * ff + 2.0 * (d * d + 2.0 * d * ff),
+                2.0 * n_pad * (d * d + 2.0 * d * ff), 8.0 * n + 12.0 * d * (double)(n_pad / rows));
   static bool once[2] = {false, false};
   if (d == 128) {
     if (!once[0]) { if (int rc = set_lds(k_layer_bwd_ffn<128>, lds)) return rc; once[0] = true; }
@@ -782,10 +782,10 @@ int gd_layer_fused_bwd_in(hipStream_t st, int d, const void* dqk, const void* dv
   const bool ln = dx == nullptr && dx_bf == nullptr;
   const int rows = gd_layer_fused_rows(d);
   const int lds = rows * (3 * d * 2 + 16);
-  GdTimed timed(GD_T_TOK_GEMM, st,
-                2.0 * n_pad * 3 * d + (double)n * d * (2 + (ln ? 2 + 2 + 2 : 4)) + (ln ? 8.0 * n + 12.0 * d * (double)(n_pad / rows) : 0.0) +
-                    2.0 * 3 * d * d,
-                2.0 * n_pad * 3 * d * d);
+  // bf16 rows: dqk, dv, da in (+ both LayerNorm addends in, df out | the skip-path gradient in, dx out); two weight images.  Side:
+  // statistics + partial rows, or the fp32 dx rows
+  GdTimed timed(GD_T_TOK_GEMM, st, 2.0 * n_pad * 3 * d + (double)n * d * (2 + (ln ? 2 + 2 + 2 : (dx_bf ? 2 + 2 : 0))) + 2.0 * 3 * d * d,
+                2.0 * n_pad * 3 * d * d, ln ? 8.0 * n + 12.0 * d * (double)(n_pad / rows) : (dx_bf ? 0.0 : 4.0 * n * d));
   static bool once[4] = {false, false, false, false};
 #define LI_CASE(D_, LN_, idx)                                                                                   \
   {                                                                                                             \
@@ -817,7 +817,7 @@ int gd_layer_fused_ln2_top(hipStream_t st, int d, const float* dy, const void* d
                            const float* gamma, long long n, long long n_pad, void* dout, float* part) {
   LtArgs A = {dy, (const unsigned short*)dy_bf, (const unsigned short*)ln_a, (const unsigned short*)ln_b, stats, gamma, n, (unsigned short*)dout, part};
   const int rows = gd_layer_fused_rows(d);
-  GdTimed timed(GD_T_TOK_GEMM, st, (double)n * d * ((dy ? 4 : 2) + 2 + 2 + 2) + 8.0 * n + 12.0 * d * (double)(n_pad / rows));
+  GdTimed timed(GD_T_TOK_GEMM, st, (double)n * d * ((dy ? 0 : 2) + 2 + 2 + 2), 0.0, (dy ? 4.0 * n * d : 0.0) + 8.0 * n + 12.0 * d * (double)(n_pad / rows));
   if (d == 128) hipLaunchKernelGGL(k_ln2_bwd_top<128>, dim3((unsigned)(n_pad / rows)), dim3(512), 0, st, A);
   else if (d == 256) hipLaunchKernelGGL(k_ln2_bwd_top<256>, dim3((unsigned)(n_pad / rows)), dim3(512), 0, st, A);
   else GD_REQUIRE(false, "layer_fused_ln2_top: d must be 128 or 256");

@@ -90,6 +90,7 @@ SIGNATURES = {
     "gdmae_kernel_timing_slots": (_I, []),
     "gdmae_kernel_timing_name": (C.c_char_p, [_I]),
     "gdmae_kernel_timing_read": (_I, [_I, _P, _P, _P, _P]),
+    "gdmae_kernel_timing_read_side": (_I, [_I, _P]),
     "gdmae_add_layernorm_workspace_bytes": (_Z, [_I]),
     "gdmae_add_layernorm_fwd": (_I, [_P, _P, _I, _P, _P, _L, _I, _F, _P, _P, _P, _P]),
     "gdmae_add_layernorm_bwd": (_I, [_P, _P, _I, _P, _P, _P, _P, _I, _L, _I, _P, _P, _P, _P, _P]),

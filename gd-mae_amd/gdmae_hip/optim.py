@@ -298,6 +298,17 @@ class GradSync:
         # collectives issued from tensor hooks on the autograd thread, on the communication stream - is exercised on a box
         # with a single GPU (RCCL refuses two ranks per device)
         self.force = os.environ.get("GDMAE_SYNC_FORCE", "0") == "1"
+        # The overlap rests on autograd delivering a marked tensor's gradient only after every node recorded behind it has run.
+        # The FIRST step of any job that really exchanges gradients therefore runs as a 'check' step on its own (snapshots at the
+        # hooks, compared with the final local gradients, reduction at the tail): a model change that breaks the marks raises at
+        # iteration 0 instead of training on partial sums.  GDMAE_SYNC_AUTOCHECK=0 switches it off.
+        self.autocheck = os.environ.get("GDMAE_SYNC_AUTOCHECK", "1") != "0"
+        self.checked_steps = 0
+        self._step_mode = self.mode
+        # measure: keep (compute-stream, communication-stream) event pairs of the finish() hand-over; exposed_ms() = how long the
+        # compute stream had to wait for the collectives after its own backward work was done (bench.py --gpus N)
+        self.measure = False
+        self._pairs = []
 
     def _active(self):
         return self.mode != "off" and (self.opt.world_size() > 1 or (self.force and dist.is_initialized()))
@@ -305,6 +316,9 @@ class GradSync:
     def begin_step(self):
         assert self.mode in ("overlap", "tail", "check", "off"), self.mode
         self.launched, self.works, self.log, self._snap = set(), [], [], {}
+        self._step_mode = self.mode
+        if self.mode == "overlap" and self.autocheck and self.checked_steps == 0 and self._active():
+            self._step_mode = "check"
 
     def bucket_names(self):
         return [b for b, _, _ in self.opt.buckets]
@@ -316,9 +330,9 @@ class GradSync:
         names = list(done_buckets)
 
         def hook(_g):
-            if self.mode == "overlap":
+            if self._step_mode == "overlap":
                 self.reduce(names, "overlapped")
-            elif self.mode == "check":
+            elif self._step_mode == "check":
                 for b, lo, hi in self.opt.buckets:
                     if b in names and b not in self._snap:
                         self._snap[b] = self.opt.flat_grad[lo:hi].clone()
@@ -349,7 +363,8 @@ class GradSync:
     def finish(self):
         if not self._active():
             return
-        if self.mode == "check":
+        if self._step_mode == "check":
+            self.checked_steps += 1
             for b, lo, hi in self.opt.buckets:
                 snap = self._snap.get(b)
                 if snap is not None and not torch.equal(snap, self.opt.flat_grad[lo:hi]):
@@ -357,8 +372,27 @@ class GradSync:
                                        "of this bucket is used before the marked tensor (its all-reduce would have been launched "
                                        "on an unfinished gradient)")
         self.reduce(self.bucket_names(), "tail")
+        pair = None
+        if self.measure and self.opt.flat_grad.is_cuda and self._comm is not None:
+            pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            pair[0].record()                              # the compute stream has nothing left but to wait ...
+            pair[1].record(self._comm)                    # ... for the last collective
+            self._pairs.append(pair)
         for w in self.works:
             w.wait()                                      # NCCL/RCCL: orders the CURRENT stream behind the collective
         if self.opt.flat_grad.is_cuda and self._comm is not None:
             torch.cuda.current_stream().wait_stream(self._comm)
         self.works = []
+
+    def exposed_ms(self):
+        """Mean time per measured step the compute stream waited for the gradient exchange (0 when the collectives finished under
+        the backward); synchronises with the recorded events."""
+        if not self._pairs:
+            return None
+        tot = 0.0
+        for a, b in self._pairs:
+            b.synchronize()
+            tot += max(0.0, a.elapsed_time(b))
+        n = len(self._pairs)
+        self._pairs = []
+        return tot / n

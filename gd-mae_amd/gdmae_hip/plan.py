@@ -383,6 +383,9 @@ def encoder_plan(vox: VoxelPlan, strides, window_shapes, drop_infos, keep_frac: 
 # the whole plan as ONE call of the library (csrc/plan.hip: gdmae_geometry_plan)
 # ------------------------------------------------------------------------------------------------
 import collections
+import time as _time
+
+EVENT_WAIT_S = 0.0     # seconds the host has spent blocked in PlanPrefetch.finish() waiting for a plan's counts (bench.py reads it)
 
 _PLAN_SHAPES = collections.OrderedDict()   # shape key -> (PlanParams, {name: (offset, bytes)}, arena bytes, per-stage geometry): LRU
 _PLAN_SHAPES_MAX = 32
@@ -538,7 +541,10 @@ class PlanPrefetch:
         # invariant behind the missing record_stream calls (see __init__): the plan arena is only ever ALLOCATED on the plan
         # stream inside __init__ and only ever CONSUMED on the stream that issues the prefetches
         assert self.serial or torch.cuda.current_stream() != self.side, "plan tensors must not be consumed on the plan stream"
+        global EVENT_WAIT_S
+        t_w = _time.perf_counter()
         self.event.synchronize()
+        EVENT_WAIT_S += _time.perf_counter() - t_w          # host blocked on the plan stream (it runs ahead of the GPU otherwise)
         torch.cuda.current_stream().wait_event(self.event)
         c = self.host.tolist()
         if self._pinned is not None:                               # read: the buffer may serve the next prefetch

@@ -341,6 +341,10 @@ int gdmae_kernel_timing(int on);
 int gdmae_kernel_timing_slots(void);
 const char* gdmae_kernel_timing_name(int slot);
 int gdmae_kernel_timing_read(int slot, double* total_ms, long long* calls, double* bytes, double* flops);
+/* For the fused layer launches (csrc/layer_fused.hip) `bytes` counts the bf16 operand / result rows and the weight images only;
+ * what those launches move besides (fp32 statistics rows, per-workgroup partial rows, fp32 rows at the stage boundary, the
+ * y + pos copy of a layer output) is summed here. */
+int gdmae_kernel_timing_read_side(int slot, double* side_bytes);
 /* out[0] = sum(term) / sum(weights), out[1] = 1 / sum(weights) (both 0 when no weight is positive): the weighted mean
  * that finishes pytorch3d.loss.chamfer_distance (spt_backbone_mae.py:83-89), one single-workgroup launch. */
 int gdmae_weighted_mean_finish(const float* term, const float* weights, long long n, float* out, void* stream);

@@ -91,6 +91,13 @@ def _overlap_worker(rank, world, port, q):
     model = _Staged()
     opt = optim.FlatAdamOneCycle(model, configs.optimization_cfg(), total_steps=10)
     out = []
+    # iteration 0 of a job that exchanges gradients is an automatic 'check' step (GradSync.autocheck): snapshots at the hooks are
+    # compared with the final local gradients and everything is reduced at the tail; the overlapped exchange starts with step 1
+    assert opt.sync.autocheck and opt.sync.checked_steps == 0
+    opt.zero_grad()
+    model(torch.randn(5, 6, generator=torch.Generator().manual_seed(77 + rank)), opt.sync).square().sum().backward()
+    opt.all_reduce_grads()
+    assert opt.sync.checked_steps == 1 and [how for _, how in opt.sync.log] == ["tail"] * 4, opt.sync.log
     for it in range(2):                                       # two steps: the per-step state of GradSync resets
         opt.zero_grad()
         x = torch.randn(5, 6, generator=torch.Generator().manual_seed(10 * it + rank))

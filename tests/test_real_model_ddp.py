@@ -63,6 +63,7 @@ def _grad_worker_body(rank, world, port, config, B, q):
     from gdmae_hip import configs, optim
     cfg, ds, net, pts = _build(config, B, rank)
     opt = optim.FlatAdamOneCycle(net, configs.optimization_cfg(B), total_steps=10)
+    opt.sync.autocheck = False          # the modes are driven explicitly here (the automatic first-step check is covered on the CPU)
     grads, logs = {}, {}
     for mode in ("off", "overlap", "tail", "check"):
         opt.sync.mode = mode
@@ -158,6 +159,7 @@ def _rccl_worker_body(port, q):
     cfg, ds, net, pts = _build("A", 2, 0)
     opt = optim.FlatAdamOneCycle(net, configs.optimization_cfg(2), total_steps=10)
     opt.sync.force = True
+    opt.sync.autocheck = False
     grads, logs = {}, {}
     for mode in ("off", "overlap", "tail", "check", "overlap"):
         opt.sync.mode = mode
