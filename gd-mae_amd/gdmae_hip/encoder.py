@@ -269,9 +269,12 @@ def _param_args(plist, cdt, direct):
         if packed is not None:
             tensors["packed"] = packed
             a.packed = L.ptr(packed)
-    if stable:
+    if all(t is not None for t in direct):
+        # gradients accumulate straight into the flat optimizer buffer - also on a step whose shadows are stale (a torch-side weight
+        # change between two optimizer steps: the operands are then cast / packed on the spot, nothing is cached)
         for k, g in zip(_GRAD_FIELDS, direct):
             setattr(a, k, L.ptr(g))
+    if stable:
         # the shadows are refreshed in place by the optimizer; a changed version only matters for pointer identity
         if cache is None:
             cache = Win._gd_layer_args = {}

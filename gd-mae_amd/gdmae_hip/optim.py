@@ -157,6 +157,14 @@ class FlatAdamOneCycle:
             from . import packing
             packing.repack_registered()          # fragment-ordered images of the encoder weights (one launch)
 
+    def refresh_weights(self):
+        """Call after changing parameter VALUES behind autograd's back (``p.data.copy_``, an EMA swap through ``.data``, a raw
+        pointer write): the bf16 shadows and the packed MFMA weight images are re-derived from the fp32 masters.  Changes through
+        torch that bump the parameter's version counter (``load_state_dict``, ``p.copy_`` under no_grad) are noticed without it."""
+        for p in self.params:
+            p._gd_shadow = None
+        self._refresh_shadows()
+
     def _check_views(self):
         for p in self.params:
             if p.grad is not p._gd_flat_grad:

@@ -178,17 +178,19 @@ def test_train_step_is_finite_and_deterministic_at_full_size(scene):
     assert torch.equal(res[0][1], res[1][1]), float((res[0][1] - res[1][1]).abs().max())
 
 
-def test_one_full_size_frame_matches_the_oracle():
-    """Config B at full size, ONE frame (the oracle needs ~5 s for it): HIP fp32 path vs oracle/gdmae_oracle.forward on the
-    same seeded frame, weights and masking noise - voxel indices, inverse map, token mask, stage active sets bit-exact,
-    Chamfer loss within 1e-4 relative (north_star), stage / decoder features within 5e-4."""
+@pytest.mark.parametrize("config,min_points", [("B", 170_000), ("E", 55_000)])
+def test_one_full_size_frame_matches_the_oracle(config, min_points):
+    """Configs B (Waymo-shape, 180 k points, 12 layers 128 / 256 / 256) and E (ONCE-shape, 60 k points, 6 layers d = 256) at full
+    size, ONE frame (the oracle needs a few seconds for it): HIP fp32 path vs oracle/gdmae_oracle.forward on the same seeded frame,
+    weights and masking noise - voxel indices, inverse map, token mask, stage active sets bit-exact, Chamfer loss within 1e-4
+    relative (north_star), stage / decoder features within 5e-4."""
     from gdmae_hip import configs, synth
     from oracle import gdmae_oracle as orc
     from pcdet.models import build_network
-    cfg, ds, skw = configs.named_config("B", mask_ratio=0.75)
+    cfg, ds, skw = configs.named_config(config, mask_ratio=0.75)
     pts = synth.synth_batch(31337, 1, ds.point_cloud_range, **skw)
-    assert pts.shape[0] > 170_000
-    shapes = orc.param_shapes(cfg, 5)
+    assert pts.shape[0] > min_points
+    shapes = orc.param_shapes(cfg, ds.point_feature_encoder.num_point_features)
     sd = orc.seeded_state_dict(shapes, seed=21)
     o = orc.forward(torch.from_numpy(pts), 1, cfg, {k: v.clone() for k, v in sd.items()}, ds.point_cloud_range, ds.voxel_size,
                     ds.grid_size, noise_seed=9)
@@ -212,6 +214,12 @@ def test_one_full_size_frame_matches_the_oracle():
     assert torch.equal(fr["gt_points"].cpu(), o["gt_points"])
     rel = abs(float(ret["loss"]) - float(o["loss"])) / abs(float(o["loss"]))
     assert rel < 1e-4, (float(ret["loss"]), float(o["loss"]), rel)
+
+
+# bounds of the bench (bf16) mode against the fp32 parity mode at full size: <= 2 x the deviations measured on MI355X (printed by the
+# test; DESIGN.md section 5 keeps the measured values) so that a regression in a fused epilogue cannot hide under a loose bound
+# measured (round 4, fused layer path): loss 9.9e-5, gradient norms 3.1e-2, cosine 0.99412, tau 5.6e-2 of the largest |dtau|, tau vector 4.8e-2
+LOSS_REL, NORM_REL, COS_MIN, TAU_ABS, TAU_L2 = 2.5e-4, 0.065, 0.988, 0.12, 0.10
 
 
 def test_bench_mode_matches_fp32_mode_at_full_size(scene):
@@ -252,25 +260,28 @@ def test_bench_mode_matches_fp32_mode_at_full_size(scene):
     lb, gb, mb, cb = res["bench"]
     lf, gf, mf, cf = res["fp32"]
     assert torch.equal(mb, mf) and torch.equal(cb, cf)
-    assert abs(lb - lf) <= 1e-2 * abs(lf), (lb, lf)
     taus = [n for n in gf if n.endswith("tau")]
     tau_scale = max(float(gf[n].abs().max()) for n in taus)
-    import json, os
-    if os.path.isdir('gpurun_out'):
-        json.dump({n: (float(gb[n][0]), float(gf[n][0])) for n in taus}, open('gpurun_out/tau_table.json', 'w'), indent=1)
     bad = []
+    worst = {"norm": 0.0, "cos": 1.0, "tau": 0.0}
     for n in gf:
         a, b = gb[n].reshape(-1), gf[n].reshape(-1)
         if n.endswith("tau"):
-            if abs(float(a[0] - b[0])) > 0.20 * tau_scale + 0.10 * abs(float(b[0])):
+            worst["tau"] = max(worst["tau"], abs(float(a[0] - b[0])) / tau_scale)
+            if abs(float(a[0] - b[0])) > TAU_ABS * tau_scale + 0.10 * abs(float(b[0])):
                 bad.append((n, float(a[0]), float(b[0])))
             continue
         na, nb = float(a.norm()), float(b.norm())
         cos = float((a * b).sum()) / (na * nb + 1e-300)
-        if abs(na - nb) > 0.10 * nb or cos < 0.97:
+        worst["norm"], worst["cos"] = max(worst["norm"], abs(na - nb) / nb), min(worst["cos"], cos)
+        if abs(na - nb) > NORM_REL * nb or cos < COS_MIN:
             bad.append((n, na, nb, cos))
     tb, tf = torch.stack([gb[n][0] for n in taus]), torch.stack([gf[n][0] for n in taus])
-    assert float((tb - tf).norm()) <= 0.20 * float(tf.norm()), (tb.tolist(), tf.tolist())
+    tau_l2 = float((tb - tf).norm()) / float(tf.norm())
+    print(f"[bench vs fp32, full size] loss rel {abs(lb - lf) / abs(lf):.3e}; worst gradient-norm deviation {worst['norm']:.3e}, worst cosine "
+          f"{worst['cos']:.5f}; tau: worst |d| / max|dtau| {worst['tau']:.3e}, vector L2 rel {tau_l2:.3e}")
+    assert abs(lb - lf) <= LOSS_REL * abs(lf), (lb, lf)
+    assert tau_l2 <= TAU_L2, (tb.tolist(), tf.tolist())
     assert not bad, bad
 
 

@@ -731,6 +731,9 @@ def test_bench_mode_gradients_reach_every_parameter(name):
     # in DESIGN.md section 7), so they are only required to be finite and non-zero here
     tol = np.array([np.inf if k.endswith("tau") else 0.12 for k in names])
     assert np.isfinite(gn).all()
+    nt = np.array([not k.endswith("tau") for k in names])
+    print(f"[bench mode vs fp32 golden, {name}] loss rel {abs(float(ret['loss']) - float(z['loss'])) / float(z['loss']):.3e}, worst gradient-norm "
+          f"deviation (tau excluded) {rel[nt].max():.3e}")
     assert (rel <= tol).all(), [(names[i], rel[i]) for i in np.flatnonzero(rel > tol)]
 
 
@@ -793,6 +796,84 @@ def test_stage_executor_equals_per_layer_calls():
     assert res[True][0] == res[False][0]
     g1, g0 = res[True][1], res[False][1]
     assert float((g1 - g0).norm()) <= 1e-6 * float(g0.norm()), float((g1 - g0).norm() / g0.norm())
+
+
+def test_packed_weight_images_follow_weight_changes_between_optimizer_steps():
+    """The packed MFMA weight images (encoder layers, sparse convolutions, decoder conv_out) are refreshed by the optimizer once
+    per step; a weight change through torch in between - load_state_dict after a first forward (mid-training resume) - keeps every
+    data_ptr, so a registry keyed by pointers alone would run the implicit sparse convolutions and the token GEMMs on the OLD
+    weights while the bf16 shadows see the new ones.  Loss and gradients after the reload must equal those of a model built with
+    the new weights from the start; a change through .data needs FlatAdamOneCycle.refresh_weights()."""
+    import logging
+    from gdmae_hip import configs, optim
+    from pcdet.models import build_network
+    z, ds, cfg, shapes = load_case("waymo_b1")
+    sd_a = orc.seeded_state_dict(shapes, seed=int(z["seed"]))
+    sd_b = orc.seeded_state_dict(shapes, seed=int(z["seed"]) + 5)
+
+    def run(net, opt):
+        opt.zero_grad()
+        bd = {"points": torch.from_numpy(z["points"]).to(dev()), "batch_size": int(z["batch_size"]),
+              "mae_noise": torch.from_numpy(z["noise"]).to(dev())}
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            ret, _, _ = net(bd)
+        ret["loss"].backward()
+        return float(ret["loss"]), opt.flat_grad.clone()
+
+    def fresh(sd):
+        torch.manual_seed(0)
+        net = build_network(cfg, len(ds.class_names), ds, logging.getLogger("t")).to(dev()).train()
+        net.load_state_dict(sd, strict=False)
+        return net, optim.FlatAdamOneCycle(net, configs.optimization_cfg(8), total_steps=10)
+
+    net_b, opt_b = fresh(sd_b)
+    l_ref, g_ref = run(net_b, opt_b)
+    net, opt = fresh(sd_a)
+    l_a, _ = run(net, opt)                                   # registers + packs every image from weights A
+    assert abs(l_a - l_ref) > 1e-3 * abs(l_ref)              # the two weight sets really differ
+    net.load_state_dict(sd_b, strict=False)                  # in place: same storage, version counters bumped
+    l1, g1 = run(net, opt)
+    assert l1 == l_ref, (l1, l_ref)
+    assert torch.equal(g1, g_ref)
+    # ... and through .data (no version bump) with the explicit refresh
+    with torch.no_grad():
+        for k, p in net.named_parameters():
+            p.data.copy_(sd_a[k].to(p.device))
+    opt.refresh_weights()
+    l2, _ = run(net, opt)
+    assert l2 == l_a, (l2, l_a)
+
+
+def test_plan_layouts_are_cached_per_capacity_bucket():
+    """Real batches differ in point count at every step: the plan layout (arena offsets) is cached per capacity bucket of 16384
+    points in a bounded LRU, the exact count travels with the call, and results do not depend on which layout served the call; the
+    mask ratio is part of the key (a second model with another ratio and the same shapes gets its own entry)."""
+    from gdmae_hip import configs, plan as gplan, synth
+    from pcdet.models.backbones_3d.spt_backbone import stage_plan_args
+    cfg, ds, skw = configs.named_config("A")
+    pts = torch.from_numpy(synth.synth_batch(3, 2, ds.point_cloud_range, **skw)).to(dev())
+    args = (ds.point_cloud_range, ds.voxel_size, ds.grid_size, 2, *stage_plan_args(cfg.BACKBONE_3D.SST_BLOCK_LIST))
+    n0 = pts.shape[0]
+    gplan._PLAN_SHAPES.clear()
+    outs = []
+    for n in (n0, n0 - 1, n0 - 777, n0 - 16385):
+        noise = torch.rand(n0, generator=torch.Generator().manual_seed(5)).to(dev())
+        vox, ep = gplan.PlanPrefetch(pts[:n].contiguous(), *args, keep_frac=0.5, noise=noise).finish()
+        ref_v = gplan.voxelize(pts[:n].contiguous(), ds.point_cloud_range, ds.voxel_size, ds.grid_size, 2)
+        assert vox.N == ref_v.N and vox.M == ref_v.M and torch.equal(vox.voxel_coords, ref_v.voxel_coords)
+        assert torch.equal(vox.inverse, ref_v.inverse)
+        outs.append((vox.N, vox.M, ep.stages[0].n_tok))
+    assert len(gplan._PLAN_SHAPES) == 2, list(gplan._PLAN_SHAPES)      # three counts share a bucket, the fourth is one bucket lower
+    gplan.PlanPrefetch(pts, *args, keep_frac=0.25).finish()
+    assert len(gplan._PLAN_SHAPES) == 3
+    # many prefetches in flight before any finish(): every one owns its pinned read-back buffer
+    pend = [gplan.PlanPrefetch(pts[:n0 - 100 * i].contiguous(), *args, keep_frac=0.5) for i in range(12)]
+    got = [p.finish()[0].N for p in pend]
+    want = [gplan.voxelize(pts[:n0 - 100 * i].contiguous(), ds.point_cloud_range, ds.voxel_size, ds.grid_size, 2).N for i in range(12)]
+    assert got == want
+    for i in range(40):                                                # the cache stays bounded
+        gplan._plan_shape(20000 + 16384 * i, pts.shape[1], 2, *args[:3], *args[4:], 0.5, None)
+    assert len(gplan._PLAN_SHAPES) <= gplan._PLAN_SHAPES_MAX
 
 
 @pytest.mark.parametrize("name", ["waymo_b1", "once_e_b1"])

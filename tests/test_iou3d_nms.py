@@ -41,6 +41,61 @@ def test_oracle_overlap_agrees_with_exact_clipping():
     assert abs(float(orc.overlap(a, inner)) - float(inner[3] * inner[4])) < 1e-3
 
 
+# Known answers from plane geometry (boxes [x, y, z, dx, dy, dz, heading]; area in m^2) - they pin BOTH the oracle and the kernels
+# independently of either implementation and of the reference's 1e-2 corner margin (no case has a corner within the margin of an
+# edge of the other box, except the last two, whose exact value is the limit of the margin rule)
+_S2 = float(np.sqrt(2.0))
+KNOWN_OVERLAPS = [
+    # axis-aligned partial overlap: [-2, 2] x [-1, 1] with the box shifted by (1, 0.5) -> 3 x 1.5
+    ([0, 0, 0, 4, 2, 1, 0.0], [1, 0.5, 0, 4, 2, 1, 0.0], 4.5),
+    # the same rectangle turned by 90 degrees about the common centre -> the 2 x 2 square
+    ([0, 0, 0, 4, 2, 1, 0.0], [0, 0, 0, 4, 2, 1, np.pi / 2], 4.0),
+    # a 2 x 2 square and its 45-degree turn: the regular octagon 8 (sqrt 2 - 1) a^2, a = 1
+    ([3, -2, 0, 2, 2, 1, 0.0], [3, -2, 0, 2, 2, 1, np.pi / 4], 8.0 * (_S2 - 1.0)),
+    # headings of pi and -pi / 2 are the same rectangles
+    ([0, 0, 0, 4, 2, 1, np.pi], [1, 0.5, 0, 4, 2, 1, 0.0], 4.5),
+    ([0, 0, 0, 4, 2, 1, 0.0], [0, 0, 0, 4, 2, 1, -np.pi / 2], 4.0),
+    # a small square inside a large turned one -> the small area
+    ([5, 5, 0, 6, 6, 1, 0.3], [5.2, 4.9, 0, 1, 1, 1, 1.1], 1.0),
+    # a 45-degree square (half diagonal sqrt 2) whose corner reaches 0.5 into an axis-aligned one: right triangle, legs 0.5 sqrt 2 ... area 0.25
+    ([0, 0, 0, 2, 2, 1, 0.0], [1 + _S2 - 0.5, 0, 0, 2, 2, 1, np.pi / 4], 0.25),
+    # disjoint by 5 cm, and by far
+    ([0, 0, 0, 2, 2, 1, 0.0], [2.05, 0, 0, 2, 2, 1, 0.0], 0.0),
+    ([0, 0, 0, 2, 2, 1, 0.7], [40, -30, 0, 2, 2, 1, 0.2], 0.0),
+]
+
+
+def test_oracle_overlap_known_answers():
+    """The restated reference algorithm against closed-form intersection areas (fp32: 1e-4 absolute on areas of 0.25 .. 4.5 m^2)."""
+    for a, b, area in KNOWN_OVERLAPS:
+        a, b = np.asarray(a, dtype=np.float32), np.asarray(b, dtype=np.float32)
+        for p, q in ((a, b), (b, a)):
+            got = float(orc.overlap(p, q))
+            assert abs(got - area) <= 1e-4, (p.tolist(), q.tolist(), got, area)
+            assert abs(orc.exact_overlap(p, q) - area) <= 1e-6
+        if area > 0:
+            union = float(a[3] * a[4] + b[3] * b[4]) - area
+            assert abs(float(orc.iou_bev(a, b)) - area / union) <= 1e-5
+
+
+@pytest.mark.gpu
+def test_hip_bev_overlap_known_answers():
+    """boxes_iou_bev / boxes_iou3d_gpu (HIP kernels behind the reference's API names) against the same closed forms."""
+    from pcdet.ops.iou3d_nms import iou3d_nms_utils as U
+    dev = torch.device("cuda:0")
+    A = torch.tensor([k[0] for k in KNOWN_OVERLAPS], dtype=torch.float32, device=dev)
+    B = torch.tensor([k[1] for k in KNOWN_OVERLAPS], dtype=torch.float32, device=dev)
+    area = np.array([k[2] for k in KNOWN_OVERLAPS])
+    iou = U.boxes_iou_bev(A, B).cpu().numpy()
+    Aa, Ba = (A[:, 3] * A[:, 4]).cpu().numpy(), (B[:, 3] * B[:, 4]).cpu().numpy()
+    want = area / np.maximum(Aa + Ba - area, 1e-8)
+    assert np.abs(np.diag(iou) - want).max() <= 1e-5, (np.diag(iou), want)
+    assert np.abs(np.diag(U.boxes_iou_bev(B, A).cpu().numpy()) - want).max() <= 1e-5
+    # all boxes have z = 0, dz = 1: the 3-D IoU is area x 1 over the summed volumes minus it
+    iou3 = U.boxes_iou3d_gpu(A, B).cpu().numpy()
+    assert np.abs(np.diag(iou3) - want).max() <= 1e-5
+
+
 @pytest.mark.gpu
 def test_hip_bev_iou_and_nms_match_oracle():
     """boxes_iou_bev / boxes_iou3d_gpu / nms_gpu / nms_normal_gpu (reference API names, HIP kernels) vs the CPU oracle."""

@@ -40,6 +40,12 @@ hs = 0.0
 for i in range(10 + K, 10 + 2 * K):
     torch.cuda.synchronize(); a = time.perf_counter(); step(i); hs += time.perf_counter() - a
 print(f"host time of a step issued into an idle device: {hs / K * 1e3:.2f} ms")
+if "--single-thread-backward" in sys.argv:      # backward nodes on the calling thread: cProfile sees the Function.backward bodies
+    torch.autograd.set_multithreading_enabled(False)
+    hs = 0.0
+    for i in range(10 + 2 * K, 10 + 3 * K):
+        torch.cuda.synchronize(); a = time.perf_counter(); step(i); hs += time.perf_counter() - a
+    print(f"host time of a step issued into an idle device, single-threaded autograd: {hs / K * 1e3:.2f} ms")
 pr = cProfile.Profile()
 base = 10 + 2 * K
 torch.cuda.synchronize()
