@@ -27,7 +27,7 @@ struct TimedCall {
 std::vector<TimedCall> g_timed[GD_T_SLOTS];
 const char* const kSlotNames[GD_T_SLOTS] = {"k_win_attn_fwd", "k_win_attn_bwd", "k_tok_gemm", "k_dw_grouped", "k_conv3x3_tiles",
                                             "k_conv_grad_taps", "k_spconv_fwd", "k_spconv_bwd", "k_dec_conv_bwd", "k_vfe",
-                                            "k_plan", "k_layer_tail", "k_ffn", "", "", ""};
+                                            "k_plan", "k_layer_tail", "k_ffn", "k_rows_gemm", "", ""};
 struct Pending {
   int slot;
   TimedCall tc;

@@ -34,7 +34,7 @@ extern "C" void gd_set_error(int code, const char* file, int line, const char* m
 enum {
   GD_T_ATTN_FWD = 0, GD_T_ATTN_BWD = 1, GD_T_TOK_GEMM = 2, GD_T_DW_GROUPED = 3, GD_T_CONV_TILES = 4, GD_T_GRAD_TAPS = 5,
   GD_T_SPCONV_FWD = 6, GD_T_SPCONV_BWD = 7, GD_T_DEC_CONV_BWD = 8, GD_T_VFE = 9, GD_T_PLAN = 10, GD_T_LAYER_TAIL = 11,
-  GD_T_FFN = 12, GD_T_SLOTS = 16
+  GD_T_FFN = 12, GD_T_ROWS_GEMM = 13, GD_T_SLOTS = 16
 };
 extern int g_gd_timing_on;
 void* gd_timing_begin(int slot, hipStream_t st);

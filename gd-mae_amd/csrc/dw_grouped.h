@@ -24,6 +24,8 @@ struct GdDwGroup {
   int S;
   long long rows_per_slice;
   long long n_valid;    // rows >= n_valid are treated as zero
+  int guard_rows = 0;   // 1: the operands are allocated for n_valid rows only - row loads past the end repeat row n_valid - 1 (and are
+                        // cleared like every row >= n_valid); 0: the buffers extend to the padded row count
 };
 
 bool gd_dw_group_supported(long long n_pad, int d, int ff);

@@ -34,14 +34,16 @@ __device__ __forceinline__ int stage_off(int row, int u16) { return row * kRowBy
 struct Chunk {          // this thread's four 16-byte pieces of a staged chunk (rows r, r + 16, r + 32, r + 48)
   uint4 q0, q1, q2, q3;
 };
-__device__ __forceinline__ Chunk load_chunk(const unsigned short* __restrict__ base, int ld, long long row0, int col0, int tid) {
-  const int c = tid & 15, r = tid >> 4;
-  const unsigned short* p = base + (row0 + r) * ld + col0 + c * 8;
+// last: highest row that may be read (rows past it repeat it; they are cleared by mask_chunk before they are staged)
+__device__ __forceinline__ Chunk load_chunk(const unsigned short* __restrict__ base, int ld, long long row0, int col0, int tid, long long last) {
+  const int c = tid & 15;
+  const long long r = row0 + (tid >> 4);
+  const unsigned short* p = base + col0 + c * 8;
   Chunk k;
-  k.q0 = *reinterpret_cast<const uint4*>(p);
-  k.q1 = *reinterpret_cast<const uint4*>(p + 16ll * ld);
-  k.q2 = *reinterpret_cast<const uint4*>(p + 32ll * ld);
-  k.q3 = *reinterpret_cast<const uint4*>(p + 48ll * ld);
+  k.q0 = *reinterpret_cast<const uint4*>(p + (r < last ? r : last) * ld);
+  k.q1 = *reinterpret_cast<const uint4*>(p + (r + 16 < last ? r + 16 : last) * ld);
+  k.q2 = *reinterpret_cast<const uint4*>(p + (r + 32 < last ? r + 32 : last) * ld);
+  k.q3 = *reinterpret_cast<const uint4*>(p + (r + 48 < last ? r + 48 : last) * ld);
   return k;
 }
 // X rows through an index (rulebook column of a sparse convolution); rows >= n_valid are not looked up.  Branch-free: the four
@@ -185,11 +187,12 @@ __global__ __launch_bounds__(256, 2) void k_dw_grouped(GdDwGroup A) {
   // two chunks in flight in registers (the loads of chunk c + 2 are issued behind the barrier of chunk c: ~2 compute phases of
   // latency cover per load), two LDS buffers
   const int gcol = tm * kTile, xcol = tn * kTile;
+  const long long last = A.guard_rows ? A.n_valid - 1 : (1ll << 60);
   // gathered X: the indices of chunk c + 4 are requested when the rows of chunk c + 2 are (one more stage of look-ahead for the
   // dependent load); i0 / i1 hold the indices of the next even / odd chunk to fetch
   ChunkIdx i0 = {-1, -1, -1, -1}, i1 = {-1, -1, -1, -1};
   auto load_x = [&](long long row0, ChunkIdx& I) {
-    if (!xidx) return load_chunk(X, N, row0, xcol, tid);
+    if (!xidx) return load_chunk(X, N, row0, xcol, tid, last);
     const Chunk k = x_f32 ? load_chunk_rows<true>(X, N, I, xcol, tid) : load_chunk_rows<false>(X, N, I, xcol, tid);
     I = load_chunk_idx(xidx, xstride, row0 + 2 * kChunk, A.n_valid, tid);      // for this buffer's next chunk
     return k;
@@ -198,10 +201,10 @@ __global__ __launch_bounds__(256, 2) void k_dw_grouped(GdDwGroup A) {
     i0 = load_chunk_idx(xidx, xstride, r0, A.n_valid, tid);
     i1 = load_chunk_idx(xidx, xstride, r0 + kChunk, A.n_valid, tid);
   }
-  Chunk g0 = load_chunk(G, M, r0, gcol, tid), x0 = load_x(r0, i0);
+  Chunk g0 = load_chunk(G, M, r0, gcol, tid, last), x0 = load_x(r0, i0);
   Chunk g1 = g0, x1 = x0;
   if (nchunk > 1) {
-    g1 = load_chunk(G, M, r0 + kChunk, gcol, tid);
+    g1 = load_chunk(G, M, r0 + kChunk, gcol, tid, last);
     x1 = load_x(r0 + kChunk, i1);
   }
   auto compute = [&](const unsigned char* bg, const unsigned char* bx) {
@@ -229,7 +232,7 @@ __global__ __launch_bounds__(256, 2) void k_dw_grouped(GdDwGroup A) {
     }
     __syncthreads();          // chunk c staged; buffer 0 was last read two phases ago, before the previous barrier
     if (c + 2 < nchunk) {
-      g0 = load_chunk(G, M, r0 + (long long)(c + 2) * kChunk, gcol, tid);
+      g0 = load_chunk(G, M, r0 + (long long)(c + 2) * kChunk, gcol, tid, last);
       x0 = load_x(r0 + (long long)(c + 2) * kChunk, i0);
     }
     compute(bufg0, bufx0);
@@ -243,7 +246,7 @@ __global__ __launch_bounds__(256, 2) void k_dw_grouped(GdDwGroup A) {
       }
       __syncthreads();
       if (c + 3 < nchunk) {
-        g1 = load_chunk(G, M, r0 + (long long)(c + 3) * kChunk, gcol, tid);
+        g1 = load_chunk(G, M, r0 + (long long)(c + 3) * kChunk, gcol, tid, last);
         x1 = load_x(r0 + (long long)(c + 3) * kChunk, i1);
       }
       compute(bufg1, bufx1);

@@ -21,9 +21,6 @@
 #include "tok_tiles.h"
 
 // experiment switches (tools/build_variant.sh): weight prefetch distance, row tile of the d = 256 stages, resident workgroups
-#ifndef TL_PF
-#define TL_PF TG_PF
-#endif
 #ifndef TL_ROWS256
 #define TL_ROWS256 32
 #endif
@@ -32,116 +29,6 @@
 #endif
 
 namespace {
-
-// ---- one product of a row tile:  acc[j][b] (32 channels x 32 rows, fp32) += W (ND, KD) X^T, X = bf16 rows in LDS ---------------
-template <int KD, int ND, int ROWS>
-struct TlShape {
-  static constexpr int KS = KD / 16;                                    // k-steps
-  static constexpr int MB = ND / 32;                                    // 32-channel blocks of the output
-  static constexpr int MPW = MB >= TG_WAVES ? MB / TG_WAVES : 1;        // channel blocks per wavefront
-  static constexpr int NPW = MB >= TG_WAVES ? ROWS / 32 : 1;            // 32-row blocks per wavefront
-  static_assert(MB >= TG_WAVES || (MB * (ROWS / 32) == TG_WAVES), "every wavefront needs an output block");
-  __device__ static int mb0(int wv) { return MB >= TG_WAVES ? wv : (wv / (ROWS / 32)); }
-  __device__ static int nb0(int wv) { return MB >= TG_WAVES ? 0 : (wv % (ROWS / 32)); }
-};
-
-// fragment (ks, j) of a wavefront; the image of a second matrix continues the K dimension after KSPLIT k-steps (the q/k and v
-// halves of the packed in-projection are two images)
-template <int KD, int ND, int ROWS, int KSPLIT>
-__device__ __forceinline__ uint4 tl_wfrag(const uint4* __restrict__ w0, const uint4* __restrict__ w1, int ks, int j) {
-  using S = TlShape<KD, ND, ROWS>;
-  return ks < KSPLIT ? w0[((size_t)ks * S::MB + j * TG_WAVES) * 64] : w1[((size_t)(ks - KSPLIT) * S::MB + j * TG_WAVES) * 64];
-}
-
-template <int KD, int ND, int ROWS, int KSPLIT = KD / 16>
-struct TlProd {
-  using S = TlShape<KD, ND, ROWS>;
-  TgFrag wr[TL_PF + 1][S::MPW];
-  const uint4* __restrict__ w0;
-  const uint4* __restrict__ w1;
-  // first TL_PF k-steps of the weights: issued early (before a row pass or a tile load) so that their latency is hidden
-  __device__ __forceinline__ void prefetch(const uint4* W0, const uint4* W1, int wv, int lane) {
-    w0 = W0 + (size_t)S::mb0(wv) * 64 + lane;
-    w1 = W1 ? W1 + (size_t)S::mb0(wv) * 64 + lane : w0;
-#pragma unroll
-    for (int ks = 0; ks < TL_PF; ++ks)
-#pragma unroll
-      for (int j = 0; j < S::MPW; ++j) wr[ks][j].q = tl_wfrag<KD, ND, ROWS, KSPLIT>(w0, w1, ks, j);
-  }
-  __device__ __forceinline__ void run(const unsigned char* xs, int XP, int wv, int lane, f32x16 (&acc)[S::MPW][S::NPW]) {
-    const unsigned char* lb = xs + ((S::nb0(wv) * 32) + (lane & 31)) * XP + (lane >> 5) * 16;
-    TgFrag sf[2][S::NPW];
-#pragma unroll
-    for (int b = 0; b < S::NPW; ++b) sf[0][b].q = *(const uint4*)(lb + b * 32 * XP);
-#pragma unroll
-    for (int ks = 0; ks < S::KS; ++ks) {
-      if (ks + TL_PF < S::KS) {
-#pragma unroll
-        for (int j = 0; j < S::MPW; ++j) wr[(ks + TL_PF) % (TL_PF + 1)][j].q = tl_wfrag<KD, ND, ROWS, KSPLIT>(w0, w1, ks + TL_PF, j);
-      }
-      if (ks + 1 < S::KS) {
-#pragma unroll
-        for (int b = 0; b < S::NPW; ++b) sf[(ks + 1) & 1][b].q = *(const uint4*)(lb + b * 32 * XP + (ks + 1) * 32);
-      }
-#pragma unroll
-      for (int j = 0; j < S::MPW; ++j)
-#pragma unroll
-        for (int b = 0; b < S::NPW; ++b)
-          acc[j][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[ks % (TL_PF + 1)][j].v, sf[ks & 1][b].v, acc[j][b], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-};
-
-template <int MPW, int NPW>
-__device__ __forceinline__ void tl_zero(f32x16 (&acc)[MPW][NPW]) {
-#pragma unroll
-  for (int j = 0; j < MPW; ++j)
-#pragma unroll
-    for (int b = 0; b < NPW; ++b)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[j][b][i] = 0.f;
-}
-
-// accumulators (+ bias) -> bf16 -> LDS tile [row][channel] with row pitch SP
-template <int KD, int ND, int ROWS>
-__device__ __forceinline__ void tl_stage(const f32x16 (&acc)[TlShape<KD, ND, ROWS>::MPW][TlShape<KD, ND, ROWS>::NPW], const unsigned short* bias,
-                                         unsigned char* out, int SP, int wv, int lane) {
-  using S = TlShape<KD, ND, ROWS>;
-#pragma unroll
-  for (int j = 0; j < S::MPW; ++j) {
-    const int cb = (S::mb0(wv) + j * TG_WAVES) * 32 + 4 * (lane >> 5);
-#pragma unroll
-    for (int b = 0; b < S::NPW; ++b) {
-      const int row = (S::nb0(wv) + b) * 32 + (lane & 31);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[j][b][4 * q + e];
-        if (bias) {
-          const uint2 bq = *(const uint2*)(bias + cb + 8 * q);
-          v[0] += __uint_as_float(bq.x << 16); v[1] += __uint_as_float(bq.x & 0xFFFF0000u);
-          v[2] += __uint_as_float(bq.y << 16); v[3] += __uint_as_float(bq.y & 0xFFFF0000u);
-        }
-        uint2 o;
-        o.x = tg_pack2(v[0], v[1]);
-        o.y = tg_pack2(v[2], v[3]);
-        *(uint2*)(out + row * SP + (cb + 8 * q) * 2) = o;
-      }
-    }
-  }
-}
-
-__device__ __forceinline__ void tl_unpack4(const uint2& q, float (&f)[4]) {
-  f[0] = __uint_as_float(q.x << 16); f[1] = __uint_as_float(q.x & 0xFFFF0000u);
-  f[2] = __uint_as_float(q.y << 16); f[3] = __uint_as_float(q.y & 0xFFFF0000u);
-}
-__device__ __forceinline__ uint2 tl_pack4(const float (&f)[4]) {
-  uint2 q;
-  q.x = tg_pack2(f[0], f[1]); q.y = tg_pack2(f[2], f[3]);
-  return q;
-}
 
 template <int D>
 struct TlRows {
@@ -223,20 +110,6 @@ struct TlLnBwd {
     }
   }
 };
-
-// rows of a bf16 (n_pad, W) matrix -> LDS tile, 16 bytes per thread and access; c_off: first column of the tile (bytes)
-template <int W, int ROWS>
-__device__ __forceinline__ void tl_load_tile(const unsigned short* __restrict__ src, long long row0, unsigned char* dst, int P, int c_off, int tid) {
-  constexpr int CPR = W / 8, RPP = 512 / CPR;
-  static_assert(ROWS % RPP == 0 || RPP > ROWS, "tile load");
-  const int c = tid % CPR, r = tid / CPR;
-#pragma unroll
-  for (int p = 0; p < (ROWS + RPP - 1) / RPP; ++p) {
-    const int row = p * RPP + r;
-    if (RPP > ROWS && row >= ROWS) break;
-    *(uint4*)(dst + row * P + c_off + c * 16) = *(const uint4*)(src + (row0 + row) * W + c * 8);
-  }
-}
 
 // ------------------------------------------------------------------------------------------------
 // forward

@@ -344,6 +344,60 @@ class DecoderHead(torch.autograd.Function):
         return tuple(grads)
 
 
+class DeconvRowsFn(torch.autograd.Function):
+    """P (n * s*s, cout) = rows of ConvTranspose2d(k = s, stride s, no bias) at the active tokens (csrc/rows_gemm.hip): x (n, cin)
+    bf16 token rows, weight (cin, cout, s, s) fp32 owned by a flat optimizer (its gradient is accumulated there directly).  Replaces
+    the weight permute + cast and the three library GEMMs (forward, input gradient, split-K weight gradient) of a deblock."""
+
+    @staticmethod
+    def forward(ctx, x, weight, direct):
+        cin, cout, s, _ = weight.shape
+        n = x.shape[0]
+        dev = x.device
+        x = x.contiguous()
+        nb = L.load().gdmae_deconv_rows_packed_bytes(cin, cout, s)
+        pf = torch.empty(nb, dtype=torch.uint8, device=dev)
+        pb = torch.empty(nb, dtype=torch.uint8, device=dev)
+        L.call("gdmae_deconv_rows_pack", L.ptr(weight), cin, cout, s, L.ptr(pf), L.ptr(pb), L.stream())
+        P = torch.empty(n * s * s, cout, dtype=torch.bfloat16, device=dev)
+        L.call("gdmae_deconv_rows_fwd", L.ptr(x), n, cin, cout, s, L.ptr(pf), L.ptr(P), L.stream())
+        ctx.save_for_backward(x, pb)
+        ctx.meta = (cin, cout, s, direct)
+        return P
+
+    @staticmethod
+    def backward(ctx, dP):
+        x, pb = ctx.saved_tensors
+        cin, cout, s, direct = ctx.meta
+        n = x.shape[0]
+        dP = dP.contiguous()
+        if dP.dtype != torch.bfloat16:
+            dP = dP.to(torch.bfloat16)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(n, cin, dtype=torch.bfloat16, device=x.device)
+            L.call("gdmae_deconv_rows_bwd_input", L.ptr(dP), n, cin, cout, s, L.ptr(pb), L.ptr(dx), L.stream())
+        ws = torch.empty(L.load().gdmae_deconv_rows_dw_workspace_bytes(n, cin, cout, s), dtype=torch.uint8, device=x.device)
+        L.call("gdmae_deconv_rows_bwd_weight", L.ptr(x), L.ptr(dP), n, cin, cout, s, L.ptr(direct), L.ptr(ws), L.stream())
+        return dx, None, None
+
+
+DECONV_ROWS = os.environ.get("GDMAE_DECONV_ROWS", "1") != "0"     # False: weight permute + library GEMMs (A/B reference)
+
+
+def deconv_rows(x, deconv):
+    """Token rows of a ConvTranspose2d(k = s, stride s, no bias) block: -> (n * s*s, cout), row (token, dy * s + dx)."""
+    w = deconv.weight
+    s = int(deconv.stride[0])
+    cin, cout = w.shape[0], w.shape[1]
+    direct = ops.direct_grad(w)
+    if (DECONV_ROWS and x.is_cuda and torch.is_autocast_enabled() and x.dtype == torch.bfloat16 and direct is not None and w.dtype == torch.float32
+            and w.is_contiguous() and cin in (128, 256) and cout == 128 and s in (1, 2, 4) and x.shape[0] > 0):
+        return DeconvRowsFn.apply(x, w, direct)
+    wmat = w.permute(0, 2, 3, 1).reshape(cin, s * s * cout)                  # columns ordered (dy, dx, c)
+    return ops.linear(x, wmat.t()).view(-1, cout)
+
+
 def upsampled_sites(stage_plan, s: int, Y: int, X: int) -> torch.Tensor:
     """(n_tok * s*s,) int32 full-resolution cell of every (token, dy, dx) of a stride-s stage (prepared with the geometry
     plan when the stage's stride matches)."""
@@ -373,9 +427,7 @@ def sparse_decoder(model_cfg, deblocks, conv_out, hidden, pillar_cell, cell2pill
         deconv, bn = deblocks[i][0], deblocks[i][1]
         s = int(deconv.stride[0])
         assert deconv.kernel_size == (s, s) and sp.Y * s == Y and sp.X * s == X and deconv.bias is None
-        cin, cout = deconv.weight.shape[0], deconv.weight.shape[1]
-        wmat = deconv.weight.permute(0, 2, 3, 1).reshape(cin, s * s * cout)      # columns ordered (dy, dx, c)
-        P = ops.linear(h.features, wmat.t()).view(-1, cout)                      # (n_tok * s*s, cout)
+        P = deconv_rows(h.features, deconv)                                      # (n_tok * s*s, cout)
         args += [upsampled_sites(sp, s, Y, X), P, bn.weight, bn.bias]
         bns.append(bn)
     conv, bn2 = conv_out[0], conv_out[1]

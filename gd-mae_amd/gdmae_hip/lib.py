@@ -131,6 +131,12 @@ SIGNATURES = {
     "gdmae_encoder_layer_bwd": (_I, [_P, _P]),
     "gdmae_encoder_stage_fwd": (_I, [_P, _I, _P]),
     "gdmae_encoder_stage_bwd": (_I, [_P, _I, _P]),
+    "gdmae_deconv_rows_packed_bytes": (_Z, [_I, _I, _I]),
+    "gdmae_deconv_rows_pack": (_I, [_P, _I, _I, _I, _P, _P, _P]),
+    "gdmae_deconv_rows_fwd": (_I, [_P, _L, _I, _I, _I, _P, _P, _P]),
+    "gdmae_deconv_rows_bwd_input": (_I, [_P, _L, _I, _I, _I, _P, _P, _P]),
+    "gdmae_deconv_rows_dw_workspace_bytes": (_Z, [_L, _I, _I, _I]),
+    "gdmae_deconv_rows_bwd_weight": (_I, [_P, _P, _L, _I, _I, _I, _P, _P, _P]),
     "gdmae_encoder_set_layer_path": (_I, [_I]),
     "gdmae_encoder_stage_fused": (_I, [_P, _I]),
     "gdmae_group_gt_points": (_I, [_P, _I, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P]),

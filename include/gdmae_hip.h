@@ -579,6 +579,21 @@ int gdmae_encoder_set_layer_path(int path);
 /* 1 when gdmae_encoder_stage_fwd / _bwd would take the fused path (1 above) for these layers, else 0 */
 int gdmae_encoder_stage_fused(const gdmae_layer_args* layers /* host array */, int n_layers);
 
+/* ---- a16: the decoder's ConvTranspose2d(k = s, stride s, no bias) blocks on token rows (csrc/rows_gemm.hip) ----------------- *
+ * Reference: spt_backbone_mae.py:30-45 `decoder_deblocks` (applied to the densified maps at :125-131).  With kernel = stride the
+ * outputs of an input site do not overlap: P (n, s*s*cout) = X (n, cin) Wm, Wm[ci][(dy*s+dx, c)] = weight[ci][c][dy][dx]; row
+ * (token, dy*s+dx) of P viewed as (n*s*s, cout) is the deconvolution output at the full-resolution site of (token, dy, dx).
+ * cin in {128, 256}, cout = 128, s in {1, 2, 4}; X / P / dP / dX bf16 rows (n is NOT padded: loads are guarded), weight fp32
+ * (cin, cout, s, s).  gdmae_deconv_rows_pack writes both MFMA-fragment-ordered images (gdmae_deconv_rows_packed_bytes each) in
+ * one launch; _bwd_weight ACCUMULATES X^T dP into `dW` in the weight's own layout (fixed summation order). */
+size_t gdmae_deconv_rows_packed_bytes(int cin, int cout, int s);
+int gdmae_deconv_rows_pack(const float* weight, int cin, int cout, int s, void* packed_fwd, void* packed_bwd, void* stream);
+int gdmae_deconv_rows_fwd(const void* X, long long n, int cin, int cout, int s, const void* packed_fwd, void* P, void* stream);
+int gdmae_deconv_rows_bwd_input(const void* dP, long long n, int cin, int cout, int s, const void* packed_bwd, void* dX, void* stream);
+size_t gdmae_deconv_rows_dw_workspace_bytes(long long n, int cin, int cout, int s);
+int gdmae_deconv_rows_bwd_weight(const void* X, const void* dP, long long n, int cin, int cout, int s, float* dW, void* workspace,
+                                 void* stream);
+
 /* ---- a17-a19: reconstruction targets and Chamfer loss ----------------------------------------- *
  * gdmae_group_gt_points replaces sst_ops_cuda.group_inner_inds_wrapper (sst_ops_api.cpp:8;
  * sst_ops_gpu.cu:22-39) + points[group_inds] + get_voxel_centers (common_utils.py:130-145):

@@ -798,6 +798,45 @@ def test_stage_executor_equals_per_layer_calls():
     assert float((g1 - g0).norm()) <= 1e-6 * float(g0.norm()), float((g1 - g0).norm() / g0.norm())
 
 
+@pytest.mark.parametrize("cin,s,n", [(128, 1, 4097), (256, 2, 5000), (256, 4, 3001), (128, 2, 63)])
+def test_deconv_rows_match_conv_transpose(cin, s, n):
+    """gdmae_deconv_rows_* (csrc/rows_gemm.hip: the decoder's ConvTranspose2d(k = s, stride s) blocks on token rows, forward /
+    input gradient / weight gradient, row counts that are not multiples of any tile) against F.conv_transpose2d on the same bf16
+    values in fp64: every token placed on its own cell of an (n, 1) map, so the s x s output patch of a token is row block
+    (token, dy * s + dx) of P."""
+    import torch.nn.functional as F
+    from gdmae_hip import lib as L
+    cout = 128
+    g = torch.Generator().manual_seed(cin + s)
+    w = (torch.randn(cin, cout, s, s, generator=g) * 0.05).to(dev())
+    x = torch.randn(n, cin, generator=g).to(dev()).to(torch.bfloat16)
+    dP = torch.randn(n * s * s, cout, generator=g).to(dev()).to(torch.bfloat16)
+    lib = L.load()
+    nb = lib.gdmae_deconv_rows_packed_bytes(cin, cout, s)
+    pf, pb = (torch.empty(nb, dtype=torch.uint8, device=dev()) for _ in range(2))
+    L.call("gdmae_deconv_rows_pack", L.ptr(w), cin, cout, s, L.ptr(pf), L.ptr(pb), L.stream())
+    P = torch.empty(n * s * s, cout, dtype=torch.bfloat16, device=dev())
+    L.call("gdmae_deconv_rows_fwd", L.ptr(x), n, cin, cout, s, L.ptr(pf), L.ptr(P), L.stream())
+    dX = torch.empty(n, cin, dtype=torch.bfloat16, device=dev())
+    L.call("gdmae_deconv_rows_bwd_input", L.ptr(dP), n, cin, cout, s, L.ptr(pb), L.ptr(dX), L.stream())
+    dW = torch.full((cin, cout, s, s), 0.5, dtype=torch.float32, device=dev())          # accumulated into
+    ws = torch.empty(lib.gdmae_deconv_rows_dw_workspace_bytes(n, cin, cout, s), dtype=torch.uint8, device=dev())
+    L.call("gdmae_deconv_rows_bwd_weight", L.ptr(x), L.ptr(dP), n, cin, cout, s, L.ptr(dW), L.ptr(ws), L.stream())
+    # reference: the same bf16 operand values in fp64 through torch's transposed convolution and its autograd
+    wq = w.to(torch.bfloat16).double().cpu().requires_grad_(True)
+    xq = x.double().cpu().requires_grad_(True)
+    y = F.conv_transpose2d(xq.t().reshape(1, cin, n, 1), wq, stride=s)                     # (1, cout, n s, s)
+    ref = y[0].reshape(cout, n, s, s).permute(1, 2, 3, 0).reshape(n * s * s, cout)       # row (token, dy * s + dx)
+    assert float((P.double().cpu() - ref.detach()).abs().max()) <= 8e-3 * float(ref.detach().abs().max())     # bf16 rounding of the result
+    (ref * dP.double().cpu()).sum().backward()
+    assert float((dX.double().cpu() - xq.grad).abs().max()) <= 8e-3 * float(xq.grad.abs().max())
+    got = dW.double().cpu() - 0.5
+    assert float((got - wq.grad).abs().max()) <= 2e-5 * float(wq.grad.abs().max()) + 1e-6 * n, float((got - wq.grad).abs().max())
+    dW2 = torch.full_like(dW, 0.5)
+    L.call("gdmae_deconv_rows_bwd_weight", L.ptr(x), L.ptr(dP), n, cin, cout, s, L.ptr(dW2), L.ptr(ws), L.stream())
+    assert torch.equal(dW, dW2)                                                           # fixed summation order
+
+
 def test_packed_weight_images_follow_weight_changes_between_optimizer_steps():
     """The packed MFMA weight images (encoder layers, sparse convolutions, decoder conv_out) are refreshed by the optimizer once
     per step; a weight change through torch in between - load_state_dict after a first forward (mid-training resume) - keeps every
