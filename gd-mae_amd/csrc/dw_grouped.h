@@ -16,6 +16,9 @@ struct GdDwJob {
   const int* xidx;
   int xidx_stride;
   int x_f32;
+  // optional: G rows narrower than M (a gradient with fewer than 128 channels, e.g. the 48-wide prediction head): row pitch g_ld
+  // elements, columns >= g_cols read as zero (0 = M for both)
+  int g_ld, g_cols;
 };
 struct GdDwGroup {
   GdDwJob job[GD_DW_MAX_JOBS];

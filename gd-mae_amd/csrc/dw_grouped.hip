@@ -35,11 +35,16 @@ struct Chunk {          // this thread's four 16-byte pieces of a staged chunk (
   uint4 q0, q1, q2, q3;
 };
 // last: highest row that may be read (rows past it repeat it; they are cleared by mask_chunk before they are staged)
-__device__ __forceinline__ Chunk load_chunk(const unsigned short* __restrict__ base, int ld, long long row0, int col0, int tid, long long last) {
+__device__ __forceinline__ Chunk load_chunk(const unsigned short* __restrict__ base, int ld, long long row0, int col0, int tid, long long last,
+                                            int cols = 1 << 30) {
   const int c = tid & 15;
   const long long r = row0 + (tid >> 4);
   const unsigned short* p = base + col0 + c * 8;
   Chunk k;
+  if (col0 + c * 8 >= cols) {                           // columns past the operand's width (narrow G): zero
+    k.q0 = k.q1 = k.q2 = k.q3 = make_uint4(0u, 0u, 0u, 0u);
+    return k;
+  }
   k.q0 = *reinterpret_cast<const uint4*>(p + (r < last ? r : last) * ld);
   k.q1 = *reinterpret_cast<const uint4*>(p + (r + 16 < last ? r + 16 : last) * ld);
   k.q2 = *reinterpret_cast<const uint4*>(p + (r + 32 < last ? r + 32 : last) * ld);
@@ -153,6 +158,7 @@ __global__ __launch_bounds__(256, 2) void k_dw_grouped(GdDwGroup A) {
   int M = A.job[0].M, N = A.job[0].N, tile0 = 0;
   const int* xidx = A.job[0].xidx;
   int xstride = A.job[0].xidx_stride, x_f32 = A.job[0].x_f32;
+  int g_ld = A.job[0].g_ld, g_cols = A.job[0].g_cols;
 #pragma unroll
   for (int j = 1; j < GD_DW_MAX_JOBS; ++j)
     if (j < A.n_jobs && t >= A.job[j].tile0) {
@@ -166,7 +172,11 @@ __global__ __launch_bounds__(256, 2) void k_dw_grouped(GdDwGroup A) {
       xidx = A.job[j].xidx;
       xstride = A.job[j].xidx_stride;
       x_f32 = A.job[j].x_f32;
+      g_ld = A.job[j].g_ld;
+      g_cols = A.job[j].g_cols;
     }
+  if (g_ld == 0) g_ld = M;
+  if (g_cols == 0) g_cols = M;
   const int tn_count = N / kTile;
   const int tm = (t - tile0) / tn_count, tn = (t - tile0) - tm * tn_count;
   const long long r0 = (long long)s * A.rows_per_slice;
@@ -201,10 +211,10 @@ __global__ __launch_bounds__(256, 2) void k_dw_grouped(GdDwGroup A) {
     i0 = load_chunk_idx(xidx, xstride, r0, A.n_valid, tid);
     i1 = load_chunk_idx(xidx, xstride, r0 + kChunk, A.n_valid, tid);
   }
-  Chunk g0 = load_chunk(G, M, r0, gcol, tid, last), x0 = load_x(r0, i0);
+  Chunk g0 = load_chunk(G, g_ld, r0, gcol, tid, last, g_cols), x0 = load_x(r0, i0);
   Chunk g1 = g0, x1 = x0;
   if (nchunk > 1) {
-    g1 = load_chunk(G, M, r0 + kChunk, gcol, tid, last);
+    g1 = load_chunk(G, g_ld, r0 + kChunk, gcol, tid, last, g_cols);
     x1 = load_x(r0 + kChunk, i1);
   }
   auto compute = [&](const unsigned char* bg, const unsigned char* bx) {
@@ -232,7 +242,7 @@ __global__ __launch_bounds__(256, 2) void k_dw_grouped(GdDwGroup A) {
     }
     __syncthreads();          // chunk c staged; buffer 0 was last read two phases ago, before the previous barrier
     if (c + 2 < nchunk) {
-      g0 = load_chunk(G, M, r0 + (long long)(c + 2) * kChunk, gcol, tid, last);
+      g0 = load_chunk(G, g_ld, r0 + (long long)(c + 2) * kChunk, gcol, tid, last, g_cols);
       x0 = load_x(r0 + (long long)(c + 2) * kChunk, i0);
     }
     compute(bufg0, bufx0);
@@ -246,7 +256,7 @@ __global__ __launch_bounds__(256, 2) void k_dw_grouped(GdDwGroup A) {
       }
       __syncthreads();
       if (c + 3 < nchunk) {
-        g1 = load_chunk(G, M, r0 + (long long)(c + 3) * kChunk, gcol, tid, last);
+        g1 = load_chunk(G, g_ld, r0 + (long long)(c + 3) * kChunk, gcol, tid, last, g_cols);
         x1 = load_x(r0 + (long long)(c + 3) * kChunk, i1);
       }
       compute(bufg1, bufx1);

@@ -159,6 +159,143 @@ __global__ __launch_bounds__(256) void k_deconv_dw_reduce(const float* __restric
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Prediction head: nn.Linear(128 -> n_out <= 64) on the fp32 decoder rows of ALL pillars (reference spt_backbone_mae.py:52,74
+// `decoder_pred`, 16 points x 3 = 48 outputs).  Under autocast the framework ran a cast pass, a library GEMM with K / N = 48
+// (unaligned: 62 us for the input gradient alone) and another cast; here the fp32 rows are rounded on their way into LDS, the
+// weight image is zero-padded to 64 outputs, and the weight / bias gradients are one register-tiled VALU pass over row blocks.
+// ------------------------------------------------------------------------------------------------
+constexpr int kPredK = 128, kPredN = 64, kPredRows = 128;     // TlShape<128, 64, 128>: 2 channel blocks x 4 row blocks
+
+// images of W (n_out, 128) fp32: forward (64, 128) rows >= n_out zero; input gradient (128, 64) columns >= n_out zero; bias (64) bf16
+__global__ __launch_bounds__(256) void k_pred_pack(const float* __restrict__ w, const float* __restrict__ b, int n_out, uint4* __restrict__ fwd,
+                                                   uint4* __restrict__ bwd, unsigned short* __restrict__ bias) {
+  const int total = kPredK * kPredN / 8;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 2 * total; i += gridDim.x * blockDim.x) {
+    const bool is_bwd = i >= total;
+    const int e = is_bwd ? i - total : i, lane = e & 63;
+    float f[8];
+    if (!is_bwd) {                                      // A (64, 128): row o, column ci
+      const int MB = kPredN / 32, mb = (e >> 6) % MB, ks = (e >> 6) / MB;
+      const int o = mb * 32 + (lane & 31), k0 = ks * 16 + (lane >> 5) * 8;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] = o < n_out ? w[o * kPredK + k0 + j] : 0.f;
+    } else {                                            // A (128, 64): row ci, column o
+      const int MB = kPredK / 32, mb = (e >> 6) % MB, ks = (e >> 6) / MB;
+      const int ci = mb * 32 + (lane & 31), k0 = ks * 16 + (lane >> 5) * 8;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] = (k0 + j) < n_out ? w[(k0 + j) * kPredK + ci] : 0.f;
+    }
+    (is_bwd ? bwd : fwd)[e] = tg_pack8(f);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < kPredN) bias[threadIdx.x] = tg_f2bf(b && (int)threadIdx.x < n_out ? b[threadIdx.x] : 0.f);
+}
+
+struct PhArgs {
+  const float* X;               // (n, 128) fp32
+  const uint4* Wp;              // packed (64, 128)
+  const unsigned short* bias;   // (64) bf16
+  unsigned short* Y;            // (n, n_out) bf16
+  long long n;
+  int n_out;
+  unsigned short* Xb;           // optional (n, 128) bf16: the rounded operand rows, kept for the weight gradient
+};
+__global__ __launch_bounds__(512, 2) void k_pred_fwd(PhArgs A) {
+  constexpr int XP = kPredK * 2 + 16, SP = kPredN * 2 + 16;
+  using S = TlShape<kPredK, kPredN, kPredRows>;
+  extern __shared__ __align__(16) unsigned char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const long long row0 = (long long)blockIdx.x * kPredRows;
+  TlProd<kPredK, kPredN, kPredRows> pr;
+  pr.prefetch(A.Wp, nullptr, wv, lane);
+  {   // fp32 rows -> bf16 tile: 16 chunks of 8 channels per row, 32 rows per pass
+    const int c = tid & 15, r = tid >> 4;
+#pragma unroll
+    for (int p = 0; p < kPredRows / 32; ++p) {
+      const int row = p * 32 + r;
+      long long g = row0 + row;
+      g = g < A.n ? g : A.n - 1;
+      const float4 a = *(const float4*)(A.X + g * kPredK + c * 8), b = *(const float4*)(A.X + g * kPredK + c * 8 + 4);
+      const float f[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+      const uint4 q = tg_pack8(f);
+      *(uint4*)(lds + row * XP + c * 16) = q;
+      if (A.Xb && row0 + row < A.n) *(uint4*)(A.Xb + (row0 + row) * kPredK + c * 8) = q;
+    }
+  }
+  __syncthreads();
+  f32x16 acc[S::MPW][S::NPW];
+  tl_zero(acc);
+  pr.run(lds, XP, wv, lane, acc);
+  __syncthreads();
+  tl_stage<kPredK, kPredN, kPredRows>(acc, A.bias, lds, SP, wv, lane);
+  __syncthreads();
+  const int cpr = A.n_out >> 2;                         // 8-byte chunks per output row (n_out % 4 == 0)
+  for (int i = tid; i < kPredRows * cpr; i += 512) {
+    const int row = i / cpr, c = i - row * cpr;
+    if (row0 + row < A.n) *(uint2*)(A.Y + (row0 + row) * A.n_out + c * 4) = *(const uint2*)(lds + row * SP + c * 8);
+  }
+}
+
+struct PbArgs {
+  const unsigned short* dY;     // (n, n_out) bf16
+  const uint4* Wp;              // packed (128, 64)
+  float* dX;                    // (n, 128) fp32
+  long long n;
+  int n_out;
+};
+// dX (n, 128) fp32 = dY (n, n_out) W: K padded to 64 with zero columns
+__global__ __launch_bounds__(512, 2) void k_pred_bwd_input(PbArgs A) {
+  constexpr int ROWS = 64, KD = kPredN, ND = kPredK, XP = KD * 2 + 16;
+  using S = TlShape<KD, ND, ROWS>;
+  extern __shared__ __align__(16) unsigned char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const long long row0 = (long long)blockIdx.x * ROWS;
+  TlProd<KD, ND, ROWS> pr;
+  pr.prefetch(A.Wp, nullptr, wv, lane);
+  {
+    const int cpr = A.n_out >> 2;                       // 8-byte chunks per row that hold data; the tile row has 16
+    for (int i = tid; i < ROWS * 16; i += 512) {
+      const int row = i >> 4, c = i & 15;
+      long long g = row0 + row;
+      g = g < A.n ? g : A.n - 1;
+      uint2 q = make_uint2(0u, 0u);
+      if (c < cpr) q = *(const uint2*)(A.dY + g * A.n_out + c * 4);
+      *(uint2*)(lds + row * XP + c * 8) = q;
+    }
+  }
+  __syncthreads();
+  f32x16 acc[S::MPW][S::NPW];
+  tl_zero(acc);
+  pr.run(lds, XP, wv, lane, acc);
+  // fp32 rows straight from the accumulators: lane = row, registers = channels cb + 8 q + e
+  const int cb = S::mb0(wv) * 32 + 4 * (lane >> 5);
+  const long long row = row0 + S::nb0(wv) * 32 + (lane & 31);
+  if (row < A.n) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      *(float4*)(A.dX + row * ND + cb + 8 * q) = make_float4(acc[0][0][4 * q], acc[0][0][4 * q + 1], acc[0][0][4 * q + 2], acc[0][0][4 * q + 3]);
+  }
+}
+
+// dW[o][ci] += sum_s part[s][o][ci] (o < n_out; part (S, 128, 128) from the grouped TN kernel with G = dY zero-padded to 128
+// columns), db[o] += sum_s colpart[s][o]: fixed order
+__global__ __launch_bounds__(256) void k_pred_dw_reduce(const float* __restrict__ part, const float* __restrict__ colpart, int S, int n_out,
+                                                        float* __restrict__ dW, float* __restrict__ db) {
+  const int total = n_out * kPredK + n_out;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    const bool is_b = e >= n_out * kPredK;
+    float a = 0.f;
+    if (is_b) {
+      const int o = e - n_out * kPredK;
+      for (int s = 0; s < S; ++s) a += colpart[(long long)s * 128 + o];
+      if (db) db[o] += a;
+    } else {
+      for (int s = 0; s < S; ++s) a += part[(long long)s * 128 * kPredK + e];
+      dW[e] += a;
+    }
+  }
+}
+
 template <typename K>
 int rg_set_lds(K kernel, int bytes) {
   GD_CHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
@@ -251,6 +388,66 @@ extern "C" int gdmae_deconv_rows_bwd_weight(const void* X, const void* dP, long 
   Gp.guard_rows = 1;                                     // neither operand is allocated beyond n rows
   if (int rc = gd_dw_grouped_s(st, Gp, n_pad, n, S)) return rc;
   hipLaunchKernelGGL(k_deconv_dw_reduce, dim3(gd_div_up((long long)cin * N, 256)), dim3(256), 0, st, (const float*)workspace, S, cin, cout, s * s, dW);
+  GD_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- prediction head (see k_pred_fwd): K = 128 inputs (fp32 rows), n_out <= 64 outputs, n_out % 4 == 0 ---------------------------
+extern "C" size_t gdmae_pred_head_packed_bytes(void) { return 2 * (size_t)kPredK * kPredN * 2 + 256; }
+extern "C" int gdmae_pred_head_pack(const float* weight, const float* bias, int n_in, int n_out, void* packed, void* stream) {
+  GD_REQUIRE(n_in == kPredK && n_out >= 4 && n_out <= kPredN && n_out % 4 == 0, "pred_head: 128 inputs, 4..64 outputs (multiple of 4)");
+  uint4* fwd = (uint4*)packed;
+  uint4* bwd = fwd + kPredK * kPredN / 8;
+  unsigned short* b16 = (unsigned short*)(bwd + kPredK * kPredN / 8);
+  hipLaunchKernelGGL(k_pred_pack, dim3(8), dim3(256), 0, (hipStream_t)stream, weight, bias, n_out, fwd, bwd, b16);
+  GD_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int gdmae_pred_head_fwd(const float* X, long long n, int n_out, const void* packed, void* Y, void* X_bf16, void* stream) {
+  if (n <= 0) return 0;
+  const uint4* fwd = (const uint4*)packed;
+  const unsigned short* b16 = (const unsigned short*)(fwd + 2 * (kPredK * kPredN / 8));
+  PhArgs A{X, fwd, b16, (unsigned short*)Y, n, n_out, (unsigned short*)X_bf16};
+  constexpr int lds = kPredRows * (kPredK * 2 + 16);
+  static bool once = false;
+  if (!once) { if (int rc = rg_set_lds(k_pred_fwd, lds)) return rc; once = true; }
+  GdTimed timed(GD_T_ROWS_GEMM, (hipStream_t)stream, (double)n * (4.0 * kPredK + 2.0 * n_out + (X_bf16 ? 2.0 * kPredK : 0.0)), 2.0 * n * kPredK * kPredN);
+  hipLaunchKernelGGL(k_pred_fwd, dim3((unsigned)gd_div_up(n, kPredRows)), dim3(512), lds, (hipStream_t)stream, A);
+  GD_LAUNCH_CHECK();
+  return 0;
+}
+static int pred_slices(long long n, long long* n_pad) { return gd_dw_pick(n, 1, 512, n_pad); }
+extern "C" size_t gdmae_pred_head_bwd_workspace_bytes(long long n) {
+  long long n_pad = 0;
+  const int S = pred_slices(n, &n_pad);
+  return gd_align((size_t)S * 128 * kPredK * sizeof(float)) + gd_align((size_t)S * 128 * sizeof(float));
+}
+// X_bf16: the (n, 128) bf16 rows gdmae_pred_head_fwd wrote; dX (n, 128) fp32 (may be null), dW (n_out, 128) / db (n_out) fp32
+// ACCUMULATED (db may be null)
+extern "C" int gdmae_pred_head_bwd(const void* dY, const void* X_bf16, long long n, int n_out, const void* packed, float* dX, float* dW, float* db,
+                                   void* workspace, void* stream) {
+  if (n <= 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const uint4* bwd = (const uint4*)packed + kPredK * kPredN / 8;
+  if (dX) {
+    PbArgs A{(const unsigned short*)dY, bwd, dX, n, n_out};
+    constexpr int lds = 64 * (kPredN * 2 + 16);
+    GdTimed timed(GD_T_ROWS_GEMM, st, (double)n * (2.0 * n_out + 4.0 * kPredK), 2.0 * n * kPredK * kPredN);
+    hipLaunchKernelGGL(k_pred_bwd_input, dim3((unsigned)gd_div_up(n, 64)), dim3(512), lds, st, A);
+    GD_LAUNCH_CHECK();
+  }
+  // dW = dY^T X as one 128 x 128 tile of the grouped TN kernel: G = dY with its 48-element rows read as 128 zero-padded columns
+  long long n_pad = 0;
+  const int S = pred_slices(n, &n_pad);
+  float* part = (float*)workspace;
+  float* colpart = (float*)((char*)workspace + gd_align((size_t)S * 128 * kPredK * sizeof(float)));
+  GdDwGroup Gp;
+  Gp.n_jobs = 1;
+  Gp.job[0] = GdDwJob{dY, X_bf16, 128, kPredK, part, colpart, 0, nullptr, 0, 0, n_out, n_out};
+  Gp.guard_rows = 1;
+  if (int rc = gd_dw_grouped_s(st, Gp, n_pad, n, S)) return rc;
+  hipLaunchKernelGGL(k_pred_dw_reduce, dim3(gd_div_up(n_out * kPredK + n_out, 256)), dim3(256), 0, st, (const float*)part, (const float*)colpart, S,
+                     n_out, dW, db);
   GD_LAUNCH_CHECK();
   return 0;
 }

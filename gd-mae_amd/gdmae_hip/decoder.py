@@ -398,6 +398,56 @@ def deconv_rows(x, deconv):
     return ops.linear(x, wmat.t()).view(-1, cout)
 
 
+class PredHeadFn(torch.autograd.Function):
+    """bf16(x W^T + b) for the prediction head nn.Linear(128 -> 48) on the fp32 decoder rows of all pillars (csrc/rows_gemm.hip
+    k_pred_*; reference spt_backbone_mae.py:52,74): no cast passes, no unaligned library GEMMs."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, direct):
+        n, n_out = x.shape[0], weight.shape[0]
+        x = x.contiguous()
+        packed = torch.empty(L.load().gdmae_pred_head_packed_bytes(), dtype=torch.uint8, device=x.device)
+        L.call("gdmae_pred_head_pack", L.ptr(weight), None if bias is None else L.ptr(bias), weight.shape[1], n_out, L.ptr(packed), L.stream())
+        y = torch.empty(n, n_out, dtype=torch.bfloat16, device=x.device)
+        xb = torch.empty(n, x.shape[1], dtype=torch.bfloat16, device=x.device)      # the rounded operand rows: operand of the weight gradient
+        L.call("gdmae_pred_head_fwd", L.ptr(x), n, n_out, L.ptr(packed), L.ptr(y), L.ptr(xb), L.stream())
+        ctx.save_for_backward(xb, packed)
+        ctx.meta = (n_out, direct, weight.shape, None if bias is None else bias.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, packed = ctx.saved_tensors
+        n_out, direct, wshape, bshape = ctx.meta
+        n = x.shape[0]
+        dy = dy.contiguous()
+        if dy.dtype != torch.bfloat16:
+            dy = dy.to(torch.bfloat16)
+        dx = torch.empty(x.shape, dtype=torch.float32, device=x.device) if ctx.needs_input_grad[0] else None
+        if direct is not None:
+            dW, db = direct
+            ret = (None, None)
+        else:
+            dW = torch.zeros(wshape, dtype=torch.float32, device=x.device)
+            db = None if bshape is None else torch.zeros(bshape, dtype=torch.float32, device=x.device)
+            ret = (dW, db)
+        ws = torch.empty(L.load().gdmae_pred_head_bwd_workspace_bytes(n), dtype=torch.uint8, device=x.device)
+        L.call("gdmae_pred_head_bwd", L.ptr(dy), L.ptr(x), n, n_out, L.ptr(packed), None if dx is None else L.ptr(dx), L.ptr(dW),
+               None if db is None else L.ptr(db), L.ptr(ws), L.stream())
+        return (dx, *ret, None)
+
+
+def pred_head(x, linear):
+    """``linear`` (nn.Linear 128 -> n_out) applied to fp32 rows under autocast: -> (n, n_out) bf16."""
+    w, b = linear.weight, linear.bias
+    if (DECONV_ROWS and x.is_cuda and torch.is_autocast_enabled() and x.dtype == torch.float32 and w.dtype == torch.float32 and w.is_contiguous()
+            and w.shape[1] == 128 and 4 <= w.shape[0] <= 64 and w.shape[0] % 4 == 0 and x.shape[0] > 0):
+        dw, db = ops.direct_grad(w), (ops.direct_grad(b) if b is not None else None)
+        direct = (dw, db) if (dw is not None and (b is None or db is not None)) else None
+        return PredHeadFn.apply(x, w, b, direct)
+    return ops.linear(x, w, b)
+
+
 def upsampled_sites(stage_plan, s: int, Y: int, X: int) -> torch.Tensor:
     """(n_tok * s*s,) int32 full-resolution cell of every (token, dy, dx) of a stride-s stage (prepared with the geometry
     plan when the stage's stride matches)."""

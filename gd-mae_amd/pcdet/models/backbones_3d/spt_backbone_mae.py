@@ -108,5 +108,5 @@ class SPTBackboneMAE(nn.Module):
     def target_assigner(self, batch_dict):
         vox = batch_dict['_gdmae_vox']
         gt = ops.group_gt_points(vox, self.mask_cfg.NUM_GT_POINTS)         # (M, K, 3), centre-relative
-        pred = ops.linear(batch_dict['voxel_features'], self.decoder_pred.weight, self.decoder_pred.bias).view(vox.M, -1, 3)
+        pred = gdec.pred_head(batch_dict['voxel_features'], self.decoder_pred).view(vox.M, -1, 3)
         return {'pred_points': pred, 'gt_points': gt, 'mask': batch_dict['voxel_mae_mask']}

@@ -594,6 +594,18 @@ size_t gdmae_deconv_rows_dw_workspace_bytes(long long n, int cin, int cout, int 
 int gdmae_deconv_rows_bwd_weight(const void* X, const void* dP, long long n, int cin, int cout, int s, float* dW, void* workspace,
                                  void* stream);
 
+/* The prediction head nn.Linear(128 -> n_out) on the fp32 decoder rows of all pillars (spt_backbone_mae.py:52,74 `decoder_pred`;
+ * n_out = 48 = 16 points x 3; 4 <= n_out <= 64, n_out % 4 == 0).  X (n, 128) fp32 is rounded to bf16 on load, Y (n, n_out) bf16 =
+ * bf16(X W^T + b) (the autocast linear's rounding points); backward: dX (n, 128) fp32 (optional), dW (n_out, 128) and db (n_out) fp32
+ * ACCUMULATED in a fixed order.  packed: gdmae_pred_head_packed_bytes(), refreshed by gdmae_pred_head_pack whenever the weights change. */
+size_t gdmae_pred_head_packed_bytes(void);
+int gdmae_pred_head_pack(const float* weight, const float* bias, int n_in, int n_out, void* packed, void* stream);
+int gdmae_pred_head_fwd(const float* X, long long n, int n_out, const void* packed, void* Y, void* X_bf16 /* (n, 128) bf16 out: the rounded
+                        operand rows, operand of the weight gradient */, void* stream);
+size_t gdmae_pred_head_bwd_workspace_bytes(long long n);
+int gdmae_pred_head_bwd(const void* dY, const void* X_bf16, long long n, int n_out, const void* packed, float* dX, float* dW, float* db,
+                        void* workspace, void* stream);
+
 /* ---- a17-a19: reconstruction targets and Chamfer loss ----------------------------------------- *
  * gdmae_group_gt_points replaces sst_ops_cuda.group_inner_inds_wrapper (sst_ops_api.cpp:8;
  * sst_ops_gpu.cu:22-39) + points[group_inds] + get_voxel_centers (common_utils.py:130-145):
