@@ -29,7 +29,8 @@ struct AdamArgs {
 };
 
 __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                              float* __restrict__ v, AdamArgs A, const float* __restrict__ sq_norm) {
+                                              float* __restrict__ v, AdamArgs A, const float* __restrict__ sq_norm,
+                                              unsigned short* __restrict__ p_bf16) {
   float coef = A.grad_scale;
   if (A.max_norm > 0.f) {
     const float total = sqrtf(*sq_norm) * A.grad_scale;      // norm of the AVERAGED gradient
@@ -47,7 +48,12 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float
       m[i] = mi;
       v[i] = vi;
       const float denom = sqrtf(vi) / A.bc2_sqrt + A.eps;
-      p[i] = pi - step * (mi / denom);
+      const float pn = pi - step * (mi / denom);
+      p[i] = pn;
+      if (p_bf16) {                                    // the bf16 shadow the GEMMs read: written here instead of by a cast pass
+        unsigned u = __float_as_uint(pn);
+        p_bf16[i] = (u & 0x7F800000u) == 0x7F800000u ? (unsigned short)(u >> 16) : (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+      }
     }
   }
 }
@@ -66,9 +72,19 @@ extern "C" int gdmae_grad_sq_norm(const float* grad, long long n, float* partial
 // segments: HOST array of 2 * n_segments element offsets [begin, end) into the flat buffers (the parameters that are
 // optimised; everything else only takes part in the norm).  grad_scale multiplies the gradient (and the norm) first:
 // 1 / world size after a SUM all-reduce.
+extern "C" int gdmae_adam_step_shadow(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const long long* segments,
+                                      int n_segments, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                                      float max_norm, float grad_scale, const float* sq_norm, void* param_bf16, void* stream);
 extern "C" int gdmae_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const long long* segments,
                                int n_segments, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                                float max_norm, float grad_scale, const float* sq_norm, void* stream) {
+  return gdmae_adam_step_shadow(param, grad, exp_avg, exp_avg_sq, segments, n_segments, lr, beta1, beta2, eps, weight_decay, step, max_norm,
+                                grad_scale, sq_norm, nullptr, stream);
+}
+// ... and the bf16 copy of every UPDATED element into param_bf16 (same offsets; may be null)
+extern "C" int gdmae_adam_step_shadow(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const long long* segments,
+                                      int n_segments, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                                      float max_norm, float grad_scale, const float* sq_norm, void* param_bf16, void* stream) {
   GD_REQUIRE(step >= 1, "step counts from 1");
   GD_REQUIRE(n_segments >= 0 && n_segments <= GD_ADAM_MAX_SEG, "adam_step: at most 64 segments");
   AdamArgs A;
@@ -95,7 +111,8 @@ extern "C" int gdmae_adam_step(float* param, const float* grad, float* exp_avg, 
   if (A.nseg == 0) return 0;                       // nothing to optimise
   int grid = gd_div_up(longest, 256);
   if (grid > 4096) grid = 4096;
-  hipLaunchKernelGGL(k_adam, dim3(grid), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, A, sq_norm);
+  hipLaunchKernelGGL(k_adam, dim3(grid), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, A, sq_norm,
+                     (unsigned short*)param_bf16);
   GD_LAUNCH_CHECK();
   return 0;
 }

@@ -195,10 +195,11 @@ struct PhArgs {
   const float* X;               // (n, 128) fp32
   const uint4* Wp;              // packed (64, 128)
   const unsigned short* bias;   // (64) bf16
-  unsigned short* Y;            // (n, n_out) bf16
+  unsigned short* Y;            // optional (n, n_out) bf16
   long long n;
   int n_out;
   unsigned short* Xb;           // optional (n, 128) bf16: the rounded operand rows, kept for the weight gradient
+  float* Yf;                    // optional (n, n_out) fp32: the same rounded outputs widened (what the Chamfer kernel reads)
 };
 __global__ __launch_bounds__(512, 2) void k_pred_fwd(PhArgs A) {
   constexpr int XP = kPredK * 2 + 16, SP = kPredN * 2 + 16;
@@ -232,16 +233,26 @@ __global__ __launch_bounds__(512, 2) void k_pred_fwd(PhArgs A) {
   const int cpr = A.n_out >> 2;                         // 8-byte chunks per output row (n_out % 4 == 0)
   for (int i = tid; i < kPredRows * cpr; i += 512) {
     const int row = i / cpr, c = i - row * cpr;
-    if (row0 + row < A.n) *(uint2*)(A.Y + (row0 + row) * A.n_out + c * 4) = *(const uint2*)(lds + row * SP + c * 8);
+    if (row0 + row < A.n) {
+      const uint2 q = *(const uint2*)(lds + row * SP + c * 8);
+      if (A.Y) *(uint2*)(A.Y + (row0 + row) * A.n_out + c * 4) = q;
+      if (A.Yf)
+        *(float4*)(A.Yf + (row0 + row) * A.n_out + c * 4) = make_float4(__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xFFFF0000u),
+                                                                       __uint_as_float(q.y << 16), __uint_as_float(q.y & 0xFFFF0000u));
+    }
   }
 }
 
 struct PbArgs {
-  const unsigned short* dY;     // (n, n_out) bf16
+  const void* dY;               // (n, n_out) bf16, or fp32 (dy_f32): then rounded here and written to dYb for the weight gradient
   const uint4* Wp;              // packed (128, 64)
-  float* dX;                    // (n, 128) fp32
+  float* dX;                    // (n, 128) fp32 or null
   long long n;
   int n_out;
+  int dy_f32;
+  unsigned short* dYb;          // (n, n_out) bf16 out (dy_f32 only)
+  const float *scale_a, *scale_b;   // optional device scalars: the fp32 rows are multiplied by scale_a[0] * scale_b[0] first (the loss's
+                                    // upstream gradient x 1 / sum of weights: no scaling pass over the Chamfer gradient)
 };
 // dX (n, 128) fp32 = dY (n, n_out) W: K padded to 64 with zero columns
 __global__ __launch_bounds__(512, 2) void k_pred_bwd_input(PbArgs A) {
@@ -252,6 +263,7 @@ __global__ __launch_bounds__(512, 2) void k_pred_bwd_input(PbArgs A) {
   const long long row0 = (long long)blockIdx.x * ROWS;
   TlProd<KD, ND, ROWS> pr;
   pr.prefetch(A.Wp, nullptr, wv, lane);
+  const float scale = (A.dy_f32 && A.scale_a) ? A.scale_a[0] * (A.scale_b ? A.scale_b[0] : 1.f) : 1.f;
   {
     const int cpr = A.n_out >> 2;                       // 8-byte chunks per row that hold data; the tile row has 16
     for (int i = tid; i < ROWS * 16; i += 512) {
@@ -259,7 +271,16 @@ __global__ __launch_bounds__(512, 2) void k_pred_bwd_input(PbArgs A) {
       long long g = row0 + row;
       g = g < A.n ? g : A.n - 1;
       uint2 q = make_uint2(0u, 0u);
-      if (c < cpr) q = *(const uint2*)(A.dY + g * A.n_out + c * 4);
+      if (c < cpr) {
+        if (A.dy_f32) {
+          float4 v = *(const float4*)((const float*)A.dY + g * A.n_out + c * 4);
+          v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+          q.x = tg_pack2(v.x, v.y); q.y = tg_pack2(v.z, v.w);
+          if (row0 + row < A.n) *(uint2*)(A.dYb + g * A.n_out + c * 4) = q;
+        } else {
+          q = *(const uint2*)((const unsigned short*)A.dY + g * A.n_out + c * 4);
+        }
+      }
       *(uint2*)(lds + row * XP + c * 8) = q;
     }
   }
@@ -270,7 +291,7 @@ __global__ __launch_bounds__(512, 2) void k_pred_bwd_input(PbArgs A) {
   // fp32 rows straight from the accumulators: lane = row, registers = channels cb + 8 q + e
   const int cb = S::mb0(wv) * 32 + 4 * (lane >> 5);
   const long long row = row0 + S::nb0(wv) * 32 + (lane & 31);
-  if (row < A.n) {
+  if (row < A.n && A.dX) {
 #pragma unroll
     for (int q = 0; q < 4; ++q)
       *(float4*)(A.dX + row * ND + cb + 8 * q) = make_float4(acc[0][0][4 * q], acc[0][0][4 * q + 1], acc[0][0][4 * q + 2], acc[0][0][4 * q + 3]);
@@ -403,11 +424,11 @@ extern "C" int gdmae_pred_head_pack(const float* weight, const float* bias, int 
   GD_LAUNCH_CHECK();
   return 0;
 }
-extern "C" int gdmae_pred_head_fwd(const float* X, long long n, int n_out, const void* packed, void* Y, void* X_bf16, void* stream) {
+extern "C" int gdmae_pred_head_fwd(const float* X, long long n, int n_out, const void* packed, void* Y, void* X_bf16, float* Y_f32, void* stream) {
   if (n <= 0) return 0;
   const uint4* fwd = (const uint4*)packed;
   const unsigned short* b16 = (const unsigned short*)(fwd + 2 * (kPredK * kPredN / 8));
-  PhArgs A{X, fwd, b16, (unsigned short*)Y, n, n_out, (unsigned short*)X_bf16};
+  PhArgs A{X, fwd, b16, (unsigned short*)Y, n, n_out, (unsigned short*)X_bf16, Y_f32};
   constexpr int lds = kPredRows * (kPredK * 2 + 16);
   static bool once = false;
   if (!once) { if (int rc = rg_set_lds(k_pred_fwd, lds)) return rc; once = true; }
@@ -422,15 +443,17 @@ extern "C" size_t gdmae_pred_head_bwd_workspace_bytes(long long n) {
   const int S = pred_slices(n, &n_pad);
   return gd_align((size_t)S * 128 * kPredK * sizeof(float)) + gd_align((size_t)S * 128 * sizeof(float));
 }
+// dY (n, n_out) bf16, or fp32 with dy_f32 = 1 (rounded in the input-gradient launch, the rounded rows go to dY_bf16 (n, n_out));
 // X_bf16: the (n, 128) bf16 rows gdmae_pred_head_fwd wrote; dX (n, 128) fp32 (may be null), dW (n_out, 128) / db (n_out) fp32
 // ACCUMULATED (db may be null)
-extern "C" int gdmae_pred_head_bwd(const void* dY, const void* X_bf16, long long n, int n_out, const void* packed, float* dX, float* dW, float* db,
-                                   void* workspace, void* stream) {
+extern "C" int gdmae_pred_head_bwd(const void* dY, int dy_f32, void* dY_bf16, const float* scale_a, const float* scale_b, const void* X_bf16,
+                                   long long n, int n_out, const void* packed, float* dX, float* dW, float* db, void* workspace, void* stream) {
   if (n <= 0) return 0;
+  GD_REQUIRE(!dy_f32 || dY_bf16 != nullptr, "pred_head_bwd: an fp32 dY needs the (n, n_out) bf16 buffer its rounded rows are written to");
   hipStream_t st = (hipStream_t)stream;
   const uint4* bwd = (const uint4*)packed + kPredK * kPredN / 8;
-  if (dX) {
-    PbArgs A{(const unsigned short*)dY, bwd, dX, n, n_out};
+  if (dX || dy_f32) {
+    PbArgs A{dY, bwd, dX, n, n_out, dy_f32, (unsigned short*)dY_bf16, scale_a, scale_b};
     constexpr int lds = 64 * (kPredN * 2 + 16);
     GdTimed timed(GD_T_ROWS_GEMM, st, (double)n * (2.0 * n_out + 4.0 * kPredK), 2.0 * n * kPredK * kPredN);
     hipLaunchKernelGGL(k_pred_bwd_input, dim3((unsigned)gd_div_up(n, 64)), dim3(512), lds, st, A);
@@ -443,7 +466,7 @@ extern "C" int gdmae_pred_head_bwd(const void* dY, const void* X_bf16, long long
   float* colpart = (float*)((char*)workspace + gd_align((size_t)S * 128 * kPredK * sizeof(float)));
   GdDwGroup Gp;
   Gp.n_jobs = 1;
-  Gp.job[0] = GdDwJob{dY, X_bf16, 128, kPredK, part, colpart, 0, nullptr, 0, 0, n_out, n_out};
+  Gp.job[0] = GdDwJob{dy_f32 ? dY_bf16 : dY, X_bf16, 128, kPredK, part, colpart, 0, nullptr, 0, 0, n_out, n_out};
   Gp.guard_rows = 1;
   if (int rc = gd_dw_grouped_s(st, Gp, n_pad, n, S)) return rc;
   hipLaunchKernelGGL(k_pred_dw_reduce, dim3(gd_div_up(n_out * kPredK + n_out, 256)), dim3(256), 0, st, (const float*)part, (const float*)colpart, S,

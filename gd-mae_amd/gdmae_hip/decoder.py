@@ -408,9 +408,11 @@ class PredHeadFn(torch.autograd.Function):
         x = x.contiguous()
         packed = torch.empty(L.load().gdmae_pred_head_packed_bytes(), dtype=torch.uint8, device=x.device)
         L.call("gdmae_pred_head_pack", L.ptr(weight), None if bias is None else L.ptr(bias), weight.shape[1], n_out, L.ptr(packed), L.stream())
-        y = torch.empty(n, n_out, dtype=torch.bfloat16, device=x.device)
         xb = torch.empty(n, x.shape[1], dtype=torch.bfloat16, device=x.device)      # the rounded operand rows: operand of the weight gradient
-        L.call("gdmae_pred_head_fwd", L.ptr(x), n, n_out, L.ptr(packed), L.ptr(y), L.ptr(xb), L.stream())
+        # the result is rounded to bf16 like the autocast linear's, but handed on widened to fp32: its consumer (the Chamfer kernel)
+        # reads fp32 rows, and an fp32 output receives the loss's fp32 gradient without a cast in between
+        y = torch.empty(n, n_out, dtype=torch.float32, device=x.device)
+        L.call("gdmae_pred_head_fwd", L.ptr(x), n, n_out, L.ptr(packed), None, L.ptr(xb), L.ptr(y), L.stream())
         ctx.save_for_backward(xb, packed)
         ctx.meta = (n_out, direct, weight.shape, None if bias is None else bias.shape)
         return y
@@ -421,8 +423,10 @@ class PredHeadFn(torch.autograd.Function):
         n_out, direct, wshape, bshape = ctx.meta
         n = x.shape[0]
         dy = dy.contiguous()
-        if dy.dtype != torch.bfloat16:
-            dy = dy.to(torch.bfloat16)
+        if dy.dtype not in (torch.bfloat16, torch.float32):
+            dy = dy.float()
+        f32 = dy.dtype == torch.float32                   # rounded inside the input-gradient launch (no cast pass)
+        dyb = torch.empty(dy.shape, dtype=torch.bfloat16, device=x.device) if f32 else None
         dx = torch.empty(x.shape, dtype=torch.float32, device=x.device) if ctx.needs_input_grad[0] else None
         if direct is not None:
             dW, db = direct
@@ -432,19 +436,26 @@ class PredHeadFn(torch.autograd.Function):
             db = None if bshape is None else torch.zeros(bshape, dtype=torch.float32, device=x.device)
             ret = (dW, db)
         ws = torch.empty(L.load().gdmae_pred_head_bwd_workspace_bytes(n), dtype=torch.uint8, device=x.device)
-        L.call("gdmae_pred_head_bwd", L.ptr(dy), L.ptr(x), n, n_out, L.ptr(packed), None if dx is None else L.ptr(dx), L.ptr(dW),
-               None if db is None else L.ptr(db), L.ptr(ws), L.stream())
+        scale = ops.LAZY_SCALE.pop(dy.data_ptr(), None) if f32 else None         # (upstream gradient, 1 / sum of weights) of the Chamfer mean
+        if scale is None and ops.LAZY_SCALE:
+            raise RuntimeError("an unscaled Chamfer gradient was handed over (ops.LAZY_SCALE) but did not arrive here as the same tensor")
+        L.call("gdmae_pred_head_bwd", L.ptr(dy), int(f32), None if dyb is None else L.ptr(dyb), None if scale is None else L.ptr(scale[0]),
+               None if scale is None else L.ptr(scale[1]), L.ptr(x), n, n_out, L.ptr(packed),
+               None if dx is None else L.ptr(dx), L.ptr(dW), None if db is None else L.ptr(db), L.ptr(ws), L.stream())
         return (dx, *ret, None)
 
 
 def pred_head(x, linear):
-    """``linear`` (nn.Linear 128 -> n_out) applied to fp32 rows under autocast: -> (n, n_out) bf16."""
+    """``linear`` (nn.Linear 128 -> n_out) applied to fp32 rows under autocast: -> (n, n_out) bf16-rounded values (fp32 storage on the fused
+    path, bf16 from the library path)."""
     w, b = linear.weight, linear.bias
     if (DECONV_ROWS and x.is_cuda and torch.is_autocast_enabled() and x.dtype == torch.float32 and w.dtype == torch.float32 and w.is_contiguous()
             and w.shape[1] == 128 and 4 <= w.shape[0] <= 64 and w.shape[0] % 4 == 0 and x.shape[0] > 0):
         dw, db = ops.direct_grad(w), (ops.direct_grad(b) if b is not None else None)
         direct = (dw, db) if (dw is not None and (b is None or db is not None)) else None
-        return PredHeadFn.apply(x, w, b, direct)
+        y = PredHeadFn.apply(x, w, b, direct)
+        y._gd_pred_head = True                 # its backward applies the scalars of a mean on load (ops.ChamferLoss lazy_scale)
+        return y
     return ops.linear(x, w, b)
 
 

@@ -139,9 +139,9 @@ SIGNATURES = {
     "gdmae_deconv_rows_bwd_weight": (_I, [_P, _P, _L, _I, _I, _I, _P, _P, _P]),
     "gdmae_pred_head_packed_bytes": (_Z, []),
     "gdmae_pred_head_pack": (_I, [_P, _P, _I, _I, _P, _P]),
-    "gdmae_pred_head_fwd": (_I, [_P, _L, _I, _P, _P, _P, _P]),
+    "gdmae_pred_head_fwd": (_I, [_P, _L, _I, _P, _P, _P, _P, _P]),
     "gdmae_pred_head_bwd_workspace_bytes": (_Z, [_L]),
-    "gdmae_pred_head_bwd": (_I, [_P, _P, _L, _I, _P, _P, _P, _P, _P, _P]),
+    "gdmae_pred_head_bwd": (_I, [_P, _I, _P, _P, _P, _P, _L, _I, _P, _P, _P, _P, _P, _P]),
     "gdmae_encoder_set_layer_path": (_I, [_I]),
     "gdmae_encoder_stage_fused": (_I, [_P, _I]),
     "gdmae_group_gt_points": (_I, [_P, _I, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
@@ -162,6 +162,7 @@ SIGNATURES = {
     "gdmae_geometry_plan": (_I, [_P, _P, _P, _P, _Z, _P]),
     "gdmae_grad_sq_norm": (_I, [_P, _L, _P, _P, _P]),
     "gdmae_adam_step": (_I, [_P, _P, _P, _P, _P, _I, _F, _F, _F, _F, _F, _I, _F, _F, _P, _P]),
+    "gdmae_adam_step_shadow": (_I, [_P, _P, _P, _P, _P, _I, _F, _F, _F, _F, _F, _I, _F, _F, _P, _P, _P]),
 }
 
 class LayerArgs(C.Structure):

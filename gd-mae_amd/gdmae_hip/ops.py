@@ -434,12 +434,21 @@ def group_gt_points(vox, K: int, want_index: bool = False):
     return (gt, gi) if want_index else gt
 
 
+LAZY_SCALE = {}      # data_ptr of an UNSCALED fp32 Chamfer gradient -> (upstream gradient, 1 / sum of weights), consumed by the
+                     # prediction head's backward (gdmae_hip.decoder.PredHeadFn), which applies the scale on load
+
+
 class ChamferLoss(torch.autograd.Function):
-    """pytorch3d-style weighted Chamfer distance; gradient w.r.t. pred only (gt carries none)."""
+    """pytorch3d-style weighted Chamfer distance; gradient w.r.t. pred only (gt carries none).
+
+    ``lazy_scale``: pred (fp32) comes straight from the fused prediction head (decoder.pred_head): the backward hands over the
+    unscaled per-point gradient with the two scalars on the side (LAZY_SCALE) - the head's input-gradient launch multiplies on
+    load, so no pass over the (M, 16, 3) gradient runs here."""
 
     @staticmethod
-    def forward(ctx, pred, gt, weights):
+    def forward(ctx, pred, gt, weights, lazy_scale=False):
         ctx.pred_dtype = pred.dtype       # bf16 rows of the prediction head under autocast: gradient returned in bf16
+        ctx.lazy = bool(lazy_scale and pred.dtype == torch.float32)
         pred, gt, weights = _f32c(pred.float()), _f32c(gt), _f32c(weights)
         M, P1, _ = pred.shape
         P2 = gt.shape[1]
@@ -455,8 +464,12 @@ class ChamferLoss(torch.autograd.Function):
     def backward(ctx, g):
         dpred, res = ctx.saved_tensors
         inv = res[1]
+        if ctx.lazy:
+            LAZY_SCALE.clear()                   # at most one pending hand-over
+            LAZY_SCALE[dpred.data_ptr()] = (g.detach().reshape(1).float().contiguous(), res[1:2])
+            return dpred, None, None, None
         if ctx.pred_dtype == torch.float32:
-            return dpred * (g * inv), None, None
+            return dpred * (g * inv), None, None, None
         out = torch.empty_like(dpred, dtype=ctx.pred_dtype)
         torch.mul(dpred, g * inv, out=out)       # scale and cast in one pass
-        return out, None, None
+        return out, None, None, None

@@ -141,9 +141,15 @@ class FlatAdamOneCycle:
         self._grad_scale = 1.0
         self.sync = GradSync(self)
 
-    def _refresh_shadows(self):
-        """One cast of the flat buffer -> bf16 views per parameter (consumed by gdmae_hip.ops.shadow)."""
-        self.flat_param_bf16.copy_(self.flat_param)
+    def _refresh_shadows(self, cast=True):
+        """One cast of the flat buffer -> bf16 views per parameter (consumed by gdmae_hip.ops.shadow).  ``cast=False``: the shadow
+        buffer is current (written by the optimizer launch itself)."""
+        if not cast:
+            # a torch-side weight change since the last stamp (load_state_dict between two steps): the optimizer launch only rewrote
+            # the elements it updates, so re-derive everything
+            cast = any(getattr(p, "_gd_shadow", None) is None or p._gd_shadow[1] != p._version for p in self.params)
+        if cast:
+            self.flat_param_bf16.copy_(self.flat_param)
         off = 0
         for p in self.params:
             k = p.numel()
@@ -205,13 +211,14 @@ class FlatAdamOneCycle:
         if self.flat_param.is_cuda:
             st = L.stream()
             L.call("gdmae_grad_sq_norm", L.ptr(self.flat_grad), self.n, L.ptr(self._part), L.ptr(self._sq), st)
-            L.call("gdmae_adam_step", L.ptr(self.flat_param), L.ptr(self.flat_grad), L.ptr(self.exp_avg),
+            L.call("gdmae_adam_step_shadow", L.ptr(self.flat_param), L.ptr(self.flat_grad), L.ptr(self.exp_avg),
                    L.ptr(self.exp_avg_sq), L.host_i64(self.segments), len(self.segments) // 2, float(lr), float(beta1), 0.99, 1e-8,
-                   float(c.WEIGHT_DECAY), self.t, float(c.GRAD_NORM_CLIP), float(self._grad_scale), L.ptr(self._sq), st)
+                   float(c.WEIGHT_DECAY), self.t, float(c.GRAD_NORM_CLIP), float(self._grad_scale), L.ptr(self._sq),
+                   L.ptr(self.flat_param_bf16), st)
         else:
             raise RuntimeError("FlatAdamOneCycle.step needs the HIP library and device buffers (no CPU fallback)")
         self._grad_scale = 1.0
-        self._refresh_shadows()
+        self._refresh_shadows(cast=False)       # the Adam launch wrote the bf16 copy of every element it updated
         return lr, beta1
 
     # ---- checkpoint wire format: the reference stores OptimWrapper.opt.state_dict(), i.e. the state_dict of a

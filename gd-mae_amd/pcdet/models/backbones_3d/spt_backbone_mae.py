@@ -40,7 +40,8 @@ class SPTBackboneMAE(nn.Module):
     def get_loss(self, tb_dict=None):
         tb_dict = {} if tb_dict is None else tb_dict
         r = self.forward_ret_dict
-        return ops.ChamferLoss.apply(r['pred_points'], r['gt_points'], r['mask']), tb_dict
+        # pred straight from the fused prediction head: the scalars of the mean are applied by the head's backward on load
+        return ops.ChamferLoss.apply(r['pred_points'], r['gt_points'], r['mask'], bool(r.get('pred_lazy_scale', False))), tb_dict
 
     def forward(self, batch_dict):
         """Inputs: DynVFE's ``voxel_features`` + the voxel plan.  Optional ``mae_noise`` (M,) injects the
@@ -108,5 +109,6 @@ class SPTBackboneMAE(nn.Module):
     def target_assigner(self, batch_dict):
         vox = batch_dict['_gdmae_vox']
         gt = ops.group_gt_points(vox, self.mask_cfg.NUM_GT_POINTS)         # (M, K, 3), centre-relative
-        pred = gdec.pred_head(batch_dict['voxel_features'], self.decoder_pred).view(vox.M, -1, 3)
-        return {'pred_points': pred, 'gt_points': gt, 'mask': batch_dict['voxel_mae_mask']}
+        flat = gdec.pred_head(batch_dict['voxel_features'], self.decoder_pred)
+        return {'pred_points': flat.view(vox.M, -1, 3), 'gt_points': gt, 'mask': batch_dict['voxel_mae_mask'],
+                'pred_lazy_scale': bool(getattr(flat, '_gd_pred_head', False))}

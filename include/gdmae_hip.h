@@ -601,10 +601,15 @@ int gdmae_deconv_rows_bwd_weight(const void* X, const void* dP, long long n, int
 size_t gdmae_pred_head_packed_bytes(void);
 int gdmae_pred_head_pack(const float* weight, const float* bias, int n_in, int n_out, void* packed, void* stream);
 int gdmae_pred_head_fwd(const float* X, long long n, int n_out, const void* packed, void* Y, void* X_bf16 /* (n, 128) bf16 out: the rounded
-                        operand rows, operand of the weight gradient */, void* stream);
+                        operand rows, operand of the weight gradient */, float* Y_f32 /* optional (n, n_out): Y widened to fp32; Y itself may then be NULL */,
+                        void* stream);
 size_t gdmae_pred_head_bwd_workspace_bytes(long long n);
-int gdmae_pred_head_bwd(const void* dY, const void* X_bf16, long long n, int n_out, const void* packed, float* dX, float* dW, float* db,
-                        void* workspace, void* stream);
+int gdmae_pred_head_bwd(const void* dY, int dy_f32 /* dY holds fp32 rows: rounded here, the rounded rows written to dY_bf16 */,
+                        void* dY_bf16 /* (n, n_out) bf16 scratch, dy_f32 only */,
+                        const float* scale_a, const float* scale_b /* optional device scalars (dy_f32 only): dY is multiplied by
+                        scale_a[0] * scale_b[0] on load - the loss's upstream gradient and 1 / sum of weights of the Chamfer mean */,
+                        const void* X_bf16, long long n, int n_out,
+                        const void* packed, float* dX, float* dW, float* db, void* workspace, void* stream);
 
 /* ---- a17-a19: reconstruction targets and Chamfer loss ----------------------------------------- *
  * gdmae_group_gt_points replaces sst_ops_cuda.group_inner_inds_wrapper (sst_ops_api.cpp:8;
@@ -745,6 +750,11 @@ int gdmae_grad_sq_norm(const float* grad, long long n, float* partials /* >= 102
 int gdmae_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const long long* segments,
                     int n_segments, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                     float max_norm, float grad_scale, const float* sq_norm, void* stream);
+/* the same step, additionally writing the bf16 copy of every UPDATED element to param_bf16 (same element offsets; NULL = none): the
+ * shadow the bf16 GEMMs read comes out of the optimizer launch instead of a cast pass over the flat buffer */
+int gdmae_adam_step_shadow(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const long long* segments,
+                           int n_segments, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                           float max_norm, float grad_scale, const float* sq_norm, void* param_bf16, void* stream);
 
 #ifdef __cplusplus
 }

@@ -852,8 +852,12 @@ def test_pred_head_matches_fp64_linear(n):
     L.call("gdmae_pred_head_pack", L.ptr(W), L.ptr(b), 128, 48, L.ptr(packed), L.stream())
     y = torch.empty(n, 48, dtype=torch.bfloat16, device=dev())
     xb = torch.empty(n, 128, dtype=torch.bfloat16, device=dev())
-    L.call("gdmae_pred_head_fwd", L.ptr(x), n, 48, L.ptr(packed), L.ptr(y), L.ptr(xb), L.stream())
-    assert torch.equal(xb, x.to(torch.bfloat16))
+    yf = torch.empty(n, 48, dtype=torch.float32, device=dev())
+    L.call("gdmae_pred_head_fwd", L.ptr(x), n, 48, L.ptr(packed), L.ptr(y), L.ptr(xb), L.ptr(yf), L.stream())
+    assert torch.equal(xb, x.to(torch.bfloat16)) and torch.equal(yf, y.float())
+    yf2 = torch.empty_like(yf)
+    L.call("gdmae_pred_head_fwd", L.ptr(x), n, 48, L.ptr(packed), None, None, L.ptr(yf2), L.stream())
+    assert torch.equal(yf2, yf)
     xq, Wq, bq = x.to(torch.bfloat16).double(), W.to(torch.bfloat16).double(), b.to(torch.bfloat16).double()
     ref = xq @ Wq.t() + bq
     assert float((y.double() - ref).abs().max()) <= 8e-3 * float(ref.abs().max())
@@ -861,14 +865,25 @@ def test_pred_head_matches_fp64_linear(n):
     dW = torch.full((48, 128), 0.25, dtype=torch.float32, device=dev())
     db = torch.full((48,), -1.0, dtype=torch.float32, device=dev())
     ws = torch.empty(lib.gdmae_pred_head_bwd_workspace_bytes(n), dtype=torch.uint8, device=dev())
-    L.call("gdmae_pred_head_bwd", L.ptr(dy), L.ptr(xb), n, 48, L.ptr(packed), L.ptr(dx), L.ptr(dW), L.ptr(db), L.ptr(ws), L.stream())
+    L.call("gdmae_pred_head_bwd", L.ptr(dy), 0, None, None, None, L.ptr(xb), n, 48, L.ptr(packed), L.ptr(dx), L.ptr(dW), L.ptr(db), L.ptr(ws), L.stream())
     assert float((dx.double() - dy.double() @ Wq).abs().max()) <= 1e-5 * float((dy.double() @ Wq).abs().max())
     rw, rb = dy.double().t() @ xq, dy.double().sum(0)
     assert float(((dW.double() - 0.25) - rw).abs().max()) <= 2e-5 * float(rw.abs().max()) + 1e-7 * n
     assert float(((db.double() + 1.0) - rb).abs().max()) <= 2e-5 * float(rb.abs().max()) + 1e-7 * n
     dW2, db2 = torch.full_like(dW, 0.25), torch.full_like(db, -1.0)
-    L.call("gdmae_pred_head_bwd", L.ptr(dy), L.ptr(xb), n, 48, L.ptr(packed), None, L.ptr(dW2), L.ptr(db2), L.ptr(ws), L.stream())
+    L.call("gdmae_pred_head_bwd", L.ptr(dy), 0, None, None, None, L.ptr(xb), n, 48, L.ptr(packed), None, L.ptr(dW2), L.ptr(db2), L.ptr(ws), L.stream())
     assert torch.equal(dW, dW2) and torch.equal(db, db2)
+    # fp32 gradient rows (what the Chamfer backward hands over): rounded inside the launch, identical results
+    dyf, dyb = dy.float(), torch.empty_like(dy)
+    dx3, dW3, db3 = torch.empty_like(dx), torch.full_like(dW, 0.25), torch.full_like(db, -1.0)
+    L.call("gdmae_pred_head_bwd", L.ptr(dyf), 1, L.ptr(dyb), None, None, L.ptr(xb), n, 48, L.ptr(packed), L.ptr(dx3), L.ptr(dW3), L.ptr(db3), L.ptr(ws),
+           L.stream())
+    assert torch.equal(dyb, dy) and torch.equal(dx3, dx) and torch.equal(dW3, dW) and torch.equal(db3, db)
+    # ... with the two device scalars of the Chamfer mean folded in: dY = (2 x 0.25) x unscaled rows
+    sa, sb = torch.tensor([2.0], device=dev()), torch.tensor([0.25], device=dev())
+    L.call("gdmae_pred_head_bwd", L.ptr(dyf * 2.0), 1, L.ptr(dyb), L.ptr(sa), L.ptr(sb), L.ptr(xb), n, 48, L.ptr(packed), L.ptr(dx3), L.ptr(dW3),
+           L.ptr(db3), L.ptr(ws), L.stream())
+    assert torch.equal(dyb, dy) and torch.equal(dx3, dx)
 
 
 def test_packed_weight_images_follow_weight_changes_between_optimizer_steps():
