@@ -13,3 +13,8 @@ int gd_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const void* A
             size_t ws_bytes, bool loose = false);
 // dst[i] (+)= sum_{s < S} part[s * P + i], P % 4 == 0
 int gd_splitk_acc(hipStream_t st, const float* part, int S, long long P, float* dst, int accumulate);
+
+// fp32 operands, fp32 result, exact fp32 MFMA arithmetic in a fixed order (gemm_f32.hip): what gd_gemm runs for HIP_R_32F
+// (GDMAE_GEMM_F32=0: hipBLASLt instead, A/B reference)
+int gd_gemm_f32(hipStream_t st, bool ta, bool tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                const float* bias, int batch, long long sA, long long sB, long long sC);

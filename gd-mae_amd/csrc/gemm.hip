@@ -77,6 +77,14 @@ std::mutex g_lt_mu;
 int gd_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
             hipDataType tab, hipDataType tc, const void* bias, int batch, long long sA, long long sB, long long sC, void* ws,
             size_t ws_bytes, bool loose) {
+  if (tab == HIP_R_32F && tc == HIP_R_32F) {
+    // the fp32 parity mode: exact-fp32 MFMA products in a fixed order on this library's own kernel (gemm_f32.hip)
+    static const int lt = getenv("GDMAE_GEMM_F32") ? atoi(getenv("GDMAE_GEMM_F32")) == 0 : 0;
+    if (!lt) {
+      ++g_gemm_calls;
+      return gd_gemm_f32(st, ta, tb, M, N, K, (const float*)A, lda, (const float*)B, ldb, (float*)C, ldc, (const float*)bias, batch, sA, sB, sC);
+    }
+  }
   std::lock_guard<std::mutex> lock(g_lt_mu);
   if (!g_lt) LT_CHECK(hipblasLtCreate(&g_lt));
   // loose shapes: extents are bucketed to 3 significant bits (<= 25 % apart; extents <= 64 to multiples of 16), so the

@@ -1,0 +1,112 @@
+// fp32 GEMM of the PARITY mode on the matrix cores (the fp32 mode carries north_star's 1e-4 bound): every product the
+// fp32 path used to hand to hipBLASLt - token GEMMs of the encoder layers, im2col products of the sparse convolutions, their input
+// gradients, the batched split-K weight gradients, the deconvolution / prediction-head linears - through one hand-written kernel
+// with EXACT fp32 arithmetic: v_mfma_f32_32x32x2_f32 multiplies fp32 operands and accumulates in fp32 (no bf16 / tf32 rounding of
+// the inputs), in a fixed order that does not depend on timing (the library's algorithm choice did: csrc/gemm.hip).
+//
+//   column-major  C (M x N, ldc) = op(A) op(B) [+ bias(M)],  op = identity or transpose, strided batches
+//
+// One workgroup (4 wavefronts = 2 x 2 blocks of 32 x 32) owns a 64 x 64 tile of C; k advances in tiles of 16 staged in LDS as
+// As[k][m] / Bs[k][n] (the MFMA's operand order: lane = (row | column, k parity)), the next tile's elements are in flight in
+// registers while the current one is multiplied.  Loads follow whichever index is contiguous in memory for the given transposes;
+// all extents are guarded, so any M, N, K is served.  Throughput is secondary here (the parity mode runs at a quarter of the bf16
+// mode's rate whatever the GEMMs do); what matters is that the mode's arithmetic is this repository's own.
+#include "common.h"
+#include "gemm.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+constexpr int kTM = 64, kTN = 64, kTK = 16, kPad = 4;
+
+struct GfArgs {
+  const float* A;
+  const float* B;
+  float* C;
+  const float* bias;
+  int M, N, K, lda, ldb, ldc, ta, tb;
+  long long sA, sB, sC;
+  int swap_xy;              // blockIdx.x walks the N tiles (the longer extent goes to x: y is limited to 65535)
+};
+
+__global__ __launch_bounds__(256) void k_gemm_f32(GfArgs G) {
+  __shared__ float As[kTK][kTM + kPad];
+  __shared__ float Bs[kTK][kTN + kPad];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wm = wv >> 1, wn = wv & 1;
+  const int m0 = (G.swap_xy ? blockIdx.y : blockIdx.x) * kTM, n0 = (G.swap_xy ? blockIdx.x : blockIdx.y) * kTN;
+  const float* __restrict__ A = G.A + (long long)blockIdx.z * G.sA;
+  const float* __restrict__ B = G.B + (long long)blockIdx.z * G.sB;
+  float* __restrict__ C = G.C + (long long)blockIdx.z * G.sC;
+  // element (m, k) of op(A): !ta -> A[m + k lda] (m contiguous), ta -> A[k + m lda] (k contiguous); same for op(B)(k, n)
+  int am[4], ak[4], bn[4], bk[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (!G.ta) { am[i] = tid & 63; ak[i] = (tid >> 6) + 4 * i; } else { ak[i] = tid & 15; am[i] = (tid >> 4) + 16 * i; }
+    if (G.tb) { bn[i] = tid & 63; bk[i] = (tid >> 6) + 4 * i; } else { bk[i] = tid & 15; bn[i] = (tid >> 4) + 16 * i; }
+  }
+  auto load_a = [&](int k0, float (&v)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + am[i], k = k0 + ak[i];
+      v[i] = (m < G.M && k < G.K) ? (G.ta ? A[k + (long long)m * G.lda] : A[m + (long long)k * G.lda]) : 0.f;
+    }
+  };
+  auto load_b = [&](int k0, float (&v)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int n = n0 + bn[i], k = k0 + bk[i];
+      v[i] = (n < G.N && k < G.K) ? (G.tb ? B[n + (long long)k * G.ldb] : B[k + (long long)n * G.ldb]) : 0.f;
+    }
+  };
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  float va[4], vb[4];
+  load_a(0, va);
+  load_b(0, vb);
+  for (int k0 = 0; k0 < G.K; k0 += kTK) {
+    __syncthreads();                                   // the previous tile has been consumed
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      As[ak[i]][am[i]] = va[i];
+      Bs[bk[i]][bn[i]] = vb[i];
+    }
+    __syncthreads();
+    if (k0 + kTK < G.K) {                              // next tile: in flight behind the MFMAs
+      load_a(k0 + kTK, va);
+      load_b(k0 + kTK, vb);
+    }
+#pragma unroll
+    for (int kk = 0; kk < kTK / 2; ++kk) {
+      const float a = As[2 * kk + (lane >> 5)][wm * 32 + (lane & 31)];
+      const float b = Bs[2 * kk + (lane >> 5)][wn * 32 + (lane & 31)];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+  }
+  // acc[4 q + e]: row m = 8 q + e + 4 (lane >> 5) of the wavefront's block, column n = lane & 31
+  const int n = n0 + wn * 32 + (lane & 31);
+  if (n < G.N) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int m = m0 + wm * 32 + 8 * q + 4 * (lane >> 5);
+      float v[4] = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (m + e < G.M) C[(m + e) + (long long)n * G.ldc] = v[e] + (G.bias ? G.bias[m + e] : 0.f);
+    }
+  }
+}
+}  // namespace
+
+int gd_gemm_f32(hipStream_t st, bool ta, bool tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                const float* bias, int batch, long long sA, long long sB, long long sC) {
+  GD_REQUIRE(M > 0 && N > 0 && K > 0 && batch >= 1 && batch <= 65535, "gemm_f32: bad extents");
+  const unsigned gm = (unsigned)gd_div_up(M, kTM), gn = (unsigned)gd_div_up(N, kTN);
+  const int swap = gn > gm;
+  GfArgs G{A, B, C, bias, M, N, K, lda, ldb, ldc, ta ? 1 : 0, tb ? 1 : 0, sA, sB, sC, swap};
+  const dim3 grid(swap ? gn : gm, swap ? gm : gn, (unsigned)batch);
+  GD_REQUIRE(grid.y <= 65535, "gemm_f32: both extents too large for one launch");
+  hipLaunchKernelGGL(k_gemm_f32, grid, dim3(256), 0, st, G);
+  GD_LAUNCH_CHECK();
+  return 0;
+}

@@ -837,6 +837,40 @@ def test_deconv_rows_match_conv_transpose(cin, s, n):
     assert torch.equal(dW, dW2)                                                           # fixed summation order
 
 
+@pytest.mark.parametrize("M,N,K", [(4099, 256, 128), (777, 48, 128), (130, 2304, 1152), (20000, 64, 11 * 8)])
+def test_fp32_gemm_is_exact_fp32_on_own_kernel(M, N, K):
+    """gdmae_gemm with fp32 operands (the parity mode's token / im2col products: csrc/gemm_f32.hip, exact-fp32 MFMA, fixed order)
+    against the fp64 product: all four transpose combinations the library's callers use, bias, ragged extents; and the split-K
+    weight-gradient entry.  1e-6 relative to the row scale = fp32 accumulation of K <= 1152 terms; bit-identical when repeated."""
+    from gdmae_hip import lib as L
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g).to(dev())
+    b = torch.randn(K, N, generator=g).to(dev())
+    bias = torch.randn(N, generator=g).to(dev())
+    ws = torch.empty(L.load().gdmae_gemm_workspace_bytes(), dtype=torch.uint8, device=dev())
+    ref = a.double() @ b.double()
+    tol = 2e-6 * float(ref.abs().max()) * max(1.0, (K / 128) ** 0.5)
+    for ta, tb in ((0, 0), (0, 1), (1, 0), (1, 1)):
+        A = a.t().contiguous() if ta else a
+        B = b.t().contiguous() if tb else b
+        for bs in (None, bias):
+            out = torch.full((M, N), float("nan"), device=dev())
+            L.call("gdmae_gemm", L.ptr(A), L.ptr(B), L.ptr(out), M, N, K, ta, tb, 0, 0, None if bs is None else L.ptr(bs), L.ptr(ws), L.stream())
+            want = ref if bs is None else ref + bs.double()
+            assert float((out.double() - want).abs().max()) <= tol, (ta, tb, bs is not None, float((out.double() - want).abs().max()), tol)
+            out2 = torch.empty_like(out)
+            L.call("gdmae_gemm", L.ptr(A), L.ptr(B), L.ptr(out2), M, N, K, ta, tb, 0, 0, None if bs is None else L.ptr(bs), L.ptr(ws), L.stream())
+            assert torch.equal(out, out2)
+    # split-K weight gradient: C (m, n) = A^T B over the long row extent
+    if N % 8 == 0 and K % 8 == 0:
+        wsk = torch.empty(L.load().gdmae_gemm_tn_splitk_workspace_bytes(M, K, N), dtype=torch.uint8, device=dev())
+        x2 = torch.randn(M, N, generator=g).to(dev())
+        c = torch.empty(K, N, device=dev())
+        L.call("gdmae_gemm_tn_splitk", L.ptr(a), L.ptr(x2), L.ptr(c), M, K, N, 0, 0, L.ptr(wsk), L.stream())
+        want = a.double().t() @ x2.double()
+        assert float((c.double() - want).abs().max()) <= 3e-6 * float(want.abs().max()) * max(1.0, (M / 1024) ** 0.5)
+
+
 @pytest.mark.parametrize("n", [131072 + 37, 700])
 def test_pred_head_matches_fp64_linear(n):
     """gdmae_pred_head_* (nn.Linear(128 -> 48) on fp32 rows, csrc/rows_gemm.hip) against the fp64 product of the same bf16-rounded
