@@ -107,6 +107,70 @@ def test_bev_backbone_and_center_head_match_reference_golden():
 
 
 @pytest.mark.gpu
+def test_detector_end_to_end_matches_reference_golden():
+    """The whole fine-tune chain DynVFE -> SPTBackbone -> SSTBEVBackbone -> CenterHead (fp32) against the golden captured from the
+    UNMODIFIED reference chain on the same seeded points, boxes and weights (tests/golden/make_golden_detector.py): pillar set
+    bit-exact, dense maps 5e-4, CenterHead loss terms 1e-4, every parameter's gradient norm through the whole chain 2e-2 (the
+    backbone's bound; tau gradients as in test_finetune_backbone_vs_reference_golden)."""
+    from oracle import gdmae_oracle as orc
+    from pcdet.models.backbones_2d import SSTBEVBackbone
+    from pcdet.models.backbones_3d import SPTBackbone
+    from pcdet.models.backbones_3d.vfe import DynVFE
+    from pcdet.models.dense_heads import CenterHead
+    z = dict(np.load(os.path.join(GOLDEN, "detector_kitti_b2.npz")))
+    dev = torch.device("cuda:0")
+    ds = configs.SyntheticDatasetInfo(**configs.KITTI)
+    F, B, seed = int(z["num_point_features"]), int(z["batch_size"]), int(z["seed"])
+    cfg3 = configs.gdmae_ssl_model_cfg(eval_metric="kitti")
+    vfe = DynVFE(model_cfg=cfg3.VFE, num_point_features=F, voxel_size=ds.voxel_size, point_cloud_range=ds.point_cloud_range,
+                 grid_size=ds.grid_size)
+    bb = SPTBackbone(model_cfg=configs.gdmae_finetune_backbone_cfg(eval_metric="kitti"), input_channels=vfe.get_output_feature_dim(),
+                     grid_size=ds.grid_size, voxel_size=ds.voxel_size, point_cloud_range=ds.point_cloud_range)
+    b2d = SSTBEVBackbone(model_cfg=configs.sst_bev_backbone_cfg(), input_channels=128)
+    head = CenterHead(model_cfg=configs.center_head_cfg(), input_channels=b2d.num_bev_features, num_class=3,
+                      class_names=['Vehicle', 'Pedestrian', 'Cyclist'], grid_size=np.asarray(ds.grid_size),
+                      point_cloud_range=np.asarray(ds.point_cloud_range, dtype=np.float32), voxel_size=list(ds.voxel_size),
+                      predict_boxes_when_training=False)
+
+    class Front(torch.nn.Module):
+        def __init__(s):
+            super().__init__()
+            s.vfe, s.backbone_3d = vfe, bb
+
+    class Back(torch.nn.Module):
+        def __init__(s):
+            super().__init__()
+            s.backbone_2d, s.dense_head = b2d, head
+    front, back = Front(), Back()
+    shapes = {str(n): tuple(int(v) for v in sh if v > 0) for n, sh in zip(z["front_names"], z["front_shapes"])}
+    assert {k: tuple(v.shape) for k, v in front.named_parameters()} == shapes
+    front.load_state_dict(orc.seeded_state_dict(shapes, seed=seed), strict=False)
+    back.load_state_dict(seeded_head_state(back, seed), strict=False)
+    front, back = front.to(dev).train(), back.to(dev).train()
+    torch.backends.cudnn.allow_tf32 = False
+    bd = bb(vfe({"points": torch.from_numpy(z["points"]).to(dev), "batch_size": B}))
+    assert np.array_equal(bd["voxel_coords"].cpu().numpy(), z["voxel_coords"])
+    bd["gt_boxes"] = torch.from_numpy(z["gt_boxes"]).to(dev)
+    bd = head(b2d(bd))
+    loss, tb = head.get_loss()
+    loss.backward()
+    assert_sampled_close(bd["spatial_features"], z["spatial_features_s"], z["spatial_features_c"], 5e-4, "spatial_features")
+    assert_sampled_close(bd["spatial_features_2d"], z["feat2d_s"], z["feat2d_c"], 5e-4, "spatial_features_2d")
+    assert abs(float(loss) - float(z["loss"])) <= 1e-4 * float(z["loss"]), (float(loss), float(z["loss"]))
+    assert abs(float(tb["hm_loss_head_0"]) - float(z["hm_loss"])) <= 1e-4 * float(z["hm_loss"])
+    assert abs(float(tb["loc_loss_head_0"]) - float(z["loc_loss"])) <= 1e-4 * float(z["loc_loss"])
+    g = {**dict(front.named_parameters()), **dict(back.named_parameters())}
+    names = [str(k) for k in z["param_names"]]
+    gn = np.array([float(g[k].grad.double().norm()) for k in names])
+    ref = z["grad_norm"]
+    is_tau = np.array([k.endswith("tau") for k in names])
+    slack = np.where(is_tau, 2e-2 * np.median(ref[is_tau]), 1e-6 * ref.max())
+    tol = np.where(is_tau, 2.5e-1, 2e-2)
+    bad = np.abs(gn - ref) > tol * ref + slack
+    assert not bad.any(), [(names[i], gn[i], ref[i]) for i in np.flatnonzero(bad)]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("autocast", [False, True])
 def test_config_d_training_step(autocast):
     """BASELINE config D (KITTI-shape 20 k points, 0.16 m pillars, SPTBackbone + SSTBEVBackbone + CenterHead / CenterPoint)
