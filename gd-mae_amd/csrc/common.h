@@ -296,6 +296,11 @@ __device__ inline void gd_scan_get(const unsigned long long* w, U128& v) {
 // the value stores above (sc1: past the per-XCD L2) have been acknowledged before the flag store below is issued.  A
 // workgroup-scope release fence emits NO wait on gfx950 (verified in the ISA: the two stores went out back to back and a
 // reader on another XCD saw the flag before the value); an agent-scope one adds an L2 write-back the protocol does not need.
+// The vmcnt wait orders stores only on targets whose stores are counted by vmcnt (gfx9 family: gfx942, gfx950).  gfx10+ counts
+// them in a separate counter (vscnt): there the flag could overtake the value without any diagnostic - refuse to build.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "gd_scan_store_done relies on stores being counted by vmcnt (gfx942 / gfx950); use an agent-scope release on other targets"
+#endif
 __device__ inline void gd_scan_store_done() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 struct GdNoTotal {
   template <typename T>

@@ -19,6 +19,12 @@ def fold(x2d: torch.Tensor, count: int, gamma: torch.Tensor, beta: torch.Tensor,
     """Column statistics of the contiguous (R, C) fp32/bf16 matrix over ``count`` samples.
     -> (stats f64[2C] = mean|rstd, ab f32[2C] = a|b with y = a*x + b, mv f32[2C] = mean|biased var).
     ``bn``: the nn.BatchNorm module whose running statistics are updated in the same launch (training mode)."""
+    if isinstance(bn, torch.nn.SyncBatchNorm):
+        # tools/train.py:120-121 (--sync_bn, off by default in every shipped script): statistics over all ranks need two small
+        # collectives per BatchNorm and direction; the fused row kernels compute per-GPU statistics (the reference default) and must
+        # not silently do so under a module that promises synchronised ones
+        raise NotImplementedError("SyncBatchNorm is not supported by the fused BatchNorm kernels (per-GPU statistics, the reference's "
+                                  "default); run without --sync_bn")
     R, C = x2d.shape
     assert x2d.is_contiguous() and x2d.dtype in (torch.float32, torch.bfloat16)
     assert gamma.dtype == torch.float32 and beta.dtype == torch.float32

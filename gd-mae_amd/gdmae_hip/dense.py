@@ -56,7 +56,8 @@ def conv_bn_relu_cat(blocks, xs) -> torch.Tensor:
              for b, y in zip(blocks, ys))
     ok = ok and len({(y.shape[0],) + tuple(y.shape[2:]) + (y.dtype,) for y in ys}) == 1 and len({float(b[1].eps) for b in blocks}) == 1
     if not ok:
-        return torch.cat([b[2](b[1](y)) for b, y in zip(blocks, ys)], dim=1)
+        # whatever follows the convolution in each block, applied as the module sequence would (blocks that are not conv + BN + ReLU)
+        return torch.cat([nn.Sequential(*list(b)[1:])(y) for b, y in zip(blocks, ys)], dim=1)
     B, _, Y, X = ys[0].shape
     args = []
     for b, y in zip(blocks, ys):
