@@ -155,6 +155,7 @@ def _pmc_traffic(kernels):
 ROOFLINE_KERNELS = {
     "k_tok_gemm": ("hbm", ("k_tok_gemm", "k_tok_gemm_multi", "k_tok_ffn", "k_layer_fwd", "k_layer_bwd_ffn", "k_layer_bwd_in", "k_ln2_bwd_top")),
     "k_dw_grouped": ("hbm", ("k_dw_grouped",)),
+    "k_rows_gemm": ("hbm", ("k_rows_gemm", "k_rows_gemm_kc", "k_pred_fwd", "k_pred_bwd_input")),
     "k_layer_tail": ("hbm", ("k_layer_tail",)),
     "k_conv3x3_tiles": ("mfma", ("k_conv3x3_tiles",)),
     "k_conv_grad_taps": ("hbm", ("k_conv_grad_taps",)),

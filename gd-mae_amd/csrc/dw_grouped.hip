@@ -17,6 +17,7 @@
 // the 2-4x re-reads of a slice's activations by the tiles that share them are served by that XCD's L2.
 #include "common.h"
 #include "dw_grouped.h"
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -294,7 +295,10 @@ bool gd_dw_group_supported(long long n_pad, int d, int ff) {
   return d % kTile == 0 && ff % kTile == 0 && d <= 512 && ff <= 1024 && n_pad > 0 && n_pad % (8 * kChunk) == 0;
 }
 // number of row slices: a multiple of 8 (one XCD per slice residue), tiles x slices ~ 2 workgroups per CU
-int gd_dw_group_slices(long long n_pad, int tiles_total) { return gd_dw_group_slices_for(n_pad, tiles_total, 512); }
+int gd_dw_group_slices(long long n_pad, int tiles_total) {
+  static const int wgs = getenv("GDMAE_DW_WGS") ? atoi(getenv("GDMAE_DW_WGS")) : 512;      // experiment switch
+  return gd_dw_group_slices_for(n_pad, tiles_total, wgs);
+}
 // Slice count FIRST, then the row padding that makes it fit (gathered launches: the row count is data dependent, and a padding
 // granule of 1024 rows capped the slices at 16 - 288 workgroups for the 384 k decoder sites): S doubles while tiles x S stays within
 // max_wgs and a slice keeps >= 4 chunks; *n_pad = rows padded to S x 64.
