@@ -158,20 +158,26 @@ __device__ __forceinline__ uint4 tl_wfrag(const uint4* __restrict__ w0, const ui
   return ks < KSPLIT ? w0[((size_t)ks * mbs + j * TG_WAVES) * 64] : w1[((size_t)(ks - KSPLIT) * mbs + j * TG_WAVES) * 64];
 }
 
+// prefetch distance of a product: TL_PF k-steps, TL_PF1 for products whose wavefronts own ONE channel block (a ring of TL_PF1 + 1
+// fragments = 4 VGPRs each; with two blocks per wavefront the deeper ring would not fit 128 registers)
+#ifndef TL_PF1
+#define TL_PF1 TL_PF
+#endif
 template <int KD, int ND, int ROWS, int KSPLIT = KD / 16>
 struct TlProd {
+  static constexpr int PFD = (TlShape<KD, ND, ROWS>::MPW == 1 && KD / 16 > TL_PF1) ? TL_PF1 : TL_PF;
   using S = TlShape<KD, ND, ROWS>;
-  TgFrag wr[TL_PF + 1][S::MPW];
+  TgFrag wr[PFD + 1][S::MPW];
   const uint4* __restrict__ w0;
   const uint4* __restrict__ w1;
   int mbs;
-  // first TL_PF k-steps of the weights: issued early (before a row pass or a tile load) so that their latency is hidden
+  // first PFD k-steps of the weights: issued early (before a row pass or a tile load) so that their latency is hidden
   __device__ __forceinline__ void prefetch(const uint4* W0, const uint4* W1, int wv, int lane, int image_blocks = S::MB) {
     mbs = image_blocks;
     w0 = W0 + (size_t)S::mb0(wv) * 64 + lane;
     w1 = W1 ? W1 + (size_t)S::mb0(wv) * 64 + lane : w0;
 #pragma unroll
-    for (int ks = 0; ks < TL_PF; ++ks)
+    for (int ks = 0; ks < PFD; ++ks)
 #pragma unroll
       for (int j = 0; j < S::MPW; ++j) wr[ks][j].q = tl_wfrag<KD, ND, ROWS, KSPLIT>(w0, w1, ks, j, mbs);
   }
@@ -182,9 +188,9 @@ struct TlProd {
     for (int b = 0; b < S::NPW; ++b) sf[0][b].q = *(const uint4*)(lb + b * 32 * XP);
 #pragma unroll
     for (int ks = 0; ks < S::KS; ++ks) {
-      if (ks + TL_PF < S::KS) {
+      if (ks + PFD < S::KS) {
 #pragma unroll
-        for (int j = 0; j < S::MPW; ++j) wr[(ks + TL_PF) % (TL_PF + 1)][j].q = tl_wfrag<KD, ND, ROWS, KSPLIT>(w0, w1, ks + TL_PF, j, mbs);
+        for (int j = 0; j < S::MPW; ++j) wr[(ks + PFD) % (PFD + 1)][j].q = tl_wfrag<KD, ND, ROWS, KSPLIT>(w0, w1, ks + PFD, j, mbs);
       }
       if (ks + 1 < S::KS) {
 #pragma unroll
@@ -194,7 +200,7 @@ struct TlProd {
       for (int j = 0; j < S::MPW; ++j)
 #pragma unroll
         for (int b = 0; b < S::NPW; ++b)
-          acc[j][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[ks % (TL_PF + 1)][j].v, sf[ks & 1][b].v, acc[j][b], 0, 0, 0);
+          acc[j][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[ks % (PFD + 1)][j].v, sf[ks & 1][b].v, acc[j][b], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
