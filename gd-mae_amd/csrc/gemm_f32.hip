@@ -9,10 +9,12 @@
 // One workgroup (4 wavefronts = 2 x 2 blocks of 32 x 32) owns a 64 x 64 tile of C; k advances in tiles of 16 staged in LDS as
 // As[k][m] / Bs[k][n] (the MFMA's operand order: lane = (row | column, k parity)), the next tile's elements are in flight in
 // registers while the current one is multiplied.  Loads follow whichever index is contiguous in memory for the given transposes;
-// all extents are guarded, so any M, N, K is served.  Throughput is secondary here (the parity mode runs at a quarter of the bf16
+// (16-byte loads when base, leading dimension and batch stride allow); all extents are guarded, so any M, N, K is served.  A 64 x 128
+// tile with two column blocks per wavefront measured slower on the step (47.8 vs 45.4 ms: the products are skinny, N = 128 - 512).  Throughput is secondary here (the parity mode runs at a quarter of the bf16
 // mode's rate whatever the GEMMs do); what matters is that the mode's arithmetic is this repository's own.
 #include "common.h"
 #include "gemm.h"
+#include <stdint.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -27,6 +29,7 @@ struct GfArgs {
   int M, N, K, lda, ldb, ldc, ta, tb;
   long long sA, sB, sC;
   int swap_xy;              // blockIdx.x walks the N tiles (the longer extent goes to x: y is limited to 65535)
+  int vec_a, vec_b;         // 16-byte loads along the contiguous index of op(A) / op(B) (base, leading dimension and batch stride aligned)
 };
 
 __global__ __launch_bounds__(256) void k_gemm_f32(GfArgs G) {
@@ -44,7 +47,29 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GfArgs G) {
     if (!G.ta) { am[i] = tid & 63; ak[i] = (tid >> 6) + 4 * i; } else { ak[i] = tid & 15; am[i] = (tid >> 4) + 16 * i; }
     if (G.tb) { bn[i] = tid & 63; bk[i] = (tid >> 6) + 4 * i; } else { bk[i] = tid & 15; bn[i] = (tid >> 4) + 16 * i; }
   }
+  // vectorised variants: one float4 per thread along the contiguous index (the four elements share the other index)
+  if (G.vec_a) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (!G.ta) { am[i] = 4 * (tid & 15) + i; ak[i] = tid >> 4; } else { ak[i] = 4 * (tid & 3) + i; am[i] = tid >> 2; }
+    }
+  }
+  if (G.vec_b) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (G.tb) { bn[i] = 4 * (tid & 15) + i; bk[i] = tid >> 4; } else { bk[i] = 4 * (tid & 3) + i; bn[i] = tid >> 2; }
+    }
+  }
   auto load_a = [&](int k0, float (&v)[4]) {
+    if (G.vec_a) {
+      const int m = m0 + am[0], k = k0 + ak[0];
+      const bool in = G.ta ? (m < G.M && k + 3 < G.K) : (m + 3 < G.M && k < G.K);
+      if (in) {
+        const float4 q = *(const float4*)(G.ta ? A + k + (long long)m * G.lda : A + m + (long long)k * G.lda);
+        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+        return;
+      }
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int m = m0 + am[i], k = k0 + ak[i];
@@ -52,6 +77,15 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GfArgs G) {
     }
   };
   auto load_b = [&](int k0, float (&v)[4]) {
+    if (G.vec_b) {
+      const int n = n0 + bn[0], k = k0 + bk[0];
+      const bool in = G.tb ? (n + 3 < G.N && k < G.K) : (n < G.N && k + 3 < G.K);
+      if (in) {
+        const float4 q = *(const float4*)(G.tb ? B + n + (long long)k * G.ldb : B + k + (long long)n * G.ldb);
+        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+        return;
+      }
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int n = n0 + bn[i], k = k0 + bk[i];
@@ -103,7 +137,8 @@ int gd_gemm_f32(hipStream_t st, bool ta, bool tb, int M, int N, int K, const flo
   GD_REQUIRE(M > 0 && N > 0 && K > 0 && batch >= 1 && batch <= 65535, "gemm_f32: bad extents");
   const unsigned gm = (unsigned)gd_div_up(M, kTM), gn = (unsigned)gd_div_up(N, kTN);
   const int swap = gn > gm;
-  GfArgs G{A, B, C, bias, M, N, K, lda, ldb, ldc, ta ? 1 : 0, tb ? 1 : 0, sA, sB, sC, swap};
+  auto aligned = [](const float* p, int ld, long long stride) { return ((uintptr_t)p & 15) == 0 && ld % 4 == 0 && stride % 4 == 0; };
+  GfArgs G{A, B, C, bias, M, N, K, lda, ldb, ldc, ta ? 1 : 0, tb ? 1 : 0, sA, sB, sC, swap, aligned(A, lda, sA) ? 1 : 0, aligned(B, ldb, sB) ? 1 : 0};
   const dim3 grid(swap ? gn : gm, swap ? gm : gn, (unsigned)batch);
   GD_REQUIRE(grid.y <= 65535, "gemm_f32: both extents too large for one launch");
   hipLaunchKernelGGL(k_gemm_f32, grid, dim3(256), 0, st, G);
