@@ -498,14 +498,23 @@ def sparse_decoder(model_cfg, deblocks, conv_out, hidden, pillar_cell, cell2pill
     dense = None
     if want_dense:
         with torch.no_grad():
-            if y2.shape[0] != R:      # tile-compact conv output: expand (only callers that want the reference's dense map)
+            a2 = (bn2.weight * torch.rsqrt(var2 + bn2.eps)).float().contiguous()
+            b2 = (bn2.bias - a2 * mean2).float().contiguous()
+            if y2.shape[0] != R and y2.dtype == torch.bfloat16 and y2.shape[1] % 8 == 0:
+                # tile-compact conv output -> the reference's dense map in one pass (expand + BatchNorm affine + ReLU)
                 dt = tiles[0]
                 C2 = y2.shape[1]
-                ybg = DecoderHead.last_ybg
-                yd = torch.empty(R, C2, dtype=y2.dtype, device=y2.device)
-                L.call("gdmae_tiles_to_dense", L.ptr(y2), L.ptr(dt.tile_slot), L.ptr(ybg), B, Y, X, C2, y2.element_size(), L.ptr(yd),
-                       L.stream())
-                y2 = yd
-            a2 = bn2.weight * torch.rsqrt(var2 + bn2.eps)
-            dense = torch.relu(y2.float() * a2 + (bn2.bias - a2 * mean2)).view(B, Y, X, -1).permute(0, 3, 1, 2)
+                dmap = torch.empty(R, C2, dtype=torch.float32, device=y2.device)
+                L.call("gdmae_tiles_to_dense_affine_relu", L.ptr(y2), L.ptr(dt.tile_slot), L.ptr(DecoderHead.last_ybg), B, Y, X, C2,
+                       L.ptr(a2), L.ptr(b2), L.ptr(dmap), L.stream())
+                dense = dmap.view(B, Y, X, -1).permute(0, 3, 1, 2)
+            else:
+                if y2.shape[0] != R:
+                    dt = tiles[0]
+                    C2 = y2.shape[1]
+                    yd = torch.empty(R, C2, dtype=y2.dtype, device=y2.device)
+                    L.call("gdmae_tiles_to_dense", L.ptr(y2), L.ptr(dt.tile_slot), L.ptr(DecoderHead.last_ybg), B, Y, X, C2, y2.element_size(),
+                           L.ptr(yd), L.stream())
+                    y2 = yd
+                dense = torch.relu(y2.float() * a2 + b2).view(B, Y, X, -1).permute(0, 3, 1, 2)
     return out, dense

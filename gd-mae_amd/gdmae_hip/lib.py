@@ -76,6 +76,7 @@ SIGNATURES = {
                                      _P, _P]),
     "gdmae_tiles_gather_rows": (_I, [_P, _P, _P, _P, _L, _I, _I, _I, _I, _P, _P]),
     "gdmae_tiles_to_dense": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
+    "gdmae_tiles_to_dense_affine_relu": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P]),
     "gdmae_rows_bwd": (_I, [_P, _I, _P, _L, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P, _I, _P]),
     "gdmae_segment_max_affine": (_I, [_P, _I, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
     "gdmae_segmax_bwd_stats": (_I, [_P, _I, _P, _P, _P, _L, _I, _P, _P, _P, _P, _P]),

@@ -280,6 +280,10 @@ int gdmae_tiles_gather_rows(const void* Yc, const int* tile_slot, const void* yb
                             int C, int elem_bytes, void* out, void* stream);
 int gdmae_tiles_to_dense(const void* Yc, const int* tile_slot, const void* ybg, int B, int H, int W, int C, int elem_bytes,
                          void* out, void* stream);
+/* The reference's dense spatial_features (spt_backbone_mae.py:130-138) from the tile-compact bf16 conv output in one pass:
+ * out (B*H*W, C) fp32 = relu(a[c] * y + b[c]) (folded BatchNorm2d), y from the active tiles or the border-class constants. */
+int gdmae_tiles_to_dense_affine_relu(const void* Yc, const int* tile_slot, const void* ybg, int B, int H, int W, int C, const float* a,
+                                     const float* b, float* out, void* stream);
 
 /* The three row kernels above also serve BatchNorm1d + ReLU of the DynVFE point MLP (site = NULL: identity rows,
  * Z/dZ = a plain (n, C) matrix with z_row_elems = C, col0 = 0).  Fused DynVFE tail (dyn_vfe.py:107-109):
