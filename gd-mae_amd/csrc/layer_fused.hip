@@ -27,6 +27,11 @@
 #ifndef TL_MINW
 #define TL_MINW 4
 #endif
+// TL_HALVES = 2: one workgroup = two independent 8-wavefront row tiles that share barriers (and thereby the timing of their weight
+// fragment loads: the second request for a fragment finds the line in the CU's L1); same wavefronts per CU as two workgroups
+#ifndef TL_HALVES
+#define TL_HALVES 1
+#endif
 
 namespace {
 
@@ -134,16 +139,19 @@ struct LfArgs {
 };
 
 template <int D>
-__global__ __launch_bounds__(512, TL_MINW) void k_layer_fwd(LfArgs A) {
+__global__ __launch_bounds__(512 * TL_HALVES, TL_MINW) void k_layer_fwd(LfArgs A) {
   constexpr int FF = 2 * D;
   using R = TlRows<D>;
   constexpr int ROWS = R::ROWS, LPR = R::LPR, LRPP = R::LRPP, LPASS = R::LPASS;
   constexpr int XP = D * 2 + 16, HP = FF * 2 + 16;
-  extern __shared__ __align__(16) unsigned char lds[];
+  extern __shared__ __align__(16) unsigned char lds_all[];
+  const int tile_in_wg = threadIdx.x >> 9;           // TL_HALVES row tiles per workgroup, 512 threads each
+  unsigned char* const lds = lds_all + tile_in_wg * (ROWS * XP + ROWS * HP);
   unsigned char* const xl = lds;                     // o tile -> a (staging) -> x1 tile -> f (staging)
   unsigned char* const hl = lds + ROWS * XP;         // h (staging) -> gelu(h) tile
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const long long row0 = (long long)blockIdx.x * ROWS;
+  const int tid = threadIdx.x & 511, lane = tid & 63, wv = tid >> 6;
+  const long long tile_id = (long long)blockIdx.x * TL_HALVES + tile_in_wg;
+  const long long row0 = tile_id * ROWS;
   const int lc0 = 4 * (tid % LPR), lr = tid / LPR;
 
   TlProd<D, D, ROWS> pa;
@@ -288,17 +296,20 @@ struct LbArgs {
 };
 
 template <int D>
-__global__ __launch_bounds__(512, TL_MINW) void k_layer_bwd_ffn(LbArgs A) {
+__global__ __launch_bounds__(512 * TL_HALVES, TL_MINW) void k_layer_bwd_ffn(LbArgs A) {
   constexpr int FF = 2 * D;
   using R = TlRows<D>;
   constexpr int ROWS = R::ROWS, LPR = R::LPR, LRPP = R::LRPP, LPASS = R::LPASS;
   constexpr int XP = D * 2 + 16, HP = FF * 2 + 16;
   static_assert(LRPP * 3 * D * 4 <= ROWS * HP, "partial-row reduction fits the hidden tile");
-  extern __shared__ __align__(16) unsigned char lds[];
+  extern __shared__ __align__(16) unsigned char lds_all[];
+  const int tile_in_wg = threadIdx.x >> 9;
+  unsigned char* const lds = lds_all + tile_in_wg * (ROWS * XP + ROWS * HP);
   unsigned char* const gl = lds;                     // df tile -> dx1 (staging) -> da tile -> do (staging)
   unsigned char* const hl = lds + ROWS * XP;         // dg (staging) -> dh tile -> reduction scratch
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const long long row0 = (long long)blockIdx.x * ROWS;
+  const int tid = threadIdx.x & 511, lane = tid & 63, wv = tid >> 6;
+  const long long tile_id = (long long)blockIdx.x * TL_HALVES + tile_in_wg;
+  const long long row0 = tile_id * ROWS;
   const int lc0 = 4 * (tid % LPR), lr = tid / LPR;
 
   TlProd<D, FF, ROWS> pa;
@@ -385,7 +396,7 @@ __global__ __launch_bounds__(512, TL_MINW) void k_layer_bwd_ffn(LbArgs A) {
       *(uint2*)(gl + rl * XP + lc0 * 2) = q;
       if (live) *(uint2*)(A.da + row * D + lc0) = q;
     }
-    L.finish(reinterpret_cast<float*>(hl), A.part + (long long)blockIdx.x * 3 * D, tid);   // its barrier also publishes the da tile
+    L.finish(reinterpret_cast<float*>(hl), A.part + tile_id * 3 * D, tid);   // its barrier also publishes the da tile
   }
   // ---- do = da Wo
   {
@@ -429,14 +440,17 @@ struct LiArgs {
 };
 
 template <int D, bool LN>
-__global__ __launch_bounds__(512, TL_MINW) void k_layer_bwd_in(LiArgs A) {
+__global__ __launch_bounds__(512 * TL_HALVES, TL_MINW) void k_layer_bwd_in(LiArgs A) {
   using R = TlRows<D>;
   constexpr int ROWS = R::ROWS, LPR = R::LPR, LRPP = R::LRPP, LPASS = R::LPASS;
   constexpr int KD = 3 * D, XP = KD * 2 + 16, SP = D * 2 + 16;
   static_assert(LRPP * 3 * D * 4 + ROWS * SP <= ROWS * XP, "staging tile + reduction scratch fit the operand tile");
-  extern __shared__ __align__(16) unsigned char lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const long long row0 = (long long)blockIdx.x * ROWS;
+  extern __shared__ __align__(16) unsigned char lds_all[];
+  const int tile_in_wg = threadIdx.x >> 9;
+  unsigned char* const lds = lds_all + tile_in_wg * (ROWS * XP);
+  const int tid = threadIdx.x & 511, lane = tid & 63, wv = tid >> 6;
+  const long long tile_id = (long long)blockIdx.x * TL_HALVES + tile_in_wg;
+  const long long row0 = tile_id * ROWS;
   const int lc0 = 4 * (tid % LPR), lr = tid / LPR;
 
   TlProd<KD, D, ROWS, 2 * D / 16> pa;
@@ -484,7 +498,7 @@ __global__ __launch_bounds__(512, TL_MINW) void k_layer_bwd_in(LiArgs A) {
       L.row(d, live, xa_pf[p], xb_pf[p], st_pf[p], g, o);
       if (live) *(uint2*)(A.dout + row * D + lc0) = tl_pack4(o);
     }
-    L.finish(reinterpret_cast<float*>(lds + ROWS * SP), A.part + (long long)blockIdx.x * 3 * D, tid);
+    L.finish(reinterpret_cast<float*>(lds + ROWS * SP), A.part + tile_id * 3 * D, tid);
   } else {
 #pragma unroll
     for (int p = 0; p < LPASS; ++p) {
@@ -595,7 +609,7 @@ int gd_layer_fused_fwd(hipStream_t st, int d, const void* o, const void* x, cons
   A.a = (unsigned short*)a; A.x1 = (unsigned short*)x1; A.h = (unsigned short*)h; A.f = (unsigned short*)f; A.st1 = st1; A.st2 = st2;
   A.y = y; A.y_bf = (unsigned short*)y_bf; A.ypos_bf = (unsigned short*)ypos_bf; A.pos_table = pos_table; A.tok_pos = tok_pos;
   const int rows = gd_layer_fused_rows(d), ff = 2 * d;
-  const int lds = rows * (d * 2 + 16) + rows * (ff * 2 + 16);
+  const int lds = TL_HALVES * (rows * (d * 2 + 16) + rows * (ff * 2 + 16));
   // bf16 rows: o, x in; a, x1, h, f, y (or x + y) out; three weight images.  Side: fp32 y at the stage boundary, the y + pos copy,
   // the stage input re-read for the block residual, statistics rows, position ids
   GdTimed timed(GD_T_TOK_GEMM, st,
@@ -605,10 +619,10 @@ int gd_layer_fused_fwd(hipStream_t st, int d, const void* o, const void* x, cons
   static bool once[2] = {false, false};
   if (d == 128) {
     if (!once[0]) { if (int rc = set_lds(k_layer_fwd<128>, lds)) return rc; once[0] = true; }
-    hipLaunchKernelGGL(k_layer_fwd<128>, dim3((unsigned)(n_pad / rows)), dim3(512), lds, st, A);
+    hipLaunchKernelGGL(k_layer_fwd<128>, dim3((unsigned)(n_pad / (rows * TL_HALVES))), dim3(512 * TL_HALVES), lds, st, A);
   } else if (d == 256) {
     if (!once[1]) { if (int rc = set_lds(k_layer_fwd<256>, lds)) return rc; once[1] = true; }
-    hipLaunchKernelGGL(k_layer_fwd<256>, dim3((unsigned)(n_pad / rows)), dim3(512), lds, st, A);
+    hipLaunchKernelGGL(k_layer_fwd<256>, dim3((unsigned)(n_pad / (rows * TL_HALVES))), dim3(512 * TL_HALVES), lds, st, A);
   } else {
     GD_REQUIRE(false, "layer_fused_fwd: d must be 128 or 256");
   }
@@ -624,7 +638,7 @@ int gd_layer_fused_bwd_ffn(hipStream_t st, int d, const void* df, const void* h,
   A.st1 = st1; A.g1 = g1; A.W2t = (const uint4*)W2t; A.W1t = (const uint4*)W1t; A.Wot = (const uint4*)Wot; A.n = n; A.n_pad = n_pad;
   A.dh = (unsigned short*)dh; A.gact = (unsigned short*)gact; A.da = (unsigned short*)da; A.d_o = (unsigned short*)d_o; A.part = part;
   const int rows = gd_layer_fused_rows(d), ff = 2 * d;
-  const int lds = rows * (d * 2 + 16) + rows * (ff * 2 + 16);
+  const int lds = TL_HALVES * (rows * (d * 2 + 16) + rows * (ff * 2 + 16));
   // bf16 rows: df, h, x, a in; dh, gelu(h), da, do out; three weight images.  Side: statistics rows, partial rows
   GdTimed timed(GD_T_TOK_GEMM, st,
                 2.0 * n_pad * d + 2.0 * n_pad * ff + (double)n * d * (2 + 2 + 2) + 2.0 * n_pad * d + 4.0 * n_pad * ff + 2.0 * (d * d + 2.0 * d * ff),
@@ -632,10 +646,10 @@ int gd_layer_fused_bwd_ffn(hipStream_t st, int d, const void* df, const void* h,
   static bool once[2] = {false, false};
   if (d == 128) {
     if (!once[0]) { if (int rc = set_lds(k_layer_bwd_ffn<128>, lds)) return rc; once[0] = true; }
-    hipLaunchKernelGGL(k_layer_bwd_ffn<128>, dim3((unsigned)(n_pad / rows)), dim3(512), lds, st, A);
+    hipLaunchKernelGGL(k_layer_bwd_ffn<128>, dim3((unsigned)(n_pad / (rows * TL_HALVES))), dim3(512 * TL_HALVES), lds, st, A);
   } else if (d == 256) {
     if (!once[1]) { if (int rc = set_lds(k_layer_bwd_ffn<256>, lds)) return rc; once[1] = true; }
-    hipLaunchKernelGGL(k_layer_bwd_ffn<256>, dim3((unsigned)(n_pad / rows)), dim3(512), lds, st, A);
+    hipLaunchKernelGGL(k_layer_bwd_ffn<256>, dim3((unsigned)(n_pad / (rows * TL_HALVES))), dim3(512 * TL_HALVES), lds, st, A);
   } else {
     GD_REQUIRE(false, "layer_fused_bwd_ffn: d must be 128 or 256");
   }
@@ -654,7 +668,7 @@ int gd_layer_fused_bwd_in(hipStream_t st, int d, const void* dqk, const void* dv
   A.st = stats; A.gamma = gamma; A.dout = (unsigned short*)dout; A.part = part; A.dx = dx;
   const bool ln = dx == nullptr && dx_bf == nullptr;
   const int rows = gd_layer_fused_rows(d);
-  const int lds = rows * (3 * d * 2 + 16);
+  const int lds = TL_HALVES * rows * (3 * d * 2 + 16);
   // bf16 rows: dqk, dv, da in (+ both LayerNorm addends in, df out | the skip-path gradient in, dx out); two weight images.  Side:
   // statistics + partial rows, or the fp32 dx rows
   GdTimed timed(GD_T_TOK_GEMM, st, 2.0 * n_pad * 3 * d + (double)n * d * (2 + (ln ? 2 + 2 + 2 : (dx_bf ? 2 + 2 : 0))) + 2.0 * 3 * d * d,
@@ -663,7 +677,7 @@ int gd_layer_fused_bwd_in(hipStream_t st, int d, const void* dqk, const void* dv
 #define LI_CASE(D_, LN_, idx)                                                                                   \
   {                                                                                                             \
     if (!once[idx]) { if (int rc = set_lds(k_layer_bwd_in<D_, LN_>, lds)) return rc; once[idx] = true; }        \
-    hipLaunchKernelGGL((k_layer_bwd_in<D_, LN_>), dim3((unsigned)(n_pad / rows)), dim3(512), lds, st, A);       \
+    hipLaunchKernelGGL((k_layer_bwd_in<D_, LN_>), dim3((unsigned)(n_pad / (rows * TL_HALVES))), dim3(512 * TL_HALVES), lds, st, A);       \
   }
   if (d == 128 && ln) LI_CASE(128, true, 0)
   else if (d == 128) LI_CASE(128, false, 1)
