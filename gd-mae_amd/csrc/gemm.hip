@@ -62,6 +62,7 @@ hipblasLtHandle_t g_lt = nullptr;
 std::map<GemmKey, GemmPlan> g_plans;
 long long g_gemm_calls = 0, g_gemm_tuned = 0;     // gdmae_gemm_stats: library GEMM calls / plans created (first use of a shape bucket)
 std::mutex g_lt_mu;
+int g_tune_override = -1;      // gdmae_gemm_tuning
 
 #define LT_CHECK(x)                                                         \
   do {                                                                      \
@@ -146,7 +147,8 @@ int gd_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const void* A
     // GDMAE_GEMM_TUNE: 0 = heuristic's first choice, 1 (default) = time its 16 best, 2 = time EVERY algorithm of the
     // library that supports the problem (hipblaslt_ext::getAllAlgos + matmulIsAlgoSupported; ~50 ms per shape, once -
     // measured on this workload: no better than 1, the 16 best already contain the fastest kernels).
-    static const int tune = getenv("GDMAE_GEMM_TUNE") ? atoi(getenv("GDMAE_GEMM_TUNE")) : 1;
+    static const int tune_env = getenv("GDMAE_GEMM_TUNE") ? atoi(getenv("GDMAE_GEMM_TUNE")) : 1;
+    const int tune = g_tune_override >= 0 ? g_tune_override : tune_env;
     constexpr int kMaxAlgo = 16;
     std::vector<hipblasLtMatmulHeuristicResult_t> cand(kMaxAlgo);
     int found = 0;
@@ -275,6 +277,23 @@ extern "C" size_t gdmae_gemm_workspace_bytes(void) { return GD_LT_WORKSPACE; }
 
 // calls[0] = library GEMM calls so far, calls[1] = algorithm plans created so far (each = first use of a shape bucket: candidate
 // timing with stream synchronisation): a training loop is in its steady state once calls[1] stops growing
+// mode 0 / 1 / 2 as GDMAE_GEMM_TUNE (0: the heuristic's first algorithm - no timing, i.e. the same algorithm for the same shape in every
+// process and test order; 1: time the 16 best; 2: time all), -1: back to the environment's choice.  Drops every cached plan, so the
+// next use of a shape selects again.
+extern "C" int gdmae_gemm_tuning(int mode) {
+  GD_REQUIRE(mode >= -1 && mode <= 2, "gemm_tuning: -1, 0, 1 or 2");
+  std::lock_guard<std::mutex> lock(g_lt_mu);
+  g_tune_override = mode;
+  for (auto& kv : g_plans) {
+    if (kv.second.desc) hipblasLtMatmulDescDestroy(kv.second.desc);
+    if (kv.second.la) hipblasLtMatrixLayoutDestroy(kv.second.la);
+    if (kv.second.lb) hipblasLtMatrixLayoutDestroy(kv.second.lb);
+    if (kv.second.lc) hipblasLtMatrixLayoutDestroy(kv.second.lc);
+  }
+  g_plans.clear();
+  return 0;
+}
+
 extern "C" int gdmae_gemm_stats(long long* calls) {
   calls[0] = g_gemm_calls;
   calls[1] = g_gemm_tuned;

@@ -103,6 +103,7 @@ SIGNATURES = {
     "gdmae_sum_partials_gated": (_I, [_P, _L, _F, _P, _P, _F, _P]),
     "gdmae_gemm_workspace_bytes": (_Z, []),
     "gdmae_gemm_stats": (_I, [_P]),
+    "gdmae_gemm_tuning": (_I, [_I]),
     "gdmae_gemm": (_I, [_P, _P, _P, _L, _L, _L, _I, _I, _I, _I, _P, _P, _P]),
     "gdmae_gemm_tn_splitk_workspace_bytes": (_Z, [_L, _I, _I]),
     "gdmae_gemm_tn_splitk": (_I, [_P, _P, _P, _L, _I, _I, _I, _I, _P, _P]),

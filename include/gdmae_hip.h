@@ -393,6 +393,10 @@ int gdmae_add3_to(const float* a, const void* b, int b_bf16, const void* c, int 
 /* calls[0] = library GEMM calls so far, calls[1] = algorithm plans created so far (first use of a shape bucket = candidate timing
  * with stream synchronisation): a loop has reached its steady state once calls[1] stops growing. */
 int gdmae_gemm_stats(long long* calls);
+/* Algorithm selection of the hipBLASLt front end (bf16 operands; the op-by-op reference paths of the tests): 0 = the heuristic's first
+ * algorithm (deterministic across processes and call orders), 1 = time the 16 best at the first use of a shape (default), 2 = time
+ * every supporting algorithm, -1 = the GDMAE_GEMM_TUNE environment default.  Clears the plan cache. */
+int gdmae_gemm_tuning(int mode);
 size_t gdmae_gemm_workspace_bytes(void);
 int gdmae_gemm(const void* A, const void* B, void* C, long long M, long long N, long long K, int trans_a, int trans_b,
                int ab_bf16, int c_f32, const void* bias, void* workspace, void* stream);
