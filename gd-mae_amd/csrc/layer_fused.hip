@@ -39,7 +39,7 @@ template <int D>
 struct TlRows {
   static constexpr int ROWS = D >= 256 ? TL_ROWS256 : 64;
   static constexpr int LPR = D / 4;                 // lanes per row in the LayerNorm passes (4 consecutive columns per lane)
-  static constexpr int LRPP = 512 / LPR;            // rows per pass
+  static constexpr int LRPP = TL_THREADS / LPR;     // rows per pass
   static constexpr int LPASS = ROWS / LRPP;
 };
 
@@ -107,7 +107,7 @@ struct TlLnBwd {
       red[(r * 3 + 2) * D + c0 + k] = dsx[k];
     }
     __syncthreads();
-    for (int c = tid; c < 3 * D; c += 512) {
+    for (int c = tid; c < 3 * D; c += TL_THREADS) {
       float a = 0.f;
 #pragma unroll
       for (int q = 0; q < LRPP; ++q) a += red[q * 3 * D + c];
@@ -139,17 +139,17 @@ struct LfArgs {
 };
 
 template <int D>
-__global__ __launch_bounds__(512 * TL_HALVES, TL_MINW) void k_layer_fwd(LfArgs A) {
+__global__ __launch_bounds__(TL_THREADS * TL_HALVES, TL_MINW) void k_layer_fwd(LfArgs A) {
   constexpr int FF = 2 * D;
   using R = TlRows<D>;
   constexpr int ROWS = R::ROWS, LPR = R::LPR, LRPP = R::LRPP, LPASS = R::LPASS;
   constexpr int XP = D * 2 + 16, HP = FF * 2 + 16;
   extern __shared__ __align__(16) unsigned char lds_all[];
-  const int tile_in_wg = threadIdx.x >> 9;           // TL_HALVES row tiles per workgroup, 512 threads each
+  const int tile_in_wg = threadIdx.x / TL_THREADS;   // TL_HALVES row tiles per workgroup, TL_THREADS threads each
   unsigned char* const lds = lds_all + tile_in_wg * (ROWS * XP + ROWS * HP);
   unsigned char* const xl = lds;                     // o tile -> a (staging) -> x1 tile -> f (staging)
   unsigned char* const hl = lds + ROWS * XP;         // h (staging) -> gelu(h) tile
-  const int tid = threadIdx.x & 511, lane = tid & 63, wv = tid >> 6;
+  const int tid = threadIdx.x % TL_THREADS, lane = tid & 63, wv = tid >> 6;
   const long long tile_id = (long long)blockIdx.x * TL_HALVES + tile_in_wg;
   const long long row0 = tile_id * ROWS;
   const int lc0 = 4 * (tid % LPR), lr = tid / LPR;
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(512 * TL_HALVES, TL_MINW) void k_layer_fwd(LfArgs A
   __syncthreads();
   // ---- a = o Wo^T + bo
   {
-    f32x16 acc[1][TlShape<D, D, ROWS>::NPW];
+    f32x16 acc[TlShape<D, D, ROWS>::MPW][TlShape<D, D, ROWS>::NPW];
     tl_zero(acc);
     pa.run(xl, XP, wv, lane, acc);
     __syncthreads();                                 // every wavefront is done with the o tile
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(512 * TL_HALVES, TL_MINW) void k_layer_fwd(LfArgs A
   __syncthreads();
   // ---- h leaves for HBM (the backward differentiates the GELU at it), gelu(h) replaces it in LDS
   {
-    constexpr int CPR = FF / 8, RPP = 512 / CPR;
+    constexpr int CPR = FF / 8, RPP = TL_THREADS / CPR;
     const int c = tid % CPR, r = tid / CPR;
 #pragma unroll
     for (int p = 0; p < ROWS / RPP; ++p) {
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(512 * TL_HALVES, TL_MINW) void k_layer_fwd(LfArgs A
   __syncthreads();
   // ---- f = gelu(h) W2^T + b2  (staged over the x1 tile: nobody reads it any more)
   {
-    f32x16 acc[1][TlShape<FF, D, ROWS>::NPW];
+    f32x16 acc[TlShape<FF, D, ROWS>::MPW][TlShape<FF, D, ROWS>::NPW];
     tl_zero(acc);
     pc.run(hl, HP, wv, lane, acc);
     tl_stage<FF, D, ROWS>(acc, A.b2, xl, XP, wv, lane);
@@ -296,18 +296,18 @@ struct LbArgs {
 };
 
 template <int D>
-__global__ __launch_bounds__(512 * TL_HALVES, TL_MINW) void k_layer_bwd_ffn(LbArgs A) {
+__global__ __launch_bounds__(TL_THREADS * TL_HALVES, TL_MINW) void k_layer_bwd_ffn(LbArgs A) {
   constexpr int FF = 2 * D;
   using R = TlRows<D>;
   constexpr int ROWS = R::ROWS, LPR = R::LPR, LRPP = R::LRPP, LPASS = R::LPASS;
   constexpr int XP = D * 2 + 16, HP = FF * 2 + 16;
   static_assert(LRPP * 3 * D * 4 <= ROWS * HP, "partial-row reduction fits the hidden tile");
   extern __shared__ __align__(16) unsigned char lds_all[];
-  const int tile_in_wg = threadIdx.x >> 9;
+  const int tile_in_wg = threadIdx.x / TL_THREADS;
   unsigned char* const lds = lds_all + tile_in_wg * (ROWS * XP + ROWS * HP);
   unsigned char* const gl = lds;                     // df tile -> dx1 (staging) -> da tile -> do (staging)
   unsigned char* const hl = lds + ROWS * XP;         // dg (staging) -> dh tile -> reduction scratch
-  const int tid = threadIdx.x & 511, lane = tid & 63, wv = tid >> 6;
+  const int tid = threadIdx.x % TL_THREADS, lane = tid & 63, wv = tid >> 6;
   const long long tile_id = (long long)blockIdx.x * TL_HALVES + tile_in_wg;
   const long long row0 = tile_id * ROWS;
   const int lc0 = 4 * (tid % LPR), lr = tid / LPR;
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(512 * TL_HALVES, TL_MINW) void k_layer_bwd_ffn(LbAr
   TlProd<D, FF, ROWS> pa;
   pa.prefetch(A.W2t, nullptr, wv, lane);
   // operands of the row passes that do not depend on the products: requested now
-  constexpr int HCPR = FF / 8, HRPP = 512 / HCPR, HPASS = ROWS / HRPP;
+  constexpr int HCPR = FF / 8, HRPP = TL_THREADS / HCPR, HPASS = ROWS / HRPP;
   const int hc = tid % HCPR, hr = tid / HCPR;
   uint4 h_pf[HPASS];
 #pragma unroll
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(512 * TL_HALVES, TL_MINW) void k_layer_bwd_ffn(LbAr
   __syncthreads();
   // ---- dx1 = dh W1 (staged over the df tile: its rows are in registers)
   {
-    f32x16 acc[1][TlShape<FF, D, ROWS>::NPW];
+    f32x16 acc[TlShape<FF, D, ROWS>::MPW][TlShape<FF, D, ROWS>::NPW];
     tl_zero(acc);
     pb.run(hl, HP, wv, lane, acc);
     tl_stage<FF, D, ROWS>(acc, nullptr, gl, XP, wv, lane);
@@ -400,7 +400,7 @@ __global__ __launch_bounds__(512 * TL_HALVES, TL_MINW) void k_layer_bwd_ffn(LbAr
   }
   // ---- do = da Wo
   {
-    f32x16 acc[1][TlShape<D, D, ROWS>::NPW];
+    f32x16 acc[TlShape<D, D, ROWS>::MPW][TlShape<D, D, ROWS>::NPW];
     tl_zero(acc);
     pc.run(gl, XP, wv, lane, acc);
     __syncthreads();                                 // every wavefront is done with the da tile
@@ -408,7 +408,7 @@ __global__ __launch_bounds__(512 * TL_HALVES, TL_MINW) void k_layer_bwd_ffn(LbAr
   }
   __syncthreads();
   {
-    constexpr int CPR = D / 8, RPP = 512 / CPR;
+    constexpr int CPR = D / 8, RPP = TL_THREADS / CPR;
     const int c = tid % CPR, r = tid / CPR;
 #pragma unroll
     for (int p = 0; p < (ROWS + RPP - 1) / RPP; ++p) {
@@ -440,15 +440,15 @@ struct LiArgs {
 };
 
 template <int D, bool LN>
-__global__ __launch_bounds__(512 * TL_HALVES, TL_MINW) void k_layer_bwd_in(LiArgs A) {
+__global__ __launch_bounds__(TL_THREADS * TL_HALVES, TL_MINW) void k_layer_bwd_in(LiArgs A) {
   using R = TlRows<D>;
   constexpr int ROWS = R::ROWS, LPR = R::LPR, LRPP = R::LRPP, LPASS = R::LPASS;
   constexpr int KD = 3 * D, XP = KD * 2 + 16, SP = D * 2 + 16;
   static_assert(LRPP * 3 * D * 4 + ROWS * SP <= ROWS * XP, "staging tile + reduction scratch fit the operand tile");
   extern __shared__ __align__(16) unsigned char lds_all[];
-  const int tile_in_wg = threadIdx.x >> 9;
+  const int tile_in_wg = threadIdx.x / TL_THREADS;
   unsigned char* const lds = lds_all + tile_in_wg * (ROWS * XP);
-  const int tid = threadIdx.x & 511, lane = tid & 63, wv = tid >> 6;
+  const int tid = threadIdx.x % TL_THREADS, lane = tid & 63, wv = tid >> 6;
   const long long tile_id = (long long)blockIdx.x * TL_HALVES + tile_in_wg;
   const long long row0 = tile_id * ROWS;
   const int lc0 = 4 * (tid % LPR), lr = tid / LPR;
@@ -472,7 +472,7 @@ __global__ __launch_bounds__(512 * TL_HALVES, TL_MINW) void k_layer_bwd_in(LiArg
   tl_load_tile<D, ROWS>(A.dv, row0, lds, XP, 4 * D, tid);
   __syncthreads();
   {
-    f32x16 acc[1][TlShape<KD, D, ROWS>::NPW];
+    f32x16 acc[TlShape<KD, D, ROWS>::MPW][TlShape<KD, D, ROWS>::NPW];
     tl_zero(acc);
     pa.run(lds, XP, wv, lane, acc);
     __syncthreads();
@@ -533,7 +533,7 @@ struct LtArgs {
   float* part;
 };
 template <int D>
-__global__ __launch_bounds__(512) void k_ln2_bwd_top(LtArgs A) {
+__global__ __launch_bounds__(TL_THREADS) void k_ln2_bwd_top(LtArgs A) {
   using R = TlRows<D>;
   constexpr int ROWS = R::ROWS, LPR = R::LPR, LRPP = R::LRPP, LPASS = R::LPASS;
   __shared__ float red[LRPP * 3 * D];
@@ -619,10 +619,10 @@ int gd_layer_fused_fwd(hipStream_t st, int d, const void* o, const void* x, cons
   static bool once[2] = {false, false};
   if (d == 128) {
     if (!once[0]) { if (int rc = set_lds(k_layer_fwd<128>, lds)) return rc; once[0] = true; }
-    hipLaunchKernelGGL(k_layer_fwd<128>, dim3((unsigned)(n_pad / (rows * TL_HALVES))), dim3(512 * TL_HALVES), lds, st, A);
+    hipLaunchKernelGGL(k_layer_fwd<128>, dim3((unsigned)(n_pad / (rows * TL_HALVES))), dim3(TL_THREADS * TL_HALVES), lds, st, A);
   } else if (d == 256) {
     if (!once[1]) { if (int rc = set_lds(k_layer_fwd<256>, lds)) return rc; once[1] = true; }
-    hipLaunchKernelGGL(k_layer_fwd<256>, dim3((unsigned)(n_pad / (rows * TL_HALVES))), dim3(512 * TL_HALVES), lds, st, A);
+    hipLaunchKernelGGL(k_layer_fwd<256>, dim3((unsigned)(n_pad / (rows * TL_HALVES))), dim3(TL_THREADS * TL_HALVES), lds, st, A);
   } else {
     GD_REQUIRE(false, "layer_fused_fwd: d must be 128 or 256");
   }
@@ -646,10 +646,10 @@ int gd_layer_fused_bwd_ffn(hipStream_t st, int d, const void* df, const void* h,
   static bool once[2] = {false, false};
   if (d == 128) {
     if (!once[0]) { if (int rc = set_lds(k_layer_bwd_ffn<128>, lds)) return rc; once[0] = true; }
-    hipLaunchKernelGGL(k_layer_bwd_ffn<128>, dim3((unsigned)(n_pad / (rows * TL_HALVES))), dim3(512 * TL_HALVES), lds, st, A);
+    hipLaunchKernelGGL(k_layer_bwd_ffn<128>, dim3((unsigned)(n_pad / (rows * TL_HALVES))), dim3(TL_THREADS * TL_HALVES), lds, st, A);
   } else if (d == 256) {
     if (!once[1]) { if (int rc = set_lds(k_layer_bwd_ffn<256>, lds)) return rc; once[1] = true; }
-    hipLaunchKernelGGL(k_layer_bwd_ffn<256>, dim3((unsigned)(n_pad / (rows * TL_HALVES))), dim3(512 * TL_HALVES), lds, st, A);
+    hipLaunchKernelGGL(k_layer_bwd_ffn<256>, dim3((unsigned)(n_pad / (rows * TL_HALVES))), dim3(TL_THREADS * TL_HALVES), lds, st, A);
   } else {
     GD_REQUIRE(false, "layer_fused_bwd_ffn: d must be 128 or 256");
   }
@@ -677,7 +677,7 @@ int gd_layer_fused_bwd_in(hipStream_t st, int d, const void* dqk, const void* dv
 #define LI_CASE(D_, LN_, idx)                                                                                   \
   {                                                                                                             \
     if (!once[idx]) { if (int rc = set_lds(k_layer_bwd_in<D_, LN_>, lds)) return rc; once[idx] = true; }        \
-    hipLaunchKernelGGL((k_layer_bwd_in<D_, LN_>), dim3((unsigned)(n_pad / (rows * TL_HALVES))), dim3(512 * TL_HALVES), lds, st, A);       \
+    hipLaunchKernelGGL((k_layer_bwd_in<D_, LN_>), dim3((unsigned)(n_pad / (rows * TL_HALVES))), dim3(TL_THREADS * TL_HALVES), lds, st, A);       \
   }
   if (d == 128 && ln) LI_CASE(128, true, 0)
   else if (d == 128) LI_CASE(128, false, 1)
@@ -705,8 +705,8 @@ int gd_layer_fused_ln2_top(hipStream_t st, int d, const float* dy, const void* d
   LtArgs A = {dy, (const unsigned short*)dy_bf, (const unsigned short*)ln_a, (const unsigned short*)ln_b, stats, gamma, n, (unsigned short*)dout, part};
   const int rows = gd_layer_fused_rows(d);
   GdTimed timed(GD_T_TOK_GEMM, st, (double)n * d * ((dy ? 0 : 2) + 2 + 2 + 2), 0.0, (dy ? 4.0 * n * d : 0.0) + 8.0 * n + 12.0 * d * (double)(n_pad / rows));
-  if (d == 128) hipLaunchKernelGGL(k_ln2_bwd_top<128>, dim3((unsigned)(n_pad / rows)), dim3(512), 0, st, A);
-  else if (d == 256) hipLaunchKernelGGL(k_ln2_bwd_top<256>, dim3((unsigned)(n_pad / rows)), dim3(512), 0, st, A);
+  if (d == 128) hipLaunchKernelGGL(k_ln2_bwd_top<128>, dim3((unsigned)(n_pad / rows)), dim3(TL_THREADS), 0, st, A);
+  else if (d == 256) hipLaunchKernelGGL(k_ln2_bwd_top<256>, dim3((unsigned)(n_pad / rows)), dim3(TL_THREADS), 0, st, A);
   else GD_REQUIRE(false, "layer_fused_ln2_top: d must be 128 or 256");
   GD_LAUNCH_CHECK();
   return 0;

@@ -132,21 +132,25 @@ __device__ inline float tg_group_sum(float v) {
 
 // ------------------------------------------------------------------------------------------------
 // Row-tile building blocks shared by the fused layer launches (layer_fused.hip) and the row GEMMs of the decoder (rows_gemm.hip):
-// 512 threads = 8 wavefronts, a tile of ROWS bf16 rows in LDS, weights streamed as MFMA A operands from a packed image.
+// TL_THREADS threads = TL_WAVES wavefronts (512 = 8 by default), a tile of ROWS bf16 rows in LDS, weights streamed as MFMA A operands from a packed image.
 // ------------------------------------------------------------------------------------------------
 #ifndef TL_PF
 #define TL_PF TG_PF      // weight prefetch distance in k-steps (experiment switch, tools/build_variant.sh)
 #endif
+#ifndef TL_WAVES
+#define TL_WAVES TG_WAVES   // wavefronts of a row tile's workgroup (experiment switch: 4 = 256 threads, three workgroups per CU)
+#endif
+#define TL_THREADS (64 * TL_WAVES)
 // ---- one product of a row tile:  acc[j][b] (32 channels x 32 rows, fp32) += W (ND, KD) X^T, X = bf16 rows in LDS ---------------
 template <int KD, int ND, int ROWS>
 struct TlShape {
   static constexpr int KS = KD / 16;                                    // k-steps
   static constexpr int MB = ND / 32;                                    // 32-channel blocks of the output
-  static constexpr int MPW = MB >= TG_WAVES ? MB / TG_WAVES : 1;        // channel blocks per wavefront
-  static constexpr int NPW = MB >= TG_WAVES ? ROWS / 32 : 1;            // 32-row blocks per wavefront
-  static_assert(MB >= TG_WAVES || (MB * (ROWS / 32) == TG_WAVES), "every wavefront needs an output block");
-  __device__ static int mb0(int wv) { return MB >= TG_WAVES ? wv : (wv / (ROWS / 32)); }
-  __device__ static int nb0(int wv) { return MB >= TG_WAVES ? 0 : (wv % (ROWS / 32)); }
+  static constexpr int MPW = MB >= TL_WAVES ? MB / TL_WAVES : 1;        // channel blocks per wavefront
+  static constexpr int NPW = MB >= TL_WAVES ? ROWS / 32 : 1;            // 32-row blocks per wavefront
+  static_assert(MB >= TL_WAVES || (MB * (ROWS / 32) == TL_WAVES), "every wavefront needs an output block");
+  __device__ static int mb0(int wv) { return MB >= TL_WAVES ? wv : (wv / (ROWS / 32)); }
+  __device__ static int nb0(int wv) { return MB >= TL_WAVES ? 0 : (wv % (ROWS / 32)); }
 };
 
 // fragment (ks, j) of a wavefront; the image of a second matrix continues the K dimension after KSPLIT k-steps (the q/k and v
@@ -155,7 +159,7 @@ struct TlShape {
 // column slice of a wider one)
 template <int KD, int ND, int ROWS, int KSPLIT>
 __device__ __forceinline__ uint4 tl_wfrag(const uint4* __restrict__ w0, const uint4* __restrict__ w1, int ks, int j, int mbs) {
-  return ks < KSPLIT ? w0[((size_t)ks * mbs + j * TG_WAVES) * 64] : w1[((size_t)(ks - KSPLIT) * mbs + j * TG_WAVES) * 64];
+  return ks < KSPLIT ? w0[((size_t)ks * mbs + j * TL_WAVES) * 64] : w1[((size_t)(ks - KSPLIT) * mbs + j * TL_WAVES) * 64];
 }
 
 // prefetch distance of a product: TL_PF k-steps, TL_PF1 for products whose wavefronts own ONE channel block (a ring of TL_PF1 + 1
@@ -223,7 +227,7 @@ __device__ __forceinline__ void tl_stage(const f32x16 (&acc)[TlShape<KD, ND, ROW
   using S = TlShape<KD, ND, ROWS>;
 #pragma unroll
   for (int j = 0; j < S::MPW; ++j) {
-    const int cb = (S::mb0(wv) + j * TG_WAVES) * 32 + 4 * (lane >> 5);
+    const int cb = (S::mb0(wv) + j * TL_WAVES) * 32 + 4 * (lane >> 5);
 #pragma unroll
     for (int b = 0; b < S::NPW; ++b) {
       const int row = (S::nb0(wv) + b) * 32 + (lane & 31);
@@ -259,7 +263,7 @@ __device__ __forceinline__ uint2 tl_pack4(const float (&f)[4]) {
 // rows of a bf16 (n_pad, W) matrix -> LDS tile, 16 bytes per thread and access; c_off: first column of the tile (bytes)
 template <int W, int ROWS>
 __device__ __forceinline__ void tl_load_tile(const unsigned short* __restrict__ src, long long row0, unsigned char* dst, int P, int c_off, int tid) {
-  constexpr int CPR = W / 8, RPP = 512 / CPR;
+  constexpr int CPR = W / 8, RPP = TL_THREADS / CPR;
   static_assert(ROWS % RPP == 0 || RPP > ROWS, "tile load");
   const int c = tid % CPR, r = tid / CPR;
 #pragma unroll
