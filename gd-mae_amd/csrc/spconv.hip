@@ -46,17 +46,21 @@ struct SpArgs {
 };
 
 constexpr int kWaves = 8;
-constexpr int kRing = 8;      // weight fragments in flight (ring), prefetch distance 4 k-steps
-constexpr int kPf = 4;
 
-template <int COUT>
+// Rows per workgroup.  The weights are the dominant stream (every workgroup walks all 9 tap images: 1.2 MB at 256 x 256, from L2),
+// so 64 rows instead of round 3's 32 at COUT = 256 halve it (k_spconv forward 244 -> 202 us per step); fp32 rows at 256 x 256 keep
+// 32 (the unconverted rows of a 64-row tile do not fit 128 registers).
+#ifndef SP_ROWS256
+#define SP_ROWS256 64        // experiment switch
+#endif
+template <int CIN, int COUT, bool SRC_F32>
 struct SpRows {
-  static constexpr int value = COUT >= 256 ? 32 : 64;
+  static constexpr int value = COUT >= 256 ? ((SRC_F32 && CIN >= 256) ? 32 : SP_ROWS256) : 64;
 };
 
 template <int CIN, int COUT, bool SRC_F32>
 __global__ __launch_bounds__(512, 2) void k_spconv(SpArgs A) {
-  constexpr int ROWS = SpRows<COUT>::value;
+  constexpr int ROWS = SpRows<CIN, COUT, SRC_F32>::value;
   constexpr int KS = CIN / 16;                     // k-steps per tap
   constexpr int MB = COUT / 32;                    // 32-channel blocks
   constexpr int MPW = MB >= kWaves ? MB / kWaves : 1;
@@ -66,7 +70,7 @@ __global__ __launch_bounds__(512, 2) void k_spconv(SpArgs A) {
   constexpr int CPR = CIN / 8;                     // 16-byte chunks per gathered row
   constexpr int RPP = 512 / CPR;                   // rows per pass of the 512 threads
   constexpr int P = ROWS / RPP;                    // passes per tap
-  static_assert(KS % kRing == 0 && P >= 1 && ROWS % RPP == 0, "unsupported shape");
+  static_assert(P >= 1 && ROWS % RPP == 0, "unsupported shape");
   extern __shared__ __align__(16) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const long long row0 = (long long)blockIdx.x * ROWS;
@@ -74,46 +78,82 @@ __global__ __launch_bounds__(512, 2) void k_spconv(SpArgs A) {
   const int nb0 = MB >= kWaves ? 0 : (wv & 1);
   const uint4* __restrict__ wp = A.Wp + (size_t)mb0 * 64 + lane;        // + (gstep * MB + j * kWaves) * 64
 
-  // ---- weight fragments of the first k-steps
-  SpFrag wr[kRing][MPW];
+  // ---- weight fragments: a ring of ONE WHOLE TAP (KS k-steps).  Step ks of tap t multiplies slot ks and reloads it with the
+  // fragment of tap t + 1 right away.  The load counter retires in order, so waiting for a fragment also waits for every load
+  // issued before it: with a short ring the gather of the next tap's rows (issued at the top of a tap) was drained by the first
+  // fragment requested after it, a few k-steps later; now every fragment a tap consumes was requested BEFORE that tap's gather, and
+  // the gather has the whole tap of MFMAs to land.
+  // (CIN = 256 with 64-row tiles or fp32 rows: half a tap, both: a quarter - the whole one does not fit 128 registers next to the
+  // gathered rows.)
+  constexpr int RING = (KS == 16 && (ROWS == 64 || SRC_F32)) ? ((SRC_F32 && ROWS == 64) ? 4 : 8) : KS;
+  SpFrag wr[RING][MPW];
 #pragma unroll
-  for (int ks = 0; ks < kPf; ++ks)
+  for (int ks = 0; ks < RING; ++ks)
 #pragma unroll
     for (int j = 0; j < MPW; ++j) wr[ks][j].q = wp[((size_t)ks * MB + j * kWaves) * 64];
 
-  // ---- gather machinery: this thread's chunk c of rows gr[p]
+  // ---- gather machinery: this thread's 16-byte chunk gc of rows grow[p].  Every load is unconditional (missing taps and rows past
+  // the end read row 0 / the last rulebook row and are cleared by a mask when the tile is staged): a branch around a load makes the
+  // compiler drain the load counter where the paths join.  The counter is in-order, so the first weight fragment needed after a
+  // gather was issued waits for the gather as well (see the weight ring above).  Rows are fetched one tap ahead; fp32 rows are
+  // converted when they are staged, not when they are loaded.
+  constexpr int GD = 1;                            // gather distance in taps
+  constexpr int RQ = SRC_F32 ? 2 : 1;              // 16-byte registers per gathered chunk
   const int gc = tid % CPR;
-  int idx_cur[P], idx_nxt[P];
-  long long grow[P];
+  long long nrow[P];                               // rulebook row (clamped)
+  unsigned rvalid = 0u;
 #pragma unroll
   for (int p = 0; p < P; ++p) {
-    grow[p] = row0 + p * RPP + tid / CPR;
-    idx_cur[p] = grow[p] < A.n ? A.nbr[grow[p] * 9] : -1;
-    idx_nxt[p] = grow[p] < A.n ? A.nbr[grow[p] * 9 + 1] : -1;
+    const long long g = row0 + p * RPP + tid / CPR;
+    rvalid |= g < A.n ? 1u << p : 0u;
+    nrow[p] = (g < A.n ? g : A.n - 1) * 9;
   }
-  uint4 rq[P];
-  auto fetch = [&](const int (&idx)[P]) {
+  int idx[P];                                      // sources of the next tap to fetch
+  uint4 rq[1][P][RQ];
+  unsigned keep[1] = {0u};                         // bit p: the chunk holds a real row
+  auto load_idx = [&](int tap) {
+#pragma unroll
+    for (int p = 0; p < P; ++p) idx[p] = A.nbr[nrow[p] + tap];
+  };
+  auto fetch = [&](int slot) {
+    unsigned k = 0u;
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-      uint4 q = make_uint4(0u, 0u, 0u, 0u);
-      if (idx[p] >= 0) {
-        if (SRC_F32) {
-          const float* s = (const float*)A.X + (long long)idx[p] * CIN + gc * 8;
-          const float4 a = *reinterpret_cast<const float4*>(s), b = *reinterpret_cast<const float4*>(s + 4);
-          q.x = sp_pack2(a.x, a.y); q.y = sp_pack2(a.z, a.w); q.z = sp_pack2(b.x, b.y); q.w = sp_pack2(b.z, b.w);
-        } else {
-          q = *reinterpret_cast<const uint4*>((const unsigned short*)A.X + (long long)idx[p] * CIN + gc * 8);
-        }
+      asm volatile("" : "+v"(idx[p]));             // the index is looked at HERE, not where it was loaded (a compare hoisted to the
+                                                   // load would wait for it a tap early)
+      const bool ok = idx[p] >= 0 && ((rvalid >> p) & 1u);
+      const long long j = ok ? idx[p] : 0;
+      k |= ok ? 1u << p : 0u;
+      if (SRC_F32) {
+        const float* s = (const float*)A.X + j * CIN + gc * 8;
+        rq[slot][p][0] = *reinterpret_cast<const uint4*>(s);
+        rq[slot][p][RQ - 1] = *reinterpret_cast<const uint4*>(s + 4);
+      } else {
+        rq[slot][p][0] = *reinterpret_cast<const uint4*>((const unsigned short*)A.X + j * CIN + gc * 8);
       }
-      rq[p] = q;
+    }
+    keep[slot] = k;
+  };
+  auto stage = [&](unsigned char* b, int slot) {
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      uint4 q;
+      if (SRC_F32) {
+        const uint4 a = rq[slot][p][0], c = rq[slot][p][RQ - 1];
+        q.x = sp_pack2(__uint_as_float(a.x), __uint_as_float(a.y)); q.y = sp_pack2(__uint_as_float(a.z), __uint_as_float(a.w));
+        q.z = sp_pack2(__uint_as_float(c.x), __uint_as_float(c.y)); q.w = sp_pack2(__uint_as_float(c.z), __uint_as_float(c.w));
+      } else {
+        q = rq[slot][p][0];
+      }
+      const unsigned m = ((keep[slot] >> p) & 1u) ? 0xFFFFFFFFu : 0u;
+      q.x &= m; q.y &= m; q.z &= m; q.w &= m;
+      *reinterpret_cast<uint4*>(b + (p * RPP + tid / CPR) * XP + gc * 16) = q;
     }
   };
-  auto stage = [&](unsigned char* b) {
-#pragma unroll
-    for (int p = 0; p < P; ++p) *reinterpret_cast<uint4*>(b + (p * RPP + tid / CPR) * XP + gc * 16) = rq[p];
-  };
-  fetch(idx_cur);
-  stage(lds);
+  load_idx(0);
+  fetch(0);
+  load_idx(1);
+  stage(lds, 0);
   __syncthreads();
 
   f32x16 acc[MPW][NPW];
@@ -124,29 +164,34 @@ __global__ __launch_bounds__(512, 2) void k_spconv(SpArgs A) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[j][b][i] = 0.f;
 
-  for (int tap = 0; tap < 9; ++tap) {
-    if (tap < 8) fetch(idx_nxt);                                   // next tap's rows: in flight behind this tap's MFMAs
-    if (tap < 7) {
 #pragma unroll
-      for (int p = 0; p < P; ++p) idx_nxt[p] = grow[p] < A.n ? A.nbr[grow[p] * 9 + tap + 2] : -1;
+  for (int tap = 0; tap < 9; ++tap) {              // fully unrolled: every condition below is a compile-time constant
+    if (tap + GD < 9) {
+      fetch(0);                                    // in flight behind this tap's MFMAs
+      if (tap + GD + 1 < 9) load_idx(tap + GD + 1);
     }
+    __builtin_amdgcn_sched_barrier(0);             // ... and issued before them
     const unsigned char* lb = lds + (tap & 1) * (ROWS * XP) + ((nb0 * 32) + (lane & 31)) * XP + (lane >> 5) * 16;
-    const size_t g0 = (size_t)tap * KS;
+    SpFrag sf[2][NPW];
+#pragma unroll
+    for (int b = 0; b < NPW; ++b) sf[0][b].q = *reinterpret_cast<const uint4*>(lb + b * 32 * XP);
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      if (tap < 8 || ks + kPf < KS) {
+      if (ks + 1 < KS) {
 #pragma unroll
-        for (int j = 0; j < MPW; ++j) wr[(ks + kPf) % kRing][j].q = wp[((g0 + ks + kPf) * MB + j * kWaves) * 64];
+        for (int b = 0; b < NPW; ++b) sf[(ks + 1) & 1][b].q = *reinterpret_cast<const uint4*>(lb + b * 32 * XP + (ks + 1) * 32);
       }
-      SpFrag sf[NPW];
-#pragma unroll
-      for (int b = 0; b < NPW; ++b) sf[b].q = *reinterpret_cast<const uint4*>(lb + b * 32 * XP + ks * 32);
 #pragma unroll
       for (int j = 0; j < MPW; ++j)
 #pragma unroll
-        for (int b = 0; b < NPW; ++b) acc[j][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[ks % kRing][j].v, sf[b].v, acc[j][b], 0, 0, 0);
+        for (int b = 0; b < NPW; ++b) acc[j][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[ks % RING][j].v, sf[ks & 1][b].v, acc[j][b], 0, 0, 0);
+      if (tap * KS + ks + RING < 9 * KS) {
+#pragma unroll
+        for (int j = 0; j < MPW; ++j) wr[ks % RING][j].q = wp[(((size_t)tap * KS + ks + RING) * MB + j * kWaves) * 64];
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
-    if (tap < 8) stage(lds + ((tap + 1) & 1) * (ROWS * XP));
+    if (tap < 8) stage(lds + ((tap + 1) & 1) * (ROWS * XP), 0);
     __syncthreads();
   }
 
@@ -182,7 +227,7 @@ __global__ __launch_bounds__(512, 2) void k_spconv(SpArgs A) {
 
 template <int CIN, int COUT, bool SRC_F32>
 int sp_launch(const SpArgs& A, hipStream_t st) {
-  constexpr int ROWS = SpRows<COUT>::value;
+  constexpr int ROWS = SpRows<CIN, COUT, SRC_F32>::value;
   constexpr int tile = ROWS * (CIN * 2 + 16), stg = ROWS * (COUT * 2 + 16);
   constexpr int lds = 2 * tile > stg ? 2 * tile : stg;
   static bool once = false;
