@@ -26,11 +26,7 @@
 
 // ---- global-memory row IO: fp32 or bf16 (token GEMM outputs under bf16 autocast), fp32 in registers ----
 __device__ inline float bf2f(unsigned v) { return __uint_as_float(v << 16); }
-__device__ inline unsigned f2bf(float f) {   // round-to-nearest-even
-  unsigned u = __float_as_uint(f);
-  if ((u & 0x7F800000u) == 0x7F800000u) return u >> 16;
-  return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
-}
+__device__ inline unsigned f2bf(float f) { return gd_to_bf16(f); }   // round-to-nearest-even
 struct IoF32 {
   typedef float T;
   template <int DH>

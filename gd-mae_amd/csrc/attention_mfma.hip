@@ -31,11 +31,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ float am_exp(float x) { return __expf(x); }
 
 __device__ inline float am_bf2f(unsigned v) { return __uint_as_float(v << 16); }
-__device__ inline unsigned am_f2bf(float f) {
-  unsigned u = __float_as_uint(f);
-  if ((u & 0x7F800000u) == 0x7F800000u) return u >> 16;
-  return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
-}
+__device__ inline unsigned am_f2bf(float f) { return gd_to_bf16(f); }
 
 struct AmF32 {
   typedef float T;

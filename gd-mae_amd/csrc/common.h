@@ -36,6 +36,17 @@ enum {
   GD_T_SPCONV_FWD = 6, GD_T_SPCONV_BWD = 7, GD_T_DEC_CONV_BWD = 8, GD_T_VFE = 9, GD_T_PLAN = 10, GD_T_LAYER_TAIL = 11,
   GD_T_FFN = 12, GD_T_ROWS_GEMM = 13, GD_T_SLOTS = 16
 };
+// fp32 -> bf16, round to nearest even.  gfx950 converts in hardware, two values per instruction (v_cvt_pk_bf16_f32); the integer
+// sequence the kernels carried before (compare, add 0x7FFF + lsb, shift: ~13 VALU operations per pair) was a measurable share of
+// every bf16 epilogue.  Finite values and infinities round exactly as before; a NaN stays a (quiet) NaN.
+typedef __bf16 gd_bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float gd_f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned gd_pack_bf16(float lo, float hi) {          // lo in bits 0 - 15
+  const gd_f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, gd_bf16x2_t));
+}
+__device__ __forceinline__ unsigned short gd_to_bf16(float f) { return (unsigned short)(gd_pack_bf16(f, 0.f) & 0xFFFFu); }
+
 extern int g_gd_timing_on;
 void* gd_timing_begin(int slot, hipStream_t st);
 void gd_timing_end(void* handle, hipStream_t st, double bytes, double flops, double side);

@@ -17,11 +17,7 @@ int gd_spconv(hipStream_t st, const void* X, int x_f32, const int* nbr, const vo
 
 namespace {
 
-__device__ inline unsigned short cb_f2bf(float f) {
-  unsigned u = __float_as_uint(f);
-  if ((u & 0x7F800000u) == 0x7F800000u) return (unsigned short)(u >> 16);
-  return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
-}
+__device__ inline unsigned short cb_f2bf(float f) { return gd_to_bf16(f); }
 
 // out[s, :] = bf16(src[idx[s], :]) (0 for idx < 0): im2col gather of fp32 token rows with the cast folded in
 __global__ __launch_bounds__(256) void k_gather_rows_f32_bf16(const float* __restrict__ src, const int* __restrict__ idx,

@@ -40,12 +40,8 @@ union CtFrag {
 #define CT_NRED 256              // rows the per-tile statistics partials are pre-reduced to
 
 __device__ inline float ct_bf2f(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
-__device__ inline unsigned short ct_f2bf(float f) {
-  unsigned u = __float_as_uint(f);
-  if ((u & 0x7F800000u) == 0x7F800000u) return (unsigned short)(u >> 16);
-  return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
-}
-__device__ inline unsigned ct_pack2(float lo, float hi) { return ct_f2bf(lo) | ((unsigned)ct_f2bf(hi) << 16); }
+__device__ inline unsigned short ct_f2bf(float f) { return gd_to_bf16(f); }
+__device__ inline unsigned ct_pack2(float lo, float hi) { return gd_pack_bf16(lo, hi); }
 __device__ inline void ct_unpack8(const uint4& u, float (&f)[8]) {
   const unsigned w[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll

@@ -14,11 +14,7 @@
 #include "conv_tiles.h"
 
 __device__ inline float dec_bf2f(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
-__device__ inline unsigned short dec_f2bf(float f) {
-  unsigned u = __float_as_uint(f);
-  if ((u & 0x7F800000u) == 0x7F800000u) return (unsigned short)(u >> 16);
-  return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
-}
+__device__ inline unsigned short dec_f2bf(float f) { return gd_to_bf16(f); }
 template <bool BF>
 __device__ inline float dec_ld(const void* p, long long i) {
   return BF ? dec_bf2f(((const unsigned short*)p)[i]) : ((const float*)p)[i];

@@ -56,14 +56,9 @@ __device__ __forceinline__ void zero_chunk_unless(Chunk& k, unsigned keep_mask) 
 // indices of a thread's pieces are loaded first, then the four rows (row 0 for a missing tap, cleared afterwards), so a chunk costs
 // two round trips instead of eight serialised ones.
 __device__ __forceinline__ uint4 cvt_f32x8(const float4& a, const float4& b) {
-  auto f2bf = [](float f) -> unsigned {
-    unsigned u = __float_as_uint(f);
-    if ((u & 0x7F800000u) == 0x7F800000u) return u >> 16;
-    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
-  };
   uint4 q;
-  q.x = f2bf(a.x) | (f2bf(a.y) << 16); q.y = f2bf(a.z) | (f2bf(a.w) << 16);
-  q.z = f2bf(b.x) | (f2bf(b.y) << 16); q.w = f2bf(b.z) | (f2bf(b.w) << 16);
+  q.x = gd_pack_bf16(a.x, a.y); q.y = gd_pack_bf16(a.z, a.w);
+  q.z = gd_pack_bf16(b.x, b.y); q.w = gd_pack_bf16(b.z, b.w);
   return q;
 }
 struct ChunkIdx {

@@ -22,11 +22,7 @@ constexpr long long kPad = 2048;
 constexpr size_t kLtWorkspace = GD_LT_WORKSPACE;
 
 __device__ inline float el_bf2f(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
-__device__ inline unsigned short el_f2bf(float f) {
-  unsigned u = __float_as_uint(f);
-  if ((u & 0x7F800000u) == 0x7F800000u) return (unsigned short)(u >> 16);
-  return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
-}
+__device__ inline unsigned short el_f2bf(float f) { return gd_to_bf16(f); }
 
 // ------------------------------------------------------------------------------------------
 // small kernels

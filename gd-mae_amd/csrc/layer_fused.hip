@@ -154,6 +154,14 @@ __global__ __launch_bounds__(TL_THREADS * TL_HALVES, TL_MINW) void k_layer_fwd(L
   const long long row0 = tile_id * ROWS;
   const int lc0 = 4 * (tid % LPR), lr = tid / LPR;
 
+  // Optional outputs select POINTERS once (to something readable when the output is absent); the loads themselves are unconditional:
+  // a uniform branch around a load is a join with a load in flight, and the compiler drains the load counter there - one serial
+  // round trip per optional load (this kernel had twelve of them per tile: four token positions at the top, four block-residual
+  // rows and four position-table rows at the bottom).
+  const bool has_pos = A.ypos_bf != nullptr, has_res = A.res_out != nullptr;
+  const int* __restrict__ tokp = has_pos ? A.tok_pos : (const int*)A.x;
+  const float* __restrict__ ptab = has_pos ? A.pos_table : A.g1;
+  const unsigned short* __restrict__ res0p = has_res ? A.res0 : A.x;
   TlProd<D, D, ROWS> pa;
   pa.prefetch(A.Wo, nullptr, wv, lane);
   uint2 res_pf[LPASS];
@@ -163,7 +171,7 @@ __global__ __launch_bounds__(TL_THREADS * TL_HALVES, TL_MINW) void k_layer_fwd(L
     const long long row = row0 + p * LRPP + lr;
     const long long rr = row < A.n ? row : A.n - 1;
     res_pf[p] = *(const uint2*)(A.x + rr * D + lc0);
-    pos_pf[p] = A.ypos_bf ? A.tok_pos[rr] : 0;
+    pos_pf[p] = tokp[rr];
   }
   tl_load_tile<D, ROWS>(A.o, row0, xl, XP, 0, tid);
   __syncthreads();
@@ -171,9 +179,11 @@ __global__ __launch_bounds__(TL_THREADS * TL_HALVES, TL_MINW) void k_layer_fwd(L
   {
     f32x16 acc[TlShape<D, D, ROWS>::MPW][TlShape<D, D, ROWS>::NPW];
     tl_zero(acc);
+    TlBias<D, D, ROWS> bia;
+    bia.load(A.bo, wv, lane);                        // lands behind the product
     pa.run(xl, XP, wv, lane, acc);
     __syncthreads();                                 // every wavefront is done with the o tile
-    tl_stage<D, D, ROWS>(acc, A.bo, xl, XP, wv, lane);
+    tl_stage<D, D, ROWS>(acc, bia, xl, XP, wv, lane);
   }
   TlProd<D, FF, ROWS> pb;
   pb.prefetch(A.W1, nullptr, wv, lane);
@@ -212,7 +222,7 @@ __global__ __launch_bounds__(TL_THREADS * TL_HALVES, TL_MINW) void k_layer_fwd(L
     f32x16 acc[TlShape<D, FF, ROWS>::MPW][TlShape<D, FF, ROWS>::NPW];
     tl_zero(acc);
     pb.run(xl, XP, wv, lane, acc);
-    tl_stage<D, FF, ROWS>(acc, A.b1, hl, HP, wv, lane);
+    tl_stage<D, FF, ROWS>(acc, A.b1, hl, HP, wv, lane);     // (two channel blocks per wavefront: no registers for an early bias)
   }
   TlProd<FF, D, ROWS> pc;
   pc.prefetch(A.W2, nullptr, wv, lane);
@@ -238,14 +248,26 @@ __global__ __launch_bounds__(TL_THREADS * TL_HALVES, TL_MINW) void k_layer_fwd(L
   {
     f32x16 acc[TlShape<FF, D, ROWS>::MPW][TlShape<FF, D, ROWS>::NPW];
     tl_zero(acc);
+    TlBias<FF, D, ROWS> bic;
+    bic.load(A.b2, wv, lane);
     pc.run(hl, HP, wv, lane, acc);
-    tl_stage<FF, D, ROWS>(acc, A.b2, xl, XP, wv, lane);
+    tl_stage<FF, D, ROWS>(acc, bic, xl, XP, wv, lane);
   }
   __syncthreads();
   // ---- y = LN2(x1 + f)
   {
     const float4 g4 = *(const float4*)(A.g2 + lc0), b4 = *(const float4*)(A.be2 + lc0);
     const float g[4] = {g4.x, g4.y, g4.z, g4.w}, bt[4] = {b4.x, b4.y, b4.z, b4.w};
+    uint2 r0q[LPASS];
+    float4 p4q[LPASS];
+#pragma unroll
+    for (int p = 0; p < LPASS; ++p) {                // the optional operands of every pass, requested together
+      const long long row = row0 + p * LRPP + lr;
+      const long long rr = row < A.n ? row : A.n - 1;
+      asm volatile("" : "+v"(pos_pf[p]));            // looked at here, not where it was loaded
+      r0q[p] = *(const uint2*)(res0p + rr * D + lc0);
+      p4q[p] = *(const float4*)(ptab + (long long)(has_pos ? pos_pf[p] : 0) * D + lc0);
+    }
 #pragma unroll
     for (int p = 0; p < LPASS; ++p) {
       const int rl = p * LRPP + lr;
@@ -262,16 +284,15 @@ __global__ __launch_bounds__(TL_THREADS * TL_HALVES, TL_MINW) void k_layer_fwd(L
       const long long e = row * D + lc0;
       TG_ST_U2(A.f + e, fq);
       if (A.y) TG_ST_F4(A.y + e, o[0], o[1], o[2], o[3]);
-      if (A.res_out) {
+      if (has_res) {
         float r0[4];
-        tl_unpack4(*(const uint2*)(A.res0 + e), r0);
+        tl_unpack4(r0q[p], r0);
         const float rs[4] = {r0[0] + o[0], r0[1] + o[1], r0[2] + o[2], r0[3] + o[3]};
         *(uint2*)(A.res_out + e) = tl_pack4(rs);
       }
       if (A.y_bf) *(uint2*)(A.y_bf + e) = tl_pack4(o);
-      if (A.ypos_bf) {
-        const float4 p4 = *(const float4*)(A.pos_table + (long long)pos_pf[p] * D + lc0);
-        const float op[4] = {o[0] + p4.x, o[1] + p4.y, o[2] + p4.z, o[3] + p4.w};
+      if (has_pos) {
+        const float op[4] = {o[0] + p4q[p].x, o[1] + p4q[p].y, o[2] + p4q[p].z, o[3] + p4q[p].w};
         *(uint2*)(A.ypos_bf + e) = tl_pack4(op);
       }
       if (lc0 == 0) *(float2*)(A.st2 + row * 2) = st;

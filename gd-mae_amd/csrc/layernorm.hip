@@ -11,11 +11,7 @@
 #include "common.h"
 
 __device__ inline float bf16_to_f(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
-__device__ inline unsigned short f_to_bf16(float f) {
-  unsigned u = __float_as_uint(f);
-  if ((u & 0x7F800000u) == 0x7F800000u) return (unsigned short)(u >> 16);
-  return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
-}
+__device__ inline unsigned short f_to_bf16(float f) { return gd_to_bf16(f); }
 
 // Layout: a lane owns 4 consecutive columns (one 16-byte access per fp32 operand, 8 bytes per bf16 operand), LPR = d / 4
 // lanes form a row, a wavefront holds 64 / LPR rows (4 / 2 / 1 for d = 64 / 128 / 256); reductions are xor-shuffles
@@ -300,11 +296,7 @@ __device__ inline void add3_load8(const void* p, int bf, long long e8, float (&v
     v[0] += x.x; v[1] += x.y; v[2] += x.z; v[3] += x.w; v[4] += y.x; v[5] += y.y; v[6] += y.z; v[7] += y.w;
   }
 }
-__device__ inline unsigned add3_f2bf(float f) {
-  unsigned u = __float_as_uint(f);
-  if ((u & 0x7F800000u) == 0x7F800000u) return u >> 16;
-  return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
-}
+__device__ inline unsigned add3_f2bf(float f) { return gd_to_bf16(f); }
 __global__ __launch_bounds__(256) void k_add3(const float* __restrict__ a, const void* __restrict__ b, int b_bf16,
                                               const void* __restrict__ c, int c_bf16, long long total, void* __restrict__ out, int out_bf16) {
   const long long n8 = total >> 3;

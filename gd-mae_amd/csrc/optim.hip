@@ -51,8 +51,7 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float
       const float pn = pi - step * (mi / denom);
       p[i] = pn;
       if (p_bf16) {                                    // the bf16 shadow the GEMMs read: written here instead of by a cast pass
-        unsigned u = __float_as_uint(pn);
-        p_bf16[i] = (u & 0x7F800000u) == 0x7F800000u ? (unsigned short)(u >> 16) : (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+        p_bf16[i] = gd_to_bf16(pn);
       }
     }
   }

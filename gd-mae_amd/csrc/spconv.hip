@@ -30,12 +30,8 @@ union SpFrag {
   uint4 q;
   bf16x8 v;
 };
-__device__ inline unsigned short sp_f2bf(float f) {
-  unsigned u = __float_as_uint(f);
-  if ((u & 0x7F800000u) == 0x7F800000u) return (unsigned short)(u >> 16);
-  return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
-}
-__device__ inline unsigned sp_pack2(float lo, float hi) { return sp_f2bf(lo) | ((unsigned)sp_f2bf(hi) << 16); }
+__device__ inline unsigned short sp_f2bf(float f) { return gd_to_bf16(f); }
+__device__ inline unsigned sp_pack2(float lo, float hi) { return gd_pack_bf16(lo, hi); }
 
 struct SpArgs {
   const void* X;          // (n_src, CIN) bf16 or fp32 rows

@@ -177,6 +177,18 @@ __device__ __forceinline__ void tg_tile(const TgArgs& A, const long long tile, c
     for (int b = 0; b < NPW; ++b)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[j][b][i] = 0.f;
+  // bias fragments: requested together, unconditionally (from a readable stand-in when there is no bias, then masked) and before the
+  // product - a runtime `if (bias)` around each load is a join with a load in flight: the compiler drained the load counter after
+  // every one of the four (serial L2 round trips behind the product)
+  uint2 bq[MPW][4];
+  const unsigned bmask = (EPI != TG_GELU_BWD && A.bias) ? 0xFFFFFFFFu : 0u;
+  {
+    const unsigned short* bp = bmask ? A.bias : (const unsigned short*)A.Wp;
+#pragma unroll
+    for (int j = 0; j < MPW; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bq[j][q] = *(const uint2*)(bp + (mb0 + j * TG_WAVES) * 32 + 4 * (lane >> 5) + 8 * q);
+  }
   {
     const unsigned char* lb = lds + ((nb0 * 32) + (lane & 31)) * XP + (lane >> 5) * 16;
     TgFrag sf[2][NPW];
@@ -214,10 +226,10 @@ __device__ __forceinline__ void tg_tile(const TgArgs& A, const long long tile, c
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = acc[j][b][4 * q + e];
-        if (EPI != TG_GELU_BWD && A.bias) {
-          const uint2 bq = *(const uint2*)(A.bias + cb + 8 * q);
-          v[0] += __uint_as_float(bq.x << 16); v[1] += __uint_as_float(bq.x & 0xFFFF0000u);
-          v[2] += __uint_as_float(bq.y << 16); v[3] += __uint_as_float(bq.y & 0xFFFF0000u);
+        {
+          const unsigned bx = bq[j][q].x & bmask, by = bq[j][q].y & bmask;      // + 0 without a bias
+          v[0] += __uint_as_float(bx << 16); v[1] += __uint_as_float(bx & 0xFFFF0000u);
+          v[2] += __uint_as_float(by << 16); v[3] += __uint_as_float(by & 0xFFFF0000u);
         }
         uint2 o;
         o.x = tg_pack2(v[0], v[1]);

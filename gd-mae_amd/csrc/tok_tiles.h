@@ -11,7 +11,11 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #ifndef TG_NT_STORES
 #define TG_NT_STORES 1
 #endif
-#if TG_NT_STORES
+#ifdef TL_EXP_NOSTORE      // experiment: the streaming stores never execute (the values stay live)
+#define TG_ST_U2(ptr, val) do { if (blockIdx.x == 0x7fffffffu) *(uint2*)(ptr) = (val); } while (0)
+#define TG_ST_U4(ptr, val) do { if (blockIdx.x == 0x7fffffffu) *(uint4*)(ptr) = (val); } while (0)
+#define TG_ST_F4(ptr, a, b, c, d) do { if (blockIdx.x == 0x7fffffffu) *(float4*)(ptr) = make_float4(a, b, c, d); } while (0)
+#elif TG_NT_STORES
 #define TG_ST_U2(ptr, val) __builtin_nontemporal_store(*(const unsigned long long*)&(val), (unsigned long long*)(ptr))
 #define TG_ST_U4(ptr, val)                                                              \
   do {                                                                                  \
@@ -74,12 +78,8 @@ union TgFrag {
 enum { TG_PLAIN = 0, TG_GELU = 1, TG_GELU_BWD = 2, TG_RES_LN = 3, TG_LN_BWD = 4 };
 
 __device__ inline float tg_bf2f(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
-__device__ inline unsigned short tg_f2bf(float f) {
-  unsigned u = __float_as_uint(f);
-  if ((u & 0x7F800000u) == 0x7F800000u) return (unsigned short)(u >> 16);
-  return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
-}
-__device__ inline unsigned tg_pack2(float lo, float hi) { return tg_f2bf(lo) | ((unsigned)tg_f2bf(hi) << 16); }
+__device__ inline unsigned short tg_f2bf(float f) { return gd_to_bf16(f); }
+__device__ inline unsigned tg_pack2(float lo, float hi) { return gd_pack_bf16(lo, hi); }
 __device__ inline void tg_unpack8(const uint4& u, float (&f)[8]) {
   const unsigned w[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
@@ -186,6 +186,9 @@ struct TlProd {
       for (int j = 0; j < S::MPW; ++j) wr[ks][j].q = tl_wfrag<KD, ND, ROWS, KSPLIT>(w0, w1, ks, j, mbs);
   }
   __device__ __forceinline__ void run(const unsigned char* xs, int XP, int wv, int lane, f32x16 (&acc)[S::MPW][S::NPW]) {
+#ifdef TL_EXP_NOMFMA
+    return;
+#endif
     const unsigned char* lb = xs + ((S::nb0(wv) * 32) + (lane & 31)) * XP + (lane >> 5) * 16;
     TgFrag sf[2][S::NPW];
 #pragma unroll
@@ -220,10 +223,24 @@ __device__ __forceinline__ void tl_zero(f32x16 (&acc)[MPW][NPW]) {
       for (int i = 0; i < 16; ++i) acc[j][b][i] = 0.f;
 }
 
-// accumulators (+ bias) -> bf16 -> LDS tile [row][channel] with row pitch SP
+// accumulators (+ bias) -> bf16 -> LDS tile [row][channel] with row pitch SP.  The bias fragments of the wavefront are requested
+// together and unconditionally (HAS_BIAS is a compile-time flag): a runtime `if (bias)` around each load made the compiler drain the
+// load counter after every one of them (a join with a load in flight) - four serial L2 round trips per product.
+// bias fragments of a wavefront's output blocks: load() before the product runs (they land behind its MFMAs), used by tl_stage_pre
 template <int KD, int ND, int ROWS>
-__device__ __forceinline__ void tl_stage(const f32x16 (&acc)[TlShape<KD, ND, ROWS>::MPW][TlShape<KD, ND, ROWS>::NPW], const unsigned short* bias,
-                                         unsigned char* out, int SP, int wv, int lane) {
+struct TlBias {
+  using S = TlShape<KD, ND, ROWS>;
+  uint2 bq[S::MPW][4];
+  __device__ __forceinline__ void load(const unsigned short* bias, int wv, int lane) {
+#pragma unroll
+    for (int j = 0; j < S::MPW; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bq[j][q] = *(const uint2*)(bias + (S::mb0(wv) + j * TL_WAVES) * 32 + 4 * (lane >> 5) + 8 * q);
+  }
+};
+template <int KD, int ND, int ROWS, bool HAS_BIAS>
+__device__ __forceinline__ void tl_stage_pre(const f32x16 (&acc)[TlShape<KD, ND, ROWS>::MPW][TlShape<KD, ND, ROWS>::NPW],
+                                             const uint2 (&bq)[TlShape<KD, ND, ROWS>::MPW][4], unsigned char* out, int SP, int wv, int lane) {
   using S = TlShape<KD, ND, ROWS>;
 #pragma unroll
   for (int j = 0; j < S::MPW; ++j) {
@@ -236,10 +253,9 @@ __device__ __forceinline__ void tl_stage(const f32x16 (&acc)[TlShape<KD, ND, ROW
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = acc[j][b][4 * q + e];
-        if (bias) {
-          const uint2 bq = *(const uint2*)(bias + cb + 8 * q);
-          v[0] += __uint_as_float(bq.x << 16); v[1] += __uint_as_float(bq.x & 0xFFFF0000u);
-          v[2] += __uint_as_float(bq.y << 16); v[3] += __uint_as_float(bq.y & 0xFFFF0000u);
+        if constexpr (HAS_BIAS) {
+          v[0] += __uint_as_float(bq[j][q].x << 16); v[1] += __uint_as_float(bq[j][q].x & 0xFFFF0000u);
+          v[2] += __uint_as_float(bq[j][q].y << 16); v[3] += __uint_as_float(bq[j][q].y & 0xFFFF0000u);
         }
         uint2 o;
         o.x = tg_pack2(v[0], v[1]);
@@ -248,6 +264,24 @@ __device__ __forceinline__ void tl_stage(const f32x16 (&acc)[TlShape<KD, ND, ROW
       }
     }
   }
+}
+template <int KD, int ND, int ROWS>
+__device__ __forceinline__ void tl_stage(const f32x16 (&acc)[TlShape<KD, ND, ROWS>::MPW][TlShape<KD, ND, ROWS>::NPW], decltype(nullptr),
+                                         unsigned char* out, int SP, int wv, int lane) {
+  uint2 none[TlShape<KD, ND, ROWS>::MPW][4];
+  tl_stage_pre<KD, ND, ROWS, false>(acc, none, out, SP, wv, lane);
+}
+template <int KD, int ND, int ROWS>
+__device__ __forceinline__ void tl_stage(const f32x16 (&acc)[TlShape<KD, ND, ROWS>::MPW][TlShape<KD, ND, ROWS>::NPW], const unsigned short* bias,
+                                         unsigned char* out, int SP, int wv, int lane) {
+  TlBias<KD, ND, ROWS> b;
+  b.load(bias, wv, lane);                                            // bias must not be null
+  tl_stage_pre<KD, ND, ROWS, true>(acc, b.bq, out, SP, wv, lane);
+}
+template <int KD, int ND, int ROWS>
+__device__ __forceinline__ void tl_stage(const f32x16 (&acc)[TlShape<KD, ND, ROWS>::MPW][TlShape<KD, ND, ROWS>::NPW], const TlBias<KD, ND, ROWS>& b,
+                                         unsigned char* out, int SP, int wv, int lane) {
+  tl_stage_pre<KD, ND, ROWS, true>(acc, b.bq, out, SP, wv, lane);
 }
 
 __device__ __forceinline__ void tl_unpack4(const uint2& q, float (&f)[4]) {

@@ -37,10 +37,7 @@ struct VfeGeom {
 
 enum { VF_STATS = 0, VF_APPLY = 1, VF_BSTATS = 2, VF_DW = 3 };
 
-__device__ inline unsigned short vf_f2bf(float f) {   // round to nearest even (finite inputs)
-  const unsigned u = __float_as_uint(f);
-  return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
-}
+__device__ inline unsigned short vf_f2bf(float f) { return gd_to_bf16(f); }   // round to nearest even
 
 // decorated features of point i (all zero past the end): the arithmetic of k_decorate (segment.hip), kept in registers
 // `cpp` (coords per pillar): `coords` holds one row per PILLAR (voxel_coords) instead of one per point - the layout of

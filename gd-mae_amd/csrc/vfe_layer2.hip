@@ -47,10 +47,7 @@ constexpr int V2_MAX_GRID = 1024;     // rows of the statistics partials
 constexpr int V2_DW_GRID = 1024;      // rows of the dW partials (32 KB each)
 
 __device__ __forceinline__ int v2_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
-__device__ __forceinline__ unsigned short v2_f2bf(float f) {
-  const unsigned u = __float_as_uint(f);
-  return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
-}
+__device__ __forceinline__ unsigned short v2_f2bf(float f) { return gd_to_bf16(f); }
 __device__ __forceinline__ f32x16 v2_mfma(bf16x8 a, bf16x8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }

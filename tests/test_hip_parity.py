@@ -1695,3 +1695,26 @@ def test_spconv_implicit_gemm_matches_gathered_product(cin, cout, src_f32):
         err = float((Y.float() - ref).abs().max())
         assert err <= 2 ** -7 * float(ref.abs().max()), (transposed, err, float(ref.abs().max()))     # one bf16 rounding of the result
         assert float(Y[::7].abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+def test_bf16_stores_round_to_nearest_even_like_torch():
+    """Every bf16 epilogue converts with the hardware instruction (common.h gd_pack_bf16): bit-identical to torch's cast (round to
+    nearest even) on random bit patterns, exact ties, subnormals and infinities; NaN stays NaN.  (-0.0 is left out: the carrier
+    kernel adds its optional operands to +0.)"""
+    from gdmae_hip import lib as L
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    bits = torch.randint(-2**31 + 1, 2**31 - 1, (1 << 20,), generator=g, dtype=torch.int64).to(torch.int32)
+    ties = (torch.randint(0, 1 << 16, (1 << 16,), generator=g, dtype=torch.int64) << 16 | 0x8000).to(torch.int32)       # exactly half way
+    near = ties + torch.randint(-1, 2, ties.shape, generator=g, dtype=torch.int32)
+    special = torch.tensor([0, 0x7F800000, -8388608, 1, 0x00007FFF, 0x00008000, 0x00008001, 0x007FFFFF, 0x7F7FFFFF, 0x7F7F8000,
+                            0x7FC00000, 0x7F800001], dtype=torch.int32)
+    a = torch.cat([bits, ties, near, special]).view(torch.float32).to(dev)
+    out = torch.empty(a.numel(), dtype=torch.bfloat16, device=dev)
+    L.call("gdmae_add3_to", L.ptr(a), None, 0, None, 0, a.numel(), L.ptr(out), 1, L.stream())
+    torch.cuda.synchronize()
+    ref = a.to(torch.bfloat16)
+    nan = torch.isnan(a)
+    assert torch.equal(torch.isnan(out), nan)
+    assert torch.equal(out[~nan].view(torch.int16), ref[~nan].view(torch.int16))
