@@ -84,12 +84,20 @@ __device__ __forceinline__ int unit_off(int row, int unit) {
   const int x = ((row >> 1) & 1) | (((row >> 3) & 1) << 1) | (((row >> 2) & 1) << 2);
   return row * kPitch + 4 * (unit ^ x);
 }
+// Rows are loaded unconditionally (a padding row reads token 0) and cleared afterwards by keep_row: a load under `act ? ... : 0`
+// is a branch, and where it joins the compiler drains the load counter - the q / k / v / dO rows arrived one round trip after the other.
 template <int NP>
-__device__ __forceinline__ Row<NP> load_row(const unsigned short* __restrict__ base, bool act) {
+__device__ __forceinline__ Row<NP> load_row(const unsigned short* __restrict__ base) {
   Row<NP> r;
 #pragma unroll
-  for (int p = 0; p < NP; ++p) r.p[p] = act ? *reinterpret_cast<const uint2*>(base + 16 * p) : make_uint2(0u, 0u);
+  for (int p = 0; p < NP; ++p) r.p[p] = *reinterpret_cast<const uint2*>(base + 16 * p);
   return r;
+}
+template <int NP>
+__device__ __forceinline__ void keep_row(Row<NP>& r, bool act) {
+  const unsigned m = act ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+  for (int p = 0; p < NP; ++p) { r.p[p].x &= m; r.p[p].y &= m; }
 }
 template <int NP>
 __device__ __forceinline__ void store_tile(unsigned short* __restrict__ tile, int c, int g, const Row<NP>& r) {
@@ -179,7 +187,7 @@ __device__ __forceinline__ bool next_pass(Pass& ps, const int (&len)[kWinPerWave
   ps.a = a;
   ps.b = b;
   ps.wid = wid;
-  ps.tok = idx >= 0 ? csr_tok[idx] : 0;
+  ps.tok = csr_tok[idx >= 0 ? idx : 0];           // padding rows read entry 0: their rows are cleared (keep_row), no branch around the load
   return true;
 }
 
@@ -199,8 +207,10 @@ __global__ __launch_bounds__(256) void k_attn_t16_fwd(A16Args A) {
 #pragma unroll
   for (int i = 0; i < kWinPerWave; ++i) {
     const int w = kWinPerWave * wq + i;
-    len[i] = w < A.n_win ? A.win_len[w] : 0;
-    start[i] = w < A.n_win ? A.win_start[w] : 0;
+    const int wc = w < A.n_win ? w : A.n_win - 1;         // unconditional loads, the length cleared afterwards
+    const int l_ = A.win_len[wc];
+    start[i] = A.win_start[wc];
+    len[i] = w < A.n_win ? l_ : 0;
   }
   const float inv_tau = 1.f / fmaxf(*A.tau, A.tau_min);
   const int d = A.d;
@@ -209,9 +219,12 @@ __global__ __launch_bounds__(256) void k_attn_t16_fwd(A16Args A) {
   while (next_pass(ps, len, start, A.csr_tok, c)) {
     const bool act = ps.wid != kPadWin;
     const int tok = ps.tok;
-    const Row<NP> q = load_row<NP>(A.qk + (long long)tok * 2 * d + col, act);
-    const Row<NP> k = load_row<NP>(A.qk + (long long)tok * 2 * d + d + col, act);
-    const Row<NP> v = load_row<NP>(A.v + (long long)tok * d + col, act);
+    Row<NP> q = load_row<NP>(A.qk + (long long)tok * 2 * d + col);
+    Row<NP> k = load_row<NP>(A.qk + (long long)tok * 2 * d + d + col);
+    Row<NP> v = load_row<NP>(A.v + (long long)tok * d + col);
+    keep_row<NP>(q, act);
+    keep_row<NP>(k, act);
+    keep_row<NP>(v, act);
     store_tile<NP>(tV, c, g, v);
     const float qa = inv_norm<NP>(q) * inv_tau;
     const float kin = inv_norm<NP>(k);
@@ -271,8 +284,10 @@ __global__ __launch_bounds__(256) void k_attn_t16_bwd(A16BwdArgs A) {
 #pragma unroll
   for (int i = 0; i < kWinPerWave; ++i) {
     const int w = kWinPerWave * wq + i;
-    len[i] = w < A.n_win ? A.win_len[w] : 0;
-    start[i] = w < A.n_win ? A.win_start[w] : 0;
+    const int wc = w < A.n_win ? w : A.n_win - 1;         // unconditional loads, the length cleared afterwards
+    const int l_ = A.win_len[wc];
+    start[i] = A.win_start[wc];
+    len[i] = w < A.n_win ? l_ : 0;
   }
   const float inv_tau = 1.f / fmaxf(*A.tau, A.tau_min);
   const int d = A.d;
@@ -282,10 +297,14 @@ __global__ __launch_bounds__(256) void k_attn_t16_bwd(A16BwdArgs A) {
   while (next_pass(ps, len, start, A.csr_tok, c)) {
     const bool act = ps.wid != kPadWin;
     const int tok = ps.tok;
-    const Row<NP> q = load_row<NP>(A.qk + (long long)tok * 2 * d + col, act);
-    const Row<NP> k = load_row<NP>(A.qk + (long long)tok * 2 * d + d + col, act);
-    const Row<NP> v = load_row<NP>(A.v + (long long)tok * d + col, act);
-    const Row<NP> dO = load_row<NP>(A.dout + (long long)tok * d + col, act);
+    Row<NP> q = load_row<NP>(A.qk + (long long)tok * 2 * d + col);
+    Row<NP> k = load_row<NP>(A.qk + (long long)tok * 2 * d + d + col);
+    Row<NP> v = load_row<NP>(A.v + (long long)tok * d + col);
+    Row<NP> dO = load_row<NP>(A.dout + (long long)tok * d + col);
+    keep_row<NP>(q, act);
+    keep_row<NP>(k, act);
+    keep_row<NP>(v, act);
+    keep_row<NP>(dO, act);
     const float qin = inv_norm<NP>(q);
     const float kin = inv_norm<NP>(k);
     const float qa = qin * inv_tau;

@@ -81,12 +81,26 @@ __device__ __forceinline__ int unit_off(int row, int unit) {      // element off
   const int x = (((row >> 1) ^ (row >> 4)) & 1) | (((row >> 2) & 3) << 1);
   return row * kPitch + 4 * (unit ^ x);
 }
+// Rows are loaded UNCONDITIONALLY (a padded slot reads the window's last token) and cleared afterwards by keep_row: a load under
+// `act ? ... : 0` is a branch, and where it joins the compiler drains the load counter - the q / k / v / dO rows of a window used to
+// arrive one round trip after the other.
 template <int NPC>
-__device__ __forceinline__ Row<NPC> load_row(const unsigned short* __restrict__ base, bool act) {
+__device__ __forceinline__ Row<NPC> load_row(const unsigned short* __restrict__ base) {
   Row<NPC> r;
 #pragma unroll
-  for (int t = 0; t < NPC; ++t) r.p[t] = act ? *reinterpret_cast<const uint2*>(base + 8 * t) : make_uint2(0u, 0u);
+  for (int t = 0; t < NPC; ++t) r.p[t] = *reinterpret_cast<const uint2*>(base + 8 * t);
   return r;
+}
+template <int NPC>
+__device__ __forceinline__ void keep_row(Row<NPC>& r, bool act) {
+  const unsigned m = act ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+  for (int t = 0; t < NPC; ++t) { r.p[t].x &= m; r.p[t].y &= m; }
+}
+// token of window slot r (slots past the window's length repeat its last token; their rows are cleared by keep_row)
+__device__ __forceinline__ int slot_token(const int* __restrict__ csr_tok, int start, int r, int n) {
+  const int rr = r < n ? r : (n > 0 ? n - 1 : 0);
+  return csr_tok[start + rr];
 }
 template <int NPC>
 __device__ __forceinline__ void store_tile(unsigned short* __restrict__ tile, int row, int h, const Row<NPC>& r) {
@@ -187,11 +201,14 @@ __device__ __forceinline__ void t32_fwd_body(const T32Args& A, const unsigned bl
   for (int ti = 0; ti < NT; ++ti) {
     const int r = 32 * ti + rho;
     const bool act = r < n;
-    tok[ti] = act ? A.csr_tok[start + r] : 0;
+    tok[ti] = slot_token(A.csr_tok, start, r, n);
     const int col = hd * DH + 4 * h;
-    q[ti] = load_row<NPC>(A.qk + (long long)tok[ti] * 2 * d + col, act);
-    k[ti] = load_row<NPC>(A.qk + (long long)tok[ti] * 2 * d + d + col, act);
-    const Row<NPC> v = load_row<NPC>(A.v + (long long)tok[ti] * d + col, act);
+    q[ti] = load_row<NPC>(A.qk + (long long)tok[ti] * 2 * d + col);
+    k[ti] = load_row<NPC>(A.qk + (long long)tok[ti] * 2 * d + d + col);
+    Row<NPC> v = load_row<NPC>(A.v + (long long)tok[ti] * d + col);
+    keep_row<NPC>(q[ti], act);
+    keep_row<NPC>(k[ti], act);
+    keep_row<NPC>(v, act);
     store_tile<NPC>(tV, r, h, v);
     qc[ti] = inv_norm<NPC>(q[ti]) * inv_tau * kLog2e;
     const float kin = inv_norm<NPC>(k[ti]);
@@ -262,11 +279,19 @@ __device__ __forceinline__ void t32_bwd_body(const T32BwdArgs& A, const unsigned
   for (int ti = 0; ti < NT; ++ti) {
     const int r = 32 * ti + rho;
     const bool act = r < n;
-    tok[ti] = act ? A.csr_tok[start + r] : 0;
-    q[ti] = load_row<NPC>(A.qk + (long long)tok[ti] * 2 * d + col, act);
-    k[ti] = load_row<NPC>(A.qk + (long long)tok[ti] * 2 * d + d + col, act);
-    v[ti] = load_row<NPC>(A.v + (long long)tok[ti] * d + col, act);
-    dO[ti] = load_row<NPC>(A.dout + (long long)tok[ti] * d + col, act);
+    tok[ti] = slot_token(A.csr_tok, start, r, n);
+    q[ti] = load_row<NPC>(A.qk + (long long)tok[ti] * 2 * d + col);
+    k[ti] = load_row<NPC>(A.qk + (long long)tok[ti] * 2 * d + d + col);
+    v[ti] = load_row<NPC>(A.v + (long long)tok[ti] * d + col);
+    dO[ti] = load_row<NPC>(A.dout + (long long)tok[ti] * d + col);
+  }
+#pragma unroll
+  for (int ti = 0; ti < NT; ++ti) {
+    const bool act = 32 * ti + rho < n;
+    keep_row<NPC>(q[ti], act);
+    keep_row<NPC>(k[ti], act);
+    keep_row<NPC>(v[ti], act);
+    keep_row<NPC>(dO[ti], act);
   }
 #pragma unroll
   for (int ti = 0; ti < NT; ++ti) {
@@ -441,11 +466,14 @@ __device__ __forceinline__ void t64_fwd_body(const T32Args& A, const unsigned bl
   const int d = A.d;
   const int r = 32 * sub + rho;
   const bool act = r < n;
-  const int tok = act ? A.csr_tok[start + r] : 0;
+  const int tok = slot_token(A.csr_tok, start, r, n);
   const int col = hd * DH + 4 * h;
-  const Row<NPC> q = load_row<NPC>(A.qk + (long long)tok * 2 * d + col, act);
-  const Row<NPC> k = load_row<NPC>(A.qk + (long long)tok * 2 * d + d + col, act);
-  const Row<NPC> v = load_row<NPC>(A.v + (long long)tok * d + col, act);
+  Row<NPC> q = load_row<NPC>(A.qk + (long long)tok * 2 * d + col);
+  Row<NPC> k = load_row<NPC>(A.qk + (long long)tok * 2 * d + d + col);
+  Row<NPC> v = load_row<NPC>(A.v + (long long)tok * d + col);
+  keep_row<NPC>(q, act);
+  keep_row<NPC>(k, act);
+  keep_row<NPC>(v, act);
   store_tile<NPC>(tK, r, h, k);
   store_tile<NPC>(tV, r, h, v);
   const float qc = inv_norm<NPC>(q) * inv_tau * kLog2e;
@@ -511,12 +539,16 @@ __device__ __forceinline__ void t64_bwd_body(const T32BwdArgs& A, const unsigned
   const int d = A.d;
   const int r = 32 * sub + rho;
   const bool act = r < n;
-  const int tok = act ? A.csr_tok[start + r] : 0;
+  const int tok = slot_token(A.csr_tok, start, r, n);
   const int col = hd * DH + 4 * h;
-  const Row<NPC> q = load_row<NPC>(A.qk + (long long)tok * 2 * d + col, act);
-  const Row<NPC> k = load_row<NPC>(A.qk + (long long)tok * 2 * d + d + col, act);
-  const Row<NPC> v = load_row<NPC>(A.v + (long long)tok * d + col, act);
-  const Row<NPC> dO = load_row<NPC>(A.dout + (long long)tok * d + col, act);
+  Row<NPC> q = load_row<NPC>(A.qk + (long long)tok * 2 * d + col);
+  Row<NPC> k = load_row<NPC>(A.qk + (long long)tok * 2 * d + d + col);
+  Row<NPC> v = load_row<NPC>(A.v + (long long)tok * d + col);
+  Row<NPC> dO = load_row<NPC>(A.dout + (long long)tok * d + col);
+  keep_row<NPC>(q, act);
+  keep_row<NPC>(k, act);
+  keep_row<NPC>(v, act);
+  keep_row<NPC>(dO, act);
   store_tile<NPC>(tK, r, h, k);
   store_tile<NPC>(tV, r, h, v);
   store_tile<NPC>(tQ, r, h, q);
