@@ -80,6 +80,20 @@ __device__ __forceinline__ void v2_load_y(const unsigned short* __restrict__ y1,
     if (!live) ya[s].u = make_uint4(0, 0, 0, 0);
   }
 }
+// the same in two steps for software-pipelined loops: the loads now, the clearing of a dead row where the fragments are first needed
+// (a select right behind the load waits for it there, and a prefetch "in flight behind the arithmetic" is drained before it starts)
+__device__ __forceinline__ void v2_load_y_raw(const unsigned short* __restrict__ y1, long long row, int half, V2Frag (&ya)[4]) {
+#pragma unroll
+  for (int s = 0; s < 4; ++s) ya[s].u = *reinterpret_cast<const uint4*>(y1 + row * V2_CI + 16 * s + 8 * half);
+}
+__device__ __forceinline__ void v2_keep_y(V2Frag (&ya)[4], bool live) {
+  const unsigned m = live ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    ya[s].u.x &= m; ya[s].u.y &= m; ya[s].u.z &= m; ya[s].u.w &= m;
+    asm volatile("" : "+v"(ya[s].u.x), "+v"(ya[s].u.y), "+v"(ya[s].u.z), "+v"(ya[s].u.w));      // here, not where the compiler would sink it
+  }
+}
 
 // pillar id and A fragments of this lane's row (n) of tile t
 __device__ __forceinline__ void v2_load_tile(const unsigned short* __restrict__ y1, const int* __restrict__ rowpil, long long t,
@@ -203,13 +217,15 @@ __global__ __launch_bounds__(V2_WAVES * 64) void k_v2_max(const unsigned short* 
   for (int it = 0; it < iters; ++it) {
     const int qt = q0 + 16 * it;                 // first row of this worker's 16-row slice
     const int nrows = q1 - qt < 16 ? (q1 - qt > 0 ? q1 - qt : 0) : 16;
-    if (it + 1 < iters) {                        // next tile: in flight during this tile's walk
-      const int row = lq0 + 16 * (it + 1) + ld_r;
-      const bool live = row < lq1;
-      const int rc = live ? row : (lq1 > 0 ? lq1 - 1 : 0);
+    bool live_n;
+    {                                            // next tile: in flight during this tile's products (unconditional: past the
+      const int row = lq0 + 16 * (it + 1) + ld_r;      // worker's last slice the clamped row is re-read and cleared)
+      live_n = row < lq1;
+      const int rc = live_n ? row : (lq1 > 0 ? lq1 - 1 : 0);
       pln = rowpil[rc];
-      v2_load_y(y1, rc, live, half, yn);
+      v2_load_y_raw(y1, rc, half, yn);
     }
+    __builtin_amdgcn_sched_barrier(0);           // the loads go out first
     int prow[16];                                // pillar of each of this worker's rows (uniform within the half-wave)
 #pragma unroll
     for (int r = 0; r < 16; ++r) prow[r] = __shfl(pl, v2_row(r, half), 64);   // the lane that loaded this worker's row r
@@ -225,6 +241,10 @@ __global__ __launch_bounds__(V2_WAVES * 64) void k_v2_max(const unsigned short* 
     f32x16 h[4];
 #pragma unroll
     for (int b = 0; b < 4; ++b) h[b] = v2_h(ya, sW, n, half, b);
+    // the next tile is waited for HERE, before this tile's stores go out: loads and stores retire out of order with respect to each
+    // other, so once stores are pending any wait for a load is a full drain of both
+    v2_keep_y(yn, live_n);
+    asm volatile("" : "+v"(pln));
     if (st[0] && cur_in >= 0) {                  // the pillar carried over from the previous tile ends here
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
