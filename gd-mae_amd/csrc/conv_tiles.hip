@@ -33,9 +33,18 @@ union CtFrag {
 #define CT_SITE_PITCH 272        // 128 bf16 + 16 bytes: consecutive sites advance one 16-byte bank quad
 #define CT_ROW_PITCH 2944        // 10 sites = 2720, padded to 128 (mod 256): patch rows alternate bank halves
 #define CT_TILE_PITCH 29440      // 10 patch rows
-#define CT_LDS_BYTES 58880       // two patches
+// CT_TPW tiles per workgroup (experiment switch): 2 = four wavefronts, two workgroups per CU; 4 = eight wavefronts, ONE workgroup per
+// CU whose wavefronts w and w + 4 stream the same weight fragments right after the same barrier (the second request meets the line
+// in the CU's L1: half the L2 -> CU weight stream for the same wavefronts per CU)
+#ifndef CT_TPW
+#define CT_TPW 2
+#endif
+#define CT_THREADS (CT_TPW * 128)
+#define CT_NWAVES (CT_TPW * 2)
+#define CT_LDS_BYTES (CT_TPW * CT_TILE_PITCH)       // the patches (58880 for two)
 #define CT_STAGE_PITCH 17408     // 64 sites x 272: epilogue staging of one tile
-#define CT_RED_OFF 34816         // after the two staging areas: (2 tiles, 4 waves, 2 stats, 128) fp32 = 8 KB
+#define CT_RED_OFF (CT_TPW * CT_STAGE_PITCH)        // after the staging areas: (tiles, waves, 2 stats, 128) fp32
+#define CT_SPP (CT_THREADS / 16)                    // patch entries per gather pass
 #define CT_MAX_SRC 3
 #define CT_NRED 256              // rows the per-tile statistics partials are pre-reduced to
 
@@ -255,14 +264,16 @@ struct CtArgs {
 // byte offset of k-step st (tap st >> 3, 16-channel step st & 7) inside the LDS patch
 #define CT_OFF(st) ((((st) >> 3) / 3) * CT_ROW_PITCH + (((st) >> 3) % 3) * CT_SITE_PITCH + ((st) & 7) * 32)
 
-__global__ __launch_bounds__(256, 2) void k_conv3x3_tiles(CtArgs A) {
+__global__ __launch_bounds__(CT_THREADS, CT_TPW == 2 ? 2 : 1) void k_conv3x3_tiles(CtArgs A) {
   extern __shared__ __align__(16) unsigned char lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int slot0 = blockIdx.x * 2;
-  int tb[2], ty0[2], tx0[2];
-  bool have[2];
+  const int tid = threadIdx.x, lane = tid & 63, wvg = tid >> 6;
+  const int wv = wvg & 3;              // output-channel block of the wavefront
+  const int tg = wvg >> 2;             // its pair of tiles
+  const int slot0 = blockIdx.x * CT_TPW;
+  int tb[CT_TPW], ty0[CT_TPW], tx0[CT_TPW];
+  bool have[CT_TPW];
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
+  for (int t = 0; t < CT_TPW; ++t) {
     have[t] = slot0 + t < A.n_act;
     const int tile = have[t] ? A.tile_list[slot0 + t] : 0;
     tx0[t] = (tile % A.TW) * 8;
@@ -273,7 +284,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_tiles(CtArgs A) {
   const int lc = tid & 15;     // 16-byte chunk (8 channels) of a 128-channel row
   const int lsg = tid >> 4;    // patch entry within a pass of 16
   // site operand: lane n = lane & 31 -> site (row n >> 3 of a 4-row half tile, column n & 7), k-group lane >> 5
-  const unsigned char* lb = lds + ((lane & 31) >> 3) * CT_ROW_PITCH + (lane & 7) * CT_SITE_PITCH + (lane >> 5) * 16;
+  const unsigned char* lb = lds + tg * 2 * CT_TILE_PITCH + ((lane & 31) >> 3) * CT_ROW_PITCH + (lane & 7) * CT_SITE_PITCH + (lane >> 5) * 16;
   f32x16 acc0, acc1, acc2, acc3;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc0[i] = acc1[i] = acc2[i] = acc3[i] = 0.f;
@@ -301,10 +312,10 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_tiles(CtArgs A) {
       int code[13];   // >= 0: row of P, -1: background, -2: zero (outside the map), -3: nothing to write
 #pragma unroll
       for (int p = 0; p < 13; ++p) {
-        const int e = p * 16 + lsg;
+        const int e = p * CT_SPP + lsg;
         int c = -3;
-        if (e < 200) {
-          const int t = e >= 100;
+        if (e < 100 * CT_TPW) {
+          const int t = e / 100;
           const int r = e - 100 * t;
           const int py = r / 10, px = r - py * 10;
           if (have[t]) {
@@ -325,8 +336,8 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_tiles(CtArgs A) {
 #pragma unroll
       for (int p = 0; p < 13; ++p) {
         if (code[p] == -3) continue;
-        const int e = p * 16 + lsg;
-        const int t = e >= 100;
+        const int e = p * CT_SPP + lsg;
+        const int t = e / 100;
         const int r = e - 100 * t;
         const int py = r / 10, px = r - py * 10;
         uint4 o;
@@ -387,7 +398,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_tiles(CtArgs A) {
     uint2 o;                                                                                                           \
     o.x = ct_pack2(acc[4 * j], acc[4 * j + 1]);                                                                        \
     o.y = ct_pack2(acc[4 * j + 2], acc[4 * j + 3]);                                                                    \
-    *(uint2*)(lds + ((sb) >> 1) * CT_STAGE_PITCH + (((sb) & 1) * 32 + n) * CT_SITE_PITCH + (cb + 8 * j) * 2) = o;      \
+    *(uint2*)(lds + (tg * 2 + ((sb) >> 1)) * CT_STAGE_PITCH + (((sb) & 1) * 32 + n) * CT_SITE_PITCH + (cb + 8 * j) * 2) = o; \
   }
     CT_STAGE(acc0, 0)
     CT_STAGE(acc1, 1)
@@ -398,14 +409,14 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_tiles(CtArgs A) {
   __syncthreads();
   float* red = (float*)(lds + CT_RED_OFF);
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
+  for (int t = 0; t < CT_TPW; ++t) {
     if (!have[t]) continue;
     float s[8], q2[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) s[j] = q2[j] = 0.f;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const int site = p * 16 + lsg;
+    for (int p = 0; p < 64 / CT_SPP; ++p) {
+      const int site = p * CT_SPP + lsg;
       const uint4 v = *(const uint4*)(lds + t * CT_STAGE_PITCH + site * CT_SITE_PITCH + lc * 16);
       *(uint4*)(A.Yc + ((long long)(slot0 + t) * GD_TILE_SITES + site) * CT_C + lc * 8) = v;
       if (ty0[t] + (site >> 3) < A.H && tx0[t] + (site & 7) < A.W) {
@@ -428,19 +439,19 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_tiles(CtArgs A) {
     if (lane < 16) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        red[((t * 4 + wv) * 2 + 0) * CT_C + lc * 8 + j] = s[j];
-        red[((t * 4 + wv) * 2 + 1) * CT_C + lc * 8 + j] = q2[j];
+        red[((t * CT_NWAVES + wvg) * 2 + 0) * CT_C + lc * 8 + j] = s[j];
+        red[((t * CT_NWAVES + wvg) * 2 + 1) * CT_C + lc * 8 + j] = q2[j];
       }
     }
   }
   __syncthreads();
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    if (!have[t]) continue;
+  for (int t = 0; t < CT_TPW; ++t) {
+    if (!have[t] || tid >= 256) continue;
     const int stat = tid >> 7, ch = tid & 127;
     float v = 0.f;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) v += red[((t * 4 + w) * 2 + stat) * CT_C + ch];
+    for (int w = 0; w < CT_NWAVES; ++w) v += red[((t * CT_NWAVES + w) * 2 + stat) * CT_C + ch];
     A.part[(long long)(slot0 + t) * 256 + tid] = v;
   }
 }
@@ -550,7 +561,12 @@ extern "C" int gdmae_conv3x3_tiles_fwd(const void* const* P, const int* const* m
   float* red = ar.take<float>((size_t)(CT_NRED + 2) * 256);
   A.part = part;
   if (n_act > 0) {
-    hipLaunchKernelGGL(k_conv3x3_tiles, dim3((n_act + 1) / 2), dim3(256), CT_LDS_BYTES, st, A);
+    static bool once = false;
+    if (!once) {
+      GD_CHECK(hipFuncSetAttribute((const void*)k_conv3x3_tiles, hipFuncAttributeMaxDynamicSharedMemorySize, CT_LDS_BYTES));
+      once = true;
+    }
+    hipLaunchKernelGGL(k_conv3x3_tiles, dim3((n_act + CT_TPW - 1) / CT_TPW), dim3(CT_THREADS), CT_LDS_BYTES, st, A);
     GD_LAUNCH_CHECK();
   }
   hipLaunchKernelGGL(k_ct_stats_reduce, dim3(CT_NRED + 1), dim3(256), 0, st, (const float*)part, n_act, tile_list,
