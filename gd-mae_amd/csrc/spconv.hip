@@ -51,7 +51,10 @@ constexpr int kWaves = 8;
 #endif
 template <int CIN, int COUT, bool SRC_F32>
 struct SpRows {
-  static constexpr int value = COUT >= 256 ? ((SRC_F32 && CIN >= 256) ? 32 : SP_ROWS256) : 64;
+#ifndef SP_ROWS128
+#define SP_ROWS128 128       // rows per workgroup at 128 -> 128 with bf16 rows (experiment switch; 64 = before)
+#endif
+  static constexpr int value = COUT >= 256 ? ((SRC_F32 && CIN >= 256) ? 32 : SP_ROWS256) : ((CIN == 128 && !SRC_F32) ? SP_ROWS128 : 64);
 };
 
 template <int CIN, int COUT, bool SRC_F32>
@@ -60,7 +63,9 @@ __global__ __launch_bounds__(512, 2) void k_spconv(SpArgs A) {
   constexpr int KS = CIN / 16;                     // k-steps per tap
   constexpr int MB = COUT / 32;                    // 32-channel blocks
   constexpr int MPW = MB >= kWaves ? MB / kWaves : 1;
-  constexpr int NPW = MB >= kWaves ? ROWS / 32 : 1;
+  constexpr int WPB = MB >= kWaves ? 1 : kWaves / MB;         // wavefronts that share a 32-channel block (they split the rows)
+  constexpr int NPW = (ROWS / 32) / WPB;                      // 32-row blocks per wavefront (they share its weight fragments)
+  static_assert(NPW >= 1 && NPW * WPB * 32 == ROWS, "row blocks");
   constexpr int XP = CIN * 2 + 16;                 // LDS row pitch of a gathered tile (conflict-free ds_read_b128)
   constexpr int SP = COUT * 2 + 16;                // ... of the output staging tile
   constexpr int CPR = CIN / 8;                     // 16-byte chunks per gathered row
@@ -70,8 +75,8 @@ __global__ __launch_bounds__(512, 2) void k_spconv(SpArgs A) {
   extern __shared__ __align__(16) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const long long row0 = (long long)blockIdx.x * ROWS;
-  const int mb0 = MB >= kWaves ? wv : (wv >> 1);
-  const int nb0 = MB >= kWaves ? 0 : (wv & 1);
+  const int mb0 = wv / WPB;
+  const int nb0 = (wv % WPB) * NPW;
   const uint4* __restrict__ wp = A.Wp + (size_t)mb0 * 64 + lane;        // + (gstep * MB + j * kWaves) * 64
 
   // ---- weight fragments: a ring of ONE WHOLE TAP (KS k-steps).  Step ks of tap t multiplies slot ks and reloads it with the
@@ -81,7 +86,7 @@ __global__ __launch_bounds__(512, 2) void k_spconv(SpArgs A) {
   // the gather has the whole tap of MFMAs to land.
   // (CIN = 256 with 64-row tiles or fp32 rows: half a tap, both: a quarter - the whole one does not fit 128 registers next to the
   // gathered rows.)
-  constexpr int RING = (KS == 16 && (ROWS == 64 || SRC_F32)) ? ((SRC_F32 && ROWS == 64) ? 4 : 8) : KS;
+  constexpr int RING = (KS == 16 && (ROWS == 64 || SRC_F32)) ? ((SRC_F32 && ROWS == 64) ? 4 : 8) : ((KS == 8 && ROWS == 128) ? 4 : KS);
   SpFrag wr[RING][MPW];
 #pragma unroll
   for (int ks = 0; ks < RING; ++ks)
