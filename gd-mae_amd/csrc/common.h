@@ -148,6 +148,32 @@ __device__ inline T gd_block_exclusive_scan(T v, T& total, T* smem /* BLOCK/64 +
   return excl;
 }
 
+// Sum over the LPR (16 / 32 / 64) consecutive lanes of a lane group, result in every lane of the group, WITHOUT the LDS crossbar:
+// `__shfl_xor` is a ds_bpermute (an LDS-pipe operation with its own wait) - the LayerNorm row passes of the fused layer kernels issued 56
+// of them per thread, one dependent round trip each.  DPP row operations (quad permutes, half-row and row mirrors) cover the first
+// four steps at VALU rate, v_permlane16_swap / v_permlane32_swap (gfx950) the last two.  Every lane of a group ends with the same
+// bits (each step adds two partial sums that are the same pair in both lanes).
+template <int CTRL>
+__device__ __forceinline__ float gd_dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+template <int LPR>
+__device__ __forceinline__ float gd_group_sum(float v) {
+  static_assert(LPR == 16 || LPR == 32 || LPR == 64, "lane group");
+  v += gd_dpp_mov<0xB1>(v);        // quad_perm [1, 0, 3, 2]: lane ^ 1
+  v += gd_dpp_mov<0x4E>(v);        // quad_perm [2, 3, 0, 1]: lane ^ 2
+  v += gd_dpp_mov<0x141>(v);       // row_half_mirror: the other quad of the 8-lane half row
+  v += gd_dpp_mov<0x140>(v);       // row_mirror: the other half of the 16-lane row
+  if (LPR >= 32) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);       // rows 0 + 1, 2 + 3
+  }
+  if (LPR >= 64) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);       // both halves of the wavefront
+  }
+  return v;
+}
 __device__ inline float gd_wave_sum(float v) {
 #pragma unroll
   for (int d = GD_WAVE / 2; d > 0; d >>= 1) v += __shfl_xor(v, d, GD_WAVE);

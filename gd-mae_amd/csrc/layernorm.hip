@@ -18,9 +18,7 @@ __device__ inline unsigned short f_to_bf16(float f) { return gd_to_bf16(f); }
 // inside the LPR-lane group.
 template <int LPR>
 __device__ inline float ln_group_sum(float v) {
-#pragma unroll
-  for (int d = LPR / 2; d > 0; d >>= 1) v += __shfl_xor(v, d, GD_WAVE);
-  return v;
+  return gd_group_sum<LPR>(v);       // the same reduction as the fused epilogues (tok_tiles.h): rows stay bit-identical to them
 }
 __device__ inline void ln_ld4(const float* __restrict__ p, long long e, float (&v)[4]) {
   const float4 q = *reinterpret_cast<const float4*>(p + e);

@@ -125,9 +125,7 @@ __device__ inline float tg_gelu_grad(float h) {
 // sum over the LPR (power of two, <= 64) consecutive lanes that share a row
 template <int LPR>
 __device__ inline float tg_group_sum(float v) {
-#pragma unroll
-  for (int d = LPR / 2; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
-  return v;
+  return gd_group_sum<LPR>(v);       // DPP / permlane swaps instead of six ds_bpermute round trips (common.h)
 }
 
 // ------------------------------------------------------------------------------------------------
