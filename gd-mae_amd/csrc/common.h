@@ -159,7 +159,7 @@ __device__ __forceinline__ float gd_dpp_mov(float v) {
 }
 template <int LPR>
 __device__ __forceinline__ float gd_group_sum(float v) {
-  static_assert(LPR == 16 || LPR == 32 || LPR == 64, "lane group");
+  static_assert(LPR >= 16 && (LPR & (LPR - 1)) == 0, "lane group");      // > 64 (instantiated for shapes that never launch) acts as 64
   v += gd_dpp_mov<0xB1>(v);        // quad_perm [1, 0, 3, 2]: lane ^ 1
   v += gd_dpp_mov<0x4E>(v);        // quad_perm [2, 3, 0, 1]: lane ^ 2
   v += gd_dpp_mov<0x141>(v);       // row_half_mirror: the other quad of the 8-lane half row
