@@ -309,7 +309,21 @@ __global__ __launch_bounds__(CT_THREADS, CT_TPW == 2 ? 2 : 1) void k_conv3x3_til
       }
       const int ls = S.ls, sm = (1 << ls) - 1;
       const int Hs = A.H >> ls, Ws = A.W >> ls;
+      // The 13 cell -> token lookups of a thread are requested together and unconditionally (entries outside the map or past the
+      // patches read cell 0 and ignore it), then the 13 rows (row 0 of a readable stand-in for background / outside / unused entries
+      // and for a stage without rows): behind its own `if` every load was followed by a drain of the load counter at the join.
       int code[13];   // >= 0: row of P, -1: background, -2: zero (outside the map), -3: nothing to write
+      int tokv[13];
+#pragma unroll
+      for (int p = 0; p < 13; ++p) {
+        const int e = p * CT_SPP + lsg;
+        const int t = e / 100 < CT_TPW ? e / 100 : CT_TPW - 1;
+        const int r = e - 100 * (e / 100);
+        const int py = r / 10, px = r - py * 10;
+        const int y = ty0[t] + py - 1, x = tx0[t] + px - 1;
+        const bool inb = e < 100 * CT_TPW && have[t] && y >= 0 && y < A.H && x >= 0 && x < A.W;
+        tokv[p] = S.map[inb ? (tb[t] * Hs + (y >> ls)) * Ws + (x >> ls) : 0];
+      }
 #pragma unroll
       for (int p = 0; p < 13; ++p) {
         const int e = p * CT_SPP + lsg;
@@ -322,17 +336,17 @@ __global__ __launch_bounds__(CT_THREADS, CT_TPW == 2 ? 2 : 1) void k_conv3x3_til
             const int y = ty0[t] + py - 1, x = tx0[t] + px - 1;
             c = -2;
             if (y >= 0 && y < A.H && x >= 0 && x < A.W) {
-              const int tok = S.map[(tb[t] * Hs + (y >> ls)) * Ws + (x >> ls)];
+              const int tok = tokv[p];
               c = tok < 0 ? -1 : (((tok << ls) + (y & sm)) << ls) + (x & sm);
             }
           }
         }
         code[p] = c;
       }
+      const unsigned short* __restrict__ Prows = S.P ? S.P : (const unsigned short*)S.a;      // a: 128 floats, readable as one row
       uint4 q[13];
 #pragma unroll
-      for (int p = 0; p < 13; ++p)
-        if (code[p] >= 0) q[p] = *(const uint4*)(S.P + (long long)code[p] * CT_C + lc * 8);
+      for (int p = 0; p < 13; ++p) q[p] = *(const uint4*)(Prows + (long long)(code[p] >= 0 ? code[p] : 0) * CT_C + lc * 8);
 #pragma unroll
       for (int p = 0; p < 13; ++p) {
         if (code[p] == -3) continue;
