@@ -95,13 +95,22 @@ template <int ND>
 struct TgRows {
   static constexpr int value = ND >= 256 ? 32 : 64;
 };
+// ... per epilogue: the plain products (q / k / v projections: no row pass, nothing but the weight image re-streamed per tile
+// competes with their rows) take TG_PLAIN_ROWS at ND = 256 (experiment switch)
+#ifndef TG_PLAIN_ROWS
+#define TG_PLAIN_ROWS 32
+#endif
+template <int ND, int EPI>
+struct TgRowsE {
+  static constexpr int value = (EPI == TG_PLAIN && ND >= 256) ? TG_PLAIN_ROWS : TgRows<ND>::value;
+};
 
 // One row tile.  tile: index of the tile (rows tile * ROWS ..); mbs: 32-channel blocks per k-step of the packed weight image
 // A.Wp points into (MB for a whole image, more when the workgroup owns a channel slice of a wider one); ldo: row pitch of out0
 // in elements (plain epilogue only)
 template <int KD, int ND, int EPI>
 __device__ __forceinline__ void tg_tile(const TgArgs& A, const long long tile, const int mbs, const int ldo) {
-  constexpr int ROWS = TgRows<ND>::value;   // 4 waves per SIMD = two workgroups per CU: <= 128 VGPRs
+  constexpr int ROWS = TgRowsE<ND, EPI>::value;   // 4 waves per SIMD = two workgroups per CU: <= 128 VGPRs
   constexpr int KS = KD / 16;                       // k-steps
   constexpr int MB = ND / 32;                       // 32-channel blocks of the output
   constexpr int MPW = MB >= TG_WAVES ? MB / TG_WAVES : 1;   // channel blocks per wavefront
@@ -432,7 +441,7 @@ __global__ __launch_bounds__(512, 4) void k_tok_gemm_multi(TgMulti M) {
 
 template <int KD, int ND>
 static int tg_launch_multi(const TgMulti& M, hipStream_t st) {
-  constexpr int ROWS = TgRows<ND>::value;
+  constexpr int ROWS = TgRowsE<ND, TG_PLAIN>::value;
   constexpr int lds = ROWS * ((KD > ND ? KD : ND) * 2 + 16);
   static bool once = false;
   if (!once) {
@@ -449,7 +458,7 @@ static int tg_launch_multi(const TgMulti& M, hipStream_t st) {
 
 template <int KD, int ND, int EPI>
 static int tg_launch(const TgArgs& A, hipStream_t st) {
-  constexpr int ROWS = TgRows<ND>::value;
+  constexpr int ROWS = TgRowsE<ND, EPI>::value;
   constexpr int lds_tile = ROWS * ((KD > ND ? KD : ND) * 2 + 16);
   constexpr int lds_red = EPI == TG_LN_BWD ? (512 / (ND / 4)) * 3 * ND * 4 : 0;
   constexpr int lds = lds_tile > lds_red ? lds_tile : lds_red;
