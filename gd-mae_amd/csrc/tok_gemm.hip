@@ -98,7 +98,7 @@ struct TgRows {
 // ... per epilogue: the plain products (q / k / v projections: no row pass, nothing but the weight image re-streamed per tile
 // competes with their rows) take TG_PLAIN_ROWS at ND = 256 (experiment switch)
 #ifndef TG_PLAIN_ROWS
-#define TG_PLAIN_ROWS 32
+#define TG_PLAIN_ROWS 64
 #endif
 template <int ND, int EPI>
 struct TgRowsE {
