@@ -79,7 +79,10 @@ __device__ __forceinline__ void rg_store_tile(const unsigned char* src, int P, u
 
 template <int NSL>
 struct RgRows {
-  static constexpr int value = NSL >= 256 ? 32 : 64;
+#ifndef RG_ROWS_WIDE
+#define RG_ROWS_WIDE 64       // rows per workgroup for column slices >= 256 (32 before: deconvolution rows 217 -> 198 us per step)
+#endif
+  static constexpr int value = NSL >= 256 ? RG_ROWS_WIDE : 64;
 };
 
 struct RgArgs {
