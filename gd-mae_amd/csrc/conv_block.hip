@@ -100,7 +100,15 @@ __global__ __launch_bounds__(256) void k_spconv_dw_reduce(const float* __restric
     const long long r = e % mn4;
     const float4* p = reinterpret_cast<const float4*>(part + k * per_tap) + r;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int s = 0; s < S; ++s) {
+    int s = 0;
+    for (; s + 8 <= S; s += 8) {                   // eight slices in flight, added in slice order (bit-identical to the serial loop)
+      float4 v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = p[(long long)(s + j) * mn4];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { acc.x += v[j].x; acc.y += v[j].y; acc.z += v[j].z; acc.w += v[j].w; }
+    }
+    for (; s < S; ++s) {
       const float4 v = p[(long long)s * mn4];
       acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }

@@ -155,7 +155,15 @@ __global__ __launch_bounds__(256) void k_deconv_dw_reduce(const float* __restric
   const long long P = (long long)cin * ss * cout;
   for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < P; e += (long long)gridDim.x * blockDim.x) {
     float a = 0.f;
-    for (int s = 0; s < S; ++s) a += part[(long long)s * P + e];
+    int s = 0;
+    for (; s + 8 <= S; s += 8) {                   // eight slices in flight, added in slice order
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = part[(long long)(s + j) * P + e];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a += v[j];
+    }
+    for (; s < S; ++s) a += part[(long long)s * P + e];
     const int n = (int)(e % (ss * cout)), ci = (int)(e / (ss * cout));
     const int q = n / cout, c = n - q * cout;
     dW[((long long)ci * cout + c) * ss + q] += a;
@@ -303,6 +311,20 @@ __global__ __launch_bounds__(512, 2) void k_pred_bwd_input(PbArgs A) {
 
 // dW[o][ci] += sum_s part[s][o][ci] (o < n_out; part (S, 128, 128) from the grouped TN kernel with G = dY zero-padded to 128
 // columns), db[o] += sum_s colpart[s][o]: fixed order
+// sum of S slice values at stride `st`, eight loads in flight, added in slice order (bit-identical to a one-load-per-iteration loop)
+__device__ __forceinline__ float rg_slice_sum(const float* __restrict__ p, int S, long long st) {
+  float a = 0.f;
+  int s = 0;
+  for (; s + 8 <= S; s += 8) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = p[(long long)(s + j) * st];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a += v[j];
+  }
+  for (; s < S; ++s) a += p[(long long)s * st];
+  return a;
+}
 __global__ __launch_bounds__(256) void k_pred_dw_reduce(const float* __restrict__ part, const float* __restrict__ colpart, int S, int n_out,
                                                         float* __restrict__ dW, float* __restrict__ db) {
   const int total = n_out * kPredK + n_out;
@@ -311,10 +333,10 @@ __global__ __launch_bounds__(256) void k_pred_dw_reduce(const float* __restrict_
     float a = 0.f;
     if (is_b) {
       const int o = e - n_out * kPredK;
-      for (int s = 0; s < S; ++s) a += colpart[(long long)s * 128 + o];
+      a += rg_slice_sum(colpart + o, S, 128);
       if (db) db[o] += a;
     } else {
-      for (int s = 0; s < S; ++s) a += part[(long long)s * 128 * kPredK + e];
+      a += rg_slice_sum(part + e, S, 128ll * kPredK);
       dW[e] += a;
     }
   }

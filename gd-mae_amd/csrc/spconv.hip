@@ -305,8 +305,19 @@ __global__ __launch_bounds__(256) void k_tap_dw_reduce(const float* __restrict__
     const long long km = e / N;
     const int m = (int)(km % M), k = (int)(km / M);
     const float* p = part + k * per_tap + (long long)m * N + n;
+    // eight slices requested before the first is added (same order of additions: bit-identical to the one-load-per-iteration loop,
+    // which was S serial round trips per thread)
+    const long long st = (long long)M * N;
     float acc = 0.f;
-    for (int s = 0; s < S; ++s) acc += p[(long long)s * M * N];
+    int s = 0;
+    for (; s + 8 <= S; s += 8) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = p[(long long)(s + j) * st];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc += v[j];
+    }
+    for (; s < S; ++s) acc += p[(long long)s * st];
     out[((long long)k * N + n) * ld_out + m_off + m] += acc;
   }
 }
