@@ -15,6 +15,11 @@
 // behind the MFMAs) and writes its fp32 partial tile; partial tiles are summed in a fixed order by the caller's reduce
 // kernel (deterministic).  All tiles of a slice - every matrix of the layer - are placed on ONE XCD (blockIdx % 8), so
 // the 2-4x re-reads of a slice's activations by the tiles that share them are served by that XCD's L2.
+//
+// Load discipline (round 4, what the ISA said - DESIGN 9): the kernel is templated on the X addressing mode and every load is
+// unconditional (clamped indices, masks applied when a chunk is staged), so that no control-flow path joins another with loads in
+// flight: the compiler's wait insertion answered every such join with `s_waitcnt vmcnt(0)`, i.e. it drained the loads of chunk c + 2
+// before the products of chunk c (132 -> 92 us for the five gradients of a d = 256 layer at 49 k rows).
 #include "common.h"
 #include "dw_grouped.h"
 #include <stdlib.h>

@@ -6,7 +6,7 @@
 //
 // Round 2 materialised the im2col matrix (n x 9 CIN bf16: 207 MB for the 256 -> 256 block of stage 2), ran a library GEMM
 // over it and kept it for the weight gradient; the input gradient did the same over the transposed rulebook.  Here the
-// gathered rows never leave the CU: a workgroup (8 wavefronts) owns 32 or 64 output rows and the FULL output width; per tap
+// gathered rows never leave the CU: a workgroup (8 wavefronts) owns 32, 64 or 128 output rows (SpRows) and the FULL output width; per tap
 // it gathers its rows' CIN-vectors through the rulebook straight into an LDS tile (the next tap's rows are in flight in
 // registers while the current tap is multiplied), and accumulates Y^T = W X^T with v_mfma_f32_32x32x16_bf16 exactly as
 // the token GEMMs do (A = weights streamed in fragment order from a packed image - 9 per-tap images back to back, refreshed
