@@ -376,7 +376,14 @@ int gd_dw_grouped_s(hipStream_t st, GdDwGroup& A, long long n_pad, long long n_v
     fl += 2.0 * n_valid * (double)A.job[j].M * A.job[j].N;
   }
   GdTimed timed(GD_T_DW_GROUPED, st, by, fl);
-  GD_REQUIRE(n_valid >= 1 && n_pad < (1ll << 31), "dw_grouped: row count");
+  GD_REQUIRE(n_valid >= 0 && n_pad < (1ll << 31), "dw_grouped: row count");
+  if (n_valid == 0) {                    // no rows (an empty stage): the partial tiles are zero; the kernel's clamped loads need a row 0
+    for (int j = 0; j < A.n_jobs; ++j) {
+      GD_CHECK(hipMemsetAsync(A.job[j].part, 0, (size_t)A.S * A.job[j].M * A.job[j].N * sizeof(float), st));
+      if (A.job[j].colpart) GD_CHECK(hipMemsetAsync(A.job[j].colpart, 0, (size_t)A.S * A.job[j].M * sizeof(float), st));
+    }
+    return 0;
+  }
   const int xm = A.job[0].xidx ? (A.job[0].x_f32 ? 2 : 1) : 0;
   for (int j = 1; j < A.n_jobs; ++j)
     GD_REQUIRE((A.job[j].xidx ? (A.job[j].x_f32 ? 2 : 1) : 0) == xm, "dw_grouped: the jobs of a launch share the X addressing mode");
