@@ -523,6 +523,21 @@ int gd_attn_t3264_bwd(const void* qk, const void* v, const void* dout, void* dqk
                       const int* wl32, int n32, float* part32, const int* ws64, const int* wl64, int n64, float* part64, int d, int H,
                       const float* tau, float tau_min, hipStream_t st);
 
+// workgroup-cooperative variant of the same two levels (attention_coop.hip, round 5): whole row segments through LDS, 16 bytes per lane
+int gd_attn_coop_fwd(const void* qk, const void* v, void* out, const int* csr_tok, const int* ws32, const int* wl32, int n32, const int* ws64,
+                     const int* wl64, int n64, int d, int H, const float* tau, float tau_min, hipStream_t st);
+int gd_attn_coop_bwd(const void* qk, const void* v, const void* dout, void* dqk, void* dv, const int* csr_tok, const int* ws32, const int* wl32,
+                     int n32, float* part32, const int* ws64, const int* wl64, int n64, float* part64, int d, int H, const float* tau,
+                     float tau_min, hipStream_t st);
+
+// ... all levels of a layer merged: forward one launch, backward T = 64 | T = 32 + T = 16 (attention_coop.hip)
+int gd_attn_levels_fwd(const void* qk, const void* v, void* out, const int* csr_tok, const int* ws16, const int* wl16, int n16, const int* ws32,
+                       const int* wl32, int n32, const int* ws64, const int* wl64, int n64, int d, int H, const float* tau, float tau_min,
+                       hipStream_t st);
+int gd_attn_levels_bwd(const void* qk, const void* v, const void* dout, void* dqk, void* dv, const int* csr_tok, const int* ws16, const int* wl16,
+                       int n16, float* part16, const int* ws32, const int* wl32, int n32, float* part32, const int* ws64, const int* wl64, int n64,
+                       float* part64, int d, int H, const float* tau, float tau_min, hipStream_t st);
+
 // bf16-MFMA variant of the T = 16 level for bf16 token I/O (attention_t16.hip)
 int gd_attn_t16_fwd(const void* qk, const void* v, void* out, const int* csr_tok, const int* win_start, const int* win_len, int n_win,
                     int d, int H, const float* tau, float tau_min, hipStream_t st);
@@ -531,10 +546,13 @@ int gd_attn_t16_bwd(const void* qk, const void* v, const void* dout, void* dqk, 
 
 // 0: bf16 I/O on the bf16 matrix-core kernels at every level (attention_t16.hip, attention_t32.hip), fp32 I/O
 //    on the exact-fp32 MFMA kernels for T >= 32 and the lane-per-query VALU kernels for T = 16;
-// 1: VALU kernels only;  2: like 0 but always the exact-fp32 MFMA kernels for T >= 32 and the VALU kernels for T = 16
+// 1: VALU kernels only;  2: like 0 but always the exact-fp32 MFMA kernels for T >= 32 and the VALU kernels for T = 16;
+// 3: like 0 with the round-4 one-wavefront-per-(window, head) kernels for the bf16 T = 32 / 64 levels (attention_t32.hip) instead of the
+//    workgroup-cooperative ones (attention_coop.hip) - A/B reference
 static int g_attn_impl = 0;
+static inline bool attn_auto() { return g_attn_impl == 0 || g_attn_impl == 3; }
 extern "C" int gdmae_set_attention_impl(int impl) {
-  GD_REQUIRE(impl >= 0 && impl <= 2, "attention impl: 0 (auto), 1 (VALU only) or 2 (fp32 MFMA)");
+  GD_REQUIRE(impl >= 0 && impl <= 3, "attention impl: 0 (auto), 1 (VALU only), 2 (fp32 MFMA) or 3 (auto, per-(window, head) bf16 kernels)");
   g_attn_impl = impl;
   return 0;
 }
@@ -551,9 +569,12 @@ extern "C" int gdmae_window_attention_fwd(const void* qk, const void* v, void* o
   GD_REQUIRE(T == 16 || T == 32 || T == 64, "T must be 16/32/64");
   GD_REQUIRE(H % (GD_WAVE / T) == 0, "heads must pack evenly into a wavefront");
   hipStream_t st = (hipStream_t)stream;
-  if (g_attn_impl == 0 && T == 16 && io_bf16 && H % 4 == 0)
+  if (attn_auto() && T == 16 && io_bf16 && H % 4 == 0)
     return gd_attn_t16_fwd(qk, v, out, csr_tok, win_start, win_len, n_win, d, H, tau, tau_min, st);
-  if (g_attn_impl == 0 && T >= 32 && io_bf16)
+  if (g_attn_impl == 0 && T >= 32 && io_bf16 && H % 4 == 0)
+    return T == 32 ? gd_attn_coop_fwd(qk, v, out, csr_tok, win_start, win_len, n_win, nullptr, nullptr, 0, d, H, tau, tau_min, st)
+                   : gd_attn_coop_fwd(qk, v, out, csr_tok, nullptr, nullptr, 0, win_start, win_len, n_win, d, H, tau, tau_min, st);
+  if (attn_auto() && T >= 32 && io_bf16)
     return gd_attn_t32_fwd(qk, v, out, csr_tok, win_start, win_len, n_win, T, d, H, tau, tau_min, st);
   if (g_attn_impl != 1 && T >= 32)
     return gd_attn_mfma_fwd(qk, v, out, io_bf16, csr_tok, win_start, win_len, n_win, T, d, H, tau, tau_min, st);
@@ -572,9 +593,14 @@ extern "C" int gdmae_window_attention_bwd(const void* qk, const void* v, const v
   GD_REQUIRE(T == 16 || T == 32 || T == 64, "T must be 16/32/64");
   GD_REQUIRE(H % (GD_WAVE / T) == 0, "heads must pack evenly into a wavefront");
   hipStream_t st = (hipStream_t)stream;
-  if (g_attn_impl == 0 && T == 16 && io_bf16 && H % 4 == 0)
+  if (attn_auto() && T == 16 && io_bf16 && H % 4 == 0)
     return gd_attn_t16_bwd(qk, v, dout, dqk, dv, dtau_part, csr_tok, win_start, win_len, n_win, d, H, tau, tau_min, st);
-  if (g_attn_impl == 0 && T >= 32 && io_bf16)
+  if (g_attn_impl == 0 && T >= 32 && io_bf16 && H % 4 == 0)
+    return T == 32 ? gd_attn_coop_bwd(qk, v, dout, dqk, dv, csr_tok, win_start, win_len, n_win, dtau_part, nullptr, nullptr, 0, nullptr, d, H, tau,
+                                      tau_min, st)
+                   : gd_attn_coop_bwd(qk, v, dout, dqk, dv, csr_tok, nullptr, nullptr, 0, nullptr, win_start, win_len, n_win, dtau_part, d, H, tau,
+                                      tau_min, st);
+  if (attn_auto() && T >= 32 && io_bf16)
     return gd_attn_t32_bwd(qk, v, dout, dqk, dv, dtau_part, csr_tok, win_start, win_len, n_win, T, d, H, tau, tau_min, st);
   if (g_attn_impl != 1 && T >= 32)
     return gd_attn_mfma_bwd(qk, v, dout, dqk, dv, io_bf16, dtau_part, csr_tok, win_start, win_len, n_win, T, d, H, tau,
@@ -597,7 +623,7 @@ static double attn_alg_bytes(int n_levels, const int* n_win, const int* win_len_
 }
 
 static bool levels_fast_path(int io_bf16, int n_levels, const int* max_tokens, int H, int d) {
-  if (g_attn_impl != 0 || !io_bf16 || H % 4 != 0 || d % H != 0 || (d / H != 16 && d / H != 32)) return false;
+  if (!attn_auto() || !io_bf16 || H % 4 != 0 || d % H != 0 || (d / H != 16 && d / H != 32)) return false;
   for (int l = 0; l < n_levels; ++l)
     if (max_tokens[l] != 16 && max_tokens[l] != 32 && max_tokens[l] != 64) return false;
   return true;
@@ -628,6 +654,8 @@ extern "C" int gdmae_window_attention_levels_fwd(const void* qk, const void* v, 
     ws[k] = win_start + base; wl[k] = win_len + base; nw[k] = n_win[l];
     base += n_win[l];
   }
+  if (g_attn_impl == 0)
+    return gd_attn_levels_fwd(qk, v, out, csr_tok, ws[0], wl[0], nw[0], ws[1], wl[1], nw[1], ws[2], wl[2], nw[2], d, H, tau, tau_min, st);
   if (nw[0] > 0) {
     const int rc = gd_attn_t16_fwd(qk, v, out, csr_tok, ws[0], wl[0], nw[0], d, H, tau, tau_min, st);
     if (rc != 0) return rc;
@@ -665,6 +693,9 @@ extern "C" int gdmae_window_attention_levels_bwd(const void* qk, const void* v, 
     base += n_win[l];
     pbase += (long long)n_win[l] * H;
   }
+  if (g_attn_impl == 0)
+    return gd_attn_levels_bwd(qk, v, dout, dqk, dv, csr_tok, ws[0], wl[0], nw[0], part[0], ws[1], wl[1], nw[1], part[1], ws[2], wl[2], nw[2], part[2],
+                              d, H, tau, tau_min, st);
   if (nw[0] > 0) {
     const int rc = gd_attn_t16_bwd(qk, v, dout, dqk, dv, part[0], csr_tok, ws[0], wl[0], nw[0], d, H, tau, tau_min, st);
     if (rc != 0) return rc;

@@ -1,0 +1,502 @@
+// Workgroup-cooperative bf16-MFMA windowed cosine attention, T = 32 / 64 occupancy levels (throughput mode; round 5).
+//
+// Contract and arithmetic: reference cosine_msa.py:114-176 / sst_basic_block.py:22-54 through the window CSR, exactly as
+// attention_t32.hip (raw-operand logits normalised on the accumulator, S^T layout for the forward and dQ, S layout for dK / dV, no
+// atomics).  What is new is how rows travel (attn_tiles.h): a workgroup = one window x HW heads whose row segments are contiguous
+// (T = 64: 2 heads x 2 wavefronts, T = 32: 4 heads x 1 wavefront); all 256 threads load the q / k / v (/ dO) segments of the window's rows
+// 16 bytes per lane - whole cache lines - into the swizzled LDS tiles, the wavefronts take their MFMA operand pieces from there, and the
+// results go back through the same tiles as 16-byte row segments.  The row norms are taken in the cooperative pass (adjacent lanes
+// hold a head's chunks), the window descriptor is a scalar load (the window is uniform per workgroup).
+#include "attn_tiles.h"
+#include "attn16_wave.h"
+#include <stdlib.h>
+
+using namespace attn;
+
+namespace {
+struct CArgs {
+  const unsigned short* qk;
+  const unsigned short* v;
+  unsigned short* out;
+  const int* csr_tok;
+  const int* win_start;
+  const int* win_len;
+  int n_win, d, H;
+  const float* tau;
+  float tau_min;
+};
+struct CBwdArgs {
+  const unsigned short* qk;
+  const unsigned short* v;
+  const unsigned short* dout;
+  unsigned short* dqk;
+  unsigned short* dv;
+  float* dtau_part;
+  const int* csr_tok;
+  const int* win_start;
+  const int* win_len;
+  int n_win, d, H;
+  const float* tau;
+  float tau_min;
+};
+
+// LDS per head: tiles of ROWS x 64 B + per-row scalars
+template <int ROWS>
+constexpr int fwd_head_lds() { return 3 * ROWS * kPitch * 2 + 2 * ROWS * 4; }           // Q, K, V | 1 / |k|, 1 / |q|
+template <int ROWS>
+constexpr int bwd_head_lds() { return 4 * ROWS * kPitch * 2 + 5 * ROWS * 4 + 16; }      // K, V, Q, dO | kin, qa, lse, D, qin | dtau slot
+
+// ---------------------------------------------------------------------------------------------------------------------
+// forward.  NW = wavefronts per head (T = 64: 2, each owns a 32-query tile; T = 32: 1), HW = heads per workgroup = 4 / NW
+// ---------------------------------------------------------------------------------------------------------------------
+template <int DH, int NW>
+__device__ __forceinline__ void coop_fwd(const CArgs& A, const unsigned blk, unsigned char* __restrict__ smem) {
+  constexpr int NPC = DH / 8, HW = 4 / NW, ROWS = 32 * NW;
+  using G = Coop<DH, HW, ROWS>;
+  constexpr int HL = fwd_head_lds<ROWS>();
+  const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
+  const int rho = lane & 31, h = lane >> 5, sub = wib % NW, hw = wib / NW;
+  const int HG = A.H / HW;
+  const int w = blk / HG, hg = blk - w * HG;
+  const int n = A.win_len[w], start = A.win_start[w];
+  const float inv_tau = 1.f / fmaxf(*A.tau, A.tau_min);
+  const int d = A.d;
+  // ---- cooperative load: q / k / v segments of the window's rows -> tiles, norms -> scalar rows
+  const int lr = tid / G::LPR, ch = tid % G::LPR, chl = ch / G::CPH, cq = ch % G::CPH;
+  unsigned short* cQ = reinterpret_cast<unsigned short*>(smem + chl * HL);
+  unsigned short* cK = cQ + ROWS * kPitch;
+  unsigned short* cV = cK + ROWS * kPitch;
+  float* cKin = reinterpret_cast<float*>(cV + ROWS * kPitch);
+  float* cQn = cKin + ROWS;
+  const int col = hg * HW * DH + ch * 8;
+  int tok[G::P];
+#pragma unroll
+  for (int p = 0; p < G::P; ++p) {
+    const int r = p * G::RPI + lr;
+    const int rc = r < n ? r : n - 1;
+    tok[p] = A.csr_tok[start + (rc > 0 ? rc : 0)];       // slots past the window repeat its last token; cleared below
+  }
+  uint4 q16[G::P], k16[G::P], v16[G::P];
+#pragma unroll
+  for (int p = 0; p < G::P; ++p) {
+    const unsigned short* qp = A.qk + (long long)tok[p] * 2 * d + col;
+    q16[p] = *reinterpret_cast<const uint4*>(qp);
+    k16[p] = *reinterpret_cast<const uint4*>(qp + d);
+    v16[p] = *reinterpret_cast<const uint4*>(A.v + (long long)tok[p] * d + col);
+  }
+#pragma unroll
+  for (int p = 0; p < G::P; ++p) {
+    const int r = p * G::RPI + lr;
+    if (G::RPI * G::P > ROWS && r >= ROWS) continue;
+    const unsigned m = r < n ? 0xFFFFFFFFu : 0u;
+    q16[p] = and16(q16[p], m);
+    k16[p] = and16(k16[p], m);
+    v16[p] = and16(v16[p], m);
+    const float qn = inv_norm_chunks<G::CPH>(ssq16(q16[p]));
+    const float kn = inv_norm_chunks<G::CPH>(ssq16(k16[p]));
+    if (cq == 0) {
+      cQn[r] = qn;
+      cKin[r] = kn;
+    }
+    tile_put16(cQ, r, cq, q16[p]);
+    tile_put16(cK, r, cq, k16[p]);
+    tile_put16(cV, r, cq, v16[p]);
+  }
+  __syncthreads();
+  // ---- this wavefront: head hw, query tile sub
+  unsigned short* tQ = reinterpret_cast<unsigned short*>(smem + hw * HL);
+  unsigned short* tK = tQ + ROWS * kPitch;
+  unsigned short* tV = tK + ROWS * kPitch;
+  const float* sKin = reinterpret_cast<const float*>(tV + ROWS * kPitch);
+  const float* sQn = sKin + ROWS;
+  const int r = 32 * sub + rho;
+  const Row<NPC> q = lds_row<NPC>(tQ, r, h);
+  const float qc = sQn[r] * inv_tau * kLog2e;              // (1 / |q| tau) log2(e): exponent scale of this lane's query column
+  f32x16 aS[NW];
+  float m = -INFINITY;
+#pragma unroll
+  for (int kj = 0; kj < NW; ++kj) {
+    const Row<NPC> kk = lds_row<NPC>(tK, 32 * kj + rho, h);
+    aS[kj] = mma_rows<NPC>(kk, q, splat(0.f));            // S^T[key][query], raw dot products
+    float kr[16];
+    row_scalars(sKin + 32 * kj, h, kr);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      aS[kj][e] = (32 * kj + c_row(e, h) < n) ? aS[kj][e] * kr[e] : kPadKey;
+      m = fmaxf(m, aS[kj][e]);
+    }
+  }
+  m = half_max(m);
+  float l = 0.f;
+#pragma unroll
+  for (int kj = 0; kj < NW; ++kj)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const float p = __builtin_amdgcn_exp2f((aS[kj][e] - m) * qc);
+      aS[kj][e] = p;
+      l += p;
+    }
+  l = half_sum(l);
+  const float il = __builtin_amdgcn_rcpf(l);
+  f32x16 o = splat(0.f);
+#pragma unroll
+  for (int kj = 0; kj < NW; ++kj) o = mma_tokens(tV + 32 * kj * kPitch, aS[kj], o, lane);      // O^T[dh][query]
+  // ---- results -> own rows of the Q tile (this wavefront is its only reader) -> cooperative store
+  {
+    Row<NPC> ob;
+#pragma unroll
+    for (int t = 0; t < NPC; ++t) ob.p[t] = pack_piece(o[4 * t] * il, o[4 * t + 1] * il, o[4 * t + 2] * il, o[4 * t + 3] * il);
+    store_tile<NPC>(tQ, r, h, ob);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int p = 0; p < G::P; ++p) {
+    const int r2 = p * G::RPI + lr;
+    if (r2 < n && r2 < ROWS) *reinterpret_cast<uint4*>(A.out + (long long)tok[p] * d + col) = tile_get16(cQ, r2, cq);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// backward
+// ---------------------------------------------------------------------------------------------------------------------
+template <int DH, int NW>
+__device__ __forceinline__ void coop_bwd(const CBwdArgs& A, const unsigned blk, unsigned char* __restrict__ smem) {
+  constexpr int NPC = DH / 8, HW = 4 / NW, ROWS = 32 * NW;
+  using G = Coop<DH, HW, ROWS>;
+  constexpr int HL = bwd_head_lds<ROWS>();
+  const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
+  const int rho = lane & 31, h = lane >> 5, sub = wib % NW, hw = wib / NW;
+  const int HG = A.H / HW;
+  const int w = blk / HG, hg = blk - w * HG;
+  const int n = A.win_len[w], start = A.win_start[w];
+  const float inv_tau = 1.f / fmaxf(*A.tau, A.tau_min);
+  const int d = A.d;
+  // ---- cooperative load
+  const int lr = tid / G::LPR, ch = tid % G::LPR, chl = ch / G::CPH, cq = ch % G::CPH;
+  unsigned short* cK = reinterpret_cast<unsigned short*>(smem + chl * HL);
+  unsigned short* cV = cK + ROWS * kPitch;
+  unsigned short* cQ = cV + ROWS * kPitch;
+  unsigned short* cO = cQ + ROWS * kPitch;
+  float* cKin = reinterpret_cast<float*>(cO + ROWS * kPitch);
+  float* cQa = cKin + ROWS;
+  float* cQn = cKin + 4 * ROWS;
+  const int col = hg * HW * DH + ch * 8;
+  int tok[G::P];
+#pragma unroll
+  for (int p = 0; p < G::P; ++p) {
+    const int r = p * G::RPI + lr;
+    const int rc = r < n ? r : n - 1;
+    tok[p] = A.csr_tok[start + (rc > 0 ? rc : 0)];
+  }
+  uint4 q16[G::P], k16[G::P], v16[G::P], o16[G::P];
+#pragma unroll
+  for (int p = 0; p < G::P; ++p) {
+    const unsigned short* qp = A.qk + (long long)tok[p] * 2 * d + col;
+    q16[p] = *reinterpret_cast<const uint4*>(qp);
+    k16[p] = *reinterpret_cast<const uint4*>(qp + d);
+    v16[p] = *reinterpret_cast<const uint4*>(A.v + (long long)tok[p] * d + col);
+    o16[p] = *reinterpret_cast<const uint4*>(A.dout + (long long)tok[p] * d + col);
+  }
+#pragma unroll
+  for (int p = 0; p < G::P; ++p) {
+    const int r = p * G::RPI + lr;
+    if (G::RPI * G::P > ROWS && r >= ROWS) continue;
+    const unsigned m = r < n ? 0xFFFFFFFFu : 0u;
+    q16[p] = and16(q16[p], m);
+    k16[p] = and16(k16[p], m);
+    v16[p] = and16(v16[p], m);
+    o16[p] = and16(o16[p], m);
+    const float qn = inv_norm_chunks<G::CPH>(ssq16(q16[p]));
+    const float kn = inv_norm_chunks<G::CPH>(ssq16(k16[p]));
+    if (cq == 0) {
+      cQn[r] = qn;
+      cQa[r] = qn * inv_tau;
+      cKin[r] = kn;
+    }
+    tile_put16(cQ, r, cq, q16[p]);
+    tile_put16(cK, r, cq, k16[p]);
+    tile_put16(cV, r, cq, v16[p]);
+    tile_put16(cO, r, cq, o16[p]);
+  }
+  __syncthreads();
+  // ---- this wavefront: head hw, query tile sub (phase 1), key tile sub (phase 2)
+  unsigned short* tK = reinterpret_cast<unsigned short*>(smem + hw * HL);
+  unsigned short* tV = tK + ROWS * kPitch;
+  unsigned short* tQ = tV + ROWS * kPitch;
+  unsigned short* tO = tQ + ROWS * kPitch;
+  float* sKin = reinterpret_cast<float*>(tO + ROWS * kPitch);
+  float* sQa = sKin + ROWS;
+  float* sLse = sQa + ROWS;          // log2 units
+  float* sD = sLse + ROWS;
+  const float* sQn = sD + ROWS;
+  float* sPair = sKin + 5 * ROWS;
+  const int r = 32 * sub + rho;
+  const bool act = r < n;
+  const Row<NPC> q = lds_row<NPC>(tQ, r, h), k = lds_row<NPC>(tK, r, h), v = lds_row<NPC>(tV, r, h), dO = lds_row<NPC>(tO, r, h);
+  const float qin = sQn[r], kin = sKin[r];
+  const float qa = qin * inv_tau, qc = qa * kLog2e;
+  float dtau;
+  Row<NPC> dqr;
+  // ================= phase 1: this wave's query tile -> dQ =================
+  {
+    f32x16 aS[NW], aP[NW];
+    float m = -INFINITY;
+#pragma unroll
+    for (int kj = 0; kj < NW; ++kj) {
+      const Row<NPC> kk = NW == 1 ? k : lds_row<NPC>(tK, 32 * kj + rho, h), vv = NW == 1 ? v : lds_row<NPC>(tV, 32 * kj + rho, h);
+      aS[kj] = mma_rows<NPC>(kk, q, splat(0.f));
+      aP[kj] = mma_rows<NPC>(vv, dO, splat(0.f));
+      float kr[16];
+      row_scalars(sKin + 32 * kj, h, kr);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        aS[kj][e] = (32 * kj + c_row(e, h) < n) ? aS[kj][e] * kr[e] : kPadKey;      // t = (q . k) / |k|
+        m = fmaxf(m, aS[kj][e]);
+      }
+    }
+    m = half_max(m);
+    float l = 0.f, Dn = 0.f, E1 = 0.f, E2 = 0.f;
+#pragma unroll
+    for (int kj = 0; kj < NW; ++kj)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float t = aS[kj][e];
+        const float p = __builtin_amdgcn_exp2f((t - m) * qc);     // exactly 0 for padded keys
+        const float pp = p * aP[kj][e];
+        l += p;
+        Dn += pp;
+        E1 = fmaf(pp, t, E1);
+        E2 = fmaf(p, t, E2);
+        aS[kj][e] = p;
+      }
+    l = half_sum(l);
+    Dn = half_sum(Dn);
+    const float il = __builtin_amdgcn_rcpf(l);
+    const float D = Dn * il;
+    // sum_keys dS a = qa (E1 - D E2) / l over this lane's keys; d a / d tau = -a / tau
+    dtau = -(E1 - D * E2) * il * (qa * inv_tau);
+    if (h == 0) {
+      sLse[r] = act ? fmaf(m, qc, __builtin_amdgcn_logf(l)) : 1e30f;      // log2 units; padded query: p = 0 in phase 2
+      sD[r] = D;
+    }
+    f32x16 oq = splat(0.f);
+#pragma unroll
+    for (int kj = 0; kj < NW; ++kj) {
+      float kr[16];
+      row_scalars(sKin + 32 * kj, h, kr);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) aS[kj][e] = aS[kj][e] * (aP[kj][e] - D) * (kr[e] * il);      // dS / |k|
+      oq = mma_tokens(tK + 32 * kj * kPitch, aS[kj], oq, lane);                                 // dQ^^T[dh][query] (without 1 / tau)
+    }
+    float qh[NPC][4], pr = 0.f;
+#pragma unroll
+    for (int t = 0; t < NPC; ++t) {
+      piece_f32(q.p[t], qh[t]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        qh[t][j] *= qin;
+        pr = fmaf(qh[t][j], oq[4 * t + j], pr);
+      }
+    }
+    pr = half_sum(pr);
+#pragma unroll
+    for (int t = 0; t < NPC; ++t)
+      dqr.p[t] = pack_piece((oq[4 * t] - qh[t][0] * pr) * qa, (oq[4 * t + 1] - qh[t][1] * pr) * qa, (oq[4 * t + 2] - qh[t][2] * pr) * qa,
+                            (oq[4 * t + 3] - qh[t][3] * pr) * qa);
+  }
+  // one partial per (window, head): the query-tile sums of a head's wavefronts meet in LDS
+  dtau = gd_wave_sum(dtau);
+  if (NW == 2) {
+    if (sub == 1 && lane == 0) *sPair = dtau;
+    __syncthreads();                       // also publishes sLse / sD of the other query tile
+    if (sub == 0 && lane == 0) A.dtau_part[(long long)w * A.H + hg * HW + hw] = dtau + *sPair;
+  } else {
+    if (lane == 0) A.dtau_part[(long long)w * A.H + hg * HW + hw] = dtau;
+    __builtin_amdgcn_wave_barrier();
+  }
+  // ================= phase 2: this wave's key tile -> dK, dV =================
+  Row<NPC> dkr, dvr;
+  {
+    const float kc = kin * kLog2e;
+    f32x16 okk = splat(0.f), ov = splat(0.f);
+#pragma unroll
+    for (int qi = 0; qi < NW; ++qi) {
+      const Row<NPC> qq = NW == 1 ? q : lds_row<NPC>(tQ, 32 * qi + rho, h), oo = NW == 1 ? dO : lds_row<NPC>(tO, 32 * qi + rho, h);
+      f32x16 aS = mma_rows<NPC>(qq, k, splat(act ? 0.f : -1e30f));     // S[query][key]; padded key (lane): p = 0
+      f32x16 aP = mma_rows<NPC>(oo, v, splat(0.f));                    // dP[query][key]
+      float qr[16], lr_[16], dr[16];
+      row_scalars(sQa + 32 * qi, h, qr);
+      row_scalars(sLse + 32 * qi, h, lr_);
+      row_scalars(sD + 32 * qi, h, dr);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float p = __builtin_amdgcn_exp2f(fmaf(aS[e], qr[e] * kc, -lr_[e]));   // 0 for padded keys and padded queries
+        aS[e] = p * (aP[e] - dr[e]) * qr[e];                                         // dS / (|q| tau)
+        aP[e] = p;
+      }
+      okk = mma_tokens(tQ + 32 * qi * kPitch, aS, okk, lane);      // dK^^T[dh][key]
+      ov = mma_tokens(tO + 32 * qi * kPitch, aP, ov, lane);        // dV^T[dh][key]
+    }
+    float kh[NPC][4], pr = 0.f;
+#pragma unroll
+    for (int t = 0; t < NPC; ++t) {
+      piece_f32(k.p[t], kh[t]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        kh[t][j] *= kin;
+        pr = fmaf(kh[t][j], okk[4 * t + j], pr);
+      }
+    }
+    pr = half_sum(pr);
+#pragma unroll
+    for (int t = 0; t < NPC; ++t) {
+      dkr.p[t] = pack_piece((okk[4 * t] - kh[t][0] * pr) * kin, (okk[4 * t + 1] - kh[t][1] * pr) * kin, (okk[4 * t + 2] - kh[t][2] * pr) * kin,
+                            (okk[4 * t + 3] - kh[t][3] * pr) * kin);
+      dvr.p[t] = pack_piece(ov[4 * t], ov[4 * t + 1], ov[4 * t + 2], ov[4 * t + 3]);
+    }
+  }
+  // ---- results -> tiles (every wavefront of the head is done reading them) -> cooperative stores
+  __syncthreads();
+  store_tile<NPC>(tK, r, h, dqr);
+  store_tile<NPC>(tV, r, h, dkr);
+  store_tile<NPC>(tQ, r, h, dvr);
+  __syncthreads();
+#pragma unroll
+  for (int p = 0; p < G::P; ++p) {
+    const int r2 = p * G::RPI + lr;
+    if (r2 < n && r2 < ROWS) {
+      unsigned short* gp = A.dqk + (long long)tok[p] * 2 * d + col;
+      *reinterpret_cast<uint4*>(gp) = tile_get16(cK, r2, cq);
+      *reinterpret_cast<uint4*>(gp + d) = tile_get16(cV, r2, cq);
+      *reinterpret_cast<uint4*>(A.dv + (long long)tok[p] * d + col) = tile_get16(cQ, r2, cq);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// kernels: the T = 64 and T = 32 levels of a layer in ONE launch (the T = 64 workgroups first - they run longest)
+// ---------------------------------------------------------------------------------------------------------------------
+template <int DH>
+__global__ __launch_bounds__(256) void k_attn_coop_fwd(CArgs A64, CArgs A32, unsigned nb64) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_coop[];
+  if (blockIdx.x < nb64) coop_fwd<DH, 2>(A64, blockIdx.x, smem_coop);
+  else coop_fwd<DH, 1>(A32, blockIdx.x - nb64, smem_coop);
+}
+template <int DH>
+__global__ __launch_bounds__(256) void k_attn_coop_bwd(CBwdArgs A64, CBwdArgs A32, unsigned nb64) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_coop[];
+  if (blockIdx.x < nb64) coop_bwd<DH, 2>(A64, blockIdx.x, smem_coop);
+  else coop_bwd<DH, 1>(A32, blockIdx.x - nb64, smem_coop);
+}
+// ... and ALL levels of a layer in one launch: the sparse level's wavefronts (attn16_wave.h: one (window quad, head) each, a chain of
+// dependent round trips with next to no arithmetic) ride along with the dense levels' workgroups instead of paying a launch of their own.
+// first16 = the T = 16 workgroups take the lowest block indices (their chains start at once; the dense workgroups fill in behind).
+template <int DH>
+__global__ __launch_bounds__(256) void k_attn_levels_fwd(CArgs A64, CArgs A32, t16w::A16Args A16, unsigned nb64, unsigned nb32, unsigned nb16,
+                                                         int first16) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_coop[];
+  unsigned b = blockIdx.x;
+  if (first16) {
+    if (b < nb16) return t16w::t16_fwd_body<DH>(A16, b, smem_coop);
+    b -= nb16;
+  }
+  if (b < nb64) return coop_fwd<DH, 2>(A64, b, smem_coop);
+  b -= nb64;
+  if (b < nb32) return coop_fwd<DH, 1>(A32, b, smem_coop);
+  t16w::t16_fwd_body<DH>(A16, b - nb32, smem_coop);
+}
+// backward: the T = 64 workgroups keep their own launch (197 registers: two wavefronts per SIMD would throttle the sparse level),
+// T = 32 and T = 16 share one
+template <int DH>
+__global__ __launch_bounds__(256) void k_attn_lo_bwd(CBwdArgs A32, t16w::A16BwdArgs A16, unsigned nb32, unsigned nb16, int first16) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_coop[];
+  unsigned b = blockIdx.x;
+  if (first16) {
+    if (b < nb16) return t16w::t16_bwd_body<DH>(A16, b, nb16, smem_coop);
+    b -= nb16;
+  }
+  if (b < nb32) return coop_bwd<DH, 1>(A32, b, smem_coop);
+  t16w::t16_bwd_body<DH>(A16, b - nb32, nb16, smem_coop);
+}
+constexpr int imax(int a, int b) { return a > b ? a : b; }
+}  // namespace
+
+// bf16 I/O, H % 4 == 0.  n32 / n64: windows of the T = 32 / T = 64 levels (either may be 0), (win_start, win_len) of each level.
+int gd_attn_coop_fwd(const void* qk, const void* v, void* out, const int* csr_tok, const int* ws32, const int* wl32, int n32, const int* ws64,
+                     const int* wl64, int n64, int d, int H, const float* tau, float tau_min, hipStream_t st) {
+  const CArgs A32{(const unsigned short*)qk, (const unsigned short*)v, (unsigned short*)out, csr_tok, ws32, wl32, n32, d, H, tau, tau_min};
+  const CArgs A64{(const unsigned short*)qk, (const unsigned short*)v, (unsigned short*)out, csr_tok, ws64, wl64, n64, d, H, tau, tau_min};
+  const int DH = d / H;
+  const unsigned nb32 = (unsigned)((long long)n32 * (H / 4)), nb64 = (unsigned)((long long)n64 * (H / 2));
+  if (nb32 + nb64 == 0) return 0;
+  constexpr int lds = imax(2 * fwd_head_lds<64>(), 4 * fwd_head_lds<32>());
+  if (DH == 16) hipLaunchKernelGGL((k_attn_coop_fwd<16>), dim3(nb64 + nb32), dim3(256), lds, st, A64, A32, nb64);
+  else hipLaunchKernelGGL((k_attn_coop_fwd<32>), dim3(nb64 + nb32), dim3(256), lds, st, A64, A32, nb64);
+  GD_LAUNCH_CHECK();
+  return 0;
+}
+
+// part32 / part64: n32 * H / n64 * H partial slots of d loss / d tau (one per window and head)
+int gd_attn_coop_bwd(const void* qk, const void* v, const void* dout, void* dqk, void* dv, const int* csr_tok, const int* ws32, const int* wl32,
+                     int n32, float* part32, const int* ws64, const int* wl64, int n64, float* part64, int d, int H, const float* tau,
+                     float tau_min, hipStream_t st) {
+  const CBwdArgs A32{(const unsigned short*)qk, (const unsigned short*)v, (const unsigned short*)dout, (unsigned short*)dqk, (unsigned short*)dv,
+                     part32, csr_tok, ws32, wl32, n32, d, H, tau, tau_min};
+  const CBwdArgs A64{(const unsigned short*)qk, (const unsigned short*)v, (const unsigned short*)dout, (unsigned short*)dqk, (unsigned short*)dv,
+                     part64, csr_tok, ws64, wl64, n64, d, H, tau, tau_min};
+  const int DH = d / H;
+  const unsigned nb32 = (unsigned)((long long)n32 * (H / 4)), nb64 = (unsigned)((long long)n64 * (H / 2));
+  if (nb32 + nb64 == 0) return 0;
+  constexpr int lds = imax(2 * bwd_head_lds<64>(), 4 * bwd_head_lds<32>());
+  if (DH == 16) hipLaunchKernelGGL((k_attn_coop_bwd<16>), dim3(nb64 + nb32), dim3(256), lds, st, A64, A32, nb64);
+  else hipLaunchKernelGGL((k_attn_coop_bwd<32>), dim3(nb64 + nb32), dim3(256), lds, st, A64, A32, nb64);
+  GD_LAUNCH_CHECK();
+  return 0;
+}
+
+static int g_first16 = -1;
+static int first16() {
+  if (g_first16 < 0) g_first16 = getenv("GDMAE_ATTN_FIRST16") ? atoi(getenv("GDMAE_ATTN_FIRST16")) : 1;
+  return g_first16;
+}
+
+// every level of a layer (T = 16: windows [0, n16) of (ws16, wl16), H % 4 == 0) - forward: one launch
+int gd_attn_levels_fwd(const void* qk, const void* v, void* out, const int* csr_tok, const int* ws16, const int* wl16, int n16, const int* ws32,
+                       const int* wl32, int n32, const int* ws64, const int* wl64, int n64, int d, int H, const float* tau, float tau_min,
+                       hipStream_t st) {
+  const CArgs A32{(const unsigned short*)qk, (const unsigned short*)v, (unsigned short*)out, csr_tok, ws32, wl32, n32, d, H, tau, tau_min};
+  const CArgs A64{(const unsigned short*)qk, (const unsigned short*)v, (unsigned short*)out, csr_tok, ws64, wl64, n64, d, H, tau, tau_min};
+  const t16w::A16Args A16{(const unsigned short*)qk, (const unsigned short*)v, (unsigned short*)out, csr_tok, ws16, wl16, n16, d, H, tau, tau_min};
+  const int DH = d / H;
+  const unsigned nb32 = (unsigned)((long long)n32 * (H / 4)), nb64 = (unsigned)((long long)n64 * (H / 2));
+  const unsigned nb16 = (unsigned)((long long)gd_div_up(n16, t16w::kWinPerWave) * (H / 4));
+  if (nb16 + nb32 + nb64 == 0) return 0;
+  constexpr int lds = imax(imax(2 * fwd_head_lds<64>(), 4 * fwd_head_lds<32>()), 4 * t16w::kWaveLds);
+  if (DH == 16) hipLaunchKernelGGL((k_attn_levels_fwd<16>), dim3(nb64 + nb32 + nb16), dim3(256), lds, st, A64, A32, A16, nb64, nb32, nb16, first16());
+  else hipLaunchKernelGGL((k_attn_levels_fwd<32>), dim3(nb64 + nb32 + nb16), dim3(256), lds, st, A64, A32, A16, nb64, nb32, nb16, first16());
+  GD_LAUNCH_CHECK();
+  return 0;
+}
+// backward: T = 64 alone (if any), T = 32 + T = 16 together
+int gd_attn_levels_bwd(const void* qk, const void* v, const void* dout, void* dqk, void* dv, const int* csr_tok, const int* ws16, const int* wl16,
+                       int n16, float* part16, const int* ws32, const int* wl32, int n32, float* part32, const int* ws64, const int* wl64, int n64,
+                       float* part64, int d, int H, const float* tau, float tau_min, hipStream_t st) {
+  const int DH = d / H;
+  if (n64 > 0) {
+    const int rc = gd_attn_coop_bwd(qk, v, dout, dqk, dv, csr_tok, nullptr, nullptr, 0, nullptr, ws64, wl64, n64, part64, d, H, tau, tau_min, st);
+    if (rc) return rc;
+  }
+  const CBwdArgs A32{(const unsigned short*)qk, (const unsigned short*)v, (const unsigned short*)dout, (unsigned short*)dqk, (unsigned short*)dv,
+                     part32, csr_tok, ws32, wl32, n32, d, H, tau, tau_min};
+  const t16w::A16BwdArgs A16{(const unsigned short*)qk, (const unsigned short*)v, (const unsigned short*)dout, (unsigned short*)dqk,
+                             (unsigned short*)dv, part16, csr_tok, ws16, wl16, n16, d, H, tau, tau_min};
+  const unsigned nb32 = (unsigned)((long long)n32 * (H / 4));
+  const unsigned nb16 = (unsigned)((long long)gd_div_up(n16, t16w::kWinPerWave) * (H / 4));
+  if (nb16 + nb32 == 0) return 0;
+  constexpr int lds = imax(4 * bwd_head_lds<32>(), 4 * t16w::kWaveLds);
+  if (DH == 16) hipLaunchKernelGGL((k_attn_lo_bwd<16>), dim3(nb32 + nb16), dim3(256), lds, st, A32, A16, nb32, nb16, first16());
+  else hipLaunchKernelGGL((k_attn_lo_bwd<32>), dim3(nb32 + nb16), dim3(256), lds, st, A32, A16, nb32, nb16, first16());
+  GD_LAUNCH_CHECK();
+  return 0;
+}
+

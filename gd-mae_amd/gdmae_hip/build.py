@@ -14,7 +14,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.abspath(os.path.join(HERE, "..", "csrc"))
 LIB = os.path.join(CSRC, "libgdmae_hip.so")
-SOURCES = ["capi.hip", "voxelize.hip", "mask.hip", "partition.hip", "segment.hip", "attention.hip", "attention_mfma.hip", "attention_t32.hip", "attention_t16.hip", "layernorm.hip", "decoder.hip", "chamfer.hip",
+SOURCES = ["capi.hip", "voxelize.hip", "mask.hip", "partition.hip", "segment.hip", "attention.hip", "attention_mfma.hip", "attention_t32.hip", "attention_t16.hip", "attention_coop.hip", "layernorm.hip", "decoder.hip", "chamfer.hip",
            "optim.hip", "input_pipeline.hip", "gemm.hip", "gemm_f32.hip", "encoder_layer.hip", "conv_block.hip", "vfe_fused.hip", "vfe_layer2.hip", "conv_tiles.hip", "tok_gemm.hip", "layer_fused.hip", "rows_gemm.hip", "dw_grouped.hip", "center_head.hip", "iou3d_nms.hip", "plan.hip", "spconv.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-Wno-unused-result"]
@@ -25,6 +25,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 # (551 -> 177 of ~5000 instructions in the T = 64 backward)
 EXTRA_FLAGS = {"attention_t32.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
                "attention_t16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
+               "attention_coop.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
                "vfe_fused.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
                "vfe_layer2.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
@@ -42,7 +43,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
         src = os.path.join(CSRC, s)
         obj = os.path.join(CSRC, s.replace(".hip", ".o"))
         objs.append(obj)
-        if force or _newer(src, obj) or any(_newer(d, obj) for d in deps):
+        own = [os.path.join(CSRC, "attn_tiles.h"), os.path.join(CSRC, "attn16_wave.h")] if s in ("attention_coop.hip", "attention_t16.hip") else []
+        if force or _newer(src, obj) or any(_newer(d, obj) for d in deps + own):
             cmd = [hipcc, *FLAGS, *EXTRA_FLAGS.get(s, []), "-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)

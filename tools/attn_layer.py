@@ -1,0 +1,50 @@
+"""All occupancy levels of one attention call (the entry the layer executor uses) on the bench workload's windows, per stage and
+shift: product path (impl 0: merged workgroup-cooperative launches) against the round-4 per-(window, head) kernels (impl 3)."""
+import logging, os, sys
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [REPO, os.path.join(REPO, "gd-mae_amd")]
+import torch
+from gdmae_hip import configs, synth
+from gdmae_hip import lib as L
+from pcdet.models import build_network
+dev = torch.device("cuda:0")
+cfg, ds, skw = configs.named_config("B", mask_ratio=0.75)
+net = build_network(cfg, 3, ds, logging.getLogger("p")).to(dev).train()
+frames = int(os.environ.get("FRAMES", "8"))
+pts = torch.from_numpy(synth.synth_batch(5, frames, ds.point_cloud_range, **skw)).to(dev)
+vox, plan = net.backbone_3d.prefetch_plan(pts, frames).finish()
+tot = {0: [0.0, 0.0], 3: [0.0, 0.0]}
+for si, st in enumerate(plan.stages):
+    d = cfg.BACKBONE_3D.SST_BLOCK_LIST[si].ENCODER.D_MODEL
+    H = cfg.BACKBONE_3D.SST_BLOCK_LIST[si].ENCODER.NHEAD
+    for shift, w in enumerate(st.windows):
+        qk = torch.randn(st.n_tok, 2 * d, device=dev).to(torch.bfloat16)
+        v = torch.randn(st.n_tok, d, device=dev).to(torch.bfloat16)
+        g = torch.randn(st.n_tok, d, device=dev).to(torch.bfloat16)
+        out = torch.empty_like(v); dqk = torch.empty_like(qk); dv = torch.empty_like(v)
+        tau = torch.full((1,), 0.1, device=dev)
+        part = torch.zeros(sum(w.n_win) * H + 1, device=dev)
+        nl = len(w.n_win)
+        nw_h, T_h = L.host_i32(w.n_win), L.host_i32(w.max_tokens)
+        def fwd():
+            L.call("gdmae_window_attention_levels_fwd", L.ptr(qk), L.ptr(v), L.ptr(out), 1, L.ptr(w.csr_tok), L.ptr(w.win_start), L.ptr(w.win_len), nl,
+                   nw_h, T_h, d, H, L.ptr(tau), 0.01, L.stream())
+        def bwd():
+            L.call("gdmae_window_attention_levels_bwd", L.ptr(qk), L.ptr(v), L.ptr(g), L.ptr(dqk), L.ptr(dv), 1, L.ptr(part), L.ptr(w.csr_tok),
+                   L.ptr(w.win_start), L.ptr(w.win_len), nl, nw_h, T_h, d, H, L.ptr(tau), 0.01, L.stream())
+        line = f"stage {si} shift {shift} windows {w.n_win} tokens {w.n_tok}:"
+        for impl in (3, 0):
+            L.call("gdmae_set_attention_impl", impl)
+            res = []
+            for f in (fwd, bwd):
+                for _ in range(3): f()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize(); e0.record()
+                for _ in range(20): f()
+                e1.record(); torch.cuda.synchronize()
+                res.append(e0.elapsed_time(e1) / 20 * 1e3)
+            tot[impl][0] += res[0]; tot[impl][1] += res[1]
+            line += f"   impl {impl}: fwd {res[0]:6.1f} bwd {res[1]:6.1f} us"
+        print(line)
+L.call("gdmae_set_attention_impl", 0)
+print("per step (2 layers per shift and stage):", {k: [round(2 * x, 1) for x in v] for k, v in tot.items()})
