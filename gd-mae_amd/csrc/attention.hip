@@ -523,20 +523,14 @@ int gd_attn_t3264_bwd(const void* qk, const void* v, const void* dout, void* dqk
                       const int* wl32, int n32, float* part32, const int* ws64, const int* wl64, int n64, float* part64, int d, int H,
                       const float* tau, float tau_min, hipStream_t st);
 
-// workgroup-cooperative variant of the same two levels (attention_coop.hip, round 5): whole row segments through LDS, 16 bytes per lane
-int gd_attn_coop_fwd(const void* qk, const void* v, void* out, const int* csr_tok, const int* ws32, const int* wl32, int n32, const int* ws64,
-                     const int* wl64, int n64, int d, int H, const float* tau, float tau_min, hipStream_t st);
-int gd_attn_coop_bwd(const void* qk, const void* v, const void* dout, void* dqk, void* dv, const int* csr_tok, const int* ws32, const int* wl32,
-                     int n32, float* part32, const int* ws64, const int* wl64, int n64, float* part64, int d, int H, const float* tau,
-                     float tau_min, hipStream_t st);
-
-// ... all levels of a layer merged: forward one launch, backward T = 64 | T = 32 + T = 16 (attention_coop.hip)
-int gd_attn_levels_fwd(const void* qk, const void* v, void* out, const int* csr_tok, const int* ws16, const int* wl16, int n16, const int* ws32,
-                       const int* wl32, int n32, const int* ws64, const int* wl64, int n64, int d, int H, const float* tau, float tau_min,
-                       hipStream_t st);
-int gd_attn_levels_bwd(const void* qk, const void* v, const void* dout, void* dqk, void* dv, const int* csr_tok, const int* ws16, const int* wl16,
-                       int n16, float* part16, const int* ws32, const int* wl32, int n32, float* part32, const int* ws64, const int* wl64, int n64,
-                       float* part64, int d, int H, const float* tau, float tau_min, hipStream_t st);
+// workgroup-cooperative kernels, all levels of a layer in one launch per direction (attention_coop.hip, round 5): whole row segments
+// through LDS, 16 bytes per lane; the forward leaves the rows' log-sum-exp for the backward, which also reads the forward's output
+int gd_attn_levels_fwd(const void* qk, const void* v, void* out, float* lse, const int* csr_tok, const int* ws16, const int* wl16, int n16,
+                       const int* ws32, const int* wl32, int n32, const int* ws64, const int* wl64, int n64, int d, int H, const float* tau,
+                       float tau_min, hipStream_t st);
+int gd_attn_levels_bwd(const void* qk, const void* v, const void* o, const float* lse, const void* dout, void* dqk, void* dv, const int* csr_tok,
+                       const int* ws16, const int* wl16, int n16, float* part16, const int* ws32, const int* wl32, int n32, float* part32,
+                       const int* ws64, const int* wl64, int n64, float* part64, int d, int H, const float* tau, float tau_min, hipStream_t st);
 
 // bf16-MFMA variant of the T = 16 level for bf16 token I/O (attention_t16.hip)
 int gd_attn_t16_fwd(const void* qk, const void* v, void* out, const int* csr_tok, const int* win_start, const int* win_len, int n_win,
@@ -572,8 +566,10 @@ extern "C" int gdmae_window_attention_fwd(const void* qk, const void* v, void* o
   if (attn_auto() && T == 16 && io_bf16 && H % 4 == 0)
     return gd_attn_t16_fwd(qk, v, out, csr_tok, win_start, win_len, n_win, d, H, tau, tau_min, st);
   if (g_attn_impl == 0 && T >= 32 && io_bf16 && H % 4 == 0)
-    return T == 32 ? gd_attn_coop_fwd(qk, v, out, csr_tok, win_start, win_len, n_win, nullptr, nullptr, 0, d, H, tau, tau_min, st)
-                   : gd_attn_coop_fwd(qk, v, out, csr_tok, nullptr, nullptr, 0, win_start, win_len, n_win, d, H, tau, tau_min, st);
+    return T == 32 ? gd_attn_levels_fwd(qk, v, out, nullptr, csr_tok, nullptr, nullptr, 0, win_start, win_len, n_win, nullptr, nullptr, 0, d, H, tau,
+                                        tau_min, st)
+                   : gd_attn_levels_fwd(qk, v, out, nullptr, csr_tok, nullptr, nullptr, 0, nullptr, nullptr, 0, win_start, win_len, n_win, d, H, tau,
+                                        tau_min, st);
   if (attn_auto() && T >= 32 && io_bf16)
     return gd_attn_t32_fwd(qk, v, out, csr_tok, win_start, win_len, n_win, T, d, H, tau, tau_min, st);
   if (g_attn_impl != 1 && T >= 32)
@@ -595,11 +591,6 @@ extern "C" int gdmae_window_attention_bwd(const void* qk, const void* v, const v
   hipStream_t st = (hipStream_t)stream;
   if (attn_auto() && T == 16 && io_bf16 && H % 4 == 0)
     return gd_attn_t16_bwd(qk, v, dout, dqk, dv, dtau_part, csr_tok, win_start, win_len, n_win, d, H, tau, tau_min, st);
-  if (g_attn_impl == 0 && T >= 32 && io_bf16 && H % 4 == 0)
-    return T == 32 ? gd_attn_coop_bwd(qk, v, dout, dqk, dv, csr_tok, win_start, win_len, n_win, dtau_part, nullptr, nullptr, 0, nullptr, d, H, tau,
-                                      tau_min, st)
-                   : gd_attn_coop_bwd(qk, v, dout, dqk, dv, csr_tok, nullptr, nullptr, 0, nullptr, win_start, win_len, n_win, dtau_part, d, H, tau,
-                                      tau_min, st);
   if (attn_auto() && T >= 32 && io_bf16)
     return gd_attn_t32_bwd(qk, v, dout, dqk, dv, dtau_part, csr_tok, win_start, win_len, n_win, T, d, H, tau, tau_min, st);
   if (g_attn_impl != 1 && T >= 32)
@@ -630,7 +621,8 @@ static bool levels_fast_path(int io_bf16, int n_levels, const int* max_tokens, i
 }
 extern "C" int gdmae_window_attention_levels_fwd(const void* qk, const void* v, void* out, int io_bf16, const int* csr_tok,
                                                  const int* win_start, const int* win_len, int n_levels, const int* n_win,
-                                                 const int* max_tokens, int d, int H, const float* tau, float tau_min, void* stream) {
+                                                 const int* max_tokens, int d, int H, const float* tau, float tau_min, float* lse,
+                                                 void* stream) {
   hipStream_t st = (hipStream_t)stream;
   // algorithmic bytes: q, k, v rows read + out row written per token (4 d elements) + CSR; the token count is not an argument
   // of this entry - the caller (encoder_layer.hip) adds it through gd_attn_timing_tokens
@@ -655,7 +647,7 @@ extern "C" int gdmae_window_attention_levels_fwd(const void* qk, const void* v, 
     base += n_win[l];
   }
   if (g_attn_impl == 0)
-    return gd_attn_levels_fwd(qk, v, out, csr_tok, ws[0], wl[0], nw[0], ws[1], wl[1], nw[1], ws[2], wl[2], nw[2], d, H, tau, tau_min, st);
+    return gd_attn_levels_fwd(qk, v, out, lse, csr_tok, ws[0], wl[0], nw[0], ws[1], wl[1], nw[1], ws[2], wl[2], nw[2], d, H, tau, tau_min, st);
   if (nw[0] > 0) {
     const int rc = gd_attn_t16_fwd(qk, v, out, csr_tok, ws[0], wl[0], nw[0], d, H, tau, tau_min, st);
     if (rc != 0) return rc;
@@ -666,7 +658,7 @@ extern "C" int gdmae_window_attention_levels_fwd(const void* qk, const void* v, 
 extern "C" int gdmae_window_attention_levels_bwd(const void* qk, const void* v, const void* dout, void* dqk, void* dv, int io_bf16,
                                                  float* dtau_part, const int* csr_tok, const int* win_start, const int* win_len,
                                                  int n_levels, const int* n_win, const int* max_tokens, int d, int H, const float* tau,
-                                                 float tau_min, void* stream) {
+                                                 float tau_min, const void* out, const float* lse, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   GdTimed timed(GD_T_ATTN_BWD, st, attn_alg_bytes(n_levels, n_win, nullptr, g_attn_tokens, d, io_bf16 ? 2 : 4, 7));
   if (!levels_fast_path(io_bf16, n_levels, max_tokens, H, d)) {
@@ -693,9 +685,9 @@ extern "C" int gdmae_window_attention_levels_bwd(const void* qk, const void* v, 
     base += n_win[l];
     pbase += (long long)n_win[l] * H;
   }
-  if (g_attn_impl == 0)
-    return gd_attn_levels_bwd(qk, v, dout, dqk, dv, csr_tok, ws[0], wl[0], nw[0], part[0], ws[1], wl[1], nw[1], part[1], ws[2], wl[2], nw[2], part[2],
-                              d, H, tau, tau_min, st);
+  if (g_attn_impl == 0 && out != nullptr && lse != nullptr)
+    return gd_attn_levels_bwd(qk, v, out, lse, dout, dqk, dv, csr_tok, ws[0], wl[0], nw[0], part[0], ws[1], wl[1], nw[1], part[1], ws[2], wl[2], nw[2],
+                              part[2], d, H, tau, tau_min, st);
   if (nw[0] > 0) {
     const int rc = gd_attn_t16_bwd(qk, v, dout, dqk, dv, part[0], csr_tok, ws[0], wl[0], nw[0], d, H, tau, tau_min, st);
     if (rc != 0) return rc;

@@ -18,6 +18,7 @@ struct CArgs {
   const unsigned short* qk;
   const unsigned short* v;
   unsigned short* out;
+  float* lse;                   // (n_tok, H) log2 sum exp of a row's logits (for the backward), or null
   const int* csr_tok;
   const int* win_start;
   const int* win_len;
@@ -28,6 +29,8 @@ struct CArgs {
 struct CBwdArgs {
   const unsigned short* qk;
   const unsigned short* v;
+  const unsigned short* o;      // the forward's output rows
+  const float* lse;             // the forward's lse
   const unsigned short* dout;
   unsigned short* dqk;
   unsigned short* dv;
@@ -42,7 +45,7 @@ struct CBwdArgs {
 
 // LDS per head: tiles of ROWS x 64 B + per-row scalars
 template <int ROWS>
-constexpr int fwd_head_lds() { return 3 * ROWS * kPitch * 2 + 2 * ROWS * 4; }           // Q, K, V | 1 / |k|, 1 / |q|
+constexpr int fwd_head_lds() { return 3 * ROWS * kPitch * 2 + 3 * ROWS * 4; }           // Q, K, V | 1 / |k|, 1 / |q|, lse
 template <int ROWS>
 constexpr int bwd_head_lds() { return 4 * ROWS * kPitch * 2 + 5 * ROWS * 4 + 16; }      // K, V, Q, dO | kin, qa, lse, D, qin | dtau slot
 
@@ -109,6 +112,7 @@ __device__ __forceinline__ void coop_fwd(const CArgs& A, const unsigned blk, uns
   unsigned short* tV = tK + ROWS * kPitch;
   const float* sKin = reinterpret_cast<const float*>(tV + ROWS * kPitch);
   const float* sQn = sKin + ROWS;
+  float* sLse = reinterpret_cast<float*>(tV + ROWS * kPitch) + 2 * ROWS;
   const int r = 32 * sub + rho;
   const Row<NPC> q = lds_row<NPC>(tQ, r, h);
   const float qc = sQn[r] * inv_tau * kLog2e;              // (1 / |q| tau) log2(e): exponent scale of this lane's query column
@@ -138,6 +142,7 @@ __device__ __forceinline__ void coop_fwd(const CArgs& A, const unsigned blk, uns
     }
   l = half_sum(l);
   const float il = __builtin_amdgcn_rcpf(l);
+  if (h == 0) sLse[r] = fmaf(m, qc, __builtin_amdgcn_logf(l));      // log2 units: p = exp2(t qc - lse)
   f32x16 o = splat(0.f);
 #pragma unroll
   for (int kj = 0; kj < NW; ++kj) o = mma_tokens(tV + 32 * kj * kPitch, aS[kj], o, lane);      // O^T[dh][query]
@@ -152,12 +157,19 @@ __device__ __forceinline__ void coop_fwd(const CArgs& A, const unsigned blk, uns
 #pragma unroll
   for (int p = 0; p < G::P; ++p) {
     const int r2 = p * G::RPI + lr;
-    if (r2 < n && r2 < ROWS) *reinterpret_cast<uint4*>(A.out + (long long)tok[p] * d + col) = tile_get16(cQ, r2, cq);
+    if (r2 < n && r2 < ROWS) {
+      *reinterpret_cast<uint4*>(A.out + (long long)tok[p] * d + col) = tile_get16(cQ, r2, cq);
+      if (cq == 0 && A.lse) A.lse[(long long)tok[p] * A.H + hg * HW + chl] = (cKin + 2 * ROWS)[r2];
+    }
   }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// backward
+// backward.  The forward left lse[token][head] = log2 sum_k exp(logit) (coop_fwd), and D[query] = sum_k P dP = dO[query] . O[query] is a
+// row dot product of the saved attention output - so nothing about a query has to be reduced over the keys here: a probability is
+// p = exp2(logit log2(e) - lse) wherever it is needed.  Phase 1 (this wave's 32 queries, S^T layout) walks the key tiles one at a time
+// with 32 instead of 64 accumulator registers live; phase 2 (this wave's 32 keys, S layout) needs nothing from phase 1.  <= 128
+// registers: four wavefronts per SIMD (the two-pass form needed 197), and the sparse level can share the launch.
 // ---------------------------------------------------------------------------------------------------------------------
 template <int DH, int NW>
 __device__ __forceinline__ void coop_bwd(const CBwdArgs& A, const unsigned blk, unsigned char* __restrict__ smem) {
@@ -179,6 +191,8 @@ __device__ __forceinline__ void coop_bwd(const CBwdArgs& A, const unsigned blk, 
   unsigned short* cO = cQ + ROWS * kPitch;
   float* cKin = reinterpret_cast<float*>(cO + ROWS * kPitch);
   float* cQa = cKin + ROWS;
+  float* cLse = cKin + 2 * ROWS;
+  float* cD = cKin + 3 * ROWS;
   float* cQn = cKin + 4 * ROWS;
   const int col = hg * HW * DH + ch * 8;
   int tok[G::P];
@@ -188,7 +202,8 @@ __device__ __forceinline__ void coop_bwd(const CBwdArgs& A, const unsigned blk, 
     const int rc = r < n ? r : n - 1;
     tok[p] = A.csr_tok[start + (rc > 0 ? rc : 0)];
   }
-  uint4 q16[G::P], k16[G::P], v16[G::P], o16[G::P];
+  uint4 q16[G::P], k16[G::P], v16[G::P], o16[G::P], x16[G::P];
+  float lse_[G::P];
 #pragma unroll
   for (int p = 0; p < G::P; ++p) {
     const unsigned short* qp = A.qk + (long long)tok[p] * 2 * d + col;
@@ -196,6 +211,8 @@ __device__ __forceinline__ void coop_bwd(const CBwdArgs& A, const unsigned blk, 
     k16[p] = *reinterpret_cast<const uint4*>(qp + d);
     v16[p] = *reinterpret_cast<const uint4*>(A.v + (long long)tok[p] * d + col);
     o16[p] = *reinterpret_cast<const uint4*>(A.dout + (long long)tok[p] * d + col);
+    x16[p] = *reinterpret_cast<const uint4*>(A.o + (long long)tok[p] * d + col);
+    lse_[p] = A.lse[(long long)tok[p] * A.H + hg * HW + chl];
   }
 #pragma unroll
   for (int p = 0; p < G::P; ++p) {
@@ -208,10 +225,15 @@ __device__ __forceinline__ void coop_bwd(const CBwdArgs& A, const unsigned blk, 
     o16[p] = and16(o16[p], m);
     const float qn = inv_norm_chunks<G::CPH>(ssq16(q16[p]));
     const float kn = inv_norm_chunks<G::CPH>(ssq16(k16[p]));
+    float dd = dot16(o16[p], x16[p]);                     // D = dO . O over the head's channels (0 for padded rows: dO cleared)
+    dd += gd_dpp_mov<0xB1>(dd);
+    if (G::CPH >= 4) dd += gd_dpp_mov<0x4E>(dd);
     if (cq == 0) {
       cQn[r] = qn;
       cQa[r] = qn * inv_tau;
       cKin[r] = kn;
+      cLse[r] = r < n ? lse_[p] : 1e30f;                  // padded query: p = exp2(. - 1e30) = 0 everywhere
+      cD[r] = dd;                                         // (enters the dP accumulators negated)
     }
     tile_put16(cQ, r, cq, q16[p]);
     tile_put16(cK, r, cq, k16[p]);
@@ -219,6 +241,7 @@ __device__ __forceinline__ void coop_bwd(const CBwdArgs& A, const unsigned blk, 
     tile_put16(cO, r, cq, o16[p]);
   }
   __syncthreads();
+  __builtin_amdgcn_sched_barrier(0);
   // ---- this wavefront: head hw, query tile sub (phase 1), key tile sub (phase 2)
   unsigned short* tK = reinterpret_cast<unsigned short*>(smem + hw * HL);
   unsigned short* tV = tK + ROWS * kPitch;
@@ -232,62 +255,36 @@ __device__ __forceinline__ void coop_bwd(const CBwdArgs& A, const unsigned blk, 
   float* sPair = sKin + 5 * ROWS;
   const int r = 32 * sub + rho;
   const bool act = r < n;
-  const Row<NPC> q = lds_row<NPC>(tQ, r, h), k = lds_row<NPC>(tK, r, h), v = lds_row<NPC>(tV, r, h), dO = lds_row<NPC>(tO, r, h);
-  const float qin = sQn[r], kin = sKin[r];
-  const float qa = qin * inv_tau, qc = qa * kLog2e;
   float dtau;
   Row<NPC> dqr;
   // ================= phase 1: this wave's query tile -> dQ =================
   {
-    f32x16 aS[NW], aP[NW];
-    float m = -INFINITY;
-#pragma unroll
-    for (int kj = 0; kj < NW; ++kj) {
-      const Row<NPC> kk = NW == 1 ? k : lds_row<NPC>(tK, 32 * kj + rho, h), vv = NW == 1 ? v : lds_row<NPC>(tV, 32 * kj + rho, h);
-      aS[kj] = mma_rows<NPC>(kk, q, splat(0.f));
-      aP[kj] = mma_rows<NPC>(vv, dO, splat(0.f));
-      float kr[16];
-      row_scalars(sKin + 32 * kj, h, kr);
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        aS[kj][e] = (32 * kj + c_row(e, h) < n) ? aS[kj][e] * kr[e] : kPadKey;      // t = (q . k) / |k|
-        m = fmaxf(m, aS[kj][e]);
-      }
-    }
-    m = half_max(m);
-    float l = 0.f, Dn = 0.f, E1 = 0.f, E2 = 0.f;
-#pragma unroll
-    for (int kj = 0; kj < NW; ++kj)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const float t = aS[kj][e];
-        const float p = __builtin_amdgcn_exp2f((t - m) * qc);     // exactly 0 for padded keys
-        const float pp = p * aP[kj][e];
-        l += p;
-        Dn += pp;
-        E1 = fmaf(pp, t, E1);
-        E2 = fmaf(p, t, E2);
-        aS[kj][e] = p;
-      }
-    l = half_sum(l);
-    Dn = half_sum(Dn);
-    const float il = __builtin_amdgcn_rcpf(l);
-    const float D = Dn * il;
-    // sum_keys dS a = qa (E1 - D E2) / l over this lane's keys; d a / d tau = -a / tau
-    dtau = -(E1 - D * E2) * il * (qa * inv_tau);
-    if (h == 0) {
-      sLse[r] = act ? fmaf(m, qc, __builtin_amdgcn_logf(l)) : 1e30f;      // log2 units; padded query: p = 0 in phase 2
-      sD[r] = D;
-    }
+    const Row<NPC> q = lds_row<NPC>(tQ, r, h), dO = lds_row<NPC>(tO, r, h);
+    const float qin = sQn[r];
+    const float qa = qin * inv_tau, qc = qa * kLog2e;
+    const float lse = sLse[r], D = sD[r];
     f32x16 oq = splat(0.f);
+    float dt = 0.f;
 #pragma unroll
     for (int kj = 0; kj < NW; ++kj) {
+      const Row<NPC> kk = lds_row<NPC>(tK, 32 * kj + rho, h), vv = lds_row<NPC>(tV, 32 * kj + rho, h);
+      f32x16 aS = mma_rows<NPC>(kk, q, splat(0.f));
+      const f32x16 aP = mma_rows<NPC>(vv, dO, splat(-D));                          // dP^T - D: the accumulator starts at -D[query]
       float kr[16];
       row_scalars(sKin + 32 * kj, h, kr);
 #pragma unroll
-      for (int e = 0; e < 16; ++e) aS[kj][e] = aS[kj][e] * (aP[kj][e] - D) * (kr[e] * il);      // dS / |k|
-      oq = mma_tokens(tK + 32 * kj * kPitch, aS[kj], oq, lane);                                 // dQ^^T[dh][query] (without 1 / tau)
+      for (int e = 0; e < 16; ++e) {
+        const float t = (32 * kj + c_row(e, h) < n) ? aS[e] * kr[e] : kPadKey;      // t = (q . k) / |k|; padded key: p = 0
+        const float p = __builtin_amdgcn_exp2f(fmaf(t, qc, -lse));
+        const float ds = p * aP[e];
+        dt = fmaf(ds, t, dt);
+        aS[e] = ds * kr[e];                                                          // dS / |k|: the A operand is the raw K row
+      }
+      oq = mma_tokens(tK + 32 * kj * kPitch, aS, oq, lane);                          // dQ^^T[dh][query] (without 1 / tau)
+      __builtin_amdgcn_sched_barrier(0);
     }
+    // sum_keys dS a = qa sum dS t over this lane's keys; d a / d tau = -a / tau
+    dtau = -dt * (qa * inv_tau);
     float qh[NPC][4], pr = 0.f;
 #pragma unroll
     for (int t = 0; t < NPC; ++t) {
@@ -304,38 +301,40 @@ __device__ __forceinline__ void coop_bwd(const CBwdArgs& A, const unsigned blk, 
       dqr.p[t] = pack_piece((oq[4 * t] - qh[t][0] * pr) * qa, (oq[4 * t + 1] - qh[t][1] * pr) * qa, (oq[4 * t + 2] - qh[t][2] * pr) * qa,
                             (oq[4 * t + 3] - qh[t][3] * pr) * qa);
   }
-  // one partial per (window, head): the query-tile sums of a head's wavefronts meet in LDS
   dtau = gd_wave_sum(dtau);
-  if (NW == 2) {
-    if (sub == 1 && lane == 0) *sPair = dtau;
-    __syncthreads();                       // also publishes sLse / sD of the other query tile
-    if (sub == 0 && lane == 0) A.dtau_part[(long long)w * A.H + hg * HW + hw] = dtau + *sPair;
-  } else {
-    if (lane == 0) A.dtau_part[(long long)w * A.H + hg * HW + hw] = dtau;
-    __builtin_amdgcn_wave_barrier();
-  }
+  if (NW == 2 && sub == 1 && lane == 0) *sPair = dtau;        // read after the barrier below
+  __builtin_amdgcn_sched_barrier(0);                           // the phases are independent: keep the scheduler from overlapping their registers
   // ================= phase 2: this wave's key tile -> dK, dV =================
   Row<NPC> dkr, dvr;
   {
+    const Row<NPC> k = lds_row<NPC>(tK, r, h), v = lds_row<NPC>(tV, r, h);
+    const float kin = sKin[r];
     const float kc = kin * kLog2e;
     f32x16 okk = splat(0.f), ov = splat(0.f);
 #pragma unroll
     for (int qi = 0; qi < NW; ++qi) {
-      const Row<NPC> qq = NW == 1 ? q : lds_row<NPC>(tQ, 32 * qi + rho, h), oo = NW == 1 ? dO : lds_row<NPC>(tO, 32 * qi + rho, h);
+      const Row<NPC> qq = lds_row<NPC>(tQ, 32 * qi + rho, h), oo = lds_row<NPC>(tO, 32 * qi + rho, h);
       f32x16 aS = mma_rows<NPC>(qq, k, splat(act ? 0.f : -1e30f));     // S[query][key]; padded key (lane): p = 0
-      f32x16 aP = mma_rows<NPC>(oo, v, splat(0.f));                    // dP[query][key]
-      float qr[16], lr_[16], dr[16];
+      f32x16 aP;                                                       // dP[query][key] - D[query]: the accumulator starts at -D
+      {
+        float dr[16];
+        row_scalars(sD + 32 * qi, h, dr);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) aP[e] = -dr[e];
+      }
+      aP = mma_rows<NPC>(oo, v, aP);
+      float qr[16], lr_[16];
       row_scalars(sQa + 32 * qi, h, qr);
       row_scalars(sLse + 32 * qi, h, lr_);
-      row_scalars(sD + 32 * qi, h, dr);
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const float p = __builtin_amdgcn_exp2f(fmaf(aS[e], qr[e] * kc, -lr_[e]));   // 0 for padded keys and padded queries
-        aS[e] = p * (aP[e] - dr[e]) * qr[e];                                         // dS / (|q| tau)
+        aS[e] = p * aP[e] * qr[e];                                                   // dS / (|q| tau)
         aP[e] = p;
       }
       okk = mma_tokens(tQ + 32 * qi * kPitch, aS, okk, lane);      // dK^^T[dh][key]
       ov = mma_tokens(tO + 32 * qi * kPitch, aP, ov, lane);        // dV^T[dh][key]
+      __builtin_amdgcn_sched_barrier(0);
     }
     float kh[NPC][4], pr = 0.f;
 #pragma unroll
@@ -357,6 +356,7 @@ __device__ __forceinline__ void coop_bwd(const CBwdArgs& A, const unsigned blk, 
   }
   // ---- results -> tiles (every wavefront of the head is done reading them) -> cooperative stores
   __syncthreads();
+  if (lane == 0 && sub == 0) A.dtau_part[(long long)w * A.H + hg * HW + hw] = NW == 2 ? dtau + *sPair : dtau;      // one partial per (window, head)
   store_tile<NPC>(tK, r, h, dqr);
   store_tile<NPC>(tV, r, h, dkr);
   store_tile<NPC>(tQ, r, h, dvr);
@@ -374,23 +374,11 @@ __device__ __forceinline__ void coop_bwd(const CBwdArgs& A, const unsigned blk, 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// kernels: the T = 64 and T = 32 levels of a layer in ONE launch (the T = 64 workgroups first - they run longest)
+// kernels: ALL occupancy levels of a layer in ONE launch per direction.  The sparse level's wavefronts (attn16_wave.h: one (window quad,
+// head) each, a chain of dependent round trips with next to no arithmetic) ride along with the dense levels' workgroups instead of
+// paying a launch of their own; first16 = they take the lowest block indices (their chains start at once, the dense workgroups fill
+// in behind - measured better than the other order, tools/attn_layer.py).
 // ---------------------------------------------------------------------------------------------------------------------
-template <int DH>
-__global__ __launch_bounds__(256) void k_attn_coop_fwd(CArgs A64, CArgs A32, unsigned nb64) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_coop[];
-  if (blockIdx.x < nb64) coop_fwd<DH, 2>(A64, blockIdx.x, smem_coop);
-  else coop_fwd<DH, 1>(A32, blockIdx.x - nb64, smem_coop);
-}
-template <int DH>
-__global__ __launch_bounds__(256) void k_attn_coop_bwd(CBwdArgs A64, CBwdArgs A32, unsigned nb64) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_coop[];
-  if (blockIdx.x < nb64) coop_bwd<DH, 2>(A64, blockIdx.x, smem_coop);
-  else coop_bwd<DH, 1>(A32, blockIdx.x - nb64, smem_coop);
-}
-// ... and ALL levels of a layer in one launch: the sparse level's wavefronts (attn16_wave.h: one (window quad, head) each, a chain of
-// dependent round trips with next to no arithmetic) ride along with the dense levels' workgroups instead of paying a launch of their own.
-// first16 = the T = 16 workgroups take the lowest block indices (their chains start at once; the dense workgroups fill in behind).
 template <int DH>
 __global__ __launch_bounds__(256) void k_attn_levels_fwd(CArgs A64, CArgs A32, t16w::A16Args A16, unsigned nb64, unsigned nb32, unsigned nb16,
                                                          int first16) {
@@ -405,10 +393,24 @@ __global__ __launch_bounds__(256) void k_attn_levels_fwd(CArgs A64, CArgs A32, t
   if (b < nb32) return coop_fwd<DH, 1>(A32, b, smem_coop);
   t16w::t16_fwd_body<DH>(A16, b - nb32, smem_coop);
 }
-// backward: the T = 64 workgroups keep their own launch (197 registers: two wavefronts per SIMD would throttle the sparse level),
-// T = 32 and T = 16 share one
 template <int DH>
-__global__ __launch_bounds__(256) void k_attn_lo_bwd(CBwdArgs A32, t16w::A16BwdArgs A16, unsigned nb32, unsigned nb16, int first16) {
+__global__ __launch_bounds__(256, 3) void k_attn_levels_bwd(CBwdArgs A64, CBwdArgs A32, t16w::A16BwdArgs A16, unsigned nb64, unsigned nb32,
+                                                            unsigned nb16, int first16) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_coop[];
+  unsigned b = blockIdx.x;
+  if (first16) {
+    if (b < nb16) return t16w::t16_bwd_body<DH>(A16, b, nb16, smem_coop);
+    b -= nb16;
+  }
+  if (b < nb64) return coop_bwd<DH, 2>(A64, b, smem_coop);
+  b -= nb64;
+  if (b < nb32) return coop_bwd<DH, 1>(A32, b, smem_coop);
+  t16w::t16_bwd_body<DH>(A16, b - nb32, nb16, smem_coop);
+}
+// a layer without T = 64 windows (the first stage at high mask ratios): the sparse level dominates and wants more wavefronts per SIMD
+// than the T = 64 body's registers allow
+template <int DH>
+__global__ __launch_bounds__(256, 4) void k_attn_lo_bwd(CBwdArgs A32, t16w::A16BwdArgs A16, unsigned nb32, unsigned nb16, int first16) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_coop[];
   unsigned b = blockIdx.x;
   if (first16) {
@@ -421,51 +423,19 @@ __global__ __launch_bounds__(256) void k_attn_lo_bwd(CBwdArgs A32, t16w::A16BwdA
 constexpr int imax(int a, int b) { return a > b ? a : b; }
 }  // namespace
 
-// bf16 I/O, H % 4 == 0.  n32 / n64: windows of the T = 32 / T = 64 levels (either may be 0), (win_start, win_len) of each level.
-int gd_attn_coop_fwd(const void* qk, const void* v, void* out, const int* csr_tok, const int* ws32, const int* wl32, int n32, const int* ws64,
-                     const int* wl64, int n64, int d, int H, const float* tau, float tau_min, hipStream_t st) {
-  const CArgs A32{(const unsigned short*)qk, (const unsigned short*)v, (unsigned short*)out, csr_tok, ws32, wl32, n32, d, H, tau, tau_min};
-  const CArgs A64{(const unsigned short*)qk, (const unsigned short*)v, (unsigned short*)out, csr_tok, ws64, wl64, n64, d, H, tau, tau_min};
-  const int DH = d / H;
-  const unsigned nb32 = (unsigned)((long long)n32 * (H / 4)), nb64 = (unsigned)((long long)n64 * (H / 2));
-  if (nb32 + nb64 == 0) return 0;
-  constexpr int lds = imax(2 * fwd_head_lds<64>(), 4 * fwd_head_lds<32>());
-  if (DH == 16) hipLaunchKernelGGL((k_attn_coop_fwd<16>), dim3(nb64 + nb32), dim3(256), lds, st, A64, A32, nb64);
-  else hipLaunchKernelGGL((k_attn_coop_fwd<32>), dim3(nb64 + nb32), dim3(256), lds, st, A64, A32, nb64);
-  GD_LAUNCH_CHECK();
-  return 0;
-}
-
-// part32 / part64: n32 * H / n64 * H partial slots of d loss / d tau (one per window and head)
-int gd_attn_coop_bwd(const void* qk, const void* v, const void* dout, void* dqk, void* dv, const int* csr_tok, const int* ws32, const int* wl32,
-                     int n32, float* part32, const int* ws64, const int* wl64, int n64, float* part64, int d, int H, const float* tau,
-                     float tau_min, hipStream_t st) {
-  const CBwdArgs A32{(const unsigned short*)qk, (const unsigned short*)v, (const unsigned short*)dout, (unsigned short*)dqk, (unsigned short*)dv,
-                     part32, csr_tok, ws32, wl32, n32, d, H, tau, tau_min};
-  const CBwdArgs A64{(const unsigned short*)qk, (const unsigned short*)v, (const unsigned short*)dout, (unsigned short*)dqk, (unsigned short*)dv,
-                     part64, csr_tok, ws64, wl64, n64, d, H, tau, tau_min};
-  const int DH = d / H;
-  const unsigned nb32 = (unsigned)((long long)n32 * (H / 4)), nb64 = (unsigned)((long long)n64 * (H / 2));
-  if (nb32 + nb64 == 0) return 0;
-  constexpr int lds = imax(2 * bwd_head_lds<64>(), 4 * bwd_head_lds<32>());
-  if (DH == 16) hipLaunchKernelGGL((k_attn_coop_bwd<16>), dim3(nb64 + nb32), dim3(256), lds, st, A64, A32, nb64);
-  else hipLaunchKernelGGL((k_attn_coop_bwd<32>), dim3(nb64 + nb32), dim3(256), lds, st, A64, A32, nb64);
-  GD_LAUNCH_CHECK();
-  return 0;
-}
-
 static int g_first16 = -1;
 static int first16() {
   if (g_first16 < 0) g_first16 = getenv("GDMAE_ATTN_FIRST16") ? atoi(getenv("GDMAE_ATTN_FIRST16")) : 1;
   return g_first16;
 }
 
-// every level of a layer (T = 16: windows [0, n16) of (ws16, wl16), H % 4 == 0) - forward: one launch
-int gd_attn_levels_fwd(const void* qk, const void* v, void* out, const int* csr_tok, const int* ws16, const int* wl16, int n16, const int* ws32,
-                       const int* wl32, int n32, const int* ws64, const int* wl64, int n64, int d, int H, const float* tau, float tau_min,
-                       hipStream_t st) {
-  const CArgs A32{(const unsigned short*)qk, (const unsigned short*)v, (unsigned short*)out, csr_tok, ws32, wl32, n32, d, H, tau, tau_min};
-  const CArgs A64{(const unsigned short*)qk, (const unsigned short*)v, (unsigned short*)out, csr_tok, ws64, wl64, n64, d, H, tau, tau_min};
+// bf16 I/O, H % 4 == 0, head dim 16 / 32.  (ws, wl, n) per level: windows [0, n) of the level's (win_start, win_len); any may be empty.
+// lse (optional): (n_tok, H) fp32, written for the rows of the T = 32 / 64 levels - what gd_attn_levels_bwd reads.
+int gd_attn_levels_fwd(const void* qk, const void* v, void* out, float* lse, const int* csr_tok, const int* ws16, const int* wl16, int n16,
+                       const int* ws32, const int* wl32, int n32, const int* ws64, const int* wl64, int n64, int d, int H, const float* tau,
+                       float tau_min, hipStream_t st) {
+  const CArgs A32{(const unsigned short*)qk, (const unsigned short*)v, (unsigned short*)out, lse, csr_tok, ws32, wl32, n32, d, H, tau, tau_min};
+  const CArgs A64{(const unsigned short*)qk, (const unsigned short*)v, (unsigned short*)out, lse, csr_tok, ws64, wl64, n64, d, H, tau, tau_min};
   const t16w::A16Args A16{(const unsigned short*)qk, (const unsigned short*)v, (unsigned short*)out, csr_tok, ws16, wl16, n16, d, H, tau, tau_min};
   const int DH = d / H;
   const unsigned nb32 = (unsigned)((long long)n32 * (H / 4)), nb64 = (unsigned)((long long)n64 * (H / 2));
@@ -477,26 +447,30 @@ int gd_attn_levels_fwd(const void* qk, const void* v, void* out, const int* csr_
   GD_LAUNCH_CHECK();
   return 0;
 }
-// backward: T = 64 alone (if any), T = 32 + T = 16 together
-int gd_attn_levels_bwd(const void* qk, const void* v, const void* dout, void* dqk, void* dv, const int* csr_tok, const int* ws16, const int* wl16,
-                       int n16, float* part16, const int* ws32, const int* wl32, int n32, float* part32, const int* ws64, const int* wl64, int n64,
-                       float* part64, int d, int H, const float* tau, float tau_min, hipStream_t st) {
+// o, lse: the forward's output rows and lse.  part16 / part32 / part64: partial slots of d loss / d tau (n * H per level)
+int gd_attn_levels_bwd(const void* qk, const void* v, const void* o, const float* lse, const void* dout, void* dqk, void* dv, const int* csr_tok,
+                       const int* ws16, const int* wl16, int n16, float* part16, const int* ws32, const int* wl32, int n32, float* part32,
+                       const int* ws64, const int* wl64, int n64, float* part64, int d, int H, const float* tau, float tau_min, hipStream_t st) {
   const int DH = d / H;
-  if (n64 > 0) {
-    const int rc = gd_attn_coop_bwd(qk, v, dout, dqk, dv, csr_tok, nullptr, nullptr, 0, nullptr, ws64, wl64, n64, part64, d, H, tau, tau_min, st);
-    if (rc) return rc;
-  }
-  const CBwdArgs A32{(const unsigned short*)qk, (const unsigned short*)v, (const unsigned short*)dout, (unsigned short*)dqk, (unsigned short*)dv,
-                     part32, csr_tok, ws32, wl32, n32, d, H, tau, tau_min};
+  const CBwdArgs A32{(const unsigned short*)qk, (const unsigned short*)v, (const unsigned short*)o, lse, (const unsigned short*)dout,
+                     (unsigned short*)dqk, (unsigned short*)dv, part32, csr_tok, ws32, wl32, n32, d, H, tau, tau_min};
+  const CBwdArgs A64{(const unsigned short*)qk, (const unsigned short*)v, (const unsigned short*)o, lse, (const unsigned short*)dout,
+                     (unsigned short*)dqk, (unsigned short*)dv, part64, csr_tok, ws64, wl64, n64, d, H, tau, tau_min};
   const t16w::A16BwdArgs A16{(const unsigned short*)qk, (const unsigned short*)v, (const unsigned short*)dout, (unsigned short*)dqk,
                              (unsigned short*)dv, part16, csr_tok, ws16, wl16, n16, d, H, tau, tau_min};
-  const unsigned nb32 = (unsigned)((long long)n32 * (H / 4));
+  const unsigned nb32 = (unsigned)((long long)n32 * (H / 4)), nb64 = (unsigned)((long long)n64 * (H / 2));
   const unsigned nb16 = (unsigned)((long long)gd_div_up(n16, t16w::kWinPerWave) * (H / 4));
-  if (nb16 + nb32 == 0) return 0;
-  constexpr int lds = imax(4 * bwd_head_lds<32>(), 4 * t16w::kWaveLds);
-  if (DH == 16) hipLaunchKernelGGL((k_attn_lo_bwd<16>), dim3(nb32 + nb16), dim3(256), lds, st, A32, A16, nb32, nb16, first16());
-  else hipLaunchKernelGGL((k_attn_lo_bwd<32>), dim3(nb32 + nb16), dim3(256), lds, st, A32, A16, nb32, nb16, first16());
+  if (nb16 + nb32 + nb64 == 0) return 0;
+  if (nb64 == 0) {
+    constexpr int lds_lo = imax(4 * bwd_head_lds<32>(), 4 * t16w::kWaveLds);
+    if (DH == 16) hipLaunchKernelGGL((k_attn_lo_bwd<16>), dim3(nb32 + nb16), dim3(256), lds_lo, st, A32, A16, nb32, nb16, first16());
+    else hipLaunchKernelGGL((k_attn_lo_bwd<32>), dim3(nb32 + nb16), dim3(256), lds_lo, st, A32, A16, nb32, nb16, first16());
+    GD_LAUNCH_CHECK();
+    return 0;
+  }
+  constexpr int lds = imax(imax(2 * bwd_head_lds<64>(), 4 * bwd_head_lds<32>()), 4 * t16w::kWaveLds);
+  if (DH == 16) hipLaunchKernelGGL((k_attn_levels_bwd<16>), dim3(nb64 + nb32 + nb16), dim3(256), lds, st, A64, A32, A16, nb64, nb32, nb16, first16());
+  else hipLaunchKernelGGL((k_attn_levels_bwd<32>), dim3(nb64 + nb32 + nb16), dim3(256), lds, st, A64, A32, A16, nb64, nb32, nb16, first16());
   GD_LAUNCH_CHECK();
   return 0;
 }
-

@@ -166,6 +166,15 @@ __device__ __forceinline__ float ssq16(uint4 v) {
   ss = __builtin_amdgcn_fdot2_f32_bf16(d, d, ss, false);
   return ss;
 }
+// dot product of the 8 bf16 pairs of two chunks
+__device__ __forceinline__ float dot16(uint4 a, uint4 b) {
+  float ss = 0.f;
+  ss = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, a.x), __builtin_bit_cast(bf16x2, b.x), ss, false);
+  ss = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, a.y), __builtin_bit_cast(bf16x2, b.y), ss, false);
+  ss = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, a.z), __builtin_bit_cast(bf16x2, b.z), ss, false);
+  ss = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, a.w), __builtin_bit_cast(bf16x2, b.w), ss, false);
+  return ss;
+}
 // 1 / max(|row|, 1e-12) from the per-chunk sums of squares: the CPH (2 or 4) chunks of a head are adjacent lanes
 template <int CPH>
 __device__ __forceinline__ float inv_norm_chunks(float ss) {

@@ -461,7 +461,7 @@ void add_zero(ZeroJobs& z, void* base, long long n, long long n_pad, long long r
 }
 
 struct Saved {   // layout of the activation block kept between forward and backward
-  char *xb, *xpb, *qk, *v, *o, *a, *x1, *st1, *x1b, *h, *gact, *f, *st2;
+  char *xb, *xpb, *qk, *v, *o, *a, *x1, *st1, *x1b, *h, *gact, *f, *st2, *lse;
   size_t bytes;
 };
 Saved saved_layout(void* base, long long n_pad, int d, int ff, int es) {
@@ -473,6 +473,7 @@ Saved saved_layout(void* base, long long n_pad, int d, int ff, int es) {
   s.a = take(rd * es); s.x1 = take(rd * 4); s.st1 = take((size_t)n_pad * 8);
   s.x1b = es == 2 ? take(rd * es) : s.x1;
   s.h = take(rf * es); s.gact = take(rf * es); s.f = take(rd * es); s.st2 = take((size_t)n_pad * 8);
+  s.lse = take((size_t)n_pad * (d / 16) * 4);      // log-sum-exp of the attention rows: (n, H) fp32, H <= d / 16
   s.bytes = off;
   return s;
 }
@@ -698,7 +699,7 @@ static int layer_fwd(const gdmae_layer_args* a, const gdmae_layer_args* next, bo
   }
   gd_attn_timing_tokens(n);
   GD_TRY(gdmae_window_attention_levels_fwd(s.qk, s.v, s.o, a->bf16, a->csr_tok, a->win_start, a->win_len, a->n_levels, a->n_win,
-                                           a->max_tokens, d, a->nhead, a->tau, a->tau_min, stream));
+                                           a->max_tokens, d, a->nhead, a->tau, a->tau_min, (float*)s.lse, stream));
   if (fused) {
     // out-projection + residual + LayerNorm 1; linear1 + GELU; linear2 + residual + LayerNorm 2 (+ the next layer's
     // q/k/v operands): three launches for what is eight in the unfused sequence
@@ -762,7 +763,7 @@ static int stage_fwd_v2(const gdmae_layer_args* layers, int n_layers, void* stre
     GD_TRY(gd_tok_gemm_qkv(st, s.xpb, s.xb, pk.qk, pk.v, a->bin, n_pad, d, s.qk, s.v));
     gd_attn_timing_tokens(n);
     GD_TRY(gdmae_window_attention_levels_fwd(s.qk, s.v, s.o, 1, a->csr_tok, a->win_start, a->win_len, a->n_levels, a->n_win, a->max_tokens, d,
-                                             a->nhead, a->tau, a->tau_min, stream));
+                                             a->nhead, a->tau, a->tau_min, (float*)s.lse, stream));
     const gdmae_layer_args* next = i + 1 < n_layers ? &layers[i + 1] : nullptr;
     void *y_bf = nullptr, *ypos_bf = nullptr;
     if (next) {
@@ -928,7 +929,7 @@ static int layer_bwd(const gdmae_layer_args* a, bool upstream3, bool defer_add3,
   for (int l = 0; l < a->n_levels; ++l) pbase += (long long)a->n_win[l] * a->nhead;
   gd_attn_timing_tokens(n);
   GD_TRY(gdmae_window_attention_levels_bwd(s.qk, s.v, w.d_o, w.dqk, w.dv, a->bf16, (float*)w.apart, a->csr_tok, a->win_start, a->win_len,
-                                           a->n_levels, a->n_win, a->max_tokens, d, a->nhead, a->tau, a->tau_min, stream));
+                                           a->n_levels, a->n_win, a->max_tokens, d, a->nhead, a->tau, a->tau_min, s.o, (const float*)s.lse, stream));
   if (!grouped) GD_TRY(gdmae_sum_partials_gated((const float*)w.apart, pbase, 1.f, (float*)w.dtau, a->tau, a->tau_min, stream));
   const char* Win = (const char*)a->Win;
   const int nb_rows = gd_ln_partial_rows(n, d), nb_fused = (int)(n_pad / gd_tok_gemm_rows(d));
@@ -1004,7 +1005,7 @@ static int stage_bwd_v2(const gdmae_layer_args* layers, int n_layers, void* stre
     for (int l = 0; l < a->n_levels; ++l) pbase += (long long)a->n_win[l] * a->nhead;
     gd_attn_timing_tokens(n);
     GD_TRY(gdmae_window_attention_levels_bwd(s.qk, s.v, w.d_o, w.dqk, w.dv, 1, (float*)w.apart, a->csr_tok, a->win_start, a->win_len,
-                                             a->n_levels, a->n_win, a->max_tokens, d, a->nhead, a->tau, a->tau_min, stream));
+                                             a->n_levels, a->n_win, a->max_tokens, d, a->nhead, a->tau, a->tau_min, s.o, (const float*)s.lse, stream));
     const int nb = (int)(n_pad / gd_layer_fused_rows(d));
     GD_TRY(grouped_dw_and_tail(a, s, w, c, n, n_pad, nb, nb, pbase));
     if (i > 0) {

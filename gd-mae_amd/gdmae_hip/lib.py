@@ -83,8 +83,8 @@ SIGNATURES = {
     "gdmae_segmax_bn_bwd": (_I, [_P, _I, _P, _P, _P, _P, _L, _I, _P, _P, _P, _P, _I, _P]),
     "gdmae_window_attention_fwd": (_I, [_P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P, _F, _P]),
     "gdmae_window_attention_bwd": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P, _F, _P]),
-    "gdmae_window_attention_levels_fwd": (_I, [_P, _P, _P, _I, _P, _P, _P, _I, _P, _P, _I, _I, _P, _F, _P]),
-    "gdmae_window_attention_levels_bwd": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P, _P, _I, _I, _P, _F, _P]),
+    "gdmae_window_attention_levels_fwd": (_I, [_P, _P, _P, _I, _P, _P, _P, _I, _P, _P, _I, _I, _P, _F, _P, _P]),
+    "gdmae_window_attention_levels_bwd": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P, _P, _I, _I, _P, _F, _P, _P, _P]),
     "gdmae_attention_timing": (_I, [_I]),
     "gdmae_attention_timing_read": (_I, [_I, _P, _P]),
     "gdmae_kernel_timing": (_I, [_I]),

@@ -378,15 +378,15 @@ class WindowCosineAttention(torch.autograd.Function):
         n, d = v.shape
         out = torch.empty(n, d, dtype=v.dtype, device=v.device)
         tau_flat = tau.detach().reshape(1).float().contiguous()
-        base = 0
-        for lvl, nw in enumerate(wplan.n_win):
-            if nw > 0:
-                # algorithmic bytes: q,k,v rows read + out row written per token, + CSR (4 B/token + 8 B/window)
-                with timing.kernel("k_win_attn_fwd", wplan.n_tok[lvl] * (4 * d * es + 4) + 8 * nw):
-                    L.call("gdmae_window_attention_fwd", L.ptr(qk), L.ptr(v), L.ptr(out), bf, L.ptr(wplan.csr_tok),
-                           L.ptr(wplan.win_start[base:]), L.ptr(wplan.win_len[base:]), nw, wplan.max_tokens[lvl], d, nhead,
-                           L.ptr(tau_flat), float(tau_min), L.stream())
-            base += nw
+        # all occupancy levels through the entry the layer executor uses (bf16 rows: one launch; it leaves the rows' log-sum-exp for
+        # the backward); algorithmic bytes: q,k,v rows read + out row written per token, + CSR (4 B/token + 8 B/window)
+        lse = torch.empty(n, nhead, dtype=torch.float32, device=v.device)
+        nl = len(wplan.n_win)
+        with timing.kernel("k_win_attn_fwd", n * (4 * d * es + 4) + 8 * sum(wplan.n_win)):
+            L.call("gdmae_window_attention_levels_fwd", L.ptr(qk), L.ptr(v), L.ptr(out), bf, L.ptr(wplan.csr_tok), L.ptr(wplan.win_start),
+                   L.ptr(wplan.win_len), nl, L.host_i32(wplan.n_win), L.host_i32(wplan.max_tokens), d, nhead, L.ptr(tau_flat), float(tau_min),
+                   L.ptr(lse), L.stream())
+        ctx.out, ctx.lse = out.detach(), lse
         ctx.save_for_backward(qk, v, tau_flat)
         ctx.wplan, ctx.nhead, ctx.tau_min, ctx.tau_shape, ctx.tau_dtype = wplan, nhead, tau_min, tau.shape, tau.dtype
         return out
@@ -403,17 +403,12 @@ class WindowCosineAttention(torch.autograd.Function):
         dv = torch.empty_like(v)
         n_items = [nw * H for nw in wplan.n_win]      # one partial per (window, head) at most
         part = torch.zeros(max(sum(n_items), 1), dtype=torch.float32, device=v.device)   # VALU levels fill fewer slots
-        base, pbase = 0, 0
-        for lvl, nw in enumerate(wplan.n_win):
-            if nw > 0:
-                # algorithmic bytes: q,k,v,dout rows read + dq,dk,dv rows written per token (7 d elements), + CSR
-                with timing.kernel("k_win_attn_bwd", wplan.n_tok[lvl] * (7 * d * es + 4) + 8 * nw):
-                    L.call("gdmae_window_attention_bwd", L.ptr(qk), L.ptr(v), L.ptr(g), L.ptr(dqk), L.ptr(dv), bf,
-                           L.ptr(part[pbase:]), L.ptr(wplan.csr_tok), L.ptr(wplan.win_start[base:]),
-                           L.ptr(wplan.win_len[base:]), nw, wplan.max_tokens[lvl], d, H, L.ptr(tau_flat),
-                           float(ctx.tau_min), L.stream())
-            base += nw
-            pbase += n_items[lvl]
+        pbase = sum(n_items)
+        # algorithmic bytes: q,k,v,dout rows read + dq,dk,dv rows written per token (7 d elements), + CSR
+        with timing.kernel("k_win_attn_bwd", n * (7 * d * es + 4) + 8 * sum(wplan.n_win)):
+            L.call("gdmae_window_attention_levels_bwd", L.ptr(qk), L.ptr(v), L.ptr(g), L.ptr(dqk), L.ptr(dv), bf, L.ptr(part), L.ptr(wplan.csr_tok),
+                   L.ptr(wplan.win_start), L.ptr(wplan.win_len), len(wplan.n_win), L.host_i32(wplan.n_win), L.host_i32(wplan.max_tokens), d, H,
+                   L.ptr(tau_flat), float(ctx.tau_min), L.ptr(ctx.out), L.ptr(ctx.lse), L.stream())
         dtau = torch.empty(1, dtype=torch.float32, device=v.device)
         # d clamp(tau, min)/d tau = 1 where tau >= min (torch.clamp backward), folded into the partial sum
         L.call("gdmae_sum_partials_gated", L.ptr(part), pbase, 1.0, L.ptr(dtau), L.ptr(tau_flat), float(ctx.tau_min),

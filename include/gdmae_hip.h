@@ -321,15 +321,18 @@ int gdmae_window_attention_bwd(const void* qk, const void* v, const void* dout, 
                                int n_win, int T, int d, int H, const float* tau, float tau_min, void* stream);
 /* All occupancy levels of one shift in one call (what the layer executor issues): the windows of level l are
  * win_start / win_len [sum_{k<l} n_win[k], ...), max_tokens[l] its padded token count; dtau_part holds
- * sum_l n_win[l] * H partial slots, level after level.  bf16 rows go out as two launches (T = 16; T = 32 and T = 64
- * together), everything else level by level through the functions above. */
+ * sum_l n_win[l] * H partial slots, level after level.  bf16 rows with levels of 16 / 32 / 64 tokens go out as ONE launch per direction
+ * (csrc/attention_coop.hip), everything else level by level through the functions above.
+ * lse (forward, optional): (n_tok, H) fp32, receives log2 sum_k exp(logit) of every row of the T = 32 / 64 levels; the backward takes it
+ * back together with the forward's output rows `out` (both optional there: without them the backward re-derives the softmax statistics on
+ * the one-wavefront-per-(window, head) kernels). */
 int gdmae_window_attention_levels_fwd(const void* qk, const void* v, void* out, int io_bf16, const int* csr_tok,
                                       const int* win_start, const int* win_len, int n_levels, const int* n_win,
-                                      const int* max_tokens, int d, int H, const float* tau, float tau_min, void* stream);
+                                      const int* max_tokens, int d, int H, const float* tau, float tau_min, float* lse, void* stream);
 int gdmae_window_attention_levels_bwd(const void* qk, const void* v, const void* dout, void* dqk, void* dv, int io_bf16,
                                       float* dtau_part, const int* csr_tok, const int* win_start, const int* win_len,
-                                      int n_levels, const int* n_win, const int* max_tokens, int d, int H,
-                                      const float* tau, float tau_min, void* stream);
+                                      int n_levels, const int* n_win, const int* max_tokens, int d, int H, const float* tau,
+                                      float tau_min, const void* out, const float* lse, void* stream);
 /* Measurement hook (bench.py roofline leg): HIP-event brackets around the two all-levels entries on the stream they launch on.
  * gdmae_attention_timing(1) starts collecting (dropping earlier records), (0) stops; gdmae_attention_timing_read returns the
  * summed milliseconds and the number of calls of the forward (which = 0) / backward (which = 1) entry. */

@@ -327,10 +327,13 @@ def test_packed_window_attention_edge_cases(d, H):
         dvv = torch.zeros(n_tok, d, dtype=torch.bfloat16, device=dv)
         part = torch.full((sum(n_win) * H,), 123.0, device=dv)             # every slot must be written
         if levels_entry:
+            # "lse": the product path - the forward leaves the rows' log-sum-exp, the backward takes it and the forward's output
+            # (one launch per direction); True: without them (the backward re-derives the statistics, per-(window, head) kernels)
+            lse = torch.full((n_tok, H), float("nan"), device=dv) if levels_entry == "lse" else None
             L.call("gdmae_window_attention_levels_fwd", L.ptr(qk), L.ptr(v), L.ptr(out), 1, L.ptr(csr), L.ptr(ws), L.ptr(wl), 3, nw_h, T_h, d, H,
-                   L.ptr(tau), 0.01, L.stream())
+                   L.ptr(tau), 0.01, L.ptr(lse), L.stream())
             L.call("gdmae_window_attention_levels_bwd", L.ptr(qk), L.ptr(v), L.ptr(go), L.ptr(dqk), L.ptr(dvv), 1, L.ptr(part), L.ptr(csr),
-                   L.ptr(ws), L.ptr(wl), 3, nw_h, T_h, d, H, L.ptr(tau), 0.01, L.stream())
+                   L.ptr(ws), L.ptr(wl), 3, nw_h, T_h, d, H, L.ptr(tau), 0.01, L.ptr(out if lse is not None else None), L.ptr(lse), L.stream())
         else:
             base = pb = 0
             for nw, T in zip(n_win, (16, 32, 64)):
@@ -344,7 +347,7 @@ def test_packed_window_attention_edge_cases(d, H):
 
     try:
         ref = run(1, False)
-        for entry in (False, True):
+        for entry in (False, True, "lse"):
             got = run(0, entry)
             for a, b, nm in zip(got[:3], ref[:3], ("out", "dqk", "dv")):
                 rel = float((a - b).norm() / b.norm())

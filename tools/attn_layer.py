@@ -25,13 +25,14 @@ for si, st in enumerate(plan.stages):
         tau = torch.full((1,), 0.1, device=dev)
         part = torch.zeros(sum(w.n_win) * H + 1, device=dev)
         nl = len(w.n_win)
+        lse = torch.empty(st.n_tok, H, device=dev)
         nw_h, T_h = L.host_i32(w.n_win), L.host_i32(w.max_tokens)
         def fwd():
             L.call("gdmae_window_attention_levels_fwd", L.ptr(qk), L.ptr(v), L.ptr(out), 1, L.ptr(w.csr_tok), L.ptr(w.win_start), L.ptr(w.win_len), nl,
-                   nw_h, T_h, d, H, L.ptr(tau), 0.01, L.stream())
+                   nw_h, T_h, d, H, L.ptr(tau), 0.01, L.ptr(lse), L.stream())
         def bwd():
             L.call("gdmae_window_attention_levels_bwd", L.ptr(qk), L.ptr(v), L.ptr(g), L.ptr(dqk), L.ptr(dv), 1, L.ptr(part), L.ptr(w.csr_tok),
-                   L.ptr(w.win_start), L.ptr(w.win_len), nl, nw_h, T_h, d, H, L.ptr(tau), 0.01, L.stream())
+                   L.ptr(w.win_start), L.ptr(w.win_len), nl, nw_h, T_h, d, H, L.ptr(tau), 0.01, L.ptr(out), L.ptr(lse), L.stream())
         line = f"stage {si} shift {shift} windows {w.n_win} tokens {w.n_tok}:"
         for impl in (3, 0):
             L.call("gdmae_set_attention_impl", impl)
