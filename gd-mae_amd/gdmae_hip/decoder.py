@@ -399,7 +399,7 @@ def deconv_rows(x, deconv):
 
 
 class PredHeadFn(torch.autograd.Function):
-    """bf16(x W^T + b) for the prediction head nn.Linear(128 -> 48) on the fp32 decoder rows of all pillars (csrc/rows_gemm.hip
+    """x W^T + b (fp32-accurate forward, bf16-operand backward) for the prediction head nn.Linear(128 -> 48) on the fp32 decoder rows of all pillars (csrc/rows_gemm.hip
     k_pred_*; reference spt_backbone_mae.py:52,74): no cast passes, no unaligned library GEMMs."""
 
     @staticmethod
@@ -409,8 +409,8 @@ class PredHeadFn(torch.autograd.Function):
         packed = torch.empty(L.load().gdmae_pred_head_packed_bytes(), dtype=torch.uint8, device=x.device)
         L.call("gdmae_pred_head_pack", L.ptr(weight), None if bias is None else L.ptr(bias), weight.shape[1], n_out, L.ptr(packed), L.stream())
         xb = torch.empty(n, x.shape[1], dtype=torch.bfloat16, device=x.device)      # the rounded operand rows: operand of the weight gradient
-        # the result is rounded to bf16 like the autocast linear's, but handed on widened to fp32: its consumer (the Chamfer kernel)
-        # reads fp32 rows, and an fp32 output receives the loss's fp32 gradient without a cast in between
+        # fp32-accurate result (three-term split-bf16 product, fp32 bias): the Chamfer kernel squares these offsets, and a bf16-rounded
+        # output biases the loss by 1 - 4e-4 relative; an fp32 output also receives the loss's fp32 gradient without a cast in between
         y = torch.empty(n, n_out, dtype=torch.float32, device=x.device)
         L.call("gdmae_pred_head_fwd", L.ptr(x), n, n_out, L.ptr(packed), None, L.ptr(xb), L.ptr(y), L.stream())
         ctx.save_for_backward(xb, packed)
@@ -446,11 +446,11 @@ class PredHeadFn(torch.autograd.Function):
 
 
 def pred_head(x, linear):
-    """``linear`` (nn.Linear 128 -> n_out) applied to fp32 rows under autocast: -> (n, n_out) bf16-rounded values (fp32 storage on the fused
-    path, bf16 from the library path)."""
+    """``linear`` (nn.Linear 128 -> n_out) applied to fp32 rows under autocast: -> (n, n_out) fp32 values accurate to fp32 on the fused path
+    (bf16 from the library path)."""
     w, b = linear.weight, linear.bias
     if (DECONV_ROWS and x.is_cuda and torch.is_autocast_enabled() and x.dtype == torch.float32 and w.dtype == torch.float32 and w.is_contiguous()
-            and w.shape[1] == 128 and 4 <= w.shape[0] <= 64 and w.shape[0] % 4 == 0 and x.shape[0] > 0):
+            and w.shape[1] == 128 and 8 <= w.shape[0] <= 64 and w.shape[0] % 8 == 0 and x.shape[0] > 0):
         dw, db = ops.direct_grad(w), (ops.direct_grad(b) if b is not None else None)
         direct = (dw, db) if (dw is not None and (b is None or db is not None)) else None
         y = PredHeadFn.apply(x, w, b, direct)

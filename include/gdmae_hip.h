@@ -606,13 +606,15 @@ int gdmae_deconv_rows_bwd_weight(const void* X, const void* dP, long long n, int
                                  void* stream);
 
 /* The prediction head nn.Linear(128 -> n_out) on the fp32 decoder rows of all pillars (spt_backbone_mae.py:52,74 `decoder_pred`;
- * n_out = 48 = 16 points x 3; 4 <= n_out <= 64, n_out % 4 == 0).  X (n, 128) fp32 is rounded to bf16 on load, Y (n, n_out) bf16 =
- * bf16(X W^T + b) (the autocast linear's rounding points); backward: dX (n, 128) fp32 (optional), dW (n_out, 128) and db (n_out) fp32
- * ACCUMULATED in a fixed order.  packed: gdmae_pred_head_packed_bytes(), refreshed by gdmae_pred_head_pack whenever the weights change. */
+ * n_out = 48 = 16 points x 3; 8 <= n_out <= 64, n_out % 8 == 0).  The forward is fp32-accurate on the bf16 matrix cores: X and W are
+ * split into their bf16 rounding and the bf16 rounding of the remainder, X W^T = Xh Wh + Xl Wh + Xh Wl in fp32 accumulators (the Chamfer
+ * loss squares these offsets: bf16-rounded outputs bias it by 1 - 4e-4 relative); Y_f32 (n, n_out) receives the accumulated values,
+ * Y (n, n_out) bf16 their rounding.  Backward on bf16 operands (X_bf16 = bf16(X), bf16(dY)): dX (n, 128) fp32 (optional), dW (n_out, 128)
+ * and db (n_out) fp32 ACCUMULATED in a fixed order.  packed: gdmae_pred_head_packed_bytes(), refreshed by gdmae_pred_head_pack whenever the weights change. */
 size_t gdmae_pred_head_packed_bytes(void);
 int gdmae_pred_head_pack(const float* weight, const float* bias, int n_in, int n_out, void* packed, void* stream);
 int gdmae_pred_head_fwd(const float* X, long long n, int n_out, const void* packed, void* Y, void* X_bf16 /* (n, 128) bf16 out: the rounded
-                        operand rows, operand of the weight gradient */, float* Y_f32 /* optional (n, n_out): Y widened to fp32; Y itself may then be NULL */,
+                        operand rows, operand of the weight gradient */, float* Y_f32 /* optional (n, n_out) fp32 result; Y itself may then be NULL */,
                         void* stream);
 size_t gdmae_pred_head_bwd_workspace_bytes(long long n);
 int gdmae_pred_head_bwd(const void* dY, int dy_f32 /* dY holds fp32 rows: rounded here, the rounded rows written to dY_bf16 */,

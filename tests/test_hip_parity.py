@@ -704,11 +704,22 @@ def test_prefetched_plan_is_identical_to_inline_plan():
     assert float(ret0["loss"]) == float(ret1["loss"])
 
 
+# bench (bf16) mode against the REFERENCE's fp32 goldens: bounds = 2 x the deviations measured on MI355X (round 5, printed by the test and
+# by tools/bench_vs_golden.py; loss floor 1e-4 = north_star's bound).  Measured: loss 4.5e-4 / 1.9e-5 / 7.2e-5 / 1.2e-4, worst
+# per-parameter gradient-norm deviation 4.4 / 4.0 / 2.8 / 4.1 %, temperature gradients within 21 / 23 / 24 / 9 % of the largest |dtau|.
+# Before the prediction head's forward became fp32-accurate (rows_gemm.hip k_pred_fwd) the loss sat at 4.8e-4 / 2.7e-4 / 3.5e-4 / 1.4e-4:
+# the Chamfer loss squares those offsets, so their rounding is a bias.  What remains on kitti_b2 is the rounding of the decoder's GEMM
+# OPERANDS (tools/oracle_rounding_injection.py: each of deconvolution / conv_out operands / conv_out output moves the fp32 oracle's loss
+# by 0.7 - 2.4e-4 with either sign when rounded to bf16) - inherent to bf16 products, not a stored tensor.
+BENCH_LOSS_REL = {"kitti_b2": 9e-4, "kitti_b2_m75": 1e-4, "waymo_b1": 1.5e-4, "once_e_b1": 2.4e-4}
+BENCH_NORM_REL, BENCH_TAU_ABS = 0.09, 0.5
+
+
 @pytest.mark.parametrize("name", CASES + ["once_e_b1"])
 def test_bench_mode_gradients_reach_every_parameter(name):
-    """The configuration bench.py times (flat optimizer with bf16 weight shadows + bf16 autocast + fused layers):
-    every parameter must receive its gradient (a detached shadow silently dropping one is 'work skipped'), and the
-    per-parameter gradient norms must agree with the fp32 reference golden within bf16 noise."""
+    """The configuration bench.py times (flat optimizer with bf16 weight shadows + bf16 autocast + fused layers) against the fp32
+    goldens generated from the unmodified reference: every parameter must receive its gradient (a detached shadow silently dropping
+    one is 'work skipped'); loss, per-parameter gradient norms and temperature gradients within 2 x the measured bf16 deviations."""
     import logging
     from gdmae_hip import configs, optim
     from pcdet.models import build_network
@@ -723,21 +734,23 @@ def test_bench_mode_gradients_reach_every_parameter(name):
           "mae_noise": torch.from_numpy(z["noise"]).to(dev())}
     with torch.autocast("cuda", dtype=torch.bfloat16):
         ret, _, _ = net(bd)
-    assert abs(float(ret["loss"]) - float(z["loss"])) <= 2e-2 * float(z["loss"])
+    loss_rel = abs(float(ret["loss"].detach()) - float(z["loss"])) / float(z["loss"])
     ret["loss"].backward()
     names = sorted(shapes)
     params = dict(net.named_parameters())
     gn = np.array([float(params[k].grad.double().norm()) for k in names])
+    assert np.isfinite(gn).all()
     assert (gn > 0).all(), [names[i] for i in np.flatnonzero(gn == 0)]
     rel = np.abs(gn - z["grad_norm"]) / (z["grad_norm"] + 1e-12)
-    # tau gradients are heavily cancelling sums of O(1e-4): with bf16 q/k/v I/O they are noise-dominated (documented
-    # in DESIGN.md section 7), so they are only required to be finite and non-zero here
-    tol = np.array([np.inf if k.endswith("tau") else 0.12 for k in names])
-    assert np.isfinite(gn).all()
+    # tau gradients are heavily cancelling sums of O(1e-4) on an ABSOLUTE noise floor set by the bf16 q / k / v rows (DESIGN.md section
+    # 5): bounded against the largest |dtau| of the case, like at full size (test_full_size_properties.py TAU_ABS)
     nt = np.array([not k.endswith("tau") for k in names])
-    print(f"[bench mode vs fp32 golden, {name}] loss rel {abs(float(ret['loss']) - float(z['loss'])) / float(z['loss']):.3e}, worst gradient-norm "
-          f"deviation (tau excluded) {rel[nt].max():.3e}")
-    assert (rel <= tol).all(), [(names[i], rel[i]) for i in np.flatnonzero(rel > tol)]
+    tau_dev = np.abs(gn[~nt] - z["grad_norm"][~nt]).max() / z["grad_norm"][~nt].max()
+    print(f"[bench mode vs fp32 golden, {name}] loss rel {loss_rel:.3e}, worst gradient-norm deviation (tau excluded) {rel[nt].max():.3e}, "
+          f"tau: worst | |g| - |g_ref| | / max |g_ref| {tau_dev:.3e}")
+    assert loss_rel <= BENCH_LOSS_REL[name], loss_rel
+    assert (rel[nt] <= BENCH_NORM_REL).all(), [(names[i], rel[i]) for i in np.flatnonzero(nt & (rel > BENCH_NORM_REL))]
+    assert tau_dev <= BENCH_TAU_ABS, tau_dev
 
 
 @pytest.mark.parametrize("bdt", [torch.float32, torch.bfloat16])
@@ -876,8 +889,10 @@ def test_fp32_gemm_is_exact_fp32_on_own_kernel(M, N, K):
 
 @pytest.mark.parametrize("n", [131072 + 37, 700])
 def test_pred_head_matches_fp64_linear(n):
-    """gdmae_pred_head_* (nn.Linear(128 -> 48) on fp32 rows, csrc/rows_gemm.hip) against the fp64 product of the same bf16-rounded
-    operands: forward to bf16 rounding, input gradient to fp32 round-off, weight / bias gradients accumulated, repeatable."""
+    """gdmae_pred_head_* (nn.Linear(128 -> 48) on fp32 rows, csrc/rows_gemm.hip): the forward (three-term split-bf16 product, fp32 bias)
+    against the fp64 product of the UNROUNDED fp32 operands to 2e-5 of the largest value (a bf16-operand product sits at 4e-3); the
+    backward against the fp64 products of the bf16-rounded operands: input gradient to fp32 round-off, weight / bias gradients
+    accumulated, repeatable."""
     from gdmae_hip import lib as L
     g = torch.Generator().manual_seed(n)
     x = torch.randn(n, 128, generator=g).to(dev())
@@ -891,13 +906,13 @@ def test_pred_head_matches_fp64_linear(n):
     xb = torch.empty(n, 128, dtype=torch.bfloat16, device=dev())
     yf = torch.empty(n, 48, dtype=torch.float32, device=dev())
     L.call("gdmae_pred_head_fwd", L.ptr(x), n, 48, L.ptr(packed), L.ptr(y), L.ptr(xb), L.ptr(yf), L.stream())
-    assert torch.equal(xb, x.to(torch.bfloat16)) and torch.equal(yf, y.float())
+    assert torch.equal(xb, x.to(torch.bfloat16)) and torch.equal(y, yf.to(torch.bfloat16))
     yf2 = torch.empty_like(yf)
     L.call("gdmae_pred_head_fwd", L.ptr(x), n, 48, L.ptr(packed), None, None, L.ptr(yf2), L.stream())
     assert torch.equal(yf2, yf)
-    xq, Wq, bq = x.to(torch.bfloat16).double(), W.to(torch.bfloat16).double(), b.to(torch.bfloat16).double()
-    ref = xq @ Wq.t() + bq
-    assert float((y.double() - ref).abs().max()) <= 8e-3 * float(ref.abs().max())
+    ref = x.double() @ W.double().t() + b.double()
+    assert float((yf.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+    xq, Wq = x.to(torch.bfloat16).double(), W.to(torch.bfloat16).double()
     dx = torch.empty(n, 128, dtype=torch.float32, device=dev())
     dW = torch.full((48, 128), 0.25, dtype=torch.float32, device=dev())
     db = torch.full((48,), -1.0, dtype=torch.float32, device=dev())
