@@ -229,12 +229,12 @@ def test_bench_mode_matches_fp32_mode_at_full_size(scene):
     """8 full-size frames, the exact configuration bench.py times (bf16 autocast, fused VFE layers, stage executor, tile
     convolution, flat optimizer with bf16 weight shadows) against the HIP fp32 parity mode with the dense decoder dataflow
     (the mode held to 1e-4 of the reference above and in test_hip_parity) on the same weights, frames and masking noise:
-    identical geometry, loss within 1 %, every parameter's gradient norm within 10 % and direction within cos >= 0.97
-    (bf16 activations: 2^-9 relative rounding per stored tensor, 12 encoder layers).  tau (one scalar per layer whose
-    gradient is a heavily cancelling sum over all (window, head, query, key) terms: 2e-5 .. 2e-4 here) carries an
-    ABSOLUTE noise floor from the bf16 q/k/v rows, measured at <= 4e-5 = 17 % of the largest |dtau|: it is bounded by
-    |dtau_bf16 - dtau_fp32| <= 20 % of the largest |dtau_fp32| over the layers + 10 % of its own value, and the 12-vector
-    of tau gradients by a relative L2 error of 20 % (measured 11 %)."""
+    identical geometry; loss, every parameter's gradient norm and direction within the constants above (LOSS_REL 2.5e-4, NORM_REL
+    6.5 %, COS_MIN 0.988 = 2 x the measured deviations; round 5 measured 1.4e-4, 2.1 %, 0.99424).  tau (one scalar per layer whose
+    gradient is a heavily cancelling sum over all (window, head, query, key) terms: 2e-5 .. 2e-4 here) carries an ABSOLUTE noise
+    floor from the bf16 q/k/v rows: it is bounded by |dtau_bf16 - dtau_fp32| <= TAU_ABS (20 %) of the largest |dtau_fp32| over the
+    layers + 10 % of its own value, and the 12-vector of tau gradients by a relative L2 error of TAU_L2 (20 %); measured 5.6 - 15 % /
+    4.8 - 10 % over rounds 4 and 5."""
     import numpy as np
     from gdmae_hip import configs, optim
     from pcdet.models import build_network
