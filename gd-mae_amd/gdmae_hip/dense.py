@@ -12,7 +12,98 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
+from . import lib as L
+from . import ops
 from .vfe import BNReLURows, BNReLURowsCat
+
+
+# ------------------------------------------------------------------------------------------------
+# Conv2d(k = 3, stride 1, padding = dilation) on channels-last bf16 maps: csrc/conv_dense.hip (forward, input gradient, weight gradient)
+# ------------------------------------------------------------------------------------------------
+def _pad32(c: int) -> int:
+    return (c + 31) // 32 * 32
+
+
+def conv3x3_supported(conv: nn.Module, x: torch.Tensor) -> bool:
+    """The library's dense convolution takes this layer on this input: 3 x 3, stride 1, padding = dilation in {1, 2}, one group, zero
+    padding, bf16 compute (autocast), input channels in multiples of 64 (the weight gradient's blocks)."""
+    if not (isinstance(conv, nn.Conv2d) and x.is_cuda and x.dim() == 4 and torch.is_autocast_enabled()):
+        return False
+    d = conv.dilation[0]
+    return (conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.dilation == (d, d) and conv.padding == (d, d) and d in (1, 2)
+            and conv.groups == 1 and conv.padding_mode == 'zeros' and conv.in_channels % 64 == 0 and conv.in_channels <= 1024
+            and conv.out_channels <= 1024 and (d == 1 or conv.out_channels % 64 == 0) and conv.weight.dtype == torch.float32)
+
+
+class Conv3x3Dense(torch.autograd.Function):
+    """conv2d(x, weight, bias, padding = dil, dilation = dil) with bf16 operands / fp32 accumulation on channels-last maps (reference
+    call sites: sst_bev_backbone.py:14-19, center_head.py:20-35, spt_backbone.py:289-291).  x: (B, Cin, H, W) in any layout / dtype
+    (moved to channels-last bf16 if it is not there already); returns a (B, Cout, H, W) view of a channels-last bf16 map."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, dil, direct):
+        B, cin, H, W = x.shape
+        cout = weight.shape[0]
+        cl = _pad32(cout)
+        xr = x.permute(0, 2, 3, 1)
+        xr = xr.to(torch.bfloat16) if xr.dtype != torch.bfloat16 else xr
+        xr = xr.contiguous()                                                   # (B, H, W, cin): no copy for a channels-last bf16 map
+        w = weight.contiguous()
+        packed = torch.empty(L.load().gdmae_conv3x3_dense_packed_bytes(cin, cout), dtype=torch.uint8, device=x.device)
+        L.call("gdmae_conv3x3_dense_pack", L.ptr(w), cin, cout, dil, 0, L.ptr(packed), L.stream())
+        bl = None
+        if bias is not None:
+            bl = torch.zeros(cl, dtype=torch.float32, device=x.device)
+            bl[:cout] = bias.detach().float()
+        y = torch.empty(B, H, W, cl, dtype=torch.bfloat16, device=x.device)
+        L.call("gdmae_conv3x3_dense", L.ptr(xr), B, H, W, cin, cl, dil, L.ptr(packed), None if bl is None else L.ptr(bl), L.ptr(y), L.stream())
+        ctx.save_for_backward(xr, w)
+        ctx.meta = (dil, cout, cl, bias is not None, direct, x.dtype)
+        return (y if cl == cout else y[..., :cout]).permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xr, w = ctx.saved_tensors
+        dil, cout, cl, has_bias, direct, x_dtype = ctx.meta
+        B, H, W, cin = xr.shape
+        dev = xr.device
+        g = dy.permute(0, 2, 3, 1)
+        if cl == cout:
+            g = (g if g.dtype == torch.bfloat16 else g.to(torch.bfloat16)).contiguous()
+        else:                                                                  # pad the gradient's channels to the launch's width
+            gp = torch.zeros(B, H, W, cl, dtype=torch.bfloat16, device=dev)
+            gp[..., :cout] = g
+            g = gp
+        dx = None
+        if ctx.needs_input_grad[0]:
+            packed = torch.empty(L.load().gdmae_conv3x3_dense_packed_bytes(cin, cout), dtype=torch.uint8, device=dev)
+            L.call("gdmae_conv3x3_dense_pack", L.ptr(w), cin, cout, dil, 1, L.ptr(packed), L.stream())
+            dxr = torch.empty(B, H, W, cin, dtype=torch.bfloat16, device=dev)
+            L.call("gdmae_conv3x3_dense", L.ptr(g), B, H, W, cl, cin, dil, L.ptr(packed), None, L.ptr(dxr), L.stream())
+            dx = dxr.permute(0, 3, 1, 2)
+            if x_dtype != torch.bfloat16:
+                dx = dx.to(x_dtype)
+        dwd, dbd = direct if direct is not None else (None, None)
+        dW = dwd if dwd is not None else torch.zeros(w.shape, dtype=torch.float32, device=dev)
+        ws = torch.empty(L.load().gdmae_conv3x3_dense_dw_workspace_bytes(B, H, W, cin, cl), dtype=torch.uint8, device=dev)
+        L.call("gdmae_conv3x3_dense_bwd_weight", L.ptr(xr), L.ptr(g), B, H, W, cin, cl, cin, cout, dil, L.ptr(dW), L.ptr(ws), L.stream())
+        db = None
+        if has_bias:
+            db = ops.colsum_f32(g.view(B * H * W, cl))[:cout]
+            if dbd is not None:
+                dbd.add_(db)
+                db = None
+        return dx, (None if dwd is not None else dW), db, None, None
+
+
+def conv3x3(conv: nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
+    """``conv(x)`` through the library's dense convolution when it qualifies (conv3x3_supported), the framework's otherwise."""
+    if not conv3x3_supported(conv, x):
+        return conv(x)
+    dw = ops.direct_grad(conv.weight)
+    db = ops.direct_grad(conv.bias) if conv.bias is not None else None
+    direct = (dw, db) if (dw is not None and (conv.bias is None or db is not None)) else None
+    return Conv3x3Dense.apply(x, conv.weight, conv.bias, int(conv.dilation[0]), direct)
 
 
 def rows_supported(y: torch.Tensor, bn: nn.BatchNorm2d) -> bool:
@@ -38,7 +129,7 @@ def conv_bn_relu(block: nn.Sequential, x: torch.Tensor, shortcut: torch.Tensor |
     (evaluation mode uses the running statistics: a per-channel affine the framework fuses itself).  ``shortcut``: a map of the output's
     shape added after the ReLU (in the same pass on the row path)."""
     if len(block) == 3 and isinstance(block[1], nn.BatchNorm2d) and isinstance(block[2], nn.ReLU):
-        y = block[0](x)
+        y = conv3x3(block[0], x) if isinstance(block[0], nn.Conv2d) else block[0](x)
         if rows_supported(y, block[1]) and (shortcut is None or shortcut.is_contiguous(memory_format=torch.channels_last)):
             return bn_relu_2d(y, block[1], shortcut)
         y = block[2](block[1](y))

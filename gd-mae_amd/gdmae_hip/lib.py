@@ -85,6 +85,11 @@ SIGNATURES = {
     "gdmae_window_attention_bwd": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P, _F, _P]),
     "gdmae_window_attention_levels_fwd": (_I, [_P, _P, _P, _I, _P, _P, _P, _I, _P, _P, _I, _I, _P, _F, _P, _P]),
     "gdmae_window_attention_levels_bwd": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P, _P, _I, _I, _P, _F, _P, _P, _P]),
+    "gdmae_conv3x3_dense_packed_bytes": (_Z, [_I, _I]),
+    "gdmae_conv3x3_dense_pack": (_I, [_P, _I, _I, _I, _I, _P, _P]),
+    "gdmae_conv3x3_dense": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "gdmae_conv3x3_dense_dw_workspace_bytes": (_Z, [_I, _I, _I, _I, _I]),
+    "gdmae_conv3x3_dense_bwd_weight": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     "gdmae_attention_timing": (_I, [_I]),
     "gdmae_attention_timing_read": (_I, [_I, _P, _P]),
     "gdmae_kernel_timing": (_I, [_I]),

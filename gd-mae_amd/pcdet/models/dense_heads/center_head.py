@@ -53,7 +53,7 @@ class SeparateHead(nn.Module):
         for name in self.sep_head_dict:
             y = x
             for layer in getattr(self, name):
-                y = gdense.conv_bn_relu(layer, y) if isinstance(layer, nn.Sequential) else layer(y)
+                y = gdense.conv_bn_relu(layer, y) if isinstance(layer, nn.Sequential) else gdense.conv3x3(layer, y)
             out[name] = y
         return out
 

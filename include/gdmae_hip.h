@@ -624,6 +624,26 @@ int gdmae_pred_head_bwd(const void* dY, int dy_f32 /* dY holds fp32 rows: rounde
                         const void* X_bf16, long long n, int n_out,
                         const void* packed, float* dX, float* dW, float* db, void* workspace, void* stream);
 
+/* ---- f1: dense 3x3 convolution of channels-last bf16 maps (fine-tune detector) ----------------- *
+ * Conv2d(cin, cout, 3, stride 1, padding = dilation in {1, 2}) on (B, H, W, C) bf16 maps on the bf16 matrix cores: forward, input
+ * gradient (the same launch on the transposed, tap-flipped image) and weight gradient.  Replaces F.conv2d -> MIOpen at
+ * pcdet/models/backbones_2d/sst_bev_backbone.py:14-19,34-40 (SSTBEVBackbone), pcdet/models/dense_heads/center_head.py:20-35,96-104
+ * (SeparateHead, shared_conv) and pcdet/models/backbones_3d/spt_backbone.py:282-303 (conv_out of the dense decoder).
+ * Channel counts of a LAUNCH (cin_l, cout_l) are multiples of 32: a layer's cin / cout padded with zero weights (pack) and zero
+ * channels (maps); dilation 2 needs cin_l % 64 == 0 and cout_l % 64 == 0.  csrc/conv_dense.hip. */
+size_t gdmae_conv3x3_dense_packed_bytes(int cin, int cout);
+/* weight (cout, cin, 3, 3) fp32 -> fragment-ordered bf16 image; transposed = 1: the image of the input-gradient launch
+ * (cout_pad -> cin_pad channels).  Refresh whenever the weight changes. */
+int gdmae_conv3x3_dense_pack(const float* weight, int cin, int cout, int dil, int transposed, void* packed, void* stream);
+/* Y (B, H, W, cout_l) bf16 = conv(X (B, H, W, cin_l) bf16) + bias (cout_l fp32, optional) */
+int gdmae_conv3x3_dense(const void* X, int B, int H, int W, int cin_l, int cout_l, int dil, const void* packed, const float* bias,
+                        void* Y, void* stream);
+size_t gdmae_conv3x3_dense_dw_workspace_bytes(int B, int H, int W, int cin_l, int cout_l);
+/* dW (cout, cin, 3, 3) fp32 ACCUMULATED (fixed summation order) from X (B, H, W, cin_l) and dY (B, H, W, cout_l), cin_l % 64 == 0,
+ * cout_l % 32 == 0 */
+int gdmae_conv3x3_dense_bwd_weight(const void* X, const void* dY, int B, int H, int W, int cin_l, int cout_l, int cin, int cout, int dil,
+                                   float* dW, void* workspace, void* stream);
+
 /* ---- a17-a19: reconstruction targets and Chamfer loss ----------------------------------------- *
  * gdmae_group_gt_points replaces sst_ops_cuda.group_inner_inds_wrapper (sst_ops_api.cpp:8;
  * sst_ops_gpu.cu:22-39) + points[group_inds] + get_voxel_centers (common_utils.py:130-145):

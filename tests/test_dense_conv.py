@@ -1,0 +1,78 @@
+"""GPU parity of the dense 3x3 convolution (csrc/conv_dense.hip, row f1: SSTBEVBackbone / CenterHead / dense conv_out - reference
+sst_bev_backbone.py:14-40, center_head.py:20-35, spt_backbone.py:289-291) against torch's CPU convolution in fp64 on the same
+bf16-rounded operands: forward, input gradient and weight / bias gradients, through the C ABI and through the autograd wrapper."""
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def _ref(x, w, b, dil, gy):
+    """fp64 CPU reference on the bf16-rounded x / w / gy: y, dx, dw, db."""
+    xd = x.to(torch.bfloat16).double().cpu().requires_grad_(True)
+    wd = w.to(torch.bfloat16).double().cpu().requires_grad_(True)
+    bd = None if b is None else b.double().cpu().requires_grad_(True)
+    y = F.conv2d(xd, wd, bd, padding=dil, dilation=dil)
+    y.backward(gy.to(torch.bfloat16).double().cpu())
+    return y.detach(), xd.grad, wd.grad, None if bd is None else bd.grad
+
+
+CASES = [(2, 20, 27, 128, 128, 1, False), (1, 17, 16, 128, 128, 2, False), (2, 9, 30, 384, 128, 1, False), (2, 16, 24, 128, 64, 1, True),
+         (1, 24, 17, 64, 64, 1, True), (2, 12, 21, 64, 3, 1, True), (1, 8, 8, 64, 2, 1, True), (1, 30, 9, 64, 1, 1, True)]
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout,dil,bias", CASES)
+def test_dense_conv3x3_matches_cpu_fp64(B, H, W, cin, cout, dil, bias):
+    from gdmae_hip import dense as gdense
+    g = torch.Generator().manual_seed(cin * 7 + cout + dil)
+    x = torch.randn(B, cin, H, W, generator=g).to(dev())
+    conv = nn.Conv2d(cin, cout, 3, padding=dil, dilation=dil, bias=bias).to(dev())
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) * (2.0 / (9 * cin)) ** 0.5)
+        if bias:
+            conv.bias.copy_(torch.randn(cout, generator=g))
+    gy = torch.randn(B, cout, H, W, generator=g).to(dev())
+    xg = x.clone().requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        assert gdense.conv3x3_supported(conv, xg)
+        y = gdense.conv3x3(conv, xg)
+    assert y.shape == (B, cout, H, W) and y.dtype == torch.bfloat16
+    y.backward(gy)
+    ry, rdx, rdw, rdb = _ref(x, conv.weight.detach(), conv.bias.detach() if bias else None, dil, gy)
+    sc = float(ry.abs().max())
+    assert float((y.detach().double().cpu() - ry).abs().max()) <= 6e-3 * sc                 # bf16 output rounding: 2^-8 of the largest value
+    assert float((xg.grad.double().cpu() - rdx).abs().max()) <= 6e-3 * float(rdx.abs().max())
+    # weight gradient: fp32 accumulation of exact bf16 products in a fixed order
+    assert float((conv.weight.grad.double().cpu() - rdw).abs().max()) <= 2e-5 * float(rdw.abs().max()) + 1e-6
+    if bias:
+        assert float((conv.bias.grad.double().cpu() - rdb).abs().max()) <= 2e-5 * float(rdb.abs().max()) + 1e-6
+    # repeatable bit for bit
+    conv.weight.grad = None
+    xg2 = x.clone().requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y2 = gdense.conv3x3(conv, xg2)
+    y2.backward(gy)
+    assert torch.equal(y2, y) and torch.equal(xg2.grad, xg.grad)
+
+
+def test_dense_conv3x3_accumulates_into_given_gradient():
+    """gdmae_conv3x3_dense_bwd_weight ADDS to dW (the flat optimizer hands its gradient buffer over)."""
+    from gdmae_hip import lib as L
+    B, H, W, cin, cout = 1, 16, 16, 64, 64
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(B, H, W, cin, generator=g).to(dev()).to(torch.bfloat16)
+    dy = torch.randn(B, H, W, cout, generator=g).to(dev()).to(torch.bfloat16)
+    lib = L.load()
+    ws = torch.empty(lib.gdmae_conv3x3_dense_dw_workspace_bytes(B, H, W, cin, cout), dtype=torch.uint8, device=dev())
+    d0 = torch.zeros(cout, cin, 3, 3, device=dev())
+    L.call("gdmae_conv3x3_dense_bwd_weight", L.ptr(x), L.ptr(dy), B, H, W, cin, cout, cin, cout, 1, L.ptr(d0), L.ptr(ws), L.stream())
+    d1 = torch.full((cout, cin, 3, 3), 0.5, device=dev())
+    L.call("gdmae_conv3x3_dense_bwd_weight", L.ptr(x), L.ptr(dy), B, H, W, cin, cout, cin, cout, 1, L.ptr(d1), L.ptr(ws), L.stream())
+    assert torch.allclose(d1 - 0.5, d0, rtol=0, atol=1e-4 * float(d0.abs().max()))
+    assert float(d0.abs().max()) > 0

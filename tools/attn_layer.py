@@ -14,6 +14,9 @@ frames = int(os.environ.get("FRAMES", "8"))
 pts = torch.from_numpy(synth.synth_batch(5, frames, ds.point_cloud_range, **skw)).to(dev)
 vox, plan = net.backbone_3d.prefetch_plan(pts, frames).finish()
 tot = {0: [0.0, 0.0], 3: [0.0, 0.0]}
+IDENT = bool(os.environ.get("IDENT"))       # experiment: tokens already in window-major order (csr_tok = identity)
+COLD = bool(os.environ.get("COLD"))         # every timed call behind a 1 GB fill (L2 / MALL hold none of its operands)
+flush = torch.empty(1 << 30, dtype=torch.uint8, device=dev) if COLD else None
 for si, st in enumerate(plan.stages):
     d = cfg.BACKBONE_3D.SST_BLOCK_LIST[si].ENCODER.D_MODEL
     H = cfg.BACKBONE_3D.SST_BLOCK_LIST[si].ENCODER.NHEAD
@@ -27,11 +30,12 @@ for si, st in enumerate(plan.stages):
         nl = len(w.n_win)
         lse = torch.empty(st.n_tok, H, device=dev)
         nw_h, T_h = L.host_i32(w.n_win), L.host_i32(w.max_tokens)
+        csr = torch.arange(st.n_tok, dtype=torch.int32, device=dev) if IDENT else w.csr_tok
         def fwd():
-            L.call("gdmae_window_attention_levels_fwd", L.ptr(qk), L.ptr(v), L.ptr(out), 1, L.ptr(w.csr_tok), L.ptr(w.win_start), L.ptr(w.win_len), nl,
+            L.call("gdmae_window_attention_levels_fwd", L.ptr(qk), L.ptr(v), L.ptr(out), 1, L.ptr(csr), L.ptr(w.win_start), L.ptr(w.win_len), nl,
                    nw_h, T_h, d, H, L.ptr(tau), 0.01, L.ptr(lse), L.stream())
         def bwd():
-            L.call("gdmae_window_attention_levels_bwd", L.ptr(qk), L.ptr(v), L.ptr(g), L.ptr(dqk), L.ptr(dv), 1, L.ptr(part), L.ptr(w.csr_tok),
+            L.call("gdmae_window_attention_levels_bwd", L.ptr(qk), L.ptr(v), L.ptr(g), L.ptr(dqk), L.ptr(dv), 1, L.ptr(part), L.ptr(csr),
                    L.ptr(w.win_start), L.ptr(w.win_len), nl, nw_h, T_h, d, H, L.ptr(tau), 0.01, L.ptr(out), L.ptr(lse), L.stream())
         line = f"stage {si} shift {shift} windows {w.n_win} tokens {w.n_tok}:"
         for impl in (3, 0):
@@ -40,6 +44,13 @@ for si, st in enumerate(plan.stages):
             for f in (fwd, bwd):
                 for _ in range(3): f()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                if COLD:
+                    t = 0.0
+                    for _ in range(8):
+                        flush.fill_(1); e0.record(); f(); e1.record(); torch.cuda.synchronize()
+                        t += e0.elapsed_time(e1)
+                    res.append(t / 8 * 1e3)
+                    continue
                 torch.cuda.synchronize(); e0.record()
                 for _ in range(20): f()
                 e1.record(); torch.cuda.synchronize()
