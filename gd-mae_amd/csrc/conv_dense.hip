@@ -433,7 +433,7 @@ __global__ __launch_bounds__(256) void k_cd_dw_reduce(const float* __restrict__ 
 }
 
 static int cd_dw_slices(int n_tiles, int NY, int* tiles_per_wg) {
-  int S = gd_div_up(1024, NY);                     // ~ 4 workgroups per CU over all (co, ci) blocks
+  int S = gd_div_up(512, NY);                      // two workgroups per CU (what the registers allow) over all (co, ci) blocks
   if (S > n_tiles) S = n_tiles;
   if (S < 1) S = 1;
   const int tpw = gd_div_up(n_tiles, S);

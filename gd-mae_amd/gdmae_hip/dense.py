@@ -138,11 +138,12 @@ def conv_bn_relu(block: nn.Sequential, x: torch.Tensor, shortcut: torch.Tensor |
     return y if shortcut is None else y + shortcut
 
 
-def conv_bn_relu_cat(blocks, xs) -> torch.Tensor:
+def conv_bn_relu_cat(blocks, xs, ys=None) -> torch.Tensor:
     """cat([block_i(x_i)], dim=1) for Sequential(conv | deconv, BatchNorm2d, ReLU) blocks on maps of one spatial size (the decoder's
     three deblocks, spt_backbone.py:296-303 / spt_backbone_mae.py:125-132): BatchNorm + ReLU of every branch write their column
     slice of the channels-last result directly - no cat pass, and the backward reads its slice of the gradient in place."""
-    ys = [b[0](x) for b, x in zip(blocks, xs)]
+    if ys is None:                                    # ys: the blocks' convolution outputs, computed by the caller
+        ys = [b[0](x) for b, x in zip(blocks, xs)]
     ok = all(len(b) == 3 and isinstance(b[1], nn.BatchNorm2d) and isinstance(b[2], nn.ReLU) and rows_supported(y, b[1])
              for b, y in zip(blocks, ys))
     ok = ok and len({(y.shape[0],) + tuple(y.shape[2:]) + (y.dtype,) for y in ys}) == 1 and len({float(b[1].eps) for b in blocks}) == 1

@@ -108,10 +108,35 @@ def build_decoder(model_cfg):
     return deblocks, conv_out, out_c
 
 
+def deconv_map(h, deconv, Y: int, X: int):
+    """ConvTranspose2d(k = s, stride s, no bias) of the DENSE map of a sparse stage output, without the dense product: a zero site
+    maps to an s x s block of zeros, so the result is the token rows' product P (n s^2, cout) (gdmae_hip.decoder.deconv_rows: the
+    library's row GEMM) scattered to the (token, dy, dx) sites of a zero map - what F.conv_transpose2d (MIOpen) computed on
+    B Y X sites, 97 % of them empty (reference spt_backbone.py:296-299).  -> (B, cout, Y, X) view of a channels-last map."""
+    from gdmae_hip import decoder as gdec
+    sp = h.stage_plan
+    s = int(deconv.stride[0])
+    P = gdec.deconv_rows(h.features, deconv)
+    sites = gdec.upsampled_sites(sp, s, Y, X)
+    flat = ops.ScatterToDense.apply(P, sites, sp.B * Y * X)
+    return flat.view(sp.B, Y, X, -1).permute(0, 3, 1, 2)
+
+
 def run_decoder(model_cfg, deblocks, conv_out, hidden):
     """Densify each source stage -> ConvTranspose2d(k=s)+BN+ReLU -> cat -> Conv2d 3x3+BN+ReLU
-    (spt_backbone_mae.py:125-133).  Dense maps are channels-last in memory."""
-    xs = [hidden[int(src[-1]) - 1].dense() for src in model_cfg.FEATURES_SOURCE]
+    (spt_backbone_mae.py:125-133).  Dense maps are channels-last in memory.  Under autocast no library convolution runs: the
+    deconvolutions are row products on the active tokens (deconv_map), conv_out is csrc/conv_dense.hip."""
+    srcs = [hidden[int(src[-1]) - 1] for src in model_cfg.FEATURES_SOURCE]
+    strides = [int(b[0].stride[0]) for b in deblocks]
+    Y, X = srcs[0].stage_plan.Y * strides[0], srcs[0].stage_plan.X * strides[0]
+    rows_ok = (torch.is_autocast_enabled() and all(
+        isinstance(b[0], nn.ConvTranspose2d) and b[0].kernel_size == (s, s) and b[0].stride == (s, s) and b[0].bias is None and
+        b[0].padding == (0, 0) and b[0].output_padding == (0, 0) and h.features.is_cuda and h.stage_plan.Y * s == Y and h.stage_plan.X * s == X
+        for b, s, h in zip(deblocks, strides, srcs)))
+    if rows_ok:
+        ys = [deconv_map(h, b[0], Y, X) for b, h in zip(deblocks, srcs)]
+        return gdense.conv_bn_relu(conv_out, gdense.conv_bn_relu_cat(list(deblocks), None, ys=ys))
+    xs = [h.dense() for h in srcs]
     y = gdense.conv_bn_relu(conv_out, gdense.conv_bn_relu_cat(list(deblocks), xs))
     return y
 
