@@ -57,8 +57,8 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the extra legs (resident inputs, fp32, mask 0.85, config E, config-C batch)")
     ap.add_argument("--legs", choices=("default", "full"), default="default",
-                    help="full: also the config D (fine-tune) leg - its dense convolutions go through MIOpen, which compiles / searches "
-                         "kernels at first use: 5 - 7 minutes on a fresh box, so it is not part of the default run")
+                    help="kept for command-line compatibility: every leg, config D (fine-tune) included, is part of the default run since its "
+                         "dense convolutions are the library's own (round 5)")
     ap.add_argument("--feed", default="h2d", choices=["h2d", "resident"], help="h2d: every batch copied from pinned host memory inside the timed region")
     ap.add_argument("--prefetch", type=int, default=1, help="1: build the geometry plan of batch t+1 on a side stream")
     ap.add_argument("--miopen-find", type=int, default=1, help="1: torch.backends.cudnn.benchmark (MIOpen find mode)")
@@ -233,6 +233,13 @@ def measure_roofline(step, feed, n_steps=4):
             d["algorithmic_flops_per_launch"] = int(v["flops_per_launch"])
         else:
             d["algorithmic_bytes_per_launch"] = int(v["bytes_per_launch"])
+            if name == "k_dw_grouped":
+                # what the workgroups request from L2: every job's G and X rows (the nine tap jobs of a gathered launch read the same G
+                # nine times) - divided by the HBM peak this is NOT a roofline fraction, it is listed for what it is
+                sb = v.get("side_bytes", 0.0)
+                d["l2_stream_bytes_per_launch"] = int(sb / max(v["launches"], 1))
+                d["l2_stream_GBs"] = round(sb / sec / 1e9, 1)
+                d["algorithmic_bytes_note"] = "every distinct operand matrix of a launch once (G and X of the nine tap jobs counted once) + index columns + fp32 partial tiles"
             if name == "k_tok_gemm":
                 # what the family's launches move BESIDES the bf16 operand / result rows and weight images the fraction is computed
                 # from: fp32 statistics rows, per-workgroup partial rows, fp32 rows at the stage boundary, the y + pos copies
@@ -253,7 +260,8 @@ def measure_roofline(step, feed, n_steps=4):
     out["timed"] = "HIP events on the launch stream, product path (native stage executor), %d steps after the timed region" % n_steps
     out["traffic"], src = _pmc_traffic(devk)
     if src:
-        out["traffic_source"] = src + " (2 x FETCH_SIZE + WRITE_SIZE per launch, committed rocprofv3 --pmc passes of this command)"
+        out["traffic_source"] = ("PROFILING BOX, not this run: " + src + " (2 x FETCH_SIZE + WRITE_SIZE per launch, committed rocprofv3 --pmc "
+                                 "passes of this command - PMC counters cannot be collected inside a timed bench run)")
     out["also"] = {n: describe(n, v)[0] for n, v in summ.items() if n != top}
     return out
 
@@ -600,12 +608,9 @@ def main():
             # ---- config C's per-GPU batch on this one GPU (the N = 1 point of the driver's scaling curve runs 8 frames per GPU;
             #      this is the same step at the 4 frames per GPU that --gpus 2 / 4 / 8 use) and the other single-GPU configs
             extra = [("config_C_batch_4_per_gpu", "B", 4), ("config_E", "E", 8)]
-            if args.legs == "full":
-                extra.append(("config_D_finetune", "D", 8))
-            else:
-                also["config_D_finetune"] = {"skipped": "MIOpen compiles / searches the dense fine-tune convolutions at first use (5 - 7 minutes on a "
-                                                        "fresh box): run `python bench.py --legs full` or `python bench.py --config D`; the last "
-                                                        "full run is committed as profiles/r03_bench_n1.json"}
+            # config D (fine-tune step) is part of the default run since round 5: its dense convolutions are the library's own
+            # (csrc/conv_dense.hip), there is no MIOpen search at first use any more
+            extra.append(("config_D_finetune", "D", 8))
             for key, cfg_name, b in extra:
                 try:
                     t_build = time.perf_counter()
@@ -632,17 +637,22 @@ def main():
             if ep.dec_tiles is not None:
                 nt = B * ((int(ds.grid_size[1]) + 7) // 8) * ((int(ds.grid_size[0]) + 7) // 8)
                 out["config"]["decoder_active_tiles"] = f"{ep.dec_tiles.n_act} of {nt}"
-            out["step_bytes_model"] = {"bytes_train_per_frame": int(bytes_train), "achieved_GBs": round(bytes_train * fps / world / 1e9, 1),
-                                       "frac_of_8TBs": round(bytes_train * fps / world / 1e9 / HBM_PEAK_GBS, 4),
-                                       "note": "SURVEY 8d whole-step algorithmic bytes with the DENSE-decoder term (2208 x all BEV cells x a: bytes "
-                                               "this build does not move - it flatters the step) x frames/s per GPU; the sparse_decoder entry "
-                                               "counts the decoder term over the sites of the active 8 x 8 tiles only, which is what runs"}
+            dense_model = {"bytes_train_per_frame": int(bytes_train), "achieved_GBs": round(bytes_train * fps / world / 1e9, 1),
+                           "frac_of_8TBs": round(bytes_train * fps / world / 1e9 / HBM_PEAK_GBS, 4),
+                           "note": "SURVEY 8d whole-step algorithmic bytes with the DENSE-decoder term (2208 x all BEV cells x a): bytes this "
+                                   "build does not move - it flatters the step; listed for comparison only"}
             if ep.dec_tiles is not None:
+                # first: the byte model of what actually runs (decoder term over the sites of the active 8 x 8 tiles only)
                 g_act = 64.0 * ep.dec_tiles.n_act / B
                 bt_sp = 3 * algorithmic_bytes_per_frame(N, M, Ms, dsz, g_act, a)
-                out["step_bytes_model"]["sparse_decoder"] = {
+                out["step_bytes_model"] = {
                     "bytes_train_per_frame": int(bt_sp), "achieved_GBs": round(bt_sp * fps / world / 1e9, 1),
-                    "frac_of_8TBs": round(bt_sp * fps / world / 1e9 / HBM_PEAK_GBS, 4), "decoder_sites_per_frame": int(g_act)}
+                    "frac_of_8TBs": round(bt_sp * fps / world / 1e9 / HBM_PEAK_GBS, 4), "decoder_sites_per_frame": int(g_act),
+                    "note": "SURVEY 8d whole-step algorithmic bytes x frames/s per GPU, decoder term over the sites of the active tiles (what "
+                            "this build moves)",
+                    "dense_decoder_formula": dense_model}
+            else:
+                out["step_bytes_model"] = dense_model
         if distd:
             opt = wl.opt
             out["grad_sync"] = {"buckets": [[b, hi - lo] for b, lo, hi in opt.buckets], "last_step": opt.sync.log,
@@ -657,9 +667,13 @@ def main():
             out["roofline"] = roofline
         shares = os.path.join(REPO, "profiles", "class_shares.json")
         if os.path.exists(shares):
-            out["kernel_time_shares"] = json.load(open(shares))
+            # NOT measured in this run: the committed one-step rocprofv3 trace of the builder's profiling box
+            out["kernel_time_shares_profiling_box"] = json.load(open(shares))
         if also:
             out["also"] = also
+            if isinstance(also.get("drop_in_default"), dict) and "value" in also["drop_in_default"]:
+                # what a tools/train.py user gets without touching a switch (the reference module's dense spatial_features map written)
+                out["config"]["drop_in_default_frames_per_s"] = also["drop_in_default"]["value"]
         if not args.no_cpu_baseline and world == 1 and pre:      # reported at N = 1 only (rank 0's host cores)
             out["cpu_baseline"] = measure_cpu_baseline(args.config, args.mask_ratio)
         print(json.dumps(out), flush=True)

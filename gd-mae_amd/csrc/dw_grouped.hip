@@ -370,12 +370,24 @@ int gd_dw_grouped_s(hipStream_t st, GdDwGroup& A, long long n_pad, long long n_v
   GD_REQUIRE(A.S % 8 == 0 && n_pad % ((long long)A.S * kChunk) == 0, "dw_grouped: slices must be a multiple of 8 that divides the row chunks");
   A.rows_per_slice = n_pad / A.S;
   A.n_valid = n_valid;
-  double by = 0.0, fl = 0.0;   // operands read once (the re-reads by the tiles of a slice are L2 hits), fp32 partial tiles written
+  // Algorithmic (HBM) bytes: every DISTINCT operand matrix of the launch once - the nine tap jobs of a gathered launch share one G
+  // and one X, the q/k and v gradients of a layer share nothing - + the index columns + the fp32 partial tiles written.  What the
+  // workgroups request from L2 (every job reads its G and X rows: the 9-fold re-read of G by the tap jobs, the 2 - 4-fold re-reads by
+  // the tiles of a slice not even counted) is reported separately as the side figure (bench.py: l2_stream_bytes_per_launch).
+  double by = 0.0, fl = 0.0, l2 = 0.0;
   for (int j = 0; j < A.n_jobs; ++j) {
-    by += 2.0 * n_valid * (A.job[j].M + A.job[j].N) + 4.0 * A.S * (double)A.job[j].M * A.job[j].N;
+    bool g_new = true, x_new = true;
+    for (int i = 0; i < j; ++i) {
+      g_new = g_new && A.job[i].G != A.job[j].G;
+      x_new = x_new && A.job[i].X != A.job[j].X;
+    }
+    const double gcols = A.job[j].g_cols ? A.job[j].g_cols : A.job[j].M, xb = A.job[j].x_f32 ? 4.0 : 2.0;
+    const double part = 4.0 * A.S * (double)A.job[j].M * A.job[j].N;
+    by += (g_new ? 2.0 * n_valid * gcols : 0.0) + (x_new ? xb * n_valid * A.job[j].N : 0.0) + (A.job[j].xidx ? 4.0 * n_valid : 0.0) + part;
+    l2 += 2.0 * n_valid * gcols + xb * n_valid * A.job[j].N + (A.job[j].xidx ? 4.0 * n_valid : 0.0) + part;
     fl += 2.0 * n_valid * (double)A.job[j].M * A.job[j].N;
   }
-  GdTimed timed(GD_T_DW_GROUPED, st, by, fl);
+  GdTimed timed(GD_T_DW_GROUPED, st, by, fl, l2);
   GD_REQUIRE(n_valid >= 0 && n_pad < (1ll << 31), "dw_grouped: row count");
   if (n_valid == 0) {                    // no rows (an empty stage): the partial tiles are zero; the kernel's clamped loads need a row 0
     for (int j = 0; j < A.n_jobs; ++j) {
