@@ -99,14 +99,17 @@ struct CdArgs {
   const unsigned short* X;      // (B, H, W, cin) bf16
   const uint4* Wp;
   const float* bias;            // (cout) fp32 or null
-  unsigned short* Y;            // (B, H, W, cout) bf16
+  unsigned short* Y;            // (B, H, W, cout) bf16 (OF32: fp32)
   int B, H, W, TH, TW, cin, cout, phases, mb_total;
   int n_tiles;
+  int accumulate;               // OF32: the result is added to what Y holds
 };
 
 #define CD_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 
-template <int CIB, int CO, int DIL>
+// OF32: the accumulators (+ bias) leave as fp32 rows, optionally added to the map's previous content - the building block of the
+// fp32-grade convolution of the parity mode (three launches on the bf16 value / remainder splits of both operands, conv3x3_f32)
+template <int CIB, int CO, int DIL, bool OF32>
 __global__ __launch_bounds__(256, 2) void k_conv3x3_dense(CdArgs A) {
   using Gm = CdGeom<CIB, DIL>;
   constexpr int PW = Gm::PW, SITE = Gm::SITE, ROW = Gm::ROW, TILE = Gm::TILE, KS = Gm::KS;
@@ -117,7 +120,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_dense(CdArgs A) {
   constexpr int ENT = 2 * PW * PW;              // patch entries of both tiles
   constexpr int EPP = 256 / CPS;                // entries per pass of the 256 threads
   constexpr int NPASS = (ENT + EPP - 1) / EPP;
-  constexpr int SP = CO * 2 + 16;               // staging pitch of the epilogue
+  constexpr int SP = CO * (OF32 ? 4 : 2) + 16;  // staging pitch of the epilogue
   constexpr int RING = STEPS > 8 ? 8 : STEPS - 1;       // weight prefetch distance in k-steps
   extern __shared__ __align__(16) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -221,38 +224,54 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_dense(CdArgs A) {
       const int site = (sb0 + b) * 32 + n;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        uint2 o;
-        o.x = cd_pack2(acc[b][4 * j] + bv[4 * j], acc[b][4 * j + 1] + bv[4 * j + 1]);
-        o.y = cd_pack2(acc[b][4 * j + 2] + bv[4 * j + 2], acc[b][4 * j + 3] + bv[4 * j + 3]);
-        *reinterpret_cast<uint2*>(lds + site * SP + (c0 + 8 * j) * 2) = o;
+        if constexpr (OF32) {
+          *reinterpret_cast<float4*>(lds + site * SP + (c0 + 8 * j) * 4) =
+              make_float4(acc[b][4 * j] + bv[4 * j], acc[b][4 * j + 1] + bv[4 * j + 1], acc[b][4 * j + 2] + bv[4 * j + 2], acc[b][4 * j + 3] + bv[4 * j + 3]);
+        } else {
+          uint2 o;
+          o.x = cd_pack2(acc[b][4 * j] + bv[4 * j], acc[b][4 * j + 1] + bv[4 * j + 1]);
+          o.y = cd_pack2(acc[b][4 * j + 2] + bv[4 * j + 2], acc[b][4 * j + 3] + bv[4 * j + 3]);
+          *reinterpret_cast<uint2*>(lds + site * SP + (c0 + 8 * j) * 2) = o;
+        }
       }
     }
   }
   __syncthreads();
   {
-    constexpr int OCPS = CO / 8;
+    constexpr int OCPS = CO / (OF32 ? 4 : 8);       // 16-byte chunks per site
     for (int i = tid; i < 128 * OCPS; i += 256) {
       const int site = i / OCPS, c = i - site * OCPS;
       const int t = site >> 6, ss = site & 63;
       const int y = ty0[t] + (ss >> 3), x = tx0[t] + (ss & 7);
-      if (have[t] && y < A.H && x < A.W)
-        *reinterpret_cast<uint4*>(A.Y + (((long long)tb[t] * A.H + y) * A.W + x) * A.cout + cb * CO + c * 8) =
-            *reinterpret_cast<const uint4*>(lds + site * SP + c * 16);
+      if (have[t] && y < A.H && x < A.W) {
+        const long long row = ((long long)tb[t] * A.H + y) * A.W + x;
+        if constexpr (OF32) {
+          float* dst = reinterpret_cast<float*>(A.Y) + row * A.cout + cb * CO + c * 4;
+          float4 v = *reinterpret_cast<const float4*>(lds + site * SP + c * 16);
+          if (A.accumulate) {
+            const float4 o = *reinterpret_cast<const float4*>(dst);
+            v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+          }
+          *reinterpret_cast<float4*>(dst) = v;
+        } else {
+          *reinterpret_cast<uint4*>(A.Y + row * A.cout + cb * CO + c * 8) = *reinterpret_cast<const uint4*>(lds + site * SP + c * 16);
+        }
+      }
     }
   }
 }
 
-template <int CIB, int CO, int DIL>
+template <int CIB, int CO, int DIL, bool OF32>
 int cd_launch(const CdArgs& A, hipStream_t st) {
   using Gm = CdGeom<CIB, DIL>;
-  constexpr int patch = 2 * Gm::TILE, stg = 128 * (CO * 2 + 16);
+  constexpr int patch = 2 * Gm::TILE, stg = 128 * (CO * (OF32 ? 4 : 2) + 16);
   constexpr int lds = patch > stg ? patch : stg;
   static bool once = false;
   if (!once) {
-    GD_CHECK(hipFuncSetAttribute((const void*)k_conv3x3_dense<CIB, CO, DIL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    GD_CHECK(hipFuncSetAttribute((const void*)k_conv3x3_dense<CIB, CO, DIL, OF32>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     once = true;
   }
-  hipLaunchKernelGGL((k_conv3x3_dense<CIB, CO, DIL>), dim3((unsigned)gd_div_up(A.n_tiles, 2), (unsigned)(A.cout / CO)), dim3(256), lds, st, A);
+  hipLaunchKernelGGL((k_conv3x3_dense<CIB, CO, DIL, OF32>), dim3((unsigned)gd_div_up(A.n_tiles, 2), (unsigned)(A.cout / CO)), dim3(256), lds, st, A);
   GD_LAUNCH_CHECK();
   return 0;
 }
@@ -466,19 +485,20 @@ extern "C" int gdmae_conv3x3_dense_pack(const float* weight, int cin, int cout, 
   return 0;
 }
 
-// Y (B, H, W, cout_l) bf16 = conv3x3(X (B, H, W, cin_l) bf16) (+ bias): cin_l / cout_l = the LAUNCH's channel counts, multiples of 32
+// Y (B, H, W, cout_l) = conv3x3(X (B, H, W, cin_l) bf16) (+ bias): cin_l / cout_l = the LAUNCH's channel counts, multiples of 32
 // (the padded counts of gdmae_conv3x3_dense_pack; for the input gradient the roles of the layer's cin / cout are swapped).
-extern "C" int gdmae_conv3x3_dense(const void* X, int B, int H, int W, int cin_l, int cout_l, int dil, const void* packed, const float* bias,
-                                   void* Y, void* stream) {
+// out_f32 = 0: Y bf16; 1: Y fp32, added to its previous content when accumulate != 0.
+static int cd_conv(const void* X, int B, int H, int W, int cin_l, int cout_l, int dil, const void* packed, const float* bias, void* Y, int out_f32,
+                   int accumulate, void* stream) {
   GD_REQUIRE(cin_l % 32 == 0 && cout_l % 32 == 0 && cd_shape_ok(cin_l, cout_l, dil), "conv3x3_dense: channel counts must be multiples of 32");
   if (B <= 0 || H <= 0 || W <= 0) return 0;
   const int cib = cd_cib(cin_l, dil), co = cd_co(cout_l);
   CdArgs A{(const unsigned short*)X, (const uint4*)packed, bias, (unsigned short*)Y, B, H, W, (H + 7) / 8, (W + 7) / 8, cin_l, cout_l,
-           cin_l / cib, cout_l / 32, 0};
+           cin_l / cib, cout_l / 32, 0, accumulate};
   A.n_tiles = B * A.TH * A.TW;
   hipStream_t st = (hipStream_t)stream;
 #define CD_CASE(ci, c, d) \
-  if (cib == ci && co == c && dil == d) return cd_launch<ci, c, d>(A, st);
+  if (cib == ci && co == c && dil == d) return out_f32 ? cd_launch<ci, c, d, true>(A, st) : cd_launch<ci, c, d, false>(A, st);
   CD_CASE(128, 128, 1)
   CD_CASE(128, 64, 1)
   CD_CASE(128, 32, 1)
@@ -492,6 +512,14 @@ extern "C" int gdmae_conv3x3_dense(const void* X, int B, int H, int W, int cin_l
   CD_CASE(64, 64, 2)
 #undef CD_CASE
   GD_REQUIRE(false, "conv3x3_dense: unsupported shape (dilation 2 needs input channels in multiples of 64 and >= 64 output channels)");
+}
+extern "C" int gdmae_conv3x3_dense(const void* X, int B, int H, int W, int cin_l, int cout_l, int dil, const void* packed, const float* bias,
+                                   void* Y, void* stream) {
+  return cd_conv(X, B, H, W, cin_l, cout_l, dil, packed, bias, Y, 0, 0, stream);
+}
+extern "C" int gdmae_conv3x3_dense_f32out(const void* X, int B, int H, int W, int cin_l, int cout_l, int dil, const void* packed, const float* bias,
+                                          float* Y, int accumulate, void* stream) {
+  return cd_conv(X, B, H, W, cin_l, cout_l, dil, packed, bias, Y, 1, accumulate, stream);
 }
 
 static int cd_dw_cob(int cout_l) { return cout_l % 64 == 0 ? 64 : 32; }

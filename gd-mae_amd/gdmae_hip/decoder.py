@@ -189,10 +189,18 @@ class DecoderHead(torch.autograd.Function):
                 L.call("gdmae_rows_affine_relu_scatter", L.ptr(Ps[i]), _bf(Ps[i]), L.ptr(sites[i]), Ps[i].shape[0], w,
                        L.ptr(ab_l[i]), L.ptr(ab_l[i][w:]), L.ptr(Z), _bf(Z), Z.shape[1], col, L.stream())
                 col += w
-            wc = ops.shadow(conv_w, cdt)
-            with torch.autocast("cuda", enabled=False):
-                y2 = F.conv2d(Z.view(B, H, W, -1).permute(0, 3, 1, 2), wc, None, 1, 1)
-            y2 = y2.permute(0, 2, 3, 1)
+            # the dense convolution of the materialised map through csrc/conv_dense.hip: bf16 operands in the throughput mode, the fp32-grade
+            # three-term form in the parity mode (F.conv2d -> MIOpen before round 5)
+            from . import dense as gdense
+            C2o = conv_w.shape[0]
+            if cdt == torch.bfloat16 and Z.shape[1] % 64 == 0 and conv_w.dtype == torch.float32:
+                y2 = gdense.Conv3x3Dense.apply(Z.view(B, H, W, -1).permute(0, 3, 1, 2), conv_w.detach(), None, 1, None).permute(0, 2, 3, 1)
+            elif cdt == torch.float32 and Z.shape[1] % 64 == 0:
+                y2 = gdense.conv3x3_f32_rows(Z.view(B, H, W, -1), conv_w.detach().float().contiguous(), None, 1)[..., :C2o]
+            else:
+                wc = ops.shadow(conv_w, cdt)
+                with torch.autocast("cuda", enabled=False):
+                    y2 = F.conv2d(Z.view(B, H, W, -1).permute(0, 3, 1, 2), wc, None, 1, 1).permute(0, 2, 3, 1)
             if not y2.is_contiguous():
                 y2 = y2.contiguous()
             y2 = y2.view(R, -1)

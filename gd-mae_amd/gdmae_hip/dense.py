@@ -26,8 +26,9 @@ def _pad32(c: int) -> int:
 
 def conv3x3_supported(conv: nn.Module, x: torch.Tensor) -> bool:
     """The library's dense convolution takes this layer on this input: 3 x 3, stride 1, padding = dilation in {1, 2}, one group, zero
-    padding, bf16 compute (autocast), input channels in multiples of 64 (the weight gradient's blocks)."""
-    if not (isinstance(conv, nn.Conv2d) and x.is_cuda and x.dim() == 4 and torch.is_autocast_enabled()):
+    padding, input channels in multiples of 64 (the weight gradient's blocks); bf16 operands under autocast, the fp32-grade three-term
+    form (Conv3x3DenseF32) for fp32 maps otherwise."""
+    if not (isinstance(conv, nn.Conv2d) and x.is_cuda and x.dim() == 4 and (torch.is_autocast_enabled() or x.dtype == torch.float32)):
         return False
     d = conv.dilation[0]
     return (conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.dilation == (d, d) and conv.padding == (d, d) and d in (1, 2)
@@ -96,6 +97,106 @@ class Conv3x3Dense(torch.autograd.Function):
         return dx, (None if dwd is not None else dW), db, None, None
 
 
+def _split_bf16(x32: torch.Tensor):
+    """fp32 -> three bf16 pieces (value, remainder, remainder of the remainder): x = p0 + p1 + p2 exactly up to 2^-25 |x| (3 x 8 mantissa
+    bits), each piece the bf16 rounding of what the pieces before it left."""
+    p0 = x32.to(torch.bfloat16)
+    r = x32 - p0.float()
+    p1 = r.to(torch.bfloat16)
+    p2 = (r - p1.float()).to(torch.bfloat16)
+    return p0, p1, p2
+
+
+# products of pieces (operand piece, weight piece) that matter at fp32 accuracy: |p_i| <= 2^-8i |x|, so the six pairs with i + j <= 2 reach
+# 2^-24 of a product; summed smallest first
+_PAIRS = ((2, 0), (0, 2), (1, 1), (1, 0), (0, 1), (0, 0))
+
+
+def _packed_split(w: torch.Tensor, cin: int, cout: int, dil: int, transposed: int):
+    """fragment-ordered images of the three bf16 pieces of W (the pack kernel rounds what it is given)."""
+    n = L.load().gdmae_conv3x3_dense_packed_bytes(cin, cout)
+    out = []
+    r = w
+    for _ in range(3):
+        img = torch.empty(n, dtype=torch.uint8, device=w.device)
+        L.call("gdmae_conv3x3_dense_pack", L.ptr(r), cin, cout, dil, transposed, L.ptr(img), L.stream())
+        out.append(img)
+        r = (r - r.to(torch.bfloat16).float()).contiguous()
+    return out
+
+
+def conv3x3_f32_rows(xr: torch.Tensor, w: torch.Tensor, bias, dil: int, transposed: int = 0, split=None) -> torch.Tensor:
+    """fp32-accurate 3 x 3 convolution of a channels-last fp32 map xr (B, H, W, C): operands split into three bf16 pieces each, the six
+    piece products that matter accumulated in fp32 across six launches of the bf16 matrix-core kernel (k_conv3x3_dense<.., OF32>);
+    -> (B, H, W, pad32(out channels)) fp32.  transposed = 1: the input gradient (xr = the output gradient, w the layer's (cout, cin, 3,
+    3) weight).  split: the pieces of xr when the caller has them."""
+    B, H, W, C = xr.shape
+    cout, cin = w.shape[0], w.shape[1]
+    o_l = _pad32(cin if transposed else cout)
+    xs = split if split is not None else _split_bf16(xr)
+    wsp = _packed_split(w, cin, cout, dil, transposed)
+    y = torch.empty(B, H, W, o_l, dtype=torch.float32, device=xr.device)
+    bl = None
+    if bias is not None:
+        bl = torch.zeros(o_l, dtype=torch.float32, device=xr.device)
+        bl[:bias.numel()] = bias.detach().float()
+    for n, (i, j) in enumerate(_PAIRS):
+        last = n == len(_PAIRS) - 1
+        L.call("gdmae_conv3x3_dense_f32out", L.ptr(xs[i]), B, H, W, C, o_l, dil, L.ptr(wsp[j]), L.ptr(bl) if (bl is not None and last) else None,
+               L.ptr(y), int(n > 0), L.stream())
+    return y
+
+
+class Conv3x3DenseF32(torch.autograd.Function):
+    """Conv3x3Dense for fp32 maps (no autocast: the parity mode and the fp32 fine-tune chain the goldens pin): every product as six bf16
+    matrix-core launches on three-piece splits of its operands with fp32 accumulation - forward, input gradient and weight gradient -
+    instead of F.conv2d -> MIOpen.  A product is reproduced to 2^-24: fp32 accuracy (a two-piece split, 2^-16, moved the most
+    cancellation-prone gradient of the detector golden - one attention temperature - by 40 %)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, dil, direct):
+        B, cin, H, W = x.shape
+        cout = weight.shape[0]
+        xr = x.permute(0, 2, 3, 1).float().contiguous()
+        xs = _split_bf16(xr)
+        w = weight.detach().float().contiguous()
+        y = conv3x3_f32_rows(xr, w, bias, dil, 0, xs)
+        ctx.save_for_backward(*xs, w)
+        ctx.meta = (dil, cout, y.shape[-1], bias is not None, direct)
+        return (y if y.shape[-1] == cout else y[..., :cout]).permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x0, x1, x2, w = ctx.saved_tensors
+        xs = (x0, x1, x2)
+        dil, cout, cl, has_bias, direct = ctx.meta
+        B, H, W, cin = x0.shape
+        dev = x0.device
+        g = dy.permute(0, 2, 3, 1).float()
+        if cl == cout:
+            g = g.contiguous()
+        else:
+            gp = torch.zeros(B, H, W, cl, dtype=torch.float32, device=dev)
+            gp[..., :cout] = g
+            g = gp
+        gs = _split_bf16(g)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = conv3x3_f32_rows(g, w, None, dil, 1, gs).permute(0, 3, 1, 2)
+        dwd, dbd = direct if direct is not None else (None, None)
+        dW = dwd if dwd is not None else torch.zeros(w.shape, dtype=torch.float32, device=dev)
+        ws = torch.empty(L.load().gdmae_conv3x3_dense_dw_workspace_bytes(B, H, W, cin, cl), dtype=torch.uint8, device=dev)
+        for i, j in _PAIRS:
+            L.call("gdmae_conv3x3_dense_bwd_weight", L.ptr(xs[i]), L.ptr(gs[j]), B, H, W, cin, cl, cin, cout, dil, L.ptr(dW), L.ptr(ws), L.stream())
+        db = None
+        if has_bias:
+            db = ops.colsum_f32(g.view(B * H * W, cl))[:cout]
+            if dbd is not None:
+                dbd.add_(db)
+                db = None
+        return dx, (None if dwd is not None else dW), db, None, None
+
+
 def conv3x3(conv: nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
     """``conv(x)`` through the library's dense convolution when it qualifies (conv3x3_supported), the framework's otherwise."""
     if not conv3x3_supported(conv, x):
@@ -103,7 +204,8 @@ def conv3x3(conv: nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
     dw = ops.direct_grad(conv.weight)
     db = ops.direct_grad(conv.bias) if conv.bias is not None else None
     direct = (dw, db) if (dw is not None and (conv.bias is None or db is not None)) else None
-    return Conv3x3Dense.apply(x, conv.weight, conv.bias, int(conv.dilation[0]), direct)
+    fn = Conv3x3Dense if torch.is_autocast_enabled() else Conv3x3DenseF32
+    return fn.apply(x, conv.weight, conv.bias, int(conv.dilation[0]), direct)
 
 
 def rows_supported(y: torch.Tensor, bn: nn.BatchNorm2d) -> bool:

@@ -638,6 +638,11 @@ int gdmae_conv3x3_dense_pack(const float* weight, int cin, int cout, int dil, in
 /* Y (B, H, W, cout_l) bf16 = conv(X (B, H, W, cin_l) bf16) + bias (cout_l fp32, optional) */
 int gdmae_conv3x3_dense(const void* X, int B, int H, int W, int cin_l, int cout_l, int dil, const void* packed, const float* bias,
                         void* Y, void* stream);
+/* ... with fp32 output rows, optionally ADDED to Y's previous content: six launches on the three-piece bf16 splits of both operands
+ * (x = p0 + p1 + p2 to 2^-25; the pairs with i + j <= 2) give the convolution to fp32 accuracy - the fp32 parity mode's decoder conv_out
+ * (spt_backbone_mae.py:46-50) and the fp32 fine-tune convolutions, gdmae_hip/dense.py Conv3x3DenseF32 */
+int gdmae_conv3x3_dense_f32out(const void* X, int B, int H, int W, int cin_l, int cout_l, int dil, const void* packed, const float* bias,
+                               float* Y, int accumulate, void* stream);
 size_t gdmae_conv3x3_dense_dw_workspace_bytes(int B, int H, int W, int cin_l, int cout_l);
 /* dW (cout, cin, 3, 3) fp32 ACCUMULATED (fixed summation order) from X (B, H, W, cin_l) and dY (B, H, W, cout_l), cin_l % 64 == 0,
  * cout_l % 32 == 0 */

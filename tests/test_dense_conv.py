@@ -76,3 +76,34 @@ def test_dense_conv3x3_accumulates_into_given_gradient():
     L.call("gdmae_conv3x3_dense_bwd_weight", L.ptr(x), L.ptr(dy), B, H, W, cin, cout, cin, cout, 1, L.ptr(d1), L.ptr(ws), L.stream())
     assert torch.allclose(d1 - 0.5, d0, rtol=0, atol=1e-4 * float(d0.abs().max()))
     assert float(d0.abs().max()) > 0
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout,dil,bias", [(2, 20, 27, 128, 128, 1, False), (1, 17, 16, 128, 128, 2, False), (1, 9, 30, 384, 128, 1, False),
+                                                     (1, 24, 17, 64, 64, 1, True), (2, 12, 21, 64, 3, 1, True)])
+def test_dense_conv3x3_fp32_grade_matches_cpu_fp64(B, H, W, cin, cout, dil, bias):
+    """No autocast: the six-term split form (Conv3x3DenseF32: three bf16 pieces per operand) against the fp64 convolution of the
+    UNROUNDED fp32 operands - forward, input gradient, weight / bias gradients to 2e-6 of the largest value, i.e. fp32 round-off (a
+    bf16-operand product sits at 4e-3, a two-piece split at 1e-5)."""
+    from gdmae_hip import dense as gdense
+    g = torch.Generator().manual_seed(cin * 3 + cout + dil)
+    x = torch.randn(B, cin, H, W, generator=g).to(dev())
+    conv = nn.Conv2d(cin, cout, 3, padding=dil, dilation=dil, bias=bias).to(dev())
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) * (2.0 / (9 * cin)) ** 0.5)
+        if bias:
+            conv.bias.copy_(torch.randn(cout, generator=g))
+    gy = torch.randn(B, cout, H, W, generator=g).to(dev())
+    xg = x.clone().requires_grad_(True)
+    assert gdense.conv3x3_supported(conv, xg)
+    y = gdense.conv3x3(conv, xg)
+    assert y.dtype == torch.float32 and y.shape == (B, cout, H, W)
+    y.backward(gy)
+    xd, wd = x.double().cpu().requires_grad_(True), conv.weight.detach().double().cpu().requires_grad_(True)
+    bd = conv.bias.detach().double().cpu().requires_grad_(True) if bias else None
+    ry = F.conv2d(xd, wd, bd, padding=dil, dilation=dil)
+    ry.backward(gy.double().cpu())
+    for got, ref, nm in ((y.detach(), ry.detach(), "y"), (xg.grad, xd.grad, "dx"), (conv.weight.grad, wd.grad, "dw")):
+        err = float((got.double().cpu() - ref).abs().max()) / float(ref.abs().max())
+        assert err <= 2e-6, (nm, err)
+    if bias:
+        assert float((conv.bias.grad.double().cpu() - bd.grad).abs().max()) <= 3e-5 * float(bd.grad.abs().max())
