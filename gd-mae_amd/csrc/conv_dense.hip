@@ -53,7 +53,12 @@ struct CdGeom {
 
 static inline int cd_pad32(int c) { return (c + 31) / 32 * 32; }
 // input channels per phase of a convolution with cin_pad input channels
-static inline int cd_cib(int cin_pad, int dil) { return (cin_pad % 128 == 0 && dil == 1) ? 128 : (cin_pad % 64 == 0 ? 64 : 32); }
+// 64 even where 128 divides: the patches of a 128-channel phase take 58.9 KB of LDS and 182 registers (two workgroups per CU), those
+// of a 64-channel phase 33 KB / 156 (three): 128 -> 128 at config D's map size 633 -> 527 us, 128 -> 64 340 -> 264 us
+static inline int cd_cib(int cin_pad, int dil) {
+  (void)dil;
+  return cin_pad % 64 == 0 ? 64 : 32;
+}
 static inline int cd_co(int cout_pad) { return cout_pad % 128 == 0 ? 128 : (cout_pad % 64 == 0 ? 64 : 32); }
 
 // ------------------------------------------------------------------------------------------------
@@ -103,7 +108,14 @@ struct CdArgs {
   int B, H, W, TH, TW, cin, cout, phases, mb_total;
   int n_tiles;
   int accumulate;               // OF32: the result is added to what Y holds
+  int ncb;                      // CO blocks of the output (cout / CO)
+  float* stat_part;             // optional (tile pairs, 2, cout) fp32: per-channel sum / sum of squares of the ROUNDED outputs of the
+                                // workgroup's in-map sites (BatchNorm statistics of the layer that follows), bf16 output only
 };
+
+#ifndef CD_MPW128
+#define CD_MPW128 1             // channel blocks per wavefront at CO = 128 (experiment switch; 2 = a 2 x 2 blocking: measured slower)
+#endif
 
 #define CD_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 
@@ -114,7 +126,13 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_dense(CdArgs A) {
   using Gm = CdGeom<CIB, DIL>;
   constexpr int PW = Gm::PW, SITE = Gm::SITE, ROW = Gm::ROW, TILE = Gm::TILE, KS = Gm::KS;
   constexpr int MBLK = CO / 32;                 // 32-channel blocks of the workgroup's output
-  constexpr int NPW = MBLK;                     // 32-site blocks per wavefront (4 wavefronts x NPW x 32 sites x 32 channels = 128 x CO)
+  // a wavefront owns MPW channel blocks x NPW site blocks (4 wavefronts x MPW x NPW x 32 x 32 = CO x 128).  CO = 128: 2 x 2 - every
+  // site fragment read from LDS feeds two products and every weight fragment two: with 1 x 4 (k_conv3x3_tiles' blocking) the four
+  // ds_read_b128 per k-step of the eight resident wavefronts are exactly the CU's 128 B / clk of LDS bandwidth at the rate the matrix
+  // cores could take them - the kernel ran at the LDS roof, half the MFMA one (796 TFLOP/s at 128 -> 128)
+  constexpr int MPW = CD_MPW128 == 2 && CO == 128 ? 2 : 1;
+  constexpr int MG = MBLK / MPW;                // wavefront groups along the channels
+  constexpr int NPW = MBLK / MPW;               // 32-site blocks per wavefront
   constexpr int STEPS = 9 * KS;
   constexpr int CPS = CIB / 8;                  // 16-byte chunks per site
   constexpr int ENT = 2 * PW * PW;              // patch entries of both tiles
@@ -124,13 +142,17 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_dense(CdArgs A) {
   constexpr int RING = STEPS > 8 ? 8 : STEPS - 1;       // weight prefetch distance in k-steps
   extern __shared__ __align__(16) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int mb = wv % MBLK, sb0 = (wv / MBLK) * NPW;
-  const int cb = blockIdx.y;
+  const int mb = (wv % MG) * MPW, sb0 = (wv / MG) * NPW;
+  // blockIdx -> (tile pair, CO block): the CO blocks of a tile pair read the same patches, so they sit next to each other on ONE XCD
+  // (consecutive workgroup ids go round the eight XCDs, each with its own L2)
+  const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+  const int cb = q % A.ncb, tp = (q / A.ncb) * 8 + xcd;
+  if (2 * tp >= A.n_tiles) return;
   int tb[2], ty0[2], tx0[2];
   bool have[2];
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
-    const int tile = blockIdx.x * 2 + t;
+    const int tile = tp * 2 + t;
     have[t] = tile < A.n_tiles;
     const int tl = have[t] ? tile : 0;
     tx0[t] = (tl % A.TW) * 8;
@@ -139,11 +161,13 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_dense(CdArgs A) {
     tb[t] = r / A.TH;
   }
   const int lc = tid % CPS, le = tid / CPS;
-  f32x16 acc[NPW];
+  f32x16 acc[MPW][NPW];
 #pragma unroll
-  for (int b = 0; b < NPW; ++b)
+  for (int j = 0; j < MPW; ++j)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[b][i] = 0.f;
+    for (int b = 0; b < NPW; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[j][b][i] = 0.f;
   const unsigned char* lb[NPW];
 #pragma unroll
   for (int b = 0; b < NPW; ++b) {
@@ -188,14 +212,19 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_dense(CdArgs A) {
     {
       const uint4* __restrict__ wp = A.Wp + ((size_t)g * STEPS * A.mb_total + cb * MBLK + mb) * 64 + lane;
       const size_t wstep = (size_t)A.mb_total * 64;
-      CdFrag wr[RING + 1], sf[2][NPW];
+      CdFrag wr[RING + 1][MPW], sf[2][NPW];
 #pragma unroll
-      for (int st = 0; st < RING; ++st) wr[st].q = wp[st * wstep];
+      for (int st = 0; st < RING; ++st)
+#pragma unroll
+        for (int j = 0; j < MPW; ++j) wr[st][j].q = wp[st * wstep + j * 64];
 #pragma unroll
       for (int b = 0; b < NPW; ++b) sf[0][b].q = *reinterpret_cast<const uint4*>(lb[b]);
 #pragma unroll
       for (int st = 0; st < STEPS; ++st) {
-        if (st + RING < STEPS) wr[(st + RING) % (RING + 1)].q = wp[(st + RING) * wstep];
+        if (st + RING < STEPS) {
+#pragma unroll
+          for (int j = 0; j < MPW; ++j) wr[(st + RING) % (RING + 1)][j].q = wp[(st + RING) * wstep + j * 64];
+        }
         if (st + 1 < STEPS) {
           const int tap = (st + 1) / KS, ks = (st + 1) - tap * KS;
           const int off = (tap / 3) * DIL * ROW + (tap % 3) * DIL * SITE + ks * 32;
@@ -203,7 +232,9 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_dense(CdArgs A) {
           for (int b = 0; b < NPW; ++b) sf[(st + 1) & 1][b].q = *reinterpret_cast<const uint4*>(lb[b] + off);
         }
 #pragma unroll
-        for (int b = 0; b < NPW; ++b) acc[b] = CD_MFMA(wr[st % (RING + 1)].v, sf[st & 1][b].v, acc[b]);
+        for (int j = 0; j < MPW; ++j)
+#pragma unroll
+          for (int b = 0; b < NPW; ++b) acc[j][b] = CD_MFMA(wr[st % (RING + 1)][j].v, sf[st & 1][b].v, acc[j][b]);
         __builtin_amdgcn_sched_barrier(0);      // nothing moves across a step: the prefetch distances are what is written here
       }
     }
@@ -213,25 +244,29 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_dense(CdArgs A) {
   // ---- epilogue: Y^T accumulators (row = channel by register, column = site by lane) (+ bias) -> bf16 site-major rows in LDS
   {
     const int n = lane & 31;
-    const int c0 = mb * 32 + 4 * (lane >> 5);
-    float bv[16];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int jm = 0; jm < MPW; ++jm) {
+      const int c0 = (mb + jm) * 32 + 4 * (lane >> 5);
+      float bv[16];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) bv[4 * j + e] = A.bias ? A.bias[cb * CO + c0 + 8 * j + e] : 0.f;
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-    for (int b = 0; b < NPW; ++b) {
-      const int site = (sb0 + b) * 32 + n;
+        for (int e = 0; e < 4; ++e) bv[4 * j + e] = A.bias ? A.bias[cb * CO + c0 + 8 * j + e] : 0.f;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if constexpr (OF32) {
-          *reinterpret_cast<float4*>(lds + site * SP + (c0 + 8 * j) * 4) =
-              make_float4(acc[b][4 * j] + bv[4 * j], acc[b][4 * j + 1] + bv[4 * j + 1], acc[b][4 * j + 2] + bv[4 * j + 2], acc[b][4 * j + 3] + bv[4 * j + 3]);
-        } else {
-          uint2 o;
-          o.x = cd_pack2(acc[b][4 * j] + bv[4 * j], acc[b][4 * j + 1] + bv[4 * j + 1]);
-          o.y = cd_pack2(acc[b][4 * j + 2] + bv[4 * j + 2], acc[b][4 * j + 3] + bv[4 * j + 3]);
-          *reinterpret_cast<uint2*>(lds + site * SP + (c0 + 8 * j) * 2) = o;
+      for (int b = 0; b < NPW; ++b) {
+        const int site = (sb0 + b) * 32 + n;
+        const f32x16& a = acc[jm][b];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if constexpr (OF32) {
+            *reinterpret_cast<float4*>(lds + site * SP + (c0 + 8 * j) * 4) =
+                make_float4(a[4 * j] + bv[4 * j], a[4 * j + 1] + bv[4 * j + 1], a[4 * j + 2] + bv[4 * j + 2], a[4 * j + 3] + bv[4 * j + 3]);
+          } else {
+            uint2 o;
+            o.x = cd_pack2(a[4 * j] + bv[4 * j], a[4 * j + 1] + bv[4 * j + 1]);
+            o.y = cd_pack2(a[4 * j + 2] + bv[4 * j + 2], a[4 * j + 3] + bv[4 * j + 3]);
+            *reinterpret_cast<uint2*>(lds + site * SP + (c0 + 8 * j) * 2) = o;
+          }
         }
       }
     }
@@ -259,6 +294,55 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_dense(CdArgs A) {
       }
     }
   }
+  // ---- BatchNorm statistics of the rounded outputs: a thread keeps ONE 8-channel chunk (256 % OCPS == 0) and walks the sites
+  if constexpr (!OF32) {
+    if (A.stat_part != nullptr) {
+      constexpr int OCPS = CO / 8, TPC = 256 / OCPS;        // threads per chunk
+      float sm[8], sq[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sm[j] = sq[j] = 0.f;
+      const int c = tid % OCPS;
+      for (int site = tid / OCPS; site < 128; site += TPC) {
+        const int t = site >> 6, ss = site & 63;
+        const int y = ty0[t] + (ss >> 3), x = tx0[t] + (ss & 7);
+        if (have[t] && y < A.H && x < A.W) {
+          const uint4 v = *reinterpret_cast<const uint4*>(lds + site * SP + c * 16);
+          const unsigned w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float lo = __uint_as_float(w4[k] << 16), hi = __uint_as_float(w4[k] & 0xFFFF0000u);
+            sm[2 * k] += lo; sm[2 * k + 1] += hi;
+            sq[2 * k] = fmaf(lo, lo, sq[2 * k]); sq[2 * k + 1] = fmaf(hi, hi, sq[2 * k + 1]);
+          }
+        }
+      }
+      __syncthreads();                                       // the staging tile has been read
+      float* red = reinterpret_cast<float*>(lds);            // [256 threads][16]
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        red[tid * 16 + j] = sm[j];
+        red[tid * 16 + 8 + j] = sq[j];
+      }
+      __syncthreads();
+      if (tid < 2 * CO) {
+        const int stat = tid / CO, ch = tid - stat * CO;
+        float a = 0.f;
+        for (int r = 0; r < TPC; ++r) a += red[(r * OCPS + (ch >> 3)) * 16 + stat * 8 + (ch & 7)];      // fixed order
+        A.stat_part[((size_t)tp * 2 + stat) * A.cout + cb * CO + ch] = a;
+      }
+    }
+  }
+}
+
+// rows [r * per, (r + 1) * per) of part (n_rows, W) summed in order -> out (n_out, W)
+__global__ __launch_bounds__(256) void k_cd_stats_prereduce(const float* __restrict__ part, int n_rows, int Wd, int per, float* __restrict__ out) {
+  const int r = blockIdx.x;
+  for (int c = threadIdx.x; c < Wd; c += 256) {
+    float a = 0.f;
+    const int lo = r * per, hi = lo + per < n_rows ? lo + per : n_rows;
+    for (int i = lo; i < hi; ++i) a += part[(size_t)i * Wd + c];
+    out[(size_t)r * Wd + c] = a;
+  }
 }
 
 template <int CIB, int CO, int DIL, bool OF32>
@@ -271,7 +355,10 @@ int cd_launch(const CdArgs& A, hipStream_t st) {
     GD_CHECK(hipFuncSetAttribute((const void*)k_conv3x3_dense<CIB, CO, DIL, OF32>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     once = true;
   }
-  hipLaunchKernelGGL((k_conv3x3_dense<CIB, CO, DIL, OF32>), dim3((unsigned)gd_div_up(A.n_tiles, 2), (unsigned)(A.cout / CO)), dim3(256), lds, st, A);
+  CdArgs B_ = A;
+  B_.ncb = A.cout / CO;
+  const unsigned ntp8 = (unsigned)gd_div_up(gd_div_up(A.n_tiles, 2), 8) * 8;           // tile pairs, padded to the XCD count
+  hipLaunchKernelGGL((k_conv3x3_dense<CIB, CO, DIL, OF32>), dim3(ntp8 * (unsigned)B_.ncb), dim3(256), lds, st, B_);
   GD_LAUNCH_CHECK();
   return 0;
 }
@@ -285,6 +372,7 @@ struct CdDwArgs {
   float* part;                  // (S, NY, 9, COB, 64) fp32
   int B, H, W, TH, TW, cin, cout, nci;
   int n_tiles, tiles_per_wg;
+  int ny, n_slices;
 };
 
 // Staged 64-channel tiles ([site row][64 channels], 128-byte rows; rows = the sites of a patch / tile row by row): the two 64-byte
@@ -313,10 +401,15 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_dense_dw(CdDwArgs A) {
   unsigned char* ldx = lds;                                // patch: PS rows x 128 B
   unsigned char* ldg = lds + PS * 128;                     // dY tile: 64 rows x COB * 2 B
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int cob = blockIdx.y / A.nci, cib = blockIdx.y - cob * A.nci;
+  // blockIdx -> (slice of tiles, (co, ci) block): the NY blocks of a slice walk the same tiles - next to each other on ONE XCD, whose L2
+  // then serves the NY-fold re-reads of the slice's X patches and dY tiles
+  const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+  const int by = q % A.ny, sl = (q / A.ny) * 8 + xcd;
+  if (sl >= A.n_slices) return;
+  const int cob = by / A.nci, cib = by - cob * A.nci;
   const int cw = COB == 64 ? (wv >> 1) : 0, iw = wv & 1;
   const int tap0 = COB == 64 ? 0 : (wv >> 1) * 5;          // COB = 32: wavefronts 0 / 1 take taps 0 .. 4, 2 / 3 taps 5 .. 8
-  const int t_begin = blockIdx.x * A.tiles_per_wg;
+  const int t_begin = sl * A.tiles_per_wg;
   const int t_end = t_begin + A.tiles_per_wg < A.n_tiles ? t_begin + A.tiles_per_wg : A.n_tiles;
   f32x16 acc[NT];
 #pragma unroll
@@ -413,7 +506,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_dense_dw(CdDwArgs A) {
     __syncthreads();
   }
   // ---- partial blocks: D[m = co by register][n = ci by lane]
-  float* out = A.part + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 9 * COB * 64;
+  float* out = A.part + ((size_t)sl * A.ny + by) * 9 * COB * 64;
 #pragma unroll
   for (int k = 0; k < NT; ++k) {
     const int tap = tap0 + k;
@@ -489,19 +582,16 @@ extern "C" int gdmae_conv3x3_dense_pack(const float* weight, int cin, int cout, 
 // (the padded counts of gdmae_conv3x3_dense_pack; for the input gradient the roles of the layer's cin / cout are swapped).
 // out_f32 = 0: Y bf16; 1: Y fp32, added to its previous content when accumulate != 0.
 static int cd_conv(const void* X, int B, int H, int W, int cin_l, int cout_l, int dil, const void* packed, const float* bias, void* Y, int out_f32,
-                   int accumulate, void* stream) {
+                   int accumulate, void* stream, float* stat_ws = nullptr) {
   GD_REQUIRE(cin_l % 32 == 0 && cout_l % 32 == 0 && cd_shape_ok(cin_l, cout_l, dil), "conv3x3_dense: channel counts must be multiples of 32");
   if (B <= 0 || H <= 0 || W <= 0) return 0;
   const int cib = cd_cib(cin_l, dil), co = cd_co(cout_l);
   CdArgs A{(const unsigned short*)X, (const uint4*)packed, bias, (unsigned short*)Y, B, H, W, (H + 7) / 8, (W + 7) / 8, cin_l, cout_l,
-           cin_l / cib, cout_l / 32, 0, accumulate};
+           cin_l / cib, cout_l / 32, 0, accumulate, 1, stat_ws};
   A.n_tiles = B * A.TH * A.TW;
   hipStream_t st = (hipStream_t)stream;
 #define CD_CASE(ci, c, d) \
   if (cib == ci && co == c && dil == d) return out_f32 ? cd_launch<ci, c, d, true>(A, st) : cd_launch<ci, c, d, false>(A, st);
-  CD_CASE(128, 128, 1)
-  CD_CASE(128, 64, 1)
-  CD_CASE(128, 32, 1)
   CD_CASE(64, 128, 1)
   CD_CASE(64, 64, 1)
   CD_CASE(64, 32, 1)
@@ -517,6 +607,26 @@ extern "C" int gdmae_conv3x3_dense(const void* X, int B, int H, int W, int cin_l
                                    void* Y, void* stream) {
   return cd_conv(X, B, H, W, cin_l, cout_l, dil, packed, bias, Y, 0, 0, stream);
 }
+// ... + the BatchNorm statistics of the layer that follows: stat_rows (GDMAE_CD_STAT_ROWS = 256, 2, cout_l) fp32 partial rows of the
+// per-channel sum / sum of squares of the rounded outputs over all B H W sites (the format gdmae_bn_fold_partials takes) - the epilogue
+// of the convolution instead of a pass over its output.  workspace: gdmae_conv3x3_dense_stats_workspace_bytes.
+static const int kCdStatRows = 256;
+extern "C" size_t gdmae_conv3x3_dense_stats_workspace_bytes(int B, int H, int W, int cout_l) {
+  const long long ntp = gd_div_up((long long)B * ((H + 7) / 8) * ((W + 7) / 8), 2);
+  return gd_align((size_t)ntp * 2 * cout_l * sizeof(float));
+}
+extern "C" int gdmae_conv3x3_dense_stats(const void* X, int B, int H, int W, int cin_l, int cout_l, int dil, const void* packed, const float* bias,
+                                         void* Y, float* stat_rows, void* workspace, void* stream) {
+  GD_REQUIRE(stat_rows != nullptr && workspace != nullptr, "conv3x3_dense_stats: statistics rows and workspace");
+  if (B <= 0 || H <= 0 || W <= 0) return 0;
+  if (int rc = cd_conv(X, B, H, W, cin_l, cout_l, dil, packed, bias, Y, 0, 0, stream, (float*)workspace)) return rc;
+  const int ntp = gd_div_up((long long)B * ((H + 7) / 8) * ((W + 7) / 8), 2);
+  hipLaunchKernelGGL(k_cd_stats_prereduce, dim3(kCdStatRows), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, ntp, 2 * cout_l,
+                     gd_div_up(ntp, kCdStatRows), stat_rows);
+  GD_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int gdmae_conv3x3_dense_stat_rows(void) { return kCdStatRows; }
 extern "C" int gdmae_conv3x3_dense_f32out(const void* X, int B, int H, int W, int cin_l, int cout_l, int dil, const void* packed, const float* bias,
                                           float* Y, int accumulate, void* stream) {
   return cd_conv(X, B, H, W, cin_l, cout_l, dil, packed, bias, Y, 1, accumulate, stream);
@@ -539,9 +649,10 @@ extern "C" int gdmae_conv3x3_dense_bwd_weight(const void* X, const void* dY, int
   if (B <= 0 || H <= 0 || W <= 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   const int cob = cd_dw_cob(cout_l), nci = cin_l / 64, NY = (cout_l / cob) * nci;
-  CdDwArgs A{(const unsigned short*)X, (const unsigned short*)dY, (float*)workspace, B, H, W, (H + 7) / 8, (W + 7) / 8, cin_l, cout_l, nci, 0, 0};
+  CdDwArgs A{(const unsigned short*)X, (const unsigned short*)dY, (float*)workspace, B, H, W, (H + 7) / 8, (W + 7) / 8, cin_l, cout_l, nci, 0, 0, NY, 0};
   A.n_tiles = B * A.TH * A.TW;
   const int S = cd_dw_slices(A.n_tiles, NY, &A.tiles_per_wg);
+  A.n_slices = S;
   const int PW = 8 + 2 * dil;
   const int lds = PW * PW * 128 + 64 * cob * 2;
 #define CD_DW(c, d)                                                                                                               \
@@ -551,7 +662,7 @@ extern "C" int gdmae_conv3x3_dense_bwd_weight(const void* X, const void* dY, int
       GD_CHECK(hipFuncSetAttribute((const void*)k_conv3x3_dense_dw<c, d>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));    \
       once = true;                                                                                                                \
     }                                                                                                                             \
-    hipLaunchKernelGGL((k_conv3x3_dense_dw<c, d>), dim3((unsigned)S, (unsigned)NY), dim3(256), lds, st, A);                       \
+    hipLaunchKernelGGL((k_conv3x3_dense_dw<c, d>), dim3((unsigned)(gd_div_up(S, 8) * 8 * NY)), dim3(256), lds, st, A);            \
   }
   CD_DW(64, 1)
   CD_DW(64, 2)

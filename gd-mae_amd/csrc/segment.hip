@@ -421,6 +421,15 @@ int gd_bn_fold_from_partials(hipStream_t st, const float* part, int nblk, int C,
   GD_LAUNCH_CHECK();
   return 0;
 }
+// C ABI of the same: BatchNorm fold from partial rows part (nblk, 2, C) fp32 = per-row-block {column sums, column sums of squares} that a
+// producer's epilogue left (csrc/conv_dense.hip gdmae_conv3x3_dense_stats) - gdmae_bn_fold without its pass over x
+extern "C" int gdmae_bn_fold_partials(const float* part, int nblk, int C, double count, const float* gamma, const float* beta, double eps,
+                                      double momentum, float* running_mean, float* running_var, long long* num_batches, double* stats,
+                                      float* ab, float* mv, void* stream) {
+  GD_REQUIRE(part != nullptr && nblk >= 1 && C >= 1, "bn_fold_partials: partial rows");
+  return gd_bn_fold_from_partials((hipStream_t)stream, part, nblk, C, count, gamma, beta, eps, momentum, running_mean, running_var,
+                                  num_batches, stats, ab, mv);
+}
 int gd_partials_to_f64(hipStream_t st, const float* part, int nblk, int C2, double* out) {
   hipLaunchKernelGGL(k_colstats_final, dim3(gd_div_up(C2, 16)), dim3(256), 0, st, part, nblk, C2, out);
   GD_LAUNCH_CHECK();

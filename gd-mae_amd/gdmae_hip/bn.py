@@ -15,10 +15,12 @@ from . import lib as L
 from . import ops
 
 
-def fold(x2d: torch.Tensor, count: int, gamma: torch.Tensor, beta: torch.Tensor, eps: float, bn=None):
+def fold(x2d: torch.Tensor, count: int, gamma: torch.Tensor, beta: torch.Tensor, eps: float, bn=None, partials=None):
     """Column statistics of the contiguous (R, C) fp32/bf16 matrix over ``count`` samples.
     -> (stats f64[2C] = mean|rstd, ab f32[2C] = a|b with y = a*x + b, mv f32[2C] = mean|biased var).
-    ``bn``: the nn.BatchNorm module whose running statistics are updated in the same launch (training mode)."""
+    ``bn``: the nn.BatchNorm module whose running statistics are updated in the same launch (training mode).
+    ``partials``: (nblk, 2, C) fp32 partial {sums, sums of squares} of x2d's columns that its producer left (the dense convolution's
+    epilogue, gdmae_hip.dense): the fold runs from them, without the pass over x2d."""
     if isinstance(bn, torch.nn.SyncBatchNorm):
         # tools/train.py:120-121 (--sync_bn, off by default in every shipped script): statistics over all ranks need two small
         # collectives per BatchNorm and direction; the fused row kernels compute per-GPU statistics (the reference default) and must
@@ -38,6 +40,12 @@ def fold(x2d: torch.Tensor, count: int, gamma: torch.Tensor, beta: torch.Tensor,
     if bn is not None and bn.training and bn.running_mean is not None:
         rm, rv, nb, mom = bn.running_mean, bn.running_var, bn.num_batches_tracked, float(bn.momentum)
         assert rm.dtype == torch.float32 and rv.dtype == torch.float32 and nb.dtype == torch.int64
+    if partials is not None:
+        assert partials.dtype == torch.float32 and partials.is_contiguous() and partials.shape[1:] == (2, C), partials.shape
+        L.call("gdmae_bn_fold_partials", L.ptr(partials), partials.shape[0], C, float(count), L.ptr(gamma), L.ptr(beta), float(eps), mom,
+               L.ptr(rm) if rm is not None else None, L.ptr(rv) if rv is not None else None, L.ptr(nb) if nb is not None else None,
+               L.ptr(stats), L.ptr(ab), L.ptr(mv), L.stream())
+        return stats, ab, mv
     L.call("gdmae_bn_fold", L.ptr(x2d), R, C, int(x2d.dtype == torch.bfloat16), float(count), L.ptr(gamma), L.ptr(beta), float(eps),
            mom, L.ptr(rm) if rm is not None else None, L.ptr(rv) if rv is not None else None,
            L.ptr(nb) if nb is not None else None, L.ptr(stats), L.ptr(ab), L.ptr(mv), L.ptr(ws), L.stream())

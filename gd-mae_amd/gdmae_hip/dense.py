@@ -42,7 +42,7 @@ class Conv3x3Dense(torch.autograd.Function):
     (moved to channels-last bf16 if it is not there already); returns a (B, Cout, H, W) view of a channels-last bf16 map."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, dil, direct):
+    def forward(ctx, x, weight, bias, dil, direct, want_stats=False):
         B, cin, H, W = x.shape
         cout = weight.shape[0]
         cl = _pad32(cout)
@@ -57,13 +57,25 @@ class Conv3x3Dense(torch.autograd.Function):
             bl = torch.zeros(cl, dtype=torch.float32, device=x.device)
             bl[:cout] = bias.detach().float()
         y = torch.empty(B, H, W, cl, dtype=torch.bfloat16, device=x.device)
-        L.call("gdmae_conv3x3_dense", L.ptr(xr), B, H, W, cin, cl, dil, L.ptr(packed), None if bl is None else L.ptr(bl), L.ptr(y), L.stream())
         ctx.save_for_backward(xr, w)
         ctx.meta = (dil, cout, cl, bias is not None, direct, x.dtype)
-        return (y if cl == cout else y[..., :cout]).permute(0, 3, 1, 2)
+        if want_stats and cl == cout:
+            # + the column sums / sums of squares of the rounded output as the convolution's epilogue: the BatchNorm that follows
+            # folds from these rows (bn.fold partials) instead of reading the map again
+            lib = L.load()
+            part = torch.empty(lib.gdmae_conv3x3_dense_stat_rows(), 2, cl, dtype=torch.float32, device=x.device)
+            ws = torch.empty(lib.gdmae_conv3x3_dense_stats_workspace_bytes(B, H, W, cl), dtype=torch.uint8, device=x.device)
+            L.call("gdmae_conv3x3_dense_stats", L.ptr(xr), B, H, W, cin, cl, dil, L.ptr(packed), None if bl is None else L.ptr(bl), L.ptr(y),
+                   L.ptr(part), L.ptr(ws), L.stream())
+            ctx.mark_non_differentiable(part)
+            ctx.set_materialize_grads(False)
+            return y.permute(0, 3, 1, 2), part
+        L.call("gdmae_conv3x3_dense", L.ptr(xr), B, H, W, cin, cl, dil, L.ptr(packed), None if bl is None else L.ptr(bl), L.ptr(y), L.stream())
+        out = (y if cl == cout else y[..., :cout]).permute(0, 3, 1, 2)
+        return (out, None) if want_stats else out
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, *_):
         xr, w = ctx.saved_tensors
         dil, cout, cl, has_bias, direct, x_dtype = ctx.meta
         B, H, W, cin = xr.shape
@@ -94,7 +106,7 @@ class Conv3x3Dense(torch.autograd.Function):
             if dbd is not None:
                 dbd.add_(db)
                 db = None
-        return dx, (None if dwd is not None else dW), db, None, None
+        return dx, (None if dwd is not None else dW), db, None, None, None
 
 
 def _split_bf16(x32: torch.Tensor):
@@ -197,15 +209,19 @@ class Conv3x3DenseF32(torch.autograd.Function):
         return dx, (None if dwd is not None else dW), db, None, None
 
 
-def conv3x3(conv: nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
-    """``conv(x)`` through the library's dense convolution when it qualifies (conv3x3_supported), the framework's otherwise."""
+def conv3x3(conv: nn.Conv2d, x: torch.Tensor, want_stats: bool = False):
+    """``conv(x)`` through the library's dense convolution when it qualifies (conv3x3_supported), the framework's otherwise.
+    want_stats: -> (y, partial column-sum rows of y or None) - the statistics of a BatchNorm that follows, from the epilogue."""
     if not conv3x3_supported(conv, x):
-        return conv(x)
+        y = conv(x)
+        return (y, None) if want_stats else y
     dw = ops.direct_grad(conv.weight)
     db = ops.direct_grad(conv.bias) if conv.bias is not None else None
     direct = (dw, db) if (dw is not None and (conv.bias is None or db is not None)) else None
-    fn = Conv3x3Dense if torch.is_autocast_enabled() else Conv3x3DenseF32
-    return fn.apply(x, conv.weight, conv.bias, int(conv.dilation[0]), direct)
+    if torch.is_autocast_enabled():
+        return Conv3x3Dense.apply(x, conv.weight, conv.bias, int(conv.dilation[0]), direct, want_stats)
+    y = Conv3x3DenseF32.apply(x, conv.weight, conv.bias, int(conv.dilation[0]), direct)
+    return (y, None) if want_stats else y
 
 
 def rows_supported(y: torch.Tensor, bn: nn.BatchNorm2d) -> bool:
@@ -214,14 +230,15 @@ def rows_supported(y: torch.Tensor, bn: nn.BatchNorm2d) -> bool:
             y.dtype in (torch.float32, torch.bfloat16) and y.is_contiguous(memory_format=torch.channels_last))
 
 
-def bn_relu_2d(y: torch.Tensor, bn: nn.BatchNorm2d, shortcut: torch.Tensor | None = None) -> torch.Tensor:
-    """relu(bn(y)) [+ shortcut] for a channels-last (B, C, Y, X) map in training mode; the result is channels-last in y's dtype."""
+def bn_relu_2d(y: torch.Tensor, bn: nn.BatchNorm2d, shortcut: torch.Tensor | None = None, partials=None) -> torch.Tensor:
+    """relu(bn(y)) [+ shortcut] for a channels-last (B, C, Y, X) map in training mode; the result is channels-last in y's dtype.
+    partials: the column-sum rows y's producer left (conv3x3 want_stats) - the statistics pass over y is skipped."""
     B, C, Y, X = y.shape
     rows = y.permute(0, 2, 3, 1).reshape(B * Y * X, C)                 # a view: channels-last storage
     res = None
     if shortcut is not None:
         res = shortcut.to(y.dtype).permute(0, 2, 3, 1).reshape(B * Y * X, C)
-    out, _, _ = BNReLURows.apply(rows, bn.weight, bn.bias, float(bn.eps), bn, res)
+    out, _, _ = BNReLURows.apply(rows, bn.weight, bn.bias, float(bn.eps), bn, res, partials)
     return out.view(B, Y, X, C).permute(0, 3, 1, 2)
 
 
@@ -231,9 +248,9 @@ def conv_bn_relu(block: nn.Sequential, x: torch.Tensor, shortcut: torch.Tensor |
     (evaluation mode uses the running statistics: a per-channel affine the framework fuses itself).  ``shortcut``: a map of the output's
     shape added after the ReLU (in the same pass on the row path)."""
     if len(block) == 3 and isinstance(block[1], nn.BatchNorm2d) and isinstance(block[2], nn.ReLU):
-        y = conv3x3(block[0], x) if isinstance(block[0], nn.Conv2d) else block[0](x)
+        y, part = conv3x3(block[0], x, want_stats=True) if isinstance(block[0], nn.Conv2d) else (block[0](x), None)
         if rows_supported(y, block[1]) and (shortcut is None or shortcut.is_contiguous(memory_format=torch.channels_last)):
-            return bn_relu_2d(y, block[1], shortcut)
+            return bn_relu_2d(y, block[1], shortcut, part)
         y = block[2](block[1](y))
         return y if shortcut is None else y + shortcut
     y = block(x)

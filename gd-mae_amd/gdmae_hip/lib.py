@@ -88,6 +88,10 @@ SIGNATURES = {
     "gdmae_conv3x3_dense_packed_bytes": (_Z, [_I, _I]),
     "gdmae_conv3x3_dense_pack": (_I, [_P, _I, _I, _I, _I, _P, _P]),
     "gdmae_conv3x3_dense": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "gdmae_conv3x3_dense_stats_workspace_bytes": (_Z, [_I, _I, _I, _I]),
+    "gdmae_conv3x3_dense_stat_rows": (_I, []),
+    "gdmae_conv3x3_dense_stats": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "gdmae_bn_fold_partials": (_I, [_P, _I, _I, _D, _P, _P, _D, _D, _P, _P, _P, _P, _P, _P, _P]),
     "gdmae_conv3x3_dense_f32out": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P]),
     "gdmae_conv3x3_dense_dw_workspace_bytes": (_Z, [_I, _I, _I, _I, _I]),
     "gdmae_conv3x3_dense_bwd_weight": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P]),

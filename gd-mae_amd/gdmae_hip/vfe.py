@@ -28,10 +28,10 @@ class BNReLURows(torch.autograd.Function):
     of x's dtype added AFTER the ReLU in the same pass (identity shortcut of a dense block; its gradient is the output gradient)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, bn=None, residual=None):
+    def forward(ctx, x, gamma, beta, eps, bn=None, residual=None, partials=None):
         x = x.contiguous()
         n, C = x.shape
-        stats, ab, mv = gbn.fold(x, n, gamma, beta, eps, bn)
+        stats, ab, mv = gbn.fold(x, n, gamma, beta, eps, bn, partials)       # partials: column-sum rows x's producer left (bn.fold)
         out = torch.empty_like(x)
         if residual is not None:
             assert residual.shape == x.shape and residual.dtype == x.dtype and residual.is_contiguous() and C % 8 == 0
@@ -51,7 +51,7 @@ class BNReLURows(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g, _m, _v):
         if g is None:
-            return None, None, None, None, None, None
+            return None, None, None, None, None, None, None
         x, ab, stats, gamma = ctx.saved_tensors
         n, C = x.shape
         g = g.contiguous()
@@ -63,7 +63,7 @@ class BNReLURows(torch.autograd.Function):
         dx = torch.empty_like(x)
         L.call("gdmae_rows_bwd", L.ptr(x), _bf(x), None, n, C, L.ptr(ab), L.ptr(ab[C:]), L.ptr(c01), L.ptr(c01[C:]), L.ptr(g),
                _bf(g), C, 0, L.ptr(dx), _bf(dx), L.stream())
-        return dx, dgamma, dbeta, None, None, (g if ctx.has_res else None)
+        return dx, dgamma, dbeta, None, None, (g if ctx.has_res else None), None
 
 
 class BNReLURowsCat(torch.autograd.Function):

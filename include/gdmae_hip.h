@@ -223,6 +223,11 @@ int gdmae_rows_bwd(const void* P, int p_bf16, const int* site, long long n, int 
 int gdmae_bn_fold(const void* x, long long R, int C, int is_bf16, double count, const float* gamma, const float* beta,
                   double eps, double momentum, float* running_mean, float* running_var, long long* num_batches,
                   double* stats, float* ab, float* mv, void* workspace, void* stream);
+/* gdmae_bn_fold from partial rows part (nblk, 2, C) fp32 = {column sums, column sums of squares} per row block, left by a producer's
+ * epilogue (gdmae_conv3x3_dense_stats): the same outputs without the pass over x */
+int gdmae_bn_fold_partials(const float* part, int nblk, int C, double count, const float* gamma, const float* beta, double eps,
+                           double momentum, float* running_mean, float* running_var, long long* num_batches, double* stats, float* ab,
+                           float* mv, void* stream);
 int gdmae_bn_bwd_coeffs(const double* st, int n_st, const double* stats, const float* ab, const float* gamma, int C,
                         double count, const double* tot, float* dgamma, float* dbeta, int accumulate, float* c01,
                         void* stream);
@@ -638,6 +643,13 @@ int gdmae_conv3x3_dense_pack(const float* weight, int cin, int cout, int dil, in
 /* Y (B, H, W, cout_l) bf16 = conv(X (B, H, W, cin_l) bf16) + bias (cout_l fp32, optional) */
 int gdmae_conv3x3_dense(const void* X, int B, int H, int W, int cin_l, int cout_l, int dil, const void* packed, const float* bias,
                         void* Y, void* stream);
+/* ... + the statistics of the BatchNorm that follows the convolution as its epilogue: stat_rows (gdmae_conv3x3_dense_stat_rows() = 256,
+ * 2, cout_l) fp32 partial rows {sum, sum of squares} per channel of the ROUNDED outputs over all B H W sites, summed in a fixed order;
+ * gdmae_bn_fold_partials turns them into the folded affine (no pass over Y).  workspace: gdmae_conv3x3_dense_stats_workspace_bytes. */
+size_t gdmae_conv3x3_dense_stats_workspace_bytes(int B, int H, int W, int cout_l);
+int gdmae_conv3x3_dense_stat_rows(void);
+int gdmae_conv3x3_dense_stats(const void* X, int B, int H, int W, int cin_l, int cout_l, int dil, const void* packed, const float* bias,
+                              void* Y, float* stat_rows, void* workspace, void* stream);
 /* ... with fp32 output rows, optionally ADDED to Y's previous content: six launches on the three-piece bf16 splits of both operands
  * (x = p0 + p1 + p2 to 2^-25; the pairs with i + j <= 2) give the convolution to fp32 accuracy - the fp32 parity mode's decoder conv_out
  * (spt_backbone_mae.py:46-50) and the fp32 fine-tune convolutions, gdmae_hip/dense.py Conv3x3DenseF32 */

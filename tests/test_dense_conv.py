@@ -107,3 +107,29 @@ def test_dense_conv3x3_fp32_grade_matches_cpu_fp64(B, H, W, cin, cout, dil, bias
         assert err <= 2e-6, (nm, err)
     if bias:
         assert float((conv.bias.grad.double().cpu() - bd.grad).abs().max()) <= 3e-5 * float(bd.grad.abs().max())
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout,dil", [(2, 20, 27, 128, 128, 1), (1, 17, 16, 128, 128, 2), (2, 16, 24, 128, 64, 1), (1, 33, 9, 64, 64, 1)])
+def test_dense_conv3x3_statistics_epilogue(B, H, W, cin, cout, dil):
+    """gdmae_conv3x3_dense_stats: the (256, 2, C) partial rows the epilogue leaves sum to the column sums / sums of squares of the bf16
+    output map (partial tiles at the map border excluded from nothing, padded sites from everything), the output equals the plain
+    launch's, and BatchNorm + ReLU folded from those rows equals the one folded from a pass over the map."""
+    from gdmae_hip import dense as gdense
+    g = torch.Generator().manual_seed(cin + cout + dil)
+    x = torch.randn(B, cin, H, W, generator=g).to(dev())
+    conv = nn.Conv2d(cin, cout, 3, padding=dil, dilation=dil, bias=True).to(dev())
+    bn = nn.BatchNorm2d(cout, eps=1e-3, momentum=0.01).to(dev()).train()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y0 = gdense.conv3x3(conv, x)
+        y1, part = gdense.conv3x3(conv, x, want_stats=True)
+    assert torch.equal(y0, y1) and part.shape == (256, 2, cout)
+    rows = y1.permute(0, 2, 3, 1).reshape(-1, cout).double()
+    s1, s2 = part[:, 0].double().sum(0), part[:, 1].double().sum(0)
+    assert float((s1 - rows.sum(0)).abs().max()) <= 1e-5 * float(rows.abs().sum(0).max())
+    assert float((s2 - (rows * rows).sum(0)).abs().max()) <= 1e-5 * float((rows * rows).sum(0).max())
+    bn2 = nn.BatchNorm2d(cout, eps=1e-3, momentum=0.01).to(dev()).train()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        a = gdense.bn_relu_2d(y1, bn, None, part)
+        b = gdense.bn_relu_2d(y1, bn2, None, None)
+    assert float((a.float() - b.float()).abs().max()) <= 2e-2 * float(b.float().abs().max())       # one bf16 ulp where the fold differs in the last bit
+    assert torch.allclose(bn.running_mean, bn2.running_mean, rtol=1e-5, atol=1e-7) and torch.allclose(bn.running_var, bn2.running_var, rtol=1e-5, atol=1e-7)
