@@ -24,7 +24,9 @@
 // the tiles: per tile the halo patch of X (64 channels) and the tile of dY are staged ONCE and all nine taps read the patch at
 // shifted rows (nine 32 x 32 accumulators per wavefront); the next tile's rows are in flight in registers behind the products.
 // fp32 partial blocks per slice, summed in a fixed order by k_cd_dw_reduce (deterministic) straight into the (cout, cin, 3, 3)
-// gradient.
+// gradient.  0.6 - 0.84 PFLOP/s at config D's map (tools/bench_conv_dense.py).  Measured and dropped (round 5): eight wavefronts of
+// five accumulators (four per SIMD: 674 -> 712 us at 128 -> 128 - the loop is not latency-bound); both co blocks x five taps per
+// wavefront (every X fragment feeds two products, 0.7 instead of 1.11 LDS fragment reads per product: 2.44 -> 2.63 ms at 384 -> 128).
 #include "../../include/gdmae_hip.h"
 #include "common.h"
 #include <stdlib.h>
@@ -340,7 +342,15 @@ __global__ __launch_bounds__(256) void k_cd_stats_prereduce(const float* __restr
   for (int c = threadIdx.x; c < Wd; c += 256) {
     float a = 0.f;
     const int lo = r * per, hi = lo + per < n_rows ? lo + per : n_rows;
-    for (int i = lo; i < hi; ++i) a += part[(size_t)i * Wd + c];
+    int i = lo;
+    for (; i + 8 <= hi; i += 8) {                  // eight rows in flight, added in row order
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = part[(size_t)(i + j) * Wd + c];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a += v[j];
+    }
+    for (; i < hi; ++i) a += part[(size_t)i * Wd + c];
     out[(size_t)r * Wd + c] = a;
   }
 }
