@@ -30,9 +30,25 @@ union CtFrag {
 };
 
 #define CT_C 128                 // channels per source stage and output channels
-#define CT_SITE_PITCH 272        // 128 bf16 + 16 bytes: consecutive sites advance one 16-byte bank quad
-#define CT_ROW_PITCH 2944        // 10 sites = 2720, padded to 128 (mod 256): patch rows alternate bank halves
-#define CT_TILE_PITCH 29440      // 10 patch rows
+#define CT_SITE_PITCH 272        // staged OUTPUT rows: 128 bf16 + 16 bytes
+// Channels of a source stage per phase (patch gather + 9 taps of products).  128: one phase per stage, 58.9 KB of patches, two
+// workgroups per CU.  64 (experiment switch, round 5 - what paid in conv_dense.hip, 633 -> 527 us at 128 -> 128): two phases per stage
+// on half the channels each - 33 KB of patches, three workgroups per CU, the same weight image (a phase walks the k-steps hf * 4 ...
+// hf * 4 + 3 of every tap).  Measured HERE: 576 vs 565 us per step (the map gather + BatchNorm of the patch entries needs 213
+// registers; at the 168 of three workgroups per CU 30 of them spill) - not the default.
+#ifndef CT_CH
+#define CT_CH 128
+#endif
+#ifndef CT_RING
+#define CT_RING 8                                   // weight prefetch distance in k-steps
+#endif
+#define CT_HALVES (CT_C / CT_CH)
+#define CT_KS (CT_CH / 16)                          // k-steps per tap and phase
+#define CT_NSTEP (9 * CT_KS)
+#define CT_CPS (CT_CH / 8)                          // 16-byte chunks per patch site
+#define CT_PSITE (CT_CH * 2 + 16)                   // patch site pitch: consecutive sites advance one 16-byte bank quad
+#define CT_ROW_PITCH (CT_CH == 128 ? 2944 : 1664)   // 10 sites, padded to 128 (mod 256): patch rows alternate bank halves
+#define CT_TILE_PITCH (10 * CT_ROW_PITCH)           // 10 patch rows
 // CT_TPW tiles per workgroup (experiment switch): 2 = four wavefronts, two workgroups per CU; 4 = eight wavefronts, ONE workgroup per
 // CU whose wavefronts w and w + 4 stream the same weight fragments right after the same barrier (the second request meets the line
 // in the CU's L1: half the L2 -> CU weight stream for the same wavefronts per CU)
@@ -41,10 +57,14 @@ union CtFrag {
 #endif
 #define CT_THREADS (CT_TPW * 128)
 #define CT_NWAVES (CT_TPW * 2)
-#define CT_LDS_BYTES (CT_TPW * CT_TILE_PITCH)       // the patches (58880 for two)
 #define CT_STAGE_PITCH 17408     // 64 sites x 272: epilogue staging of one tile
 #define CT_RED_OFF (CT_TPW * CT_STAGE_PITCH)        // after the staging areas: (tiles, waves, 2 stats, 128) fp32
-#define CT_SPP (CT_THREADS / 16)                    // patch entries per gather pass
+#define CT_EPI_BYTES (CT_RED_OFF + CT_TPW * CT_NWAVES * 2 * CT_C * 4)
+#define CT_PATCH_BYTES (CT_TPW * CT_TILE_PITCH)     // the patches (58880 for two tiles of 128 channels, 33280 of 64)
+#define CT_LDS_BYTES (CT_PATCH_BYTES > CT_EPI_BYTES ? CT_PATCH_BYTES : CT_EPI_BYTES)
+#define CT_SPP (CT_THREADS / CT_CPS)                // patch entries per gather pass
+#define CT_NPASS ((100 * CT_TPW + CT_SPP - 1) / CT_SPP)
+#define CT_ESPP (CT_THREADS / 16)                   // output sites per epilogue pass (16 chunks per 128-channel row)
 #define CT_MAX_SRC 3
 #define CT_NRED 256              // rows the per-tile statistics partials are pre-reduced to
 
@@ -261,10 +281,12 @@ struct CtArgs {
 
 #define CT_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 
-// byte offset of k-step st (tap st >> 3, 16-channel step st & 7) inside the LDS patch
-#define CT_OFF(st) ((((st) >> 3) / 3) * CT_ROW_PITCH + (((st) >> 3) % 3) * CT_SITE_PITCH + ((st) & 7) * 32)
+// byte offset of k-step st of a phase (tap st / CT_KS, 16-channel step st % CT_KS) inside the LDS patch
+#define CT_OFF(st) ((((st) / CT_KS) / 3) * CT_ROW_PITCH + (((st) / CT_KS) % 3) * CT_PSITE + ((st) % CT_KS) * 32)
+// the same k-step in the packed image of a stage (8 k-steps per tap)
+#define CT_WSTEP(st, hf) ((((st) / CT_KS) * 8 + (hf) * CT_KS + ((st) % CT_KS)) * 256)
 
-__global__ __launch_bounds__(CT_THREADS, CT_TPW == 2 ? 2 : 1) void k_conv3x3_tiles(CtArgs A) {
+__global__ __launch_bounds__(CT_THREADS, CT_TPW == 2 ? (CT_CH == 64 ? 3 : 2) : 1) void k_conv3x3_tiles(CtArgs A) {
   extern __shared__ __align__(16) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63, wvg = tid >> 6;
   const int wv = wvg & 3;              // output-channel block of the wavefront
@@ -281,41 +303,26 @@ __global__ __launch_bounds__(CT_THREADS, CT_TPW == 2 ? 2 : 1) void k_conv3x3_til
     ty0[t] = (r % A.TH) * 8;
     tb[t] = r / A.TH;
   }
-  const int lc = tid & 15;     // 16-byte chunk (8 channels) of a 128-channel row
-  const int lsg = tid >> 4;    // patch entry within a pass of 16
+  const int lc = tid % CT_CPS;   // 16-byte chunk (8 channels) of a phase's CT_CH channels of a patch site
+  const int lsg = tid / CT_CPS;  // patch entry within a pass
   // site operand: lane n = lane & 31 -> site (row n >> 3 of a 4-row half tile, column n & 7), k-group lane >> 5
-  const unsigned char* lb = lds + tg * 2 * CT_TILE_PITCH + ((lane & 31) >> 3) * CT_ROW_PITCH + (lane & 7) * CT_SITE_PITCH + (lane >> 5) * 16;
+  const unsigned char* lb = lds + tg * 2 * CT_TILE_PITCH + ((lane & 31) >> 3) * CT_ROW_PITCH + (lane & 7) * CT_PSITE + (lane >> 5) * 16;
   f32x16 acc0, acc1, acc2, acc3;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc0[i] = acc1[i] = acc2[i] = acc3[i] = 0.f;
 
   for (int g = 0; g < A.k; ++g) {
     const CtSrc S = A.src[g];
-    // ---- gather + normalise the two halo patches of this source stage into LDS
+    const int ls = S.ls, sm = (1 << ls) - 1;
+    const int Hs = A.H >> ls, Ws = A.W >> ls;
+    // The cell -> token lookups of a thread are requested together and unconditionally (entries outside the map or past the
+    // patches read cell 0 and ignore it), then the rows (row 0 of a readable stand-in for background / outside / unused entries
+    // and for a stage without rows): behind its own `if` every load was followed by a drain of the load counter at the join.
+    int code[CT_NPASS];   // >= 0: row of P, -1: background, -2: zero (outside the map), -3: nothing to write
     {
-      float av[8], bv[8];
-      {
-        const float4 a0 = *(const float4*)(S.a + lc * 8), a1 = *(const float4*)(S.a + lc * 8 + 4);
-        const float4 b0 = *(const float4*)(S.b + lc * 8), b1 = *(const float4*)(S.b + lc * 8 + 4);
-        av[0] = a0.x; av[1] = a0.y; av[2] = a0.z; av[3] = a0.w; av[4] = a1.x; av[5] = a1.y; av[6] = a1.z; av[7] = a1.w;
-        bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
-      }
-      uint4 bgq;
-      {
-        float r[8];
+      int tokv[CT_NPASS];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) r[j] = bv[j] > 0.f ? bv[j] : 0.f;
-        bgq.x = ct_pack2(r[0], r[1]); bgq.y = ct_pack2(r[2], r[3]); bgq.z = ct_pack2(r[4], r[5]); bgq.w = ct_pack2(r[6], r[7]);
-      }
-      const int ls = S.ls, sm = (1 << ls) - 1;
-      const int Hs = A.H >> ls, Ws = A.W >> ls;
-      // The 13 cell -> token lookups of a thread are requested together and unconditionally (entries outside the map or past the
-      // patches read cell 0 and ignore it), then the 13 rows (row 0 of a readable stand-in for background / outside / unused entries
-      // and for a stage without rows): behind its own `if` every load was followed by a drain of the load counter at the join.
-      int code[13];   // >= 0: row of P, -1: background, -2: zero (outside the map), -3: nothing to write
-      int tokv[13];
-#pragma unroll
-      for (int p = 0; p < 13; ++p) {
+      for (int p = 0; p < CT_NPASS; ++p) {
         const int e = p * CT_SPP + lsg;
         const int t = e / 100 < CT_TPW ? e / 100 : CT_TPW - 1;
         const int r = e - 100 * (e / 100);
@@ -325,7 +332,7 @@ __global__ __launch_bounds__(CT_THREADS, CT_TPW == 2 ? 2 : 1) void k_conv3x3_til
         tokv[p] = S.map[inb ? (tb[t] * Hs + (y >> ls)) * Ws + (x >> ls) : 0];
       }
 #pragma unroll
-      for (int p = 0; p < 13; ++p) {
+      for (int p = 0; p < CT_NPASS; ++p) {
         const int e = p * CT_SPP + lsg;
         int c = -3;
         if (e < 100 * CT_TPW) {
@@ -343,64 +350,85 @@ __global__ __launch_bounds__(CT_THREADS, CT_TPW == 2 ? 2 : 1) void k_conv3x3_til
         }
         code[p] = c;
       }
-      const unsigned short* __restrict__ Prows = S.P ? S.P : (const unsigned short*)S.a;      // a: 128 floats, readable as one row
-      uint4 q[13];
+    }
+    const unsigned short* __restrict__ Prows = S.P ? S.P : (const unsigned short*)S.a;      // a: 128 floats, readable as one row
+#pragma unroll 1
+    for (int hf = 0; hf < CT_HALVES; ++hf) {
+      // ---- gather + normalise this phase's channels of the two halo patches into LDS
+      {
+        const int c0 = hf * CT_CH + lc * 8;
+        float av[8], bv[8];
+        {
+          const float4 a0 = *(const float4*)(S.a + c0), a1 = *(const float4*)(S.a + c0 + 4);
+          const float4 b0 = *(const float4*)(S.b + c0), b1 = *(const float4*)(S.b + c0 + 4);
+          av[0] = a0.x; av[1] = a0.y; av[2] = a0.z; av[3] = a0.w; av[4] = a1.x; av[5] = a1.y; av[6] = a1.z; av[7] = a1.w;
+          bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
+        }
+        uint4 bgq;
+        {
+          float r[8];
 #pragma unroll
-      for (int p = 0; p < 13; ++p) q[p] = *(const uint4*)(Prows + (long long)(code[p] >= 0 ? code[p] : 0) * CT_C + lc * 8);
+          for (int j = 0; j < 8; ++j) r[j] = bv[j] > 0.f ? bv[j] : 0.f;
+          bgq.x = ct_pack2(r[0], r[1]); bgq.y = ct_pack2(r[2], r[3]); bgq.z = ct_pack2(r[4], r[5]); bgq.w = ct_pack2(r[6], r[7]);
+        }
+        uint4 q[CT_NPASS];
 #pragma unroll
-      for (int p = 0; p < 13; ++p) {
-        if (code[p] == -3) continue;
-        const int e = p * CT_SPP + lsg;
-        const int t = e / 100;
-        const int r = e - 100 * t;
-        const int py = r / 10, px = r - py * 10;
-        uint4 o;
-        if (code[p] >= 0) {
-          float f[8];
-          ct_unpack8(q[p], f);
+        for (int p = 0; p < CT_NPASS; ++p) q[p] = *(const uint4*)(Prows + (long long)(code[p] >= 0 ? code[p] : 0) * CT_C + c0);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const float h = fmaf(av[j], f[j], bv[j]);
-            f[j] = h > 0.f ? h : 0.f;
+        for (int p = 0; p < CT_NPASS; ++p) {
+          if (code[p] == -3) continue;
+          const int e = p * CT_SPP + lsg;
+          const int t = e / 100;
+          const int r = e - 100 * t;
+          const int py = r / 10, px = r - py * 10;
+          uint4 o;
+          if (code[p] >= 0) {
+            float f[8];
+            ct_unpack8(q[p], f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const float h = fmaf(av[j], f[j], bv[j]);
+              f[j] = h > 0.f ? h : 0.f;
+            }
+            o.x = ct_pack2(f[0], f[1]); o.y = ct_pack2(f[2], f[3]); o.z = ct_pack2(f[4], f[5]); o.w = ct_pack2(f[6], f[7]);
+          } else if (code[p] == -1) {
+            o = bgq;
+          } else {
+            o = make_uint4(0u, 0u, 0u, 0u);
           }
-          o.x = ct_pack2(f[0], f[1]); o.y = ct_pack2(f[2], f[3]); o.z = ct_pack2(f[4], f[5]); o.w = ct_pack2(f[6], f[7]);
-        } else if (code[p] == -1) {
-          o = bgq;
-        } else {
-          o = make_uint4(0u, 0u, 0u, 0u);
+          *(uint4*)(lds + t * CT_TILE_PITCH + py * CT_ROW_PITCH + px * CT_PSITE + lc * 16) = o;
         }
-        *(uint4*)(lds + t * CT_TILE_PITCH + py * CT_ROW_PITCH + px * CT_SITE_PITCH + lc * 16) = o;
       }
-    }
-    __syncthreads();
-    // ---- 72 k-steps (9 taps x 8): weight fragments stream from L2 eight steps ahead through a 9-slot register ring,
-    //      site fragments come from the LDS patch one step ahead; per step 1 global load, 4 LDS reads, 4 MFMAs
-    {
-      const uint4* __restrict__ wp = A.Wp + ((size_t)g * 72 * 4 + wv) * 64 + lane;
-      CtFrag wr[9], sf[2][4];
+      __syncthreads();
+      // ---- 9 taps x CT_KS k-steps: weight fragments stream from L2 eight steps ahead through a 9-slot register ring,
+      //      site fragments come from the LDS patch one step ahead; per step 1 global load, 4 LDS reads, 4 MFMAs
+      {
+        const uint4* __restrict__ wp = A.Wp + ((size_t)g * 72 * 4 + wv) * 64 + lane + (size_t)hf * CT_KS * 256;
+        CtFrag wr[CT_RING + 1], sf[2][4];
 #pragma unroll
-      for (int st = 0; st < 8; ++st) wr[st].q = wp[st * 256];
-      sf[0][0].q = *(const uint4*)(lb);
-      sf[0][1].q = *(const uint4*)(lb + 4 * CT_ROW_PITCH);
-      sf[0][2].q = *(const uint4*)(lb + CT_TILE_PITCH);
-      sf[0][3].q = *(const uint4*)(lb + CT_TILE_PITCH + 4 * CT_ROW_PITCH);
+        for (int st = 0; st < CT_RING; ++st) wr[st].q = wp[CT_WSTEP(st, 0)];
+        sf[0][0].q = *(const uint4*)(lb);
+        sf[0][1].q = *(const uint4*)(lb + 4 * CT_ROW_PITCH);
+        sf[0][2].q = *(const uint4*)(lb + CT_TILE_PITCH);
+        sf[0][3].q = *(const uint4*)(lb + CT_TILE_PITCH + 4 * CT_ROW_PITCH);
 #pragma unroll
-      for (int st = 0; st < 72; ++st) {
-        if (st + 8 < 72) wr[(st + 8) % 9].q = wp[(st + 8) * 256];
-        if (st + 1 < 72) {
-          sf[(st + 1) & 1][0].q = *(const uint4*)(lb + CT_OFF(st + 1));
-          sf[(st + 1) & 1][1].q = *(const uint4*)(lb + 4 * CT_ROW_PITCH + CT_OFF(st + 1));
-          sf[(st + 1) & 1][2].q = *(const uint4*)(lb + CT_TILE_PITCH + CT_OFF(st + 1));
-          sf[(st + 1) & 1][3].q = *(const uint4*)(lb + CT_TILE_PITCH + 4 * CT_ROW_PITCH + CT_OFF(st + 1));
+        for (int st = 0; st < CT_NSTEP; ++st) {
+          if (st + CT_RING < CT_NSTEP) wr[(st + CT_RING) % (CT_RING + 1)].q = wp[CT_WSTEP(st + CT_RING, 0)];
+          if (st + 1 < CT_NSTEP) {
+            sf[(st + 1) & 1][0].q = *(const uint4*)(lb + CT_OFF(st + 1));
+            sf[(st + 1) & 1][1].q = *(const uint4*)(lb + 4 * CT_ROW_PITCH + CT_OFF(st + 1));
+            sf[(st + 1) & 1][2].q = *(const uint4*)(lb + CT_TILE_PITCH + CT_OFF(st + 1));
+            sf[(st + 1) & 1][3].q = *(const uint4*)(lb + CT_TILE_PITCH + 4 * CT_ROW_PITCH + CT_OFF(st + 1));
+          }
+          acc0 = CT_MFMA(wr[st % (CT_RING + 1)].v, sf[st & 1][0].v, acc0);
+          acc1 = CT_MFMA(wr[st % (CT_RING + 1)].v, sf[st & 1][1].v, acc1);
+          acc2 = CT_MFMA(wr[st % (CT_RING + 1)].v, sf[st & 1][2].v, acc2);
+          acc3 = CT_MFMA(wr[st % (CT_RING + 1)].v, sf[st & 1][3].v, acc3);
+          __builtin_amdgcn_sched_barrier(0);   // nothing moves across a step: the prefetch distances are what is written here
         }
-        acc0 = CT_MFMA(wr[st % 9].v, sf[st & 1][0].v, acc0);
-        acc1 = CT_MFMA(wr[st % 9].v, sf[st & 1][1].v, acc1);
-        acc2 = CT_MFMA(wr[st % 9].v, sf[st & 1][2].v, acc2);
-        acc3 = CT_MFMA(wr[st % 9].v, sf[st & 1][3].v, acc3);
-        __builtin_amdgcn_sched_barrier(0);   // nothing moves across a step: the prefetch distances are what is written here
       }
+      __syncthreads();
     }
-    __syncthreads();
   }
 
   // ---- epilogue: Y^T accumulators (row = channel by register, column = site by lane) -> bf16 site-major rows in LDS
@@ -422,6 +450,7 @@ __global__ __launch_bounds__(CT_THREADS, CT_TPW == 2 ? 2 : 1) void k_conv3x3_til
   }
   __syncthreads();
   float* red = (float*)(lds + CT_RED_OFF);
+  const int elc = tid & 15, elsg = tid >> 4;      // 16-byte chunk of a 128-channel output row, site within a pass
 #pragma unroll
   for (int t = 0; t < CT_TPW; ++t) {
     if (!have[t]) continue;
@@ -429,10 +458,10 @@ __global__ __launch_bounds__(CT_THREADS, CT_TPW == 2 ? 2 : 1) void k_conv3x3_til
 #pragma unroll
     for (int j = 0; j < 8; ++j) s[j] = q2[j] = 0.f;
 #pragma unroll
-    for (int p = 0; p < 64 / CT_SPP; ++p) {
-      const int site = p * CT_SPP + lsg;
-      const uint4 v = *(const uint4*)(lds + t * CT_STAGE_PITCH + site * CT_SITE_PITCH + lc * 16);
-      *(uint4*)(A.Yc + ((long long)(slot0 + t) * GD_TILE_SITES + site) * CT_C + lc * 8) = v;
+    for (int p = 0; p < 64 / CT_ESPP; ++p) {
+      const int site = p * CT_ESPP + elsg;
+      const uint4 v = *(const uint4*)(lds + t * CT_STAGE_PITCH + site * CT_SITE_PITCH + elc * 16);
+      *(uint4*)(A.Yc + ((long long)(slot0 + t) * GD_TILE_SITES + site) * CT_C + elc * 8) = v;
       if (ty0[t] + (site >> 3) < A.H && tx0[t] + (site & 7) < A.W) {
         float f[8];
         ct_unpack8(v, f);
@@ -453,8 +482,8 @@ __global__ __launch_bounds__(CT_THREADS, CT_TPW == 2 ? 2 : 1) void k_conv3x3_til
     if (lane < 16) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        red[((t * CT_NWAVES + wvg) * 2 + 0) * CT_C + lc * 8 + j] = s[j];
-        red[((t * CT_NWAVES + wvg) * 2 + 1) * CT_C + lc * 8 + j] = q2[j];
+        red[((t * CT_NWAVES + wvg) * 2 + 0) * CT_C + elc * 8 + j] = s[j];
+        red[((t * CT_NWAVES + wvg) * 2 + 1) * CT_C + elc * 8 + j] = q2[j];
       }
     }
   }
