@@ -785,6 +785,7 @@ extern "C" int gdmae_encoder_stage_fwd(const gdmae_layer_args* layers, int n_lay
                           layers[i].ff == layers[0].ff && layers[i].bf16 == layers[0].bf16),
                "encoder stage: layers must chain (x[i] = y[i-1]) and share n, d, ff, dtype");
   if (stage_v2(layers, n_layers)) return stage_fwd_v2(layers, n_layers, stream);
+  GD_REQUIRE(n_layers == 1 || (uintptr_t)layers[1].x >= 4096, "encoder stage: chained by tokens (the fused path's convention) but the fused path is off");
   GD_REQUIRE(!layers[0].x_bf16 && !layers[n_layers - 1].res_out, "encoder stage: bf16 input rows / the folded block residual need the fused path");
   for (int i = 0; i < n_layers; ++i) {
     GD_REQUIRE(i == 0 || (layers[i].x == layers[i - 1].y && layers[i].n == layers[0].n && layers[i].d == layers[0].d &&
@@ -1033,7 +1034,15 @@ extern "C" int gdmae_encoder_stage_bwd(const gdmae_layer_args* layers, int n_lay
     GD_REQUIRE(layers[i].scratch == layers[0].scratch && layers[i].n == layers[0].n && layers[i].d == layers[0].d &&
                    layers[i].ff == layers[0].ff && layers[i].bf16 == layers[0].bf16,
                "encoder stage: layers must share scratch, n, d, ff, dtype");
-  if (stage_v2(layers, n_layers)) return stage_bwd_v2(layers, n_layers, stream);
+  // The forward chose its path (gdmae_encoder_stage_fused) and laid the saved blocks out for it; on the fused path the caller chains the
+  // layers with small tokens instead of row pointers (x[i] = 1 + i).  A gdmae_encoder_set_layer_path call between a forward and its
+  // backward would send token "pointers" into the per-layer kernels, or fused kernels onto a launch-per-product saved block: refuse.
+  const bool tokens = n_layers > 1 && (uintptr_t)layers[1].x < 4096;
+  if (stage_v2(layers, n_layers)) {
+    GD_REQUIRE(n_layers == 1 || tokens, "encoder stage backward: the forward of these layers ran the launch-per-product path (layer path changed in between)");
+    return stage_bwd_v2(layers, n_layers, stream);
+  }
+  GD_REQUIRE(!tokens, "encoder stage backward: the forward of these layers ran the fused path (layer path changed in between)");
   GD_REQUIRE(!layers[n_layers - 1].dres && !layers[0].dx_bf16, "encoder stage: the folded block residual needs the fused path");
   // bf16 rows with packed weights: the LayerNorm-2 backward of layer i - 1 rides on layer i's last input-gradient GEMM
   bool chain = true;

@@ -6,6 +6,7 @@
 #include <hipblaslt/hipblaslt.h>
 #include <stdlib.h>
 
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <tuple>
@@ -60,7 +61,7 @@ typedef std::tuple<int, int, int, int, int, int, int, int, int, int, int, int, i
 
 hipblasLtHandle_t g_lt = nullptr;
 std::map<GemmKey, GemmPlan> g_plans;
-long long g_gemm_calls = 0, g_gemm_tuned = 0;     // gdmae_gemm_stats: library GEMM calls / plans created (first use of a shape bucket)
+std::atomic<long long> g_gemm_calls{0}, g_gemm_tuned{0};     // gdmae_gemm_stats (atomic: the fp32 fast path counts without taking g_lt_mu): library GEMM calls / plans created (first use of a shape bucket)
 std::mutex g_lt_mu;
 int g_tune_override = -1;      // gdmae_gemm_tuning
 
@@ -190,20 +191,20 @@ int gd_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const void* A
             ok = hipblasLtMatmul(g_lt, p.desc, &alpha, A, p.la, B, p.lb, &beta, C, p.lc, C, p.lc, &cand[i].algo, ws, cand[i].workspaceSize,
                                  st) == HIPBLAS_STATUS_SUCCESS;
           if (!ok) break;
-          hipEventRecord(e0, st);
+          GD_CHECK(hipEventRecord(e0, st));
           for (int rep = 0; rep < reps && ok; ++rep)
             ok = hipblasLtMatmul(g_lt, p.desc, &alpha, A, p.la, B, p.lb, &beta, C, p.lc, C, p.lc, &cand[i].algo, ws, cand[i].workspaceSize,
                                  st) == HIPBLAS_STATUS_SUCCESS;
-          hipEventRecord(e1, st);
+          GD_CHECK(hipEventRecord(e1, st));
           GD_CHECK(hipEventSynchronize(e1));
-          hipEventElapsedTime(&ms, e0, e1);
+          GD_CHECK(hipEventElapsedTime(&ms, e0, e1));
           ms /= reps;
           if (pass == 0 && ms > 1.3f * best_ms) break;      // clearly slower than the best so far
         }
         if (ok && ms < best_ms) { best_ms = ms; best = i; }
       }
-      hipEventDestroy(e0);
-      hipEventDestroy(e1);
+      (void)hipEventDestroy(e0);
+      (void)hipEventDestroy(e1);
     }
     p.algo = cand[best].algo;
     p.ws = cand[best].workspaceSize;

@@ -130,11 +130,29 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GfArgs G) {
     }
   }
 }
+// K = 0: the empty product - C = bias (or 0), same element addressing as the product's epilogue
+__global__ __launch_bounds__(256) void k_gemm_f32_k0(float* __restrict__ C, const float* __restrict__ bias, int M, int N, int ldc, long long sC, int batch) {
+  const long long total = (long long)M * N * batch;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int m = (int)(i % M);
+    const long long r = i / M;
+    const int n = (int)(r % N);
+    const long long b = r / N;
+    C[m + (long long)n * ldc + b * sC] = bias ? bias[m] : 0.f;
+  }
+}
 }  // namespace
 
 int gd_gemm_f32(hipStream_t st, bool ta, bool tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                 const float* bias, int batch, long long sA, long long sB, long long sC) {
-  GD_REQUIRE(M > 0 && N > 0 && K > 0 && batch >= 1 && batch <= 65535, "gemm_f32: bad extents");
+  GD_REQUIRE(M >= 0 && N >= 0 && K >= 0 && batch >= 1 && batch <= 65535, "gemm_f32: bad extents");
+  if (M == 0 || N == 0) return 0;                      // nothing to write (an empty stage / batch)
+  if (K == 0) {
+    const long long total = (long long)M * N * batch;
+    hipLaunchKernelGGL(k_gemm_f32_k0, dim3((unsigned)(total / 256 + 1 > 4096 ? 4096 : total / 256 + 1)), dim3(256), 0, st, C, bias, M, N, ldc, sC, batch);
+    GD_LAUNCH_CHECK();
+    return 0;
+  }
   const unsigned gm = (unsigned)gd_div_up(M, kTM), gn = (unsigned)gd_div_up(N, kTN);
   const int swap = gn > gm;
   auto aligned = [](const float* p, int ld, long long stride) { return ((uintptr_t)p & 15) == 0 && ld % 4 == 0 && stride % 4 == 0; };
