@@ -11,6 +11,18 @@ from ...utils.spconv_utils import SparseConvTensor
 from gdmae_hip import decoder as gdec, ops, plan as gplan
 
 
+def _only_the_pred_head_sees_the_gradient(pred) -> bool:
+    """pred = view of a PredHeadFn output, no tensor hooks and no retained gradient on it or on the head's output: the gradient that
+    ops.ChamferLoss hands back reaches gdmae_hip.decoder.PredHeadFn.backward and nothing else."""
+    fn = pred.grad_fn
+    if fn is None or not type(fn).__name__.startswith('ViewBackward') or pred._backward_hooks or pred.retains_grad:
+        return False
+    nxt = [f for f, _ in fn.next_functions if f is not None]
+    if len(nxt) != 1 or 'PredHeadFn' not in type(nxt[0]).__name__:
+        return False
+    return not getattr(nxt[0], '_tensor_pre_hooks', None) and not getattr(nxt[0], '_pre_hooks', None) and not getattr(nxt[0], '_retains_grad_hooks', None)
+
+
 class SPTBackboneMAE(nn.Module):
     # 'sparse': exact sparse-aware decoder (gdmae_hip/decoder.py); 'dense': the reference's dataflow through
     # the torch modules (kept for A/B tests).  dense_spatial_features: materialise batch_dict['spatial_features']
@@ -40,8 +52,12 @@ class SPTBackboneMAE(nn.Module):
     def get_loss(self, tb_dict=None):
         tb_dict = {} if tb_dict is None else tb_dict
         r = self.forward_ret_dict
-        # pred straight from the fused prediction head: the scalars of the mean are applied by the head's backward on load
-        return ops.ChamferLoss.apply(r['pred_points'], r['gt_points'], r['mask'], bool(r.get('pred_lazy_scale', False))), tb_dict
+        # pred straight from the fused prediction head: the scalars of the mean are applied by the head's backward on load.  That
+        # hand-over (an UNSCALED gradient travelling through autograd with its scale on the side) is only safe when nothing but the
+        # head's own backward can see the gradient of pred_points: checked here, the scaled gradient otherwise
+        pred = r['pred_points']
+        lazy = bool(r.get('pred_lazy_scale', False)) and _only_the_pred_head_sees_the_gradient(pred)
+        return ops.ChamferLoss.apply(pred, r['gt_points'], r['mask'], lazy), tb_dict
 
     def forward(self, batch_dict):
         """Inputs: DynVFE's ``voxel_features`` + the voxel plan.  Optional ``mae_noise`` (M,) injects the

@@ -1736,3 +1736,45 @@ def test_bf16_stores_round_to_nearest_even_like_torch():
     nan = torch.isnan(a)
     assert torch.equal(torch.isnan(out), nan)
     assert torch.equal(out[~nan].view(torch.int16), ref[~nan].view(torch.int16))
+
+
+def test_lazy_chamfer_scale_is_used_only_when_nothing_else_sees_the_gradient():
+    """ops.ChamferLoss hands the prediction head an UNSCALED gradient with the mean's scalars on the side (no scaling pass) - only while
+    the head's backward is the sole observer of d loss / d pred_points (spt_backbone_mae._only_the_pred_head_sees_the_gradient).  A
+    tensor hook on pred_points switches to the scaled gradient: the hook sees d loss / d pred, the parameter gradients do not change."""
+    import logging
+    from gdmae_hip import configs, optim
+    from pcdet.models import build_network
+    from pcdet.models.backbones_3d import spt_backbone_mae as M
+    z, ds, cfg, shapes = load_case("kitti_b2_m75")
+    res = {}
+    for hook in (False, True):
+        torch.manual_seed(0)
+        net = build_network(cfg, len(ds.class_names), ds, logging.getLogger("t")).to(dev())
+        net.load_state_dict(orc.seeded_state_dict(shapes, seed=int(z["seed"])), strict=False)
+        net.train()
+        opt = optim.FlatAdamOneCycle(net, configs.optimization_cfg(8), total_steps=10)
+        opt.zero_grad()
+        seen = []
+        orig = net.backbone_3d.target_assigner
+
+        def hooked(bd, orig=orig, seen=seen, hook=hook):
+            r = orig(bd)
+            if hook:
+                r['pred_points'].register_hook(lambda g: seen.append(g.detach().clone()))
+            res[("lazy", hook)] = bool(r['pred_lazy_scale']) and M._only_the_pred_head_sees_the_gradient(r['pred_points'])
+            return r
+        net.backbone_3d.target_assigner = hooked
+        bd = {"points": torch.from_numpy(z["points"]).to(dev()), "batch_size": int(z["batch_size"]), "mae_noise": torch.from_numpy(z["noise"]).to(dev())}
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            ret, _, _ = net(bd)
+        ret["loss"].backward()
+        res[hook] = {k: p.grad.detach().clone() for k, p in net.named_parameters()}
+        if hook:
+            assert len(seen) == 1 and float(seen[0].abs().sum()) > 0
+            # the scaled gradient: |d loss / d pred| sums to O(1 / pillars), the unscaled one to O(1) per pillar
+            res["hook_grad_sum"] = float(seen[0].abs().sum())
+    assert res[("lazy", False)] is True and res[("lazy", True)] is False
+    for k in res[False]:
+        a, b = res[False][k].double(), res[True][k].double()
+        assert float((a - b).norm()) <= 2e-2 * float(b.norm()) + 1e-12, k       # bf16 rounding of the scaled vs unscaled gradient rows
