@@ -77,7 +77,7 @@ __device__ __forceinline__ void coop_fwd(const CArgs& A, const unsigned blk, uns
   for (int p = 0; p < G::P; ++p) {
     const int r = p * G::RPI + lr;
     const int rc = r < n ? r : n - 1;
-    tok[p] = A.csr_tok[start + (rc > 0 ? rc : 0)];       // slots past the window repeat its last token; cleared below
+    tok[p] = A.csr_tok ? A.csr_tok[start + (rc > 0 ? rc : 0)] : start + (rc > 0 ? rc : 0);       // slots past the window repeat its last token; cleared below (null: rows in window-major order)
   }
   uint4 q16[G::P], k16[G::P], v16[G::P];
 #pragma unroll
@@ -114,6 +114,7 @@ __device__ __forceinline__ void coop_fwd(const CArgs& A, const unsigned blk, uns
   const float* sQn = sKin + ROWS;
   float* sLse = reinterpret_cast<float*>(tV + ROWS * kPitch) + 2 * ROWS;
   const int r = 32 * sub + rho;
+#ifndef ATTN_EXP_NOCOMP      // experiment: loads -> tiles -> stores only (what the arithmetic costs on top of the row traffic)
   const Row<NPC> q = lds_row<NPC>(tQ, r, h);
   const float qc = sQn[r] * inv_tau * kLog2e;              // (1 / |q| tau) log2(e): exponent scale of this lane's query column
   f32x16 aS[NW];
@@ -153,6 +154,9 @@ __device__ __forceinline__ void coop_fwd(const CArgs& A, const unsigned blk, uns
     for (int t = 0; t < NPC; ++t) ob.p[t] = pack_piece(o[4 * t] * il, o[4 * t + 1] * il, o[4 * t + 2] * il, o[4 * t + 3] * il);
     store_tile<NPC>(tQ, r, h, ob);
   }
+#else
+  (void)r; (void)sKin; (void)sQn; (void)sLse; (void)tK; (void)inv_tau;
+#endif
   __syncthreads();
 #pragma unroll
   for (int p = 0; p < G::P; ++p) {
@@ -200,7 +204,7 @@ __device__ __forceinline__ void coop_bwd(const CBwdArgs& A, const unsigned blk, 
   for (int p = 0; p < G::P; ++p) {
     const int r = p * G::RPI + lr;
     const int rc = r < n ? r : n - 1;
-    tok[p] = A.csr_tok[start + (rc > 0 ? rc : 0)];
+    tok[p] = A.csr_tok ? A.csr_tok[start + (rc > 0 ? rc : 0)] : start + (rc > 0 ? rc : 0);
   }
   uint4 q16[G::P], k16[G::P], v16[G::P], o16[G::P], x16[G::P];
   float lse_[G::P];
@@ -257,6 +261,12 @@ __device__ __forceinline__ void coop_bwd(const CBwdArgs& A, const unsigned blk, 
   const bool act = r < n;
   float dtau;
   Row<NPC> dqr;
+#ifdef ATTN_EXP_NOCOMP
+  Row<NPC> dkr, dvr;
+  dtau = 0.f;
+  dqr = lds_row<NPC>(tQ, r, h); dkr = lds_row<NPC>(tK, r, h); dvr = lds_row<NPC>(tV, r, h);
+  (void)act; (void)sLse; (void)sD; (void)sQa; (void)sPair; (void)tO; (void)sQn; (void)sKin; (void)inv_tau;
+#else
   // ================= phase 1: this wave's query tile -> dQ =================
   {
     const Row<NPC> q = lds_row<NPC>(tQ, r, h), dO = lds_row<NPC>(tO, r, h);
@@ -354,6 +364,7 @@ __device__ __forceinline__ void coop_bwd(const CBwdArgs& A, const unsigned blk, 
       dvr.p[t] = pack_piece(ov[4 * t], ov[4 * t + 1], ov[4 * t + 2], ov[4 * t + 3]);
     }
   }
+#endif
   // ---- results -> tiles (every wavefront of the head is done reading them) -> cooperative stores
   __syncthreads();
   if (lane == 0 && sub == 0) A.dtau_part[(long long)w * A.H + hg * HW + hw] = NW == 2 ? dtau + *sPair : dtau;      // one partial per (window, head)

@@ -189,7 +189,7 @@ __device__ __forceinline__ bool next_pass(Pass& ps, const int (&len)[kWinPerWave
   ps.a = a;
   ps.b = b;
   ps.wid = wid;
-  ps.tok = csr_tok[idx >= 0 ? idx : 0];           // padding rows read entry 0: their rows are cleared (keep_row), no branch around the load
+  ps.tok = csr_tok ? csr_tok[idx >= 0 ? idx : 0] : (idx >= 0 ? idx : 0);           // padding rows read entry 0: their rows are cleared (keep_row), no branch around the load
   return true;
 }
 

@@ -31,6 +31,8 @@ for si, st in enumerate(plan.stages):
         lse = torch.empty(st.n_tok, H, device=dev)
         nw_h, T_h = L.host_i32(w.n_win), L.host_i32(w.max_tokens)
         csr = torch.arange(st.n_tok, dtype=torch.int32, device=dev) if IDENT else w.csr_tok
+        if os.environ.get("NOCSR"):          # experiment: no index load at all (rows in window-major order, csr_tok = null)
+            csr = None
         def fwd():
             L.call("gdmae_window_attention_levels_fwd", L.ptr(qk), L.ptr(v), L.ptr(out), 1, L.ptr(csr), L.ptr(w.win_start), L.ptr(w.win_len), nl,
                    nw_h, T_h, d, H, L.ptr(tau), 0.01, L.ptr(lse), L.stream())
@@ -38,7 +40,7 @@ for si, st in enumerate(plan.stages):
             L.call("gdmae_window_attention_levels_bwd", L.ptr(qk), L.ptr(v), L.ptr(g), L.ptr(dqk), L.ptr(dv), 1, L.ptr(part), L.ptr(csr),
                    L.ptr(w.win_start), L.ptr(w.win_len), nl, nw_h, T_h, d, H, L.ptr(tau), 0.01, L.ptr(out), L.ptr(lse), L.stream())
         line = f"stage {si} shift {shift} windows {w.n_win} tokens {w.n_tok}:"
-        for impl in (3, 0):
+        for impl in ((0,) if os.environ.get("NOCSR") else (3, 0)):
             L.call("gdmae_set_attention_impl", impl)
             res = []
             for f in (fwd, bwd):
