@@ -45,6 +45,8 @@ constexpr int V2_LDX = V2_CO + 8;     // ... of the dx tile (32 x 128) and of W^
 constexpr int V2_LDT = 32 + 8;        // ... of the transposed y1 tile (64 x 32)
 constexpr int V2_MAX_GRID = 1024;     // rows of the statistics partials
 constexpr int V2_DW_GRID = 1024;      // rows of the dW partials (32 KB each)
+constexpr int V2_MAXW_GRID = 2048;    // workgroups of k_v2_max (8 workers each; their boundary slots share the dW partial area)
+static_assert((size_t)V2_MAXW_GRID * 8 * 2 * 128 * 8 <= (size_t)V2_DW_GRID * 128 * 64 * 4, "boundary slots fit the partial area");
 
 __device__ __forceinline__ int v2_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 __device__ __forceinline__ unsigned short v2_f2bf(float f) { return gd_to_bf16(f); }
@@ -161,32 +163,37 @@ __global__ __launch_bounds__(V2_WAVES * 64) void k_v2_stats(const unsigned short
 }
 
 // ---- forward maximum -----------------------------------------------------------------------------------------
-// Every half-wave is a worker with its own contiguous, pillar-aligned range of rows.  A 32-row MFMA tile holds 16 rows
-// of each worker, permuted so that a lane's 16 accumulator registers are 16 CONSECUTIVE rows of its worker:
-// MFMA row i = (r & 3) + 8 (r >> 2) + 4 h  <->  worker h, local row r.  Each lane then walks its registers in row
-// order, closing a pillar (three coalesced 128-byte stores per column block) whenever the pillar id changes - no LDS,
-// no atomics.  arg = row of the maximum (strict >: the first row, i.e. the lowest point id, wins ties).
+// Every half-wave is a worker with its own contiguous range of `per` rows - the SAME number of rows for every worker, wherever the
+// pillar boundaries fall (ranges snapped to pillar starts gave a crowded pillar - 1 000 points next to the sensor against 11 on
+// average - to one half-wave as a serial chain of 68 tiles: 118 of the launch's 174 us did not scale with the batch).  A 32-row MFMA
+// tile holds 16 rows of each worker, permuted so that a lane's 16 accumulator registers are 16 CONSECUTIVE rows of its worker:
+// MFMA row i = (r & 3) + 8 (r >> 2) + 4 h  <->  worker h, local row r.  Each lane then walks its registers in row order, closing a
+// pillar (three coalesced 128-byte stores per column block) whenever the pillar id changes - no LDS, no atomics.  A pillar that lies
+// inside the range goes straight to out / arg; the piece of a pillar that began before the range goes to the worker's boundary slot
+// 0, the piece of one that continues behind it to slot 1 (a range inside one pillar: slot 0), and k_v2_max_fix joins the pieces of
+// such a pillar in row order.  arg = row of the maximum (strict >: the first row, i.e. the lowest point id, wins ties - (max value,
+// min row) is associative, so joining pieces in order gives the sequential walk's answer bit for bit).
 __global__ __launch_bounds__(V2_WAVES * 64) void k_v2_max(const unsigned short* __restrict__ y1, long long N,
                                                           const unsigned short* __restrict__ W, const int* __restrict__ pt_off,
                                                           const int* __restrict__ rowpil, int M, const float* __restrict__ ab,
-                                                          float* __restrict__ out, int* __restrict__ arg) {
+                                                          float* __restrict__ out, int* __restrict__ arg, long long per,
+                                                          float* __restrict__ pbest, int* __restrict__ parg) {
   __shared__ unsigned short sW[V2_CO * V2_LDW];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 31, half = lane >> 5;
   v2_load_w(W, sW);
   __syncthreads();
-  // this worker's share of the rows, snapped to pillar starts
-  const long long nwk = (long long)gridDim.x * V2_WAVES * 2, wk = ((long long)blockIdx.x * V2_WAVES + wave) * 2 + half;
-  const long long per = (N + nwk - 1) / nwk;
+  // this worker's share of the rows; head: its first pillar began before the range, tail: its last pillar continues behind it
+  const long long wk = ((long long)blockIdx.x * V2_WAVES + wave) * 2 + half;
   const long long qa = wk * per < N ? wk * per : N, qb = (wk + 1) * per < N ? (wk + 1) * per : N;
-  // snap [qa, qb) forward to pillar starts: a row starts a pillar iff its predecessor belongs to another one
-  int q0 = (int)qa, q1 = (int)qb;
+  const int q0 = (int)qa, q1 = (int)qb;
+  bool hp, tail;
   {
-    const int a0 = qa > 0 && qa < N ? rowpil[qa - 1] : -1, a1 = qa < N ? rowpil[qa] : -2;
-    const int b0 = qb > 0 && qb < N ? rowpil[qb - 1] : -1, b1 = qb < N ? rowpil[qb] : -2;
-    if (a0 == a1) q0 = pt_off[a1 + 1];
-    if (b0 == b1) q1 = pt_off[b1 + 1];
-    if (q1 < q0) q1 = q0;
+    const long long ia = qa > 0 ? qa - 1 : 0, ib = qa < N ? qa : N - 1, ic = qb > 0 ? qb - 1 : 0, id = qb < N ? qb : N - 1;
+    const int a0 = rowpil[ia], a1 = rowpil[ib], b0 = rowpil[ic], b1 = rowpil[id];     // four independent loads
+    hp = qa > 0 && qa < qb && a0 == a1;
+    tail = qb < N && qa < qb && b0 == b1;
   }
+  const long long slot0 = (wk * 2 + 0) * V2_CO, slot1 = (wk * 2 + 1) * V2_CO;
   // the tile row this lane loads as MFMA row n: worker (n >> 2) & 1, local row (n & 3) + 4 (n >> 3)
   const int ld_wk = (n >> 2) & 1, ld_r = (n & 3) + 4 * (n >> 3);
   const int q0o = __shfl(q0, lane ^ 32, 64), q1o = __shfl(q1, lane ^ 32, 64);
@@ -246,11 +253,14 @@ __global__ __launch_bounds__(V2_WAVES * 64) void k_v2_max(const unsigned short* 
     v2_keep_y(yn, live_n);
     asm volatile("" : "+v"(pln));
     if (st[0] && cur_in >= 0) {                  // the pillar carried over from the previous tile ends here
+      float* const ob = hp ? pbest : out;
+      int* const oa = hp ? parg : arg;
+      const long long o0 = hp ? slot0 : (long long)cur_in * V2_CO;
+      hp = false;
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
-        const long long o = (long long)cur_in * V2_CO + 32 * b + n;
-        out[o] = best[b];
-        arg[o] = bi[b];
+        ob[o0 + 32 * b + n] = best[b];
+        oa[o0 + 32 * b + n] = bi[b];
       }
     }
 #pragma unroll
@@ -264,11 +274,14 @@ __global__ __launch_bounds__(V2_WAVES * 64) void k_v2_max(const unsigned short* 
         bi[b] = up ? qt + r : bi[b];
       }
       if (r < 15 && st[r < 15 ? r + 1 : 15]) {   // row r closes its pillar: one branch for the four column blocks
+        float* const ob = hp ? pbest : out;
+        int* const oa = hp ? parg : arg;
+        const long long o0 = hp ? slot0 : (long long)prow[r] * V2_CO;
+        hp = false;
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-          const long long o = (long long)prow[r] * V2_CO + 32 * b + n;
-          out[o] = best[b];
-          arg[o] = bi[b];
+          ob[o0 + 32 * b + n] = best[b];
+          oa[o0 + 32 * b + n] = bi[b];
         }
       }
     }
@@ -276,14 +289,44 @@ __global__ __launch_bounds__(V2_WAVES * 64) void k_v2_max(const unsigned short* 
 #pragma unroll
     for (int s = 0; s < 4; ++s) ya[s] = yn[s];
   }
-  if (cur >= 0) {
+  if (cur >= 0) {                                // the range's last pillar: whole (out), first piece (slot 1) or a later piece (slot 0)
+    float* const ob = hp || tail ? pbest : out;
+    int* const oa = hp || tail ? parg : arg;
+    const long long o0 = hp ? slot0 : (tail ? slot1 : (long long)cur * V2_CO);
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-      const long long o = (long long)cur * V2_CO + 32 * b + n;
-      out[o] = best[b];
-      arg[o] = bi[b];
+      ob[o0 + 32 * b + n] = best[b];
+      oa[o0 + 32 * b + n] = bi[b];
     }
   }
+}
+
+// joins the pieces of every pillar that crosses a range boundary of k_v2_max: one workgroup per worker; the worker in whose range
+// the pillar BEGINS (its slot 1) walks the following workers' slot 0 pieces in row order until the pillar ends.  Chains are one
+// piece long except for crowded pillars (points / per pieces).
+__global__ __launch_bounds__(V2_CO) void k_v2_max_fix(const int* __restrict__ rowpil, long long N, long long per,
+                                                      const float* __restrict__ pbest, const int* __restrict__ parg,
+                                                      float* __restrict__ out, int* __restrict__ arg) {
+  const long long w = blockIdx.x;
+  const int c = threadIdx.x;
+  const long long qa = w * per < N ? w * per : N, qb = (w + 1) * per < N ? (w + 1) * per : N;
+  if (qa >= qb || qb >= N) return;
+  const int P = rowpil[qb - 1];
+  if (rowpil[qb] != P) return;                        // the last pillar ends with the range
+  if (qa > 0 && rowpil[qa - 1] == P) return;          // it began before this range: the chain belongs to an earlier worker
+  float bv = pbest[(w * 2 + 1) * V2_CO + c];
+  int bi = parg[(w * 2 + 1) * V2_CO + c];
+  for (long long v = w + 1;; ++v) {
+    const float pv = pbest[(v * 2) * V2_CO + c];
+    const int pi = parg[(v * 2) * V2_CO + c];
+    const bool up = pv > bv;                           // strict: the earlier piece keeps ties
+    bv = up ? pv : bv;
+    bi = up ? pi : bi;
+    const long long vb = (v + 1) * per < N ? (v + 1) * per : N;
+    if (vb >= N || rowpil[vb] != P) break;
+  }
+  out[(long long)P * V2_CO + c] = bv;
+  arg[(long long)P * V2_CO + c] = bi;
 }
 
 // ---- backward: masked gradient and its column sums ---------------------------------------------------------------
@@ -534,9 +577,17 @@ extern "C" int gdmae_vfe_max_layer_fwd(const void* y1, long long N, const void* 
   int rc = gd_bn_fold_from_partials(st, ws.part, g1, V2_CO, (double)N, gamma, beta, eps, momentum, running_mean, running_var,
                                     num_batches, stats, ab, mv);
   if (rc) return rc;
-  const int g2 = v2_grid(N, v2_resident_blocks(k_v2_max, 1, 4096));
+  // boundary pieces of k_v2_max: 2 slots x 128 columns x (value, row) per worker, in the partial area (the statistics partials have
+  // been consumed by the fold above): V2_MAXW_GRID workgroups x 8 workers x 2 KB = the area's 32 MB
+  const int g2 = v2_grid(N, v2_resident_blocks(k_v2_max, 1, V2_MAXW_GRID));
+  const long long nwk = (long long)g2 * V2_WAVES * 2, per = (N + nwk - 1) / nwk;
+  float* const pbest = ws.part;
+  int* const parg = (int*)(ws.part + nwk * 2 * V2_CO);
   hipLaunchKernelGGL(k_v2_max, dim3(g2), dim3(V2_WAVES * 64), 0, st, (const unsigned short*)y1, N, (const unsigned short*)W,
-                     pillar_pt_off, row_pillar, M, (const float*)ab, out, arg);
+                     pillar_pt_off, row_pillar, M, (const float*)ab, out, arg, per, pbest, parg);
+  GD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_v2_max_fix, dim3((unsigned)nwk), dim3(V2_CO), 0, st, row_pillar, N, per, (const float*)pbest, (const int*)parg,
+                     out, arg);
   GD_LAUNCH_CHECK();
   return 0;
 }

@@ -1215,6 +1215,55 @@ def test_vfe_point_layer_equals_op_by_op_layer(name, autocast):
             assert torch.allclose(fused_rs[k], r0, rtol=1e-5, atol=1e-6), k
 
 
+@pytest.mark.parametrize("sizes", [[1, 700, 3, 1, 2600, 17, 2, 2, 1, 90, 31, 33, 1], [5000], [1] * 300, [40, 40, 40, 41, 39, 1, 500, 16, 16, 16, 16],
+                                   [3, 12000, 2, 7000, 1]])
+def test_vfe_max_layer_crowded_pillars(sizes):
+    """gdmae_vfe_max_layer_fwd on pillars far larger than a worker's row range (k_v2_max gives every half-wave the same number of
+    rows and k_v2_max_fix joins the pieces of a pillar that crosses range boundaries - a 1 000-point pillar next to the sensor is
+    the normal case at 0.32 m): out against relu(BatchNorm1d_train(y1 W^T)) reduced per pillar in fp32 torch (2e-3: bf16 products,
+    fp32 accumulation), arg a row of ITS pillar whose value reaches the maximum, and - every second pillar made of identical rows -
+    the FIRST row of the pillar on ties, bit for bit (torch_scatter's scatter_max semantics as dyn_vfe.py:112 uses it)."""
+    from gdmae_hip import vfe as gvfe
+    d = dev()
+    gen = torch.Generator().manual_seed(len(sizes) * 7 + sizes[0])
+    N, M = sum(sizes), len(sizes)
+    y1 = torch.randn(N, 64, generator=gen).abs()
+    off = torch.tensor([0] + list(np.cumsum(sizes)), dtype=torch.int32)
+    for p in range(1, M, 2):                                   # identical rows: every row of the pillar ties in every column
+        y1[off[p]:off[p + 1]] = y1[off[p]]
+    y1 = y1.bfloat16()
+    W = (torch.randn(128, 64, generator=gen) * 0.2)
+    rowpil = torch.repeat_interleave(torch.arange(M, dtype=torch.int32), torch.tensor(sizes))
+    gamma, beta = torch.rand(128, generator=gen) + 0.5, torch.randn(128, generator=gen) * 0.3
+    out, mf, vf = gvfe.PointLayer2Max.apply(y1.to(d), rowpil.to(d), W.to(d), gamma.to(d), beta.to(d), 1e-3, off.to(d), None)
+    torch.cuda.synchronize()
+    h = y1.double() @ W.bfloat16().double().t()
+    mean, var = h.mean(0), h.var(0, unbiased=False)
+    v = torch.relu((h - mean) / torch.sqrt(var + 1e-3) * gamma.double() + beta.double())
+    ref = torch.stack([v[off[p]:off[p + 1]].max(0).values for p in range(M)])
+    o = out.cpu().double()
+    assert torch.allclose(o, ref, rtol=2e-3, atol=2e-3), float((o - ref).abs().max())
+    # the arg-max rows are an internal output: re-run the C entry to read them
+    from gdmae_hip import lib as L
+    C = 128
+    wb = W.bfloat16().to(d).contiguous()
+    o2 = torch.empty(M, C, dtype=torch.float32, device=d)
+    arg = torch.full((M, C), -7, dtype=torch.int32, device=d)
+    stats, ab, mv = torch.empty(2 * C, dtype=torch.float64, device=d), torch.empty(2 * C, device=d), torch.empty(2 * C, device=d)
+    ws = torch.empty(L.load().gdmae_vfe_max_layer_workspace_bytes(), dtype=torch.uint8, device=d)
+    y1d, rpd, offd, gd_, bd_ = y1.to(d), rowpil.to(d), off.to(d), gamma.to(d), beta.to(d)
+    L.call("gdmae_vfe_max_layer_fwd", L.ptr(y1d), N, L.ptr(wb), L.ptr(offd), L.ptr(rpd), M, L.ptr(gd_), L.ptr(bd_), 1e-3, 0.0, None,
+           None, None, L.ptr(stats), L.ptr(ab), L.ptr(mv), L.ptr(o2), L.ptr(arg), L.ptr(ws), L.stream())
+    torch.cuda.synchronize()
+    assert torch.equal(o2, out)
+    a = arg.cpu().long()
+    lo, hi = off[:-1].long()[:, None], off[1:].long()[:, None]
+    assert bool(((a >= lo) & (a < hi)).all()), "arg-max row outside its pillar"
+    assert torch.allclose(v.gather(0, a), ref, rtol=2e-3, atol=2e-3)
+    for p in range(1, M, 2):
+        assert bool((a[p] == int(off[p])).all()), (p, sizes[p], a[p].unique())
+
+
 def _random_sources(B, H, W, dens, seed):
     """Random token sets of three source stages (strides 1, 2, 4) with their dense cell -> token maps, deconvolution
     rows P (bf16) and folded BatchNorm affines; plus the dense bf16 input map the reference dataflow would build."""
