@@ -38,6 +38,14 @@ union V2Frag {
   unsigned short s[8];
 };
 
+#ifndef V2_DW_WPE
+#define V2_DW_WPE 0
+#endif
+#if V2_DW_WPE
+#define V2_DW_ATTR __attribute__((amdgpu_waves_per_eu(V2_DW_WPE, V2_DW_WPE)))
+#else
+#define V2_DW_ATTR
+#endif
 constexpr int V2_CI = 64, V2_CO = 128;
 constexpr int V2_WAVES = 4;
 constexpr int V2_LDW = V2_CI + 8;     // bf16 elements per row of the W tile (128 x 64) in LDS
@@ -173,7 +181,7 @@ __global__ __launch_bounds__(V2_WAVES * 64) void k_v2_stats(const unsigned short
 // 0, the piece of one that continues behind it to slot 1 (a range inside one pillar: slot 0), and k_v2_max_fix joins the pieces of
 // such a pillar in row order.  arg = row of the maximum (strict >: the first row, i.e. the lowest point id, wins ties - (max value,
 // min row) is associative, so joining pieces in order gives the sequential walk's answer bit for bit).
-__global__ __launch_bounds__(V2_WAVES * 64) void k_v2_max(const unsigned short* __restrict__ y1, long long N,
+__global__ __launch_bounds__(V2_WAVES * 64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_v2_max(const unsigned short* __restrict__ y1, long long N,
                                                           const unsigned short* __restrict__ W, const int* __restrict__ pt_off,
                                                           const int* __restrict__ rowpil, int M, const float* __restrict__ ab,
                                                           float* __restrict__ out, int* __restrict__ arg, long long per,
@@ -183,8 +191,8 @@ __global__ __launch_bounds__(V2_WAVES * 64) void k_v2_max(const unsigned short* 
   v2_load_w(W, sW);
   __syncthreads();
   // this worker's share of the rows; head: its first pillar began before the range, tail: its last pillar continues behind it
-  const long long wk = ((long long)blockIdx.x * V2_WAVES + wave) * 2 + half;
-  const long long qa = wk * per < N ? wk * per : N, qb = (wk + 1) * per < N ? (wk + 1) * per : N;
+  const int wk = (blockIdx.x * V2_WAVES + wave) * 2 + half;      // (int, and the slot offsets recomputed where used: 162 registers = 3 waves per SIMD)
+  const long long qa = (long long)wk * per < N ? (long long)wk * per : N, qb = (long long)(wk + 1) * per < N ? (long long)(wk + 1) * per : N;
   const int q0 = (int)qa, q1 = (int)qb;
   bool hp, tail;
   {
@@ -193,7 +201,6 @@ __global__ __launch_bounds__(V2_WAVES * 64) void k_v2_max(const unsigned short* 
     hp = qa > 0 && qa < qb && a0 == a1;
     tail = qb < N && qa < qb && b0 == b1;
   }
-  const long long slot0 = (wk * 2 + 0) * V2_CO, slot1 = (wk * 2 + 1) * V2_CO;
   // the tile row this lane loads as MFMA row n: worker (n >> 2) & 1, local row (n & 3) + 4 (n >> 3)
   const int ld_wk = (n >> 2) & 1, ld_r = (n & 3) + 4 * (n >> 3);
   const int q0o = __shfl(q0, lane ^ 32, 64), q1o = __shfl(q1, lane ^ 32, 64);
@@ -255,7 +262,7 @@ __global__ __launch_bounds__(V2_WAVES * 64) void k_v2_max(const unsigned short* 
     if (st[0] && cur_in >= 0) {                  // the pillar carried over from the previous tile ends here
       float* const ob = hp ? pbest : out;
       int* const oa = hp ? parg : arg;
-      const long long o0 = hp ? slot0 : (long long)cur_in * V2_CO;
+      const long long o0 = (long long)(hp ? wk * 2 : cur_in) * V2_CO;
       hp = false;
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
@@ -276,7 +283,7 @@ __global__ __launch_bounds__(V2_WAVES * 64) void k_v2_max(const unsigned short* 
       if (r < 15 && st[r < 15 ? r + 1 : 15]) {   // row r closes its pillar: one branch for the four column blocks
         float* const ob = hp ? pbest : out;
         int* const oa = hp ? parg : arg;
-        const long long o0 = hp ? slot0 : (long long)prow[r] * V2_CO;
+        const long long o0 = (long long)(hp ? wk * 2 : prow[r]) * V2_CO;
         hp = false;
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
@@ -292,7 +299,7 @@ __global__ __launch_bounds__(V2_WAVES * 64) void k_v2_max(const unsigned short* 
   if (cur >= 0) {                                // the range's last pillar: whole (out), first piece (slot 1) or a later piece (slot 0)
     float* const ob = hp || tail ? pbest : out;
     int* const oa = hp || tail ? parg : arg;
-    const long long o0 = hp ? slot0 : (tail ? slot1 : (long long)cur * V2_CO);
+    const long long o0 = (long long)(hp ? wk * 2 : (tail ? wk * 2 + 1 : cur)) * V2_CO;
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
       ob[o0 + 32 * b + n] = best[b];
@@ -455,7 +462,7 @@ __global__ __launch_bounds__(V2_WAVES * 64) void k_v2_dy(const unsigned short* _
 
 // ---- backward: dW = dx^T y1 ----------------------------------------------------------------------------------------
 // the four waves of a workgroup share each tile, wave w owns the 32 columns [32 w, 32 w + 32) of dx / rows of dW
-__global__ __launch_bounds__(V2_WAVES * 64) void k_v2_dw(const unsigned short* __restrict__ y1, long long N,
+__global__ __launch_bounds__(V2_WAVES * 64) V2_DW_ATTR void k_v2_dw(const unsigned short* __restrict__ y1, long long N,
                                                          const unsigned short* __restrict__ W, const int* __restrict__ rowpil,
                                                          const float* __restrict__ ab, const float* __restrict__ c01,
                                                          const int* __restrict__ arg, const float* __restrict__ gm,

@@ -1235,14 +1235,29 @@ def test_vfe_max_layer_crowded_pillars(sizes):
     W = (torch.randn(128, 64, generator=gen) * 0.2)
     rowpil = torch.repeat_interleave(torch.arange(M, dtype=torch.int32), torch.tensor(sizes))
     gamma, beta = torch.rand(128, generator=gen) + 0.5, torch.randn(128, generator=gen) * 0.3
-    out, mf, vf = gvfe.PointLayer2Max.apply(y1.to(d), rowpil.to(d), W.to(d), gamma.to(d), beta.to(d), 1e-3, off.to(d), None)
+    y1d_, Wd_, gd__, bd__ = y1.to(d).requires_grad_(), W.to(d).requires_grad_(), gamma.to(d).requires_grad_(), beta.to(d).requires_grad_()
+    out, mf, vf = gvfe.PointLayer2Max.apply(y1d_, rowpil.to(d), Wd_, gd__, bd__, 1e-3, off.to(d), None)
+    up = torch.randn(M, 128, generator=gen)
+    (out * up.to(d)).sum().backward()
     torch.cuda.synchronize()
-    h = y1.double() @ W.bfloat16().double().t()
+    out = out.detach()
+    yr, Wr = y1.double().requires_grad_(), W.bfloat16().double().requires_grad_()
+    gr, br = gamma.double().requires_grad_(), beta.double().requires_grad_()
+    h = yr @ Wr.t()
     mean, var = h.mean(0), h.var(0, unbiased=False)
-    v = torch.relu((h - mean) / torch.sqrt(var + 1e-3) * gamma.double() + beta.double())
+    v = torch.relu((h - mean) / torch.sqrt(var + 1e-3) * gr + br)
     ref = torch.stack([v[off[p]:off[p + 1]].max(0).values for p in range(M)])
     o = out.cpu().double()
-    assert torch.allclose(o, ref, rtol=2e-3, atol=2e-3), float((o - ref).abs().max())
+    assert torch.allclose(o, ref.detach(), rtol=2e-3, atol=2e-3), float((o - ref).abs().max())
+    # backward (k_v2_gstats / k_v2_dy / k_v2_dw: per-pillar (arg, gm) chunks scattered to the arg-max rows through the LDS window;
+    # [1] * 300 puts 32 pillars into a tile = four chunks): the reference routes the gradient to the FIRST maximal row as well
+    first = torch.stack([v[off[p]:off[p + 1]].max(0).indices + int(off[p]) for p in range(M)])
+    (v.gather(0, first) * up.double()).sum().backward()
+    for name, got, want, tol in (("dy1", y1d_.grad, yr.grad, 3e-2), ("dW", Wd_.grad, Wr.grad, 2e-2), ("dgamma", gd__.grad, gr.grad, 2e-2),
+                                 ("dbeta", bd__.grad, br.grad, 2e-2)):
+        e = float((got.cpu().double() - want).norm()) / max(float(want.norm()), 1e-12)
+        assert e <= tol, (name, e)
+    v, ref = v.detach(), ref.detach()
     # the arg-max rows are an internal output: re-run the C entry to read them
     from gdmae_hip import lib as L
     C = 128
