@@ -355,13 +355,28 @@ __global__ __launch_bounds__(256) void k_bn_fold_final(const float* __restrict__
   __shared__ double sh[2][16][17];
   const int cl = threadIdx.x & 15, ps = threadIdx.x >> 4;   // 16 columns x 16 partial slices per workgroup
   const int c = blockIdx.x * 16 + cl;
+  // eight partial rows (sixteen loads) in flight per thread, requested unconditionally (clamped row, masked value): the launch is a
+  // chain of dependent round trips, not bytes (fixed order: the result is bit-repeatable)
   double a1 = 0.0, a2 = 0.0;
-  if (c < C)
-#pragma unroll 8
-    for (int b = ps; b < nblk; b += 16) {
-      a1 += (double)part[(long long)b * 2 * C + c];
-      a2 += (double)part[(long long)b * 2 * C + C + c];
+  {
+    const int cc = c < C ? c : C - 1;
+    const float* p = part + cc;
+    for (int b0 = ps; b0 < nblk; b0 += 128) {
+      float v1[8], v2[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int b = b0 + 16 * u < nblk ? b0 + 16 * u : nblk - 1;
+        v1[u] = p[(long long)b * 2 * C];
+        v2[u] = p[(long long)b * 2 * C + C];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const bool ok = b0 + 16 * u < nblk;
+        a1 += ok ? (double)v1[u] : 0.0;
+        a2 += ok ? (double)v2[u] : 0.0;
+      }
     }
+  }
   sh[0][ps][cl] = a1;
   sh[1][ps][cl] = a2;
   __syncthreads();
@@ -471,20 +486,27 @@ __global__ __launch_bounds__(256) void k_bn_bwd_coeffs_rows(const float* __restr
   const int cl = threadIdx.x & 7, ps = threadIdx.x >> 3;        // 8 channels x 32 row slices per workgroup
   const int c = blockIdx.x * 8 + cl;
   const long long stride = (long long)n_st * C;
-  for (int v = 0; v < n_st; ++v) {
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    if (c < C) {
-      const float* p = part + (long long)v * C + c;
-      int b = ps;
-      for (; b + 96 < nblk; b += 128) {                          // four independent loads in flight
-        a0 += (double)p[(long long)b * stride];
-        a1 += (double)p[(long long)(b + 32) * stride];
-        a2 += (double)p[(long long)(b + 64) * stride];
-        a3 += (double)p[(long long)(b + 96) * stride];
-      }
-      for (; b < nblk; b += 32) a0 += (double)p[(long long)b * stride];
+  {
+    // the three statistics of eight partial rows (24 loads) in flight per thread, unconditional (clamped row / statistic, masked
+    // value): twelve dependent round trips per launch became two to four
+    const int cc = c < C ? c : C - 1;
+    double acc[3] = {0.0, 0.0, 0.0};
+    for (int b0 = ps; b0 < nblk; b0 += 256) {
+      float x[3][8];
+#pragma unroll
+      for (int v = 0; v < 3; ++v)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int b = b0 + 32 * u < nblk ? b0 + 32 * u : nblk - 1;
+          x[v][u] = part[(long long)b * stride + (long long)(v < n_st ? v : 0) * C + cc];
+        }
+#pragma unroll
+      for (int v = 0; v < 3; ++v)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc[v] += b0 + 32 * u < nblk ? (double)x[v][u] : 0.0;
     }
-    sh[v][ps][cl] = (a0 + a1) + (a2 + a3);
+#pragma unroll
+    for (int v = 0; v < 3; ++v) sh[v][ps][cl] = acc[v];
   }
   __syncthreads();
   if (ps != 0 || c >= C) return;

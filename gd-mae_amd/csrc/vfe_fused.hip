@@ -39,31 +39,67 @@ enum { VF_STATS = 0, VF_APPLY = 1, VF_BSTATS = 2, VF_DW = 3 };
 
 __device__ inline unsigned short vf_f2bf(float f) { return gd_to_bf16(f); }   // round to nearest even
 
-// decorated features of point i (all zero past the end): the arithmetic of k_decorate (segment.hip), kept in registers
+// decorated features of a point (all zero past the end): the arithmetic of k_decorate (segment.hip), kept in registers.
 // `cpp` (coords per pillar): `coords` holds one row per PILLAR (voxel_coords) instead of one per point - the layout of
-// the pillar-major rows (gdmae_pillar_major_rows), where the per-point coordinate table is not needed
+// the pillar-major rows (gdmae_pillar_major_rows), where the per-point coordinate table is not needed.
+// The loads of a point are two dependent round trips (its row and pillar id, then the pillar's cell and mean); a wave walks ~11
+// tiles, so they are requested as two pipeline stages: stage A of tile k + 2 and stage B of tile k + 1 while tile k is multiplied
+// (every request unconditional on a clamped index, nothing looked at before its use - DESIGN section 9, rules 1 - 3).
 template <int F>
-__device__ inline void vf_features(const float* __restrict__ pts, const long long* __restrict__ coords,
-                                   const int* __restrict__ inv, const float* __restrict__ mean, int cpp, long long i,
-                                   long long N, const VfeGeom& G, float (&f)[F + 6]) {
-  // branch-free (clamped index, zeroed afterwards): the loads of a tile are issued back to back
-  const bool live = i < N;
-  if (!live) i = N - 1;
-  const float* r = pts + i * (F + 1);
-  const int pil = inv[i];
-  const long long* c = coords + 4 * (cpp ? (long long)pil : i);   // b, z, y, x
-  const float* m = mean + (long long)pil * F;
-  const float x = r[1], y = r[2], z = r[3];
-  f[0] = __fsub_rn(x, __fadd_rn(__fmul_rn(__fadd_rn((float)c[3], 0.5f), G.vs[0]), G.lo[0]));
-  f[1] = __fsub_rn(y, __fadd_rn(__fmul_rn(__fadd_rn((float)c[2], 0.5f), G.vs[1]), G.lo[1]));
-  f[2] = __fsub_rn(z, __fadd_rn(__fmul_rn(__fadd_rn((float)c[1], 0.5f), G.vs[2]), G.lo[2]));
+struct VfA {
+  float r[F + 1];
+  int pil;
+};
+struct VfB {
+  long long c1, c2, c3;      // z, y, x cell
+  float m[3];
+};
+template <int F>
+__device__ __forceinline__ void vf_load_a(const float* __restrict__ pts, const int* __restrict__ inv, long long i, long long N, VfA<F>& A) {
+  const long long ic = i < N ? i : N - 1;
+  const float* r = pts + ic * (F + 1);
 #pragma unroll
-  for (int k = 0; k < F; ++k) f[3 + k] = r[1 + k];
-  f[3 + F] = __fsub_rn(x, m[0]);
-  f[4 + F] = __fsub_rn(y, m[1]);
-  f[5 + F] = __fsub_rn(z, m[2]);
+  for (int k = 0; k < F + 1; ++k) A.r[k] = r[k];
+  A.pil = inv[ic];
+}
+template <int F>
+__device__ __forceinline__ void vf_load_b(const long long* __restrict__ coords, const float* __restrict__ mean, int cpp, long long i,
+                                          long long N, int pil, VfB& B) {
+  const long long ic = i < N ? i : N - 1;
+  const long long* c = coords + 4 * (cpp ? (long long)pil : ic);   // b, z, y, x
+  const float* m = mean + (long long)pil * F;
+  B.c1 = c[1]; B.c2 = c[2]; B.c3 = c[3];
+  B.m[0] = m[0]; B.m[1] = m[1]; B.m[2] = m[2];
+}
+template <int F>
+__device__ __forceinline__ void vf_features(const VfA<F>& A, const VfB& B, bool live, const VfeGeom& G, float (&f)[F + 6]) {
+  const float x = A.r[1], y = A.r[2], z = A.r[3];
+  f[0] = __fsub_rn(x, __fadd_rn(__fmul_rn(__fadd_rn((float)B.c3, 0.5f), G.vs[0]), G.lo[0]));
+  f[1] = __fsub_rn(y, __fadd_rn(__fmul_rn(__fadd_rn((float)B.c2, 0.5f), G.vs[1]), G.lo[1]));
+  f[2] = __fsub_rn(z, __fadd_rn(__fmul_rn(__fadd_rn((float)B.c1, 0.5f), G.vs[2]), G.lo[2]));
+#pragma unroll
+  for (int k = 0; k < F; ++k) f[3 + k] = A.r[1 + k];
+  f[3 + F] = __fsub_rn(x, B.m[0]);
+  f[4 + F] = __fsub_rn(y, B.m[1]);
+  f[5 + F] = __fsub_rn(z, B.m[2]);
 #pragma unroll
   for (int k = 0; k < F + 6; ++k) f[k] = live ? f[k] : 0.f;
+}
+// gradient rows of a tile (this lane: columns 2 n, 2 n + 1 of its 16 accumulator rows), raw - unpacked where they are used
+template <bool BF>
+struct VfG {
+  unsigned u[BF ? 16 : 1];
+  float2 v[BF ? 1 : 16];
+};
+template <bool BF>
+__device__ __forceinline__ void vf_load_g(const void* __restrict__ g, long long base, long long N, int n, int half, VfG<BF>& Gr) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const long long row = base + 8 * (r / 4) + 4 * half + (r % 4);
+    const long long rc = row < N ? row : N - 1;      // branch-free: 16 loads in flight
+    if (BF) Gr.u[r] = ((const unsigned*)g)[rc * (VF_C / 2) + n];
+    else Gr.v[r] = ((const float2*)g)[rc * (VF_C / 2) + n];
+  }
 }
 
 // MODE STATS : part[(block, 2, 64)] = column sums of h, h^2
@@ -112,28 +148,51 @@ __global__ __launch_bounds__(VF_WAVES * 64) void k_vfe1(const float* __restrict_
   for (int r = 0; r < 16; ++r) accw[0][r] = accw[1][r] = 0.f;
 
   const long long ntiles = (N + 31) / 32;
-  for (long long t0 = (long long)blockIdx.x * VF_WAVES; t0 < ntiles; t0 += (long long)gridDim.x * VF_WAVES) {
+  const long long tstride = (long long)gridDim.x * VF_WAVES;
+  constexpr bool HAS_G = MODE == VF_BSTATS || MODE == VF_DW;
+  // STATS / APPLY: software pipeline over this wave's tiles t, t + tstride, ...: (A1, B1) = the tile being multiplied, A2 = the next
+  // tile's rows, requested an iteration ago; its stage B and the stage A of the tile after it are requested at the top.  Measured
+  // (tools/vfe_times.sh, 8 frames): STATS 41 -> 38 us, APPLY 71 -> 53 us (the wait that used to sit behind its stores); the modes
+  // with gradient rows LOSE with it (BSTATS 57 -> 63, DW 104 -> 109: 37 / 30 more registers = a wave per SIMD less, and their
+  // tiles are bound by the fp32 MFMA + VALU work, not by the round trips) and keep the plain order.
+  constexpr bool PIPE = !HAS_G;
+  VfA<F> A1, A2, A3;
+  VfB B1, B2;
+  VfG<BF> G1;
+  if (PIPE) {
+    const long long t = (long long)blockIdx.x * VF_WAVES + wave;
+    vf_load_a<F>(pts, inv, t * 32 + n, N, A1);
+    vf_load_a<F>(pts, inv, (t + tstride) * 32 + n, N, A2);
+    vf_load_b<F>(coords, mean, cpp, t * 32 + n, N, A1.pil, B1);
+  }
+  for (long long t0 = (long long)blockIdx.x * VF_WAVES; t0 < ntiles; t0 += tstride) {
     const long long base = (t0 + wave) * 32;   // may lie past N: the tile is then all zero rows
-    // gradient rows of the tile first: 16 independent loads in flight while the features / h are computed
+    if (PIPE) {
+      vf_load_a<F>(pts, inv, base + 2 * tstride * 32 + n, N, A3);
+      vf_load_b<F>(coords, mean, cpp, base + tstride * 32 + n, N, A2.pil, B2);       // A2 arrived during the previous tile
+      __builtin_amdgcn_sched_barrier(0);          // the requests go out first
+    } else {
+      // gradient rows of the tile first: 16 independent loads in flight while the features / h are computed
+      vf_load_g<BF>(g, base, N, n, half, G1);
+      vf_load_a<F>(pts, inv, base + n, N, A1);
+      vf_load_b<F>(coords, mean, cpp, base + n, N, A1.pil, B1);
+    }
     float g0[16], g1[16];
-    if (MODE == VF_BSTATS || MODE == VF_DW) {
+    if (HAS_G) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const long long row = base + 8 * (r / 4) + 4 * half + (r % 4);
-        const long long rc = row < N ? row : N - 1;      // branch-free: 16 loads in flight
         if (BF) {
-          const unsigned u = ((const unsigned*)g)[rc * (VF_C / 2) + n];
-          g0[r] = row < N ? __uint_as_float(u << 16) : 0.f;
-          g1[r] = row < N ? __uint_as_float(u & 0xFFFF0000u) : 0.f;
+          g0[r] = row < N ? __uint_as_float(G1.u[r] << 16) : 0.f;
+          g1[r] = row < N ? __uint_as_float(G1.u[r] & 0xFFFF0000u) : 0.f;
         } else {
-          const float2 u = ((const float2*)g)[rc * (VF_C / 2) + n];
-          g0[r] = row < N ? u.x : 0.f;
-          g1[r] = row < N ? u.y : 0.f;
+          g0[r] = row < N ? G1.v[r].x : 0.f;
+          g1[r] = row < N ? G1.v[r].y : 0.f;
         }
       }
     }
     float f[D];
-    vf_features<F>(pts, coords, inv, mean, cpp, base + n, N, G, f);
+    vf_features<F>(A1, B1, base + n < N, G, f);
     f32x16 h[2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) h[0][r] = h[1][r] = 0.f;
@@ -155,6 +214,12 @@ __global__ __launch_bounds__(VF_WAVES * 64) void k_vfe1(const float* __restrict_
           s2[blk] = fmaf(v, v, s2[blk]);
         }
     } else if (MODE == VF_APPLY) {
+      // the prefetched rows are waited for HERE, before this tile's stores go out: loads and stores retire out of order with respect
+      // to each other, so with stores pending the next iteration's first look at a loaded register would drain both (rule 4)
+#pragma unroll
+      for (int k = 0; k < F + 1; ++k) asm volatile("" : "+v"(A3.r[k]));
+      asm volatile("" : "+v"(A3.pil));
+      asm volatile("" : "+v"(B2.c1), "+v"(B2.c2), "+v"(B2.c3), "+v"(B2.m[0]), "+v"(B2.m[1]), "+v"(B2.m[2]));
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const long long row = base + 8 * (r / 4) + 4 * half + (r % 4);
@@ -200,6 +265,11 @@ __global__ __launch_bounds__(VF_WAVES * 64) void k_vfe1(const float* __restrict_
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
       }
+    }
+    if (PIPE) {
+      A1 = A2;
+      A2 = A3;
+      B1 = B2;
     }
   }
 
