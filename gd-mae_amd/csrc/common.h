@@ -344,10 +344,11 @@ struct GdNoTotal {
   __device__ void operator()(T) const {}
 };
 
+// one tile of a look-back scan (the whole workgroup): `nb` tiles take part, every one of them must run this exactly once
 template <typename T, typename LoadF, typename StoreF, typename TotalF>
-__global__ __launch_bounds__(GD_SCAN_BLOCK) void gd_scan_lb_kernel(long long n, LoadF load, StoreF store, TotalF on_total, T* total,
-                                                                  unsigned* ticket, unsigned* flags, unsigned long long* agg,
-                                                                  unsigned long long* incl) {
+__device__ __forceinline__ void gd_scan_lb_tile(long long n, const LoadF& load, const StoreF& store, const TotalF& on_total, T* total,
+                                                unsigned* ticket, unsigned* flags, unsigned long long* agg, unsigned long long* incl,
+                                                const unsigned nb) {
   constexpr int W = GdScanWords<T>::N;
   __shared__ T smem[GD_SCAN_BLOCK / GD_WAVE + 1];
   __shared__ unsigned s_tile;
@@ -355,7 +356,6 @@ __global__ __launch_bounds__(GD_SCAN_BLOCK) void gd_scan_lb_kernel(long long n, 
   if (threadIdx.x == 0) s_tile = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
   const unsigned tile = s_tile;
-  const unsigned nb = gridDim.x;
   const long long base = (long long)tile * GD_SCAN_TILE;
   T vals[GD_SCAN_ITEMS];
   T acc = gd_zero<T>();
@@ -442,15 +442,64 @@ __global__ __launch_bounds__(GD_SCAN_BLOCK) void gd_scan_lb_kernel(long long n, 
 }
 
 template <typename T, typename LoadF, typename StoreF, typename TotalF>
-static inline int gd_device_scan_lb(long long n, LoadF load, StoreF store, TotalF on_total, T* total, void* state, hipStream_t st) {
-  const int nb = gd_div_up(n > 0 ? n : 1, GD_SCAN_TILE);
+__global__ __launch_bounds__(GD_SCAN_BLOCK) void gd_scan_lb_kernel(long long n, LoadF load, StoreF store, TotalF on_total, T* total,
+                                                                  unsigned* ticket, unsigned* flags, unsigned long long* agg,
+                                                                  unsigned long long* incl) {
+  gd_scan_lb_tile<T>(n, load, store, on_total, total, ticket, flags, agg, incl, gridDim.x);
+}
+
+// the cross-workgroup words of a scan inside its (zeroed) state
+struct GdScanState {
+  unsigned* ticket;
+  unsigned* flags;
+  unsigned long long* agg;
+  unsigned long long* incl;
+  int nb;
+};
+template <typename T>
+static inline GdScanState gd_scan_lb_state(long long n, void* state) {
+  GdScanState S;
+  S.nb = gd_div_up(n > 0 ? n : 1, GD_SCAN_TILE);
   char* p = (char*)state;
-  unsigned* ticket = (unsigned*)p;
-  unsigned* flags = (unsigned*)(p + 8);
-  unsigned long long* agg = (unsigned long long*)(p + gd_align(8 + (size_t)nb * 4));
-  unsigned long long* incl = (unsigned long long*)((char*)agg + gd_align((size_t)nb * GdScanWords<T>::N * 8));
-  hipLaunchKernelGGL((gd_scan_lb_kernel<T, LoadF, StoreF, TotalF>), dim3(nb), dim3(GD_SCAN_BLOCK), 0, st, n, load, store, on_total, total,
-                     ticket, flags, agg, incl);
+  S.ticket = (unsigned*)p;
+  S.flags = (unsigned*)(p + 8);
+  S.agg = (unsigned long long*)(p + gd_align(8 + (size_t)S.nb * 4));
+  S.incl = (unsigned long long*)((char*)S.agg + gd_align((size_t)S.nb * GdScanWords<T>::N * 8));
+  return S;
+}
+template <typename T, typename LoadF, typename StoreF, typename TotalF>
+static inline int gd_device_scan_lb(long long n, LoadF load, StoreF store, TotalF on_total, T* total, void* state, hipStream_t st) {
+  const GdScanState S = gd_scan_lb_state<T>(n, state);
+  hipLaunchKernelGGL((gd_scan_lb_kernel<T, LoadF, StoreF, TotalF>), dim3(S.nb), dim3(GD_SCAN_BLOCK), 0, st, n, load, store, on_total, total,
+                     S.ticket, S.flags, S.agg, S.incl);
+  GD_LAUNCH_CHECK();
+  return 0;
+}
+
+// Several independent scans of the same functor types as ONE launch (blockIdx.y = scan): the geometry plan is a chain of short
+// dependent launches on its own stream, and a one- to eight-tile scan costs its launch, not its bytes (the six window scans of the
+// three stages: 79 us as six launches).
+template <typename T, typename LoadF, typename StoreF, typename TotalF, int NJ>
+struct GdScanBatch {
+  long long n[NJ];
+  LoadF load[NJ];
+  StoreF store[NJ];
+  TotalF on_total[NJ];
+  GdScanState S[NJ];
+};
+template <typename T, typename LoadF, typename StoreF, typename TotalF, int NJ>
+__global__ __launch_bounds__(GD_SCAN_BLOCK) void gd_scan_lb_batch_kernel(GdScanBatch<T, LoadF, StoreF, TotalF, NJ> Bt) {
+  const int j = blockIdx.y;
+  if ((int)blockIdx.x >= Bt.S[j].nb) return;          // (before the ticket: exactly nb tiles of a scan run)
+  gd_scan_lb_tile<T>(Bt.n[j], Bt.load[j], Bt.store[j], Bt.on_total[j], (T*)nullptr, Bt.S[j].ticket, Bt.S[j].flags, Bt.S[j].agg, Bt.S[j].incl,
+                     (unsigned)Bt.S[j].nb);
+}
+template <typename T, typename LoadF, typename StoreF, typename TotalF, int NJ>
+static inline int gd_device_scan_lb_batch(const GdScanBatch<T, LoadF, StoreF, TotalF, NJ>& Bt, int count, hipStream_t st) {
+  if (count <= 0) return 0;
+  int nb = 1;
+  for (int j = 0; j < count; ++j) nb = Bt.S[j].nb > nb ? Bt.S[j].nb : nb;
+  hipLaunchKernelGGL((gd_scan_lb_batch_kernel<T, LoadF, StoreF, TotalF, NJ>), dim3(nb, count), dim3(GD_SCAN_BLOCK), 0, st, Bt);
   GD_LAUNCH_CHECK();
   return 0;
 }

@@ -433,7 +433,7 @@ struct PlanJob {
   int* nbr_rev;
 };
 struct PlanJobs {
-  PlanJob j[4];
+  PlanJob j[12];
   int count;
 };
 __global__ __launch_bounds__(256) void k_plan_jobs(PlanJobs J) {
@@ -485,20 +485,26 @@ int gd_plan_jobs(const PlanJobs& J, long long cap_max, hipStream_t st) {
   return 0;
 }
 
-// both shifts of a stage's window partition: one count launch, one scan per shift (totals written by the scan's last tile),
-// one fill launch
-struct WinPair {
-  WinParams P[2];
-  int* win_cnt[2];
-  int* win_dense[2];
-  int* win_tokpre[2];
-  int* counts[2];
-  int *tok_win[2], *tok_level[2], *tok_slot[2], *tok_pos[2], *csr_tok[2], *win_start[2], *win_len[2];
+// the window partitions of ALL stages of a plan (both shifts each = up to GD_WIN_JOBS jobs, blockIdx.y = job): one count launch, one
+// scan launch (totals written by each scan's last tile), one fill launch - the partition of a stage only needs that stage's cell map
+constexpr int GD_WIN_JOBS = 8;
+struct WinSet {
+  WinParams P[GD_WIN_JOBS];
+  const int* map[GD_WIN_JOBS];
+  int n_win[GD_WIN_JOBS];
+  int* win_cnt[GD_WIN_JOBS];
+  int* win_dense[GD_WIN_JOBS];
+  int* win_tokpre[GD_WIN_JOBS];
+  int* counts[GD_WIN_JOBS];
+  int *tok_win[GD_WIN_JOBS], *tok_level[GD_WIN_JOBS], *tok_slot[GD_WIN_JOBS], *tok_pos[GD_WIN_JOBS], *csr_tok[GD_WIN_JOBS],
+      *win_start[GD_WIN_JOBS], *win_len[GD_WIN_JOBS];
 };
-__global__ __launch_bounds__(256) void k_win_count2(WinPair Q, const int* __restrict__ map, int n_win) {
+__global__ __launch_bounds__(256) void k_win_count2(WinSet Q) {
   const int lane = threadIdx.x & (GD_WAVE - 1);
   const int wib = threadIdx.x / GD_WAVE;
   const int sh = blockIdx.y;
+  const int n_win = Q.n_win[sh];
+  const int* __restrict__ map = Q.map[sh];
   for (int w = blockIdx.x * 4 + wib; w < n_win; w += gridDim.x * 4) {
     int ref;
     const int t = win_token(Q.P[sh], map, w, lane, ref);
@@ -522,10 +528,12 @@ struct WinTotal {
     counts[7] = nt;
   }
 };
-__global__ __launch_bounds__(256) void k_win_fill2(WinPair Q, const int* __restrict__ map, int n_win) {
+__global__ __launch_bounds__(256) void k_win_fill2(WinSet Q) {
   const int lane = threadIdx.x & (GD_WAVE - 1);
   const int wib = threadIdx.x / GD_WAVE;
   const int sh = blockIdx.y;
+  const int n_win = Q.n_win[sh];
+  const int* __restrict__ map = Q.map[sh];
   const WinParams& P = Q.P[sh];
   const int* counts = Q.counts[sh];
   for (int w = blockIdx.x * 4 + wib; w < n_win; w += gridDim.x * 4) {
@@ -562,47 +570,74 @@ size_t gd_plan_windows_ws_bytes(int B, int Y, int X, int wx, int wy) {
   return 2 * 3 * gd_align(sizeof(int) * n);
 }
 long long gd_plan_n_windows(int B, int Y, int X, int wx, int wy) { return (long long)B * ((X + wx - 1) / wx + 1) * ((Y + wy - 1) / wy + 1); }
-// out[sh][7]: tok_win, tok_level, tok_slot, tok_pos, csr_tok, win_start, win_len; counts[sh]: int[8]; lb_state: two ZEROED
-// gd_plan_win_state_bytes(n_win) states
-int gd_plan_windows(const int* map, int B, int Y, int X, int wx, int wy, int nlev, const int* drop_lo, const int* drop_hi,
-                    const int* max_tokens, int* const out[2][7], int* const counts[2], void* workspace, void* lb_state, hipStream_t st) {
-  GD_REQUIRE(wx * wy <= GD_WAVE && wx > 0 && wy > 0, "window must fit one wavefront (wx*wy <= 64)");
-  GD_REQUIRE(nlev >= 1 && nlev <= 3, "1..3 drop levels");
-  WinPair Q;
-  const long long n_win = gd_plan_n_windows(B, Y, X, wx, wy);
-  GD_REQUIRE(n_win < (1 << 21), "window grid too large for the packed scan");
-  GdArena A(workspace, gd_plan_windows_ws_bytes(B, Y, X, wx, wy));
-  for (int sh = 0; sh < 2; ++sh) {
-    WinParams& P = Q.P[sh];
-    P.B = B; P.Y = Y; P.X = X; P.wx = wx; P.wy = wy;
-    P.sx = sh ? wx / 2 : wx;   // sst_utils.py:19-22: the un-shifted pass adds a full window
-    P.sy = sh ? wy / 2 : wy;
-    P.nwx = (X + wx - 1) / wx + 1;
-    P.nwy = (Y + wy - 1) / wy + 1;
-    P.nwz = 2;
-    P.nlev = nlev;
-    for (int l = 0; l < 3; ++l) {
-      P.lo[l] = l < nlev ? drop_lo[l] : 0;
-      P.hi[l] = l < nlev ? drop_hi[l] : 0;
-      P.T[l] = l < nlev ? max_tokens[l] : 0;
+// per stage: out[sh][7]: tok_win, tok_level, tok_slot, tok_pos, csr_tok, win_start, win_len; counts[sh]: int[8]; lb_state: two ZEROED
+// gd_plan_win_state_bytes(n_win) states; workspace: gd_plan_windows_ws_bytes
+struct GdWinStage {
+  const int* map;
+  int B, Y, X, wx, wy, nlev;
+  const int *drop_lo, *drop_hi, *max_tokens;
+  int* out[2][7];
+  int* counts[2];
+  void* workspace;
+  void* lb_state;
+};
+int gd_plan_windows_all(const GdWinStage* stages, int n_stages, hipStream_t st) {
+  GD_REQUIRE(n_stages >= 1 && 2 * n_stages <= GD_WIN_JOBS, "window partitions: at most four stages per launch");
+  WinSet Q;
+  GdScanBatch<U128, WinLoad, WinStore, WinTotal, GD_WIN_JOBS> Sc;
+  long long n_max = 1;
+  for (int i = 0; i < n_stages; ++i) {
+    const GdWinStage& g = stages[i];
+    GD_REQUIRE(g.wx * g.wy <= GD_WAVE && g.wx > 0 && g.wy > 0, "window must fit one wavefront (wx*wy <= 64)");
+    GD_REQUIRE(g.nlev >= 1 && g.nlev <= 3, "1..3 drop levels");
+    const long long n_win = gd_plan_n_windows(g.B, g.Y, g.X, g.wx, g.wy);
+    GD_REQUIRE(n_win < (1 << 21), "window grid too large for the packed scan");
+    n_max = n_win > n_max ? n_win : n_max;
+    GdArena A(g.workspace, gd_plan_windows_ws_bytes(g.B, g.Y, g.X, g.wx, g.wy));
+    for (int sh = 0; sh < 2; ++sh) {
+      const int j = 2 * i + sh;
+      WinParams& P = Q.P[j];
+      P.B = g.B; P.Y = g.Y; P.X = g.X; P.wx = g.wx; P.wy = g.wy;
+      P.sx = sh ? g.wx / 2 : g.wx;   // sst_utils.py:19-22: the un-shifted pass adds a full window
+      P.sy = sh ? g.wy / 2 : g.wy;
+      P.nwx = (g.X + g.wx - 1) / g.wx + 1;
+      P.nwy = (g.Y + g.wy - 1) / g.wy + 1;
+      P.nwz = 2;
+      P.nlev = g.nlev;
+      for (int l = 0; l < 3; ++l) {
+        P.lo[l] = l < g.nlev ? g.drop_lo[l] : 0;
+        P.hi[l] = l < g.nlev ? g.drop_hi[l] : 0;
+        P.T[l] = l < g.nlev ? g.max_tokens[l] : 0;
+      }
+      Q.map[j] = g.map;
+      Q.n_win[j] = (int)n_win;
+      Q.win_cnt[j] = A.take<int>(n_win);
+      Q.win_dense[j] = A.take<int>(n_win);
+      Q.win_tokpre[j] = A.take<int>(n_win);
+      Q.counts[j] = g.counts[sh];
+      Q.tok_win[j] = g.out[sh][0]; Q.tok_level[j] = g.out[sh][1]; Q.tok_slot[j] = g.out[sh][2]; Q.tok_pos[j] = g.out[sh][3];
+      Q.csr_tok[j] = g.out[sh][4]; Q.win_start[j] = g.out[sh][5]; Q.win_len[j] = g.out[sh][6];
+      Sc.n[j] = n_win;
+      Sc.load[j] = WinLoad{P, Q.win_cnt[j]};
+      Sc.store[j] = WinStore{Q.win_dense[j], Q.win_tokpre[j]};
+      Sc.on_total[j] = WinTotal{g.counts[sh]};
+      Sc.S[j] = gd_scan_lb_state<U128>(n_win, (char*)g.lb_state + sh * gd_plan_win_state_bytes(n_win));
     }
-    Q.win_cnt[sh] = A.take<int>(n_win);
-    Q.win_dense[sh] = A.take<int>(n_win);
-    Q.win_tokpre[sh] = A.take<int>(n_win);
-    Q.counts[sh] = counts[sh];
-    Q.tok_win[sh] = out[sh][0]; Q.tok_level[sh] = out[sh][1]; Q.tok_slot[sh] = out[sh][2]; Q.tok_pos[sh] = out[sh][3];
-    Q.csr_tok[sh] = out[sh][4]; Q.win_start[sh] = out[sh][5]; Q.win_len[sh] = out[sh][6];
   }
-  int grid = gd_div_up(n_win, 4);
+  for (int j = 2 * n_stages; j < GD_WIN_JOBS; ++j) {       // unused slots: copies of job 0 (never launched)
+    Q.P[j] = Q.P[0]; Q.map[j] = Q.map[0]; Q.n_win[j] = 0;
+    Q.win_cnt[j] = Q.win_cnt[0]; Q.win_dense[j] = Q.win_dense[0]; Q.win_tokpre[j] = Q.win_tokpre[0]; Q.counts[j] = Q.counts[0];
+    Q.tok_win[j] = Q.tok_win[0]; Q.tok_level[j] = Q.tok_level[0]; Q.tok_slot[j] = Q.tok_slot[0]; Q.tok_pos[j] = Q.tok_pos[0];
+    Q.csr_tok[j] = Q.csr_tok[0]; Q.win_start[j] = Q.win_start[0]; Q.win_len[j] = Q.win_len[0];
+    Sc.n[j] = 0; Sc.load[j] = Sc.load[0]; Sc.store[j] = Sc.store[0]; Sc.on_total[j] = Sc.on_total[0]; Sc.S[j] = Sc.S[0];
+  }
+  int grid = gd_div_up(n_max, 4);
   if (grid > 4096) grid = 4096;
-  hipLaunchKernelGGL(k_win_count2, dim3(grid, 2), dim3(256), 0, st, Q, map, (int)n_win);
+  hipLaunchKernelGGL(k_win_count2, dim3(grid, 2 * n_stages), dim3(256), 0, st, Q);
   GD_LAUNCH_CHECK();
-  for (int sh = 0; sh < 2; ++sh) {
-    int rc = gd_device_scan_lb<U128>(n_win, WinLoad{Q.P[sh], Q.win_cnt[sh]}, WinStore{Q.win_dense[sh], Q.win_tokpre[sh]},
-                                     WinTotal{counts[sh]}, (U128*)nullptr, (char*)lb_state + sh * gd_plan_win_state_bytes(n_win), st);
-    if (rc) return rc;
-  }
-  hipLaunchKernelGGL(k_win_fill2, dim3(grid, 2), dim3(256), 0, st, Q, map, (int)n_win);
+  int rc = gd_device_scan_lb_batch(Sc, 2 * n_stages, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_win_fill2, dim3(grid, 2 * n_stages), dim3(256), 0, st, Q);
   GD_LAUNCH_CHECK();
   return 0;
 }

@@ -42,14 +42,22 @@ struct PlanJob {
   int* nbr_rev;
 };
 struct PlanJobs {
-  PlanJob j[4];
+  PlanJob j[12];
   int count;
 };
 int gd_plan_jobs(const PlanJobs& J, long long cap_max, hipStream_t st);
 size_t gd_plan_windows_ws_bytes(int B, int Y, int X, int wx, int wy);
 long long gd_plan_n_windows(int B, int Y, int X, int wx, int wy);
-int gd_plan_windows(const int* map, int B, int Y, int X, int wx, int wy, int nlev, const int* drop_lo, const int* drop_hi,
-                    const int* max_tokens, int* const out[2][7], int* const counts[2], void* workspace, void* lb_state, hipStream_t st);
+struct GdWinStage {
+  const int* map;
+  int B, Y, X, wx, wy, nlev;
+  const int *drop_lo, *drop_hi, *max_tokens;
+  int* out[2][7];
+  int* counts[2];
+  void* workspace;
+  void* lb_state;
+};
+int gd_plan_windows_all(const GdWinStage* stages, int n_stages, hipStream_t st);
 size_t gd_decoder_tiles_lb_state_bytes(long long nt);
 int gd_decoder_tiles_lb(const int* const* maps, const int* strides, int k, int B, int H, int W, int* tile_slot, int* tile_list, int* n_act,
                         int* flag, void* lb_state, hipStream_t st);
@@ -291,12 +299,19 @@ extern "C" int gdmae_geometry_plan(const gdmae_plan_params* p, const float* poin
     if (rc) return rc;
     lb += gd_plan_scan_state_bytes(O.cells);
   }
+  // ---- the stages.  The token sets are a chain (a strided stage's set = a scan over its output cells of the previous map); every
+  //      other table of a stage only needs the maps, so after the chain ALL index tables of ALL stages are one launch and the two
+  //      window partitions of ALL stages three (count, scans, fill) - the plan is a serial chain of short launches on its own
+  //      stream whose time the step pays almost in full
   int Yp = gy, Xp = gx;                          // grid of the current set
+  PlanJobs J;
+  J.count = 0;
+  long long cap_max = 1;
+  GdWinStage W[4];
+  GD_REQUIRE(ns <= 4, "geometry plan: at most four stages");
   for (int i = 0; i < ns; ++i) {
     const StageGeo& g = O.geo[i];
-    PlanJobs J;
-    J.count = 0;
-    long long cap_max = g.cap;
+    if (g.cap > cap_max) cap_max = g.cap;
     if (p->stride[i] == 2) {
       int rc = gd_plan_downsample(cur_map, B, Yp, Xp, I(O.s[i].tok_cell), I(O.s[i].map), n_tok + i, lb, st);
       if (rc) return rc;
@@ -316,20 +331,23 @@ extern "C" int gdmae_geometry_plan(const gdmae_plan_params* p, const float* poin
       J.j[J.count++] = PlanJob{cur_n, cur_cell, Dims{B, g.Y, g.X}, Dims{B, g.Y, g.X}, nullptr, 3, g.up_s, I(O.s[i].up_sites), nullptr};
       if (g.cap * g.up_s * g.up_s / 9 + 1 > cap_max) cap_max = g.cap * g.up_s * g.up_s / 9 + 1;
     }
-    {
-      int rc = gd_plan_jobs(J, cap_max, st);
-      if (rc) return rc;
-    }
-    int* out[2][7];
-    int* wc[2] = {win_counts + 16 * i, win_counts + 16 * i + 8};
+    GdWinStage& w = W[i];
+    w.map = cur_map;
+    w.B = B; w.Y = g.Y; w.X = g.X; w.wx = p->win_x[i]; w.wy = p->win_y[i]; w.nlev = p->n_levels[i];
+    w.drop_lo = p->drop_lo[i]; w.drop_hi = p->drop_hi[i]; w.max_tokens = p->max_tokens[i];
+    w.counts[0] = win_counts + 16 * i;
+    w.counts[1] = win_counts + 16 * i + 8;
     for (int sh = 0; sh < 2; ++sh)
-      for (int k = 0; k < 7; ++k) out[sh][k] = I(O.s[i].w[sh][k]);
-    {
-      int rc = gd_plan_windows(cur_map, B, g.Y, g.X, p->win_x[i], p->win_y[i], p->n_levels[i], p->drop_lo[i], p->drop_hi[i],
-                               p->max_tokens[i], out, wc, A + O.s[i].win_ws, lb, st);
-      if (rc) return rc;
-      lb += 2 * gd_plan_win_state_bytes(g.n_win);
-    }
+      for (int k = 0; k < 7; ++k) w.out[sh][k] = I(O.s[i].w[sh][k]);
+    w.workspace = A + O.s[i].win_ws;
+    w.lb_state = lb;
+    lb += 2 * gd_plan_win_state_bytes(g.n_win);
+  }
+  {
+    int rc = gd_plan_jobs(J, cap_max, st);
+    if (rc) return rc;
+    rc = gd_plan_windows_all(W, ns, st);
+    if (rc) return rc;
   }
   // ---- active tiles of the decoder's 3x3 convolution
   if (O.dec) {

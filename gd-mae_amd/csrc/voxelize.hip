@@ -109,7 +109,8 @@ struct CellStore {
   __device__ void operator()(long long c, unsigned long long ex, unsigned long long v) const {
     const int p = (int)(ex >> 32);
     const int cnt = (int)(unsigned)v;
-    if (cnt > GD_WAVE) {   // pillars with more than one wavefront of points: ranked by (pillar, 64-point chunk) work items
+    if (big && cnt > GD_WAVE) {   // pillars with more than one wavefront of points: ranked by (pillar, 64-point chunk) work items (null: the
+                                  // caller ranks one thread per point and needs no list - two same-address atomics per crowded pillar saved)
       const int nch = (cnt + GD_WAVE - 1) / GD_WAVE;
       const int base = atomicAdd(&big[0], nch);
       for (int k = 0; k < nch; ++k) {
@@ -404,6 +405,17 @@ struct CellTotal {
   }
 };
 
+__global__ __launch_bounds__(GD_SCAN_BLOCK) void k_vox_scans(long long n_points, KeepLoad kl, KeepStore ks, KeepTotal kt, GdScanState S0,
+                                                             long long cells, CellLoad cl, CellStore cs, CellTotal ct, GdScanState S1) {
+  if (blockIdx.y == 0) {
+    if ((int)blockIdx.x >= S0.nb) return;
+    gd_scan_lb_tile<int>(n_points, kl, ks, kt, (int*)nullptr, S0.ticket, S0.flags, S0.agg, S0.incl, (unsigned)S0.nb);
+  } else {
+    if ((int)blockIdx.x >= S1.nb) return;
+    gd_scan_lb_tile<unsigned long long>(cells, cl, cs, ct, (unsigned long long*)nullptr, S1.ticket, S1.flags, S1.agg, S1.incl, (unsigned)S1.nb);
+  }
+}
+
 // Body of gdmae_voxelize.  lb_state == null: the classic schedule (three-launch scans, finalize launch, no pillar-major rows).
 // lb_state != null (geometry plan, plan.hip): 2 * gd_scan_lb_state_bytes-sized ZEROED scan states -> single-launch scans with the
 // finalize folded in; points_pm / row_pillar (optional) are written by the ranking kernels instead of a pass of their own.
@@ -457,15 +469,15 @@ int gd_voxelize_impl(const float* points, long long n_points, int n_cols, const 
     hipLaunchKernelGGL(k_point_keys, dim3(grid_pts), dim3(256), 0, st, points, n_points, P, key, slot, cell_cnt);
     GD_LAUNCH_CHECK();
   }
-  CellStore cs{P, cell2pillar, pillar_pt_off, pillar_cell, voxel_coords, sample_pillar_off, big, big_cap};
+  CellStore cs{P, cell2pillar, pillar_pt_off, pillar_cell, voxel_coords, sample_pillar_off, (lb_state && points_pm) ? nullptr : big, big_cap};
   if (lb_state) {
+    // the kept-point scan and the cell scan only need k_point_keys: one launch (blockIdx.y picks the scan)
     char* s0 = (char*)lb_state;
     char* s1 = s0 + gd_scan_lb_state_bytes<int>(n_points);
-    int rc = gd_device_scan_lb<int>(n_points, KeepLoad{key}, KeepStore{pos}, KeepTotal{counts}, (int*)nullptr, s0, st);
-    if (rc) return rc;
-    rc = gd_device_scan_lb<unsigned long long>(cells, CellLoad{cell_cnt}, cs, CellTotal{batch_size, pillar_pt_off, sample_pillar_off, counts},
-                                               (unsigned long long*)nullptr, s1, st);
-    if (rc) return rc;
+    const GdScanState S0 = gd_scan_lb_state<int>(n_points, s0), S1 = gd_scan_lb_state<unsigned long long>(cells, s1);
+    hipLaunchKernelGGL(k_vox_scans, dim3(S0.nb > S1.nb ? S0.nb : S1.nb, 2), dim3(GD_SCAN_BLOCK), 0, st, n_points, KeepLoad{key}, KeepStore{pos},
+                       KeepTotal{counts}, S0, cells, CellLoad{cell_cnt}, cs, CellTotal{batch_size, pillar_pt_off, sample_pillar_off, counts}, S1);
+    GD_LAUNCH_CHECK();
   } else {
     int rc = gd_device_scan<int>(n_points, KeepLoad{key}, KeepStore{pos}, n_keep, (int*)scan_ws, st);
     if (rc) return rc;
