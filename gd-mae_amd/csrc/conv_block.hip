@@ -13,7 +13,12 @@
 
 // spconv.hip: implicit-GEMM sparse convolution over the rulebook (bf16, 128 / 256 channels)
 bool gd_spconv_supported(int cin, int cout);
-int gd_spconv(hipStream_t st, const void* X, int x_f32, const int* nbr, const void* Wp, long long n, int cin, int cout, void* Y, int slot);
+int gd_spconv(hipStream_t st, const void* X, int x_f32, const int* nbr, const void* Wp, long long n, int cin, int cout, void* Y, int slot,
+              float* part);
+int gd_spconv_rows(int cin, int cout, int x_f32);
+int gd_bn_fold_from_partials(hipStream_t st, const float* part, int nblk, int C, double count, const float* gamma,
+                             const float* beta, double eps, double momentum, float* running_mean, float* running_var,
+                             long long* num_batches, double* stats, float* ab, float* mv);
 
 namespace {
 
@@ -145,9 +150,20 @@ extern "C" int gdmae_conv_block_fwd(const gdmae_conv_block_args* a, void* stream
   const bool implicit = use_implicit(a);
   Scratch s = layout(a->scratch, a->n_in, a->n_out, a->cin, a->cout, es, implicit);
   const long long slots = a->n_out * 9;
+  bool stats_fused = false;
   if (implicit) {
     // the gathered rows go straight into the MFMA operand tile: no im2col matrix, no library GEMM
-    CB_TRY(gd_spconv(st, a->x, a->x_f32, a->nbr, a->packed_fwd, a->n_out, a->cin, a->cout, a->y, GD_T_SPCONV_FWD));
+    // ... and the BatchNorm statistics are its epilogue (per-workgroup column sums of the rounded rows) where the partial rows fit
+    // the statistics workspace: no pass over y
+    const int rpw = gd_spconv_rows(a->cin, a->cout, a->x_f32);
+    const long long nblk = rpw > 0 ? (a->n_out + rpw - 1) / rpw : 0;
+    static const bool fuse_ok = !(getenv("GDMAE_SPCONV_STATS") && atoi(getenv("GDMAE_SPCONV_STATS")) == 0);      // A/B switch
+    stats_fused = fuse_ok && nblk >= 1 && nblk <= 1024;
+    CB_TRY(gd_spconv(st, a->x, a->x_f32, a->nbr, a->packed_fwd, a->n_out, a->cin, a->cout, a->y, GD_T_SPCONV_FWD,
+                     stats_fused ? (float*)s.cs_ws : nullptr));
+    if (stats_fused)
+      CB_TRY(gd_bn_fold_from_partials(st, (const float*)s.cs_ws, (int)nblk, a->cout, (double)a->n_out, a->gamma, a->beta, a->eps, a->momentum,
+                                      a->running_mean, a->running_var, a->num_batches, a->stats, a->ab, a->mv));
   } else if (a->bf16 && a->x_f32) {
     long long g = (slots * (a->cin / 8) + 255) / 256;
     if (g > 16384) g = 16384;
@@ -159,8 +175,9 @@ extern "C" int gdmae_conv_block_fwd(const gdmae_conv_block_args* a, void* stream
   }
   if (!implicit)
     CB_TRY(gdmae_gemm(a->cols, a->W, a->y, a->n_out, a->cout, 9ll * a->cin, 0, 1, a->bf16, 0, nullptr, s.gemm_ws, stream));
-  CB_TRY(gdmae_bn_fold(a->y, a->n_out, a->cout, a->bf16, (double)a->n_out, a->gamma, a->beta, a->eps, a->momentum, a->running_mean,
-                       a->running_var, a->num_batches, a->stats, a->ab, a->mv, s.cs_ws, stream));
+  if (!stats_fused)
+    CB_TRY(gdmae_bn_fold(a->y, a->n_out, a->cout, a->bf16, (double)a->n_out, a->gamma, a->beta, a->eps, a->momentum, a->running_mean,
+                         a->running_var, a->num_batches, a->stats, a->ab, a->mv, s.cs_ws, stream));
   CB_TRY(gdmae_rows_affine_relu_scatter(a->y, a->bf16, nullptr, a->n_out, a->cout, a->ab, a->ab + a->cout, a->out,
                                         a->out_f32 ? 0 : a->bf16, a->cout, 0, stream));
   return 0;
@@ -201,7 +218,7 @@ extern "C" int gdmae_conv_block_bwd(const gdmae_conv_block_args* a, void* stream
                        a->dW);
     GD_LAUNCH_CHECK();
     // ---- input gradient: the same implicit GEMM over the transposed rulebook with the per-tap transposed weights
-    if (a->dx) CB_TRY(gd_spconv(st, s.dy, 0, a->nbr_t, a->packed_bwd, a->n_in, C, a->cin, a->dx, GD_T_SPCONV_BWD));
+    if (a->dx) CB_TRY(gd_spconv(st, s.dy, 0, a->nbr_t, a->packed_bwd, a->n_in, C, a->cin, a->dx, GD_T_SPCONV_BWD, nullptr));
     return 0;
   }
   // ---- weight gradient: dW (cout, 9 cin) += dy^T cols

@@ -39,6 +39,8 @@ struct SpArgs {
   const uint4* Wp;        // 9 packed (COUT, CIN) images
   unsigned short* Y;      // (n, COUT) bf16
   long long n;
+  float* part;            // optional (gridDim.x, 2, COUT): per-workgroup column sums of Y and Y^2 (the bf16-rounded values) - the
+                          // BatchNorm statistics of a conv block as this launch's epilogue instead of a pass over Y
 };
 
 constexpr int kWaves = 8;
@@ -217,11 +219,45 @@ __global__ __launch_bounds__(512, 2) void k_spconv(SpArgs A) {
     constexpr int OCPR = COUT / 8;
     constexpr int ORPP = 512 / OCPR;
     const int c = tid % OCPR, r = tid / OCPR;
+    float s1[8], s2[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s1[k] = s2[k] = 0.f;
+    const bool stats = A.part != nullptr;          // uniform
 #pragma unroll
     for (int p = 0; p < (ROWS + ORPP - 1) / ORPP; ++p) {
       const int rl = p * ORPP + r;
-      if (rl < ROWS && row0 + rl < A.n)
-        *reinterpret_cast<uint4*>(A.Y + (row0 + rl) * COUT + c * 8) = *reinterpret_cast<const uint4*>(lds + rl * SP + c * 16);
+      if (rl < ROWS && row0 + rl < A.n) {
+        const uint4 q = *reinterpret_cast<const uint4*>(lds + rl * SP + c * 16);
+        *reinterpret_cast<uint4*>(A.Y + (row0 + rl) * COUT + c * 8) = q;
+        if (stats) {
+          const unsigned w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float lo = __uint_as_float(w[k] << 16), hi = __uint_as_float(w[k] & 0xFFFF0000u);
+            s1[2 * k] += lo; s2[2 * k] = fmaf(lo, lo, s2[2 * k]);
+            s1[2 * k + 1] += hi; s2[2 * k + 1] = fmaf(hi, hi, s2[2 * k + 1]);
+          }
+        }
+      }
+    }
+    if (stats) {
+      // the ORPP row groups of a channel chunk meet in LDS (fixed order: the partial row is bit-repeatable); ORPP x 2 x COUT floats fit
+      // the tiles they replace
+      static_assert(ORPP * 2 * COUT * 4 <= 2 * ROWS * XP || ORPP * 2 * COUT * 4 <= ROWS * SP, "statistics scratch fits the tiles");
+      __syncthreads();                             // every thread is done with the staging tile
+      float* red = reinterpret_cast<float*>(lds);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        red[(r * 2 + 0) * COUT + c * 8 + k] = s1[k];
+        red[(r * 2 + 1) * COUT + c * 8 + k] = s2[k];
+      }
+      __syncthreads();
+      for (int e = tid; e < 2 * COUT; e += 512) {
+        float a = 0.f;
+#pragma unroll
+        for (int g = 0; g < ORPP; ++g) a += red[g * 2 * COUT + e];
+        A.part[(long long)blockIdx.x * 2 * COUT + e] = a;
+      }
     }
   }
 }
@@ -247,10 +283,23 @@ bool gd_spconv_supported(int cin, int cout) { return (cin == 128 || cin == 256) 
 size_t gd_spconv_packed_bytes(int cin, int cout) { return (size_t)9 * cin * cout * 2; }
 
 // Y (n, cout) bf16 = sum_tap Wp_tap X[nbr[:, tap]]; X bf16 or fp32 (x_f32) rows; Wp = 9 packed (cout, cin) images
-int gd_spconv(hipStream_t st, const void* X, int x_f32, const int* nbr, const void* Wp, long long n, int cin, int cout, void* Y, int slot) {
+// rows per workgroup of a launch = rows per statistics partial
+int gd_spconv_rows(int cin, int cout, int x_f32) {
+#define SP_CASE(ci, co) \
+  if (cin == ci && cout == co) return x_f32 ? SpRows<ci, co, true>::value : SpRows<ci, co, false>::value;
+  SP_CASE(128, 128);
+  SP_CASE(128, 256);
+  SP_CASE(256, 128);
+  SP_CASE(256, 256);
+#undef SP_CASE
+  return 0;
+}
+// part (optional): (ceil(n / gd_spconv_rows), 2, cout) fp32 partial rows of the column sums of Y, Y^2
+int gd_spconv(hipStream_t st, const void* X, int x_f32, const int* nbr, const void* Wp, long long n, int cin, int cout, void* Y, int slot,
+              float* part) {
   if (n <= 0) return 0;
   GD_REQUIRE(gd_spconv_supported(cin, cout), "spconv: channels must be 128 or 256");
-  SpArgs A{X, nbr, (const uint4*)Wp, (unsigned short*)Y, n};
+  SpArgs A{X, nbr, (const uint4*)Wp, (unsigned short*)Y, n, part};
   // gathered rows (L2) + the output rows + the weight image, per launch
   GdTimed timed(slot, st, (double)n * (9.0 * cin * (x_f32 ? 4 : 2) + 2.0 * cout + 36.0) + 18.0 * cin * cout, 2.0 * n * 9.0 * cin * cout);
 #define SP_CASE(ci, co)                                                    \
@@ -284,7 +333,13 @@ extern "C" int gdmae_spconv_pack_jobs(const float* W, int cin, int cout, int tra
 
 extern "C" int gdmae_spconv(const void* X, int x_f32, const int* nbr, const void* packed, long long n, int cin, int cout, void* Y,
                             int timing_slot, void* stream) {
-  return gd_spconv((hipStream_t)stream, X, x_f32, nbr, packed, n, cin, cout, Y, timing_slot > 0 ? timing_slot : GD_T_SPCONV_FWD);
+  return gd_spconv((hipStream_t)stream, X, x_f32, nbr, packed, n, cin, cout, Y, timing_slot > 0 ? timing_slot : GD_T_SPCONV_FWD, nullptr);
+}
+extern "C" int gdmae_spconv_stat_rows(int cin, int cout, int x_f32) { return gd_spconv_rows(cin, cout, x_f32); }
+extern "C" int gdmae_spconv_stats(const void* X, int x_f32, const int* nbr, const void* packed, long long n, int cin, int cout, void* Y,
+                                  float* part, void* stream) {
+  GD_REQUIRE(part != nullptr, "spconv_stats: partial rows");
+  return gd_spconv((hipStream_t)stream, X, x_f32, nbr, packed, n, cin, cout, Y, GD_T_SPCONV_FWD, part);
 }
 
 

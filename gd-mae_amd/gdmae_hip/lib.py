@@ -121,6 +121,8 @@ SIGNATURES = {
     "gdmae_spconv_packed_bytes": (_Z, [_I, _I]),
     "gdmae_spconv_pack_jobs": (_I, [_P, _I, _I, _I, _P, _P]),
     "gdmae_spconv": (_I, [_P, _I, _P, _P, _L, _I, _I, _P, _I, _P]),
+    "gdmae_spconv_stat_rows": (_I, [_I, _I, _I]),
+    "gdmae_spconv_stats": (_I, [_P, _I, _P, _P, _L, _I, _I, _P, _P, _P]),
     "gdmae_decoder_dy": (_I, [_P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _P, _P]),
     "gdmae_decoder_site_rulebook": (_I, [_P, _P, _I, _L, _P, _I, _I, _P, _P]),
     "gdmae_tap_dw_rows": (_L, [_L, _I, _I]),

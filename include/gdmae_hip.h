@@ -467,6 +467,12 @@ size_t gdmae_spconv_packed_bytes(int cin, int cout);
 int gdmae_spconv_pack_jobs(const float* W /* (cout, 3, 3, cin) fp32 */, int cin, int cout, int transposed, void* packed, long long* jobs);
 int gdmae_spconv(const void* X, int x_f32, const int* nbr, const void* packed, long long n, int cin, int cout, void* Y,
                  int timing_slot /* 0: the sparse-conv forward slot of gdmae_kernel_timing */, void* stream);
+/* The same launch with the BatchNorm statistics of Y as its epilogue: part (ceil(n / gdmae_spconv_stat_rows(cin, cout, x_f32)), 2, cout)
+ * fp32 = per-workgroup column sums of Y and Y^2 (of the bf16-rounded values), to be folded by gdmae_bn_fold_partials - what
+ * gdmae_conv_block_fwd does instead of a statistics pass over Y (post_act_block's BatchNorm1d, spconv_utils.py:37-56). */
+int gdmae_spconv_stat_rows(int cin, int cout, int x_f32);
+int gdmae_spconv_stats(const void* X, int x_f32, const int* nbr, const void* packed, long long n, int cin, int cout, void* Y, float* part,
+                       void* stream);
 /* ---- 3x3 conv_out backward of the generative decoder without the tap matrix (round 3; spt_backbone_mae.py:46-52 backward) ---- *
  * gdmae_decoder_dy: dYc (n_act * 64, C) bf16 = k0 + k1 * Yc + rows[pillar of the site] on the active tiles (Yc / tile_list of
  *   gdmae_conv3x3_tiles_fwd / gdmae_decoder_tiles; rows (M, C) fp32 = the sparse part of the output gradient; zero at the
