@@ -113,6 +113,8 @@ struct CdArgs {
   int ncb;                      // CO blocks of the output (cout / CO)
   float* stat_part;             // optional (tile pairs, 2, cout) fp32: per-channel sum / sum of squares of the ROUNDED outputs of the
                                 // workgroup's in-map sites (BatchNorm statistics of the layer that follows), bf16 output only
+  const unsigned short* addend; // optional (B, H, W, cout) bf16 map added to the rounded result (bf16 output only): the gradient that
+                                // reaches a layer's input along an identity shortcut joins the input gradient in its store pass
 };
 
 #ifndef CD_MPW128
@@ -291,7 +293,18 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_dense(CdArgs A) {
           }
           *reinterpret_cast<float4*>(dst) = v;
         } else {
-          *reinterpret_cast<uint4*>(A.Y + row * A.cout + cb * CO + c * 8) = *reinterpret_cast<const uint4*>(lds + site * SP + c * 16);
+          uint4 v = *reinterpret_cast<const uint4*>(lds + site * SP + c * 16);
+          if (A.addend != nullptr) {                 // uniform
+            const uint4 o = *reinterpret_cast<const uint4*>(A.addend + row * A.cout + cb * CO + c * 8);
+            const unsigned vw[4] = {v.x, v.y, v.z, v.w}, ow[4] = {o.x, o.y, o.z, o.w};
+            unsigned r[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              r[k] = cd_pack2(__uint_as_float(vw[k] << 16) + __uint_as_float(ow[k] << 16),
+                              __uint_as_float(vw[k] & 0xFFFF0000u) + __uint_as_float(ow[k] & 0xFFFF0000u));
+            v = make_uint4(r[0], r[1], r[2], r[3]);
+          }
+          *reinterpret_cast<uint4*>(A.Y + row * A.cout + cb * CO + c * 8) = v;
         }
       }
     }
@@ -592,12 +605,13 @@ extern "C" int gdmae_conv3x3_dense_pack(const float* weight, int cin, int cout, 
 // (the padded counts of gdmae_conv3x3_dense_pack; for the input gradient the roles of the layer's cin / cout are swapped).
 // out_f32 = 0: Y bf16; 1: Y fp32, added to its previous content when accumulate != 0.
 static int cd_conv(const void* X, int B, int H, int W, int cin_l, int cout_l, int dil, const void* packed, const float* bias, void* Y, int out_f32,
-                   int accumulate, void* stream, float* stat_ws = nullptr) {
+                   int accumulate, void* stream, float* stat_ws = nullptr, const void* addend = nullptr) {
   GD_REQUIRE(cin_l % 32 == 0 && cout_l % 32 == 0 && cd_shape_ok(cin_l, cout_l, dil), "conv3x3_dense: channel counts must be multiples of 32");
   if (B <= 0 || H <= 0 || W <= 0) return 0;
   const int cib = cd_cib(cin_l, dil), co = cd_co(cout_l);
   CdArgs A{(const unsigned short*)X, (const uint4*)packed, bias, (unsigned short*)Y, B, H, W, (H + 7) / 8, (W + 7) / 8, cin_l, cout_l,
-           cin_l / cib, cout_l / 32, 0, accumulate, 1, stat_ws};
+           cin_l / cib, cout_l / 32, 0, accumulate, 1, stat_ws, (const unsigned short*)addend};
+  GD_REQUIRE(addend == nullptr || (!out_f32 && stat_ws == nullptr), "conv3x3_dense: an addend goes with a plain bf16 output");
   A.n_tiles = B * A.TH * A.TW;
   hipStream_t st = (hipStream_t)stream;
 #define CD_CASE(ci, c, d) \
@@ -616,6 +630,13 @@ static int cd_conv(const void* X, int B, int H, int W, int cin_l, int cout_l, in
 extern "C" int gdmae_conv3x3_dense(const void* X, int B, int H, int W, int cin_l, int cout_l, int dil, const void* packed, const float* bias,
                                    void* Y, void* stream) {
   return cd_conv(X, B, H, W, cin_l, cout_l, dil, packed, bias, Y, 0, 0, stream);
+}
+// Y = bf16(bf16(conv(X) + bias) + addend): addend (B, H, W, cout_l) bf16 - what an elementwise addition of two bf16 maps after the
+// convolution gives, without the pass (the shortcut gradient of a Conv-BN-ReLU block with an identity shortcut, sst_bev_backbone.py:36-40)
+extern "C" int gdmae_conv3x3_dense_add(const void* X, int B, int H, int W, int cin_l, int cout_l, int dil, const void* packed, const float* bias,
+                                       const void* addend, void* Y, void* stream) {
+  GD_REQUIRE(addend != nullptr, "conv3x3_dense_add: addend");
+  return cd_conv(X, B, H, W, cin_l, cout_l, dil, packed, bias, Y, 0, 0, stream, nullptr, addend);
 }
 // ... + the BatchNorm statistics of the layer that follows: stat_rows (GDMAE_CD_STAT_ROWS = 256, 2, cout_l) fp32 partial rows of the
 // per-channel sum / sum of squares of the rounded outputs over all B H W sites (the format gdmae_bn_fold_partials takes) - the epilogue

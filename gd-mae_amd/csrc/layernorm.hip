@@ -337,3 +337,45 @@ extern "C" int gdmae_add3(const float* a, const void* b, int b_bf16, const void*
                           void* stream) {
   return gdmae_add3_to(a, b, b_bf16, c, c_bf16, total, out, 0, stream);
 }
+
+// ------------------------------------------------------------------------------------------------
+// out = sum of k (<= 8) bf16 buffers of `total` elements, accumulated in fp32 and rounded once: the gradient of a map that feeds several
+// consumers (the shared feature map under CenterHead's five branches, center_head.py:26-45) as ONE pass instead of the k - 1
+// read-read-write additions the autograd engine issues (and one rounding instead of k - 1).
+// ------------------------------------------------------------------------------------------------
+struct GdSumSrc {
+  const uint4* p[8];
+};
+__global__ __launch_bounds__(256) void k_sum_bf16(GdSumSrc S, int k, long long n16, uint4* __restrict__ out) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n16; i += (long long)gridDim.x * blockDim.x) {
+    uint4 q[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) q[j] = S.p[j < k ? j : 0][i];          // unconditional (slot 0 again past k), masked below
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float m = j < k ? 1.f : 0.f;
+      const unsigned w[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        a[2 * e] = fmaf(m, __uint_as_float(w[e] << 16), a[2 * e]);
+        a[2 * e + 1] = fmaf(m, __uint_as_float(w[e] & 0xFFFF0000u), a[2 * e + 1]);
+      }
+    }
+    uint4 o;
+    o.x = gd_pack_bf16(a[0], a[1]); o.y = gd_pack_bf16(a[2], a[3]); o.z = gd_pack_bf16(a[4], a[5]); o.w = gd_pack_bf16(a[6], a[7]);
+    out[i] = o;
+  }
+}
+extern "C" int gdmae_sum_bf16(const void* const* src, int k, long long total, void* out, void* stream) {
+  GD_REQUIRE(k >= 1 && k <= 8 && total % 8 == 0, "sum_bf16: 1..8 sources, element count a multiple of 8");
+  if (total <= 0) return 0;
+  GdSumSrc S;
+  for (int j = 0; j < 8; ++j) S.p[j] = (const uint4*)src[j < k ? j : 0];
+  const long long n16 = total / 8;
+  long long grid = (n16 + 255) / 256;
+  if (grid > 16384) grid = 16384;
+  hipLaunchKernelGGL(k_sum_bf16, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, S, k, n16, (uint4*)out);
+  GD_LAUNCH_CHECK();
+  return 0;
+}

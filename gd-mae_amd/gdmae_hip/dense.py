@@ -92,7 +92,12 @@ class Conv3x3Dense(torch.autograd.Function):
             packed = torch.empty(L.load().gdmae_conv3x3_dense_packed_bytes(cin, cout), dtype=torch.uint8, device=dev)
             L.call("gdmae_conv3x3_dense_pack", L.ptr(w), cin, cout, dil, 1, L.ptr(packed), L.stream())
             dxr = torch.empty(B, H, W, cin, dtype=torch.bfloat16, device=dev)
-            L.call("gdmae_conv3x3_dense", L.ptr(g), B, H, W, cl, cin, dil, L.ptr(packed), None, L.ptr(dxr), L.stream())
+            addend = getattr(ctx, "dx_addend", None)       # ConvBNReLUShortcut: the shortcut's gradient joins dx in the store pass
+            if addend is not None:
+                assert addend.shape == dxr.shape and addend.dtype == torch.bfloat16 and addend.is_contiguous()
+                L.call("gdmae_conv3x3_dense_add", L.ptr(g), B, H, W, cl, cin, dil, L.ptr(packed), None, L.ptr(addend), L.ptr(dxr), L.stream())
+            else:
+                L.call("gdmae_conv3x3_dense", L.ptr(g), B, H, W, cl, cin, dil, L.ptr(packed), None, L.ptr(dxr), L.stream())
             dx = dxr.permute(0, 3, 1, 2)
             if x_dtype != torch.bfloat16:
                 dx = dx.to(x_dtype)
@@ -107,6 +112,64 @@ class Conv3x3Dense(torch.autograd.Function):
                 dbd.add_(db)
                 db = None
         return dx, (None if dwd is not None else dW), db, None, None, None
+
+
+import os
+
+FUSE_SHORTCUT = os.environ.get("GDMAE_DENSE_FUSE", "1") != "0"      # A/B switch (also read by SeparateHead's FanOut)
+
+
+class _Ctx:
+    """Stand-in for the autograd context when a Function's forward / backward bodies are composed inside another Function."""
+
+    def __init__(self, needs_input_grad=()):
+        self.needs_input_grad = needs_input_grad
+        self.saved_tensors = ()
+
+    def save_for_backward(self, *ts):
+        self.saved_tensors = ts
+
+    def mark_non_differentiable(self, *ts):
+        pass
+
+    def set_materialize_grads(self, flag):
+        pass
+
+
+class ConvBNReLUShortcut(torch.autograd.Function):
+    """x + relu(bn(conv3x3(x))) for a channels-last bf16 map with as many output as input channels (the identity-shortcut blocks of
+    SSTBEVBackbone, sst_bev_backbone.py:36-40) as ONE autograd node: Conv3x3Dense and BNReLURows composed, so that the gradient the
+    shortcut carries to x is added inside the input-gradient convolution's store pass (gdmae_conv3x3_dense_add) - as two nodes the
+    engine adds the two gradients of x in a pass of its own (3 x 439 MB per block at config D)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, dil, direct, gamma, beta, eps, bn):
+        B, C, H, W = x.shape
+        c1 = _Ctx()
+        y, part = Conv3x3Dense.forward(c1, x, weight, bias, dil, direct, True)
+        assert y.shape == x.shape
+        rows = y.permute(0, 2, 3, 1).reshape(B * H * W, C)
+        res = x.permute(0, 2, 3, 1).reshape(B * H * W, C)
+        c2 = _Ctx()
+        out, _, _ = BNReLURows.forward(c2, rows, gamma, beta, eps, bn, res, part)
+        ctx.c1, ctx.c2 = c1, c2
+        ctx.set_materialize_grads(False)
+        return out.view(B, H, W, C).permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, g):
+        if g is None:
+            return (None,) * 9
+        c1, c2 = ctx.c1, ctx.c2
+        B, H, W, C = c1.saved_tensors[0].shape
+        grows = g.permute(0, 2, 3, 1).reshape(B * H * W, C)
+        grows = (grows if grows.dtype == torch.bfloat16 else grows.to(torch.bfloat16)).contiguous()
+        dy, dgamma, dbeta, _, _, gres, _ = BNReLURows.backward(c2, grows, None, None)
+        c1.needs_input_grad = (ctx.needs_input_grad[0],)
+        c1.dx_addend = gres.view(B, H, W, C) if ctx.needs_input_grad[0] else None
+        dx, dW, db, _, _, _ = Conv3x3Dense.backward(c1, dy.view(B, H, W, C).permute(0, 3, 1, 2))
+        ctx.c1 = ctx.c2 = None
+        return dx, dW, db, None, None, dgamma, dbeta, None, None
 
 
 def _split_bf16(x32: torch.Tensor):
@@ -248,6 +311,14 @@ def conv_bn_relu(block: nn.Sequential, x: torch.Tensor, shortcut: torch.Tensor |
     (evaluation mode uses the running statistics: a per-channel affine the framework fuses itself).  ``shortcut``: a map of the output's
     shape added after the ReLU (in the same pass on the row path)."""
     if len(block) == 3 and isinstance(block[1], nn.BatchNorm2d) and isinstance(block[2], nn.ReLU):
+        conv, bn = block[0], block[1]
+        if (FUSE_SHORTCUT and shortcut is x and isinstance(conv, nn.Conv2d) and torch.is_autocast_enabled() and conv3x3_supported(conv, x) and x.requires_grad
+                and x.dtype == torch.bfloat16 and x.is_contiguous(memory_format=torch.channels_last) and conv.out_channels == x.shape[1]
+                and conv.out_channels % 32 == 0 and rows_supported(x, bn)):
+            dw = ops.direct_grad(conv.weight)
+            db = ops.direct_grad(conv.bias) if conv.bias is not None else None
+            direct = (dw, db) if (dw is not None and (conv.bias is None or db is not None)) else None
+            return ConvBNReLUShortcut.apply(x, conv.weight, conv.bias, int(conv.dilation[0]), direct, bn.weight, bn.bias, float(bn.eps), bn)
         y, part = conv3x3(block[0], x, want_stats=True) if isinstance(block[0], nn.Conv2d) else (block[0](x), None)
         if rows_supported(y, block[1]) and (shortcut is None or shortcut.is_contiguous(memory_format=torch.channels_last)):
             return bn_relu_2d(y, block[1], shortcut, part)

@@ -88,6 +88,7 @@ SIGNATURES = {
     "gdmae_conv3x3_dense_packed_bytes": (_Z, [_I, _I]),
     "gdmae_conv3x3_dense_pack": (_I, [_P, _I, _I, _I, _I, _P, _P]),
     "gdmae_conv3x3_dense": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "gdmae_conv3x3_dense_add": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
     "gdmae_conv3x3_dense_stats_workspace_bytes": (_Z, [_I, _I, _I, _I]),
     "gdmae_conv3x3_dense_stat_rows": (_I, []),
     "gdmae_conv3x3_dense_stats": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
@@ -106,6 +107,7 @@ SIGNATURES = {
     "gdmae_add_layernorm_fwd": (_I, [_P, _P, _I, _P, _P, _L, _I, _F, _P, _P, _P, _P]),
     "gdmae_add_layernorm_bwd": (_I, [_P, _P, _I, _P, _P, _P, _P, _I, _L, _I, _P, _P, _P, _P, _P]),
     "gdmae_prep_tokens": (_I, [_P, _P, _P, _L, _I, _P, _P, _I, _P]),
+    "gdmae_sum_bf16": (_I, [_P, _I, _L, _P, _P]),
     "gdmae_add3": (_I, [_P, _P, _I, _P, _I, _L, _P, _P]),
     "gdmae_add3_to": (_I, [_P, _P, _I, _P, _I, _L, _P, _I, _P]),
     "gdmae_set_attention_impl": (_I, [_I]),
@@ -268,6 +270,17 @@ def host_i64(vals):
     return (C.c_longlong * len(vals))(*[int(v) for v in vals])
 
 
+def ptr_any(t):
+    """data pointer of a device tensor whose elements are dense in memory in ANY dimension order (e.g. a channels-last map)."""
+    assert t.is_cuda
+    return t.data_ptr()
+
+
 def host_ptrs(tensors):
     """Host array of device pointers (the `const T* const*` arguments of the C ABI)."""
     return (C.c_void_p * len(tensors))(*[ptr(t) for t in tensors])
+
+
+def host_ptrs_any(tensors):
+    """... of tensors that are dense in memory in any dimension order (ptr_any)."""
+    return (C.c_void_p * len(tensors))(*[ptr_any(t) for t in tensors])

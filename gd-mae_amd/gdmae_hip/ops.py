@@ -235,6 +235,37 @@ class LinearSplitK(torch.autograd.Function):
         return dx, dw, db
 
 
+class FanOut(torch.autograd.Function):
+    """``k`` handles on one tensor for ``k`` consumers whose gradients meet again in ONE pass: the autograd engine adds the gradients of a
+    multiply-used tensor pairwise (k - 1 read-read-write passes, a bf16 rounding after each); here the backward is one
+    ``gdmae_sum_bf16`` launch (k reads, one write, fp32 accumulation) when all k gradients are bf16 tensors of one dense layout, the
+    engine's own sum otherwise.  Used where the reference hands one dense map to several branches (SeparateHead, center_head.py:37-45)."""
+
+    @staticmethod
+    def forward(ctx, x, k):
+        ctx.k = int(k)
+        return tuple(x.view_as(x) for _ in range(ctx.k))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        gs = [g for g in gs if g is not None]
+        if not gs:
+            return None, None
+        if len(gs) == 1:
+            return gs[0], None
+        g0 = gs[0]
+        same = all(g.is_cuda and g.dtype == torch.bfloat16 and g.shape == g0.shape and g.stride() == g0.stride() for g in gs)
+        dense = same and g0.numel() % 8 == 0 and (g0.is_contiguous() or g0.is_contiguous(memory_format=torch.channels_last))
+        if not dense or len(gs) > 8:
+            out = gs[0]
+            for g in gs[1:]:
+                out = out + g
+            return out, None
+        out = torch.empty_like(g0)                   # preserves the (dense) strides
+        L.call("gdmae_sum_bf16", L.host_ptrs_any(gs), len(gs), g0.numel(), L.ptr_any(out), L.stream())
+        return out, None
+
+
 class ResidualAdd(torch.autograd.Function):
     """a (fp32) + b (fp32 or bf16) as one gdmae_add3_to launch: the block residual ``feat + out`` of SSTBlockV1
     (spt_backbone.py:158), where ``feat`` is the bf16 output of the sparse-conv block under autocast.  Under autocast the sum is

@@ -23,6 +23,7 @@ import torch.nn as nn
 from torch.nn.init import kaiming_normal_
 
 from gdmae_hip import dense as gdense
+from gdmae_hip import ops as gops
 from gdmae_hip import lib as L
 from ...ops.iou3d_nms import iou3d_nms_utils
 
@@ -50,8 +51,10 @@ class SeparateHead(nn.Module):
 
     def forward(self, x):
         out = {}
-        for name in self.sep_head_dict:
-            y = x
+        # one map, one branch per regression / heat-map head: the branches' input gradients meet in one pass (ops.FanOut)
+        xs = gops.FanOut.apply(x, len(self.sep_head_dict)) if (gdense.FUSE_SHORTCUT and x.is_cuda and x.requires_grad and torch.is_grad_enabled()) else None
+        for h, name in enumerate(self.sep_head_dict):
+            y = x if xs is None else xs[h]
             for layer in getattr(self, name):
                 y = gdense.conv_bn_relu(layer, y) if isinstance(layer, nn.Sequential) else gdense.conv3x3(layer, y)
             out[name] = y

@@ -383,6 +383,9 @@ int gdmae_add_layernorm_bwd(const float* a, const void* b, int b_is_bf16, const 
  * gdmae_add3: out(fp32) = a(fp32) + b + c, b/c optional fp32 or bf16 (gradient accumulation of the residual stream). */
 int gdmae_prep_tokens(const float* x, const float* pos_table, const int* tok_pos, long long n, int d, void* x_out,
                       void* xpos_out, int out_bf16, void* stream);
+/* out (total bf16 elements) = sum of k <= 8 bf16 buffers, fp32 accumulation, one rounding: the gradient of a map with several
+ * consumers in one pass (gdmae_hip.ops.FanOut; reference center_head.py:26-45 feeds one map to every branch of SeparateHead). */
+int gdmae_sum_bf16(const void* const* src, int k, long long total, void* out, void* stream);
 int gdmae_add3(const float* a, const void* b, int b_bf16, const void* c, int c_bf16, long long total, float* out, void* stream);
 /* the same with the result in fp32 (out_bf16 = 0) or bf16 (1): the block residual feat + out of SSTBlockV1 (spt_backbone.py:158)
  * goes to the next sparse convolution, which rounds its input rows to bf16 anyway - written in bf16 the 9 gathers of every row
@@ -649,6 +652,10 @@ int gdmae_conv3x3_dense_pack(const float* weight, int cin, int cout, int dil, in
 /* Y (B, H, W, cout_l) bf16 = conv(X (B, H, W, cin_l) bf16) + bias (cout_l fp32, optional) */
 int gdmae_conv3x3_dense(const void* X, int B, int H, int W, int cin_l, int cout_l, int dil, const void* packed, const float* bias,
                         void* Y, void* stream);
+/* ... + addend (B, H, W, cout_l) bf16 added to the rounded result in the store pass: the gradient an identity shortcut carries to a
+ * block's input joins the convolution's input gradient (sst_bev_backbone.py:36-40) */
+int gdmae_conv3x3_dense_add(const void* X, int B, int H, int W, int cin_l, int cout_l, int dil, const void* packed, const float* bias,
+                            const void* addend, void* Y, void* stream);
 /* ... + the statistics of the BatchNorm that follows the convolution as its epilogue: stat_rows (gdmae_conv3x3_dense_stat_rows() = 256,
  * 2, cout_l) fp32 partial rows {sum, sum of squares} per channel of the ROUNDED outputs over all B H W sites, summed in a fixed order;
  * gdmae_bn_fold_partials turns them into the folded affine (no pass over Y).  workspace: gdmae_conv3x3_dense_stats_workspace_bytes. */

@@ -217,13 +217,19 @@ def test_detector_end_to_end_bf16_against_reference_golden():
     front.load_state_dict(orc.seeded_state_dict(shapes, seed=seed), strict=False)
     back.load_state_dict(seeded_head_state(back, seed), strict=False)
     front, back = front.to(dev).train(), back.to(dev).train()
-    calls = {"n": 0}
-    orig = gdense.Conv3x3Dense.apply
+    calls = {"n": 0, "shortcut": 0}
+    orig, orig_sc = gdense.Conv3x3Dense.apply, gdense.ConvBNReLUShortcut.apply
 
     def counted(*a):
         calls["n"] += 1
         return orig(*a)
+
+    def counted_sc(*a):                     # the identity-shortcut blocks of the BEV backbone: convolution + BatchNorm + ReLU + shortcut as one node
+        calls["n"] += 1
+        calls["shortcut"] += 1
+        return orig_sc(*a)
     gdense.Conv3x3Dense.apply = counted
+    gdense.ConvBNReLUShortcut.apply = counted_sc
     try:
         with torch.autocast("cuda", dtype=torch.bfloat16):
             bd = bb(vfe({"points": torch.from_numpy(z["points"]).to(dev), "batch_size": B}))
@@ -233,8 +239,9 @@ def test_detector_end_to_end_bf16_against_reference_golden():
             loss, tb = head.get_loss()
     finally:
         gdense.Conv3x3Dense.apply = orig
+        gdense.ConvBNReLUShortcut.apply = orig_sc
     # conv_out + 4 BEV convolutions + shared_conv + 5 heads x 2: all sixteen through the library's dense convolution
-    assert calls["n"] == 16, calls
+    assert calls["n"] == 16 and calls["shortcut"] == sum(1 for i in b2d.conv_shortcut if i < len(b2d.conv_layer)), calls
     loss.backward()
     rel = lambda a, b: abs(float(a) - float(b)) / abs(float(b))      # noqa: E731
     g = {**dict(front.named_parameters()), **dict(back.named_parameters())}

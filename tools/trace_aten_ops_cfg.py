@@ -34,6 +34,8 @@ class Trace(TorchDispatchMode):
             if ts:
                 fr = [f for f in traceback.extract_stack() if "/repo/" in f.filename and "trace_aten_ops" not in f.filename and "bench.py" not in f.filename]
                 where = f"{fr[-1].filename.replace(REPO, '')}:{fr[-1].lineno}" if fr else "(autograd engine)"
+                if where == "(autograd engine)" and name.startswith(("aten.add.Tensor", "aten.mul.Tensor", "aten._to_copy")):
+                    print("  autograd-engine", name, [(tuple(t.shape), str(t.dtype).replace("torch.", ""), t.stride()) for t in ts][:2])
                 h = self.hits[(name, where)]
                 h[0] += 1
                 h[1] += max(t.numel() * t.element_size() for t in ts)
