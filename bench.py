@@ -601,7 +601,8 @@ def main():
             wl.mode["bf16"] = False
             also["fp32_parity_mode"] = timed_leg(wl, 3, max(4, args.steps // 4))
             also["fp32_parity_mode"]["note"] = ("no autocast: fp32 rows, every product on the library's own exact-fp32 MFMA GEMM (csrc/gemm_f32.hip), "
-                                                "dense F.conv2d decoder convolution (MIOpen)")
+                                                "the decoder's dense 3x3 convolution as six bf16 matrix-core launches on three-piece operand splits with fp32 accumulation "
+                                                "(csrc/conv_dense.hip OF32, 2e-6 vs fp64) - no library call in this mode either")
             wl.mode["bf16"] = True
         wl.pending.clear()
         if args.config == "B" and not explicit_batch:
