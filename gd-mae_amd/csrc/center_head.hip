@@ -217,3 +217,137 @@ extern "C" int gdmae_center_head_decode(const long long* cell, const float* scor
   GD_LAUNCH_CHECK();
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// CornerNet focal loss of CenterHead (reference pcdet/utils/loss_utils.py:273-312 on the clamped sigmoid of center_head.py:236-238):
+//     p = clamp(sigmoid(x), 1e-4, 1 - 1e-4);  pos = [gt == 1], neg = [gt < 1]
+//     loss = -(sum log(p) (1 - p)^2 pos + sum log(1 - p) p^2 (1 - gt)^4 neg) / max(#pos, 1)        (#pos = 0: only the negative sum)
+// The reference issues ~20 elementwise passes over the (B, C, H, W) heat map per direction; here one pass per direction: the
+// forward reads the logits where the head convolution left them (a column slice of a channels-last map: element strides per (b, y,
+// x, c), bf16 or fp32), writes the clamped sigmoid the reference keeps in pred_dict['hm'] and per-workgroup partial sums; the
+// backward writes d loss / d logits (scaled by the incoming scalar gradient) as a channels-last (B, H, W, C) tensor.
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct FlArgs {
+  const void* x;
+  int x_bf16;
+  long long sb, sy, sx, sc;       // element strides of the logits
+  const float* gt;                // (B, C, H, W) contiguous
+  int B, C, H, W;
+};
+__device__ __forceinline__ float fl_logit(const FlArgs& A, int b, int c, int y, int x) {
+  const long long o = b * A.sb + y * A.sy + x * A.sx + c * A.sc;
+  return A.x_bf16 ? __uint_as_float(((unsigned)((const unsigned short*)A.x)[o]) << 16) : ((const float*)A.x)[o];
+}
+__global__ __launch_bounds__(256) void k_focal_fwd(FlArgs A, float* __restrict__ prob, float* __restrict__ part) {
+  const long long total = (long long)A.B * A.C * A.H * A.W;
+  float pl = 0.f, nl = 0.f, np = 0.f;
+  for (long long e = blockIdx.x * 256ll + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const int x = (int)(e % A.W);
+    long long t = e / A.W;
+    const int y = (int)(t % A.H);
+    t /= A.H;
+    const int c = (int)(t % A.C), b = (int)(t / A.C);
+    const float v = fl_logit(A, b, c, y, x);
+    const float s = 1.f / (1.f + expf(-v));
+    const float p = fminf(fmaxf(s, 1e-4f), 1.f - 1e-4f);
+    const float g = A.gt[e];
+    if (prob) prob[e] = p;
+    if (g == 1.f) {
+      pl += logf(p) * (1.f - p) * (1.f - p);
+      np += 1.f;
+    } else if (g < 1.f) {
+      const float w = (1.f - g) * (1.f - g);
+      nl += logf(1.f - p) * p * p * (w * w);
+    }
+  }
+  __shared__ float sh[3][256];
+  sh[0][threadIdx.x] = pl; sh[1][threadIdx.x] = nl; sh[2][threadIdx.x] = np;
+  __syncthreads();
+  for (int d = 128; d > 0; d >>= 1) {
+    if ((int)threadIdx.x < d) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) sh[k][threadIdx.x] += sh[k][threadIdx.x + d];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < 3) part[(long long)blockIdx.x * 3 + threadIdx.x] = sh[threadIdx.x][0];
+}
+// out[4] = {loss, positive sum, negative sum, #pos}
+__global__ __launch_bounds__(256) void k_focal_finish(const float* __restrict__ part, int nblk, float* __restrict__ out) {
+  __shared__ double sh[3][256];
+  double a[3] = {0.0, 0.0, 0.0};
+  for (int i = threadIdx.x; i < nblk; i += 256)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) a[k] += (double)part[(long long)i * 3 + k];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) sh[k][threadIdx.x] = a[k];
+  __syncthreads();
+  for (int d = 128; d > 0; d >>= 1) {
+    if ((int)threadIdx.x < d) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) sh[k][threadIdx.x] += sh[k][threadIdx.x + d];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double pos = sh[0][0], neg = sh[1][0], n = sh[2][0];
+    out[0] = (float)(n == 0.0 ? -neg : -(pos + neg) / (n < 1.0 ? 1.0 : n));
+    out[1] = (float)pos;
+    out[2] = (float)neg;
+    out[3] = (float)n;
+  }
+}
+__global__ __launch_bounds__(256) void k_focal_bwd(FlArgs A, const float* __restrict__ fin, const float* __restrict__ gout, void* __restrict__ dx,
+                                                   int dx_bf16) {
+  const long long total = (long long)A.B * A.C * A.H * A.W;
+  const float n = fin[3];
+  const float scale = -gout[0] / (n < 1.f ? 1.f : n);        // #pos = 0: -neg_loss, i.e. the same with a divisor of 1
+  for (long long e = blockIdx.x * 256ll + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const int c = (int)(e % A.C);                            // output order: channels-last (b, y, x, c)
+    long long t = e / A.C;
+    const int x = (int)(t % A.W);
+    t /= A.W;
+    const int y = (int)(t % A.H), b = (int)(t / A.H);
+    const float v = fl_logit(A, b, c, y, x);
+    const float s = 1.f / (1.f + expf(-v));
+    const bool inside = s >= 1e-4f && s <= 1.f - 1e-4f;      // clamp passes the gradient on its closed interval
+    const float p = fminf(fmaxf(s, 1e-4f), 1.f - 1e-4f);
+    const float g = A.gt[(((long long)b * A.C + c) * A.H + y) * A.W + x];
+    float dp = 0.f;
+    if (g == 1.f) {
+      dp = (1.f - p) * (1.f - p) / p - 2.f * (1.f - p) * logf(p);
+    } else if (g < 1.f) {
+      const float w = (1.f - g) * (1.f - g);
+      dp = (w * w) * (2.f * p * logf(1.f - p) - p * p / (1.f - p));
+    }
+    const float d = inside ? scale * dp * s * (1.f - s) : 0.f;
+    if (dx_bf16) ((unsigned short*)dx)[e] = gd_to_bf16(d);
+    else ((float*)dx)[e] = d;
+  }
+}
+}  // namespace
+extern "C" int gdmae_focal_loss_rows(void) { return 1024; }
+extern "C" int gdmae_focal_loss_fwd(const void* logits, int logits_bf16, const long long* strides_byxc /* host [4]: elements */, const float* gt,
+                                    int B, int C, int H, int W, float* prob, float* partials, float* out4, void* stream) {
+  GD_REQUIRE(B >= 1 && C >= 1 && H >= 1 && W >= 1 && logits && gt && partials && out4, "focal_loss_fwd: bad arguments");
+  FlArgs A{logits, logits_bf16, strides_byxc[0], strides_byxc[1], strides_byxc[2], strides_byxc[3], gt, B, C, H, W};
+  const long long total = (long long)B * C * H * W;
+  const int nblk = (int)(total / 1024 + 1 > 1024 ? 1024 : total / 1024 + 1);
+  hipLaunchKernelGGL(k_focal_fwd, dim3(nblk), dim3(256), 0, (hipStream_t)stream, A, prob, partials);
+  GD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_focal_finish, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)partials, nblk, out4);
+  GD_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int gdmae_focal_loss_bwd(const void* logits, int logits_bf16, const long long* strides_byxc, const float* gt, int B, int C, int H, int W,
+                                    const float* out4, const float* grad_out, void* dlogits /* (B, H, W, C) */, int dlogits_bf16, void* stream) {
+  GD_REQUIRE(B >= 1 && C >= 1 && H >= 1 && W >= 1 && logits && gt && out4 && grad_out && dlogits, "focal_loss_bwd: bad arguments");
+  FlArgs A{logits, logits_bf16, strides_byxc[0], strides_byxc[1], strides_byxc[2], strides_byxc[3], gt, B, C, H, W};
+  const long long total = (long long)B * C * H * W;
+  long long g = (total + 255) / 256;
+  if (g > 8192) g = 8192;
+  hipLaunchKernelGGL(k_focal_bwd, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, A, out4, grad_out, dlogits, dlogits_bf16);
+  GD_LAUNCH_CHECK();
+  return 0;
+}

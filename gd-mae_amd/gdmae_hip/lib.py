@@ -170,6 +170,9 @@ SIGNATURES = {
     "gdmae_center_head_targets_workspace_bytes": (_Z, [_I, _I]),
     "gdmae_center_head_targets": (_I, [_P, _I, _I, _I, _P, _I, _I, _P, _P, _F, _I, _I, _I, _D, _I, _P, _P, _P, _P, _P, _P]),
     "gdmae_center_head_targets_iou": (_I, [_P, _I, _I, _I, _P, _I, _I, _P, _P, _F, _I, _I, _I, _D, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "gdmae_focal_loss_rows": (_I, []),
+    "gdmae_focal_loss_fwd": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "gdmae_focal_loss_bwd": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P]),
     "gdmae_center_head_decode": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _F, _P, _F, _I, _P, _P, _P, _P, _P]),
     "gdmae_boxes_bev_pairs": (_I, [_P, _I, _P, _I, _I, _P, _P]),
     "gdmae_nms_workspace_bytes": (_Z, [_I]),

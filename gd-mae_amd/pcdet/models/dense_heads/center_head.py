@@ -72,6 +72,59 @@ def focal_loss_centernet(pred, gt):
     return torch.where(num_pos == 0, -neg_loss, -(pos_loss + neg_loss) / num_pos.clamp(min=1))
 
 
+class FocalLossCenterNetFn(torch.autograd.Function):
+    """focal_loss_centernet(clamp(sigmoid(logits)), gt) as one launch per direction (csrc/center_head.hip gdmae_focal_loss_fwd / _bwd):
+    the logits are read where the head's convolution left them (any strides, bf16 or fp32), the backward writes a channels-last
+    gradient in the logits' dtype.  -> (loss, clamped sigmoid (B, C, H, W) fp32 - what the reference keeps in pred_dict['hm'])."""
+
+    @staticmethod
+    def forward(ctx, logits, gt):
+        B, C, H, W = logits.shape
+        assert logits.is_cuda and logits.dtype in (torch.bfloat16, torch.float32) and gt.shape == logits.shape
+        gt = gt.float().contiguous()
+        dev = logits.device
+        st = logits.stride()
+        strides = L.host_i64([st[0], st[2], st[3], st[1]])
+        base = logits                                   # the view's own data pointer (storage offset included)
+        prob = torch.empty(B, C, H, W, dtype=torch.float32, device=dev)
+        part = torch.empty(L.load().gdmae_focal_loss_rows() * 3, dtype=torch.float32, device=dev)
+        out4 = torch.empty(4, dtype=torch.float32, device=dev)
+        L.call("gdmae_focal_loss_fwd", base.data_ptr(), int(logits.dtype == torch.bfloat16), strides, L.ptr(gt), B, C, H, W, L.ptr(prob),
+               L.ptr(part), L.ptr(out4), L.stream())
+        ctx.save_for_backward(logits, gt, out4)
+        ctx.mark_non_differentiable(prob)
+        return out4[0], prob
+
+    @staticmethod
+    def backward(ctx, g, _gp):
+        logits, gt, out4 = ctx.saved_tensors
+        B, C, H, W = logits.shape
+        st = logits.stride()
+        strides = L.host_i64([st[0], st[2], st[3], st[1]])
+        dx = torch.empty(B, H, W, C, dtype=logits.dtype, device=logits.device)
+        gs = g.float().reshape(1).contiguous()
+        L.call("gdmae_focal_loss_bwd", logits.data_ptr(), int(logits.dtype == torch.bfloat16), strides, L.ptr(gt), B, C, H, W, L.ptr(out4),
+               L.ptr(gs), L.ptr(dx), int(dx.dtype == torch.bfloat16), L.stream())
+        return dx.permute(0, 3, 1, 2), None
+
+
+def reg_loss_centernet_maps(maps, mask, ind, target):
+    """reg_loss_centernet on the regression maps of a head WITHOUT concatenating them: every map is gathered at the object cells first
+    ((B, K, c_i) each, K = NUM_MAX_OBJS), the gathered columns are concatenated - the reference concatenates the (B, 8, H, W) maps and
+    gathers then (center_head.py:240-245, loss_utils.py:325-396): same values, 55 MB of fp32 copies less per direction."""
+    B = maps[0].shape[0]
+    cols = []
+    for m in maps:
+        c = m.shape[1]
+        rows = m.permute(0, 2, 3, 1).reshape(B, -1, c)                # a view for a column slice of a channels-last map
+        cols.append(rows.gather(1, ind.unsqueeze(2).expand(B, ind.shape[1], c)).float())
+    pred = torch.cat(cols, dim=2)
+    num = mask.float().sum()
+    m = mask.unsqueeze(2).expand_as(target).float() * (~torch.isnan(target)).float()
+    loss = torch.abs(pred * m - target * m).sum(dim=(0, 1))
+    return loss / torch.clamp_min(num, 1.0)
+
+
 def reg_loss_centernet(output, mask, ind, target):
     """Masked L1 on the regression maps gathered at the object cells (loss_utils.py:325-396): (dim,) per-code losses."""
     B, C = output.shape[0], output.shape[1]
@@ -150,10 +203,18 @@ class CenterHead(nn.Module):
         w = self.model_cfg.LOSS_CONFIG.LOSS_WEIGHTS
         tb_dict, loss = {}, 0
         for idx, pd in enumerate(pred_dicts):
-            pd['hm'] = self.sigmoid(pd['hm'].float())
-            hm_loss = focal_loss_centernet(pd['hm'], targets['heatmaps'][idx]) * w['cls_weight']
-            pred_boxes = torch.cat([pd[name].float() for name in self.separate_head_cfg.HEAD_ORDER], dim=1)
-            reg = reg_loss_centernet(pred_boxes, targets['masks'][idx], targets['inds'][idx], targets['target_boxes'][idx])
+            if gdense.FUSE_SHORTCUT and pd['hm'].is_cuda and pd['hm'].dtype in (torch.bfloat16, torch.float32):
+                # one launch per direction instead of the ~20 elementwise passes of sigmoid / clamp / focal loss; the regression maps
+                # gathered at the object cells before they are concatenated
+                hm_loss, pd['hm'] = FocalLossCenterNetFn.apply(pd['hm'], targets['heatmaps'][idx])
+                hm_loss = hm_loss * w['cls_weight']
+                reg = reg_loss_centernet_maps([pd[name] for name in self.separate_head_cfg.HEAD_ORDER], targets['masks'][idx],
+                                              targets['inds'][idx], targets['target_boxes'][idx])
+            else:
+                pd['hm'] = self.sigmoid(pd['hm'].float())
+                hm_loss = focal_loss_centernet(pd['hm'], targets['heatmaps'][idx]) * w['cls_weight']
+                pred_boxes = torch.cat([pd[name].float() for name in self.separate_head_cfg.HEAD_ORDER], dim=1)
+                reg = reg_loss_centernet(pred_boxes, targets['masks'][idx], targets['inds'][idx], targets['target_boxes'][idx])
             loc_loss = (reg * reg.new_tensor(w['code_weights'])).sum() * w['loc_weight']
             loss = loss + hm_loss + loc_loss
             tb_dict['hm_loss_head_%d' % idx] = hm_loss.detach()

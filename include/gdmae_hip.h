@@ -774,6 +774,16 @@ int gdmae_center_head_targets(const float* gt_boxes, int B, int n_max, int box_d
                               int n_cls, const float* pc_range /* host [x0, y0] */, const float* voxel_size /* host [vx, vy] */,
                               float feature_map_stride, int fw, int fh, int num_max_objs, double gaussian_overlap, int min_radius,
                               float* heatmap, float* ret_boxes, long long* inds, long long* mask, void* workspace, void* stream);
+/* CornerNet focal loss of CenterHead on the clamped sigmoid of the heat-map logits (loss_utils.py:273-312, center_head.py:236-238) as one
+ * pass per direction.  logits: element (b, c, y, x) at strides_byxc[0] b + [1] y + [2] x + [3] c (elements; bf16 or fp32: the column slice
+ * of the channels-last map the head convolution wrote), gt (B, C, H, W) fp32.  fwd: prob (optional, (B, C, H, W) fp32) = the clamped
+ * sigmoid, partials = gdmae_focal_loss_rows() x 3 floats of scratch, out4 = {loss, positive sum, negative sum, #pos}.  bwd: dlogits
+ * (B, H, W, C) channels-last, fp32 or bf16 = grad_out[0] * d loss / d logits. */
+int gdmae_focal_loss_rows(void);
+int gdmae_focal_loss_fwd(const void* logits, int logits_bf16, const long long* strides_byxc, const float* gt, int B, int C, int H, int W,
+                         float* prob, float* partials, float* out4, void* stream);
+int gdmae_focal_loss_bwd(const void* logits, int logits_bf16, const long long* strides_byxc, const float* gt, int B, int C, int H, int W,
+                         const float* out4, const float* grad_out, void* dlogits, int dlogits_bf16, void* stream);
 /* The same + iou_boxes (B, num_max_objs, 7) fp32 = the ground-truth box of every assigned slot (zero elsewhere): the target of the
  * IoU-aware head (center_head.py:118,161; tools/cfgs/waymo_models/gd_mae_iou.yaml:228); null = not wanted. */
 int gdmae_center_head_targets_iou(const float* gt_boxes, int B, int n_max, int box_dim, const int* class_map, int n_class_total,

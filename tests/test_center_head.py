@@ -407,3 +407,37 @@ def test_iou_rectified_multi_class_nms_decode():
     rois, scores, labels = head.reorder_rois_for_refining(B, out)
     assert rois.shape == (B, 3, 7) and float(rois[1, 1:].abs().sum()) == 0 and labels.dtype == torch.int64 and int(labels[1, 1]) == 0
     assert torch.equal(rois[0], out[0]["pred_boxes"]) and torch.equal(scores[1, :1], out[1]["pred_scores"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,n_pos", [(torch.float32, 40), (torch.bfloat16, 40), (torch.float32, 0)])
+def test_fused_focal_loss_matches_the_torch_formula(dtype, n_pos):
+    """FocalLossCenterNetFn (gdmae_focal_loss_fwd / _bwd: one pass per direction) against the written-out formula of the reference
+    (loss_utils.py:273-312 on clamp(sigmoid(x), 1e-4, 1 - 1e-4), center_head.py:236-238) evaluated by torch in fp64 on the same logits:
+    loss 1e-5, the clamped sigmoid 1e-6, the gradient 1e-4 relative (bf16 logits: within the bf16 rounding of the result) - logits as a
+    column slice of a channels-last padded map (the layout the head convolution leaves), with saturated entries on both sides of the
+    clamp and, in one case, no positive cell at all (the -neg_loss branch)."""
+    from pcdet.models.dense_heads.center_head import FocalLossCenterNetFn, focal_loss_centernet
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5 + n_pos)
+    B, C, H, W = 2, 3, 37, 29
+    ymap = (torch.randn(B, H, W, 32, generator=g) * 3).to(dtype)
+    ymap[0, 0, :5, 0] = 12.0                                   # sigmoid above 1 - 1e-4: no gradient through the clamp
+    ymap[0, 1, :5, 1] = -12.0
+    gt = torch.rand(B, C, H, W, generator=g) ** 3 * 0.999
+    idx = torch.randperm(B * C * H * W, generator=g)[:n_pos]
+    gt.view(-1)[idx] = 1.0
+    ymap = ymap.to(dev)
+    x = ymap[..., :C].permute(0, 3, 1, 2).detach().requires_grad_(True)       # (B, C, H, W) view, strides (H W 32, 1, W 32, 32)
+    loss, prob = FocalLossCenterNetFn.apply(x, gt.to(dev))
+    (loss * 1.7).backward()
+    xr = x.detach().double().cpu().requires_grad_(True)
+    pr = torch.clamp(xr.sigmoid(), min=1e-4, max=1 - 1e-4)
+    ref = focal_loss_centernet(pr, gt.double())
+    (ref * 1.7).backward()
+    assert abs(float(loss) - float(ref)) <= 1e-5 * abs(float(ref)), (float(loss), float(ref))
+    assert torch.allclose(prob.cpu().double(), pr.detach(), rtol=1e-6, atol=1e-7)
+    got, want = x.grad.double().cpu(), xr.grad
+    tol = 1e-4 if dtype == torch.float32 else 2 ** -7
+    assert float((got - want).abs().max()) <= tol * float(want.abs().max()), float((got - want).abs().max() / want.abs().max())
+    assert float(got[0, 0, 0, :5].abs().max()) == 0.0 and float(got[0, 1, 1, :5].abs().max()) == 0.0
