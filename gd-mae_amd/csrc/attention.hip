@@ -431,8 +431,43 @@ __global__ __launch_bounds__(1024) void k_sum_partials(const float* __restrict__
 __global__ __launch_bounds__(1024) void k_weighted_mean_finish(const float* __restrict__ term, const float* __restrict__ weights,
                                                                long long n, float* __restrict__ out) {
   __shared__ float sh[1024 / GD_WAVE];
-  const float t = gd_block1024_sum(term, n, sh);
-  const float w = gd_block1024_sum(weights, n, sh);
+  __shared__ float sh2[1024 / GD_WAVE];
+  // both arrays in one sweep, four 16-byte loads of each in flight per thread (a single workgroup walks 2 x 127 k floats: the launch is
+  // a chain of round trips - 30 us as two sweeps with four scalar loads in flight); fixed association order
+  float t4[4] = {0.f, 0.f, 0.f, 0.f}, w4[4] = {0.f, 0.f, 0.f, 0.f};
+  const long long n4 = ((reinterpret_cast<unsigned long long>(term) | reinterpret_cast<unsigned long long>(weights)) & 15ull) == 0 ? n / 4 : 0;
+  const float4* tv = reinterpret_cast<const float4*>(term);
+  const float4* wv = reinterpret_cast<const float4*>(weights);
+  for (long long i0 = threadIdx.x; i0 < n4; i0 += 4 * 1024) {
+    float4 a[4], b[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long long i = i0 + u * 1024 < n4 ? i0 + u * 1024 : n4 - 1;       // unconditional (clamped), masked below
+      a[u] = tv[i];
+      b[u] = wv[i];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float m = i0 + u * 1024 < n4 ? 1.f : 0.f;
+      t4[u] = fmaf(m, (a[u].x + a[u].y) + (a[u].z + a[u].w), t4[u]);
+      w4[u] = fmaf(m, (b[u].x + b[u].y) + (b[u].z + b[u].w), w4[u]);
+    }
+  }
+  for (long long i = 4 * n4 + threadIdx.x; i < n; i += 1024) {
+    t4[0] += term[i];
+    w4[0] += weights[i];
+  }
+  const float ta = gd_wave_sum((t4[0] + t4[1]) + (t4[2] + t4[3])), wa = gd_wave_sum((w4[0] + w4[1]) + (w4[2] + w4[3]));
+  if ((threadIdx.x & 63) == 0) {
+    sh[threadIdx.x / 64] = ta;
+    sh2[threadIdx.x / 64] = wa;
+  }
+  __syncthreads();
+  float t = 0.f, w = 0.f;
+  for (int k = 0; k < 1024 / GD_WAVE; ++k) {
+    t += sh[k];
+    w += sh2[k];
+  }
   if (threadIdx.x == 0) {
     const float inv = w > 0.f ? 1.0f / fmaxf(w, 1e-30f) : 0.f;
     out[0] = t * inv;
