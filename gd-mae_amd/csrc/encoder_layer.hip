@@ -195,20 +195,24 @@ __global__ __launch_bounds__(256) void k_layer_tail(TailJobs T) {
     __shared__ float shw[4];
     // 16-byte loads, four of them in flight per thread: the ~50 k partials of a layer are one latency-bound chain per thread
     // otherwise (this single workgroup was the longest-running part of the launch)
+    // (round 5: sixteen in flight, requested unconditionally on a clamped index - with four the workgroup needed twelve dependent
+    // round trips for the ~50 k partials of a d = 256 layer and set the duration of the whole launch: 13.7 us)
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     const long long n4 = T.n_part >> 2;
     const float4* p4 = reinterpret_cast<const float4*>(T.tau_part);
-    long long i = threadIdx.x;
-    for (; i + 3 * 256 < n4; i += 4 * 256) {
-      const float4 v0 = p4[i], v1 = p4[i + 256], v2 = p4[i + 512], v3 = p4[i + 768];
-      a0 += (v0.x + v0.y) + (v0.z + v0.w);
-      a1 += (v1.x + v1.y) + (v1.z + v1.w);
-      a2 += (v2.x + v2.y) + (v2.z + v2.w);
-      a3 += (v3.x + v3.y) + (v3.z + v3.w);
-    }
-    for (; i < n4; i += 256) {
-      const float4 v0 = p4[i];
-      a0 += (v0.x + v0.y) + (v0.z + v0.w);
+    for (long long i0 = threadIdx.x; i0 < n4; i0 += 16 * 256) {
+      float4 v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = p4[i0 + u * 256 < n4 ? i0 + u * 256 : n4 - 1];
+#pragma unroll
+      for (int u = 0; u < 16; u += 4) {
+        const float m0 = i0 + u * 256 < n4 ? 1.f : 0.f, m1 = i0 + (u + 1) * 256 < n4 ? 1.f : 0.f;
+        const float m2 = i0 + (u + 2) * 256 < n4 ? 1.f : 0.f, m3 = i0 + (u + 3) * 256 < n4 ? 1.f : 0.f;
+        a0 = fmaf(m0, (v[u].x + v[u].y) + (v[u].z + v[u].w), a0);
+        a1 = fmaf(m1, (v[u + 1].x + v[u + 1].y) + (v[u + 1].z + v[u + 1].w), a1);
+        a2 = fmaf(m2, (v[u + 2].x + v[u + 2].y) + (v[u + 2].z + v[u + 2].w), a2);
+        a3 = fmaf(m3, (v[u + 3].x + v[u + 3].y) + (v[u + 3].z + v[u + 3].w), a3);
+      }
     }
     for (long long j = (n4 << 2) + threadIdx.x; j < T.n_part; j += 256) a1 += T.tau_part[j];
     const float w = gd_wave_sum((a0 + a1) + (a2 + a3));
