@@ -112,6 +112,36 @@ class BNReLURowsCat(torch.autograd.Function):
         return tuple(grads)
 
 
+class _BnChannels:
+    """The slice [c0, c1) of a BatchNorm module's running statistics, as the fused layers read a module (PointLayer2Max)."""
+
+    def __init__(self, bn, c0, c1, count_batch):
+        self.training, self.momentum = bn.training, bn.momentum
+        self.running_mean = None if bn.running_mean is None else bn.running_mean[c0:c1]
+        self.running_var = None if bn.running_var is None else bn.running_var[c0:c1]
+        # num_batches_tracked counts batches, not channel blocks: only the first block increments the module's counter
+        self.num_batches_tracked = bn.num_batches_tracked if count_batch else torch.zeros_like(bn.num_batches_tracked)
+
+
+def point_layer2_max(y1, row_pillar, weight, bn, pt_off):
+    """PointLayer2Max for 64 -> 128 and - config E's DynVFE (64 -> 256, gd_mae ONCE config) - for wider layers as independent
+    128-channel blocks: Linear without bias, BatchNorm and the pillar maximum are all per OUTPUT channel, so block b of the result is
+    the fused layer on rows [128 b, 128 b + 128) of the weight / BatchNorm vectors (the recompute-fused kernels of csrc/vfe_layer2.hip
+    are written for 128 outputs); the input gradients of the blocks meet in one pass (ops.FanOut).  -> (M, C) fp32."""
+    C = weight.shape[0]
+    if C == 128:
+        return PointLayer2Max.apply(y1, row_pillar, weight, bn.weight, bn.bias, bn.eps, pt_off, bn)[0]
+    assert C % 128 == 0
+    nb = C // 128
+    ys = ops.FanOut.apply(y1, nb) if (y1.requires_grad and torch.is_grad_enabled()) else (y1,) * nb
+    outs = []
+    for b in range(nb):
+        c0, c1 = 128 * b, 128 * (b + 1)
+        outs.append(PointLayer2Max.apply(ys[b], row_pillar, weight[c0:c1], bn.weight[c0:c1], bn.bias[c0:c1], bn.eps, pt_off,
+                                         _BnChannels(bn, c0, c1, b == 0))[0])
+    return torch.cat(outs, dim=1)
+
+
 class BNReLUSegmentMax(torch.autograd.Function):
     """max over each pillar's points of relu(BatchNorm1d_train(x)); returns (out (M, C) fp32, mean, biased var)."""
 

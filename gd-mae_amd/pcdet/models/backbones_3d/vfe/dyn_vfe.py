@@ -52,7 +52,7 @@ class DynVFE(VFETemplate):
             # last layer (bf16 mode): Linear + BatchNorm + ReLU + pillar max with the pre-activation never stored; it wants
             # the rows of the first layer in pillar-major order
             last = (first and self.max_layer and nl == 2 and torch.is_autocast_enabled() and mlp[3].bias is None
-                    and tuple(mlp[3].weight.shape) == (128, 64) and vox.points_pm is not None)
+                    and mlp[3].weight.shape[1] == 64 and mlp[3].weight.shape[0] in (128, 256) and vox.points_pm is not None)
             x = None if first else ops.decorate_points(vox)
             for k in range(nl):
                 lin, bn = mlp[3 * k], mlp[3 * k + 1]
@@ -60,7 +60,7 @@ class DynVFE(VFETemplate):
                     x, _, _ = gvfe.PointLayer1.apply(vox, lin.weight, bn.weight, bn.bias, bn.eps, bn, last)
                     continue
                 if k == nl - 1 and last:
-                    x, _, _ = gvfe.PointLayer2Max.apply(x, vox.row_pillar, lin.weight, bn.weight, bn.bias, bn.eps, vox.pt_off, bn)
+                    x = gvfe.point_layer2_max(x, vox.row_pillar, lin.weight, bn, vox.pt_off)
                     continue
                 x = ops.linear(x, lin.weight, lin.bias)
                 if k < nl - 1:
