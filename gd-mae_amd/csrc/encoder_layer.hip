@@ -130,32 +130,28 @@ struct TailJobs {
   float* dtau;
 };
 __device__ inline void tail_splitk(const SplitkJobs& J, int job) {
-  __shared__ float4 sh[3][64];
+  // round 5: one 16-byte column per thread, ALL slices of it requested before the first is added (eight at a time, unconditional on
+  // a clamped slice index), added in slice order - 256 contiguous columns per workgroup instead of 64 columns x 4 slice groups
+  // meeting in LDS: a quarter of the workgroups, no barrier, 4 KB per wavefront-row of a slice
   const long long P4 = J.P4[job];
   const int S = J.S[job];
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const long long i = blockIdx.x * 64ll + tx;
-  if (blockIdx.x * 64ll >= P4) return;                 // uniform per workgroup
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (i < P4) {
-    const int s0 = (S * ty) / 4, s1 = (S * (ty + 1)) / 4;
-    const float4* p = (const float4*)J.part[job] + i;
-#pragma unroll 4
-    for (int s = s0; s < s1; ++s) {
-      const float4 v = p[(long long)s * P4];
-      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  const long long i = blockIdx.x * 256ll + threadIdx.x;
+  if (blockIdx.x * 256ll >= P4) return;                // uniform per workgroup
+  if (i >= P4) return;
+  const float4* p = (const float4*)J.part[job] + i;
+  float4* d = (float4*)J.dst[job] + i;
+  float4 acc = *d;
+  for (int s0 = 0; s0 < S; s0 += 8) {
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = p[(long long)(s0 + u < S ? s0 + u : S - 1) * P4];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float m = s0 + u < S ? 1.f : 0.f;
+      acc.x = fmaf(m, v[u].x, acc.x); acc.y = fmaf(m, v[u].y, acc.y); acc.z = fmaf(m, v[u].z, acc.z); acc.w = fmaf(m, v[u].w, acc.w);
     }
   }
-  if (ty > 0) sh[ty - 1][tx] = acc;
-  __syncthreads();
-  if (ty == 0 && i < P4) {
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { const float4 v = sh[k][tx]; acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
-    float4* d = (float4*)J.dst[job] + i;
-    const float4 o = *d;
-    acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
-    *d = acc;
-  }
+  *d = acc;
 }
 __device__ inline void tail_vectors(const AccJobs& a) {
   __shared__ float sh[16][17];
@@ -852,7 +848,7 @@ int grouped_dw_and_tail(const gdmae_layer_args* a, const Saved& s, const Scratch
   T.a = j;
   T.tau_part = (const float*)w.apart; T.n_part = pbase; T.tau = a->tau; T.tau_min = a->tau_min; T.dtau = a->dtau;
   long long gx = (cols + 15) / 16;
-  for (int q = 0; q < SJ.count; ++q) gx = (SJ.P4[q] + 63) / 64 > gx ? (SJ.P4[q] + 63) / 64 : gx;
+  for (int q = 0; q < SJ.count; ++q) gx = (SJ.P4[q] + 255) / 256 > gx ? (SJ.P4[q] + 255) / 256 : gx;
   double tail_bytes = 4.0 * pbase;
   for (int q = 0; q < SJ.count; ++q) tail_bytes += 16.0 * SJ.P4[q] * (SJ.S[q] + 2);
   for (int q = 0; q < j.count; ++q) tail_bytes += 4.0 * j.len[q] * (j.nblk[q] + 2);

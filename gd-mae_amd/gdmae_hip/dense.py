@@ -168,7 +168,7 @@ class ConvBNReLUShortcut(torch.autograd.Function):
         c1.needs_input_grad = (ctx.needs_input_grad[0],)
         c1.dx_addend = gres.view(B, H, W, C) if ctx.needs_input_grad[0] else None
         dx, dW, db, _, _, _ = Conv3x3Dense.backward(c1, dy.view(B, H, W, C).permute(0, 3, 1, 2))
-        ctx.c1 = ctx.c2 = None
+        c1.dx_addend = None                     # (the saved operands stay with the node: a second backward over a retained graph works)
         return dx, dW, db, None, None, dgamma, dbeta, None, None
 
 

@@ -717,7 +717,11 @@ def test_prefetched_plan_is_identical_to_inline_plan():
 # biases of stage 2's first block, column sums over a few hundred rows that cancel almost completely - went from 4.4 % to 9.1 % while
 # the other cases stayed at 3 - 4 % (tools/ab_bench_mode_golden.py with GDMAE_SPCONV_STATS=0 / 1: 4.4 | 9.1, 4.0 | 3.6, 2.7 | 3.4 %).
 # Its bound is therefore 2 x the larger sample.
-BENCH_LOSS_REL = {"kitti_b2": 1e-3, "kitti_b2_m75": 1e-4, "waymo_b1": 1.5e-4, "once_e_b1": 2.4e-4}
+# once_e_b1: 1.2e-4 with DynVFE's 64 -> 256 layer op by op (pre-activation rounded to bf16), 2.8e-4 since that layer runs on the
+# recompute-fused kernels (pre-activation kept in fp32: closer to fp32 on the VFE's own outputs and gradients -
+# test_vfe_point_layer_equals_op_by_op_layer[once_e_b1] - while the model's loss lands on another sample of the bf16 noise; its worst
+# gradient-norm deviation went from 4.1 to 3.1 %).
+BENCH_LOSS_REL = {"kitti_b2": 1e-3, "kitti_b2_m75": 1e-4, "waymo_b1": 1.5e-4, "once_e_b1": 5.6e-4}
 BENCH_NORM_REL = {"kitti_b2": 0.18, "kitti_b2_m75": 0.08, "waymo_b1": 0.07, "once_e_b1": 0.09}
 BENCH_TAU_ABS = 0.5
 
@@ -1166,7 +1170,7 @@ def test_native_conv_block_equals_op_by_op_block():
 
 
 @pytest.mark.parametrize("autocast", [False, True])
-@pytest.mark.parametrize("name", ["kitti_b2", "waymo_b1"])
+@pytest.mark.parametrize("name", ["kitti_b2", "waymo_b1", "once_e_b1"])
 def test_vfe_point_layer_equals_op_by_op_layer(name, autocast):
     """gdmae_vfe_point_layer_fwd/bwd (decoration + Linear + BatchNorm1d + ReLU with the pre-activation recomputed in
     MFMA accumulators) and, in bf16 mode, gdmae_vfe_max_layer_fwd/bwd (Linear + BatchNorm1d + ReLU + pillar max, same
