@@ -244,6 +244,7 @@ class FanOut(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, k):
         ctx.k = int(k)
+        ctx.set_materialize_grads(False)         # a handle nobody consumed arrives as None, not as a zero map in another layout
         return tuple(x.view_as(x) for _ in range(ctx.k))
 
     @staticmethod

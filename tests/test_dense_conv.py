@@ -133,3 +133,64 @@ def test_dense_conv3x3_statistics_epilogue(B, H, W, cin, cout, dil):
         b = gdense.bn_relu_2d(y1, bn2, None, None)
     assert float((a.float() - b.float()).abs().max()) <= 2e-2 * float(b.float().abs().max())       # one bf16 ulp where the fold differs in the last bit
     assert torch.allclose(bn.running_mean, bn2.running_mean, rtol=1e-5, atol=1e-7) and torch.allclose(bn.running_var, bn2.running_var, rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("B,H,W,c,dil", [(2, 20, 27, 128, 1), (1, 17, 16, 128, 2), (1, 9, 11, 64, 1)])
+def test_shortcut_block_as_one_node_matches_the_two_node_form(B, H, W, c, dil):
+    """dense.ConvBNReLUShortcut (x + relu(bn(conv(x))) as ONE autograd node whose input-gradient convolution adds the shortcut's gradient
+    in its store pass: gdmae_conv3x3_dense_add) against the two-node form (Conv3x3Dense, then BNReLURows with the residual, the engine
+    adding the two gradients of x): the same kernels on the same operands - output, running statistics and the parameter gradients
+    identical bit for bit, dx identical up to the one bf16 rounding the engine's addition performs in a different place (the two-node
+    form rounds dx_conv, then the sum; the fused store pass does exactly that too: bit-identical as well)."""
+    import os
+    from gdmae_hip import dense as gdense
+    g = torch.Generator().manual_seed(c + dil + H)
+    x0 = torch.randn(B, c, H, W, generator=g).to(dev()).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(B, c, H, W, generator=g).to(dev()).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w0 = torch.randn(c, c, 3, 3, generator=g) * (2.0 / (9 * c)) ** 0.5
+    res = {}
+    for fuse in (True, False):
+        gdense.FUSE_SHORTCUT = fuse
+        try:
+            block = nn.Sequential(nn.Conv2d(c, c, 3, padding=dil, dilation=dil, bias=False), nn.BatchNorm2d(c, eps=1e-3, momentum=0.01),
+                                  nn.ReLU()).to(dev()).train()
+            with torch.no_grad():
+                block[0].weight.copy_(w0)
+                block[1].weight.copy_(torch.linspace(0.5, 1.5, c))
+                block[1].bias.copy_(torch.linspace(-0.3, 0.3, c))
+            x = x0.clone().requires_grad_(True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = gdense.conv_bn_relu(block, x, shortcut=x)
+            y.backward(gy)
+            res[fuse] = (y.detach().clone(), x.grad.clone(), block[0].weight.grad.clone(), block[1].weight.grad.clone(), block[1].bias.grad.clone(),
+                         block[1].running_mean.clone(), block[1].running_var.clone())
+        finally:
+            gdense.FUSE_SHORTCUT = os.environ.get("GDMAE_DENSE_FUSE", "1") != "0"
+    for a, b in zip(res[True], res[False]):
+        assert torch.equal(a, b)
+    # ... and the sum is what torch computes from the two-node form's pieces: y = relu(bn(conv x)) + x in bf16
+    assert y.dtype == torch.bfloat16 and y.shape == x0.shape
+
+
+def test_fan_out_sums_the_gradients_in_one_pass():
+    """ops.FanOut: k handles on a bf16 channels-last map; the backward is gdmae_sum_bf16 (fp32 accumulation, one rounding) - against the
+    fp64 sum of the bf16 gradients (half a bf16 ulp), a missing consumer (None gradient) and a consumer whose gradient has another
+    layout (the engine's own sum takes over: same values within the bf16 rounding of the pairwise additions)."""
+    from gdmae_hip import ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 64, 13, 9, generator=g).to(dev()).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    ws = [torch.randn(2, 64, 13, 9, generator=g).to(dev()).to(torch.bfloat16).contiguous(memory_format=torch.channels_last) for _ in range(5)]
+    ys = ops.FanOut.apply(x, 5)
+    loss = sum((y.float() * w.float()).sum() for y, w in zip(ys[:4], ws[:4]))        # the fifth handle has no consumer
+    loss.backward()
+    ref = sum(w.double() for w in ws[:4])
+    assert x.grad.dtype == torch.bfloat16 and x.grad.stride() == x.stride()
+    assert float((x.grad.double() - ref).abs().max()) <= 2 ** -8 * float(ref.abs().max())
+    x.grad = None
+    ys = ops.FanOut.apply(x, 2)
+    (ys[0].float() * ws[0].float()).sum().backward(retain_graph=False)
+    assert torch.equal(x.grad, ws[0])                                                   # a single gradient passes through untouched
+    x.grad = None
+    ys = ops.FanOut.apply(x, 2)
+    ((ys[0].float() * ws[0].float()).sum() + (ys[1].contiguous().float() * ws[1].contiguous().float()).sum()).backward()
+    assert float((x.grad.double() - (ws[0].double() + ws[1].double())).abs().max()) <= 2 ** -7 * float((ws[0].double() + ws[1].double()).abs().max())
