@@ -10,10 +10,24 @@
 
 __global__ __launch_bounds__(256) void k_sq_partials(const float* __restrict__ g, long long n, float* __restrict__ part) {
   __shared__ float sh[4];
-  float acc = 0.f;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
-    acc = fmaf(g[i], g[i], acc);
-  acc = gd_wave_sum(acc);
+  // 16-byte loads, four in flight per thread (requested unconditionally on a clamped index): the 32 MB gradient buffer moved at
+  // 1.9 TB/s through 4-byte accesses
+  float a4[4] = {0.f, 0.f, 0.f, 0.f};
+  const long long n4 = (reinterpret_cast<unsigned long long>(g) & 15ull) == 0 ? n / 4 : 0;
+  const float4* gv = reinterpret_cast<const float4*>(g);
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i0 = blockIdx.x * (long long)blockDim.x + threadIdx.x; i0 < n4; i0 += 4 * stride) {
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = gv[i0 + u * stride < n4 ? i0 + u * stride : n4 - 1];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float m = i0 + u * stride < n4 ? 1.f : 0.f;
+      a4[u] = fmaf(m, fmaf(v[u].x, v[u].x, fmaf(v[u].y, v[u].y, fmaf(v[u].z, v[u].z, v[u].w * v[u].w))), a4[u]);
+    }
+  }
+  for (long long i = 4 * n4 + blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += stride) a4[0] = fmaf(g[i], g[i], a4[0]);
+  float acc = gd_wave_sum((a4[0] + a4[1]) + (a4[2] + a4[3]));
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x / 64] = acc;
   __syncthreads();
   if (threadIdx.x == 0) part[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
