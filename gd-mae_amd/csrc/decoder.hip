@@ -750,13 +750,21 @@ __global__ __launch_bounds__(256) void k_border_partial(const void* __restrict__
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = 0.f;
     if (tr < slots)
-      for (int i = tr; i < len; i += slots) {
-        const int y = e == 0 ? 0 : (e == 1 ? H - 1 : i);
-        const int x = e == 2 ? 0 : (e == 3 ? W - 1 : i);
-        float v[8];
-        dec_ld8<BF>(gd_y_row<BF ? 2 : 4>(Y, T, b, y, x, H, W, C), c, v);
+      for (int i0 = tr; i0 < len; i0 += 4 * slots) {       // four sites in flight (tile lookup + row: two dependent loads each), added
+        float v[4][8];                                      // in the order of the one-at-a-time walk (bit-identical sums)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] += v[j];
+        for (int u = 0; u < 4; ++u) {
+          const int i = i0 + u * slots < len ? i0 + u * slots : len - 1;
+          const int y = e == 0 ? 0 : (e == 1 ? H - 1 : i);
+          const int x = e == 2 ? 0 : (e == 3 ? W - 1 : i);
+          dec_ld8<BF>(gd_y_row<BF ? 2 : 4>(Y, T, b, y, x, H, W, C), c, v[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const bool ok = i0 + u * slots < len;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[j] = ok ? acc[j] + v[u][j] : acc[j];
+        }
       }
     if (tr < slots) {
 #pragma unroll
