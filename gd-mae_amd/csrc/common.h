@@ -203,6 +203,9 @@ __device__ inline float gd_wave_max(float v) {
 #define GD_SCAN_TILE (GD_SCAN_BLOCK * GD_SCAN_ITEMS)
 #define GD_SCAN_SINGLE_MAX (1 << 16)
 #define GD_SCAN_MAX_BLOCKS 65536
+#ifndef GD_SCAN_STRIPED
+#define GD_SCAN_STRIPED 1      // 0: experiment switch (blocked evaluation order of the look-back scans' functors)
+#endif
 
 template <typename T, typename LoadF, typename StoreF>
 __global__ __launch_bounds__(1024) void gd_scan_single_kernel(long long n, LoadF load, StoreF store, T* total) {
@@ -345,11 +348,18 @@ struct GdNoTotal {
 };
 
 // one tile of a look-back scan (the whole workgroup): `nb` tiles take part, every one of them must run this exactly once
-template <typename T, typename LoadF, typename StoreF, typename TotalF>
+// STRIPED (4-byte T): load() and store() are evaluated in striped order (element k * BLOCK + thread of the tile: the 64 lanes of a load
+// instruction touch adjacent elements) and the values / prefixes change places through a padded LDS tile; the blocked order (a
+// thread's 16 consecutive elements) makes every instruction of a functor with indexed reads touch 64 cache lines - the strided-conv
+// output scan (nine map lookups per cell, 107 workgroups) took 166 us that way.  Same values, same prefixes.
+__device__ __forceinline__ int gd_scan_pad(int x) { return x + (x >> 5); }
+template <typename T, typename LoadF, typename StoreF, typename TotalF, bool STRIPED = false>
 __device__ __forceinline__ void gd_scan_lb_tile(long long n, const LoadF& load, const StoreF& store, const TotalF& on_total, T* total,
                                                 unsigned* ticket, unsigned* flags, unsigned long long* agg, unsigned long long* incl,
                                                 const unsigned nb) {
+  static_assert(!STRIPED || sizeof(T) == 4, "striped evaluation: 4-byte values");
   constexpr int W = GdScanWords<T>::N;
+  __shared__ T s_xch[STRIPED ? GD_SCAN_TILE + GD_SCAN_TILE / 32 : 1];
   __shared__ T smem[GD_SCAN_BLOCK / GD_WAVE + 1];
   __shared__ unsigned s_tile;
   __shared__ T s_excl;
@@ -359,7 +369,23 @@ __device__ __forceinline__ void gd_scan_lb_tile(long long n, const LoadF& load, 
   const long long base = (long long)tile * GD_SCAN_TILE;
   T vals[GD_SCAN_ITEMS];
   T acc = gd_zero<T>();
-  if (base + GD_SCAN_TILE <= n) {      // full tile: no per-element bounds branch, the loads of a thread go out together
+  if constexpr (STRIPED) {
+    if (base + GD_SCAN_TILE <= n) {
+#pragma unroll
+      for (int k = 0; k < GD_SCAN_ITEMS; ++k) vals[k] = load(base + k * GD_SCAN_BLOCK + (int)threadIdx.x);
+    } else {
+#pragma unroll
+      for (int k = 0; k < GD_SCAN_ITEMS; ++k) {
+        const long long i = base + k * GD_SCAN_BLOCK + (int)threadIdx.x;
+        vals[k] = (i < n) ? load(i) : gd_zero<T>();
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < GD_SCAN_ITEMS; ++k) s_xch[gd_scan_pad(k * GD_SCAN_BLOCK + (int)threadIdx.x)] = vals[k];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < GD_SCAN_ITEMS; ++k) vals[k] = s_xch[gd_scan_pad((int)threadIdx.x * GD_SCAN_ITEMS + k)];
+  } else if (base + GD_SCAN_TILE <= n) {      // full tile: no per-element bounds branch, the loads of a thread go out together
 #pragma unroll
     for (int k = 0; k < GD_SCAN_ITEMS; ++k) vals[k] = load(base + (long long)threadIdx.x * GD_SCAN_ITEMS + k);
   } else {
@@ -433,6 +459,27 @@ __device__ __forceinline__ void gd_scan_lb_tile(long long n, const LoadF& load, 
   }
   __syncthreads();
   T run = s_excl + ex;
+  if constexpr (STRIPED) {
+    // blocked prefixes -> LDS (the values are still there: every thread rewrites only the slots it read) -> striped stores
+    T pre[GD_SCAN_ITEMS];
+#pragma unroll
+    for (int k = 0; k < GD_SCAN_ITEMS; ++k) {
+      pre[k] = run;
+      run = run + vals[k];
+    }
+#pragma unroll
+    for (int k = 0; k < GD_SCAN_ITEMS; ++k) vals[k] = s_xch[gd_scan_pad(k * GD_SCAN_BLOCK + (int)threadIdx.x)];      // this thread's striped values
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < GD_SCAN_ITEMS; ++k) s_xch[gd_scan_pad((int)threadIdx.x * GD_SCAN_ITEMS + k)] = pre[k];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < GD_SCAN_ITEMS; ++k) {
+      const long long i = base + k * GD_SCAN_BLOCK + (int)threadIdx.x;
+      if (i < n) store(i, s_xch[gd_scan_pad(k * GD_SCAN_BLOCK + (int)threadIdx.x)], vals[k]);
+    }
+    return;
+  }
 #pragma unroll
   for (int k = 0; k < GD_SCAN_ITEMS; ++k) {
     const long long i = base + (long long)threadIdx.x * GD_SCAN_ITEMS + k;
@@ -445,7 +492,7 @@ template <typename T, typename LoadF, typename StoreF, typename TotalF>
 __global__ __launch_bounds__(GD_SCAN_BLOCK) void gd_scan_lb_kernel(long long n, LoadF load, StoreF store, TotalF on_total, T* total,
                                                                   unsigned* ticket, unsigned* flags, unsigned long long* agg,
                                                                   unsigned long long* incl) {
-  gd_scan_lb_tile<T>(n, load, store, on_total, total, ticket, flags, agg, incl, gridDim.x);
+  gd_scan_lb_tile<T, LoadF, StoreF, TotalF, GD_SCAN_STRIPED && sizeof(T) == 4>(n, load, store, on_total, total, ticket, flags, agg, incl, gridDim.x);
 }
 
 // the cross-workgroup words of a scan inside its (zeroed) state

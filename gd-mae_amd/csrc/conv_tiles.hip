@@ -511,6 +511,18 @@ __global__ __launch_bounds__(256) void k_ct_stats_reduce(const float* __restrict
     const int r0 = blockIdx.x * chunk, r1 = r0 + chunk < n_act ? r0 + chunk : n_act;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     int r = r0;
+    for (; r + 15 < r1; r += 16) {                 // sixteen rows in flight, added in the order of the four-row loop below (same bits)
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = part[(long long)(r + u) * 256 + tid];
+#pragma unroll
+      for (int u = 0; u < 16; u += 4) {
+        a0 += v[u];
+        a1 += v[u + 1];
+        a2 += v[u + 2];
+        a3 += v[u + 3];
+      }
+    }
     for (; r + 3 < r1; r += 4) {
       a0 += part[(long long)r * 256 + tid];
       a1 += part[(long long)(r + 1) * 256 + tid];
@@ -528,8 +540,14 @@ __global__ __launch_bounds__(256) void k_ct_stats_reduce(const float* __restrict
   int c[9];
 #pragma unroll
   for (int k = 0; k < 9; ++k) c[k] = 0;
-  for (int i = tid; i < n_act; i += 256) {
-    const int tile = tile_list[i];
+  for (int i0 = tid; i0 < n_act; i0 += 8 * 256) {        // eight list entries in flight per thread (one workgroup walks 12 k of them)
+   int tl[8];
+#pragma unroll
+   for (int u = 0; u < 8; ++u) tl[u] = tile_list[i0 + u * 256 < n_act ? i0 + u * 256 : n_act - 1];
+#pragma unroll
+   for (int u = 0; u < 8; ++u) {
+    if (i0 + u * 256 >= n_act) continue;
+    const int tile = tl[u];
     const int tx = tile % TW, ty = (tile / TW) % TH;
     const int y0 = ty * 8, y1 = y0 + 8 < H ? y0 + 8 : H, x0 = tx * 8, x1 = x0 + 8 < W ? x0 + 8 : W;
     const int ry[3] = {y0 == 0 ? 1 : 0, 0, y1 == H ? 1 : 0};
@@ -539,6 +557,7 @@ __global__ __launch_bounds__(256) void k_ct_stats_reduce(const float* __restrict
     for (int cy = 0; cy < 3; ++cy)
 #pragma unroll
       for (int cx = 0; cx < 3; ++cx) c[cy * 3 + cx] += (cy == 1 ? my : ry[cy]) * (cx == 1 ? mx : rx[cx]);
+   }
   }
 #pragma unroll
   for (int k = 0; k < 9; ++k)
