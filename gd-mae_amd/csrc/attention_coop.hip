@@ -13,6 +13,13 @@
 
 using namespace attn;
 
+#ifndef ATTN_K64
+#define ATTN_K64 1      // head groups (2 heads each) of a T = 64 window per workgroup
+#endif
+#ifndef ATTN_K32
+#define ATTN_K32 1      // head groups (4 heads each) of a T = 32 window per workgroup
+#endif
+
 namespace {
 struct CArgs {
   const unsigned short* qk;
@@ -52,15 +59,18 @@ constexpr int bwd_head_lds() { return 4 * ROWS * kPitch * 2 + 5 * ROWS * 4 + 16;
 // ---------------------------------------------------------------------------------------------------------------------
 // forward.  NW = wavefronts per head (T = 64: 2, each owns a 32-query tile; T = 32: 1), HW = heads per workgroup = 4 / NW
 // ---------------------------------------------------------------------------------------------------------------------
-template <int DH, int NW>
+// K = head groups of the window a workgroup takes, one after the other: the row segments of group g + 1 (the neighbouring bytes of the
+// same token rows) are requested when group g's tiles are complete and stay in flight under its products and stores (registers: the
+// loads cross the barriers, s_barrier does not drain vmcnt on gfx950).
+template <int DH, int NW, int K>
 __device__ __forceinline__ void coop_fwd(const CArgs& A, const unsigned blk, unsigned char* __restrict__ smem) {
   constexpr int NPC = DH / 8, HW = 4 / NW, ROWS = 32 * NW;
   using G = Coop<DH, HW, ROWS>;
   constexpr int HL = fwd_head_lds<ROWS>();
   const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
   const int rho = lane & 31, h = lane >> 5, sub = wib % NW, hw = wib / NW;
-  const int HG = A.H / HW;
-  const int w = blk / HG, hg = blk - w * HG;
+  const int HG = A.H / (HW * K);                // workgroups per window
+  const int w = blk / HG, hg0 = (blk - w * HG) * K;
   const int n = A.win_len[w], start = A.win_start[w];
   const float inv_tau = 1.f / fmaxf(*A.tau, A.tau_min);
   const int d = A.d;
@@ -71,7 +81,7 @@ __device__ __forceinline__ void coop_fwd(const CArgs& A, const unsigned blk, uns
   unsigned short* cV = cK + ROWS * kPitch;
   float* cKin = reinterpret_cast<float*>(cV + ROWS * kPitch);
   float* cQn = cKin + ROWS;
-  const int col = hg * HW * DH + ch * 8;
+  int col = hg0 * HW * DH + ch * 8;
   int tok[G::P];
 #pragma unroll
   for (int p = 0; p < G::P; ++p) {
@@ -87,6 +97,10 @@ __device__ __forceinline__ void coop_fwd(const CArgs& A, const unsigned blk, uns
     k16[p] = *reinterpret_cast<const uint4*>(qp + d);
     v16[p] = *reinterpret_cast<const uint4*>(A.v + (long long)tok[p] * d + col);
   }
+#pragma unroll
+ for (int it = 0; it < K; ++it) {
+  const int hg = hg0 + it;
+  if (it > 0) __syncthreads();              // the previous group's stores have read the tiles
 #pragma unroll
   for (int p = 0; p < G::P; ++p) {
     const int r = p * G::RPI + lr;
@@ -106,6 +120,17 @@ __device__ __forceinline__ void coop_fwd(const CArgs& A, const unsigned blk, uns
     tile_put16(cV, r, cq, v16[p]);
   }
   __syncthreads();
+  const int col_st = col;
+  if (it + 1 < K) {                         // the next head group's segments: in flight until the top of the next iteration
+    col += HW * DH;
+#pragma unroll
+    for (int p = 0; p < G::P; ++p) {
+      const unsigned short* qp = A.qk + (long long)tok[p] * 2 * d + col;
+      q16[p] = *reinterpret_cast<const uint4*>(qp);
+      k16[p] = *reinterpret_cast<const uint4*>(qp + d);
+      v16[p] = *reinterpret_cast<const uint4*>(A.v + (long long)tok[p] * d + col);
+    }
+  }
   // ---- this wavefront: head hw, query tile sub
   unsigned short* tQ = reinterpret_cast<unsigned short*>(smem + hw * HL);
   unsigned short* tK = tQ + ROWS * kPitch;
@@ -162,10 +187,11 @@ __device__ __forceinline__ void coop_fwd(const CArgs& A, const unsigned blk, uns
   for (int p = 0; p < G::P; ++p) {
     const int r2 = p * G::RPI + lr;
     if (r2 < n && r2 < ROWS) {
-      *reinterpret_cast<uint4*>(A.out + (long long)tok[p] * d + col) = tile_get16(cQ, r2, cq);
+      *reinterpret_cast<uint4*>(A.out + (long long)tok[p] * d + col_st) = tile_get16(cQ, r2, cq);
       if (cq == 0 && A.lse) A.lse[(long long)tok[p] * A.H + hg * HW + chl] = (cKin + 2 * ROWS)[r2];
     }
   }
+ }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -390,8 +416,8 @@ __device__ __forceinline__ void coop_bwd(const CBwdArgs& A, const unsigned blk, 
 // paying a launch of their own; first16 = they take the lowest block indices (their chains start at once, the dense workgroups fill
 // in behind - measured better than the other order, tools/attn_layer.py).
 // ---------------------------------------------------------------------------------------------------------------------
-template <int DH>
-__global__ __launch_bounds__(256) void k_attn_levels_fwd(CArgs A64, CArgs A32, t16w::A16Args A16, unsigned nb64, unsigned nb32, unsigned nb16,
+template <int DH, int K64, int K32>
+__global__ __launch_bounds__(256, 4) void k_attn_levels_fwd(CArgs A64, CArgs A32, t16w::A16Args A16, unsigned nb64, unsigned nb32, unsigned nb16,
                                                          int first16) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_coop[];
   unsigned b = blockIdx.x;
@@ -399,9 +425,9 @@ __global__ __launch_bounds__(256) void k_attn_levels_fwd(CArgs A64, CArgs A32, t
     if (b < nb16) return t16w::t16_fwd_body<DH>(A16, b, smem_coop);
     b -= nb16;
   }
-  if (b < nb64) return coop_fwd<DH, 2>(A64, b, smem_coop);
+  if (b < nb64) return coop_fwd<DH, 2, K64>(A64, b, smem_coop);
   b -= nb64;
-  if (b < nb32) return coop_fwd<DH, 1>(A32, b, smem_coop);
+  if (b < nb32) return coop_fwd<DH, 1, K32>(A32, b, smem_coop);
   t16w::t16_fwd_body<DH>(A16, b - nb32, smem_coop);
 }
 template <int DH>
@@ -449,12 +475,21 @@ int gd_attn_levels_fwd(const void* qk, const void* v, void* out, float* lse, con
   const CArgs A64{(const unsigned short*)qk, (const unsigned short*)v, (unsigned short*)out, lse, csr_tok, ws64, wl64, n64, d, H, tau, tau_min};
   const t16w::A16Args A16{(const unsigned short*)qk, (const unsigned short*)v, (unsigned short*)out, csr_tok, ws16, wl16, n16, d, H, tau, tau_min};
   const int DH = d / H;
-  const unsigned nb32 = (unsigned)((long long)n32 * (H / 4)), nb64 = (unsigned)((long long)n64 * (H / 2));
+  // head groups per workgroup (ATTN_K64 / ATTN_K32, see coop_fwd) where the head count allows it
+  const bool multi = (H / 2) % ATTN_K64 == 0 && (H / 4) % ATTN_K32 == 0;
+  const int k64 = multi ? ATTN_K64 : 1, k32 = multi ? ATTN_K32 : 1;
+  const unsigned nb32 = (unsigned)((long long)n32 * (H / 4 / k32)), nb64 = (unsigned)((long long)n64 * (H / 2 / k64));
   const unsigned nb16 = (unsigned)((long long)gd_div_up(n16, t16w::kWinPerWave) * (H / 4));
   if (nb16 + nb32 + nb64 == 0) return 0;
   constexpr int lds = imax(imax(2 * fwd_head_lds<64>(), 4 * fwd_head_lds<32>()), 4 * t16w::kWaveLds);
-  if (DH == 16) hipLaunchKernelGGL((k_attn_levels_fwd<16>), dim3(nb64 + nb32 + nb16), dim3(256), lds, st, A64, A32, A16, nb64, nb32, nb16, first16());
-  else hipLaunchKernelGGL((k_attn_levels_fwd<32>), dim3(nb64 + nb32 + nb16), dim3(256), lds, st, A64, A32, A16, nb64, nb32, nb16, first16());
+  const dim3 grid(nb64 + nb32 + nb16);
+  if (multi) {
+    if (DH == 16) hipLaunchKernelGGL((k_attn_levels_fwd<16, ATTN_K64, ATTN_K32>), grid, dim3(256), lds, st, A64, A32, A16, nb64, nb32, nb16, first16());
+    else hipLaunchKernelGGL((k_attn_levels_fwd<32, ATTN_K64, ATTN_K32>), grid, dim3(256), lds, st, A64, A32, A16, nb64, nb32, nb16, first16());
+  } else {
+    if (DH == 16) hipLaunchKernelGGL((k_attn_levels_fwd<16, 1, 1>), grid, dim3(256), lds, st, A64, A32, A16, nb64, nb32, nb16, first16());
+    else hipLaunchKernelGGL((k_attn_levels_fwd<32, 1, 1>), grid, dim3(256), lds, st, A64, A32, A16, nb64, nb32, nb16, first16());
+  }
   GD_LAUNCH_CHECK();
   return 0;
 }

@@ -14,6 +14,7 @@
 #include "common.h"
 #include "dw_grouped.h"
 #include "gemm.h"
+#include "layer_tail.h"
 #include <stdlib.h>
 
 namespace {
@@ -40,14 +41,6 @@ __global__ __launch_bounds__(256) void k_zero_regions(ZeroJobs z) {
       ((uint4*)z.p[j])[i] = zero;
 }
 
-// dst[j][i] += src[j][i]  (nblk == 0)   or   dst[j][i] += sum_b src[j][b * stride + i]  (nblk partial rows, e.g. the
-// per-workgroup dgamma / dbeta / column-sum partials of the LayerNorm backward), fixed association order.
-struct AccJobs {
-  float* dst[8];
-  const float* src[8];
-  int len[8], nblk[8], stride[8];
-  int count;
-};
 __global__ __launch_bounds__(256) void k_acc_vectors(AccJobs a) {
   // 16 consecutive elements x 16 slices of the partial rows per workgroup (64-byte row segments, 8 loads in flight per
   // thread), the slices meet in LDS in a fixed order
@@ -77,15 +70,6 @@ __global__ __launch_bounds__(256) void k_acc_vectors(AccJobs a) {
   }
 }
 
-// the split-K reduces of a layer's five weight gradients as ONE launch (blockIdx.y = job):
-// dst[i] += sum_{s < S} part[s * P + i], same slicing and association order as k_splitk_acc (gemm.hip)
-struct SplitkJobs {
-  const float* part[8];
-  float* dst[8];
-  int S[8];
-  long long P4[8];
-  int count;
-};
 __global__ __launch_bounds__(256) void k_splitk_acc_jobs(SplitkJobs J) {
   __shared__ float4 sh[3][64];
   const int job = blockIdx.y;
@@ -116,111 +100,7 @@ __global__ __launch_bounds__(256) void k_splitk_acc_jobs(SplitkJobs J) {
   }
 }
 
-// The reductions that close a layer's backward as ONE launch (blockIdx.y = section):
-//   y <  J.count      split-K reduce of weight-gradient / bias-column-sum partials (as k_splitk_acc_jobs)
-//   y == J.count      vector accumulations (as k_acc_vectors: LayerNorm dgamma / dbeta / column-sum partial rows)
-//   y == J.count + 1  dtau += gate(tau) * sum of the attention partials (fixed order, one workgroup)
-struct TailJobs {
-  SplitkJobs J;
-  AccJobs a;
-  const float* tau_part;
-  long long n_part;
-  const float* tau;
-  float tau_min;
-  float* dtau;
-};
-__device__ inline void tail_splitk(const SplitkJobs& J, int job) {
-  // round 5: one 16-byte column per thread, ALL slices of it requested before the first is added (eight at a time, unconditional on
-  // a clamped slice index), added in slice order - 256 contiguous columns per workgroup instead of 64 columns x 4 slice groups
-  // meeting in LDS: a quarter of the workgroups, no barrier, 4 KB per wavefront-row of a slice
-  const long long P4 = J.P4[job];
-  const int S = J.S[job];
-  const long long i = blockIdx.x * 256ll + threadIdx.x;
-  if (blockIdx.x * 256ll >= P4) return;                // uniform per workgroup
-  if (i >= P4) return;
-  const float4* p = (const float4*)J.part[job] + i;
-  float4* d = (float4*)J.dst[job] + i;
-  float4 acc = *d;
-  for (int s0 = 0; s0 < S; s0 += 8) {
-    float4 v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = p[(long long)(s0 + u < S ? s0 + u : S - 1) * P4];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const float m = s0 + u < S ? 1.f : 0.f;
-      acc.x = fmaf(m, v[u].x, acc.x); acc.y = fmaf(m, v[u].y, acc.y); acc.z = fmaf(m, v[u].z, acc.z); acc.w = fmaf(m, v[u].w, acc.w);
-    }
-  }
-  *d = acc;
-}
-__device__ inline void tail_vectors(const AccJobs& a) {
-  __shared__ float sh[16][17];
-  const int cl = threadIdx.x & 15, ps = threadIdx.x >> 4;
-  int col = blockIdx.x * 16 + cl;
-  int j = 0;
-  while (j < a.count && col >= a.len[j]) col -= a.len[j++];
-  float acc = 0.f;
-  if (j < a.count) {
-    if (a.nblk[j] == 0) {
-      if (ps == 0) acc = a.src[j][col];
-    } else {
-      const float* p = a.src[j] + col;
-      const long long st = a.stride[j];
-#pragma unroll 8
-      for (int b = ps; b < a.nblk[j]; b += 16) acc += p[b * st];
-    }
-  }
-  sh[ps][cl] = acc;
-  __syncthreads();
-  if (ps == 0 && j < a.count) {
-    float s = 0.f;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) s += sh[k][cl];
-    a.dst[j][col] += s;
-  }
-}
-__global__ __launch_bounds__(256) void k_layer_tail(TailJobs T) {
-  const int y = blockIdx.y;
-  if (y < T.J.count) {
-    tail_splitk(T.J, y);
-  } else if (y == T.J.count) {
-    int cols = 0;
-    for (int j = 0; j < T.a.count; ++j) cols += T.a.len[j];
-    if (blockIdx.x * 16 < cols) tail_vectors(T.a);
-  } else if (blockIdx.x == 0) {
-    __shared__ float shw[4];
-    // 16-byte loads, four of them in flight per thread: the ~50 k partials of a layer are one latency-bound chain per thread
-    // otherwise (this single workgroup was the longest-running part of the launch)
-    // (round 5: sixteen in flight, requested unconditionally on a clamped index - with four the workgroup needed twelve dependent
-    // round trips for the ~50 k partials of a d = 256 layer and set the duration of the whole launch: 13.7 us)
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    const long long n4 = T.n_part >> 2;
-    const float4* p4 = reinterpret_cast<const float4*>(T.tau_part);
-    for (long long i0 = threadIdx.x; i0 < n4; i0 += 16 * 256) {
-      float4 v[16];
-#pragma unroll
-      for (int u = 0; u < 16; ++u) v[u] = p4[i0 + u * 256 < n4 ? i0 + u * 256 : n4 - 1];
-#pragma unroll
-      for (int u = 0; u < 16; u += 4) {
-        const float m0 = i0 + u * 256 < n4 ? 1.f : 0.f, m1 = i0 + (u + 1) * 256 < n4 ? 1.f : 0.f;
-        const float m2 = i0 + (u + 2) * 256 < n4 ? 1.f : 0.f, m3 = i0 + (u + 3) * 256 < n4 ? 1.f : 0.f;
-        a0 = fmaf(m0, (v[u].x + v[u].y) + (v[u].z + v[u].w), a0);
-        a1 = fmaf(m1, (v[u + 1].x + v[u + 1].y) + (v[u + 1].z + v[u + 1].w), a1);
-        a2 = fmaf(m2, (v[u + 2].x + v[u + 2].y) + (v[u + 2].z + v[u + 2].w), a2);
-        a3 = fmaf(m3, (v[u + 3].x + v[u + 3].y) + (v[u + 3].z + v[u + 3].w), a3);
-      }
-    }
-    for (long long j = (n4 << 2) + threadIdx.x; j < T.n_part; j += 256) a1 += T.tau_part[j];
-    const float w = gd_wave_sum((a0 + a1) + (a2 + a3));
-    if ((threadIdx.x & 63) == 0) shw[threadIdx.x >> 6] = w;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      float t = (shw[0] + shw[1]) + (shw[2] + shw[3]);
-      if (!(T.tau[0] >= T.tau_min)) t = 0.f;            // d clamp(tau, min) / d tau
-      T.dtau[0] += t;
-    }
-  }
-}
+__global__ __launch_bounds__(256) void k_layer_tail(TailJobs T) { tail_block(T, blockIdx.x, (int)blockIdx.y, (int)threadIdx.x); }
 
 // exact (erf) GELU, 8 elements per thread
 template <bool BF>
@@ -479,7 +359,7 @@ Saved saved_layout(void* base, long long n_pad, int d, int ff, int es) {
 }
 struct Scratch {
   char *lt_ws, *dx1_res, *dfb, *s2, *dg, *dh, *dx1_b, *dx_res, *dab, *s1, *d_o, *dqk, *dv, *apart, *dtau, *dx_qk, *dx_v, *part, *ln_ws,
-      *cs_part, *part_w[5], *ln_ws2;
+      *cs_part, *part_w[5], *ln_ws2, *ln_ws2b;
   size_t bytes;
 };
 Scratch scratch_layout(void* base, long long n_pad, int d, int ff, int es, int nhead) {
@@ -504,6 +384,7 @@ Scratch scratch_layout(void* base, long long n_pad, int d, int ff, int es, int n
     if (fused_rows > lnb) lnb = fused_rows;
     s.ln_ws = take(lnb);
     s.ln_ws2 = take(lnb);
+    s.ln_ws2b = take(lnb);
   }
   {   // one split-K partial region per weight gradient of the backward (reduced together at the end of the layer)
     const int mk5[5][2] = {{d, ff}, {ff, d}, {d, d}, {2 * d, d}, {d, d}};
@@ -570,7 +451,7 @@ int gd_layer_fused_bwd_ffn(hipStream_t st, int d, const void* df, const void* h,
                            void* d_o, float* part);
 int gd_layer_fused_bwd_in(hipStream_t st, int d, const void* dqk, const void* dv, const void* Wqkt, const void* Wvt, const void* dres, long long n,
                           long long n_pad, const void* ln_a, const void* ln_b, const float* stats, const float* gamma, void* dout, float* part,
-                          float* dx, const void* dtop, void* dx_bf);
+                          float* dx, const void* dtop, void* dx_bf, const TailJobs* tail = nullptr);
 int gd_layer_fused_ln2_top(hipStream_t st, int d, const float* dy, const void* dy_bf, const void* ln_a, const void* ln_b, const float* stats,
                            const float* gamma, long long n, long long n_pad, void* dout, float* part);
 int gd_layer_fused_prep_bf(hipStream_t st, const void* x, const float* pos_table, const int* tok_pos, long long n, int d, void* xb, void* xpb);
@@ -800,8 +681,10 @@ extern "C" int gdmae_encoder_stage_fwd(const gdmae_layer_args* layers, int n_lay
 namespace {
 // The five weight gradients + three bias column sums of a layer as ONE grouped launch, then the tail launch that reduces their
 // split-K partials together with the LayerNorm partial rows (nb1 / nb2 rows of LayerNorm 1 / 2) and the attention's dtau partials.
+// ride != null: the tail is not launched here - its job table is handed back and rides along with the layer's in-projection launch
+// (gd_layer_fused_bwd_in; ln2: the LayerNorm-2 partial rows of THIS layer, which that launch must not be writing to)
 int grouped_dw_and_tail(const gdmae_layer_args* a, const Saved& s, const Scratch& w, const Ctx& c, long long n, long long n_pad, int nb1,
-                        int nb2, long long pbase) {
+                        int nb2, long long pbase, TailJobs* ride = nullptr, const float* ln2 = nullptr) {
   const int d = a->d, ff = a->ff;
   SplitkJobs SJ;
   SJ.count = 0;
@@ -834,7 +717,7 @@ int grouped_dw_and_tail(const gdmae_layer_args* a, const Saved& s, const Scratch
   // LayerNorm / bias gradients from the per-workgroup partial rows {dgamma, dbeta, column sums of dx}; dtau from the attention partials
   AccJobs j;
   const float* p1 = (const float*)w.ln_ws;    // LayerNorm 1: dg1, dbe1, bias gradient of the out-projection
-  const float* p2 = (const float*)w.ln_ws2;   // LayerNorm 2: dg2, dbe2, bias gradient of the second FFN linear
+  const float* p2 = ln2 ? ln2 : (const float*)w.ln_ws2;   // LayerNorm 2: dg2, dbe2, bias gradient of the second FFN linear
   float* dst[6] = {a->dg1, a->dbe1, a->dbo, a->dg2, a->dbe2, a->db2};
   const float* src[6] = {p1, p1 + d, p1 + 2 * d, p2, p2 + d, p2 + 2 * d};
   int cols = 0;
@@ -847,8 +730,11 @@ int grouped_dw_and_tail(const gdmae_layer_args* a, const Saved& s, const Scratch
   T.J = SJ;
   T.a = j;
   T.tau_part = (const float*)w.apart; T.n_part = pbase; T.tau = a->tau; T.tau_min = a->tau_min; T.dtau = a->dtau;
-  long long gx = (cols + 15) / 16;
-  for (int q = 0; q < SJ.count; ++q) gx = (SJ.P4[q] + 255) / 256 > gx ? (SJ.P4[q] + 255) / 256 : gx;
+  if (ride) {
+    *ride = T;
+    return 0;
+  }
+  const long long gx = tail_grid_x(T);
   double tail_bytes = 4.0 * pbase;
   for (int q = 0; q < SJ.count; ++q) tail_bytes += 16.0 * SJ.P4[q] * (SJ.S[q] + 2);
   for (int q = 0; q < j.count; ++q) tail_bytes += 4.0 * j.len[q] * (j.nblk[q] + 2);
@@ -982,6 +868,13 @@ static int layer_bwd(const gdmae_layer_args* a, bool upstream3, bool defer_add3,
   return 0;
 }
 
+// GDMAE_LAYER_TAIL_RIDES=0: the layer tails as launches of their own (A/B switch)
+static bool tail_rides() {
+  static int v = -1;
+  if (v < 0) v = getenv("GDMAE_LAYER_TAIL_RIDES") ? atoi(getenv("GDMAE_LAYER_TAIL_RIDES")) : 1;
+  return v != 0;
+}
+
 // Backward of stage_fwd_v2: per layer the feed-forward / LayerNorm-1 / out-projection launch, the attention backward, the grouped
 // weight gradients + tail, and the in-projection launch that also runs the LayerNorm-2 backward of the layer below (df of that
 // layer and its partial rows land in the shared scratch: dfb, ln_ws2).
@@ -997,9 +890,12 @@ static int stage_bwd_v2(const gdmae_layer_args* layers, int n_layers, void* stre
     const Packed pk = packed_layout(a->packed, d, ff);
     const gdmae_layer_args* top = &layers[n_layers - 1];
     const bool res_mode = top->dres != nullptr && layers[0].dx_bf16 != nullptr;      // block residual folded into the stage
+    // the LayerNorm-2 partial rows of layer i live in ln2[i & 1]: this layer's tail reads them inside the launch that writes those of
+    // the layer below
+    float* const ln2[2] = {(float*)w.ln_ws2, (float*)w.ln_ws2b};
     if (i == n_layers - 1)
       GD_TRY(gd_layer_fused_ln2_top(st, d, res_mode ? nullptr : a->dy, res_mode ? a->dres : nullptr, s.x1b, s.f, (const float*)s.st2, a->g2, n,
-                                    n_pad, w.dfb, (float*)w.ln_ws2));
+                                    n_pad, w.dfb, ln2[i & 1]));
     GD_TRY(gd_layer_fused_bwd_ffn(st, d, w.dfb, s.h, s.xb, s.a, (const float*)s.st1, a->g1, pk.w2t, pk.w1t, pk.ot, n, n_pad, w.dh, s.gact,
                                   w.dab, w.d_o, (float*)w.ln_ws));
     long long pbase = 0;
@@ -1008,14 +904,17 @@ static int stage_bwd_v2(const gdmae_layer_args* layers, int n_layers, void* stre
     GD_TRY(gdmae_window_attention_levels_bwd(s.qk, s.v, w.d_o, w.dqk, w.dv, 1, (float*)w.apart, a->csr_tok, a->win_start, a->win_len,
                                              a->n_levels, a->n_win, a->max_tokens, d, a->nhead, a->tau, a->tau_min, s.o, (const float*)s.lse, stream));
     const int nb = (int)(n_pad / gd_layer_fused_rows(d));
-    GD_TRY(grouped_dw_and_tail(a, s, w, c, n, n_pad, nb, nb, pbase));
+    TailJobs tail;
+    const bool ride = tail_rides();
+    GD_TRY(grouped_dw_and_tail(a, s, w, c, n, n_pad, nb, nb, pbase, ride ? &tail : nullptr, ln2[i & 1]));
     if (i > 0) {
       const Saved sp = saved_layout(layers[i - 1].saved, n_pad, d, ff, 2);
       GD_TRY(gd_layer_fused_bwd_in(st, d, w.dqk, w.dv, pk.qkt, pk.vt, w.dab, n, n_pad, sp.x1b, sp.f, (const float*)sp.st2, layers[i - 1].g2,
-                                   w.dfb, (float*)w.ln_ws2, nullptr, nullptr, nullptr));
+                                   w.dfb, ln2[(i - 1) & 1], nullptr, nullptr, nullptr, ride ? &tail : nullptr));
     } else {
       GD_TRY(gd_layer_fused_bwd_in(st, d, w.dqk, w.dv, pk.qkt, pk.vt, w.dab, n, n_pad, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-                                   res_mode ? nullptr : a->dx, res_mode ? top->dres : nullptr, res_mode ? a->dx_bf16 : nullptr));
+                                   res_mode ? nullptr : a->dx, res_mode ? top->dres : nullptr, res_mode ? a->dx_bf16 : nullptr,
+                                   ride ? &tail : nullptr));
     }
   }
   return 0;

@@ -19,6 +19,7 @@
 // as GEMM operand and once as addend from the tile in LDS).  Fused phases share one row tile per workgroup: 32 rows for d = 256,
 // 64 for d = 128, 8 wavefronts, weights streamed as MFMA A operands from the fragment-ordered images of tok_gemm_pack.
 #include "tok_tiles.h"
+#include "layer_tail.h"
 
 // experiment switches (tools/build_variant.sh): weight prefetch distance, row tile of the d = 256 stages, resident workgroups
 #ifndef TL_ROWS256
@@ -460,8 +461,24 @@ struct LiArgs {
   unsigned short* dx_bf;            // (n, D) bf16 = dtop + dres + product
 };
 
+// Tail blocks (layer_tail.h): the first Tm.total workgroups of the launch do the layer's closing reductions, one 256-thread tail block each
+// (the other wavefronts of such a workgroup leave at once: s_barrier waits for the surviving waves only); they start with the launch and
+// the row tiles fill in behind them.  Tm.start[y] = first workgroup of section y.
+struct TailMap {
+  unsigned start[12];
+  unsigned total;
+  int ny;
+};
 template <int D, bool LN>
-__global__ __launch_bounds__(TL_THREADS * TL_HALVES, TL_MINW) void k_layer_bwd_in(LiArgs A) {
+__global__ __launch_bounds__(TL_THREADS * TL_HALVES, TL_MINW) void k_layer_bwd_in(LiArgs A, TailJobs T, TailMap Tm) {
+  if (blockIdx.x < Tm.total) {          // uniform per workgroup
+    if (threadIdx.x >= 256) return;
+    int y = 0;
+    while (y + 1 < Tm.ny && blockIdx.x >= Tm.start[y + 1]) ++y;
+    tail_block(T, blockIdx.x - Tm.start[y], y, (int)threadIdx.x);
+    return;
+  }
+  const unsigned blk = blockIdx.x - Tm.total;
   using R = TlRows<D>;
   constexpr int ROWS = R::ROWS, LPR = R::LPR, LRPP = R::LRPP, LPASS = R::LPASS;
   constexpr int KD = 3 * D, XP = KD * 2 + 16, SP = D * 2 + 16;
@@ -470,7 +487,7 @@ __global__ __launch_bounds__(TL_THREADS * TL_HALVES, TL_MINW) void k_layer_bwd_i
   const int tile_in_wg = threadIdx.x / TL_THREADS;
   unsigned char* const lds = lds_all + tile_in_wg * (ROWS * XP);
   const int tid = threadIdx.x % TL_THREADS, lane = tid & 63, wv = tid >> 6;
-  const long long tile_id = (long long)blockIdx.x * TL_HALVES + tile_in_wg;
+  const long long tile_id = (long long)blk * TL_HALVES + tile_in_wg;
   const long long row0 = tile_id * ROWS;
   const int lc0 = 4 * (tid % LPR), lr = tid / LPR;
 
@@ -681,8 +698,36 @@ int gd_layer_fused_bwd_ffn(hipStream_t st, int d, const void* df, const void* h,
 // LN: dout (n_pad, d) bf16 + part; otherwise dx (n, d) fp32
 int gd_layer_fused_bwd_in(hipStream_t st, int d, const void* dqk, const void* dv, const void* Wqkt, const void* Wvt, const void* dres, long long n,
                           long long n_pad, const void* ln_a, const void* ln_b, const float* stats, const float* gamma, void* dout, float* part,
-                          float* dx, const void* dtop, void* dx_bf) {
+                          float* dx, const void* dtop, void* dx_bf, const TailJobs* tail) {
   LiArgs A = {};
+  TailJobs T = {};
+  TailMap Tm = {};
+  double tail_bytes = 0.0;
+  if (tail) {       // the layer's closing reductions as the first workgroups of this launch, sections packed back to back
+    T = *tail;
+    Tm.ny = T.J.count + 2;
+    GD_REQUIRE(Tm.ny <= 11, "layer tail: sections");
+    unsigned at = 0;
+    for (int y = 0; y < Tm.ny; ++y) {
+      Tm.start[y] = at;
+      if (y < T.J.count) {
+        at += (unsigned)((T.J.P4[y] + 255) / 256);
+        tail_bytes += 16.0 * T.J.P4[y] * (T.J.S[y] + 2);
+      } else if (y == T.J.count) {
+        int cols = 0;
+        for (int q = 0; q < T.a.count; ++q) {
+          cols += T.a.len[q];
+          tail_bytes += 4.0 * T.a.len[q] * (T.a.nblk[q] + 2);
+        }
+        at += (unsigned)((cols + 15) / 16);
+      } else {
+        at += 1;
+        tail_bytes += 4.0 * T.n_part;
+      }
+    }
+    Tm.start[Tm.ny] = at;
+    Tm.total = at;
+  }
   A.dtop = (const unsigned short*)dtop; A.dx_bf = (unsigned short*)dx_bf;
   A.dqk = (const unsigned short*)dqk; A.dv = (const unsigned short*)dv; A.Wqkt = (const uint4*)Wqkt; A.Wvt = (const uint4*)Wvt;
   A.dres = (const unsigned short*)dres; A.n = n; A.n_pad = n_pad; A.ln_a = (const unsigned short*)ln_a; A.ln_b = (const unsigned short*)ln_b;
@@ -693,12 +738,12 @@ int gd_layer_fused_bwd_in(hipStream_t st, int d, const void* dqk, const void* dv
   // bf16 rows: dqk, dv, da in (+ both LayerNorm addends in, df out | the skip-path gradient in, dx out); two weight images.  Side:
   // statistics + partial rows, or the fp32 dx rows
   GdTimed timed(GD_T_TOK_GEMM, st, 2.0 * n_pad * 3 * d + (double)n * d * (2 + (ln ? 2 + 2 + 2 : (dx_bf ? 2 + 2 : 0))) + 2.0 * 3 * d * d,
-                2.0 * n_pad * 3 * d * d, ln ? 8.0 * n + 12.0 * d * (double)(n_pad / rows) : (dx_bf ? 0.0 : 4.0 * n * d));
+                2.0 * n_pad * 3 * d * d, (ln ? 8.0 * n + 12.0 * d * (double)(n_pad / rows) : (dx_bf ? 0.0 : 4.0 * n * d)) + tail_bytes);
   static bool once[4] = {false, false, false, false};
 #define LI_CASE(D_, LN_, idx)                                                                                   \
   {                                                                                                             \
     if (!once[idx]) { if (int rc = set_lds(k_layer_bwd_in<D_, LN_>, lds)) return rc; once[idx] = true; }        \
-    hipLaunchKernelGGL((k_layer_bwd_in<D_, LN_>), dim3((unsigned)(n_pad / (rows * TL_HALVES))), dim3(TL_THREADS * TL_HALVES), lds, st, A);       \
+    hipLaunchKernelGGL((k_layer_bwd_in<D_, LN_>), dim3((unsigned)(n_pad / (rows * TL_HALVES)) + Tm.total), dim3(TL_THREADS * TL_HALVES), lds, st, A, T, Tm);       \
   }
   if (d == 128 && ln) LI_CASE(128, true, 0)
   else if (d == 128) LI_CASE(128, false, 1)

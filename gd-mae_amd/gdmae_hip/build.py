@@ -37,7 +37,7 @@ def _newer(src, dst):
 def build(force: bool = False, verbose: bool = True) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
-    deps = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm.h"), os.path.join(CSRC, "conv_tiles.h"), os.path.join(CSRC, "dw_grouped.h"), os.path.join(CSRC, "tok_tiles.h"), os.path.abspath(os.path.join(CSRC, "..", "..", "include", "gdmae_hip.h"))]
+    deps = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm.h"), os.path.join(CSRC, "conv_tiles.h"), os.path.join(CSRC, "dw_grouped.h"), os.path.join(CSRC, "tok_tiles.h"), os.path.join(CSRC, "layer_tail.h"), os.path.abspath(os.path.join(CSRC, "..", "..", "include", "gdmae_hip.h"))]
     procs = []
     for s in SOURCES:
         src = os.path.join(CSRC, s)

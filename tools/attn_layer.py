@@ -30,6 +30,8 @@ for si, st in enumerate(plan.stages):
         nl = len(w.n_win)
         lse = torch.empty(st.n_tok, H, device=dev)
         nw_h, T_h = L.host_i32(w.n_win), L.host_i32(w.max_tokens)
+        if os.environ.get("LEVELS"):         # experiment: only the occupancy levels whose bit is set (1 = T16, 2 = T32, 4 = T64) have windows
+            nw_h = L.host_i32([n if (int(os.environ["LEVELS"]) >> i) & 1 else 0 for i, n in enumerate(w.n_win)])
         csr = torch.arange(st.n_tok, dtype=torch.int32, device=dev) if IDENT else w.csr_tok
         if os.environ.get("NOCSR"):          # experiment: no index load at all (rows in window-major order, csr_tok = null)
             csr = None
