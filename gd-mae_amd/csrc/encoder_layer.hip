@@ -445,7 +445,8 @@ int gd_layer_fused_rows(int d);
 int gd_layer_fused_fwd(hipStream_t st, int d, const void* o, const void* x, const void* Wo, const void* W1, const void* W2, const void* bo,
                        const void* b1, const void* b2, const float* g1, const float* be1, const float* g2, const float* be2, float eps,
                        long long n, long long n_pad, void* a, void* x1, void* h, void* f, float* st1, float* st2, float* y, void* y_bf,
-                       void* ypos_bf, const float* pos_table, const int* tok_pos, const void* res0, void* res_out);
+                       void* ypos_bf, const float* pos_table, const int* tok_pos, const void* res0, void* res_out, const void* Wqk_n = nullptr,
+                       const void* Wv_n = nullptr, const void* bin_n = nullptr, void* qk_n = nullptr, void* v_n = nullptr);
 int gd_layer_fused_bwd_ffn(hipStream_t st, int d, const void* df, const void* h, const void* x, const void* a, const float* st1, const float* g1,
                            const void* W2t, const void* W1t, const void* Wot, long long n, long long n_pad, void* dh, void* gact, void* da,
                            void* d_o, float* part);
@@ -628,6 +629,15 @@ extern "C" int gdmae_encoder_layer_fwd(const gdmae_layer_args* a, void* stream) 
 // The stage with the fused layer launches (layer_fused.hip): per layer q/k/v projections, attention, ONE launch for everything
 // behind it.  The residual stream between the layers is the bf16 row the next layer's v projection reads anyway (xb of its saved
 // block); only the last layer writes the fp32 rows the caller sees.
+// GDMAE_QKV_RIDES=1: the in-projection of layers 1 ... of a stage as two more products of the launch that closes the layer below
+// (k_layer_fwd<D, true>: the rows are still in LDS; bit-identical q / k / v).  Measured, not the default: 9 launches per step less, but the
+// step is 7.69 - 7.70 ms against 7.64 - 7.67 with the launches (4 frames: 4.83 against 4.79 - 4.82) - the phases of a row-tile workgroup
+// run one after the other at two workgroups per CU, so the products cost there what they cost in a launch of their own.
+static bool qkv_rides(const gdmae_layer_args* a) {
+  static int v = -1;
+  if (v < 0) v = getenv("GDMAE_QKV_RIDES") ? atoi(getenv("GDMAE_QKV_RIDES")) : 0;
+  return v != 0 && a->bin != nullptr;
+}
 static int stage_fwd_v2(const gdmae_layer_args* layers, int n_layers, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   for (int i = 0; i < n_layers; ++i) {
@@ -641,20 +651,27 @@ static int stage_fwd_v2(const gdmae_layer_args* layers, int n_layers, void* stre
       if (a->x_bf16) GD_TRY(gd_layer_fused_prep_bf(st, a->x, a->pos_table, a->tok_pos, n, d, s.xb, s.xpb));
       else GD_TRY(gdmae_prep_tokens(a->x, a->pos_table, a->tok_pos, n, d, s.xb, s.xpb, 1, stream));
     }
-    GD_TRY(gd_tok_gemm_qkv(st, s.xpb, s.xb, pk.qk, pk.v, a->bin, n_pad, d, s.qk, s.v));
+    // layers 1 ...: q | k and v were produced by the launch that closed the layer below (its rows were still in LDS)
+    if (i == 0 || !qkv_rides(&layers[i])) GD_TRY(gd_tok_gemm_qkv(st, s.xpb, s.xb, pk.qk, pk.v, a->bin, n_pad, d, s.qk, s.v));
     gd_attn_timing_tokens(n);
     GD_TRY(gdmae_window_attention_levels_fwd(s.qk, s.v, s.o, 1, a->csr_tok, a->win_start, a->win_len, a->n_levels, a->n_win, a->max_tokens, d,
                                              a->nhead, a->tau, a->tau_min, (float*)s.lse, stream));
     const gdmae_layer_args* next = i + 1 < n_layers ? &layers[i + 1] : nullptr;
-    void *y_bf = nullptr, *ypos_bf = nullptr;
+    void *y_bf = nullptr, *ypos_bf = nullptr, *qk_n = nullptr, *v_n = nullptr;
+    const char *wqk_n = nullptr, *wv_n = nullptr;
     if (next) {
       Saved sn = saved_layout(next->saved, n_pad, d, ff, 2);
       y_bf = sn.xb; ypos_bf = sn.xpb;
+      if (qkv_rides(next)) {
+        const Packed pn = packed_layout(next->packed, d, ff);
+        wqk_n = pn.qk; wv_n = pn.v; qk_n = sn.qk; v_n = sn.v;
+      }
     }
     GD_TRY(gd_layer_fused_fwd(st, d, s.o, s.xb, pk.o, pk.w1, pk.w2, a->bo, a->b1, a->b2, a->g1, a->be1, a->g2, a->be2, a->eps, n, n_pad, s.a,
                               s.x1b, s.h, s.f, (float*)s.st1, (float*)s.st2, (next || a->res_out) ? nullptr : a->y, y_bf, ypos_bf,
                               next ? next->pos_table : nullptr, next ? next->tok_pos : nullptr,
-                              (!next && a->res_out) ? saved_layout(layers[0].saved, n_pad, d, ff, 2).xb : nullptr, next ? nullptr : a->res_out));
+                              (!next && a->res_out) ? saved_layout(layers[0].saved, n_pad, d, ff, 2).xb : nullptr, next ? nullptr : a->res_out,
+                              wqk_n, wv_n, wqk_n ? next->bin : nullptr, qk_n, v_n));
   }
   return 0;
 }

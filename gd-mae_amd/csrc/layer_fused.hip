@@ -137,9 +137,13 @@ struct LfArgs {
   const int* tok_pos;
   const unsigned short* res0;       // optional (n_pad, D): input rows of the STAGE; res_out = bf16(res0 + y), the block residual
   unsigned short* res_out;          // optional (n, D)
+  // QKV = true: the in-projection of the NEXT layer on the rows this tile has just produced (q | k = (y + pos) Wqk^T + b, v = y Wv^T + b)
+  const uint4 *Wqk_n, *Wv_n;        // packed (2 D, D), (D, D) of the next layer
+  const unsigned short* bin_n;      // (3 D)
+  unsigned short *qk_n, *v_n;       // (n_pad, 2 D), (n_pad, D)
 };
 
-template <int D>
+template <int D, bool QKV>
 __global__ __launch_bounds__(TL_THREADS * TL_HALVES, TL_MINW) void k_layer_fwd(LfArgs A) {
   constexpr int FF = 2 * D;
   using R = TlRows<D>;
@@ -254,6 +258,9 @@ __global__ __launch_bounds__(TL_THREADS * TL_HALVES, TL_MINW) void k_layer_fwd(L
     pc.run(hl, HP, wv, lane, acc);
     tl_stage<FF, D, ROWS>(acc, bic, xl, XP, wv, lane);
   }
+  // QKV: y + pos replaces f in its slot of the x tile (operand of the q | k product), y goes to a tile behind the hidden tile's first
+  // ROWS * HP bytes (operand of the v product, then its staging tile); the q | k rows are staged over the front of the buffer
+  unsigned char* const yl = lds + ROWS * HP;
   __syncthreads();
   // ---- y = LN2(x1 + f)
   {
@@ -281,6 +288,11 @@ __global__ __launch_bounds__(TL_THREADS * TL_HALVES, TL_MINW) void k_layer_fwd(L
 #pragma unroll
       for (int k = 0; k < 4; ++k) s[k] += r4[k];
       const float2 st = tl_ln_fwd<D>(s, g, bt, A.eps, o);
+      if constexpr (QKV) {                             // operand tiles of the next layer's in-projection (pad rows: zero)
+        const float op[4] = {o[0] + p4q[p].x, o[1] + p4q[p].y, o[2] + p4q[p].z, o[3] + p4q[p].w};
+        *(uint2*)(xl + rl * XP + lc0 * 2) = live ? tl_pack4(op) : make_uint2(0u, 0u);
+        *(uint2*)(yl + rl * XP + lc0 * 2) = live ? tl_pack4(o) : make_uint2(0u, 0u);
+      }
       if (!live) continue;
       const long long e = row * D + lc0;
       TG_ST_U2(A.f + e, fq);
@@ -297,6 +309,44 @@ __global__ __launch_bounds__(TL_THREADS * TL_HALVES, TL_MINW) void k_layer_fwd(L
         *(uint2*)(A.ypos_bf + e) = tl_pack4(op);
       }
       if (lc0 == 0) *(float2*)(A.st2 + row * 2) = st;
+    }
+  }
+  if constexpr (QKV) {
+    // ---- the next layer's in-projection: same fragments, k order and rounding points as its own launch (k_tok_gemm_multi)
+    TlProd<D, D, ROWS> pv;
+    pv.prefetch(A.Wv_n, nullptr, wv, lane);
+    __syncthreads();                                   // both operand tiles are complete
+    f32x16 av[TlShape<D, D, ROWS>::MPW][TlShape<D, D, ROWS>::NPW];
+    tl_zero(av);
+    pv.run(yl, XP, wv, lane, av);
+    TlProd<D, 2 * D, ROWS> pq;
+    pq.prefetch(A.Wqk_n, nullptr, wv, lane);
+    __syncthreads();                                   // every wavefront is done with the y tile: v is staged over it
+    tl_stage<D, D, ROWS>(av, A.bin_n + 2 * D, yl, XP, wv, lane);
+    f32x16 aq[TlShape<D, 2 * D, ROWS>::MPW][TlShape<D, 2 * D, ROWS>::NPW];
+    tl_zero(aq);
+    pq.run(xl, XP, wv, lane, aq);
+    __syncthreads();                                   // ... and with the y + pos tile; the v tile is complete
+    tl_stage<D, 2 * D, ROWS>(aq, A.bin_n, lds, HP, wv, lane);
+    {
+      constexpr int CPR = D / 8, RPP = TL_THREADS / CPR;
+      const int c = tid % CPR, r = tid / CPR;
+#pragma unroll
+      for (int p = 0; p < (ROWS + RPP - 1) / RPP; ++p) {
+        const int rl = p * RPP + r;
+        if (RPP > ROWS && rl >= ROWS) break;
+        *(uint4*)(A.v_n + (row0 + rl) * D + c * 8) = *(const uint4*)(yl + rl * XP + c * 16);
+      }
+    }
+    __syncthreads();
+    {
+      constexpr int CPR = 2 * D / 8, RPP = TL_THREADS / CPR;
+      const int c = tid % CPR, r = tid / CPR;
+#pragma unroll
+      for (int p = 0; p < ROWS / RPP; ++p) {
+        const int rl = p * RPP + r;
+        *(uint4*)(A.qk_n + (row0 + rl) * (2 * D) + c * 8) = *(const uint4*)(lds + rl * HP + c * 16);
+      }
     }
   }
 }
@@ -637,8 +687,13 @@ int gd_layer_fused_rows(int d) { return d >= 256 ? TL_ROWS256 : 64; }
 int gd_layer_fused_fwd(hipStream_t st, int d, const void* o, const void* x, const void* Wo, const void* W1, const void* W2, const void* bo,
                        const void* b1, const void* b2, const float* g1, const float* be1, const float* g2, const float* be2, float eps,
                        long long n, long long n_pad, void* a, void* x1, void* h, void* f, float* st1, float* st2, float* y, void* y_bf,
-                       void* ypos_bf, const float* pos_table, const int* tok_pos, const void* res0, void* res_out) {
+                       void* ypos_bf, const float* pos_table, const int* tok_pos, const void* res0, void* res_out, const void* Wqk_n,
+                       const void* Wv_n, const void* bin_n, void* qk_n, void* v_n) {
   LfArgs A = {};
+  const bool qkv = Wqk_n != nullptr;
+  GD_REQUIRE(!qkv || (Wv_n && bin_n && qk_n && v_n && y_bf && ypos_bf), "layer_fused_fwd: the fused in-projection needs the next layer's operands");
+  A.Wqk_n = (const uint4*)Wqk_n; A.Wv_n = (const uint4*)Wv_n; A.bin_n = (const unsigned short*)bin_n;
+  A.qk_n = (unsigned short*)qk_n; A.v_n = (unsigned short*)v_n;
   A.res0 = (const unsigned short*)res0; A.res_out = (unsigned short*)res_out;
   A.o = (const unsigned short*)o; A.x = (const unsigned short*)x;
   A.Wo = (const uint4*)Wo; A.W1 = (const uint4*)W1; A.W2 = (const uint4*)W2;
@@ -651,19 +706,23 @@ int gd_layer_fused_fwd(hipStream_t st, int d, const void* o, const void* x, cons
   // bf16 rows: o, x in; a, x1, h, f, y (or x + y) out; three weight images.  Side: fp32 y at the stage boundary, the y + pos copy,
   // the stage input re-read for the block residual, statistics rows, position ids
   GdTimed timed(GD_T_TOK_GEMM, st,
-                2.0 * n_pad * d + (double)n * d * (2 + 2 + 2 + 2 + ((y_bf || res_out) ? 2 : 0)) + 2.0 * n_pad * ff + 2.0 * (d * d + 2.0 * d * ff),
-                2.0 * n_pad * (d * d + 2.0 * d * ff),
+                2.0 * n_pad * d + (double)n * d * (2 + 2 + 2 + 2 + ((y_bf || res_out) ? 2 : 0)) + 2.0 * n_pad * ff + 2.0 * (d * d + 2.0 * d * ff) +
+                    (qkv ? 2.0 * n_pad * 3 * d + 2.0 * 3 * d * d : 0.0),
+                2.0 * n_pad * (d * d + 2.0 * d * ff) + (qkv ? 2.0 * n_pad * d * 3 * d : 0.0),
                 (double)n * d * ((y ? 4 : 0) + (ypos_bf ? 2 : 0) + (res_out ? 2 : 0)) + 16.0 * n + (ypos_bf ? 4.0 * n : 0.0));
-  static bool once[2] = {false, false};
-  if (d == 128) {
-    if (!once[0]) { if (int rc = set_lds(k_layer_fwd<128>, lds)) return rc; once[0] = true; }
-    hipLaunchKernelGGL(k_layer_fwd<128>, dim3((unsigned)(n_pad / (rows * TL_HALVES))), dim3(TL_THREADS * TL_HALVES), lds, st, A);
-  } else if (d == 256) {
-    if (!once[1]) { if (int rc = set_lds(k_layer_fwd<256>, lds)) return rc; once[1] = true; }
-    hipLaunchKernelGGL(k_layer_fwd<256>, dim3((unsigned)(n_pad / (rows * TL_HALVES))), dim3(TL_THREADS * TL_HALVES), lds, st, A);
-  } else {
-    GD_REQUIRE(false, "layer_fused_fwd: d must be 128 or 256");
+  static bool once[4] = {false, false, false, false};
+  const dim3 grid((unsigned)(n_pad / (rows * TL_HALVES))), block(TL_THREADS * TL_HALVES);
+#define LF_CASE(D_, Q_, idx)                                                                              \
+  {                                                                                                       \
+    if (!once[idx]) { if (int rc = set_lds(k_layer_fwd<D_, Q_>, lds)) return rc; once[idx] = true; }      \
+    hipLaunchKernelGGL((k_layer_fwd<D_, Q_>), grid, block, lds, st, A);                                   \
   }
+  if (d == 128 && qkv) LF_CASE(128, true, 0)
+  else if (d == 128) LF_CASE(128, false, 1)
+  else if (d == 256 && qkv) LF_CASE(256, true, 2)
+  else if (d == 256) LF_CASE(256, false, 3)
+  else GD_REQUIRE(false, "layer_fused_fwd: d must be 128 or 256");
+#undef LF_CASE
   GD_LAUNCH_CHECK();
   return 0;
 }
