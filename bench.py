@@ -249,8 +249,9 @@ def measure_roofline(step, feed, n_steps=4):
                 d["side_stream_GB_per_step"] = round(sb / n_steps / 1e9, 3)
                 d["achieved_incl_side_streams"] = round((v["total_bytes"] + sb) / sec / 1e9, 1)
                 d["kernels"] = ("k_layer_fwd / k_layer_bwd_ffn / k_layer_bwd_in / k_ln2_bwd_top (csrc/layer_fused.hip: three fused launches per "
-                                "encoder layer and direction around the attention, bf16 residual stream) + k_tok_gemm_multi (q / k / v "
-                                "projections)")
+                                "encoder layer and direction around the attention, bf16 residual stream; the first workgroups of k_layer_bwd_in "
+                                "carry the layer's closing reductions - split-K partial tiles, LayerNorm partial rows, dtau: their bytes "
+                                "are side-stream bytes here) + k_tok_gemm_multi (q / k / v projections)")
         for k2, val in v.get("extra", {}).items():
             d[k2] = val
         return d, devk

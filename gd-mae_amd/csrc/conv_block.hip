@@ -14,7 +14,8 @@
 // spconv.hip: implicit-GEMM sparse convolution over the rulebook (bf16, 128 / 256 channels)
 bool gd_spconv_supported(int cin, int cout);
 int gd_spconv(hipStream_t st, const void* X, int x_f32, const int* nbr, const void* Wp, long long n, int cin, int cout, void* Y, int slot,
-              float* part);
+              float* part, const float* ride_part = nullptr, int ride_S = 0, int ride_cout = 0, int ride_cin = 0,
+              float* ride_dW = nullptr);
 int gd_spconv_rows(int cin, int cout, int x_f32);
 int gd_bn_fold_from_partials(hipStream_t st, const float* part, int nblk, int C, double count, const float* gamma,
                              const float* beta, double eps, double momentum, float* running_mean, float* running_var,
@@ -214,11 +215,24 @@ extern "C" int gdmae_conv_block_bwd(const gdmae_conv_block_args* a, void* stream
       CB_TRY(gd_dw_grouped_s(st, Gp, n_pad, a->n_out, S));
     }
     GD_REQUIRE(Gp.S == S, "conv block: slice count");
-    hipLaunchKernelGGL(k_spconv_dw_reduce, dim3(gd_div_up(9ll * C * a->cin / 4, 256)), dim3(256), 0, st, (const float*)s.dw_part, S, C, a->cin,
-                       a->dW);
-    GD_LAUNCH_CHECK();
-    // ---- input gradient: the same implicit GEMM over the transposed rulebook with the per-tap transposed weights
-    if (a->dx) CB_TRY(gd_spconv(st, s.dy, 0, a->nbr_t, a->packed_bwd, a->n_in, C, a->cin, a->dx, GD_T_SPCONV_BWD, nullptr));
+    // ---- input gradient: the same implicit GEMM over the transposed rulebook with the per-tap transposed weights; the reduce of the
+    //      weight gradient's partial tiles rides along as its first workgroups (GDMAE_DW_REDUCE_RIDES=0: a launch of its own)
+    static const bool rides = !(getenv("GDMAE_DW_REDUCE_RIDES") && atoi(getenv("GDMAE_DW_REDUCE_RIDES")) == 0);
+    bool reduced = false;
+    if (a->dx && rides) {
+      const int rc = gd_spconv(st, s.dy, 0, a->nbr_t, a->packed_bwd, a->n_in, C, a->cin, a->dx, GD_T_SPCONV_BWD, nullptr, (const float*)s.dw_part, S,
+                               C, a->cin, a->dW);
+      if (rc != -2) {
+        CB_TRY(rc);
+        reduced = true;
+      }
+    }
+    if (!reduced) {
+      hipLaunchKernelGGL(k_spconv_dw_reduce, dim3(gd_div_up(9ll * C * a->cin / 4, 256)), dim3(256), 0, st, (const float*)s.dw_part, S, C, a->cin,
+                         a->dW);
+      GD_LAUNCH_CHECK();
+      if (a->dx) CB_TRY(gd_spconv(st, s.dy, 0, a->nbr_t, a->packed_bwd, a->n_in, C, a->cin, a->dx, GD_T_SPCONV_BWD, nullptr));
+    }
     return 0;
   }
   // ---- weight gradient: dW (cout, 9 cin) += dy^T cols

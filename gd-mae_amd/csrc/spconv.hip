@@ -41,7 +41,42 @@ struct SpArgs {
   long long n;
   float* part;            // optional (gridDim.x, 2, COUT): per-workgroup column sums of Y and Y^2 (the bf16-rounded values) - the
                           // BatchNorm statistics of a conv block as this launch's epilogue instead of a pass over Y
+  // optional rider: the split-K reduce of the block's weight gradient (conv_block.hip: dW[(o * 9 + k) * cin + i] += sum_s part[k][s][o][i],
+  // slices in order) as the first `ride_blocks` workgroups of this launch - the input-gradient convolution follows the grouped
+  // weight-gradient launch anyway and touches neither its partial tiles nor dW
+  const float* ride_part;
+  float* ride_dW;
+  int ride_S, ride_cout, ride_cin;
+  unsigned ride_blocks;
 };
+
+__device__ __forceinline__ void sp_ride_dw_reduce(const SpArgs& A) {
+  const int S = A.ride_S, cout = A.ride_cout, cin = A.ride_cin;
+  const long long per_tap = (long long)S * cout * cin, mn4 = (long long)cout * cin / 4;
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < 9 * mn4; e += (long long)A.ride_blocks * blockDim.x) {
+    const int k = (int)(e / mn4);
+    const long long r = e % mn4;
+    const float4* p = reinterpret_cast<const float4*>(A.ride_part + k * per_tap) + r;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    int s = 0;
+    for (; s + 8 <= S; s += 8) {                   // eight slices in flight, added in slice order (as k_spconv_dw_reduce)
+      float4 v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = p[(long long)(s + j) * mn4];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { acc.x += v[j].x; acc.y += v[j].y; acc.z += v[j].z; acc.w += v[j].w; }
+    }
+    for (; s < S; ++s) {
+      const float4 v = p[(long long)s * mn4];
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    const long long o = (r * 4) / cin, i = (r * 4) % cin;
+    float4* d = reinterpret_cast<float4*>(A.ride_dW + (o * 9 + k) * cin + i);
+    float4 w = *d;
+    w.x += acc.x; w.y += acc.y; w.z += acc.z; w.w += acc.w;
+    *d = w;
+  }
+}
 
 constexpr int kWaves = 8;
 
@@ -75,8 +110,10 @@ __global__ __launch_bounds__(512, 2) void k_spconv(SpArgs A) {
   constexpr int P = ROWS / RPP;                    // passes per tap
   static_assert(P >= 1 && ROWS % RPP == 0, "unsupported shape");
   extern __shared__ __align__(16) unsigned char lds[];
+  if (blockIdx.x < A.ride_blocks) return sp_ride_dw_reduce(A);      // uniform per workgroup
+  const unsigned blk = blockIdx.x - A.ride_blocks;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const long long row0 = (long long)blockIdx.x * ROWS;
+  const long long row0 = (long long)blk * ROWS;
   const int mb0 = wv / WPB;
   const int nb0 = (wv % WPB) * NPW;
   const uint4* __restrict__ wp = A.Wp + (size_t)mb0 * 64 + lane;        // + (gstep * MB + j * kWaves) * 64
@@ -256,7 +293,7 @@ __global__ __launch_bounds__(512, 2) void k_spconv(SpArgs A) {
         float a = 0.f;
 #pragma unroll
         for (int g = 0; g < ORPP; ++g) a += red[g * 2 * COUT + e];
-        A.part[(long long)blockIdx.x * 2 * COUT + e] = a;
+        A.part[(long long)blk * 2 * COUT + e] = a;
       }
     }
   }
@@ -272,7 +309,7 @@ int sp_launch(const SpArgs& A, hipStream_t st) {
     GD_CHECK(hipFuncSetAttribute((const void*)k_spconv<CIN, COUT, SRC_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     once = true;
   }
-  hipLaunchKernelGGL((k_spconv<CIN, COUT, SRC_F32>), dim3((unsigned)gd_div_up(A.n, ROWS)), dim3(512), lds, st, A);
+  hipLaunchKernelGGL((k_spconv<CIN, COUT, SRC_F32>), dim3((unsigned)gd_div_up(A.n, ROWS) + A.ride_blocks), dim3(512), lds, st, A);
   GD_LAUNCH_CHECK();
   return 0;
 }
@@ -295,11 +332,17 @@ int gd_spconv_rows(int cin, int cout, int x_f32) {
   return 0;
 }
 // part (optional): (ceil(n / gd_spconv_rows), 2, cout) fp32 partial rows of the column sums of Y, Y^2
+// ride_* (optional, ride_part != null): a conv block's weight-gradient reduce carried by this launch (SpArgs); refused (-2) when this
+// launch does not happen (n <= 0) - the caller then reduces with a launch of its own
 int gd_spconv(hipStream_t st, const void* X, int x_f32, const int* nbr, const void* Wp, long long n, int cin, int cout, void* Y, int slot,
-              float* part) {
-  if (n <= 0) return 0;
+              float* part, const float* ride_part, int ride_S, int ride_cout, int ride_cin, float* ride_dW) {
+  if (n <= 0) return ride_part ? -2 : 0;
   GD_REQUIRE(gd_spconv_supported(cin, cout), "spconv: channels must be 128 or 256");
-  SpArgs A{X, nbr, (const uint4*)Wp, (unsigned short*)Y, n, part};
+  SpArgs A{X, nbr, (const uint4*)Wp, (unsigned short*)Y, n, part, nullptr, nullptr, 0, 0, 0, 0u};
+  if (ride_part) {
+    A.ride_part = ride_part; A.ride_dW = ride_dW; A.ride_S = ride_S; A.ride_cout = ride_cout; A.ride_cin = ride_cin;
+    A.ride_blocks = (unsigned)gd_div_up(9ll * ride_cout * ride_cin / 4, 512);
+  }
   // gathered rows (L2) + the output rows + the weight image, per launch
   GdTimed timed(slot, st, (double)n * (9.0 * cin * (x_f32 ? 4 : 2) + 2.0 * cout + 36.0) + 18.0 * cin * cout, 2.0 * n * 9.0 * cin * cout);
 #define SP_CASE(ci, co)                                                    \
@@ -333,13 +376,13 @@ extern "C" int gdmae_spconv_pack_jobs(const float* W, int cin, int cout, int tra
 
 extern "C" int gdmae_spconv(const void* X, int x_f32, const int* nbr, const void* packed, long long n, int cin, int cout, void* Y,
                             int timing_slot, void* stream) {
-  return gd_spconv((hipStream_t)stream, X, x_f32, nbr, packed, n, cin, cout, Y, timing_slot > 0 ? timing_slot : GD_T_SPCONV_FWD, nullptr);
+  return gd_spconv((hipStream_t)stream, X, x_f32, nbr, packed, n, cin, cout, Y, timing_slot > 0 ? timing_slot : GD_T_SPCONV_FWD, nullptr, nullptr, 0, 0, 0, nullptr);
 }
 extern "C" int gdmae_spconv_stat_rows(int cin, int cout, int x_f32) { return gd_spconv_rows(cin, cout, x_f32); }
 extern "C" int gdmae_spconv_stats(const void* X, int x_f32, const int* nbr, const void* packed, long long n, int cin, int cout, void* Y,
                                   float* part, void* stream) {
   GD_REQUIRE(part != nullptr, "spconv_stats: partial rows");
-  return gd_spconv((hipStream_t)stream, X, x_f32, nbr, packed, n, cin, cout, Y, GD_T_SPCONV_FWD, part);
+  return gd_spconv((hipStream_t)stream, X, x_f32, nbr, packed, n, cin, cout, Y, GD_T_SPCONV_FWD, part, nullptr, 0, 0, 0, nullptr);
 }
 
 

@@ -61,9 +61,10 @@ def test_bf16_rounding_is_the_hardware_instruction(tmp_path):
     """every bf16 epilogue of the fused layer kernels converts with v_cvt_pk_bf16_f32; the LayerNorm reductions use DPP row
     operations / permlane swaps, not ds_bpermute shuffles"""
     k = _isa("layer_fused.hip", tmp_path)
-    fwd = [n for n in k if "k_layer_fwdILi256E" in n]
-    assert len(fwd) == 1
-    text = "\n".join(k[fwd[0]])
-    assert text.count("v_cvt_pk_bf16_f32") >= 32
-    assert "ds_bpermute" not in text and "ds_swizzle" not in text
-    assert text.count("_dpp") + text.count("v_permlane") >= 48
+    fwd = sorted(n for n in k if "k_layer_fwdILi256E" in n)
+    assert len(fwd) == 2          # <256, false> (product) and <256, true> (next layer's in-projection on board: GDMAE_QKV_RIDES=1)
+    for name in fwd:
+        text = "\n".join(k[name])
+        assert text.count("v_cvt_pk_bf16_f32") >= 32
+        assert "ds_bpermute" not in text and "ds_swizzle" not in text
+        assert text.count("_dpp") + text.count("v_permlane") >= 48
