@@ -322,6 +322,8 @@ class Workload:
         self.host_s = 0.0
 
     def step(self, i, pts, nxt=None, k=0, nxt_ready=None):
+        if getattr(self, "pre_sync", False):          # host-time leg: every step is issued into an idle device
+            torch.cuda.synchronize()
         t_host = time.perf_counter()
         try:
             return self._step(i, pts, nxt, k, nxt_ready)
@@ -531,6 +533,22 @@ def main():
     frames = B * world * args.steps
     fps = frames / dt
     wl.advance = False
+    # what the host needs to ISSUE a step when nothing makes it wait (device idle at the start of every step, the wait for the plan's
+    # event excluded): the split of host_ms_per_step / host_wait_ms_per_step above moves with where a full launch queue happens to block
+    # the issuing thread, this number does not
+    host_idle_ms = None
+    if wl.mae and args.prefetch:
+        wl.pre_sync = True
+        wl.feed(2, args.warmup)                       # (first steps after the switch: pending plan handed over)
+        h0, w0 = wl.host_s, gplan.EVENT_WAIT_S
+        wl.feed(8, args.warmup)
+        host_idle_ms = 1e3 * ((wl.host_s - h0) - (gplan.EVENT_WAIT_S - w0)) / 8
+        wl.pre_sync = False
+        sync_all()
+        if distd:
+            hi = torch.tensor([host_idle_ms], dtype=torch.float64, device=dev)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            host_idle_ms = float(hi.item())
     loss, bd = wl.last
     final_loss = float(loss.detach())
     assert np.isfinite(final_loss), "training diverged"
@@ -539,7 +557,7 @@ def main():
     out = {"metric": "MAE pre-train frames/sec (Waymo-shape, 180k pts, 75% mask)" if pre else "fine-tune frames/sec (KITTI-shape, CenterPoint head)",
            "value": round(fps, 2),
            "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-           "ms_per_step": round(1e3 * dt / args.steps, 3), "host_ms_per_step": round(host_ms, 3), "host_wait_ms_per_step": round(host_wait_ms, 3), "device_allocs_in_timed_region": int(n_dev_alloc), "higher_is_better": True, "scaling": "weak",
+           "ms_per_step": round(1e3 * dt / args.steps, 3), "host_ms_per_step": round(host_ms, 3), "host_wait_ms_per_step": round(host_wait_ms, 3), "host_issue_ms_idle_device": None if host_idle_ms is None else round(host_idle_ms, 3), "device_allocs_in_timed_region": int(n_dev_alloc), "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
            "config": {"workload": WORKLOADS[named] + (f", mask {args.mask_ratio}" if pre else "") +
                                   ", full train step (H2D of the next batch + fwd + bwd + grad all-reduce + clip + Adam)",
