@@ -62,10 +62,10 @@ def parse():
     ap.add_argument("--feed", default="h2d", choices=["h2d", "resident"], help="h2d: every batch copied from pinned host memory inside the timed region")
     ap.add_argument("--prefetch", type=int, default=1, help="1: build the geometry plan of batch t+1 on a side stream")
     ap.add_argument("--miopen-find", type=int, default=1, help="1: torch.backends.cudnn.benchmark (MIOpen find mode)")
-    ap.add_argument("--autograd-thread", type=int, default=1,
-                    help="1 (default): torch's autograd worker thread; 0: torch.autograd.set_multithreading_enabled(False) - the ~60 hand-written "
-                         "backward nodes of a step run on the calling thread (0.5 ms less host time per step when issued into an idle device; "
-                         "no effect on the GPU-bound step: 9.30 / 5.89 ms per 8- / 4-frame step either way)")
+    ap.add_argument("--autograd-thread", type=int, default=0,
+                    help="0 (default): torch.autograd.set_multithreading_enabled(False) - the ~60 hand-written backward nodes of a step run on "
+                         "the calling thread (0.8 ms less host time per step when issued into an idle device: 3.0 vs 3.8 ms, "
+                         "tools/host_profile.py; no effect on the GPU-bound step); 1: torch's autograd worker thread (torch's default)")
     return ap.parse_args()
 
 

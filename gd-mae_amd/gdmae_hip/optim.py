@@ -145,6 +145,14 @@ class FlatAdamOneCycle:
         """One cast of the flat buffer -> bf16 views per parameter (consumed by gdmae_hip.ops.shadow).  ``cast=False``: the shadow
         buffer is current (written by the optimizer launch itself)."""
         if not cast:
+            # fast path of the training loop: no parameter changed on the torch side since the views were stamped (one pass over the
+            # version counters instead of two passes with pointer comparisons: 0.27 -> 0.05 ms of host time per step)
+            stamp = getattr(self, "_shadow_stamp", None)
+            if stamp is not None and stamp[0] == self.flat_param_bf16.data_ptr() and stamp[1] == [p._version for p in self.params]:
+                if self.flat_param.is_cuda:
+                    from . import packing
+                    packing.repack_registered()
+                return
             # a torch-side weight change since the last stamp (load_state_dict between two steps): the optimizer launch only rewrote
             # the elements it updates, so re-derive everything
             cast = any(getattr(p, "_gd_shadow", None) is None or p._gd_shadow[1] != p._version for p in self.params)
@@ -159,6 +167,7 @@ class FlatAdamOneCycle:
             if sh is None or sh[1] != p._version or sh[0].data_ptr() != self.flat_param_bf16.data_ptr() + 2 * off:
                 p._gd_shadow = (self.flat_param_bf16[off:off + k].view(p.shape), p._version)
             off += k
+        self._shadow_stamp = (self.flat_param_bf16.data_ptr(), [p._version for p in self.params])
         if self.flat_param.is_cuda:
             from . import packing
             packing.repack_registered()          # fragment-ordered images of the encoder weights (one launch)
