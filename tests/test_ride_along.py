@@ -1,0 +1,61 @@
+"""Launch-count switches of the encoder / conv-block backward and of the stage forward leave every bit where it was: the reductions that
+ride along with the launch that follows them (GDMAE_LAYER_TAIL_RIDES, GDMAE_DW_REDUCE_RIDES: DESIGN section 9) are the same sums in the same
+order as the launches of their own, and the in-projection carried by the previous layer's closing launch (GDMAE_QKV_RIDES=1) produces the
+q / k / v rows of k_tok_gemm_multi.  The switches are read once per process, so every setting is a subprocess that runs one bench-mode train
+step (flat optimizer, bf16 autocast, fused layers) on a golden case's inputs and prints a digest of the loss and of the whole flat gradient."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+STEP = r'''
+import hashlib, logging, os, sys
+REPO = sys.argv[1]
+sys.path[:0] = [REPO, os.path.join(REPO, "gd-mae_amd"), os.path.join(REPO, "tests")]
+import numpy as np, torch
+from helpers import load_case
+from oracle import gdmae_oracle as orc          # test infrastructure: seeded parameters only
+from gdmae_hip import configs, optim
+from pcdet.models import build_network
+dev = torch.device("cuda:0")
+z, ds, cfg, shapes = load_case(sys.argv[2])
+torch.manual_seed(0)
+net = build_network(cfg, len(ds.class_names), ds, logging.getLogger("t")).to(dev)
+net.load_state_dict(orc.seeded_state_dict(shapes, seed=int(z["seed"])), strict=False)
+net.train()
+opt = optim.FlatAdamOneCycle(net, configs.optimization_cfg(8), total_steps=10)
+opt.zero_grad()
+bd = {"points": torch.from_numpy(z["points"]).to(dev), "batch_size": int(z["batch_size"]), "mae_noise": torch.from_numpy(z["noise"]).to(dev)}
+with torch.autocast("cuda", dtype=torch.bfloat16):
+    ret, _, _ = net(bd)
+ret["loss"].backward()
+torch.cuda.synchronize()
+g = opt.flat_grad.detach().cpu().numpy()
+assert np.isfinite(g).all() and float(np.abs(g).sum()) > 0
+print("DIGEST", float(ret["loss"]).hex(), hashlib.sha256(g.tobytes()).hexdigest())
+'''
+
+
+def _digest(case, env_extra):
+    env = dict(os.environ)
+    for k in ("GDMAE_LAYER_TAIL_RIDES", "GDMAE_DW_REDUCE_RIDES", "GDMAE_QKV_RIDES"):
+        env.pop(k, None)
+    env.update(env_extra)
+    out = subprocess.run([sys.executable, "-c", STEP, REPO, case], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("DIGEST")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return lines[0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["waymo_b1"])
+def test_ride_along_switches_are_bit_identical(case):
+    base = _digest(case, {})
+    assert _digest(case, {}) == base, "the step itself is not bit-repeatable"
+    for env in ({"GDMAE_LAYER_TAIL_RIDES": "0"}, {"GDMAE_DW_REDUCE_RIDES": "0"}, {"GDMAE_QKV_RIDES": "1"},
+                {"GDMAE_LAYER_TAIL_RIDES": "0", "GDMAE_DW_REDUCE_RIDES": "0", "GDMAE_QKV_RIDES": "1"}):
+        assert _digest(case, env) == base, env
