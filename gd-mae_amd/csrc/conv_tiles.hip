@@ -648,8 +648,9 @@ __global__ __launch_bounds__(256) void k_tiles_gather_rows(const void* __restric
   const int cv = C * ES / 16;
   const long long total = n * cv;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const long long r = i / cv;
-    const int v = (int)(i % cv);
+    // (32-bit division where the index fits: the emulated 64-bit one costs ~100 instructions per 16 bytes)
+    const long long r = total < (1ll << 31) ? (long long)((unsigned)i / (unsigned)cv) : i / cv;
+    const int v = (int)(i - r * cv);
     const int s = cell[r];
     const int x = s % W, q = s / W, y = q % H, b = q / H;
     out[i] = ((const uint4*)gd_y_row<ES>(Yc, T, b, y, x, H, W, C))[v];

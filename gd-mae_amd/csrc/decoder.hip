@@ -953,12 +953,15 @@ __global__ __launch_bounds__(256) void k_decoder_dy(const unsigned short* __rest
                                                     const float* __restrict__ k0, const float* __restrict__ k1,
                                                     const float* __restrict__ rows, const int* __restrict__ cell2pillar, int H, int W,
                                                     int TH, int TW, int C, unsigned short* __restrict__ dYc) {
-  const int cv = C >> 3;
-  const long long total = (long long)n_act * GD_TILE_SITES * cv;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int v = (int)(i % cv);
-    const long long row = i / cv;
-    const int slot = (int)(row >> 6), loc = (int)(row & 63);
+  // index arithmetic in 32 bits (the launcher checks n_act * 64 * C / 8 < 2^31): a 64-bit division and remainder per 16 bytes are
+  // emulated (~200 instructions) next to 16 bytes of traffic each way
+  const unsigned cv = (unsigned)C >> 3;
+  const unsigned total = (unsigned)n_act * GD_TILE_SITES * cv;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const unsigned row32 = i / cv;
+    const int v = (int)(i - row32 * cv);
+    const long long row = row32;
+    const int slot = (int)(row32 >> 6), loc = (int)(row32 & 63);
     const int tile = tile_list[slot];
     const int tx = tile % TW, r = tile / TW, ty = r % TH, b = r / TH;
     const int y = ty * GD_TILE + (loc >> 3), x = tx * GD_TILE + (loc & 7);
@@ -996,6 +999,7 @@ extern "C" int gdmae_decoder_dy(const void* Yc, const int* tile_list, int n_act,
                                 const int* cell2pillar, int H, int W, int C, void* dYc, void* stream) {
   GD_REQUIRE(C % 8 == 0, "decoder_dy: C must be a multiple of 8");
   if (n_act <= 0) return 0;
+  GD_REQUIRE((long long)n_act * GD_TILE_SITES * (C / 8) < (1ll << 31), "decoder_dy: active tiles x 64 x C / 8 must fit 31 bits");
   long long g = ((long long)n_act * GD_TILE_SITES * (C / 8) + 255) / 256;
   if (g > 65536) g = 65536;
   hipLaunchKernelGGL(k_decoder_dy, dim3((int)g), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)Yc, tile_list, n_act, k0, k1, rows,
@@ -1011,8 +1015,9 @@ __global__ __launch_bounds__(256) void k_decoder_site_rulebook(const int* __rest
                                                                int* __restrict__ nbr) {
   const long long total = (long long)(*n_dev) * sites_per_tok * 9;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int k = (int)(i % 9);
-    const int s = site[i / 9];
+    const long long t = total < (1ll << 31) ? (long long)((unsigned)i / 9u) : i / 9;      // (32-bit division where the index fits)
+    const int k = (int)(i - t * 9);
+    const int s = site[t];
     const int x = s % W, r = s / W, y = r % H, b = r / H;
     const int uy = y - (k / 3 - 1), ux = x - (k % 3 - 1);
     int v = -1;
