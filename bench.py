@@ -61,6 +61,8 @@ def parse():
                          "dense convolutions are the library's own (round 5)")
     ap.add_argument("--feed", default="h2d", choices=["h2d", "resident"], help="h2d: every batch copied from pinned host memory inside the timed region")
     ap.add_argument("--prefetch", type=int, default=1, help="1: build the geometry plan of batch t+1 on a side stream")
+    ap.add_argument("--plan-at", default="conv", choices=["start", "conv", "bwd"],
+                    help="where in step t the plan of batch t+1 is issued: at the start of the step, or right before the decoder's tile convolution")
     ap.add_argument("--miopen-find", type=int, default=1, help="1: torch.backends.cudnn.benchmark (MIOpen find mode)")
     ap.add_argument("--autograd-thread", type=int, default=0,
                     help="0 (default): torch.autograd.set_multithreading_enabled(False) - the ~60 hand-written backward nodes of a step run on "
@@ -340,13 +342,20 @@ class Workload:
         if self.mae and self.args.prefetch:
             plan = self.pending.pop(id(pts), None) or net.backbone_3d.prefetch_plan(pts, B).finish()
             bd["_gdmae_vox"], bd["_gdmae_plan"] = plan
-            if nxt is not None:
-                # geometry plan of the NEXT batch: issued at the start of the step on a side stream that is ordered after the
-                # work queued so far (incl. the wait for that batch's copy) - its ~100 small kernels run under this step's
-                # forward and are complete long before the host asks for them at the end of the step
+            if nxt is not None and self.args.plan_at == "conv":
+                # geometry plan of the NEXT batch: issued from inside this step's forward right before the decoder's tile convolution
+                # (the matrix-core-bound launch of the step) on a side stream ordered after the work queued so far (incl. the wait
+                # for that batch's copy): its atomics-and-scatter kernels run under that launch (7.54 -> 7.44 ms per step same-box
+                # against issuing it at the start of the step) and are complete long before the host asks for them
+                pf = net.backbone_3d.prefetch_plan_under_decoder(nxt, B, ready=nxt_ready)
+            elif nxt is not None and self.args.plan_at == "start":
                 pf = net.backbone_3d.prefetch_plan(nxt, B, ready=nxt_ready)
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.mode["bf16"]):
             ret, tb, _ = net(bd)
+        if hasattr(pf, "ensure_issued"):
+            pf.ensure_issued()                   # (a forward without the tile convolution - fp32 mode - issues the plan here)
+        if self.mae and self.args.prefetch and nxt is not None and self.args.plan_at == "bwd":
+            pf = net.backbone_3d.prefetch_plan(nxt, B, ready=nxt_ready)      # experiment: under the first launches of the backward (slower)
         ret["loss"].backward()
         opt.all_reduce_grads()
         opt.step(i)

@@ -48,6 +48,11 @@ CONV_BWD = os.environ.get("GDMAE_DEC_BWD", "implicit")
 BN_EPS, BN_MOM = 1e-3, 0.01
 
 
+# One-shot callable invoked right before the decoder's tile convolution is launched (the one matrix-core-bound launch of the step):
+# the training loop issues the NEXT batch's geometry plan there, so that the plan's atomics-and-scatter kernels on the side stream run
+# under it instead of under the memory-bound start of the forward (bench.py --plan-at conv).
+PRE_CONV_HOOK = None
+
 def colstats(x2d: torch.Tensor):
     """(sum, sumsq) per column of a contiguous (R, C) fp32/bf16 device matrix, as float64 (C,) tensors."""
     R, C = x2d.shape
@@ -167,6 +172,10 @@ class DecoderHead(torch.autograd.Function):
             if bn2 is not None and bn2.training and bn2.running_mean is not None:
                 rm, rv, nb, mom = bn2.running_mean, bn2.running_var, bn2.num_batches_tracked, float(bn2.momentum)
             flops = 2.0 * dt.n_act * 64 * C2 * 9 * Cin
+            global PRE_CONV_HOOK
+            if PRE_CONV_HOOK is not None:        # one-shot: work to issue (on another stream) right before the tile convolution
+                hook, PRE_CONV_HOOK = PRE_CONV_HOOK, None
+                hook()
             with timing.kernel("k_conv3x3_tiles", dt.n_act * 64 * (Cin + C2) * 2, flops,
                                {"dense_equivalent_TFLOPs_per_launch": round(2.0 * R * C2 * 9 * Cin / 1e12, 4), "active_tiles": dt.n_act}):
                 L.call("gdmae_conv3x3_tiles_fwd", L.host_ptrs([P.contiguous() for P in Ps]), L.host_ptrs(maps), L.host_ptrs(a_l),

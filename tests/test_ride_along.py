@@ -59,3 +59,40 @@ def test_ride_along_switches_are_bit_identical(case):
     for env in ({"GDMAE_LAYER_TAIL_RIDES": "0"}, {"GDMAE_DW_REDUCE_RIDES": "0"}, {"GDMAE_QKV_RIDES": "1"},
                 {"GDMAE_LAYER_TAIL_RIDES": "0", "GDMAE_DW_REDUCE_RIDES": "0", "GDMAE_QKV_RIDES": "1"}):
         assert _digest(case, env) == base, env
+
+
+@pytest.mark.gpu
+def test_plan_issued_under_the_decoder_convolution():
+    """SPTBackboneMAE.prefetch_plan_under_decoder: the next batch's plan is issued from inside the current forward (right before the tile
+    convolution), finish() returns the plan prefetch_plan() builds, and a forward on it gives the loss of the inline plan, bit for bit."""
+    import logging
+    sys.path[:0] = [REPO, os.path.join(REPO, "gd-mae_amd"), os.path.join(REPO, "tests")]
+    import torch
+    from helpers import load_case
+    from oracle import gdmae_oracle as orc
+    from gdmae_hip import decoder as gdec
+    from pcdet.models import build_network
+    dev = torch.device("cuda:0")
+    z, ds, cfg, shapes = load_case("waymo_b1")
+    torch.manual_seed(0)
+    net = build_network(cfg, len(ds.class_names), ds, logging.getLogger("t")).to(dev)
+    net.load_state_dict(orc.seeded_state_dict(shapes, seed=int(z["seed"])), strict=False)
+    net.train()
+    pts, B = torch.from_numpy(z["points"]).to(dev), int(z["batch_size"])
+    noise = torch.from_numpy(z["noise"]).to(dev)
+    noise_cap = torch.cat([noise, torch.rand(pts.shape[0] - noise.numel(), device=dev)])
+    bb = net.backbone_3d
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        ref, _, _ = net({"points": pts, "batch_size": B, "mae_noise": noise})
+        pf = bb.prefetch_plan_under_decoder(pts, B, noise=noise_cap)
+        assert gdec.PRE_CONV_HOOK is not None
+        net({"points": pts, "batch_size": B, "mae_noise": noise})            # the forward that carries the issue
+        assert gdec.PRE_CONV_HOOK is None, "the forward did not pass the hook"
+        vox, plan = pf.finish()
+        out, _, _ = net({"points": pts, "batch_size": B, "_gdmae_vox": vox, "_gdmae_plan": plan})
+    assert float(out["loss"]) == float(ref["loss"])
+    # a forward that never reaches the tile convolution: finish() issues the plan itself
+    pf2 = bb.prefetch_plan_under_decoder(pts, B, noise=noise_cap)
+    vox2, plan2 = pf2.finish()
+    assert gdec.PRE_CONV_HOOK is None
+    assert torch.equal(vox2.pillar_cell, vox.pillar_cell) and torch.equal(plan2.mask, plan.mask)
