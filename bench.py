@@ -260,7 +260,9 @@ def measure_roofline(step, feed, n_steps=4):
 
     top = max(summ, key=lambda k: summ[k]["total_ms"])
     out, devk = describe(top, summ[top])
-    out["timed"] = "HIP events on the launch stream, product path (native stage executor), %d steps after the timed region" % n_steps
+    out["timed"] = ("HIP events on the launch stream, product path (native stage executor), %d steps after the timed region; the next "
+                    "batch's geometry plan (side stream) is issued at the start of these steps, not under the tile convolution as in the "
+                    "timed region" % n_steps)
     out["traffic"], src = _pmc_traffic(devk)
     if src:
         out["traffic_source"] = ("PROFILING BOX, not this run: " + src + " (2 x FETCH_SIZE + WRITE_SIZE per launch, committed rocprofv3 --pmc "
@@ -571,6 +573,10 @@ def main():
            "config": {"workload": WORKLOADS[named] + (f", mask {args.mask_ratio}" if pre else "") +
                                   ", full train step (H2D of the next batch + fwd + bwd + grad all-reduce + clip + Adam)",
                       "frames_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
+                      "geometry_plan": ("of batch t+1: one library call on a side stream, issued from inside step t's forward right before the "
+                                        "decoder's tile convolution (SPTBackboneMAE.prefetch_plan_under_decoder)" if args.plan_at == "conv" else
+                                        "of batch t+1: one library call on a side stream, issued at the %s of step t" % ("start" if args.plan_at == "start" else "start of the backward"))
+                                       if (pre and args.prefetch) else None,
                       "autograd": "backward nodes on the calling thread (torch.autograd.set_multithreading_enabled(False))" if not args.autograd_thread
                                   else "torch default (autograd worker thread)",
                       "params": n_params, "mask_ratio": args.mask_ratio if pre else None, "loss_last": round(final_loss, 5),
@@ -586,7 +592,12 @@ def main():
                                       "fp32 parity mode: bit-exact indices / masks, Chamfer loss within 1e-4 rel of the reference"}}
 
     # the roofline steps run on EVERY rank: they contain the gradient all-reduce, a collective the other ranks must join
+    # kernel brackets with the training stream alone on the device: during these extra steps the next batch's plan is issued at the START
+    # of the step (as before round 5's last change), not under the decoder's tile convolution - a bracket around that launch would
+    # otherwise time the plan's kernels with it (0.47 -> 0.37 of the matrix-core peak in the same run)
+    plan_at, args.plan_at = args.plan_at, "start"
     roofline = measure_roofline(wl.step, lambda n: wl.feed(n, total_steps - 1), 4) if (not args.no_roofline and wl.mae) else None
+    args.plan_at = plan_at
     loss, bd = wl.last
     vox, ep = bd.get("_gdmae_vox"), bd.get("_gdmae_plan")
 

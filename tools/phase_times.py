@@ -55,7 +55,12 @@ def step(i, rec):
     bd = {"points": pts, "batch_size": NB, "_gdmae_grad_sync": opt.sync}
     bd["_gdmae_vox"], bd["_gdmae_plan"] = pf.finish() if hasattr(pf, "finish") else pf
     hp0 = time.perf_counter()
-    pfn = None if REUSE else net.backbone_3d.prefetch_plan(nxt, 8, ready=resident)
+    if REUSE:
+        pfn = None
+    elif "--plan-at-start" in sys.argv:          # the plan of the next batch issued here, at the start of the step (before round 5's last change)
+        pfn = net.backbone_3d.prefetch_plan(nxt, 8, ready=resident)
+    else:                                        # ... or from inside the forward, right before the decoder's tile convolution (product)
+        pfn = net.backbone_3d.prefetch_plan_under_decoder(nxt, 8, ready=resident)
     h1 = time.perf_counter()
     HOST["issue"] = HOST.get("issue", 0.0) + (h1 - hp0 if rec else 0.0)
     with torch.autocast("cuda", dtype=torch.bfloat16):
@@ -99,7 +104,8 @@ def step(i, rec):
     h5 = time.perf_counter()
     if not REUSE:
         hw0 = time.perf_counter()
-        pfn.event.synchronize()
+        if hasattr(pfn, "event"):
+            pfn.event.synchronize()
         hw1 = time.perf_counter()
         pend[i + 1] = pfn.finish()
         if rec:
