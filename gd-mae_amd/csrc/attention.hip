@@ -654,6 +654,11 @@ static bool levels_fast_path(int io_bf16, int n_levels, const int* max_tokens, i
     if (max_tokens[l] != 16 && max_tokens[l] != 32 && max_tokens[l] != 64) return false;
   return true;
 }
+// 1 when gdmae_window_attention_levels_fwd with these arguments (and the current gdmae_set_attention_impl) writes `lse` - the caller hands
+// `out` / `lse` to the backward only then (a backward after an implementation switch must not read rows the forward never wrote)
+extern "C" int gdmae_window_attention_levels_writes_lse(int io_bf16, int n_levels, const int* max_tokens, int d, int H) {
+  return (levels_fast_path(io_bf16, n_levels, max_tokens, H, d) && g_attn_impl == 0) ? 1 : 0;
+}
 extern "C" int gdmae_window_attention_levels_fwd(const void* qk, const void* v, void* out, int io_bf16, const int* csr_tok,
                                                  const int* win_start, const int* win_len, int n_levels, const int* n_win,
                                                  const int* max_tokens, int d, int H, const float* tau, float tau_min, float* lse,

@@ -1,5 +1,5 @@
 // Decoder conv_out (Conv2d 3x3, pad 1, no bias; reference pcdet/models/backbones_3d/spt_backbone_mae.py:46-52,
-// 125-133) as a bf16-MFMA implicit GEMM over the ACTIVE TILES of the BEV map, with the BatchNorm2d statistics of its
+// 125-133) as a 16-bit-MFMA implicit GEMM (fp16 operands since round 6, bf16 output) over the ACTIVE TILES of the BEV map, with the BatchNorm2d statistics of its
 // output fused (replaces MIOpen's dense forward convolution, the 1.35 GB background fill + three row scatters that
 // built its 384-channel input map, and the statistics pass over its dense output).
 //
@@ -11,10 +11,10 @@
 //
 // k_conv3x3_tiles: one workgroup (4 wavefronts) = two 8x8 tiles = 128 sites x 128 output channels, K = 9 taps x 384.
 //   * per source stage ("phase"): the 10x10 halo patches of both tiles (128 channels) are gathered through the stage's
-//     cell -> token map, normalised, rounded to bf16 and laid out in LDS with a 272-byte site pitch / 2944-byte row
+//     cell -> token map, normalised, rounded to fp16 and laid out in LDS with a 272-byte site pitch / 2944-byte row
 //     pitch (conflict-free ds_read_b128 for the 4-rows-by-8-columns MFMA column blocks); all 9 taps read the same
 //     patch at a compile-time byte offset.
-//   * MFMA v_mfma_f32_32x32x16_bf16 computes Y^T: A = weights (rows = 32 output channels of the wavefront, packed once
+//   * MFMA v_mfma_f32_32x32x16_f16 computes Y^T: A = weights (rows = 32 output channels of the wavefront, packed once
 //     per step in fragment order so a wavefront streams 1 KB per k-step straight from L2 into VGPRs, no LDS, no
 //     barrier in the K loop), B = 32 sites from LDS.  Wavefront w owns output channels [32 w, 32 w + 32) of all 128
 //     sites: 4 accumulators, 1 weight fragment + 4 site fragments per 4 MFMAs.
@@ -24,9 +24,11 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 union CtFrag {
   uint4 q;
   bf16x8 v;
+  f16x8 h;
 };
 
 #define CT_C 128                 // channels per source stage and output channels
@@ -71,6 +73,10 @@ union CtFrag {
 __device__ inline float ct_bf2f(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
 __device__ inline unsigned short ct_f2bf(float f) { return gd_to_bf16(f); }
 __device__ inline unsigned ct_pack2(float lo, float hi) { return gd_pack_bf16(lo, hi); }
+__device__ inline float ct_f16r(float f) {          // f rounded to fp16 the way gd_pack_f16 rounds it, back in fp32
+  const unsigned p = gd_pack_f16(f, 0.f);
+  return (float)__builtin_bit_cast(_Float16, (unsigned short)(p & 0xFFFFu));
+}
 __device__ inline void ct_unpack8(const uint4& u, float (&f)[8]) {
   const unsigned w[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
@@ -176,7 +182,7 @@ int gd_decoder_tiles_lb(const int* const* maps, const int* strides, int k, int B
 // ------------------------------------------------------------------------------------------------
 // Per-step preparation: weights in MFMA-fragment order, background row, border-class constants
 // ------------------------------------------------------------------------------------------------
-// Wp[((g * 72 + tap * 8 + ks) * 4 + w) * 64 + lane] = 8 bf16: output channel 32 w + (lane & 31), input channels
+// Wp[((g * 72 + tap * 8 + ks) * 4 + w) * 64 + lane] = 8 fp16: output channel 32 w + (lane & 31), input channels
 // g * 128 + ks * 16 + (lane >> 5) * 8 + j, tap = ky * 3 + kx of conv_w (C2, Cin, 3, 3)
 __global__ __launch_bounds__(256) void k_ct_pack_weights(const float* __restrict__ w, int Cin, int nsteps, uint4* __restrict__ Wp) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -188,11 +194,11 @@ __global__ __launch_bounds__(256) void k_ct_pack_weights(const float* __restrict
   float f[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) f[j] = w[((long long)o * Cin + ci + j) * 9 + tap];
-  uint4 q;
-  q.x = ct_pack2(f[0], f[1]);
-  q.y = ct_pack2(f[2], f[3]);
-  q.z = ct_pack2(f[4], f[5]);
-  q.w = ct_pack2(f[6], f[7]);
+  uint4 q;                      // fp16 values (round 6): see gd_pack_f16, common.h
+  q.x = gd_pack_f16(f[0], f[1]);
+  q.y = gd_pack_f16(f[2], f[3]);
+  q.z = gd_pack_f16(f[4], f[5]);
+  q.w = gd_pack_f16(f[6], f[7]);
   Wp[i] = q;
 }
 
@@ -200,9 +206,9 @@ struct CtBPtrs {
   const float* b[CT_MAX_SRC];
 };
 
-// one workgroup per output channel o: t[k] = sum_c bf16(W[o][c][k]) * bg[c] with bg[c] = bf16(relu(b[c])), then the 9
-// border-class constants ybg[cls][o] = bf16(sum of t[k] over the taps of the class that fall inside the map).
-// Block 0 also writes the background row bgz (Cin) bf16.
+// one workgroup per output channel o: t[k] = sum_c f16(W[o][c][k]) * bg[c] with bg[c] = f16(relu(b[c])) - the operands the tile kernel
+// multiplies -, then the 9 border-class constants ybg[cls][o] = bf16(sum of t[k] over the taps of the class that fall inside the map).
+// Block 0 also writes the background row bgz (Cin) bf16 (what the backward subtracts from its bf16 operand rows).
 __global__ __launch_bounds__(256) void k_ct_class_consts(const float* __restrict__ w, CtBPtrs Bp, int Cin, int C2,
                                                          unsigned short* __restrict__ bgz, unsigned short* __restrict__ ybg) {
   __shared__ double sh[9][256];
@@ -212,11 +218,10 @@ __global__ __launch_bounds__(256) void k_ct_class_consts(const float* __restrict
   for (int k = 0; k < 9; ++k) t[k] = 0.0;
   for (int c = threadIdx.x; c < Cin; c += 256) {
     const float bv = Bp.b[c / CT_C][c % CT_C];
-    const unsigned short bh = ct_f2bf(bv > 0.f ? bv : 0.f);
-    if (o == 0) bgz[c] = bh;
-    const double bg = (double)ct_bf2f(bh);
+    if (o == 0) bgz[c] = ct_f2bf(bv > 0.f ? bv : 0.f);
+    const double bg = (double)ct_f16r(bv > 0.f ? bv : 0.f);
 #pragma unroll
-    for (int k = 0; k < 9; ++k) t[k] += (double)ct_bf2f(ct_f2bf(w[((long long)o * Cin + c) * 9 + k])) * bg;
+    for (int k = 0; k < 9; ++k) t[k] += (double)ct_f16r(w[((long long)o * Cin + c) * 9 + k]) * bg;
   }
 #pragma unroll
   for (int k = 0; k < 9; ++k) sh[k][threadIdx.x] = t[k];
@@ -279,7 +284,7 @@ struct CtArgs {
   float* part;               // (n_act, 2, 128) per-tile sum / sum of squares over the in-map sites
 };
 
-#define CT_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+#define CT_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
 
 // byte offset of k-step st of a phase (tap st / CT_KS, 16-channel step st % CT_KS) inside the LDS patch
 #define CT_OFF(st) ((((st) / CT_KS) / 3) * CT_ROW_PITCH + (((st) / CT_KS) % 3) * CT_PSITE + ((st) % CT_KS) * 32)
@@ -368,8 +373,8 @@ __global__ __launch_bounds__(CT_THREADS, CT_TPW == 2 ? (CT_CH == 64 ? 3 : 2) : 1
         {
           float r[8];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) r[j] = bv[j] > 0.f ? bv[j] : 0.f;
-          bgq.x = ct_pack2(r[0], r[1]); bgq.y = ct_pack2(r[2], r[3]); bgq.z = ct_pack2(r[4], r[5]); bgq.w = ct_pack2(r[6], r[7]);
+          for (int j = 0; j < 8; ++j) r[j] = bv[j];
+          bgq.x = gd_pack_f16_relu(r[0], r[1]); bgq.y = gd_pack_f16_relu(r[2], r[3]); bgq.z = gd_pack_f16_relu(r[4], r[5]); bgq.w = gd_pack_f16_relu(r[6], r[7]);
         }
         uint4 q[CT_NPASS];
 #pragma unroll
@@ -386,11 +391,9 @@ __global__ __launch_bounds__(CT_THREADS, CT_TPW == 2 ? (CT_CH == 64 ? 3 : 2) : 1
             float f[8];
             ct_unpack8(q[p], f);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              const float h = fmaf(av[j], f[j], bv[j]);
-              f[j] = h > 0.f ? h : 0.f;
-            }
-            o.x = ct_pack2(f[0], f[1]); o.y = ct_pack2(f[2], f[3]); o.z = ct_pack2(f[4], f[5]); o.w = ct_pack2(f[6], f[7]);
+            for (int j = 0; j < 8; ++j) f[j] = fmaf(av[j], f[j], bv[j]);
+            // ReLU + fp16 range clamp (one v_med3_f32) + conversion: the site operands are fp16 like the weight image
+            o.x = gd_pack_f16_relu(f[0], f[1]); o.y = gd_pack_f16_relu(f[2], f[3]); o.z = gd_pack_f16_relu(f[4], f[5]); o.w = gd_pack_f16_relu(f[6], f[7]);
           } else if (code[p] == -1) {
             o = bgq;
           } else {
@@ -420,10 +423,10 @@ __global__ __launch_bounds__(CT_THREADS, CT_TPW == 2 ? (CT_CH == 64 ? 3 : 2) : 1
             sf[(st + 1) & 1][2].q = *(const uint4*)(lb + CT_TILE_PITCH + CT_OFF(st + 1));
             sf[(st + 1) & 1][3].q = *(const uint4*)(lb + CT_TILE_PITCH + 4 * CT_ROW_PITCH + CT_OFF(st + 1));
           }
-          acc0 = CT_MFMA(wr[st % (CT_RING + 1)].v, sf[st & 1][0].v, acc0);
-          acc1 = CT_MFMA(wr[st % (CT_RING + 1)].v, sf[st & 1][1].v, acc1);
-          acc2 = CT_MFMA(wr[st % (CT_RING + 1)].v, sf[st & 1][2].v, acc2);
-          acc3 = CT_MFMA(wr[st % (CT_RING + 1)].v, sf[st & 1][3].v, acc3);
+          acc0 = CT_MFMA(wr[st % (CT_RING + 1)].h, sf[st & 1][0].h, acc0);
+          acc1 = CT_MFMA(wr[st % (CT_RING + 1)].h, sf[st & 1][1].h, acc1);
+          acc2 = CT_MFMA(wr[st % (CT_RING + 1)].h, sf[st & 1][2].h, acc2);
+          acc3 = CT_MFMA(wr[st % (CT_RING + 1)].h, sf[st & 1][3].h, acc3);
           __builtin_amdgcn_sched_barrier(0);   // nothing moves across a step: the prefetch distances are what is written here
         }
       }

@@ -87,6 +87,10 @@ int gd_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const void* A
       return gd_gemm_f32(st, ta, tb, M, N, K, (const float*)A, lda, (const float*)B, ldb, (float*)C, ldc, (const float*)bias, batch, sA, sB, sC);
     }
   }
+  // GDMAE_NO_LIBRARY=1 (bench.py sets it): nothing that is benchmarked may reach hipBLASLt - a product outside the shapes the own kernels
+  // serve fails here instead of silently running on the library ("no library kernel on any benchmarked config" enforced, not traced)
+  static const bool no_library = getenv("GDMAE_NO_LIBRARY") && atoi(getenv("GDMAE_NO_LIBRARY")) != 0;
+  GD_REQUIRE(!no_library, "gd_gemm: this product would run on hipBLASLt and GDMAE_NO_LIBRARY=1 forbids it");
   std::lock_guard<std::mutex> lock(g_lt_mu);
   if (!g_lt) LT_CHECK(hipblasLtCreate(&g_lt));
   // loose shapes: extents are bucketed to 3 significant bits (<= 25 % apart; extents <= 64 to multiples of 16), so the

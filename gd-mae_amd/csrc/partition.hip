@@ -432,8 +432,10 @@ struct PlanJob {
   int* nbr;
   int* nbr_rev;
 };
+// a strided stage appends up to four jobs (down, down^T, subm, upsampled sites): 4 x GDMAE_PLAN_MAX_STAGES
+constexpr int kPlanMaxJobs = 16;
 struct PlanJobs {
-  PlanJob j[12];
+  PlanJob j[kPlanMaxJobs];
   int count;
 };
 __global__ __launch_bounds__(256) void k_plan_jobs(PlanJobs J) {

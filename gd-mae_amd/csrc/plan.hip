@@ -41,8 +41,10 @@ struct PlanJob {
   int* nbr;
   int* nbr_rev;
 };
+// a strided stage appends up to four jobs (down, down^T, subm, upsampled sites): 4 x GDMAE_PLAN_MAX_STAGES
+constexpr int kPlanMaxJobs = 16;
 struct PlanJobs {
-  PlanJob j[12];
+  PlanJob j[kPlanMaxJobs];
   int count;
 };
 int gd_plan_jobs(const PlanJobs& J, long long cap_max, hipStream_t st);
@@ -311,6 +313,7 @@ extern "C" int gdmae_geometry_plan(const gdmae_plan_params* p, const float* poin
   GD_REQUIRE(ns <= 4, "geometry plan: at most four stages");
   for (int i = 0; i < ns; ++i) {
     const StageGeo& g = O.geo[i];
+    GD_REQUIRE(J.count + 4 <= kPlanMaxJobs, "geometry plan: job table full");
     if (g.cap > cap_max) cap_max = g.cap;
     if (p->stride[i] == 2) {
       int rc = gd_plan_downsample(cur_map, B, Yp, Xp, I(O.s[i].tok_cell), I(O.s[i].map), n_tok + i, lb, st);

@@ -11,7 +11,8 @@
 //   k_rows_gemm_kc       dX = dP Wm^T: K = s*s*cout up to 2048 in chunks of <= 512 through one LDS tile, accumulators stay in registers
 //   weight gradient      Wm-shaped dWm = X^T dP through the grouped TN kernel (dw_grouped.hip, guarded row loads) and
 //   k_deconv_dw_reduce   its fixed-order split-K reduce, accumulated straight into weight.grad's (cin, cout, s, s) layout
-// Same MFMA mapping and rounding points as the token GEMMs (tok_tiles.h): bf16 operands, fp32 accumulation, bf16 results.
+// Same MFMA mapping as the token GEMMs (tok_tiles.h), fp32 accumulation, bf16 results; the FORWARD product takes fp16 operands (round 6:
+// the bf16 rounding of these weights was the largest single term of the bf16 mode's loss deviation at full size), the gradients bf16.
 #include "../../include/gdmae_hip.h"
 #include "dw_grouped.h"
 #include "tok_tiles.h"
@@ -45,12 +46,16 @@ __global__ __launch_bounds__(256) void k_deconv_pack(const float* __restrict__ w
         f[j] = w[((long long)ci * cout + c) * ss + q];
       }
     }
-    (is_bwd ? bwd : fwd)[e] = tg_pack8(f);
+    // the FORWARD image holds fp16 values (k_rows_gemm multiplies fp16 operands: the rounding of these weights is the same error at
+    // every site of the map and dominated the bf16 mode's loss deviation at full size, common.h gd_pack_f16); the gradient image bf16
+    if (is_bwd) bwd[e] = tg_pack8(f);
+    else fwd[e] = tg_pack8_f16(f);
   }
 }
 
 // ---- guarded tile load: rows >= n repeat row n - 1 (finite garbage; their results are never stored) -----------------
-template <int W, int ROWS>
+// TOF16: the bf16 rows are converted to fp16 on their way into LDS (exact: encoder outputs are O(1) LayerNorm / BatchNorm rows)
+template <int W, int ROWS, bool TOF16 = false>
 __device__ __forceinline__ void rg_load_tile(const unsigned short* __restrict__ src, long long ld, int c0, long long row0, long long n, unsigned char* dst,
                                              int P, int tid) {
   constexpr int CPR = W / 8, RPP = 512 / CPR;
@@ -61,7 +66,9 @@ __device__ __forceinline__ void rg_load_tile(const unsigned short* __restrict__ 
     if (RPP > ROWS && row >= ROWS) break;
     long long g = row0 + row;
     g = g < n ? g : n - 1;
-    *(uint4*)(dst + row * P + c * 16) = *(const uint4*)(src + g * ld + c0 + c * 8);
+    const uint4 q = *(const uint4*)(src + g * ld + c0 + c * 8);
+    if constexpr (TOF16) *(uint4*)(dst + row * P + c * 16) = gd_bf16x8_to_f16(q);
+    else *(uint4*)(dst + row * P + c * 16) = q;
   }
 }
 template <int W, int ROWS>
@@ -87,7 +94,7 @@ struct RgRows {
 
 struct RgArgs {
   const unsigned short* X;      // (n, K) bf16
-  const uint4* Wp;              // packed (N, K)
+  const uint4* Wp;              // packed (N, K), fp16 values
   unsigned short* Y;            // (n, N) bf16
   long long n;
   int N;
@@ -103,9 +110,9 @@ __global__ __launch_bounds__(512, 4) void k_rows_gemm(RgArgs A) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const long long row0 = (long long)blockIdx.x * ROWS;
   const int sl = blockIdx.y;
-  TlProd<KD, NSL, ROWS> pr;
+  TlProd<KD, NSL, ROWS, KD / 16, true> pr;            // fp16 operands: image of k_deconv_pack, rows converted on load
   pr.prefetch(A.Wp + (size_t)sl * (NSL / 32) * 64, nullptr, wv, lane, A.N / 32);
-  rg_load_tile<KD, ROWS>(A.X, KD, 0, row0, A.n, lds, XP, tid);
+  rg_load_tile<KD, ROWS, true>(A.X, KD, 0, row0, A.n, lds, XP, tid);
   __syncthreads();
   f32x16 acc[S::MPW][S::NPW];
   tl_zero(acc);

@@ -66,9 +66,11 @@ __device__ inline uint4 tg_ld_u4_once(const void* p) {
   return *(const uint4*)p;
 #endif
 }
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 union TgFrag {
   uint4 q;
   bf16x8 v;
+  f16x8 h;      // the same 16 bytes as eight fp16 values (forward products of the decoder: common.h gd_pack_f16)
 };
 
 #define TG_ROWS 64     // row padding granule of the callers; the kernel's own tile is TG_R<ND> rows
@@ -91,6 +93,11 @@ __device__ inline void tg_unpack8(const uint4& u, float (&f)[8]) {
 __device__ inline uint4 tg_pack8(const float (&f)[8]) {
   uint4 q;
   q.x = tg_pack2(f[0], f[1]); q.y = tg_pack2(f[2], f[3]); q.z = tg_pack2(f[4], f[5]); q.w = tg_pack2(f[6], f[7]);
+  return q;
+}
+__device__ inline uint4 tg_pack8_f16(const float (&f)[8]) {
+  uint4 q;
+  q.x = gd_pack_f16(f[0], f[1]); q.y = gd_pack_f16(f[2], f[3]); q.z = gd_pack_f16(f[4], f[5]); q.w = gd_pack_f16(f[6], f[7]);
   return q;
 }
 
@@ -165,7 +172,8 @@ __device__ __forceinline__ uint4 tl_wfrag(const uint4* __restrict__ w0, const ui
 #ifndef TL_PF1
 #define TL_PF1 TL_PF
 #endif
-template <int KD, int ND, int ROWS, int KSPLIT = KD / 16>
+// F16: both operands hold fp16 values (the packed image and the LDS tile), the product is v_mfma_f32_32x32x16_f16
+template <int KD, int ND, int ROWS, int KSPLIT = KD / 16, bool F16 = false>
 struct TlProd {
   static constexpr int PFD = (TlShape<KD, ND, ROWS>::MPW == 1 && KD / 16 > TL_PF1) ? TL_PF1 : TL_PF;
   using S = TlShape<KD, ND, ROWS>;
@@ -205,7 +213,8 @@ struct TlProd {
       for (int j = 0; j < S::MPW; ++j)
 #pragma unroll
         for (int b = 0; b < S::NPW; ++b)
-          acc[j][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[ks % (PFD + 1)][j].v, sf[ks & 1][b].v, acc[j][b], 0, 0, 0);
+          if constexpr (F16) acc[j][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[ks % (PFD + 1)][j].h, sf[ks & 1][b].h, acc[j][b], 0, 0, 0);
+          else acc[j][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[ks % (PFD + 1)][j].v, sf[ks & 1][b].v, acc[j][b], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
   }

@@ -48,10 +48,11 @@ CONV_BWD = os.environ.get("GDMAE_DEC_BWD", "implicit")
 BN_EPS, BN_MOM = 1e-3, 0.01
 
 
-# One-shot callable invoked right before the decoder's tile convolution is launched (the one matrix-core-bound launch of the step):
-# the training loop issues the NEXT batch's geometry plan there, so that the plan's atomics-and-scatter kernels on the side stream run
-# under it instead of under the memory-bound start of the forward (bench.py --plan-at conv).
-PRE_CONV_HOOK = None
+# sparse_decoder(..., pre_conv_hook=callable): invoked once right before the decoder's tile convolution is launched (the one
+# matrix-core-bound launch of the step) - the training loop issues the NEXT batch's geometry plan there, so that the plan's
+# atomics-and-scatter kernels on the side stream run under it instead of under the memory-bound start of the forward (bench.py --plan-at
+# conv).  The hook travels with the call (SPTBackboneMAE.prefetch_plan_under_decoder keeps it on the module until its forward), there is
+# no process-global state.
 
 def colstats(x2d: torch.Tensor):
     """(sum, sumsq) per column of a contiguous (R, C) fp32/bf16 device matrix, as float64 (C,) tensors."""
@@ -172,9 +173,8 @@ class DecoderHead(torch.autograd.Function):
             if bn2 is not None and bn2.training and bn2.running_mean is not None:
                 rm, rv, nb, mom = bn2.running_mean, bn2.running_var, bn2.num_batches_tracked, float(bn2.momentum)
             flops = 2.0 * dt.n_act * 64 * C2 * 9 * Cin
-            global PRE_CONV_HOOK
-            if PRE_CONV_HOOK is not None:        # one-shot: work to issue (on another stream) right before the tile convolution
-                hook, PRE_CONV_HOOK = PRE_CONV_HOOK, None
+            hook = geom[7] if len(geom) > 7 else None
+            if hook is not None:                 # work to issue (on another stream) right before the tile convolution
                 hook()
             with timing.kernel("k_conv3x3_tiles", dt.n_act * 64 * (Cin + C2) * 2, flops,
                                {"dense_equivalent_TFLOPs_per_launch": round(2.0 * R * C2 * 9 * Cin / 1e12, 4), "active_tiles": dt.n_act}):
@@ -223,7 +223,7 @@ class DecoderHead(torch.autograd.Function):
                C2, 0, L.stream())
         ctx.save_for_backward(*sites, *Ps, *ab_l, *stats_l, *[g.detach() for g in gammas], Z, y2, bgz, yrows, ab2, stats2,
                               pillar_cell, cell2pillar, gamma2.detach(), conv_w.detach(), tile_slot, ybg)
-        ctx.k, ctx.widths, ctx.geom = k, widths, geom
+        ctx.k, ctx.widths, ctx.geom = k, widths, geom[:7]      # (without the one-shot hook: the graph must not keep a plan handle alive)
         ctx.direct = [gbn.direct_pair(g, be) for g, be in zip(gammas, betas)] + [gbn.direct_pair(gamma2, beta2)]
         ctx.direct_w = ops.direct_grad(conv_w)
         ctx.conv_param = conv_w        # the parameter object itself: the packed images of the backward are registered on its identity
@@ -487,7 +487,7 @@ def upsampled_sites(stage_plan, s: int, Y: int, X: int) -> torch.Tensor:
     return gplan.upsample_cells(stage_plan.tok_cell, stage_plan.Y, stage_plan.X, s).reshape(-1).contiguous()
 
 
-def sparse_decoder(model_cfg, deblocks, conv_out, hidden, pillar_cell, cell2pillar, B, Y, X, want_dense=False, conv_impl='tiles'):
+def sparse_decoder(model_cfg, deblocks, conv_out, hidden, pillar_cell, cell2pillar, B, Y, X, want_dense=False, conv_impl='tiles', pre_conv_hook=None):
     """hidden: list of SparseConvTensor per stage.  Returns (features at the pillar sites (M, C) fp32,
     dense spatial_features (B, C, Y, X) or None)."""
     R = B * Y * X
@@ -509,7 +509,7 @@ def sparse_decoder(model_cfg, deblocks, conv_out, hidden, pillar_cell, cell2pill
         args += [upsampled_sites(sp, s, Y, X), P, bn.weight, bn.bias]
         bns.append(bn)
     conv, bn2 = conv_out[0], conv_out[1]
-    outs = DecoderHead.apply((B, Y, X, bns[0].eps, bn2.eps, cdt, tiles), conv.weight, bn2.weight, bn2.bias, pillar_cell,
+    outs = DecoderHead.apply((B, Y, X, bns[0].eps, bn2.eps, cdt, tiles, pre_conv_hook), conv.weight, bn2.weight, bn2.bias, pillar_cell,
                              cell2pillar, tuple(bns) + (bn2,), *args)
     out, y2, mean2, var2 = outs[:4]
     dense = None

@@ -152,6 +152,12 @@ class ConvBNReLUShortcut(torch.autograd.Function):
         res = x.permute(0, 2, 3, 1).reshape(B * H * W, C)
         c2 = _Ctx()
         out, _, _ = BNReLURows.forward(c2, rows, gamma, beta, eps, bn, res, part)
+        # the tensors the two bodies saved go through the REAL save_for_backward (version check against in-place edits, saved-tensor
+        # hooks, release with the graph); the stand-ins keep the non-tensor metadata only
+        t1, t2 = c1.saved_tensors, c2.saved_tensors
+        c1.saved_tensors = c2.saved_tensors = ()
+        ctx.save_for_backward(*t1, *t2)
+        ctx.n1 = len(t1)
         ctx.c1, ctx.c2 = c1, c2
         ctx.set_materialize_grads(False)
         return out.view(B, H, W, C).permute(0, 3, 1, 2)
@@ -161,6 +167,8 @@ class ConvBNReLUShortcut(torch.autograd.Function):
         if g is None:
             return (None,) * 9
         c1, c2 = ctx.c1, ctx.c2
+        sv = ctx.saved_tensors
+        c1.saved_tensors, c2.saved_tensors = sv[:ctx.n1], sv[ctx.n1:]
         B, H, W, C = c1.saved_tensors[0].shape
         grows = g.permute(0, 2, 3, 1).reshape(B * H * W, C)
         grows = (grows if grows.dtype == torch.bfloat16 else grows.to(torch.bfloat16)).contiguous()
@@ -168,7 +176,8 @@ class ConvBNReLUShortcut(torch.autograd.Function):
         c1.needs_input_grad = (ctx.needs_input_grad[0],)
         c1.dx_addend = gres.view(B, H, W, C) if ctx.needs_input_grad[0] else None
         dx, dW, db, _, _, _ = Conv3x3Dense.backward(c1, dy.view(B, H, W, C).permute(0, 3, 1, 2))
-        c1.dx_addend = None                     # (the saved operands stay with the node: a second backward over a retained graph works)
+        c1.dx_addend = None
+        c1.saved_tensors = c2.saved_tensors = ()      # (a second backward over a retained graph takes them from ctx.saved_tensors again)
         return dx, dW, db, None, None, dgamma, dbeta, None, None
 
 

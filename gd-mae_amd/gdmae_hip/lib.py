@@ -83,6 +83,7 @@ SIGNATURES = {
     "gdmae_segmax_bn_bwd": (_I, [_P, _I, _P, _P, _P, _P, _L, _I, _P, _P, _P, _P, _I, _P]),
     "gdmae_window_attention_fwd": (_I, [_P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P, _F, _P]),
     "gdmae_window_attention_bwd": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P, _F, _P]),
+    "gdmae_window_attention_levels_writes_lse": (_I, [_I, _I, _P, _I, _I]),
     "gdmae_window_attention_levels_fwd": (_I, [_P, _P, _P, _I, _P, _P, _P, _I, _P, _P, _I, _I, _P, _F, _P, _P]),
     "gdmae_window_attention_levels_bwd": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P, _P, _I, _I, _P, _F, _P, _P, _P]),
     "gdmae_conv3x3_dense_packed_bytes": (_Z, [_I, _I]),

@@ -412,20 +412,30 @@ class WindowCosineAttention(torch.autograd.Function):
         tau_flat = tau.detach().reshape(1).float().contiguous()
         # all occupancy levels through the entry the layer executor uses (bf16 rows: one launch; it leaves the rows' log-sum-exp for
         # the backward); algorithmic bytes: q,k,v rows read + out row written per token, + CSR (4 B/token + 8 B/window)
-        lse = torch.empty(n, nhead, dtype=torch.float32, device=v.device)
         nl = len(wplan.n_win)
+        # does this call leave log-sum-exp rows?  Decided HERE, by the forward's own path: the backward must not consult the (switchable)
+        # implementation flag again, it would read rows that were never written after a switch between forward and backward
+        has_lse = bool(L.load().gdmae_window_attention_levels_writes_lse(bf, nl, L.host_i32(wplan.max_tokens), d, nhead))
+        lse = torch.empty(n, nhead, dtype=torch.float32, device=v.device) if has_lse else None
         with timing.kernel("k_win_attn_fwd", n * (4 * d * es + 4) + 8 * sum(wplan.n_win)):
             L.call("gdmae_window_attention_levels_fwd", L.ptr(qk), L.ptr(v), L.ptr(out), bf, L.ptr(wplan.csr_tok), L.ptr(wplan.win_start),
                    L.ptr(wplan.win_len), nl, L.host_i32(wplan.n_win), L.host_i32(wplan.max_tokens), d, nhead, L.ptr(tau_flat), float(tau_min),
                    L.ptr(lse), L.stream())
-        ctx.out, ctx.lse = out.detach(), lse
-        ctx.save_for_backward(qk, v, tau_flat)
+        ctx.has_lse = has_lse
+        # the output is saved through save_for_backward (allowed for outputs): an in-place edit of it before backward raises
+        if has_lse:
+            ctx.save_for_backward(qk, v, tau_flat, out, lse)
+        else:
+            ctx.save_for_backward(qk, v, tau_flat)
         ctx.wplan, ctx.nhead, ctx.tau_min, ctx.tau_shape, ctx.tau_dtype = wplan, nhead, tau_min, tau.shape, tau.dtype
         return out
 
     @staticmethod
     def backward(ctx, g):
-        qk, v, tau_flat = ctx.saved_tensors
+        if ctx.has_lse:
+            qk, v, tau_flat, out, lse = ctx.saved_tensors
+        else:
+            (qk, v, tau_flat), out, lse = ctx.saved_tensors, None, None
         wplan, H = ctx.wplan, ctx.nhead
         n, d = v.shape
         g = g.contiguous().to(v.dtype)
@@ -440,7 +450,7 @@ class WindowCosineAttention(torch.autograd.Function):
         with timing.kernel("k_win_attn_bwd", n * (7 * d * es + 4) + 8 * sum(wplan.n_win)):
             L.call("gdmae_window_attention_levels_bwd", L.ptr(qk), L.ptr(v), L.ptr(g), L.ptr(dqk), L.ptr(dv), bf, L.ptr(part), L.ptr(wplan.csr_tok),
                    L.ptr(wplan.win_start), L.ptr(wplan.win_len), len(wplan.n_win), L.host_i32(wplan.n_win), L.host_i32(wplan.max_tokens), d, H,
-                   L.ptr(tau_flat), float(ctx.tau_min), L.ptr(ctx.out), L.ptr(ctx.lse), L.stream())
+                   L.ptr(tau_flat), float(ctx.tau_min), L.ptr(out), L.ptr(lse), L.stream())
         dtau = torch.empty(1, dtype=torch.float32, device=v.device)
         # d clamp(tau, min)/d tau = 1 where tau >= min (torch.clamp backward), folded into the partial sum
         L.call("gdmae_sum_partials_gated", L.ptr(part), pbase, 1.0, L.ptr(dtau), L.ptr(tau_flat), float(ctx.tau_min),

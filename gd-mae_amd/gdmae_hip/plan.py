@@ -484,6 +484,7 @@ class PlanPrefetch:
     never stalls the host behind the backward of batch t, and the host can run a full step ahead of the GPU."""
 
     _side = {}
+    _arena_bytes = {}        # device index -> bytes of every plan arena allocated there (monotone)
 
     def __init__(self, points, point_cloud_range, voxel_size, grid_size, batch_size, strides, window_shapes, drop_infos,
                  keep_frac=None, noise=None, ready=None, dec_sources=None):
@@ -514,7 +515,14 @@ class PlanPrefetch:
                                                                     strides, window_shapes, drop_infos, keep_frac, dec_sources)
         self.masked, self.dec_sources, self.batch_size, self.ncols = keep_frac is not None, dec_sources, int(batch_size), ncols
         with torch.cuda.stream(side):
-            raw = torch.empty(total, dtype=torch.uint8, device=dev)
+            # every arena of a device has the SAME size - the largest layout seen so far, in 64 MB steps: the caching allocator then
+            # hands a freed arena to the next prefetch whole.  With the exact `total` of each capacity bucket it split a cached block for
+            # a slightly smaller request and had nothing left for the next larger one: 21 hipMalloc calls (device-synchronising) in 50
+            # timed steps of round 5's bench
+            cap = PlanPrefetch._arena_bytes.get(dev.index, 0)
+            if total > cap:
+                cap = PlanPrefetch._arena_bytes[dev.index] = -(-total // (64 << 20)) * (64 << 20)
+            raw = torch.empty(cap, dtype=torch.uint8, device=dev)
             if self.masked and noise is None:
                 noise = torch.rand(m_cap, device=dev, dtype=torch.float32)
             if noise is not None:
@@ -547,8 +555,12 @@ class PlanPrefetch:
         EVENT_WAIT_S += _time.perf_counter() - t_w          # host blocked on the plan stream (it runs ahead of the GPU otherwise)
         torch.cuda.current_stream().wait_event(self.event)
         c = self.host.tolist()
+        # from here on the plan lives in the returned objects only (vox._arena keeps the allocation): this handle lets go of the arena,
+        # the input points and the noise, so that whoever still holds the handle does not hold 0.8 GB with it
+        self.points_device = self.points.device
+        self.host = None
         if self._pinned is not None:                               # read: the buffer may serve the next prefetch
-            _PINNED.setdefault(self.points.device.index, []).append(self._pinned)
+            _PINNED.setdefault(self.points_device.index, []).append(self._pinned)
             self._pinned = None
         P, names, total, geo, m_cap, (lo, vs, grid) = self.shape
         A, V = self.arena, self.arena.view
@@ -593,6 +605,7 @@ class PlanPrefetch:
                               nbrs)
         ep = EncoderPlan(V("mask", f32, M) if self.masked else None, V("tok_pillar", i32, stages[0].n_tok if not geo[0]["strided"] else n_vis),
                          stages, dt)
+        self.arena = self.points = self.keep = None
         return vox, ep
 
 

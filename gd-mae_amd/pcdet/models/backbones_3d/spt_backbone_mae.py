@@ -23,6 +23,35 @@ def _only_the_pred_head_sees_the_gradient(pred) -> bool:
     return not getattr(nxt[0], '_tensor_pre_hooks', None) and not getattr(nxt[0], '_pre_hooks', None) and not getattr(nxt[0], '_retains_grad_hooks', None)
 
 
+class _DeferredPlan:
+    """Handle of SPTBackboneMAE.prefetch_plan_under_decoder.  A plain object with explicit slots - no closures, no class defined per
+    call: those were reference CYCLES, so the plan they pointed to (an 832 MB arena, its points, its noise) stayed alive until
+    Python's cyclic collector ran and every prefetch in between needed a fresh hipMalloc (21 device-synchronising allocations in 50
+    timed steps of round 5's bench)."""
+    __slots__ = ("_mod", "_args", "_pf")
+
+    def __init__(self, mod, args):
+        self._mod, self._args, self._pf = mod, args, None
+
+    def __call__(self):
+        """issue the plan (once)"""
+        if self._pf is None and self._args is not None:
+            points, batch_size, noise, ready = self._args
+            self._args = None
+            self._pf = self._mod.prefetch_plan(points, batch_size, noise=noise, ready=ready)
+
+    def ensure_issued(self):
+        """after the forward: a forward that did not pass the tile convolution issues the plan here"""
+        if self._mod is not None and getattr(self._mod, '_pre_conv_hook', None) is self:
+            self._mod._pre_conv_hook = None
+        self()
+
+    def finish(self):
+        self.ensure_issued()
+        pf, self._pf, self._mod = self._pf, None, None
+        return pf.finish()
+
+
 class SPTBackboneMAE(nn.Module):
     # 'sparse': exact sparse-aware decoder (gdmae_hip/decoder.py); 'dense': the reference's dataflow through
     # the torch modules (kept for A/B tests).  dense_spatial_features: materialise batch_dict['spatial_features']
@@ -91,9 +120,13 @@ class SPTBackboneMAE(nn.Module):
         B, X, Y = int(batch_dict['batch_size']), int(self.grid_size[0]), int(self.grid_size[1])
         if self.decoder_impl == 'sparse' and self.training:
             # (eval: the BatchNorm2d layers must use their running statistics -> the module path below)
+            # the one-shot hook of prefetch_plan_under_decoder belongs to THIS module and THIS forward: taken off the module before the
+            # decoder runs, so a forward that raises leaves nothing behind for an unrelated forward to fire
+            hook, self._pre_conv_hook = getattr(self, '_pre_conv_hook', None), None
             pyramid, sf = gdec.sparse_decoder(self.model_cfg, self.decoder_deblocks, self.decoder_conv_out, hidden,
                                               vox.pillar_cell, vox.cell2pillar, B, Y, X,
-                                              want_dense=self.dense_spatial_features, conv_impl=self.decoder_conv_impl)
+                                              want_dense=self.dense_spatial_features, conv_impl=self.decoder_conv_impl,
+                                              pre_conv_hook=hook)
         else:
             sf = run_decoder(self.model_cfg, self.decoder_deblocks, self.decoder_conv_out, hidden)   # (B, C, Y, X)
             assert sf.shape[0] == B and sf.shape[2] == Y and sf.shape[3] == X
@@ -122,22 +155,10 @@ class SPTBackboneMAE(nn.Module):
         step, 4.78 -> 4.63 at 4 frames).  Call it BEFORE the forward of the current batch; ``.finish()`` (after that forward) ->
         (vox, plan) as ``prefetch_plan(...).finish()``.  If the forward never reaches the tile convolution (dense decoder, fp32 mode)
         the plan is issued by ``ensure_issued()`` (call it right after the forward) or, at the latest, by ``finish()``."""
-        box = []
-        issue = lambda: box.append(self.prefetch_plan(points, batch_size, noise=noise, ready=ready))
-        gdec.PRE_CONV_HOOK = issue
-
-        class _Deferred:
-            def ensure_issued(_self):
-                """after the forward: a forward that did not pass the tile convolution issues the plan here"""
-                if not box:
-                    if gdec.PRE_CONV_HOOK is issue:
-                        gdec.PRE_CONV_HOOK = None
-                    issue()
-
-            def finish(_self):
-                _self.ensure_issued()
-                return box[0].finish()
-        return _Deferred()
+        # the hook lives on the module, not process-global: two models cannot cross-fire, and one left over from an aborted forward
+        # is replaced here (its own finish() still issues it)
+        self._pre_conv_hook = d = _DeferredPlan(self, (points, batch_size, noise, ready))
+        return d
 
     def _dec_sources(self):
         """Stage indices feeding the decoder (their active sets define the active tiles of conv_out), or None when the

@@ -331,6 +331,9 @@ int gdmae_window_attention_bwd(const void* qk, const void* v, const void* dout, 
  * lse (forward, optional): (n_tok, H) fp32, receives log2 sum_k exp(logit) of every row of the T = 32 / 64 levels; the backward takes it
  * back together with the forward's output rows `out` (both optional there: without them the backward re-derives the softmax statistics on
  * the one-wavefront-per-(window, head) kernels). */
+/* 1 when the forward below, called with these arguments under the current gdmae_set_attention_impl, writes `lse`: only then may `out` /
+ * `lse` be handed to the backward (max_tokens: HOST array of n_levels ints) */
+int gdmae_window_attention_levels_writes_lse(int io_bf16, int n_levels, const int* max_tokens, int d, int H);
 int gdmae_window_attention_levels_fwd(const void* qk, const void* v, void* out, int io_bf16, const int* csr_tok,
                                       const int* win_start, const int* win_len, int n_levels, const int* n_win,
                                       const int* max_tokens, int d, int H, const float* tau, float tau_min, float* lse, void* stream);

@@ -222,15 +222,19 @@ def test_one_full_size_frame_matches_the_oracle(config, min_points):
 # gradient norms 3.1e-2 / 1.7e-2, cosine 0.99412 / 0.99417.  The temperature gradients are sums of O(1e-4) terms that cancel to 2e-5 ..
 # 2e-4 and sit on an ABSOLUTE noise floor set by the bf16 q / k / v rows: 5.6e-2 / 1.5e-1 of the largest |dtau| (vector 4.8e-2 / 1.0e-1)
 # for those two arithmetically equivalent states, 1.7e-1 in round 3 - their bound stays at the floor, not at 2 x one sample of it
-LOSS_REL, NORM_REL, COS_MIN, TAU_ABS, TAU_L2 = 2.5e-4, 0.065, 0.988, 0.20, 0.20
+# round 6: LOSS_REL is north_star's own 1e-4 (the decoder's forward products take fp16 operands: the bf16 rounding of the deconvolution
+# and conv_out WEIGHTS - the same error at every site - was +7.7e-5 + 6.2e-5 of round 5's 1.5e-4, tools/weight_rounding_full_size.py);
+# measured 3.6e-5 (weight seed 7) and 2.5e-5 (seed 3)
+LOSS_REL, NORM_REL, COS_MIN, TAU_ABS, TAU_L2 = 1.0e-4, 0.065, 0.988, 0.20, 0.20
 
 
-def test_bench_mode_matches_fp32_mode_at_full_size(scene):
+@pytest.mark.parametrize("weight_seed", [7, 3])
+def test_bench_mode_matches_fp32_mode_at_full_size(scene, weight_seed):
     """8 full-size frames, the exact configuration bench.py times (bf16 autocast, fused VFE layers, stage executor, tile
     convolution, flat optimizer with bf16 weight shadows) against the HIP fp32 parity mode with the dense decoder dataflow
     (the mode held to 1e-4 of the reference above and in test_hip_parity) on the same weights, frames and masking noise:
-    identical geometry; loss, every parameter's gradient norm and direction within the constants above (LOSS_REL 2.5e-4, NORM_REL
-    6.5 %, COS_MIN 0.988 = 2 x the measured deviations; round 5 measured 1.4e-4, 2.1 %, 0.99424).  tau (one scalar per layer whose
+    identical geometry; loss within north_star's 1e-4 (LOSS_REL; round 6 measured 3.6e-5 / 2.5e-5 for the two weight seeds, round 5 1.4e-4),
+    every parameter's gradient norm and direction within NORM_REL 6.5 %, COS_MIN 0.988 (2 x the measured 2.3 %, 0.9944).  tau (one scalar per layer whose
     gradient is a heavily cancelling sum over all (window, head, query, key) terms: 2e-5 .. 2e-4 here) carries an ABSOLUTE noise
     floor from the bf16 q/k/v rows: it is bounded by |dtau_bf16 - dtau_fp32| <= TAU_ABS (20 %) of the largest |dtau_fp32| over the
     layers + 10 % of its own value, and the 12-vector of tau gradients by a relative L2 error of TAU_L2 (20 %); measured 5.6 - 15 % /
@@ -242,7 +246,7 @@ def test_bench_mode_matches_fp32_mode_at_full_size(scene):
     noise = torch.rand(vox.M, generator=torch.Generator(device="cpu").manual_seed(11)).to(dev())
     res = {}
     for mode in ("bench", "fp32"):
-        torch.manual_seed(7)
+        torch.manual_seed(weight_seed)
         net = build_network(cfg, len(ds.class_names), ds, logging.getLogger("t")).to(dev()).train()
         net.sync_loss_scalar = False
         names = [n for n, _ in net.named_parameters()]
@@ -284,6 +288,8 @@ def test_bench_mode_matches_fp32_mode_at_full_size(scene):
     print(f"[bench vs fp32, full size] loss rel {abs(lb - lf) / abs(lf):.3e}; worst gradient-norm deviation {worst['norm']:.3e}, worst cosine "
           f"{worst['cos']:.5f}; tau: worst |d| / max|dtau| {worst['tau']:.3e}, vector L2 rel {tau_l2:.3e}")
     assert abs(lb - lf) <= LOSS_REL * abs(lf), (lb, lf)
+    if weight_seed != 7:
+        return        # the gradient bounds are 2 x what seed 7 measures (tau: its noise floor); the second seed pins the LOSS bound only
     assert tau_l2 <= TAU_L2, (tb.tolist(), tf.tolist())
     assert not bad, bad
 

@@ -704,24 +704,21 @@ def test_prefetched_plan_is_identical_to_inline_plan():
     assert float(ret0["loss"]) == float(ret1["loss"])
 
 
-# bench (bf16) mode against the REFERENCE's fp32 goldens: bounds = 2 x the deviations measured on MI355X (round 5, printed by the test and
-# by tools/bench_vs_golden.py; loss floor 1e-4 = north_star's bound).  Measured: loss 4.5e-4 / 1.9e-5 / 7.2e-5 / 1.2e-4, worst
-# per-parameter gradient-norm deviation 4.4 / 4.0 / 2.8 / 4.1 %, temperature gradients within 21 / 23 / 24 / 9 % of the largest |dtau|.
-# Before the prediction head's forward became fp32-accurate (rows_gemm.hip k_pred_fwd) the loss sat at 4.8e-4 / 2.7e-4 / 3.5e-4 / 1.4e-4:
-# the Chamfer loss squares those offsets, so their rounding is a bias.  What remains on kitti_b2 is the rounding of the decoder's GEMM
-# OPERANDS (tools/oracle_rounding_injection.py: each of deconvolution / conv_out operands / conv_out output moves the fp32 oracle's loss
-# by 0.7 - 2.4e-4 with either sign when rounded to bf16) - inherent to bf16 products, not a stored tensor.
-# The gradient-norm bound of kitti_b2 is a NOISE floor, not an accuracy: when the BatchNorm statistics of the sparse-conv blocks moved
+# bench (16-bit) mode against the REFERENCE's fp32 goldens.  Round 6: the decoder's forward products (deconvolution rows, tile
+# convolution) multiply fp16 instead of bf16 operands - the bf16 rounding of those WEIGHTS was the one systematic term (the same error at
+# every site: tools/weight_rounding_full_size.py, tools/oracle_rounding_injection.py) - and the loss went from 5.2e-4 / 2.2e-5 / 2.3e-5 /
+# 2.8e-4 to 3.8e-6 / 9.1e-5 / 3.7e-5 / 1.5e-4.  What is left on these SMALL cases (1 - 2 frames, 3 - 16 k pillars) is the rounding of the bf16
+# activations, which averages over the pillars of a batch: a build with fp16 operands in EVERY forward product (sparse convolutions,
+# in-projection, out-projection, feed-forward block; measured, not kept) lands at 2.0e-4 / 3.1e-4 / 4.9e-5 / 5.4e-5 - another sample of the
+# same noise, and the fp32 oracle with exact weights and bf16-rounded activations at -1.3e-4 / +1.3e-4 / -4.1e-5 / +1.3e-5.  north_star's
+# 1e-4 is asserted where the noise has averaged out: 8 full-size frames (test_full_size_properties.py LOSS_REL, two weight seeds: 3.6e-5,
+# 2.5e-5); here the bound is the small-case noise floor, the same for every case.
+# The gradient-norm bound of kitti_b2 is a NOISE floor too: when the BatchNorm statistics of the sparse-conv blocks moved
 # into the convolution's epilogue (same sums of the same rounded values in another order: they change by 1e-7 relative, checked to
 # 1e-6 by test_spconv_implicit_gemm_matches_gathered_product), its worst parameters - the in-projection / out-projection / LayerNorm
 # biases of stage 2's first block, column sums over a few hundred rows that cancel almost completely - went from 4.4 % to 9.1 % while
 # the other cases stayed at 3 - 4 % (tools/ab_bench_mode_golden.py with GDMAE_SPCONV_STATS=0 / 1: 4.4 | 9.1, 4.0 | 3.6, 2.7 | 3.4 %).
-# Its bound is therefore 2 x the larger sample.
-# once_e_b1: 1.2e-4 with DynVFE's 64 -> 256 layer op by op (pre-activation rounded to bf16), 2.8e-4 since that layer runs on the
-# recompute-fused kernels (pre-activation kept in fp32: closer to fp32 on the VFE's own outputs and gradients -
-# test_vfe_point_layer_equals_op_by_op_layer[once_e_b1] - while the model's loss lands on another sample of the bf16 noise; its worst
-# gradient-norm deviation went from 4.1 to 3.1 %).
-BENCH_LOSS_REL = {"kitti_b2": 1e-3, "kitti_b2_m75": 1e-4, "waymo_b1": 1.5e-4, "once_e_b1": 5.6e-4}
+BENCH_LOSS_REL = {"kitti_b2": 4e-4, "kitti_b2_m75": 4e-4, "waymo_b1": 4e-4, "once_e_b1": 4e-4}
 BENCH_NORM_REL = {"kitti_b2": 0.18, "kitti_b2_m75": 0.08, "waymo_b1": 0.07, "once_e_b1": 0.09}
 BENCH_TAU_ABS = 0.5
 
@@ -1290,9 +1287,10 @@ def test_vfe_max_layer_crowded_pillars(sizes):
         assert bool((a[p] == int(off[p])).all()), (p, sizes[p], a[p].unique())
 
 
-def _random_sources(B, H, W, dens, seed):
+def _random_sources(B, H, W, dens, seed, operand_dtype=torch.float16):
     """Random token sets of three source stages (strides 1, 2, 4) with their dense cell -> token maps, deconvolution
-    rows P (bf16) and folded BatchNorm affines; plus the dense bf16 input map the reference dataflow would build."""
+    rows P (bf16) and folded BatchNorm affines; plus the dense input map the reference dataflow would build, rounded to the
+    operand type of the tile convolution (fp16 since round 6)."""
     g = torch.Generator().manual_seed(seed)
     maps, Ps, a_l, b_l, ups = [], [], [], [], [1, 2, 4]
     Z = torch.empty(B, H, W, 384)
@@ -1305,8 +1303,9 @@ def _random_sources(B, H, W, dens, seed):
         P = (torch.randn(cells.numel() * s * s, 128, generator=g) * 1.5).bfloat16()
         a = torch.rand(128, generator=g) + 0.5
         b = torch.randn(128, generator=g) * 0.5
-        zg = torch.relu(b).bfloat16().float().expand(B, H, W, 128).clone()
-        rows = torch.relu(P.float() * a + b).bfloat16().float().view(cells.numel(), s, s, 128)
+        zg = torch.relu(b).to(operand_dtype).float().expand(B, H, W, 128).clone()
+        # one rounding like the kernel's fmaf (a * P + b in fp64, then to fp32): an fp32 ulp decides one in 2^13 fp16 roundings
+        rows = torch.relu((P.double() * a.double() + b.double()).float()).to(operand_dtype).float().view(cells.numel(), s, s, 128)
         bb = cells // (Hs * Ws)
         yy = (cells // Ws) % Hs
         xx = cells % Ws
@@ -1321,8 +1320,8 @@ def _random_sources(B, H, W, dens, seed):
 @pytest.mark.parametrize("B,H,W,dens", [(2, 40, 40, (0.02, 0.03, 0.03)), (3, 44, 36, (0.01, 0.0, 0.02)), (1, 16, 24, (0.0, 0.0, 0.0)),
                                         (2, 24, 32, (0.3, 0.3, 0.5))])
 def test_conv3x3_tiles_matches_dense_conv(B, H, W, dens):
-    """The bf16-MFMA 3x3 convolution over the active tiles (gdmae_decoder_tiles + gdmae_conv3x3_tiles_pack/_fwd) against
-    F.conv2d in fp32 on the SAME bf16-rounded operands: active-tile set vs a brute-force dilation, every site of the map
+    """The 16-bit-MFMA 3x3 convolution over the active tiles (gdmae_decoder_tiles + gdmae_conv3x3_tiles_pack/_fwd) against
+    F.conv2d in fp64 on the SAME fp16-rounded operands (the kernel multiplies fp16 operands and rounds its output to bf16): active-tile set vs a brute-force dilation, every site of the map
     (active tiles and border-class constants) within bf16 output rounding, fused BatchNorm statistics, and the two readers
     (gather at cells, dense expansion).  Edge cases: maps that are not multiples of the tile, an empty stage, no active
     site at all, nearly full maps."""
@@ -1375,7 +1374,7 @@ def test_conv3x3_tiles_matches_dense_conv(B, H, W, dens):
            L.ptr(nb), L.ptr(stats), L.ptr(ab), L.ptr(mv), L.ptr(ws2), L.stream())
     yd = torch.empty(B * H * W, 128, dtype=torch.bfloat16, device=d)
     L.call("gdmae_tiles_to_dense", L.ptr(Yc), L.ptr(slot), L.ptr(ybg), B, H, W, 128, 2, L.ptr(yd), L.stream())
-    ref = F.conv2d(Z.permute(0, 3, 1, 2).double(), w.bfloat16().double(), None, 1, 1).permute(0, 2, 3, 1).reshape(B * H * W, 128)
+    ref = F.conv2d(Z.permute(0, 3, 1, 2).double(), w.half().double(), None, 1, 1).permute(0, 2, 3, 1).reshape(B * H * W, 128)
     got = yd.cpu().double()
     scale = ref.abs().max()
     # bf16 output rounding (2^-9 relative) + fp32 accumulation order over K = 3456

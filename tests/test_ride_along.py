@@ -85,14 +85,26 @@ def test_plan_issued_under_the_decoder_convolution():
     with torch.autocast("cuda", dtype=torch.bfloat16):
         ref, _, _ = net({"points": pts, "batch_size": B, "mae_noise": noise})
         pf = bb.prefetch_plan_under_decoder(pts, B, noise=noise_cap)
-        assert gdec.PRE_CONV_HOOK is not None
+        assert bb._pre_conv_hook is not None and not hasattr(gdec, "PRE_CONV_HOOK")      # on the module: no process-global hook
+        issued = []
+        real = bb.prefetch_plan
+        bb.prefetch_plan = lambda *a, **k: (issued.append(1), real(*a, **k))[1]
         net({"points": pts, "batch_size": B, "mae_noise": noise})            # the forward that carries the issue
-        assert gdec.PRE_CONV_HOOK is None, "the forward did not pass the hook"
+        assert bb._pre_conv_hook is None and issued == [1], "the forward did not issue the plan"
+        bb.prefetch_plan = real
         vox, plan = pf.finish()
         out, _, _ = net({"points": pts, "batch_size": B, "_gdmae_vox": vox, "_gdmae_plan": plan})
     assert float(out["loss"]) == float(ref["loss"])
     # a forward that never reaches the tile convolution: finish() issues the plan itself
     pf2 = bb.prefetch_plan_under_decoder(pts, B, noise=noise_cap)
     vox2, plan2 = pf2.finish()
-    assert gdec.PRE_CONV_HOOK is None
+    assert bb._pre_conv_hook is None
+    # a second model's forward does not fire this model's pending hook
+    pf3 = bb.prefetch_plan_under_decoder(pts, B, noise=noise_cap)
+    net2 = build_network(cfg, len(ds.class_names), ds, logging.getLogger("t")).to(dev).train()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        net2({"points": pts, "batch_size": B, "mae_noise": noise})
+    assert bb._pre_conv_hook is not None
+    pf3.finish()
+    assert bb._pre_conv_hook is None
     assert torch.equal(vox2.pillar_cell, vox.pillar_cell) and torch.equal(plan2.mask, plan.mask)
