@@ -453,6 +453,15 @@ def pin_rank_to_numa(local, world):
             per = len(allowed) // len(same)
             k = same.index(local)
             allowed = allowed[k * per:(k + 1) * per]
+        # rehearsal of N ranks on fewer GPUs (tools/eight_ranks_one_gpu.sh: gloo, every rank on cuda:0): the ranks that share a device
+        # split its share of the cores as if each had a device of its own there
+        share = max(1, world // max(1, torch.cuda.device_count()))
+        k = int(os.environ.get("LOCAL_RANK", "0")) // torch.cuda.device_count()
+        if os.environ.get("GDMAE_BENCH_PIN_SLICE"):            # "k/n": independent processes sharing a device (tools/eight_procs_one_gpu.sh)
+            k, share = (int(v) for v in os.environ["GDMAE_BENCH_PIN_SLICE"].split("/"))
+        if share > 1 and len(allowed) >= 2 * share:
+            per = len(allowed) // share
+            allowed = allowed[k * per:(k + 1) * per]
         if not allowed:
             return None
         os.sched_setaffinity(0, allowed)
@@ -709,6 +718,8 @@ def main():
                     "dense_decoder_formula": dense_model}
             else:
                 out["step_bytes_model"] = dense_model
+        if affinity is not None and not distd:
+            out["pin"] = affinity
         if distd:
             opt = wl.opt
             out["grad_sync"] = {"buckets": [[b, hi - lo] for b, lo, hi in opt.buckets], "last_step": opt.sync.log,

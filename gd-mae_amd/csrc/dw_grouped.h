@@ -29,6 +29,10 @@ struct GdDwGroup {
   long long n_valid;    // rows >= n_valid are treated as zero
   int guard_rows = 0;   // 1: the operands are allocated for n_valid rows only - row loads past the end repeat row n_valid - 1 (and are
                         // cleared like every row >= n_valid); 0: the buffers extend to the padded row count
+  // filled by gd_dw_grouped_s: 0 = 128 x 128 tiles (k_dw_grouped), 1 / 2 = 128 x 256 pair tiles (k_dw_grouped2: one staged G chunk
+  // serves two X sub-tiles - 1: adjacent column blocks of one job, every N a multiple of 256; 2: the same column block of two
+  // consecutive jobs that share G, X and the shape, i.e. two taps of a gathered launch)
+  int pair_mode = 0;
 };
 
 bool gd_dw_group_supported(long long n_pad, int d, int ff);

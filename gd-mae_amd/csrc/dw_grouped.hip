@@ -322,6 +322,243 @@ __global__ __launch_bounds__(256, 2) void k_dw_grouped(GdDwGroup A) {
     }
   }
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 128 x 256 pair tiles (round 6; opt-in, GDMAE_DW_PAIR=1 - measured slower, see gd_dw_grouped_s).  k_dw_grouped is bound by its L2 -> CU load stream (probe at 49 k rows, d = 256: loads alone 76 of
+// 92 us, products alone 51): a 128 x 128 tile requests 32 KB per 64-row chunk for 16 MFMAs per wavefront.  Here a workgroup of EIGHT
+// wavefronts stages ONE G chunk for TWO X sub-tiles - adjacent column blocks of the job (pair_mode 1) or the same column block of
+// two taps of a gathered launch (pair_mode 2: the nine tap jobs read the same G) - 48 KB per chunk for twice the products, i.e. 0.75
+// of the bytes per product; wavefronts 0 - 3 / 4 - 7 own the 2 x 2 blocks of sub-tile 0 / 1 exactly as the four wavefronts of
+// k_dw_grouped own theirs (same fragments, same k order: bit-identical partial tiles).  512 threads move a chunk (two 16-byte
+// pieces of G and of each X sub-tile per thread), two chunks in flight in registers, two LDS buffers of 48 KB: one workgroup per
+// CU at the two wavefronts per SIMD of the four-wavefront kernel.
+// ---------------------------------------------------------------------------------------------------------------------
+struct Chunk2 {          // rows r, r + 32 of a staged chunk (r = tid >> 4 of 512 threads)
+  uint4 q0, q1;
+};
+__device__ __forceinline__ Chunk2 load_chunk2(const unsigned short* __restrict__ p, int ld, unsigned r, unsigned last) {
+  Chunk2 k;
+  k.q0 = *reinterpret_cast<const uint4*>(p + (unsigned long long)(r < last ? r : last) * (unsigned)ld);
+  k.q1 = *reinterpret_cast<const uint4*>(p + (unsigned long long)(r + 32 < last ? r + 32 : last) * (unsigned)ld);
+  return k;
+}
+struct ChunkIdx2 {
+  int j0, j1;
+};
+__device__ __forceinline__ ChunkIdx2 load_chunk_idx2(const int* __restrict__ xidx, int stride, unsigned row0, unsigned n_valid, int tid) {
+  const unsigned r = row0 + (tid >> 4), lastv = n_valid - 1;
+  ChunkIdx2 k;
+  k.j0 = xidx[(unsigned long long)(r < lastv ? r : lastv) * (unsigned)stride];
+  k.j1 = xidx[(unsigned long long)(r + 32 < lastv ? r + 32 : lastv) * (unsigned)stride];
+  return k;
+}
+template <bool F32>
+__device__ __forceinline__ Chunk2 load_chunk_rows2(const void* __restrict__ base, int ld, const ChunkIdx2& I, int col0, int tid) {
+  const int col = col0 + (tid & 15) * 8;
+  const long long o0 = (long long)(I.j0 < 0 ? 0 : I.j0) * ld + col, o1 = (long long)(I.j1 < 0 ? 0 : I.j1) * ld + col;
+  Chunk2 k;
+  if (F32) {
+    const float* f = (const float*)base;
+    const float4 a0 = *reinterpret_cast<const float4*>(f + o0), b0 = *reinterpret_cast<const float4*>(f + o0 + 4);
+    const float4 a1 = *reinterpret_cast<const float4*>(f + o1), b1 = *reinterpret_cast<const float4*>(f + o1 + 4);
+    k.q0 = cvt_f32x8(a0, b0); k.q1 = cvt_f32x8(a1, b1);
+  } else {
+    const unsigned short* h = (const unsigned short*)base;
+    k.q0 = *reinterpret_cast<const uint4*>(h + o0);
+    k.q1 = *reinterpret_cast<const uint4*>(h + o1);
+  }
+  return k;
+}
+__device__ __forceinline__ void and_u4(uint4& q, unsigned m) { q.x &= m; q.y &= m; q.z &= m; q.w &= m; }
+// rows >= n_valid / >= the slice's end and missing taps (bits) are cleared when the chunk is staged
+__device__ __forceinline__ void clear_chunk2(Chunk2& k, long long row0, int tid, long long n_valid, unsigned miss_bits) {
+  const int r = tid >> 4;
+  and_u4(k.q0, (row0 + r < n_valid && !(miss_bits & 1u)) ? ~0u : 0u);
+  and_u4(k.q1, (row0 + r + 32 < n_valid && !(miss_bits & 2u)) ? ~0u : 0u);
+}
+__device__ __forceinline__ void store_chunk2(unsigned char* __restrict__ lds, int tid, const Chunk2& k) {
+  const int c = tid & 15, r = tid >> 4;
+  unsigned char* p = lds + stage_off(r, c);            // (row & 3) is the same for r and r + 32
+  *reinterpret_cast<uint4*>(p) = k.q0;
+  *reinterpret_cast<uint4*>(p + 32 * kRowBytes) = k.q1;
+}
+
+template <int XM>
+__global__ __launch_bounds__(512, 1) void k_dw_grouped2(GdDwGroup A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];        // [buffer][G | X sub 0 | X sub 1][kStage]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int xcd = blockIdx.x & 7, pos = blockIdx.x >> 3;
+  const int sg = pos / A.tiles_total, t = pos - sg * A.tiles_total;
+  const int s = sg * 8 + xcd;
+  const bool taps = A.pair_mode == 2;
+  const unsigned short* G = (const unsigned short*)A.job[0].G;
+  const void* X = A.job[0].X;
+  float* part = A.job[0].part;
+  float* colpart = A.job[0].colpart;
+  int M = A.job[0].M, N = A.job[0].N, tile0 = 0;
+  const int* xidx = A.job[0].xidx;
+  int xstride = A.job[0].xidx_stride;
+  // sub-tile 1 of a tap pair: the NEXT job's index column and partial tiles (null: an odd tap without a partner)
+  const int* xidx_b = A.n_jobs > 1 ? A.job[1].xidx : nullptr;
+  float* part_b = A.n_jobs > 1 ? A.job[1].part : nullptr;
+#pragma unroll
+  for (int j = 1; j < GD_DW_MAX_JOBS; ++j)
+    if (j < A.n_jobs && t >= A.job[j].tile0) {          // (tap pairs: odd jobs carry tile0 = INT_MAX and are never selected)
+      G = (const unsigned short*)A.job[j].G;
+      X = A.job[j].X;
+      part = A.job[j].part;
+      colpart = A.job[j].colpart;
+      M = A.job[j].M;
+      N = A.job[j].N;
+      tile0 = A.job[j].tile0;
+      xidx = A.job[j].xidx;
+      xstride = A.job[j].xidx_stride;
+      xidx_b = j + 1 < A.n_jobs ? A.job[j + 1 < GD_DW_MAX_JOBS ? j + 1 : j].xidx : nullptr;
+      part_b = j + 1 < A.n_jobs ? A.job[j + 1 < GD_DW_MAX_JOBS ? j + 1 : j].part : nullptr;
+    }
+  const int tn_count = taps ? N / kTile : N / (2 * kTile);
+  const int tm = (t - tile0) / tn_count, tq = (t - tile0) - tm * tn_count;
+  const int xcol_a = taps ? tq * kTile : tq * 2 * kTile, xcol_b = taps ? xcol_a : xcol_a + kTile;
+  if (!taps) { xidx_b = xidx; part_b = part; }
+  const bool have_b = part_b != nullptr;
+  if (!have_b) xidx_b = xidx;                          // readable stand-in; sub-tile 1 is computed and dropped
+  const long long r0 = (long long)s * A.rows_per_slice;
+  const int nchunk = (int)(A.rows_per_slice / kChunk);
+  const int sub = wv >> 2, wm = (wv >> 1) & 1, wn = wv & 1;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  float cs[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) cs[j] = 0.f;
+  const bool want_cs = colpart != nullptr && tq == 0;
+  const int gcol = tm * kTile;
+  const unsigned last = A.guard_rows ? (unsigned)(A.n_valid - 1) : 0xFFFFFFFFu;
+  const unsigned nv = (unsigned)A.n_valid, rb = (unsigned)r0, rt = (unsigned)r0 + (tid >> 4);
+  const int c8 = (tid & 15) * 8;
+  const unsigned short* gp = G + gcol + c8;
+  const unsigned short* xpa = (const unsigned short*)X + xcol_a + c8;
+  const unsigned short* xpb = (const unsigned short*)X + xcol_b + c8;
+  ChunkIdx2 ia0 = {-1, -1}, ia1 = {-1, -1}, ib0 = {-1, -1}, ib1 = {-1, -1};
+  unsigned ma0 = 0u, ma1 = 0u, mb0 = 0u, mb1 = 0u;
+  auto load_xa = [&](unsigned chunk, ChunkIdx2& I, unsigned& miss) {
+    if constexpr (XM == 0) {
+      return load_chunk2(xpa, N, rt + chunk * kChunk, last);
+    } else {
+      const Chunk2 k = load_chunk_rows2<XM == 2>(X, N, I, xcol_a, tid);
+      miss = (I.j0 < 0 ? 1u : 0u) | (I.j1 < 0 ? 2u : 0u);
+      I = load_chunk_idx2(xidx, xstride, rb + (chunk + 2) * kChunk, nv, tid);
+      return k;
+    }
+  };
+  auto load_xb = [&](unsigned chunk, ChunkIdx2& I, unsigned& miss) {
+    if constexpr (XM == 0) {
+      return load_chunk2(xpb, N, rt + chunk * kChunk, last);
+    } else {
+      const Chunk2 k = load_chunk_rows2<XM == 2>(X, N, I, xcol_b, tid);
+      miss = (I.j0 < 0 ? 1u : 0u) | (I.j1 < 0 ? 2u : 0u);
+      I = load_chunk_idx2(xidx_b, xstride, rb + (chunk + 2) * kChunk, nv, tid);
+      return k;
+    }
+  };
+  auto load_g = [&](unsigned chunk) { return load_chunk2(gp, M, rt + chunk * kChunk, last); };
+  if constexpr (XM != 0) {
+    ia0 = load_chunk_idx2(xidx, xstride, rb, nv, tid);
+    ib0 = load_chunk_idx2(xidx_b, xstride, rb, nv, tid);
+    ia1 = load_chunk_idx2(xidx, xstride, rb + kChunk, nv, tid);
+    ib1 = load_chunk_idx2(xidx_b, xstride, rb + kChunk, nv, tid);
+  }
+  auto compute = [&](const unsigned char* bg, const unsigned char* bx) {
+#pragma unroll
+    for (int ks = 0; ks < kChunk / 16; ++ks) {
+      const bf16x8 a0 = frag(bg, 16 * ks, wm * 64, lane), a1 = frag(bg, 16 * ks, wm * 64 + 32, lane);
+      const bf16x8 b0 = frag(bx, 16 * ks, wn * 64, lane), b1 = frag(bx, 16 * ks, wn * 64 + 32, lane);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+    }
+  };
+  unsigned char* const buf0 = lds;
+  unsigned char* const buf1 = lds + 3 * kStage;
+  const long long r_end = r0 + A.rows_per_slice < A.n_valid ? r0 + A.rows_per_slice : A.n_valid;
+  Chunk2 g0 = load_g(0), xa0 = load_xa(0, ia0, ma0), xb0 = load_xb(0, ib0, mb0);
+  __builtin_amdgcn_sched_barrier(0);
+  const unsigned c1 = nchunk > 1 ? 1u : 0u;
+  Chunk2 g1 = load_g(c1), xa1 = load_xa(c1, ia1, ma1), xb1 = load_xb(c1, ib1, mb1);
+  __builtin_amdgcn_sched_barrier(0);
+  for (int c = 0; c < nchunk; c += 2) {
+    {
+      const long long cr = r0 + (long long)c * kChunk;
+      clear_chunk2(g0, cr, tid, r_end, 0u);
+      clear_chunk2(xa0, cr, tid, r_end, XM != 0 ? ma0 : 0u);
+      clear_chunk2(xb0, cr, tid, r_end, XM != 0 ? mb0 : 0u);
+    }
+    store_chunk2(buf0, tid, g0);
+    store_chunk2(buf0 + kStage, tid, xa0);
+    store_chunk2(buf0 + 2 * kStage, tid, xb0);
+    if (want_cs) { add_bf16x8(g0.q0, cs); add_bf16x8(g0.q1, cs); }
+    __syncthreads();
+    {
+      const unsigned cn = c + 2 < nchunk ? c + 2 : nchunk - 1;
+      g0 = load_g(cn);
+      xa0 = load_xa(cn, ia0, ma0);
+      xb0 = load_xb(cn, ib0, mb0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    compute(buf0, buf0 + (1 + sub) * kStage);
+    {
+      const long long cr = r0 + (long long)(c + 1) * kChunk;
+      clear_chunk2(g1, cr, tid, r_end, 0u);
+      clear_chunk2(xa1, cr, tid, r_end, XM != 0 ? ma1 : 0u);
+      clear_chunk2(xb1, cr, tid, r_end, XM != 0 ? mb1 : 0u);
+    }
+    store_chunk2(buf1, tid, g1);
+    store_chunk2(buf1 + kStage, tid, xa1);
+    store_chunk2(buf1 + 2 * kStage, tid, xb1);
+    if (want_cs) { add_bf16x8(g1.q0, cs); add_bf16x8(g1.q1, cs); }
+    __syncthreads();
+    {
+      const unsigned cn = c + 3 < nchunk ? c + 3 : nchunk - 1;
+      g1 = load_g(cn);
+      xa1 = load_xa(cn, ia1, ma1);
+      xb1 = load_xb(cn, ib1, mb1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    compute(buf1, buf1 + (1 + sub) * kStage);
+  }
+  // ---- partial tile of this wavefront's sub-tile
+  if (sub == 0 || have_b) {
+    float* out = (sub ? part_b : part) + ((long long)s * M + tm * kTile + wm * 64) * N + (sub ? xcol_b : xcol_a) + wn * 64;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int m = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+          out[(long long)m * N + j * 32 + (lane & 31)] = acc[i][j][e];
+        }
+  }
+  if (want_cs) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(lds);       // (32 row groups, 128 columns)
+    const int c = tid & 15, r = tid >> 4;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[r * kTile + c * 8 + j] = cs[j];
+    __syncthreads();
+    if (tid < kTile) {
+      float tsum = 0.f;
+#pragma unroll
+      for (int rr = 0; rr < 32; ++rr) tsum += red[rr * kTile + tid];
+      colpart[(long long)s * M + tm * kTile + tid] = tsum;
+    }
+  }
+}
 }  // namespace
 
 bool gd_dw_group_supported(long long n_pad, int d, int ff) {
@@ -399,6 +636,53 @@ int gd_dw_grouped_s(hipStream_t st, GdDwGroup& A, long long n_pad, long long n_v
   const int xm = A.job[0].xidx ? (A.job[0].x_f32 ? 2 : 1) : 0;
   for (int j = 1; j < A.n_jobs; ++j)
     GD_REQUIRE((A.job[j].xidx ? (A.job[j].x_f32 ? 2 : 1) : 0) == xm, "dw_grouped: the jobs of a launch share the X addressing mode");
+  // ---- 128 x 256 pair tiles where the launch's jobs allow it: OPT-IN (GDMAE_DW_PAIR=1).  Built for VERDICT r5 task 4 and measured
+  // same-box (tools/ab_env.sh): 7.72 -> 7.82 ms per 8-frame step, 4.82 -> 4.86 at 4 frames - 0.75 of the L2 stream per product, but
+  // eight wavefronts behind one barrier leave ONE workgroup per CU (194 registers: two wavefronts per SIMD either way), and a CU whose
+  // only workgroup waits at a barrier idles, where two independent four-wavefront workgroups cover each other (the finding of
+  // TL_HALVES for the fused layer kernels again).  Bit-identical partial tiles (tests/test_ride_along.py runs a step with it).
+  static const bool pair_ok = getenv("GDMAE_DW_PAIR") && atoi(getenv("GDMAE_DW_PAIR")) != 0;
+  int mode = 0;
+  if (pair_ok) {
+    bool plain = true, cols = true, same = true;
+    for (int j = 0; j < A.n_jobs; ++j) {
+      const GdDwJob& q = A.job[j];
+      plain = plain && q.g_ld == 0 && q.g_cols == 0;
+      cols = cols && q.N % (2 * kTile) == 0;
+      same = same && q.G == A.job[0].G && q.X == A.job[0].X && q.M == A.job[0].M && q.N == A.job[0].N && q.xidx != nullptr &&
+             q.xidx_stride == A.job[0].xidx_stride && q.colpart == nullptr;
+    }
+    if (plain && cols) mode = 1;
+    else if (plain && same && A.n_jobs >= 2) mode = 2;
+  }
+  if (mode != 0) {
+    A.pair_mode = mode;
+    int pt = 0;
+    for (int j = 0; j < A.n_jobs; ++j) {
+      if (mode == 1) {
+        A.job[j].tile0 = pt;
+        pt += (A.job[j].M / kTile) * (A.job[j].N / (2 * kTile));
+      } else if ((j & 1) == 0) {
+        A.job[j].tile0 = pt;
+        pt += (A.job[j].M / kTile) * (A.job[j].N / kTile);
+      } else {
+        A.job[j].tile0 = 0x7FFFFFFF;                   // the second tap of a pair: reached through its partner
+      }
+    }
+    A.tiles_total = pt;
+    static bool once[3] = {false, false, false};
+    if (!once[xm]) {
+      const void* fn = xm == 0 ? (const void*)k_dw_grouped2<0> : (xm == 1 ? (const void*)k_dw_grouped2<1> : (const void*)k_dw_grouped2<2>);
+      GD_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * kStage));
+      once[xm] = true;
+    }
+    const dim3 grid2((unsigned)(pt * A.S));
+    if (xm == 0) hipLaunchKernelGGL(k_dw_grouped2<0>, grid2, dim3(512), 6 * kStage, st, A);
+    else if (xm == 1) hipLaunchKernelGGL(k_dw_grouped2<1>, grid2, dim3(512), 6 * kStage, st, A);
+    else hipLaunchKernelGGL(k_dw_grouped2<2>, grid2, dim3(512), 6 * kStage, st, A);
+    GD_LAUNCH_CHECK();
+    return 0;
+  }
   const dim3 grid((unsigned)(tiles * A.S));
   if (xm == 0) hipLaunchKernelGGL(k_dw_grouped<0>, grid, dim3(256), 4 * kStage, st, A);
   else if (xm == 1) hipLaunchKernelGGL(k_dw_grouped<1>, grid, dim3(256), 4 * kStage, st, A);

@@ -41,7 +41,7 @@ print("DIGEST", float(ret["loss"]).hex(), hashlib.sha256(g.tobytes()).hexdigest(
 
 def _digest(case, env_extra):
     env = dict(os.environ)
-    for k in ("GDMAE_LAYER_TAIL_RIDES", "GDMAE_DW_REDUCE_RIDES", "GDMAE_QKV_RIDES"):
+    for k in ("GDMAE_LAYER_TAIL_RIDES", "GDMAE_DW_REDUCE_RIDES", "GDMAE_QKV_RIDES", "GDMAE_DW_PAIR"):
         env.pop(k, None)
     env.update(env_extra)
     out = subprocess.run([sys.executable, "-c", STEP, REPO, case], env=env, capture_output=True, text=True, timeout=600)
@@ -56,7 +56,8 @@ def _digest(case, env_extra):
 def test_ride_along_switches_are_bit_identical(case):
     base = _digest(case, {})
     assert _digest(case, {}) == base, "the step itself is not bit-repeatable"
-    for env in ({"GDMAE_LAYER_TAIL_RIDES": "0"}, {"GDMAE_DW_REDUCE_RIDES": "0"}, {"GDMAE_QKV_RIDES": "1"},
+    # GDMAE_DW_PAIR=1: the grouped weight gradients on 128 x 256 pair tiles (dw_grouped.hip k_dw_grouped2, opt-in): same partial tiles
+    for env in ({"GDMAE_LAYER_TAIL_RIDES": "0"}, {"GDMAE_DW_REDUCE_RIDES": "0"}, {"GDMAE_QKV_RIDES": "1"}, {"GDMAE_DW_PAIR": "1"},
                 {"GDMAE_LAYER_TAIL_RIDES": "0", "GDMAE_DW_REDUCE_RIDES": "0", "GDMAE_QKV_RIDES": "1"}):
         assert _digest(case, env) == base, env
 
