@@ -46,18 +46,21 @@ __device__ __forceinline__ unsigned gd_pack_bf16(float lo, float hi) {          
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, gd_bf16x2_t));
 }
 __device__ __forceinline__ unsigned short gd_to_bf16(float f) { return (unsigned short)(gd_pack_bf16(f, 0.f) & 0xFFFFu); }
-// fp32 -> fp16 (v_cvt_pk_f16_f32: two values per instruction, round to nearest even), clamped to the finite range first.  The decoder's
+// fp32 -> fp16 (v_cvt_pk_f16_f32: two values per instruction, round to nearest even).  The decoder's
 // FORWARD products (deconvolution rows, tile convolution) take their operands in fp16 instead of bf16: same matrix-core rate
 // (v_mfma_f32_32x32x16_f16), 11 instead of 8 significand bits.  What the bf16 mode's loss deviates by from the fp32 mode at full size is
 // dominated by the rounding of these WEIGHTS - the same error at every site, so it does not average over the pillars the way activation
 // rounding does (tools/weight_rounding_full_size.py) - and the operands there are O(1) BatchNorm / LayerNorm outputs and O(0.01 - 1)
 // weights, far inside fp16's range; gradients (backward products) stay bf16.
 typedef _Float16 gd_f16x2_t __attribute__((ext_vector_type(2)));
+// No range clamp: a value beyond 65504 becomes inf and a NaN stays a NaN, so that a diverged run fails loudly in its loss instead of
+// training on saturated rows (the operands here never come near the limit: weights and normalised activations).
 __device__ __forceinline__ unsigned gd_pack_f16(float lo, float hi) {           // lo in bits 0 - 15
-  const gd_f32x2_t v = {__builtin_amdgcn_fmed3f(lo, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(hi, -65504.f, 65504.f)};
+  const gd_f32x2_t v = {lo, hi};
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, gd_f16x2_t));
 }
-// the same for values known to be >= 0 after the clamp from below the caller wants anyway: relu and range clamp in one v_med3_f32
+// ReLU + conversion for BatchNorm outputs: relu and the clamp to fp16's finite range are one v_med3_f32 (like the `h > 0 ? h : 0` it
+// replaces, it turns a NaN into a finite value: a NaN batch statistic shows up in the BatchNorm's own outputs, not here)
 __device__ __forceinline__ unsigned gd_pack_f16_relu(float lo, float hi) {
   const gd_f32x2_t v = {__builtin_amdgcn_fmed3f(lo, 0.f, 65504.f), __builtin_amdgcn_fmed3f(hi, 0.f, 65504.f)};
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, gd_f16x2_t));

@@ -329,7 +329,8 @@ __global__ __launch_bounds__(256, 2) void k_dw_grouped(GdDwGroup A) {
 // wavefronts stages ONE G chunk for TWO X sub-tiles - adjacent column blocks of the job (pair_mode 1) or the same column block of
 // two taps of a gathered launch (pair_mode 2: the nine tap jobs read the same G) - 48 KB per chunk for twice the products, i.e. 0.75
 // of the bytes per product; wavefronts 0 - 3 / 4 - 7 own the 2 x 2 blocks of sub-tile 0 / 1 exactly as the four wavefronts of
-// k_dw_grouped own theirs (same fragments, same k order: bit-identical partial tiles).  512 threads move a chunk (two 16-byte
+// k_dw_grouped own theirs (same fragments, same k order: bit-identical partial tiles; the optional column sums of G are taken by 32
+// instead of 16 row groups, another fixed order).  512 threads move a chunk (two 16-byte
 // pieces of G and of each X sub-tile per thread), two chunks in flight in registers, two LDS buffers of 48 KB: one workgroup per
 // CU at the two wavefronts per SIMD of the four-wavefront kernel.
 // ---------------------------------------------------------------------------------------------------------------------
@@ -640,7 +641,7 @@ int gd_dw_grouped_s(hipStream_t st, GdDwGroup& A, long long n_pad, long long n_v
   // same-box (tools/ab_env.sh): 7.72 -> 7.82 ms per 8-frame step, 4.82 -> 4.86 at 4 frames - 0.75 of the L2 stream per product, but
   // eight wavefronts behind one barrier leave ONE workgroup per CU (194 registers: two wavefronts per SIMD either way), and a CU whose
   // only workgroup waits at a barrier idles, where two independent four-wavefront workgroups cover each other (the finding of
-  // TL_HALVES for the fused layer kernels again).  Bit-identical partial tiles (tests/test_ride_along.py runs a step with it).
+  // TL_HALVES for the fused layer kernels again).  Bit-identical partial tiles; the bias column sums of a layer launch in another fixed order (tests/test_ride_along.py runs a step with it).
   static const bool pair_ok = getenv("GDMAE_DW_PAIR") && atoi(getenv("GDMAE_DW_PAIR")) != 0;
   int mode = 0;
   if (pair_ok) {

@@ -117,6 +117,10 @@ __device__ inline void tg_phi(float h, float& cdf, float& pdf_e) {
   cdf = h >= 0.f ? 1.f - q : q;
   pdf_e = e;
 }
+#ifdef TL_EXP_NOGELU     // experiment: what the GELU arithmetic costs the fused launches (wrong values: timing only)
+__device__ inline float tg_gelu(float h) { return 0.5f * h; }
+__device__ inline float tg_gelu_grad(float h) { return 0.5f + 0.f * h; }
+#else
 __device__ inline float tg_gelu(float h) {
   float cdf, e;
   tg_phi(h, cdf, e);
@@ -127,6 +131,7 @@ __device__ inline float tg_gelu_grad(float h) {
   tg_phi(h, cdf, e);
   return fmaf(h * 0.39894228040143267794f, e, cdf);
 }
+#endif
 
 
 // sum over the LPR (power of two, <= 64) consecutive lanes that share a row
