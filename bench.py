@@ -243,6 +243,13 @@ def measure_roofline(step, feed, n_steps=4):
                 d["l2_stream_bytes_per_launch"] = int(sb / max(v["launches"], 1))
                 d["l2_stream_GBs"] = round(sb / sec / 1e9, 1)
                 d["algorithmic_bytes_note"] = "every distinct operand matrix of a launch once (G and X of the nine tap jobs counted once) + index columns + fp32 partial tiles"
+            if name in ("k_win_attn_fwd", "k_win_attn_bwd"):
+                # beside the minimum rows of an attention pass (4 d forward, 7 d backward per token): the log-sum-exp rows the forward
+                # leaves, and the forward's output rows + those lse rows + the dtau partial slots the backward moves instead of re-deriving
+                # the softmax statistics (the PMC traffic of the backward is 1.40 x the 7 d model, 1.2 x with these)
+                sb = v.get("side_bytes", 0.0)
+                d["side_stream_bytes_per_launch"] = int(sb / max(v["launches"], 1))
+                d["achieved_incl_side_streams"] = round((v["total_bytes"] + sb) / sec / 1e9, 1)
             if name == "k_tok_gemm":
                 # what the family's launches move BESIDES the bf16 operand / result rows and weight images the fraction is computed
                 # from: fp32 statistics rows, per-workgroup partial rows, fp32 rows at the stage boundary, the y + pos copies

@@ -666,7 +666,10 @@ extern "C" int gdmae_window_attention_levels_fwd(const void* qk, const void* v, 
   hipStream_t st = (hipStream_t)stream;
   // algorithmic bytes: q, k, v rows read + out row written per token (4 d elements) + CSR; the token count is not an argument
   // of this entry - the caller (encoder_layer.hip) adds it through gd_attn_timing_tokens
-  GdTimed timed(GD_T_ATTN_FWD, st, attn_alg_bytes(n_levels, n_win, nullptr, g_attn_tokens, d, io_bf16 ? 2 : 4, 4));
+  // side bytes (what the launch moves besides by design): the (n_tok, H) fp32 log-sum-exp rows the cooperative path leaves for the backward
+  const bool lse_path = levels_fast_path(io_bf16, n_levels, max_tokens, H, d) && g_attn_impl == 0;
+  GdTimed timed(GD_T_ATTN_FWD, st, attn_alg_bytes(n_levels, n_win, nullptr, g_attn_tokens, d, io_bf16 ? 2 : 4, 4), 0.0,
+                (lse_path && lse) ? 4.0 * H * (double)g_attn_tokens : 0.0);
   if (!levels_fast_path(io_bf16, n_levels, max_tokens, H, d)) {
     int base = 0;
     for (int l = 0; l < n_levels; ++l) {
@@ -700,7 +703,18 @@ extern "C" int gdmae_window_attention_levels_bwd(const void* qk, const void* v, 
                                                  int n_levels, const int* n_win, const int* max_tokens, int d, int H, const float* tau,
                                                  float tau_min, const void* out, const float* lse, void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  GdTimed timed(GD_T_ATTN_BWD, st, attn_alg_bytes(n_levels, n_win, nullptr, g_attn_tokens, d, io_bf16 ? 2 : 4, 7));
+  // algorithmic bytes = the minimum of an attention backward (q, k, v, dOut rows in, dq, dk, dv rows out: 7 rows per token); side bytes =
+  // what this design reads on top of it INSTEAD of re-deriving the softmax statistics - the forward's output rows O (D = dO . O) and the
+  // log-sum-exp rows - and the per-(window, head) dtau partial slots it writes
+  double side = 0.0;
+  {
+    long long nwin = 0;
+    for (int l = 0; l < n_levels; ++l) nwin += n_win[l];
+    side = 4.0 * H * (double)nwin;
+    if (levels_fast_path(io_bf16, n_levels, max_tokens, H, d) && g_attn_impl == 0 && out != nullptr && lse != nullptr)
+      side += (double)g_attn_tokens * ((double)d * (io_bf16 ? 2 : 4) + 4.0 * H);
+  }
+  GdTimed timed(GD_T_ATTN_BWD, st, attn_alg_bytes(n_levels, n_win, nullptr, g_attn_tokens, d, io_bf16 ? 2 : 4, 7), 0.0, side);
   if (!levels_fast_path(io_bf16, n_levels, max_tokens, H, d)) {
     int base = 0;
     long long pbase = 0;
