@@ -567,7 +567,13 @@ bool gd_dw_group_supported(long long n_pad, int d, int ff) {
 }
 // number of row slices: a multiple of 8 (one XCD per slice residue), tiles x slices ~ 2 workgroups per CU
 int gd_dw_group_slices(long long n_pad, int tiles_total) {
-  static const int wgs = getenv("GDMAE_DW_WGS") ? atoi(getenv("GDMAE_DW_WGS")) : 512;      // experiment switch
+  // ~2 workgroups per CU for a layer with many rows, ~1 for a short one: every slice writes a full set of fp32 partial tiles (33 MB per
+  // d = 256 layer at 16 slices) whatever its row count, so below GDMAE_DW_ROWS rows half the slices are cheaper than the parallelism they
+  // buy (config C's 4-frame step, same box: 4.67 -> 4.64 ms with 256 workgroups for all layers; at 8 frames 512 stays best for the
+  // long stages).  GDMAE_DW_WGS pins the count (experiment switch).
+  static const int pinned = getenv("GDMAE_DW_WGS") ? atoi(getenv("GDMAE_DW_WGS")) : 0;
+  static const long long short_rows = getenv("GDMAE_DW_ROWS") ? atoll(getenv("GDMAE_DW_ROWS")) : 32768;
+  const int wgs = pinned > 0 ? pinned : (n_pad < short_rows ? 256 : 512);
   return gd_dw_group_slices_for(n_pad, tiles_total, wgs);
 }
 // Slice count FIRST, then the row padding that makes it fit (gathered launches: the row count is data dependent, and a padding
