@@ -32,15 +32,46 @@ for si, st in enumerate(plan.stages):
         nw_h, T_h = L.host_i32(w.n_win), L.host_i32(w.max_tokens)
         if os.environ.get("LEVELS"):         # experiment: only the occupancy levels whose bit is set (1 = T16, 2 = T32, 4 = T64) have windows
             nw_h = L.host_i32([n if (int(os.environ["LEVELS"]) >> i) & 1 else 0 for i, n in enumerate(w.n_win)])
+        ws_t, wl_t = w.win_start, w.win_len
+        MT = int(os.environ.get("MERGE16", "0"))          # 1 / 32: onto 32-row tiles (16-row buckets), 64: onto 64-row tiles (48-row buckets)
+        MT = 32 if MT == 1 else MT
+        if MT in (32, 64) and w.max_tokens[0] == 16 and MT in w.max_tokens and w.n_win[0] > 0:
+            # experiment (timing only, the values attend across windows): the T = 16 level's windows merged into pseudo-windows of <= 32
+            # rows (all windows whose first row lies in the same 16-row bucket of the level's CSR range) and handed to the T = 32
+            # cooperative path - what the sparse level would cost on 32-row tiles with a block-diagonal mask
+            n0 = w.n_win[0]
+            i32 = w.max_tokens.index(MT)
+            s0, l0 = w.win_start[:n0].long(), w.win_len[:n0].long()
+            b = (s0 - s0[0]) // (MT - 16)
+            first = torch.ones_like(b, dtype=torch.bool); first[1:] = b[1:] != b[:-1]
+            last = torch.ones_like(b, dtype=torch.bool); last[:-1] = b[1:] != b[:-1]
+            ms, me = s0[first], (s0 + l0)[last]
+            assert int((me - ms).max()) <= MT and int((me - ms).sum()) == int(l0.sum())
+            offs = [0]
+            for n in w.n_win: offs.append(offs[-1] + n)
+            parts_s, parts_l, nw_new = [], [], []
+            for li in range(len(w.n_win)):
+                if li == 0:
+                    nw_new.append(0)
+                    continue
+                ps, pl = [w.win_start[offs[li]:offs[li + 1]]], [w.win_len[offs[li]:offs[li + 1]]]
+                if li == i32:
+                    ps.insert(0, ms.int()); pl.insert(0, (me - ms).int())
+                parts_s += ps; parts_l += pl
+                nw_new.append(sum(int(x.numel()) for x in ps))
+            ws_t, wl_t = torch.cat(parts_s).contiguous(), torch.cat(parts_l).contiguous()
+            nw_h = L.host_i32(nw_new)
+            part = torch.zeros(sum(nw_new) * H + 1, device=dev)
+            print(f"   merged {n0} T=16 windows ({int(l0.sum())} tokens) into {ms.numel()} pseudo-windows of <= {MT} rows (mean {float((me - ms).float().mean()):.1f})")
         csr = torch.arange(st.n_tok, dtype=torch.int32, device=dev) if IDENT else w.csr_tok
         if os.environ.get("NOCSR"):          # experiment: no index load at all (rows in window-major order, csr_tok = null)
             csr = None
         def fwd():
-            L.call("gdmae_window_attention_levels_fwd", L.ptr(qk), L.ptr(v), L.ptr(out), 1, L.ptr(csr), L.ptr(w.win_start), L.ptr(w.win_len), nl,
+            L.call("gdmae_window_attention_levels_fwd", L.ptr(qk), L.ptr(v), L.ptr(out), 1, L.ptr(csr), L.ptr(ws_t), L.ptr(wl_t), nl,
                    nw_h, T_h, d, H, L.ptr(tau), 0.01, L.ptr(lse), L.stream())
         def bwd():
             L.call("gdmae_window_attention_levels_bwd", L.ptr(qk), L.ptr(v), L.ptr(g), L.ptr(dqk), L.ptr(dv), 1, L.ptr(part), L.ptr(csr),
-                   L.ptr(w.win_start), L.ptr(w.win_len), nl, nw_h, T_h, d, H, L.ptr(tau), 0.01, L.ptr(out), L.ptr(lse), L.stream())
+                   L.ptr(ws_t), L.ptr(wl_t), nl, nw_h, T_h, d, H, L.ptr(tau), 0.01, L.ptr(out), L.ptr(lse), L.stream())
         line = f"stage {si} shift {shift} windows {w.n_win} tokens {w.n_tok}:"
         for impl in ((0,) if os.environ.get("NOCSR") else (3, 0)):
             L.call("gdmae_set_attention_impl", impl)

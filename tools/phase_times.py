@@ -129,12 +129,14 @@ def gemm_stats():
 for i in range(10): step(i, False)
 torch.cuda.synchronize()
 print("library GEMM calls / plans created after the warm-up:", gemm_stats())
+ALLOC0 = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
 t0 = time.perf_counter()
 N = 40
 for i in range(10, 10 + N): step(i, True)
 torch.cuda.synchronize()
 wall = (time.perf_counter() - t0) / N * 1e3
-print("library GEMM calls / plans created after the timed steps:", gemm_stats())
+print("library GEMM calls / plans created after the timed steps:", gemm_stats(), "| hipMalloc calls inside the timed steps:",
+      torch.cuda.memory_stats(dev).get("num_device_alloc", 0) - ALLOC0)
 f = sum(a.elapsed_time(b) for a, b, _, _ in marks) / N
 b = sum(b_.elapsed_time(c) for _, b_, c, _ in marks) / N
 o = sum(c.elapsed_time(d) for _, _, c, d in marks) / N
