@@ -33,6 +33,7 @@ constexpr int VF_MAX_GRID = 1024;
 
 struct VfeGeom {
   float lo[3], vs[3];
+  int out_f16 = 0;     // VF_APPLY with 16-bit output: the rows leave as fp16 instead of bf16 (gdmae_vfe_point_layer_fwd out_bf16 = 2)
 };
 
 enum { VF_STATS = 0, VF_APPLY = 1, VF_BSTATS = 2, VF_DW = 3 };
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(VF_WAVES * 64) void k_vfe1(const float* __restrict_
         const long long row = base + 8 * (r / 4) + 4 * half + (r % 4);
         if (row < N) {
           const float y0 = fmaxf(fmaf(ca[0], h[0][r], cb[0]), 0.f), y1 = fmaxf(fmaf(ca[1], h[1][r], cb[1]), 0.f);
-          if (BF) ((unsigned*)out)[row * (VF_C / 2) + n] = (unsigned)vf_f2bf(y0) | ((unsigned)vf_f2bf(y1) << 16);
+          if (BF) ((unsigned*)out)[row * (VF_C / 2) + n] = G.out_f16 ? gd_pack_f16(y0, y1) : ((unsigned)vf_f2bf(y0) | ((unsigned)vf_f2bf(y1) << 16));
           else ((float2*)out)[row * (VF_C / 2) + n] = make_float2(y0, y1);
         }
       }
@@ -409,6 +410,7 @@ extern "C" int gdmae_vfe_point_layer_fwd(const float* points, const long long* p
   rc = gd_bn_fold_from_partials(st, part, grid, C, (double)N, gamma, beta, eps, momentum, running_mean, running_var,
                                 num_batches, stats, ab, mv);
   if (rc) return rc;
+  G.out_f16 = out_bf16 == 2;        // 16-bit rows as fp16 (the operand type of gdmae_vfe_max_layer_*_f16)
   return vf_launch<VF_APPLY>(st, F, out_bf16 != 0, points, point_coords, inverse32, pillar_mean, coords_per_pillar, N, G, W, ab, nullptr, nullptr,
                              out, nullptr);
 }

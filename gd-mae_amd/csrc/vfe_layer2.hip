@@ -2,8 +2,11 @@
 // pcdet/models/backbones_3d/vfe/dyn_vfe.py:107-112, network_utils.py:7-21:  h = y1 W^T (64 -> 128),
 // v = relu(BatchNorm1d_train(h)), pillar feature = max of v over the pillar's points [torch_scatter.scatter_max]).
 //
-// bf16 throughput mode only (y1 is the bf16 output of gdmae_vfe_point_layer_fwd; the fp32 parity mode keeps the
-// op-by-op path).  h (N x 128, 366 MB in bf16 for an 8-frame batch) is never stored: a 32-point tile of it is
+// 16-bit throughput mode only (y1 is the bf16 - or, round 6, fp16 - output of gdmae_vfe_point_layer_fwd; the fp32 parity mode keeps the
+// op-by-op path).  F16 instantiations (gdmae_vfe_max_layer_*_f16): y1 holds fp16 values and W arrives as the fp32 master matrix, rounded
+// to fp16 for the pre-activation h = y1 W^T (v_mfma_f32_32x32x16_f16) and to bf16 for the gradient product dy1 = dx W; y1^T is converted
+// to bf16 when k_v2_dw stages it.  Why: the pillar maximum passes ONE point's value on - the rounding of y1 and of W does not average
+// over a pillar's points - and DynVFE in bf16 was the largest term of config E's small-case loss scatter.  h (N x 128, 366 MB in bf16 for an 8-frame batch) is never stored: a 32-point tile of it is
 // 16 v_mfma_f32_32x32x16_bf16 from a 4 KB tile of y1, so every kernel below recomputes it in accumulators:
 //   forward   k_v2_stats  : column sums of h, h^2 (fp32 accumulators)  -> gd_bn_fold_from_partials
 //             k_v2_max    : tiles in pillar (CSR) order; the tile goes through LDS and each lane walks one column
@@ -31,10 +34,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 union V2Frag {
   uint4 u;
   uint2 u2[2];
   bf16x8 v;
+  f16x8 hv;
   unsigned short s[8];
 };
 
@@ -73,11 +78,20 @@ __device__ __forceinline__ void v2_wave_sync() {   // LDS written and read by th
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// W (128, 64) bf16 -> LDS, rows padded to V2_LDW
-__device__ __forceinline__ void v2_load_w(const unsigned short* __restrict__ W, unsigned short* __restrict__ sW) {
+// W (128, 64) -> LDS, rows padded to V2_LDW.  F16: W is the fp32 master matrix, rounded to fp16 here; else bf16, copied
+template <bool F16>
+__device__ __forceinline__ void v2_load_w(const void* __restrict__ Wv, unsigned short* __restrict__ sW) {
   for (int q = threadIdx.x; q < V2_CO * (V2_CI / 8); q += V2_WAVES * 64) {
     const int row = q >> 3, ch = q & 7;
-    *reinterpret_cast<uint4*>(sW + row * V2_LDW + 8 * ch) = *reinterpret_cast<const uint4*>(W + row * V2_CI + 8 * ch);
+    if constexpr (F16) {
+      const float* W = (const float*)Wv + row * V2_CI + 8 * ch;
+      const float4 a = *reinterpret_cast<const float4*>(W), b = *reinterpret_cast<const float4*>(W + 4);
+      uint4 o;
+      o.x = gd_pack_f16(a.x, a.y); o.y = gd_pack_f16(a.z, a.w); o.z = gd_pack_f16(b.x, b.y); o.w = gd_pack_f16(b.z, b.w);
+      *reinterpret_cast<uint4*>(sW + row * V2_LDW + 8 * ch) = o;
+    } else {
+      *reinterpret_cast<uint4*>(sW + row * V2_LDW + 8 * ch) = *reinterpret_cast<const uint4*>((const unsigned short*)Wv + row * V2_CI + 8 * ch);
+    }
   }
 }
 
@@ -115,6 +129,7 @@ __device__ __forceinline__ void v2_load_tile(const unsigned short* __restrict__ 
 }
 
 // h[:, 32 b + n] for the tile: D[i = row][j = column] = sum_k y1[row][k] W[column][k]
+template <bool F16>
 __device__ __forceinline__ f32x16 v2_h(const V2Frag (&ya)[4], const unsigned short* __restrict__ sW, int n, int half, int b) {
   f32x16 acc;
 #pragma unroll
@@ -123,18 +138,20 @@ __device__ __forceinline__ f32x16 v2_h(const V2Frag (&ya)[4], const unsigned sho
   for (int s = 0; s < 4; ++s) {
     V2Frag w;
     w.u = *reinterpret_cast<const uint4*>(sW + (32 * b + n) * V2_LDW + 16 * s + 8 * half);
-    acc = v2_mfma(ya[s].v, w.v, acc);
+    if constexpr (F16) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ya[s].hv, w.hv, acc, 0, 0, 0);
+    else acc = v2_mfma(ya[s].v, w.v, acc);
   }
   return acc;
 }
 
 // ---- forward statistics --------------------------------------------------------------------------------------
+template <bool F16>
 __global__ __launch_bounds__(V2_WAVES * 64) void k_v2_stats(const unsigned short* __restrict__ y1, long long N,
-                                                            const unsigned short* __restrict__ W, float* __restrict__ part) {
+                                                            const void* __restrict__ W, float* __restrict__ part) {
   __shared__ unsigned short sW[V2_CO * V2_LDW];
   __shared__ float sR[V2_WAVES * 2 * V2_CO];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 31, half = lane >> 5;
-  v2_load_w(W, sW);
+  v2_load_w<F16>(W, sW);
   __syncthreads();
   float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
   const long long ntiles = (N + 31) / 32;
@@ -144,7 +161,7 @@ __global__ __launch_bounds__(V2_WAVES * 64) void k_v2_stats(const unsigned short
     v2_load_y(y1, row < N ? row : N - 1, row < N, half, ya);
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-      const f32x16 h = v2_h(ya, sW, n, half, b);   // rows past N are exactly zero
+      const f32x16 h = v2_h<F16>(ya, sW, n, half, b);   // rows past N are exactly zero
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         s1[b] += h[r];
@@ -181,14 +198,15 @@ __global__ __launch_bounds__(V2_WAVES * 64) void k_v2_stats(const unsigned short
 // 0, the piece of one that continues behind it to slot 1 (a range inside one pillar: slot 0), and k_v2_max_fix joins the pieces of
 // such a pillar in row order.  arg = row of the maximum (strict >: the first row, i.e. the lowest point id, wins ties - (max value,
 // min row) is associative, so joining pieces in order gives the sequential walk's answer bit for bit).
+template <bool F16>
 __global__ __launch_bounds__(V2_WAVES * 64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_v2_max(const unsigned short* __restrict__ y1, long long N,
-                                                          const unsigned short* __restrict__ W, const int* __restrict__ pt_off,
+                                                          const void* __restrict__ W, const int* __restrict__ pt_off,
                                                           const int* __restrict__ rowpil, int M, const float* __restrict__ ab,
                                                           float* __restrict__ out, int* __restrict__ arg, long long per,
                                                           float* __restrict__ pbest, int* __restrict__ parg) {
   __shared__ unsigned short sW[V2_CO * V2_LDW];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 31, half = lane >> 5;
-  v2_load_w(W, sW);
+  v2_load_w<F16>(W, sW);
   __syncthreads();
   // this worker's share of the rows; head: its first pillar began before the range, tail: its last pillar continues behind it
   const int wk = (blockIdx.x * V2_WAVES + wave) * 2 + half;      // (int, and the slot offsets recomputed where used: 162 registers = 3 waves per SIMD)
@@ -254,7 +272,7 @@ __global__ __launch_bounds__(V2_WAVES * 64) __attribute__((amdgpu_waves_per_eu(3
     for (int r = 0; r < 16; ++r) cur = r < nrows ? prow[r] : cur;
     f32x16 h[4];
 #pragma unroll
-    for (int b = 0; b < 4; ++b) h[b] = v2_h(ya, sW, n, half, b);
+    for (int b = 0; b < 4; ++b) h[b] = v2_h<F16>(ya, sW, n, half, b);
     // the next tile is waited for HERE, before this tile's stores go out: loads and stores retire out of order with respect to each
     // other, so once stores are pending any wait for a load is a full drain of both
     v2_keep_y(yn, live_n);
@@ -416,8 +434,9 @@ __device__ __forceinline__ f32x16 v2_dx(const f32x16& h, const V2Coef& k, const 
 }
 
 // ---- backward: dy1 = dx W ------------------------------------------------------------------------------------------
+template <bool F16>
 __global__ __launch_bounds__(V2_WAVES * 64) void k_v2_dy(const unsigned short* __restrict__ y1, long long N,
-                                                         const unsigned short* __restrict__ W, const int* __restrict__ rowpil,
+                                                         const void* __restrict__ W, const int* __restrict__ rowpil,
                                                          const float* __restrict__ ab, const float* __restrict__ c01,
                                                          const int* __restrict__ arg, const float* __restrict__ gm,
                                                          unsigned* __restrict__ dy1) {
@@ -425,10 +444,10 @@ __global__ __launch_bounds__(V2_WAVES * 64) void k_v2_dy(const unsigned short* _
   __shared__ unsigned short sWT[V2_CI * V2_LDX];            // W^T: row j (input channel), column c
   __shared__ unsigned short sX[V2_WAVES * 32 * V2_LDX];     // per wave: the bf16 dx tile, row-major
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 31, half = lane >> 5;
-  v2_load_w(W, sW);
-  for (int q = threadIdx.x; q < V2_CO * V2_CI; q += V2_WAVES * 64) {
+  v2_load_w<F16>(W, sW);
+  for (int q = threadIdx.x; q < V2_CO * V2_CI; q += V2_WAVES * 64) {      // W^T in bf16: operand of the gradient product
     const int c = q >> 6, j = q & 63;
-    sWT[j * V2_LDX + c] = W[q];
+    sWT[j * V2_LDX + c] = F16 ? v2_f2bf(((const float*)W)[q]) : ((const unsigned short*)W)[q];
   }
   __syncthreads();
   unsigned short* sx = sX + wave * 32 * V2_LDX;
@@ -453,7 +472,7 @@ __global__ __launch_bounds__(V2_WAVES * 64) void k_v2_dy(const unsigned short* _
     for (int r = 0; r < 16; ++r) prow[r] = __shfl(pil, v2_row(r, half), 64);
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-      const f32x16 h = v2_h(ya, sW, n, half, b);
+      const f32x16 h = v2_h<F16>(ya, sW, n, half, b);
       const f32x16 dx = v2_dx(h, k[b], arg, gm, 32 * b + n, prow, (int)q, half);
 #pragma unroll
       for (int r = 0; r < 16; ++r) sx[v2_row(r, half) * V2_LDX + 32 * b + n] = v2_f2bf(dx[r]);
@@ -487,15 +506,16 @@ __global__ __launch_bounds__(V2_WAVES * 64) void k_v2_dy(const unsigned short* _
 
 // ---- backward: dW = dx^T y1 ----------------------------------------------------------------------------------------
 // the four waves of a workgroup share each tile, wave w owns the 32 columns [32 w, 32 w + 32) of dx / rows of dW
+template <bool F16>
 __global__ __launch_bounds__(V2_WAVES * 64) V2_DW_ATTR void k_v2_dw(const unsigned short* __restrict__ y1, long long N,
-                                                         const unsigned short* __restrict__ W, const int* __restrict__ rowpil,
+                                                         const void* __restrict__ W, const int* __restrict__ rowpil,
                                                          const float* __restrict__ ab, const float* __restrict__ c01,
                                                          const int* __restrict__ arg, const float* __restrict__ gm,
                                                          float* __restrict__ part) {
   __shared__ unsigned short sW[V2_CO * V2_LDW];
   __shared__ unsigned short sT[V2_WAVES * V2_CI * V2_LDT];   // per wave: y1 tile transposed, row j, column = tile row
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 31, half = lane >> 5;
-  v2_load_w(W, sW);
+  v2_load_w<F16>(W, sW);
   __syncthreads();
   unsigned short* st = sT + wave * V2_CI * V2_LDT;
   const int b = wave, c = 32 * b + n;
@@ -515,11 +535,12 @@ __global__ __launch_bounds__(V2_WAVES * 64) V2_DW_ATTR void k_v2_dw(const unsign
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) st[(16 * s + 8 * half + j) * V2_LDT + n] = ya[s].s[j];
+      for (int j = 0; j < 8; ++j)      // (F16: the transposed tile is the bf16 operand of the gradient product with dx)
+        st[(16 * s + 8 * half + j) * V2_LDT + n] = F16 ? v2_f2bf((float)ya[s].hv[j]) : ya[s].s[j];
     int prow[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) prow[r] = __shfl(pil, v2_row(r, half), 64);
-    const f32x16 h = v2_h(ya, sW, n, half, b);
+    const f32x16 h = v2_h<F16>(ya, sW, n, half, b);
     const f32x16 dx = v2_dx(h, k, arg, gm, c, prow, (int)q, half);
     v2_wave_sync();
     // A fragments of D[i = channel][j = column] = sum_rows y1[row][channel] dx[row][column]: channel 32 i2 + n, the 8 rows
@@ -594,43 +615,57 @@ extern "C" size_t gdmae_vfe_max_layer_workspace_bytes(void) { return v2_ws_bytes
 // row_pillar (N) = pillar of each row, pillar_pt_off (M + 1) = first row of each pillar; W (128, 64) bf16.
 // out (M, 128) fp32 = max over the pillar of relu(BatchNorm1d_train(y1 W^T)), arg = row of the maximum (first row on
 // ties = lowest point id); stats / ab / mv as gdmae_bn_fold.
-extern "C" int gdmae_vfe_max_layer_fwd(const void* y1, long long N, const void* W, const int* pillar_pt_off,
-                                       const int* row_pillar, int M, const float* gamma,
-                                       const float* beta, double eps, double momentum, float* running_mean,
-                                       float* running_var, long long* num_batches, double* stats, float* ab, float* mv,
-                                       float* out, int* arg, void* workspace, void* stream) {
+// *_f16: y1 holds fp16 values (gdmae_vfe_point_layer_fwd with out_bf16 = 2) and W is the fp32 (128, 64) master matrix.
+template <bool F16>
+static int v2_fwd(const void* y1, long long N, const void* W, const int* pillar_pt_off, const int* row_pillar, int M, const float* gamma,
+                  const float* beta, double eps, double momentum, float* running_mean, float* running_var, long long* num_batches,
+                  double* stats, float* ab, float* mv, float* out, int* arg, void* workspace, void* stream) {
   GD_REQUIRE(N > 0 && M > 0, "vfe max layer: no points");
   hipStream_t st = (hipStream_t)stream;
   const V2Ws ws = v2_ws(workspace);
-  const int g1 = v2_grid(N, v2_resident_blocks(k_v2_stats, 0, V2_MAX_GRID));
-  hipLaunchKernelGGL(k_v2_stats, dim3(g1), dim3(V2_WAVES * 64), 0, st, (const unsigned short*)y1, N, (const unsigned short*)W,
-                     ws.part);
+  const int g1 = v2_grid(N, v2_resident_blocks(k_v2_stats<F16>, F16 ? 4 : 0, V2_MAX_GRID));
+  hipLaunchKernelGGL(k_v2_stats<F16>, dim3(g1), dim3(V2_WAVES * 64), 0, st, (const unsigned short*)y1, N, W, ws.part);
   GD_LAUNCH_CHECK();
   int rc = gd_bn_fold_from_partials(st, ws.part, g1, V2_CO, (double)N, gamma, beta, eps, momentum, running_mean, running_var,
                                     num_batches, stats, ab, mv);
   if (rc) return rc;
   // boundary pieces of k_v2_max: 2 slots x 128 columns x (value, row) per worker, in the partial area (the statistics partials have
   // been consumed by the fold above): V2_MAXW_GRID workgroups x 8 workers x 2 KB = the area's 32 MB
-  const int g2 = v2_grid(N, v2_resident_blocks(k_v2_max, 1, V2_MAXW_GRID));
+  const int g2 = v2_grid(N, v2_resident_blocks(k_v2_max<F16>, F16 ? 5 : 1, V2_MAXW_GRID));
   const long long nwk = (long long)g2 * V2_WAVES * 2, per = (N + nwk - 1) / nwk;
   float* const pbest = ws.part;
   int* const parg = (int*)(ws.part + nwk * 2 * V2_CO);
-  hipLaunchKernelGGL(k_v2_max, dim3(g2), dim3(V2_WAVES * 64), 0, st, (const unsigned short*)y1, N, (const unsigned short*)W,
-                     pillar_pt_off, row_pillar, M, (const float*)ab, out, arg, per, pbest, parg);
+  hipLaunchKernelGGL(k_v2_max<F16>, dim3(g2), dim3(V2_WAVES * 64), 0, st, (const unsigned short*)y1, N, W, pillar_pt_off, row_pillar, M,
+                     (const float*)ab, out, arg, per, pbest, parg);
   GD_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_v2_max_fix, dim3((unsigned)nwk), dim3(V2_CO), 0, st, row_pillar, N, per, (const float*)pbest, (const int*)parg,
                      out, arg);
   GD_LAUNCH_CHECK();
   return 0;
 }
+extern "C" int gdmae_vfe_max_layer_fwd(const void* y1, long long N, const void* W, const int* pillar_pt_off,
+                                       const int* row_pillar, int M, const float* gamma,
+                                       const float* beta, double eps, double momentum, float* running_mean,
+                                       float* running_var, long long* num_batches, double* stats, float* ab, float* mv,
+                                       float* out, int* arg, void* workspace, void* stream) {
+  return v2_fwd<false>(y1, N, W, pillar_pt_off, row_pillar, M, gamma, beta, eps, momentum, running_mean, running_var, num_batches, stats, ab,
+                       mv, out, arg, workspace, stream);
+}
+extern "C" int gdmae_vfe_max_layer_fwd_f16(const void* y1, long long N, const float* W, const int* pillar_pt_off,
+                                           const int* row_pillar, int M, const float* gamma,
+                                           const float* beta, double eps, double momentum, float* running_mean,
+                                           float* running_var, long long* num_batches, double* stats, float* ab, float* mv,
+                                           float* out, int* arg, void* workspace, void* stream) {
+  return v2_fwd<true>(y1, N, W, pillar_pt_off, row_pillar, M, gamma, beta, eps, momentum, running_mean, running_var, num_batches, stats, ab,
+                      mv, out, arg, workspace, stream);
+}
 
 // g (M, 128) fp32: gradient of out.  gm: scratch, M * 128 floats (the masked gradient).  dy1 (N, 64) bf16 is written; dgamma / dbeta / dW (128, 64)
 // fp32 are written, or accumulated into when `accumulate`.
-extern "C" int gdmae_vfe_max_layer_bwd(const void* y1, long long N, const void* W, const int* row_pillar, int M,
-                                       const float* gamma, const double* stats, const float* ab,
-                                       const float* out, const int* arg, const float* g, void* gm,
-                                       void* dy1, float* dgamma, float* dbeta, float* dW, int accumulate, void* workspace,
-                                       void* stream) {
+template <bool F16>
+static int v2_bwd(const void* y1, long long N, const void* W, const int* row_pillar, int M, const float* gamma, const double* stats,
+                  const float* ab, const float* out, const int* arg, const float* g, void* gm, void* dy1, float* dgamma, float* dbeta,
+                  float* dW, int accumulate, void* workspace, void* stream) {
   GD_REQUIRE(N > 0 && M > 0, "vfe max layer: no points");
   hipStream_t st = (hipStream_t)stream;
   const V2Ws ws = v2_ws(workspace);
@@ -641,14 +676,28 @@ extern "C" int gdmae_vfe_max_layer_bwd(const void* y1, long long N, const void* 
   if (rc) return rc;
   rc = gdmae_bn_bwd_coeffs(ws.sums, 2, stats, ab, gamma, V2_CO, (double)N, nullptr, dgamma, dbeta, accumulate, ws.c01, stream);
   if (rc) return rc;
-  const int g1 = v2_grid(N, v2_resident_blocks(k_v2_dy, 2, 4096));
-  hipLaunchKernelGGL(k_v2_dy, dim3(g1), dim3(V2_WAVES * 64), 0, st, (const unsigned short*)y1, N, (const unsigned short*)W,
-                     row_pillar, (const float*)ab, (const float*)ws.c01, arg, (const float*)gm, (unsigned*)dy1);
+  const int g1 = v2_grid(N, v2_resident_blocks(k_v2_dy<F16>, F16 ? 6 : 2, 4096));
+  hipLaunchKernelGGL(k_v2_dy<F16>, dim3(g1), dim3(V2_WAVES * 64), 0, st, (const unsigned short*)y1, N, W, row_pillar, (const float*)ab,
+                     (const float*)ws.c01, arg, (const float*)gm, (unsigned*)dy1);
   GD_LAUNCH_CHECK();
-  int g2 = v2_resident_blocks(k_v2_dw, 3, V2_DW_GRID);     // one tile per workgroup and iteration
+  int g2 = v2_resident_blocks(k_v2_dw<F16>, F16 ? 7 : 3, V2_DW_GRID);     // one tile per workgroup and iteration
   if (g2 > (N + 31) / 32) g2 = (int)((N + 31) / 32);
-  hipLaunchKernelGGL(k_v2_dw, dim3(g2), dim3(V2_WAVES * 64), 0, st, (const unsigned short*)y1, N, (const unsigned short*)W,
-                     row_pillar, (const float*)ab, (const float*)ws.c01, arg, (const float*)gm, ws.part);
+  hipLaunchKernelGGL(k_v2_dw<F16>, dim3(g2), dim3(V2_WAVES * 64), 0, st, (const unsigned short*)y1, N, W, row_pillar, (const float*)ab,
+                     (const float*)ws.c01, arg, (const float*)gm, ws.part);
   GD_LAUNCH_CHECK();
   return gd_splitk_acc(st, ws.part, g2, (long long)V2_CO * V2_CI, dW, accumulate);
+}
+extern "C" int gdmae_vfe_max_layer_bwd(const void* y1, long long N, const void* W, const int* row_pillar, int M,
+                                       const float* gamma, const double* stats, const float* ab,
+                                       const float* out, const int* arg, const float* g, void* gm,
+                                       void* dy1, float* dgamma, float* dbeta, float* dW, int accumulate, void* workspace,
+                                       void* stream) {
+  return v2_bwd<false>(y1, N, W, row_pillar, M, gamma, stats, ab, out, arg, g, gm, dy1, dgamma, dbeta, dW, accumulate, workspace, stream);
+}
+extern "C" int gdmae_vfe_max_layer_bwd_f16(const void* y1, long long N, const float* W, const int* row_pillar, int M,
+                                           const float* gamma, const double* stats, const float* ab,
+                                           const float* out, const int* arg, const float* g, void* gm,
+                                           void* dy1, float* dgamma, float* dbeta, float* dW, int accumulate, void* workspace,
+                                           void* stream) {
+  return v2_bwd<true>(y1, N, W, row_pillar, M, gamma, stats, ab, out, arg, g, gm, dy1, dgamma, dbeta, dW, accumulate, workspace, stream);
 }

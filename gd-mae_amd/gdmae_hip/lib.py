@@ -37,6 +37,8 @@ SIGNATURES = {
     "gdmae_vfe_max_layer_workspace_bytes": (_Z, []),
     "gdmae_vfe_max_layer_fwd": (_I, [_P, _L, _P, _P, _P, _I, _P, _P, _D, _D, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gdmae_vfe_max_layer_bwd": (_I, [_P, _L, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
+    "gdmae_vfe_max_layer_fwd_f16": (_I, [_P, _L, _P, _P, _P, _I, _P, _P, _D, _D, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "gdmae_vfe_max_layer_bwd_f16": (_I, [_P, _L, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
     "gdmae_fill_rows": (_I, [_P, _L, _I, _I, _P, _P]),
     "gdmae_weighted_mean_finish": (_I, [_P, _P, _L, _P, _P]),
     "gdmae_decoder_region_workspace_bytes": (_Z, [_I, _I]),

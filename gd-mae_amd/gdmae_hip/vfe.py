@@ -190,11 +190,13 @@ class PointLayer1(torch.autograd.Function):
     Returns (out [bf16 under autocast, else fp32], mean, biased var)."""
 
     @staticmethod
-    def forward(ctx, vox, weight, gamma, beta, eps, bn=None, pillar_major=False):
+    def forward(ctx, vox, weight, gamma, beta, eps, bn=None, pillar_major=False, out_f16=False):
         dev = weight.device
         C, D = weight.shape
         assert weight.dtype == torch.float32 and weight.is_contiguous() and D == vox.n_cols + 5
         odt = torch.bfloat16 if torch.is_autocast_enabled() else torch.float32
+        if out_f16:                      # (only inside PointLayers12Max: a float16 output of its own would demand float16 gradients)
+            odt = torch.float16
         n = int(vox.N)
         out = torch.empty(n, C, dtype=odt, device=dev)
         stats = torch.empty(2 * C, dtype=torch.float64, device=dev)
@@ -208,7 +210,7 @@ class PointLayer1(torch.autograd.Function):
             rm, rv, nb, mom = bn.running_mean, bn.running_var, bn.num_batches_tracked, float(bn.momentum)
         L.call("gdmae_vfe_point_layer_fwd", *PointLayer1._geometry(vox, ctx.pm), L.ptr(weight), C, L.ptr(gamma), L.ptr(beta),
                float(eps), mom, L.ptr(rm) if rm is not None else None, L.ptr(rv) if rv is not None else None,
-               L.ptr(nb) if nb is not None else None, L.ptr(stats), L.ptr(ab), L.ptr(mv), L.ptr(out), _bf(out), L.ptr(ws),
+               L.ptr(nb) if nb is not None else None, L.ptr(stats), L.ptr(ab), L.ptr(mv), L.ptr(out), 2 if out_f16 else _bf(out), L.ptr(ws),
                L.stream())
         ctx.vox, ctx.ws = vox, ws
         ctx.save_for_backward(weight, gamma.detach(), stats, ab)
@@ -231,7 +233,7 @@ class PointLayer1(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g, _m, _v):
         if g is None:
-            return (None,) * 7
+            return (None,) * 8
         weight, gamma, stats, ab = ctx.saved_tensors
         vox, C = ctx.vox, weight.shape[0]
         g = g.contiguous()
@@ -245,8 +247,8 @@ class PointLayer1(torch.autograd.Function):
         L.call("gdmae_vfe_point_layer_bwd", *PointLayer1._geometry(vox, ctx.pm), L.ptr(weight), C, L.ptr(gamma), L.ptr(stats),
                L.ptr(ab), L.ptr(g), _bf(g), L.ptr(dg), L.ptr(db), L.ptr(dw), acc, L.ptr(ctx.ws), L.stream())
         if acc:
-            return None, None, None, None, None, None, None
-        return None, dw, dg, db, None, None, None
+            return None, None, None, None, None, None, None, None
+        return None, dw, dg, db, None, None, None, None
 
 
 class PointLayer2Max(torch.autograd.Function):
@@ -259,10 +261,13 @@ class PointLayer2Max(torch.autograd.Function):
     def forward(ctx, y1, row_pillar, weight, gamma, beta, eps, pt_off, bn=None):
         dev = y1.device
         C, K = weight.shape
-        assert (C, K) == (128, 64) and y1.dtype == torch.bfloat16 and y1.is_contiguous() and y1.shape[1] == K
+        assert (C, K) == (128, 64) and y1.dtype in (torch.bfloat16, torch.float16) and y1.is_contiguous() and y1.shape[1] == K
         assert row_pillar.dtype == torch.int32 and row_pillar.numel() == y1.shape[0]
         n, M = y1.shape[0], pt_off.numel() - 1
-        wb = ops.shadow(weight, torch.bfloat16).contiguous()
+        f16 = y1.dtype == torch.float16          # fp16 rows (inside PointLayers12Max): the kernels round the fp32 master weights themselves
+        wb = weight.detach().contiguous() if f16 else ops.shadow(weight, torch.bfloat16).contiguous()
+        assert not f16 or wb.dtype == torch.float32
+        ctx.f16 = f16
         out = torch.empty(M, C, dtype=torch.float32, device=dev)
         arg = torch.empty(M, C, dtype=torch.int32, device=dev)
         stats = torch.empty(2 * C, dtype=torch.float64, device=dev)
@@ -273,7 +278,7 @@ class PointLayer2Max(torch.autograd.Function):
         mom = 0.0
         if bn is not None and bn.training and bn.running_mean is not None:
             rm, rv, nb, mom = bn.running_mean, bn.running_var, bn.num_batches_tracked, float(bn.momentum)
-        L.call("gdmae_vfe_max_layer_fwd", L.ptr(y1), n, L.ptr(wb), L.ptr(pt_off), L.ptr(row_pillar), M, L.ptr(gamma),
+        L.call("gdmae_vfe_max_layer_fwd_f16" if f16 else "gdmae_vfe_max_layer_fwd", L.ptr(y1), n, L.ptr(wb), L.ptr(pt_off), L.ptr(row_pillar), M, L.ptr(gamma),
                L.ptr(beta), float(eps), mom, L.ptr(rm) if rm is not None else None, L.ptr(rv) if rv is not None else None,
                L.ptr(nb) if nb is not None else None, L.ptr(stats), L.ptr(ab), L.ptr(mv), L.ptr(out), L.ptr(arg), L.ptr(ws),
                L.stream())
@@ -299,10 +304,91 @@ class PointLayer2Max(torch.autograd.Function):
             dgb = torch.empty(2 * C, dtype=torch.float32, device=y1.device)
             dg, db = dgb[:C], dgb[C:]
         gm = torch.empty_like(out)
-        dy1 = torch.empty_like(y1)
-        L.call("gdmae_vfe_max_layer_bwd", L.ptr(y1), n, L.ptr(wb), L.ptr(row_pillar), M, L.ptr(gamma), L.ptr(stats), L.ptr(ab),
+        dy1 = torch.empty(y1.shape, dtype=torch.bfloat16, device=y1.device)        # gradients stay bf16 (their range is why bf16 exists)
+        L.call("gdmae_vfe_max_layer_bwd_f16" if ctx.f16 else "gdmae_vfe_max_layer_bwd", L.ptr(y1), n, L.ptr(wb), L.ptr(row_pillar), M, L.ptr(gamma), L.ptr(stats), L.ptr(ab),
                L.ptr(out), L.ptr(arg), L.ptr(g), L.ptr(gm), L.ptr(dy1), L.ptr(dg), L.ptr(db), L.ptr(dw), acc,
                L.ptr(ctx.ws), L.stream())
         if acc:
             return dy1, None, None, None, None, None, None, None
         return dy1, None, dw, dg, db, None, None, None
+
+
+
+class _StandInCtx:
+    """Autograd context of a Function whose forward / backward bodies run inside another Function (PointLayers12Max)."""
+
+    def __init__(self):
+        self.saved_tensors = ()
+        self.needs_input_grad = ()
+
+    def save_for_backward(self, *ts):
+        self.saved_tensors = ts
+
+    def mark_non_differentiable(self, *ts):
+        pass
+
+    def set_materialize_grads(self, flag):
+        pass
+
+
+class PointLayers12Max(torch.autograd.Function):
+    """Both DynVFE layers of the 16-bit mode as ONE autograd node (dyn_vfe.py:74-112): PointLayer1 (pillar-major rows) and PointLayer2Max
+    composed, so that the (N, 64) rows between them can be **fp16** - an fp16 tensor of its own between two nodes would demand an fp16
+    gradient, while the gradient rows must stay bf16.  Round 6: the pillar maximum passes ONE point's value on, so the rounding of those
+    rows and of the second layer's weights does not average over a pillar's points; with fp16 (11 significand bits, same bytes, same
+    matrix-core rate) DynVFE's share of the small-case loss scatter goes away.  Layers wider than 128 outputs
+    (config E: 64 -> 256) run as independent 128-channel blocks whose input gradients meet in one gdmae_sum_bf16 pass.
+    forward(vox, W1, gamma1, beta1, eps1, bn1, W2, gamma2, beta2, eps2, bn2) -> (M, C2) fp32."""
+
+    @staticmethod
+    def forward(ctx, vox, w1, g1, b1, eps1, bn1, w2, g2, b2, eps2, bn2):
+        c1 = _StandInCtx()
+        y1, _, _ = PointLayer1.forward(c1, vox, w1, g1, b1, eps1, bn1, True, True)
+        C2 = w2.shape[0]
+        assert C2 % 128 == 0
+        c2s, outs = [], []
+        for blk in range(C2 // 128):
+            lo, hi = 128 * blk, 128 * (blk + 1)
+            c2 = _StandInCtx()
+            bnb = bn2 if C2 == 128 else _BnChannels(bn2, lo, hi, blk == 0)
+            o, _, _ = PointLayer2Max.forward(c2, y1, vox.row_pillar, w2[lo:hi], g2[lo:hi], b2[lo:hi], eps2, vox.pt_off, bnb)
+            c2s.append(c2), outs.append(o)
+        # the tensors the bodies saved go through the real save_for_backward; the stand-ins keep the non-tensor metadata
+        saved, counts = list(c1.saved_tensors), [len(c1.saved_tensors)]
+        c1.saved_tensors = ()
+        for c2 in c2s:
+            saved += list(c2.saved_tensors)
+            counts.append(len(c2.saved_tensors))
+            c2.saved_tensors = ()
+        ctx.save_for_backward(*saved)
+        ctx.c1, ctx.c2s, ctx.counts = c1, c2s, counts
+        ctx.set_materialize_grads(False)
+        return outs[0] if len(outs) == 1 else torch.cat(outs, dim=1)
+
+    @staticmethod
+    def backward(ctx, g):
+        if g is None:
+            return (None,) * 11
+        sv, pos = ctx.saved_tensors, 0
+        c1, c2s = ctx.c1, ctx.c2s
+        c1.saved_tensors = sv[pos:pos + ctx.counts[0]]
+        pos += ctx.counts[0]
+        dy1s, dw2, dg2, db2 = [], [], [], []
+        acc2 = True
+        for i, c2 in enumerate(c2s):
+            c2.saved_tensors = sv[pos:pos + ctx.counts[i + 1]]
+            pos += ctx.counts[i + 1]
+            r = PointLayer2Max.backward(c2, g[:, 128 * i:128 * (i + 1)], None, None)
+            c2.saved_tensors = ()
+            dy1s.append(r[0])
+            acc2 = acc2 and r[2] is None
+            dw2.append(r[2]), dg2.append(r[3]), db2.append(r[4])
+        if len(dy1s) == 1:
+            dy1 = dy1s[0]
+        else:
+            dy1 = torch.empty_like(dy1s[0])
+            L.call("gdmae_sum_bf16", L.host_ptrs(dy1s), len(dy1s), dy1.numel(), L.ptr(dy1), L.stream())
+        r1 = PointLayer1.backward(c1, dy1, None, None)
+        c1.saved_tensors = ()
+        cat = (lambda ts: None if acc2 else torch.cat(ts, dim=0))
+        return (None, r1[1], r1[2], r1[3], None, None, cat(dw2), cat(dg2), cat(db2), None, None)

@@ -15,6 +15,10 @@ from ...model_utils.network_utils import make_fc_layers
 from gdmae_hip import ops, plan as gplan, vfe as gvfe
 
 
+# both fused layers as one node with fp16 rows between them (round 6); 0: two nodes, bf16 rows (A/B reference, tools/ab_env.sh)
+VFE_F16 = os.environ.get("GDMAE_VFE_F16", "1") != "0"
+
+
 class DynVFE(VFETemplate):
     fused = True      # fused BN+ReLU(+max) row kernels; False = torch BatchNorm1d / ReLU modules + segment max
     point_layer = os.environ.get("GDMAE_VFE_POINT_LAYER", "1") != "0"    # first layer as gdmae_vfe_point_layer_*
@@ -54,6 +58,11 @@ class DynVFE(VFETemplate):
             last = (first and self.max_layer and nl == 2 and torch.is_autocast_enabled() and mlp[3].bias is None
                     and mlp[3].weight.shape[1] == 64 and mlp[3].weight.shape[0] in (128, 256) and vox.points_pm is not None)
             x = None if first else ops.decorate_points(vox)
+            if first and last and VFE_F16:
+                # both layers as one autograd node with fp16 rows between them (gdmae_hip.vfe.PointLayers12Max, round 6)
+                l1, bn1, l2, bn2 = mlp[0], mlp[1], mlp[3], mlp[4]
+                x = gvfe.PointLayers12Max.apply(vox, l1.weight, bn1.weight, bn1.bias, bn1.eps, bn1, l2.weight, bn2.weight, bn2.bias, bn2.eps, bn2)
+                nl = 0
             for k in range(nl):
                 lin, bn = mlp[3 * k], mlp[3 * k + 1]
                 if k == 0 and first:

@@ -72,7 +72,8 @@ int gdmae_decorate_points(const float* points, const long long* point_coords, co
 /* First DynVFE point layer as one call per direction (dyn_vfe.py:74-109 + network_utils.py:7-21: decoration,
  * Linear(6+F -> 64, no bias), BatchNorm1d(train), ReLU).  The (N, 64) pre-activation is never stored: it is
  * recomputed from the points in MFMA accumulators for the statistics, the output, the backward statistics and the
- * weight gradient.  W (64, 6+F) fp32; out / g (N, 64) bf16 or fp32; stats / ab / mv as gdmae_bn_fold;
+ * weight gradient.  W (64, 6+F) fp32; out (N, 64) fp32 (out_bf16 = 0), bf16 (1) or fp16 (2: the rows gdmae_vfe_max_layer_*_f16
+ * read), g (N, 64) bf16 or fp32; stats / ab / mv as gdmae_bn_fold;
  * dgamma / dbeta / dW written, or accumulated into when `accumulate`.  Row i of out / g is row i of `points`.
  * coords_per_pillar != 0: the rows are the pillar-major ones of gdmae_pillar_major_rows (rows of a pillar contiguous,
  * as gdmae_vfe_max_layer_* wants them): points = points_pm, inverse32 = row_pillar, point_coords = the (M, 4)
@@ -109,6 +110,19 @@ int gdmae_vfe_max_layer_bwd(const void* y1, long long N, const void* W, const in
                             const double* stats, const float* ab, const float* out, const int* arg, const float* g, void* gm,
                             void* dy1, float* dgamma, float* dbeta, float* dW, int accumulate,
                             void* workspace, void* stream);
+/* Round 6, the same layer on fp16 rows: y1 (N, 64) holds fp16 values (gdmae_vfe_point_layer_fwd with out_bf16 = 2) and W is the fp32
+ * (128, 64) master matrix - rounded to fp16 for the pre-activation y1 W^T (v_mfma_f32_32x32x16_f16) and to bf16 for the gradient product
+ * dy1 = dx W; dy1 stays bf16.  The pillar maximum passes ONE point's value on, so the rounding of y1 and of W does not average over a
+ * pillar's points: fp16 (11 significand bits; the rows are BatchNorm + ReLU outputs) instead of bf16 (8) at the same byte count and
+ * matrix-core rate.  Same dyn_vfe.py:107-112 / scatter_max semantics as above. */
+int gdmae_vfe_max_layer_fwd_f16(const void* y1, long long N, const float* W, const int* pillar_pt_off, const int* row_pillar,
+                                int M, const float* gamma, const float* beta, double eps, double momentum,
+                                float* running_mean, float* running_var, long long* num_batches, double* stats, float* ab,
+                                float* mv, float* out, int* arg, void* workspace, void* stream);
+int gdmae_vfe_max_layer_bwd_f16(const void* y1, long long N, const float* W, const int* row_pillar, int M, const float* gamma,
+                                const double* stats, const float* ab, const float* out, const int* arg, const float* g, void* gm,
+                                void* dy1, float* dgamma, float* dbeta, float* dW, int accumulate,
+                                void* workspace, void* stream);
 int gdmae_segment_max(const float* x, const int* pillar_pt_off, const int* pillar_pts, int M, int C, float* out,
                       int* arg, void* stream);
 int gdmae_segment_max_bwd(const float* dout, const int* arg, const int* inverse32, long long N, int C, float* dx,
