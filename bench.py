@@ -601,6 +601,9 @@ def main():
            "config": {"workload": WORKLOADS[named] + (f", mask {args.mask_ratio}" if pre else "") +
                                   ", full train step (H2D of the next batch + fwd + bwd + grad all-reduce + clip + Adam)",
                       "frames_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
+                      "precision": ("16-bit mode: bf16 rows, gradients and products, fp32 accumulation; fp16 operands (11 significand bits, same "
+                                    "matrix-core rate) in the forward products of DynVFE's second layer, the decoder's deconvolution rows and its "
+                                    "tile convolution; index / loss kernels fp32, prediction head fp32-grade") if use_bf16 else "fp32",
                       "library_gemm": "forbidden: GDMAE_NO_LIBRARY=%s (a product outside the own kernels' shapes raises)" % os.environ.get("GDMAE_NO_LIBRARY"),
                       "device_allocs_in_timed_region": int(n_dev_alloc),      # hipMalloc calls between the two clocks (each synchronises the device)
                       "geometry_plan": ("of batch t+1: one library call on a side stream, issued from inside step t's forward right before the "

@@ -350,8 +350,11 @@ class PointLayers12Max(torch.autograd.Function):
         for blk in range(C2 // 128):
             lo, hi = 128 * blk, 128 * (blk + 1)
             c2 = _StandInCtx()
-            bnb = bn2 if C2 == 128 else _BnChannels(bn2, lo, hi, blk == 0)
-            o, _, _ = PointLayer2Max.forward(c2, y1, vox.row_pillar, w2[lo:hi], g2[lo:hi], b2[lo:hi], eps2, vox.pt_off, bnb)
+            if C2 == 128:          # the parameters themselves (not slices of them): their gradients go straight into the flat buffer
+                o, _, _ = PointLayer2Max.forward(c2, y1, vox.row_pillar, w2, g2, b2, eps2, vox.pt_off, bn2)
+            else:
+                o, _, _ = PointLayer2Max.forward(c2, y1, vox.row_pillar, w2[lo:hi], g2[lo:hi], b2[lo:hi], eps2, vox.pt_off,
+                                                 _BnChannels(bn2, lo, hi, blk == 0))
             c2s.append(c2), outs.append(o)
         # the tensors the bodies saved go through the real save_for_backward; the stand-ins keep the non-tensor metadata
         saved, counts = list(c1.saved_tensors), [len(c1.saved_tensors)]

@@ -60,6 +60,20 @@ def cast_hidden16(a, k):        # (fp32 stage outputs would send the deconvoluti
 
 
 gdec.sparse_decoder = no_autocast(gdec.sparse_decoder, "decoder", cast_hidden, cast_hidden16)
+# finer split inside the stages: the sparse-conv blocks (conv_down / conv_out: spconv + BatchNorm + ReLU) and the transformer layers
+import pcdet.models.backbones_3d.spt_backbone as sb_mod
+for i, blk in enumerate(bb.sst_blocks):
+    for nm in ("conv_down", "conv_out"):
+        m = getattr(blk, nm, None)
+        if m is not None:
+            m.forward = no_autocast(m.forward, "convs", cast_sp)
+
+
+def cast_feat(a, k):           # encoder_stage(blocks, feat, table, wplans, residual=...)
+    return (a[0], a[1].float()) + tuple(a[2:]), k
+
+
+sb_mod.genc.encoder_stage = no_autocast(sb_mod.genc.encoder_stage, "layers", cast_feat)
 import pcdet.models.backbones_3d.spt_backbone_mae as mae_mod
 mae_mod.gdec = gdec
 
@@ -73,6 +87,7 @@ variants = [("all 16-bit (the bench mode)", set()), ("DynVFE fp32", {"vfe"}), ("
             ("stage 3 fp32", {"stage3"}), ("all stages fp32", {"stage1", "stage2", "stage3"}), ("decoder fp32", {"decoder"}),
             ("DynVFE + stages fp32 (decoder 16-bit)", {"vfe", "stage1", "stage2", "stage3"}),
             ("stages + decoder fp32 (DynVFE 16-bit)", {"stage1", "stage2", "stage3", "decoder"}),
+            ("sparse-conv blocks of all stages fp32", {"convs"}), ("transformer layers of all stages fp32", {"layers"}),
             ("everything fp32 under the bench-mode module tree", {"vfe", "stage1", "stage2", "stage3", "decoder"})]
 for label, on in variants:
     FP32.clear(); FP32.update(on)
