@@ -355,6 +355,10 @@ class PointLayers12Max(torch.autograd.Function):
             else:
                 o, _, _ = PointLayer2Max.forward(c2, y1, vox.row_pillar, w2[lo:hi], g2[lo:hi], b2[lo:hi], eps2, vox.pt_off,
                                                  _BnChannels(bn2, lo, hi, blk == 0))
+                # slices of flat-buffer parameters: the block's gradients accumulate into the matching rows of the flat views
+                dwf, dgf, dbf = ops.direct_grad(w2), *gbn.direct_pair(g2, b2)
+                if dwf is not None and dgf is not None and dbf is not None:
+                    c2.direct = (dwf[lo:hi], dgf[lo:hi], dbf[lo:hi])
             c2s.append(c2), outs.append(o)
         # the tensors the bodies saved go through the real save_for_backward; the stand-ins keep the non-tensor metadata
         saved, counts = list(c1.saved_tensors), [len(c1.saved_tensors)]
