@@ -440,6 +440,14 @@ int gd_tok_gemm_res_ln(hipStream_t st, const void* X, const void* Wp, const void
                        const float* pos_table, const int* tok_pos, void* ypos_bf, void* f_out, int y_cached);
 
 // layer around its bytes (layer_fused.hip)
+// layer in registers (layer_v3.hip)
+int gd_layer_v3_rows();
+size_t gd_layer_v3_fwd_stream_elems(int d, int ff);
+int gd_layer_v3_fwd_pack_jobs(const float* Wo, const float* W1, const float* W2, int d, int ff, void* stream_img, long long* jobs);
+int gd_layer_v3_fwd(hipStream_t st, int d, const void* o, const void* x, const void* Wstream, const void* bo, const void* b1, const void* b2,
+                    const float* g1, const float* be1, const float* g2, const float* be2, float eps, long long n, long long n_pad, void* a,
+                    void* x1, void* h, void* f, float* st1, float* st2, float* y, void* y_bf, void* ypos_bf, const float* pos_table,
+                    const int* tok_pos, const void* res0, void* res_out);
 bool gd_layer_fused_supported(int d, int ff);
 int gd_layer_fused_rows(int d);
 int gd_layer_fused_fwd(hipStream_t st, int d, const void* o, const void* x, const void* Wo, const void* W1, const void* W2, const void* bo,
@@ -461,8 +469,17 @@ namespace {
 // packed weight image of a layer: element offsets (in bf16 elements) of the ten operands
 struct Packed {
   const char *qk, *v, *o, *w1, *w2, *w2t, *w1t, *ot, *qkt, *vt;
+  const char* f3;          // layer_v3.hip: the forward launch's weight stream (Wo | per hidden chunk W1[chunk] | W2[:, chunk])
   size_t bytes;
 };
+// GDMAE_LAYER_V3=1: the layer's forward launch on the in-register kernel of layer_v3.hip (experiment: measured slower); its
+// weight stream is packed only then
+static int layer_v3() {
+  static int v = -1;
+  if (v < 0) v = getenv("GDMAE_LAYER_V3") ? atoi(getenv("GDMAE_LAYER_V3")) : 0;
+  return v;
+}
+static bool v3_shape(int d, int ff) { return layer_v3() && (d == 128 || d == 256) && ff == 2 * d; }
 Packed packed_layout(const void* base, int d, int ff) {
   Packed p;
   size_t off = 0;
@@ -470,6 +487,7 @@ Packed packed_layout(const void* base, int d, int ff) {
   const size_t dd = (size_t)d * d, df = (size_t)d * ff;
   p.qk = take(2 * dd); p.v = take(dd); p.o = take(dd); p.w1 = take(df); p.w2 = take(df);
   p.w2t = take(df); p.w1t = take(df); p.ot = take(dd); p.qkt = take(2 * dd); p.vt = take(dd);
+  p.f3 = v3_shape(d, ff) ? take(gd_layer_v3_fwd_stream_elems(d, ff)) : nullptr;
   p.bytes = off;
   return p;
 }
@@ -532,8 +550,11 @@ extern "C" int gdmae_layer_pack_jobs(const float* Win, const float* Wo, const fl
   };
   for (int i = 0; i < 10; ++i)
     for (int k = 0; k < 6; ++k) jobs[i * 6 + k] = J[i][k];
+  if (p.f3) gd_layer_v3_fwd_pack_jobs(Wo, W1, W2, d, ff, (void*)p.f3, jobs + 60);
   return 0;
 }
+
+extern "C" int gdmae_layer_pack_job_count(int d, int ff) { return 10 + (v3_shape(d, ff) ? 1 + 2 * (ff / 128) : 0); }
 
 extern "C" int gdmae_encoder_layer_bytes(long long n, int d, int ff, int nhead, int bf16, size_t* saved_bytes,
                                          size_t* fwd_scratch_bytes, size_t* bwd_scratch_bytes) {
@@ -666,6 +687,13 @@ static int stage_fwd_v2(const gdmae_layer_args* layers, int n_layers, void* stre
         const Packed pn = packed_layout(next->packed, d, ff);
         wqk_n = pn.qk; wv_n = pn.v; qk_n = sn.qk; v_n = sn.v;
       }
+    }
+    if (layer_v3() && pk.f3 && !wqk_n) {
+      GD_TRY(gd_layer_v3_fwd(st, d, s.o, s.xb, pk.f3, a->bo, a->b1, a->b2, a->g1, a->be1, a->g2, a->be2, a->eps, n, n_pad, s.a, s.x1b, s.h, s.f,
+                             (float*)s.st1, (float*)s.st2, (next || a->res_out) ? nullptr : a->y, y_bf, ypos_bf,
+                             next ? next->pos_table : nullptr, next ? next->tok_pos : nullptr,
+                             (!next && a->res_out) ? saved_layout(layers[0].saved, n_pad, d, ff, 2).xb : nullptr, next ? nullptr : a->res_out));
+      continue;
     }
     GD_TRY(gd_layer_fused_fwd(st, d, s.o, s.xb, pk.o, pk.w1, pk.w2, a->bo, a->b1, a->b2, a->g1, a->be1, a->g2, a->be2, a->eps, n, n_pad, s.a,
                               s.x1b, s.h, s.f, (float*)s.st1, (float*)s.st2, (next || a->res_out) ? nullptr : a->y, y_bf, ypos_bf,

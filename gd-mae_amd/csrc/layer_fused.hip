@@ -179,6 +179,9 @@ __global__ __launch_bounds__(TL_THREADS * TL_HALVES, TL_MINW) void k_layer_fwd(L
     pos_pf[p] = tokp[rr];
   }
   tl_load_tile<D, ROWS>(A.o, row0, xl, XP, 0, tid);
+  // LayerNorm weights of the row pass behind the product: requested here (a load behind the barrier that opens the pass is a whole
+  // L2 round trip in front of its arithmetic)
+  const float4 g4_1 = *(const float4*)(A.g1 + lc0), b4_1 = *(const float4*)(A.be1 + lc0);
   __syncthreads();
   // ---- a = o Wo^T + bo
   {
@@ -196,7 +199,7 @@ __global__ __launch_bounds__(TL_THREADS * TL_HALVES, TL_MINW) void k_layer_fwd(L
   // ---- x1 = LN1(x + a): a leaves for HBM, x1 replaces it in LDS (operand tile of linear1) and is the residual of LN2
   uint2 x1_keep[LPASS];
   {
-    const float4 g4 = *(const float4*)(A.g1 + lc0), b4 = *(const float4*)(A.be1 + lc0);
+    const float4 g4 = g4_1, b4 = b4_1;
     const float g[4] = {g4.x, g4.y, g4.z, g4.w}, bt[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
     for (int p = 0; p < LPASS; ++p) {
@@ -250,11 +253,14 @@ __global__ __launch_bounds__(TL_THREADS * TL_HALVES, TL_MINW) void k_layer_fwd(L
   }
   __syncthreads();
   // ---- f = gelu(h) W2^T + b2  (staged over the x1 tile: nobody reads it any more)
+  float4 g4_2, b4_2;                                   // LayerNorm-2 weights, requested in front of the product
   {
     f32x16 acc[TlShape<FF, D, ROWS>::MPW][TlShape<FF, D, ROWS>::NPW];
     tl_zero(acc);
     TlBias<FF, D, ROWS> bic;
     bic.load(A.b2, wv, lane);
+    g4_2 = *(const float4*)(A.g2 + lc0);
+    b4_2 = *(const float4*)(A.be2 + lc0);
     pc.run(hl, HP, wv, lane, acc);
     tl_stage<FF, D, ROWS>(acc, bic, xl, XP, wv, lane);
   }
@@ -264,7 +270,7 @@ __global__ __launch_bounds__(TL_THREADS * TL_HALVES, TL_MINW) void k_layer_fwd(L
   __syncthreads();
   // ---- y = LN2(x1 + f)
   {
-    const float4 g4 = *(const float4*)(A.g2 + lc0), b4 = *(const float4*)(A.be2 + lc0);
+    const float4 g4 = g4_2, b4 = b4_2;
     const float g[4] = {g4.x, g4.y, g4.z, g4.w}, bt[4] = {b4.x, b4.y, b4.z, b4.w};
     uint2 r0q[LPASS];
     float4 p4q[LPASS];
@@ -436,6 +442,7 @@ __global__ __launch_bounds__(TL_THREADS * TL_HALVES, TL_MINW) void k_layer_bwd_f
     *(uint4*)(A.gact + e) = tg_pack8(v);
   }
   __syncthreads();
+  const float4 g4_1 = *(const float4*)(A.g1 + lc0);   // LayerNorm weights of the pass behind the product (see k_layer_fwd)
   // ---- dx1 = dh W1 (staged over the df tile: its rows are in registers)
   {
     f32x16 acc[TlShape<FF, D, ROWS>::MPW][TlShape<FF, D, ROWS>::NPW];
@@ -448,7 +455,7 @@ __global__ __launch_bounds__(TL_THREADS * TL_HALVES, TL_MINW) void k_layer_bwd_f
   __syncthreads();                                   // staging complete; every wavefront is done with the dh tile
   // ---- da = LN1'(df + dx1)
   {
-    const float4 g4 = *(const float4*)(A.g1 + lc0);
+    const float4 g4 = g4_1;
     const float g[4] = {g4.x, g4.y, g4.z, g4.w};
     TlLnBwd<D> L;
     L.init();
@@ -558,6 +565,7 @@ __global__ __launch_bounds__(TL_THREADS * TL_HALVES, TL_MINW) void k_layer_bwd_i
   }
   tl_load_tile<2 * D, ROWS>(A.dqk, row0, lds, XP, 0, tid);
   tl_load_tile<D, ROWS>(A.dv, row0, lds, XP, 4 * D, tid);
+  const float4 g4_ln = *(const float4*)((LN ? A.gamma : (const float*)A.dres) + lc0);
   __syncthreads();
   {
     f32x16 acc[TlShape<KD, D, ROWS>::MPW][TlShape<KD, D, ROWS>::NPW];
@@ -568,7 +576,7 @@ __global__ __launch_bounds__(TL_THREADS * TL_HALVES, TL_MINW) void k_layer_bwd_i
   }
   __syncthreads();
   if (LN) {
-    const float4 g4 = *(const float4*)(A.gamma + lc0);
+    const float4 g4 = g4_ln;
     const float g[4] = {g4.x, g4.y, g4.z, g4.w};
     TlLnBwd<D> L;
     L.init();

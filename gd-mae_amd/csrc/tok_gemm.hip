@@ -40,7 +40,26 @@ __global__ __launch_bounds__(256) void k_tg_pack(const long long* __restrict__ j
   const float* src = (const float*)J[0];
   uint4* dst = (uint4*)J[1];
   const int M = (int)J[2], K = (int)J[3], ld = (int)J[4], tr = (int)(J[5] & 1);
-  const int es = (int)(J[5] >> 2) > 0 ? (int)(J[5] >> 2) : 1;
+  const int esf = (int)((J[5] >> 2) & 0xFFFF), es = esf > 0 ? esf : 1;
+  if (J[5] & (1ll << 20)) {
+    // layer_v3.hip: fragments of v_mfma_f32_16x16x32_bf16 (16 rows x 32 k; lane = row % 16 + 16 g holds 8 k-slots), k-step major.
+    // Natural k order: slot 8 g + j = column 32 ks + 8 g + j.  Chained (bit 21): the B operand is the previous product's accumulator
+    // set, slot 8 g + j = column 32 ks + 16 (j / 4) + 4 g + j % 4.
+    const bool chained = (J[5] & (1ll << 21)) != 0;
+    const int MB16 = M / 16, total3 = (K / 32) * MB16 * 64;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total3; i += gridDim.x * blockDim.x) {
+      const int lane = i & 63, mb = (i >> 6) % MB16, ks = (i >> 6) / MB16;
+      const int r = mb * 16 + (lane & 15), g = lane >> 4;
+      float f[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c = chained ? ks * 32 + 16 * (j >> 2) + 4 * g + (j & 3) : ks * 32 + 8 * g + j;
+        f[j] = tr ? src[(long long)c * ld + (long long)r * es] : src[(long long)r * ld + (long long)c * es];
+      }
+      dst[i] = tg_pack8(f);
+    }
+    return;
+  }
   const int MB = M / 32, total = (K / 16) * MB * 64;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
     const int lane = i & 63, mb = (i >> 6) % MB, ks = (i >> 6) / MB;

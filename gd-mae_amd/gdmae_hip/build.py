@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.abspath(os.path.join(HERE, "..", "csrc"))
 LIB = os.path.join(CSRC, "libgdmae_hip.so")
 SOURCES = ["capi.hip", "voxelize.hip", "mask.hip", "partition.hip", "segment.hip", "attention.hip", "attention_mfma.hip", "attention_t32.hip", "attention_t16.hip", "attention_coop.hip", "layernorm.hip", "decoder.hip", "chamfer.hip",
-           "optim.hip", "input_pipeline.hip", "gemm.hip", "gemm_f32.hip", "encoder_layer.hip", "conv_block.hip", "vfe_fused.hip", "vfe_layer2.hip", "conv_tiles.hip", "conv_dense.hip", "tok_gemm.hip", "layer_fused.hip", "rows_gemm.hip", "dw_grouped.hip", "center_head.hip", "iou3d_nms.hip", "plan.hip", "spconv.hip"]
+           "optim.hip", "input_pipeline.hip", "gemm.hip", "gemm_f32.hip", "encoder_layer.hip", "conv_block.hip", "vfe_fused.hip", "vfe_layer2.hip", "conv_tiles.hip", "conv_dense.hip", "tok_gemm.hip", "layer_fused.hip", "layer_v3.hip", "rows_gemm.hip", "dw_grouped.hip", "center_head.hip", "iou3d_nms.hip", "plan.hip", "spconv.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-Wno-unused-result"]
 

@@ -140,6 +140,7 @@ SIGNATURES = {
     "gdmae_dw_gemm": (_I, [_P, _P, _L, _I, _I, _P, _P, _P, _P]),
     "gdmae_layer_packed_bytes": (_Z, [_I, _I]),
     "gdmae_layer_pack_jobs": (_I, [_P, _P, _P, _P, _I, _I, _P, _P]),
+    "gdmae_layer_pack_job_count": (_I, [_I, _I]),
     "gdmae_tok_gemm_pack": (_I, [_P, _I, _P]),
     "gdmae_tok_gemm": (_I, [_P, _P, _P, _L, _L, _I, _I, _I, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P]),
     "gdmae_tok_gemm_qkv": (_I, [_P, _P, _P, _P, _P, _L, _I, _P, _P, _P]),

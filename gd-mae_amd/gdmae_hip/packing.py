@@ -39,7 +39,7 @@ def _current(ent, ts):
 
 def _jobs_for(Win, Wo, W1, W2, packed):
     d, ff = Wo.shape[0], W1.shape[0]
-    jobs = (C.c_longlong * 60)()
+    jobs = (C.c_longlong * (6 * L.load().gdmae_layer_pack_job_count(d, ff)))()
     L.call("gdmae_layer_pack_jobs", L.ptr(Win), L.ptr(Wo), L.ptr(W1), L.ptr(W2), d, ff, L.ptr(packed), jobs)
     return list(jobs)
 
@@ -55,7 +55,7 @@ def pack_now(Win, Wo, W1, W2):
     d, ff = Wo.shape[0], W1.shape[0]
     packed = torch.empty(L.load().gdmae_layer_packed_bytes(d, ff), dtype=torch.uint8, device=Win.device)
     jobs = torch.tensor(_jobs_for(Win.detach(), Wo.detach(), W1.detach(), W2.detach(), packed), dtype=torch.int64).to(Win.device)
-    L.call("gdmae_tok_gemm_pack", L.ptr(jobs), 10, L.stream())
+    L.call("gdmae_tok_gemm_pack", L.ptr(jobs), jobs.numel() // 6, L.stream())
     packed._gd_jobs = jobs           # keep the table alive until the launch has run
     return packed
 

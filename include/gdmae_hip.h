@@ -559,11 +559,15 @@ typedef struct gdmae_layer_args {
 } gdmae_layer_args;
 /* Packed weight image of one layer (bf16 mode): forward operands [Win(q,k rows) | Win(v rows) | Wo | W1 | W2] followed by
  * the transposed operands of the input-gradient products [W2^T | W1^T | Wo^T | Win(q,k)^T | Win(v)^T].
- * gdmae_layer_pack_jobs fills a HOST table of 10 x 6 int64 {src, dst, M, K, ld, transpose} for gdmae_tok_gemm_pack
+ * gdmae_layer_pack_jobs fills a HOST table of gdmae_layer_pack_job_count(d, ff) x 6 int64 {src, dst, M, K, ld, flags} for gdmae_tok_gemm_pack
  * (copy it to the device; one launch packs any number of layers). */
 size_t gdmae_layer_packed_bytes(int d, int ff);
 int gdmae_layer_pack_jobs(const float* Win, const float* Wo, const float* W1, const float* W2, int d, int ff, void* packed,
-                          long long* jobs_host /* 60 */);
+                          long long* jobs_host /* 6 x gdmae_layer_pack_job_count(d, ff) */);
+/* Jobs gdmae_layer_pack_jobs writes: the ten images above plus, for d in {128, 256} and ff = 2 d, the weight STREAM of the
+ * in-register forward launch (csrc/layer_v3.hip: Wo, then per 128-channel hidden chunk W1[chunk rows] and W2[:, chunk columns] as
+ * 16 x 32 matrix-core fragments in the order the launch consumes them; EncoderLayer's linears, sst_basic_block.py:57-84). */
+int gdmae_layer_pack_job_count(int d, int ff);
 int gdmae_tok_gemm_pack(const long long* jobs_dev, int n_jobs, void* stream);
 /* Y = epilogue(X Wp^T + bias): X (n_pad, K) bf16 rows (n_pad % 64 == 0), Wp = packed (N, K) weights, bias (N) bf16 or
  * NULL; (K, N) in {128, 256} x {128, 256}, (256, 512), (512, 256).  epilogue 0: out0 = . (bf16); 1: out0 = h = . and

@@ -43,7 +43,7 @@ print("DIGEST", float(ret["loss"]).hex(), hashlib.sha256(g.tobytes()).hexdigest(
 
 def _digest(case, env_extra, save=None):
     env = dict(os.environ)
-    for k in ("GDMAE_LAYER_TAIL_RIDES", "GDMAE_DW_REDUCE_RIDES", "GDMAE_QKV_RIDES", "GDMAE_DW_PAIR"):
+    for k in ("GDMAE_LAYER_TAIL_RIDES", "GDMAE_DW_REDUCE_RIDES", "GDMAE_QKV_RIDES", "GDMAE_DW_PAIR", "GDMAE_LAYER_V3"):
         env.pop(k, None)
     env.update(env_extra)
     out = subprocess.run([sys.executable, "-c", STEP, REPO, case] + ([save] if save else []), env=env, capture_output=True, text=True, timeout=600)
@@ -125,3 +125,18 @@ def test_plan_issued_under_the_decoder_convolution():
     pf3.finish()
     assert bb._pre_conv_hook is None
     assert torch.equal(vox2.pillar_cell, vox.pillar_cell) and torch.equal(plan2.mask, plan.mask)
+
+
+@pytest.mark.gpu
+def test_in_register_layer_forward_matches_the_row_tile_kernels(tmp_path):
+    """GDMAE_LAYER_V3=1 (csrc/layer_v3.hip, opt-in experiment: one wavefront carries 16 token rows through the whole layer in registers,
+    16 x 16 x 32 matrix-core products chained through their accumulators, weights as one LDS-DMA stream): same tensors and rounding points
+    as k_layer_fwd, another summation order inside the products - the step's loss and flat gradient agree to bf16 round-off."""
+    import numpy as np
+    a, b = str(tmp_path / "base.npy"), str(tmp_path / "v3.npy")
+    da, db = _digest("waymo_b1", {}, a), _digest("waymo_b1", {"GDMAE_LAYER_V3": "1"}, b)
+    la, lb = float.fromhex(da.split()[1]), float.fromhex(db.split()[1])
+    assert abs(la - lb) <= 1e-3 * abs(la), (la, lb)
+    ga, gb = np.load(a).astype(np.float64), np.load(b).astype(np.float64)
+    cos = float(ga @ gb / (np.linalg.norm(ga) * np.linalg.norm(gb)))
+    assert cos > 0.995 and abs(np.linalg.norm(gb) / np.linalg.norm(ga) - 1) < 0.02, (cos, np.linalg.norm(ga), np.linalg.norm(gb))

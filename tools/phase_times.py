@@ -143,3 +143,11 @@ o = sum(c.elapsed_time(d) for _, _, c, d in marks) / N
 gap = sum(marks[k][3].elapsed_time(marks[k + 1][0]) for k in range(N - 1)) / (N - 1)
 print("host ms/step: " + ", ".join(f"{k} {1e3 * v / HOST['n']:.2f}" for k, v in HOST.items() if k != "n") + f" | total {1e3 * sum(v for k, v in HOST.items() if k not in ('n', 'issue', 'wait')) / HOST['n']:.2f} (issue / wait are parts of finish)")
 print(f"wall/step {wall:.3f} ms | forward span {f:.3f} backward span {b:.3f} optimizer span {o:.3f} step-to-step gap {gap:.3f} | sum {f + b + o + gap:.3f}")
+if os.environ.get("V3_TRACE_DUMP"):       # variant library built with -DV3_TRACE=<workgroup> (csrc/layer_v3.hip): stamps of the last launch
+    import ctypes as _C
+    from gdmae_hip import lib as _L
+    _buf = (_C.c_ulonglong * 256)()
+    assert _C.CDLL(_L.LIB_PATH).gdmae_debug_v3_trace(_buf) == 0
+    for w in range(4):
+        t = [_buf[w * 64 + i] for i in range(64)]
+        print("v3 wave", w, " ".join("%d:%.2f" % (i, (t[i] - t[0]) / 100.0) for i in range(64) if t[i]))
