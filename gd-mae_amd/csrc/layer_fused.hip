@@ -34,6 +34,16 @@
 #define TL_HALVES 1
 #endif
 
+#ifdef TL_TRACE      // experiment build (tools/build_variant.sh ... -DTL_TRACE=<workgroup>): per-phase time stamps of one workgroup of k_layer_fwd, 100 MHz ticks
+__device__ unsigned long long tl_trace_buf[8 * 32];
+extern "C" int gdmae_debug_tl_trace(unsigned long long* host_out) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(tl_trace_buf), sizeof(tl_trace_buf)) == hipSuccess ? 0 : 1;
+}
+#define TL_MARK(i) do { if (blockIdx.x == TL_TRACE && (threadIdx.x & 63) == 0) tl_trace_buf[(threadIdx.x >> 6) * 32 + (i)] = wall_clock64(); } while (0)
+#else
+#define TL_MARK(i) do { } while (0)
+#endif
+
 namespace {
 
 template <int D>
@@ -167,6 +177,7 @@ __global__ __launch_bounds__(TL_THREADS * TL_HALVES, TL_MINW) void k_layer_fwd(L
   const int* __restrict__ tokp = has_pos ? A.tok_pos : (const int*)A.x;
   const float* __restrict__ ptab = has_pos ? A.pos_table : A.g1;
   const unsigned short* __restrict__ res0p = has_res ? A.res0 : A.x;
+  TL_MARK(0);
   TlProd<D, D, ROWS> pa;
   pa.prefetch(A.Wo, nullptr, wv, lane);
   uint2 res_pf[LPASS];
@@ -183,6 +194,7 @@ __global__ __launch_bounds__(TL_THREADS * TL_HALVES, TL_MINW) void k_layer_fwd(L
   // L2 round trip in front of its arithmetic)
   const float4 g4_1 = *(const float4*)(A.g1 + lc0), b4_1 = *(const float4*)(A.be1 + lc0);
   __syncthreads();
+  TL_MARK(1);
   // ---- a = o Wo^T + bo
   {
     f32x16 acc[TlShape<D, D, ROWS>::MPW][TlShape<D, D, ROWS>::NPW];
@@ -190,12 +202,14 @@ __global__ __launch_bounds__(TL_THREADS * TL_HALVES, TL_MINW) void k_layer_fwd(L
     TlBias<D, D, ROWS> bia;
     bia.load(A.bo, wv, lane);                        // lands behind the product
     pa.run(xl, XP, wv, lane, acc);
+    TL_MARK(2);
     __syncthreads();                                 // every wavefront is done with the o tile
     tl_stage<D, D, ROWS>(acc, bia, xl, XP, wv, lane);
   }
   TlProd<D, FF, ROWS> pb;
   pb.prefetch(A.W1, nullptr, wv, lane);
   __syncthreads();
+  TL_MARK(3);
   // ---- x1 = LN1(x + a): a leaves for HBM, x1 replaces it in LDS (operand tile of linear1) and is the residual of LN2
   uint2 x1_keep[LPASS];
   {
@@ -225,16 +239,19 @@ __global__ __launch_bounds__(TL_THREADS * TL_HALVES, TL_MINW) void k_layer_fwd(L
     }
   }
   __syncthreads();
+  TL_MARK(4);
   // ---- h = x1 W1^T + b1
   {
     f32x16 acc[TlShape<D, FF, ROWS>::MPW][TlShape<D, FF, ROWS>::NPW];
     tl_zero(acc);
     pb.run(xl, XP, wv, lane, acc);
+    TL_MARK(5);
     tl_stage<D, FF, ROWS>(acc, A.b1, hl, HP, wv, lane);     // (two channel blocks per wavefront: no registers for an early bias)
   }
   TlProd<FF, D, ROWS> pc;
   pc.prefetch(A.W2, nullptr, wv, lane);
   __syncthreads();
+  TL_MARK(6);
   // ---- h leaves for HBM (the backward differentiates the GELU at it), gelu(h) replaces it in LDS
   {
     constexpr int CPR = FF / 8, RPP = TL_THREADS / CPR;
@@ -252,6 +269,7 @@ __global__ __launch_bounds__(TL_THREADS * TL_HALVES, TL_MINW) void k_layer_fwd(L
     }
   }
   __syncthreads();
+  TL_MARK(7);
   // ---- f = gelu(h) W2^T + b2  (staged over the x1 tile: nobody reads it any more)
   float4 g4_2, b4_2;                                   // LayerNorm-2 weights, requested in front of the product
   {
@@ -262,12 +280,14 @@ __global__ __launch_bounds__(TL_THREADS * TL_HALVES, TL_MINW) void k_layer_fwd(L
     g4_2 = *(const float4*)(A.g2 + lc0);
     b4_2 = *(const float4*)(A.be2 + lc0);
     pc.run(hl, HP, wv, lane, acc);
+    TL_MARK(8);
     tl_stage<FF, D, ROWS>(acc, bic, xl, XP, wv, lane);
   }
   // QKV: y + pos replaces f in its slot of the x tile (operand of the q | k product), y goes to a tile behind the hidden tile's first
   // ROWS * HP bytes (operand of the v product, then its staging tile); the q | k rows are staged over the front of the buffer
   unsigned char* const yl = lds + ROWS * HP;
   __syncthreads();
+  TL_MARK(9);
   // ---- y = LN2(x1 + f)
   {
     const float4 g4 = g4_2, b4 = b4_2;
@@ -317,6 +337,11 @@ __global__ __launch_bounds__(TL_THREADS * TL_HALVES, TL_MINW) void k_layer_fwd(L
       if (lc0 == 0) *(float2*)(A.st2 + row * 2) = st;
     }
   }
+  TL_MARK(10);
+#ifdef TL_TRACE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  TL_MARK(11);
+#endif
   if constexpr (QKV) {
     // ---- the next layer's in-projection: same fragments, k order and rounding points as its own launch (k_tok_gemm_multi)
     TlProd<D, D, ROWS> pv;

@@ -151,3 +151,11 @@ if os.environ.get("V3_TRACE_DUMP"):       # variant library built with -DV3_TRAC
     for w in range(4):
         t = [_buf[w * 64 + i] for i in range(64)]
         print("v3 wave", w, " ".join("%d:%.2f" % (i, (t[i] - t[0]) / 100.0) for i in range(64) if t[i]))
+if os.environ.get("TL_TRACE_DUMP"):       # variant library built with -DTL_TRACE=<workgroup> (csrc/layer_fused.hip k_layer_fwd): stamps of the last launch
+    import ctypes as _C
+    from gdmae_hip import lib as _L
+    _buf = (_C.c_ulonglong * 256)()
+    assert _C.CDLL(_L.LIB_PATH).gdmae_debug_tl_trace(_buf) == 0
+    for w in range(8):
+        t = [_buf[w * 32 + i] for i in range(32)]
+        print("tl wave", w, " ".join("%d:%.2f" % (i, (t[i] - t[0]) / 100.0) for i in range(32) if t[i]))
