@@ -26,7 +26,7 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #ifdef V3_TRACE      // experiment build (tools/build_variant.sh ... -DV3_TRACE): per-phase time stamps of one workgroup, 100 MHz ticks
-__device__ unsigned long long v3_trace_buf[4 * 64];
+__device__ unsigned long long v3_trace_buf[8 * 64];
 extern "C" int gdmae_debug_v3_trace(unsigned long long* host_out) {
   return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(v3_trace_buf), sizeof(v3_trace_buf)) == hipSuccess ? 0 : 1;
 }
@@ -41,8 +41,15 @@ extern "C" int gdmae_debug_v3_trace(unsigned long long* host_out) {
 
 namespace {
 
-constexpr int V3_WAVES = 4, V3_THREADS = 64 * V3_WAVES, V3_TROWS = 16, V3_ROWS = V3_WAVES * V3_TROWS;
-constexpr int V3_SLOT_FR = 16, V3_SLOT_B = V3_SLOT_FR * 1024, V3_RING = 4;
+#ifndef V3_NWAVES
+#define V3_NWAVES 4         // wavefronts (16 rows each) per workgroup: 4 = two workgroups per CU, 8 = one (experiment switch)
+#endif
+#ifndef V3_NRING
+#define V3_NRING 4          // LDS ring slots of 16 KB
+#endif
+constexpr int V3_WAVES = V3_NWAVES, V3_THREADS = 64 * V3_WAVES, V3_TROWS = 16, V3_ROWS = V3_WAVES * V3_TROWS;
+constexpr int V3_DPW = 16 / V3_WAVES;       // DMA instructions (1 KB fragments) per wavefront and slot
+constexpr int V3_SLOT_FR = 16, V3_SLOT_B = V3_SLOT_FR * 1024, V3_RING = V3_NRING;
 
 template <int D>
 struct V3S {
@@ -75,8 +82,8 @@ struct V3Stream {
     const unsigned char* g = src + (size_t)qc * V3_SLOT_B;
     const unsigned l = __builtin_amdgcn_readfirstlane(ring + sl * V3_SLOT_B);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(l + i * 4096), "v"(g + i * 4096) : "memory");
+    for (int i = 0; i < V3_DPW; ++i)
+      asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(l + i * 1024 * V3_WAVES), "v"(g + i * 1024 * V3_WAVES) : "memory");
   }
   __device__ __forceinline__ void start(const uint4* stream, unsigned char* lds, int wv, int lane, int slots) {
     src = (const unsigned char*)stream + 1024 * wv + 16 * lane;
@@ -96,7 +103,7 @@ __device__ __forceinline__ f32x4 v3_mma(const uint4& a, const uint4& b, f32x4 c)
 // block f % MBN).  J: index of the step within its product (the first V3_RING - 1 steps behind a row pass do not wait, see above).
 template <int J, int F0, int MBN, int NKS, int NAC>
 __device__ __forceinline__ void v3_step(V3Stream& S, const unsigned char* ring, const uint4 (&bop)[NKS], f32x4 (&acc)[NAC], int lane) {
-  if constexpr (J >= V3_RING - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((V3_RING - 2) * 4) : "memory");
+  if constexpr (J >= V3_RING - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((V3_RING - 2) * V3_DPW) : "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   S.dma(S.q + V3_RING - 1, S.slot == 0 ? V3_RING - 1 : S.slot - 1);
@@ -200,7 +207,7 @@ struct V3Fwd {
 };
 
 template <int D>
-__global__ __launch_bounds__(V3_THREADS, 2) void k_layer_fwd_v3(V3Fwd A) {
+__global__ __launch_bounds__(V3_THREADS, 8 / V3_WAVES) void k_layer_fwd_v3(V3Fwd A) {
   using C = V3S<D>;
   constexpr int FF = C::FF, NB = C::NB, KS = C::KS, HB = C::HB, HKS = C::HKS;
   extern __shared__ __align__(16) unsigned char v3_ring[];

@@ -146,7 +146,7 @@ print(f"wall/step {wall:.3f} ms | forward span {f:.3f} backward span {b:.3f} opt
 if os.environ.get("V3_TRACE_DUMP"):       # variant library built with -DV3_TRACE=<workgroup> (csrc/layer_v3.hip): stamps of the last launch
     import ctypes as _C
     from gdmae_hip import lib as _L
-    _buf = (_C.c_ulonglong * 256)()
+    _buf = (_C.c_ulonglong * 512)()
     assert _C.CDLL(_L.LIB_PATH).gdmae_debug_v3_trace(_buf) == 0
     for w in range(4):
         t = [_buf[w * 64 + i] for i in range(64)]
