@@ -695,6 +695,9 @@ def main():
             # ---- config C's per-GPU batch on this one GPU (the N = 1 point of the driver's scaling curve runs 8 frames per GPU;
             #      this is the same step at the 4 frames per GPU that --gpus 2 / 4 / 8 use) and the other single-GPU configs
             extra = [("config_C_batch_4_per_gpu", "B", 4), ("config_E", "E", 8)]
+            # ... and the headline's step at twice the reference's per-GPU batch: how much of the step is per-launch cost that more rows per
+            # launch amortise (the fused layer launches' weight stream per 32-row tile, ~7 us of fixed cost per launch)
+            extra.append(("config_B_batch_16_per_gpu", "B", 16))
             # config D (fine-tune step) is part of the default run since round 5: its dense convolutions are the library's own
             # (csrc/conv_dense.hip), there is no MIOpen search at first use any more
             extra.append(("config_D_finetune", "D", 8))
@@ -706,6 +709,8 @@ def main():
                     also[key] = timed_leg(w2, 4, max(8, args.steps // 2))
                     also[key]["leg_wall_s"] = round(time.perf_counter() - t_build, 1)
                     also[key]["workload"] = WORKLOADS["C" if key.startswith("config_C") else cfg_name]
+                    if key == "config_B_batch_16_per_gpu":
+                        also[key]["note"] = "NOT the reference's batch (BATCH_SIZE_PER_GPU = 8 is the headline): listed for the batch dependence only"
                     del w2
                     torch.cuda.empty_cache()
                 except Exception as e:     # noqa: BLE001  (an extra leg must not take the headline line down)
